@@ -1,0 +1,312 @@
+"""CPU restatement of ICP-Flow's cluster-pair registration hot path.
+
+TEST INFRASTRUCTURE ONLY -- the checker, never the product.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Every function names the reference lines it follows (paths are relative to
+/root/reference).  The arithmetic is torch-CPU float32 in the reference's
+operation order; the two device primitives (vote, K=1 brute-force NN) live in
+oracle_core.c.  The restatement is pinned by tests/golden/*.npz, which were
+produced by importing the reference's OWN vendored Python on CPU tensors
+(tools/gen_golden.py) -- see tests/test_oracle_golden.py.
+
+Third-party arithmetic that is not under /root/reference and is therefore
+restated from its published behaviour ("parity unpinned" at that boundary):
+pytorch3d 0.7.4 knn_points / wmean / matrix_to_euler_angles.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import core
+
+PAD_VALUE = 1e8          # utils_helper.py:192
+ICP_MAX_ITER = 100       # utils_icp.py:54
+ICP_REL_RMSE = 1e-6      # utils_icp.py:55
+TOPK = 5                 # utils_hist.py:21
+NMS_KERNEL = 11          # utils_hist.py:21
+
+
+def default_args(**kw):
+    """Namespace with the fields the hot path reads (demo.sh:9-13 values)."""
+    a = dict(thres_dist=0.1, translation_frame=2.0, chunk_size=50, max_points=1024,
+             thres_iou=0.2, thres_rot=0.1, thres_error=0.2, thres_box=0.1,
+             min_cluster_size=20)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+# --------------------------------------------------------------------------
+# input format, utils_helper.py:185-201
+# --------------------------------------------------------------------------
+def pad_segment(seg, max_points):
+    """[n,3] -> [max_points,4]; pads are (1e8,1e8,1e8,0); n>max: randperm subsample."""
+    n = len(seg)
+    flag = seg.new_ones((max_points, 1))
+    if n > max_points:
+        keep = torch.randperm(n)[0:max_points]              # utils_helper.py:198-201
+        seg = seg[keep, :]
+    elif n < max_points:
+        flag[n:] = 0.0
+        seg = torch.cat([seg, seg.new_full((max_points - n, 3), PAD_VALUE)], dim=0)
+    return torch.cat([seg, flag], dim=1)
+
+
+# --------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------
+def hist(X, Y, min_x, min_y, min_z, max_x, max_y, max_z, len_x, len_y, len_z, mini_batch=8):
+    """hist_cuda/hist.py:39-51 -> hist_cuda_core.cuh:40-60 (oracle_core.c)."""
+    return core.hist_vote(X, Y, (min_x, min_y, min_z), (max_x, max_y, max_z),
+                          (len_x, len_y, len_z))
+
+
+def knn_points(p1, p2, lengths1=None, lengths2=None, return_nn=False):
+    """pytorch3d.ops.knn_points(K=1): (dists [B,N1], idx [B,N1], nn [B,N1,3]|None)."""
+    return core.knn1(p1, p2, lengths1, lengths2, return_nn)
+
+
+def nearest_neighbor_batch(src, dst):
+    """utils_helper.py:20-30: un-lengthed K=1 NN, Euclidean (sqrt) distance."""
+    assert src.dim() == 3 and dst.dim() == 3 and len(src) == len(dst)
+    d2, idx, _ = knn_points(src[:, :, 0:3], dst[:, :, 0:3])
+    return idx, d2.sqrt()
+
+
+def transform_points_batch(xyz, pose):
+    """utils_helper.py:76-87: [x y z 1] @ pose^T, flag column carried through."""
+    b, n, _ = xyz.shape
+    hom = torch.cat([xyz[:, :, 0:3], xyz.new_ones((b, n, 1))], dim=-1)
+    moved = torch.bmm(hom, pose.transpose(1, 2))
+    return torch.cat([moved[:, :, 0:3], xyz[:, :, 3:4]], dim=-1)
+
+
+def wmean(x, weight, eps=1e-9):
+    """pytorch3d.ops.utils.wmean(dim=-2, keepdim=True); weight may be bool."""
+    w = weight[..., None]
+    return (x * w).sum(dim=-2, keepdim=True) / w.sum(dim=-2, keepdim=True).clamp(eps)
+
+
+def matrix_to_euler_zyx(M):
+    """pytorch3d.transforms.matrix_to_euler_angles(M, 'ZYX') in radians."""
+    return torch.stack([torch.atan2(M[..., 1, 0], M[..., 0, 0]),
+                        torch.asin(-M[..., 2, 0]),
+                        torch.atan2(M[..., 2, 1], M[..., 2, 2])], dim=-1)
+
+
+# --------------------------------------------------------------------------
+# translation histogram -> initial pose, utils_hist.py
+# --------------------------------------------------------------------------
+def bin_edges(args):
+    """utils_hist.py:61-65 (float32 torch.arange)."""
+    tf, th, eps = args.translation_frame, args.thres_dist, 1e-8
+    ex = torch.arange(-tf, tf + th - eps, th)
+    ey = torch.arange(-tf, tf + th - eps, th)
+    ez = torch.arange(-th, th + th - eps, th)
+    return ex, ey, ez
+
+
+def nms_mask(x, kernel_size=NMS_KERNEL):
+    """utils_hist.py:22-26: votes surviving the 3-D max-pool test, else 0."""
+    xp = torch.nn.functional.max_pool3d(x[:, None], kernel_size=kernel_size, stride=1,
+                                        padding=(kernel_size - 1) // 2)
+    return (x[:, None] * (x[:, None] == xp).float())[:, 0]
+
+
+def topk_nms(x, k=TOPK, kernel_size=NMS_KERNEL):
+    """utils_hist.py:21-29.  torch.topk's order among equal votes is
+    implementation-defined; the build's deterministic rule is
+    (vote descending, flat index ascending) -- a stable sort gives exactly that."""
+    b = x.shape[0]
+    flat = nms_mask(x, kernel_size).reshape(b, -1)
+    order = torch.argsort(flat, dim=1, descending=True, stable=True)[:, :k]
+    return torch.gather(flat, 1, order), order.long()
+
+
+def decode_peaks(args, idx, shape, edges):
+    """utils_hist.py:78: flat index -> left bin edge (+ thres_dist//2 == 0.0)."""
+    _, h, w, d = shape
+    ex, ey, ez = edges
+    return torch.stack([ex[idx // d // w % h], ey[idx // d % w], ez[idx % d]], dim=-1) \
+        + args.thres_dist // 2
+
+
+def estimate_init_pose_batch(args, src, dst, return_aux=False):
+    """utils_hist.py:46-124."""
+    p1, p2 = src[:, :, 0:3], dst[:, :, 0:3]
+    m1, m2 = src[:, :, -1] > 0.0, dst[:, :, -1] > 0.0
+    ex, ey, ez = bin_edges(args)
+    votes = hist(dst, src, ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(),
+                 len(ex), len(ey), len(ez))                                  # :69-72
+    b = votes.shape[0]
+    peak_votes, peak_idx = topk_nms(votes)                                    # :77
+    t_peaks = decode_peaks(args, peak_idx, votes.shape, (ex, ey, ez))         # :78
+    n = p1.shape[1]
+    cand = torch.cat([t_peaks, t_peaks.new_zeros(b, 1, 3)], dim=1)            # :83 (zero LAST)
+    k = cand.shape[1]
+    moved = (p1[:, None] + cand[:, :, None, :]).reshape(b * k, n, 3)          # :86
+    fixed = p2[:, None].expand(-1, k, -1, -1).reshape(b * k, n, 3)            # :87
+    _, e_fwd = nearest_neighbor_batch(moved, fixed)                           # :89
+    _, e_bwd = nearest_neighbor_batch(fixed, moved)                           # :90
+    e_fwd = (e_fwd.view(b, k, n) * m1[:, None]).sum(-1) / m1[:, None].sum(-1)   # :101
+    e_bwd = (e_bwd.view(b, k, n) * m2[:, None]).sum(-1) / m2[:, None].sum(-1)   # :102
+    score = torch.minimum(e_fwd, e_bwd)                                       # :103
+    _, pick = score.min(dim=-1)                                               # :104
+    t_best = cand[torch.arange(b), pick]                                      # :106
+    T = torch.eye(4)[None].repeat(b, 1, 1)                                    # :121
+    T[:, 0:3, 3] = t_best
+    if return_aux:
+        return T, dict(votes=votes, peak_votes=peak_votes, peak_idx=peak_idx,
+                       candidates=cand, score=score, pick=pick)
+    return T
+
+
+def estimate_init_pose(args, src, dst):
+    """utils_hist.py:33-44: chunk_size pairs at a time (results chunk-independent)."""
+    assert len(src) == len(dst)
+    out = [estimate_init_pose_batch(args, src[s:s + args.chunk_size], dst[s:s + args.chunk_size])
+           for s in range(0, len(src), args.chunk_size)]
+    return torch.vstack(out)
+
+
+# --------------------------------------------------------------------------
+# ICP, utils_icp_pytorch3d.py
+# --------------------------------------------------------------------------
+def corresponding_points_alignment(X, Y, weights, eps=1e-9):
+    """utils_icp_pytorch3d.py:303-382 (estimate_scale=False, allow_reflection=False).
+    X, Y [B,N,3] already mask-multiplied, weights bool [B,N].  y = x R + T."""
+    b = X.shape[0]
+    mu_x = wmean(X, weights, eps)                                             # :314
+    mu_y = wmean(Y, weights, eps)                                             # :315
+    w = weights[:, :, None]
+    Xc = (X - mu_x) * w                                                       # :318,324
+    Yc = (Y - mu_y) * w                                                       # :319,325
+    total = torch.clamp(weights.sum(1), eps)                                  # :326
+    H = torch.bmm(Xc.transpose(2, 1), Yc) / total[:, None, None]              # :335-336
+    U, S, V = torch.svd(H)                                                    # :339
+    E = torch.eye(3, dtype=H.dtype)[None].repeat(b, 1, 1)
+    E[:, -1, -1] = torch.det(torch.bmm(U, V.transpose(2, 1)))                 # :358-359
+    R = torch.bmm(torch.bmm(U, E), V.transpose(2, 1))                         # :362
+    T = mu_y[:, 0, :] - torch.bmm(mu_x, R)[:, 0, :]                           # :376
+    return R, T
+
+
+def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
+                            relative_rmse_thr=ICP_REL_RMSE, trace=False):
+    """utils_icp_pytorch3d.py:100-225.  Returns a namespace with
+    converged, rmse, Xt, R, T, iterations (number of loop bodies executed) and,
+    with trace=True, the per-iteration (R, T, rmse) history."""
+    X0 = X[:, :, 0:3].clone()                                                 # :100,115
+    Yt = Y[:, :, 0:3]
+    b = X0.shape[0]
+    m0 = X[:, :, -1] > 0.0                                                    # :109,116
+    n_x = m0.sum(-1)                                                          # :111
+    n_y = (Y[:, :, -1] > 0.0).sum(-1)                                         # :112
+    Xt = X0
+    R = torch.eye(3)[None].repeat(b, 1, 1)                                    # :140
+    T = X0.new_zeros((b, 3))
+    prev = None
+    rmse = None
+    converged = False
+    it = -1
+    history = []
+    thr2 = thres ** 2                       # python double; torch compares in fp32 (:160)
+    for it in range(max_iterations):                                          # :153
+        d2, _, nn = knn_points(Xt, Yt, n_x, n_y, return_nn=True)              # :154-157
+        w = torch.logical_and(m0, d2 <= thr2)                                 # :160-161
+        R, T = corresponding_points_alignment(X0 * w[:, :, None], nn * w[:, :, None], w)
+        Xt = torch.bmm(X0, R) + T[:, None, :]                                 # :177,395
+        sq = ((Xt - nn) ** 2).sum(2)                                          # :191
+        rmse = wmean(sq[:, :, None], w).sqrt()[:, 0, 0]                       # :192
+        rel = rmse.new_ones(b) if prev is None else (prev - rmse) / prev      # :195-198
+        if trace:
+            history.append((R.clone(), T.clone(), rmse.clone(), w.sum(-1).clone()))
+        if bool((rel <= relative_rmse_thr).all()):                            # :209
+            converged = True
+            break
+        prev = rmse
+    return SimpleNamespace(converged=converged, rmse=rmse, Xt=Xt, R=R, T=T,
+                           iterations=it + 1, history=history)
+
+
+def pytorch3d_icp(args, src, dst, max_iterations=ICP_MAX_ITER):
+    """utils_icp.py:50-73: column-vector 4x4 from the row-vector (R, T)."""
+    sol = iterative_closest_point(src, dst, thres=args.thres_dist,
+                                  max_iterations=max_iterations,
+                                  relative_rmse_thr=ICP_REL_RMSE)
+    b = len(sol.T)
+    M = torch.zeros(b, 4, 4)
+    M[:, 0:3, 0:3] = sol.R.transpose(1, 2)                                    # :63-64
+    M[:, 0:3, 3] = sol.T
+    M[:, 3, 3] = 1.0                                                          # :65
+    return M, sol
+
+
+def apply_icp(args, src, dst, init_poses, max_iterations=ICP_MAX_ITER, return_aux=False):
+    """utils_icp.py:20-48: ICP from the init pose, roll back where it did not help."""
+    moved = transform_points_batch(src, init_poses)                           # :21
+    M, sol = pytorch3d_icp(args, moved, dst, max_iterations)                  # :23
+    M = torch.bmm(M, init_poses)                                              # :24
+    valid = src[:, :, -1] > 0.0                                               # :27
+    _, e0 = nearest_neighbor_batch(moved, dst)                                # :28
+    e0 = (e0 * valid).sum(1) / valid.sum(1)                                   # :29
+    _, e1 = nearest_neighbor_batch(transform_points_batch(src, M), dst)       # :31-32
+    e1 = (e1 * valid).sum(1) / valid.sum(1)                                   # :33
+    worse = e1 >= e0                                                          # :34
+    M[worse] = init_poses[worse]                                              # :35
+    if return_aux:
+        return M, dict(error_init=e0, error_icp=e1, rolled_back=worse,
+                       iterations=sol.iterations, converged=sol.converged)
+    return M
+
+
+# --------------------------------------------------------------------------
+# orchestration + metrics, utils_match.py
+# --------------------------------------------------------------------------
+def hist_icp(args, src, dst, max_iterations=ICP_MAX_ITER, return_aux=False):
+    """utils_match.py:138-157."""
+    n1 = (src[:, :, -1] > 0.0).sum(1)
+    n2 = (dst[:, :, -1] > 0.0).sum(1)
+    swap = n1 > n2                                                            # :142 (strict)
+    a, b = src.clone(), dst.clone()
+    a[swap] = dst[swap]
+    b[swap] = src[swap]
+    init = estimate_init_pose(args, a, b)                                     # :149
+    if return_aux:
+        M, aux = apply_icp(args, a, b, init, max_iterations, return_aux=True)
+    else:
+        M, aux = apply_icp(args, a, b, init, max_iterations), None            # :150
+    if int(swap.sum()) > 0:                                                   # :152
+        M = M.clone()
+        M[swap] = torch.linalg.inv(M[swap])                                   # :154
+    if return_aux:
+        aux.update(init=init, swapped=swap)
+        return M, aux
+    return M
+
+
+def match_eval(args, pcd1, pcd2, transformations):
+    """utils_match.py:159-213 -> errors, inliers, ratios, ious [B,2]; translations, rotations [B,3]."""
+    moved = transform_points_batch(pcd1, transformations)                     # :160
+    m1 = pcd1[:, :, -1] > 0.0
+    m2 = pcd2[:, :, -1] > 0.0
+    _, e1 = nearest_neighbor_batch(moved, pcd2)                               # :165
+    _, e2 = nearest_neighbor_batch(pcd2, moved)                               # :166
+    in1 = torch.logical_and(e1 < args.thres_dist, m1).float()                 # :168 (strict <)
+    in2 = torch.logical_and(e2 < args.thres_dist, m2).float()                 # :169
+    c1, c2 = m1.sum(1), m2.sum(1)
+    ratio1 = in1.sum(1) / c1                                                  # :171
+    ratio2 = in2.sum(1) / c2                                                  # :172
+    iou1 = in1.sum(1) / (c1 + c2 - in2.sum(1))                                # :174
+    iou2 = in2.sum(1) / (c1 + c2 - in1.sum(1))                                # :175
+    err1 = (e1 * m1).sum(1) / c1                                              # :177
+    err2 = (e2 * m2).sum(1) / c2                                              # :178
+    mean_moved = (moved[:, :, 0:3] * m1[:, :, None]).sum(1) / m1.sum(1, keepdim=True)   # :180
+    mean_orig = (pcd1[:, :, 0:3] * m1[:, :, None]).sum(1) / m1.sum(1, keepdim=True)     # :181
+    translations = mean_moved - mean_orig                                     # :183
+    rotations = matrix_to_euler_zyx(transformations[:, 0:3, 0:3]) * 180.0 / np.pi      # :184
+    return (torch.stack([err1, err2], 1), torch.stack([in1.sum(1), in2.sum(1)], 1),
+            torch.stack([ratio1, ratio2], 1), torch.stack([iou1, iou2], 1),
+            translations, rotations)

@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own vendored Python on
+CPU tensors.  Runs ONLY in the build container (needs /root/reference); the GPU
+box never sees the reference -- only the arrays written here travel.
+
+What executes unmodified from /root/reference: utils_match.{hist_icp,match_eval},
+utils_hist.{topk_nms,estimate_init_pose}, utils_icp.{apply_icp,pytorch3d_icp},
+utils_icp_pytorch3d.{iterative_closest_point,corresponding_points_alignment},
+utils_helper.{nearest_neighbor_batch,transform_points_batch,pad_segment}.
+What is a stand-in (tools/standins/, this repo's own code): the un-installable
+third-party modules -- pytorch3d's knn_points/wmean/matrix_to_euler_angles and the
+CUDA-only hist_cuda vote, both backed by oracle/oracle_core.c.
+
+Fixtures hold inputs and expected outputs only (no reference source text).
+
+Usage:  python tools/gen_golden.py [--only g1,g5] [--demo]
+"""
+import argparse
+import os
+import sys
+from types import SimpleNamespace
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, "tools", "standins"))
+
+import matplotlib  # noqa: E402
+
+matplotlib.use("Agg")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import utils_helper  # noqa: E402  (reference)
+import utils_hist  # noqa: E402  (reference)
+import utils_icp  # noqa: E402  (reference)
+import utils_icp_pytorch3d  # noqa: E402  (reference)
+import utils_match  # noqa: E402  (reference)
+from hist_cuda.hist import hist as ref_hist  # noqa: E402  (stand-in vote)
+
+from icp_flow_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def args_ns(**kw):
+    a = dict(thres_dist=0.1, translation_frame=2.0, chunk_size=50, max_points=256,
+             thres_iou=0.2, thres_rot=0.1, thres_error=0.2, thres_box=0.1, min_cluster_size=20)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    meta = dict(torch_version=np.array(torch.__version__), generator=np.array("tools/gen_golden.py"))
+    np.savez_compressed(path, **arrays, **meta)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def sparse(bins):
+    flat = bins.reshape(-1)
+    nz = np.flatnonzero(flat)
+    return nz.astype(np.int64), flat[nz].astype(np.float32)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def ragged_batch(B, N, seed, first=0):
+    S, D, T = synthetic.make_batch(B, N, seed=seed, first=first, ragged=True)
+    return t(S), t(D), T
+
+
+
+def cut_is_tied(a, src, dst, swap_smaller_first=False):
+    """True where the 5th and 6th surviving peak share a POSITIVE vote count: which peaks make
+    the top-5 then depends on torch.topk's implementation-defined tie order, so
+    the chosen initial pose of that pair is not a portable expectation."""
+    if swap_smaller_first:
+        n1 = (src[:, :, 3] > 0).sum(1)
+        n2 = (dst[:, :, 3] > 0).sum(1)
+        sw = n1 > n2
+        s2, d2 = src.clone(), dst.clone()
+        s2[sw] = dst[sw]
+        d2[sw] = src[sw]
+        src, dst = s2, d2
+    tf, th = a.translation_frame, a.thres_dist
+    ex = torch.arange(-tf, tf + th - 1e-8, th)
+    ez = torch.arange(-th, 2 * th - 1e-8, th)
+    h = ref_hist(dst, src, ex.min(), ex.min(), ez.min(), ex.max(), ex.max(), ez.max(),
+                 len(ex), len(ex), len(ez))
+    xp = torch.nn.functional.max_pool3d(h[:, None], kernel_size=11, stride=1, padding=5)
+    surv = (h[:, None] * (h[:, None] == xp).float()).reshape(len(h), -1)
+    top = torch.sort(surv, dim=1, descending=True)[0][:, :6]
+    return ((top[:, 4] == top[:, 5]) & (top[:, 4] > 0)).numpy()
+
+
+# --------------------------------------------------------------------------
+def g1_hist():
+    # (a) the reference's only known-answer script, hist_cuda/test.py:16-50
+    torch.manual_seed(2022)
+    pts = torch.randn(3, 1000, 3)
+    ind = torch.randint(0, 2, size=(3, 1000, 1))
+    p1 = torch.cat([pts, ind], dim=-1)
+    p2 = p1.clone()
+    p2[:, :, 0] += 5.0
+    p2[:, :, 1] += -3.0
+    p2[:, :, 2] += -0.2
+    bx = torch.arange(-10.0, 10.0 + 0.1, 0.1)
+    bz = torch.arange(-0.5, 0.5 + 0.1, 0.1)
+    h = ref_hist(p1, p2, -10.0, -10.0, -0.5, 10.0, 10.0, 0.5, len(bx), len(bx), len(bz)).numpy()
+    nz, val = sparse(h)
+    save("g1_hist_testpy", X=p1.numpy(), Y=p2.numpy(),
+         mins=np.array([-10.0, -10.0, -0.5], np.float32), maxs=np.array([10.0, 10.0, 0.5], np.float32),
+         lens=np.array([len(bx), len(bx), len(bz)], np.int64), bins_shape=np.array(h.shape),
+         bins_nz=nz, bins_val=val,
+         argmax=np.array([int(x.argmax()) for x in h]), peak=np.array([float(x.max()) for x in h]),
+         total=np.array([float(x.sum()) for x in h]))
+
+    # (b) reference-style calls (utils_hist.py:61-72): X=dst, Y=src, min/max from arange edges
+    for tag, tf in (("tf2p0", 2.0), ("tf3p34", 3.34)):
+        a = args_ns(translation_frame=tf)
+        src, dst, _ = ragged_batch(6, 192, seed=11)
+        # pair 5: hand-made differences exactly on bin edges / box borders / outside
+        ex = torch.arange(-tf, tf + a.thres_dist - 1e-8, a.thres_dist)
+        ez = torch.arange(-a.thres_dist, 2 * a.thres_dist - 1e-8, a.thres_dist)
+        src[5] = 1e8
+        src[5, :, 3] = 0
+        dst[5] = 1e8
+        dst[5, :, 3] = 0
+        base = torch.tensor([10.0, -20.0, 0.5])
+        src[5, 0, 0:3] = base
+        src[5, 0, 3] = 1
+        deltas = [
+            (float(ex.min()), 0.0, 0.0), (float(ex.max()), 0.0, 0.0),          # on min (in) / on max (out)
+            (0.0, float(ex.min()), float(ez.min())), (0.0, 0.0, float(ez.max())),
+            (float(ex[3]), float(ex[7]), 0.0), (float(ex[-2]), float(ex[1]), float(ez[1])),
+            (np.nextafter(np.float32(ex.max()), np.float32(0)).item(), 0.05, -0.05),
+            (5.0 * tf, 0.0, 0.0), (0.0, 0.0, 0.25), (0.3, -0.7, 0.02), (0.3, -0.7, 0.02),
+        ]
+        for i, d in enumerate(deltas):
+            dst[5, i, 0:3] = base + torch.tensor(d, dtype=torch.float32)
+            dst[5, i, 3] = 1
+        h = ref_hist(dst, src, ex.min(), ex.min(), ez.min(), ex.max(), ex.max(), ez.max(),
+                     len(ex), len(ex), len(ez)).numpy()
+        nz, val = sparse(h)
+        votes, idx = utils_hist.topk_nms(torch.from_numpy(h))
+        save("g1_hist_ref_" + tag, src=src.numpy(), dst=dst.numpy(),
+             translation_frame=np.array(tf), thres_dist=np.array(a.thres_dist),
+             mins=np.array([float(ex.min()), float(ex.min()), float(ez.min())], np.float32),
+             maxs=np.array([float(ex.max()), float(ex.max()), float(ez.max())], np.float32),
+             lens=np.array([len(ex), len(ex), len(ez)], np.int64),
+             edges_x=ex.numpy(), edges_z=ez.numpy(), bins_shape=np.array(h.shape),
+             bins_nz=nz, bins_val=val,
+             # G2: reference topk_nms on these bins (tie order inside torch.topk is
+             # implementation-defined; tests compare tie-free prefixes only)
+             peak_votes=votes.numpy(), peak_idx=idx.numpy())
+
+
+def g3_nn():
+    src, dst, _ = ragged_batch(4, 160, seed=23)
+    idx, dist = utils_helper.nearest_neighbor_batch(src, dst)
+    idx2, dist2 = utils_helper.nearest_neighbor_batch(dst, src)
+    save("g3_nn", src=src.numpy(), dst=dst.numpy(), idx_fwd=idx.numpy(), dist_fwd=dist.numpy(),
+         idx_bwd=idx2.numpy(), dist_bwd=dist2.numpy())
+
+
+def g4_init_pose():
+    a = args_ns(chunk_size=3)
+    src, dst, Tt = ragged_batch(8, 256, seed=31)
+    T = utils_hist.estimate_init_pose(a, src, dst)
+    save("g4_init_pose", src=src.numpy(), dst=dst.numpy(), T_true=Tt, T_init=T.numpy(),
+         cut_tied=cut_is_tied(a, src, dst),
+         translation_frame=np.array(a.translation_frame), thres_dist=np.array(a.thres_dist))
+
+
+def _icp_case(X, Y, thres=0.1):
+    sol = utils_icp_pytorch3d.iterative_closest_point(X, Y, thres=thres, max_iterations=100,
+                                                      relative_rmse_thr=1e-6)
+    hist_R = np.stack([h.R.numpy() for h in sol.t_history])
+    hist_T = np.stack([h.T.numpy() for h in sol.t_history])
+    return dict(R=sol.RTs.R.numpy(), T=sol.RTs.T.numpy(), rmse=sol.rmse.numpy(),
+                converged=np.array(bool(sol.converged)), iterations=np.array(len(sol.t_history)),
+                hist_R=hist_R, hist_T=hist_T, Xt=sol.Xt.numpy())
+
+
+def g5_icp():
+    out = {}
+    cases = {}
+
+    def prealigned(B, N, seed, ragged, rot_deg, shift):
+        """src moved by the ground-truth motion, then perturbed by a small yaw about
+        its centroid and a sub-threshold shift, so that ICP starts with inliers."""
+        S, D, Tt = synthetic.make_batch(B, N, seed=seed, ragged=ragged)
+        src, dst = t(S), t(D)
+        for i in range(B):
+            v = src[i, :, 3] > 0
+            Ti = torch.from_numpy(Tt[i])
+            p = src[i, v, 0:3] @ Ti[:3, :3].T + Ti[:3, 3]
+            ang = np.deg2rad(rot_deg * (1.0 + 0.15 * i) * (-1) ** i)
+            c, s_ = np.cos(ang), np.sin(ang)
+            Rz = torch.tensor([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], dtype=torch.float32)
+            ctr = p.mean(0)
+            src[i, v, 0:3] = (p - ctr) @ Rz.T + ctr + torch.tensor(shift, dtype=torch.float32)
+        return src, dst
+
+    cases["a"] = prealigned(1, 64, 41, False, 1.0, [0.03, -0.02, 0.01])
+    cases["b"] = prealigned(4, 256, 43, True, 1.5, [0.04, 0.03, -0.02])
+    cases["c"] = prealigned(16, 128, 47, False, 0.8, [0.02, 0.015, -0.01])
+    # case d: degenerate members -- pair 0 regular, pair 1 ZERO inliers (10 m apart: the
+    # batch can then never satisfy the all-pairs stop), pair 2 planar (z const)
+    src, dst = prealigned(3, 96, 53, False, 0.5, [0.02, -0.01, 0.0])
+    dst[1, :, 0] += 10.0
+    src[2, :, 2] = 0.7
+    dst[2, :, 2] = 0.7
+    cases["d"] = (src, dst)
+    # case e: B=6 ragged, larger perturbation (more iterations)
+    cases["e"] = prealigned(6, 384, 59, True, 2.5, [0.06, -0.05, 0.02])
+    for k, (src, dst) in cases.items():
+        res = _icp_case(src, dst)
+        out[f"{k}_src"] = src.numpy()
+        out[f"{k}_dst"] = dst.numpy()
+        for kk, vv in res.items():
+            out[f"{k}_{kk}"] = vv
+        print(f"  icp case {k}: iterations={int(res['iterations'])} converged={bool(res['converged'])}")
+    save("g5_icp", **out)
+
+
+def g6_hist_icp():
+    a = args_ns(chunk_size=4)
+    # ragged batch: some pairs have n_src > n_dst (swapped inside hist_icp)
+    S, D, Tt = synthetic.make_batch(10, 256, seed=61, ragged=True)
+    src, dst = t(S), t(D)
+    # pair 9: identical clouds -> e_icp >= e_init -> rollback to the (zero) init pose
+    dst[9] = src[9]
+    ns = (src[:, :, 3] > 0).sum(1)
+    nd = (dst[:, :, 3] > 0).sum(1)
+    T = utils_match.hist_icp(a, src, dst)
+    # also the two stages separately on the un-swapped batch
+    init = utils_hist.estimate_init_pose(a, src, dst)
+    Ti = utils_icp.apply_icp(a, src, dst, init.clone())
+    ev = utils_match.match_eval(a, src, dst, T)
+    save("g6_hist_icp", src=src.numpy(), dst=dst.numpy(), T_true=Tt, n_src=ns.numpy(), n_dst=nd.numpy(),
+         T_hist_icp=T.numpy(), T_init_noswap=init.numpy(), T_apply_icp_noswap=Ti.numpy(),
+         cut_tied=cut_is_tied(a, src, dst, True), cut_tied_noswap=cut_is_tied(a, src, dst),
+         translation_frame=np.array(a.translation_frame), thres_dist=np.array(a.thres_dist),
+         # G7: match_eval on the final transforms
+         ev_errors=ev[0].numpy(), ev_inliers=ev[1].numpy(), ev_ratios=ev[2].numpy(),
+         ev_ious=ev[3].numpy(), ev_translations=ev[4].numpy(), ev_rotations=ev[5].numpy())
+
+    # dense (config-2 shaped, scaled down) batch: n = N, 8 pairs x 512 points
+    S, D, Tt = synthetic.make_batch(8, 512, seed=67)
+    src, dst = t(S), t(D)
+    a = args_ns(max_points=512)
+    T = utils_match.hist_icp(a, src, dst)
+    ev = utils_match.match_eval(a, src, dst, T)
+    save("g6_hist_icp_dense", seed=np.array(67), num_pairs=np.array(8), max_points=np.array(512),
+         T_true=Tt, T_hist_icp=T.numpy(), cut_tied=cut_is_tied(a, src, dst, True),
+         ev_errors=ev[0].numpy(), ev_inliers=ev[1].numpy(), ev_ratios=ev[2].numpy(),
+         ev_ious=ev[3].numpy(), ev_translations=ev[4].numpy(), ev_rotations=ev[5].numpy())
+
+
+GENS = dict(g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ns = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    want = [s for s in ns.only.split(",") if s] or list(GENS)
+    for k in want:
+        print(f"== {k}")
+        GENS[k]()
