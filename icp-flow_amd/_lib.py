@@ -1,0 +1,104 @@
+"""ctypes binding of libicpflow_hip.so (C ABI: include/icpflow_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing this module raises at
+import, and every wrapper refuses non-GPU tensors.  torch is used only as the
+owner of device memory and of the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicpflow_hip.so")
+
+STOP_REFERENCE = 0
+STOP_PER_PAIR = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python icp-flow_amd/build.py` "
+        "(hipcc --offload-arch=gfx950).  icp_flow_amd has no CPU fallback.")
+
+_L = ctypes.CDLL(LIB_PATH)
+
+_f = ctypes.c_float
+_d = ctypes.c_double
+_i = ctypes.c_int
+_p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/icpflow_hip.h declares
+SIGNATURES = {
+    "icpflow_version": (_i, []),
+    "icpflow_last_error": (ctypes.c_char_p, []),
+    "icpflow_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "icpflow_hist_vote": (_i, [_p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _p, _p]),
+    "icpflow_hist_peaks": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "icpflow_nn_batch": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
+    "icpflow_transform_points": (_i, [_p, _p, _i, _i, _p, _p]),
+    "icpflow_count_valid": (_i, [_p, _i, _i, _p, _p]),
+    "icpflow_estimate_init_pose": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _p, _p, _sz, _p]),
+    "icpflow_icp": (_i, [_p, _p, _p, _i, _i, _d, _i, _d, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "icpflow_apply_icp": (_i, [_p, _p, _p, _i, _i, _d, _i, _d, _i, _p, _p, _p, _sz, _p]),
+    "icpflow_hist_icp": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _sz, _p]),
+    "icpflow_match_eval": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_L, _name)          # AttributeError here = header/library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+VERSION = int(_L.icpflow_version())
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise RuntimeError with the library's message."""
+    rc = getattr(_L, name)(*args)
+    if rc != 0:
+        msg = _L.icpflow_last_error()
+        raise RuntimeError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def workspace_bytes(B, N, lens=(0, 0, 0)):
+    return int(_L.icpflow_workspace_bytes(int(B), int(N), int(lens[0]), int(lens[1]), int(lens[2])))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError("icp_flow_amd: input must be a GPU (HIP) tensor -- there is no CPU path "
+                               "(the reference refuses CPU tensors too, hist_cuda/cpp/hist.cpp:22)")
+
+
+def cloud(t, name="cloud"):
+    """Validate a [B,N,4] float32 cloud; returns it contiguous."""
+    require_gpu(t)
+    if t.dim() != 3 or t.shape[2] != 4:
+        raise RuntimeError(f"{name}: expected shape [B,N,4] (x,y,z,flag), got {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(device, nbytes):
+    """A cached, grow-only scratch buffer per device (torch caching-allocator owned)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

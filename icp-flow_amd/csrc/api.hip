@@ -1,0 +1,336 @@
+// api.hip -- the C ABI of libicpflow_hip.so (include/icpflow_hip.h): argument checks,
+// workspace carving and kernel sequencing.  No device synchronisation anywhere.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "kernels.hpp"
+
+using namespace icpflow;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hipfail(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+#define ICPFLOW_TRY(expr)                                  \
+    do {                                                   \
+        hipError_t e__ = (expr);                           \
+        if (e__ != hipSuccess) return hipfail(e__, #expr); \
+    } while (0)
+
+constexpr size_t kAlign = 256;
+size_t up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
+
+// One carve of the caller's workspace; the same layout backs workspace_bytes().
+struct Workspace {
+    int32_t *lenA = nullptr, *lenC = nullptr;
+    uint8_t *swap = nullptr;
+    uint32_t *bins = nullptr, *volA = nullptr, *volB = nullptr;
+    float *peakVotes = nullptr;
+    int64_t *peakIdx = nullptr;
+    float *cand = nullptr;
+    double *partial = nullptr;
+    float *Tinit = nullptr, *M = nullptr;
+    IcpState *state = nullptr;
+    IcpCtrl *ctrl = nullptr;
+    int32_t *nnj = nullptr;
+    size_t bytes = 0;
+
+    Workspace(void *base, int B, int N, size_t L)
+    {
+        size_t off = 0;
+        auto take = [&](size_t n) {
+            void *p = base ? (void *)((char *)base + off) : nullptr;
+            off += up(n);
+            return p;
+        };
+        const size_t b = (size_t)B;
+        lenA = (int32_t *)take(b * 4);
+        lenC = (int32_t *)take(b * 4);
+        swap = (uint8_t *)take(b);
+        bins = (uint32_t *)take(b * L * 4);
+        volA = (uint32_t *)take(b * L * 4);
+        volB = (uint32_t *)take(b * L * 4);
+        peakVotes = (float *)take(b * kTopK * 4);
+        peakIdx = (int64_t *)take(b * kTopK * 8);
+        cand = (float *)take(b * kCand * 3 * 4);
+        partial = (double *)take(b * 12 * (size_t)scan_qblocks(N) * kPartial * 8);
+        Tinit = (float *)take(b * 16 * 4);
+        M = (float *)take(b * 16 * 4);
+        state = (IcpState *)take(b * sizeof(IcpState));
+        ctrl = (IcpCtrl *)take(sizeof(IcpCtrl));
+        nnj = (int32_t *)take(b * (size_t)N * 4);
+        bytes = off;
+    }
+};
+
+int check_ws(void *ws, size_t have, size_t need)
+{
+    if (ws == nullptr || have < need)
+        return fail(ICPFLOW_E_WORKSPACE, "workspace too small: have %zu bytes, need %zu", have, need);
+    if (((uintptr_t)ws & 15) != 0) return fail(ICPFLOW_E_WORKSPACE, "workspace must be 16-byte aligned");
+    return 0;
+}
+
+int check_batch(const char *fn, int B, int N)
+{
+    if (B <= 0 || N <= 0) return fail(ICPFLOW_E_ARG, "%s: B (%d) and N (%d) must be positive", fn, B, N);
+    if ((long long)B * N > (1ll << 30)) return fail(ICPFLOW_E_LIMIT, "%s: B*N exceeds 2^30 rows", fn);
+    return 0;
+}
+
+int check_hist_dims(const char *fn, int lx, int ly, int lz)
+{
+    if (lx <= 0 || ly <= 0 || lz <= 0)
+        return fail(ICPFLOW_E_ARG, "%s: histogram lengths must be positive (%d,%d,%d)", fn, lx, ly, lz);
+    if ((long long)lx * ly * lz > (1ll << 28)) return fail(ICPFLOW_E_LIMIT, "%s: histogram too large", fn);
+    return 0;
+}
+
+// shared tail of apply_icp / hist_icp: ICP from Tinit, compose, check, select
+int run_icp_and_select(const float *src, const float *dst, const Workspace &w, const uint8_t *swap,
+                       const float *init, int B, int N, double thres, int maxIter, double relThr,
+                       int stopMode, int invertSwapped, float *Tout, int32_t *iters, hipStream_t s)
+{
+    ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
+                           w.state, w.ctrl, w.nnj, s));
+    if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
+    ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
+    ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
+    ICPFLOW_TRY(launch_select(w.partial, scan_qblocks(N), w.lenA, w.lenC, swap, init, w.M, B,
+                              invertSwapped, Tout, s));
+    return 0;
+}
+
+int run_init_pose(const float *src, const float *dst, const Workspace &w, const uint8_t *swap, int B,
+                  int N, const float *ex, int lx, const float *ey, int ly, const float *ez, int lz,
+                  float shift, float *Tout, hipStream_t s)
+{
+    const int lens[3] = {lx, ly, lz};
+    // vote with X = dst role, Y = src role (utils_hist.py:69)
+    ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
+    ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,
+                                      w.peakVotes, w.peakIdx, s));
+    ICPFLOW_TRY(launch_decode_candidates(w.peakIdx, B, ex, ey, ez, lx, ly, lz, shift, w.cand, s));
+    ICPFLOW_TRY(launch_scan_score(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
+    ICPFLOW_TRY(launch_score_pick(w.partial, scan_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icpflow_version(void) { return ICPFLOW_VERSION; }
+
+const char *icpflow_last_error(void) { return g_err; }
+
+size_t icpflow_workspace_bytes(int B, int N, int Lx, int Ly, int Lz)
+{
+    if (B <= 0 || N <= 0) return 0;
+    const size_t L = (size_t)(Lx > 0 ? Lx : 0) * (size_t)(Ly > 0 ? Ly : 0) * (size_t)(Lz > 0 ? Lz : 0);
+    return Workspace(nullptr, B, N, L).bytes;
+}
+
+int icpflow_hist_vote(const float *d_X, const float *d_Y, int B, int NX, int NY, float min_x,
+                      float min_y, float min_z, float max_x, float max_y, float max_z, int len_x,
+                      int len_y, int len_z, float *d_bins, icpflow_stream_t stream)
+{
+    if (!d_X || !d_Y || !d_bins) return fail(ICPFLOW_E_ARG, "icpflow_hist_vote: null pointer");
+    if (int r = check_batch("icpflow_hist_vote", B, NX)) return r;
+    if (int r = check_batch("icpflow_hist_vote", B, NY)) return r;
+    if (int r = check_hist_dims("icpflow_hist_vote", len_x, len_y, len_z)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const float mins[3] = {min_x, min_y, min_z}, maxs[3] = {max_x, max_y, max_z};
+    const int lens[3] = {len_x, len_y, len_z};
+    // counters are accumulated as uint32 in the output buffer, then converted in place
+    uint32_t *u = reinterpret_cast<uint32_t *>(d_bins);
+    ICPFLOW_TRY(launch_hist_vote(d_X, d_Y, B, NX, NY, mins, maxs, lens, nullptr, nullptr, nullptr, nullptr, u, s));
+    ICPFLOW_TRY(launch_u32_to_f32(u, d_bins, (size_t)B * len_x * len_y * len_z, s));
+    return 0;
+}
+
+int icpflow_hist_peaks(const float *d_bins, int B, int len_x, int len_y, int len_z, int k,
+                       int kernel_size, float *d_votes, int64_t *d_idx, void *d_ws, size_t ws_bytes,
+                       icpflow_stream_t stream)
+{
+    if (!d_bins || !d_votes || !d_idx) return fail(ICPFLOW_E_ARG, "icpflow_hist_peaks: null pointer");
+    if (B <= 0) return fail(ICPFLOW_E_ARG, "icpflow_hist_peaks: B must be positive");
+    if (int r = check_hist_dims("icpflow_hist_peaks", len_x, len_y, len_z)) return r;
+    if (k <= 0 || k > 8) return fail(ICPFLOW_E_ARG, "icpflow_hist_peaks: k must be in 1..8 (got %d)", k);
+    if (kernel_size <= 0 || kernel_size % 2 == 0)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_peaks: kernel_size must be odd and positive");
+    const size_t L = (size_t)len_x * len_y * len_z;
+    if ((size_t)k > L) return fail(ICPFLOW_E_ARG, "icpflow_hist_peaks: k exceeds the number of bins");
+    const size_t vol = up((size_t)B * L * 4);
+    if (int r = check_ws(d_ws, ws_bytes, 2 * vol)) return r;
+    uint32_t *A = (uint32_t *)d_ws;
+    uint32_t *Bv = (uint32_t *)((char *)d_ws + vol);
+    ICPFLOW_TRY(launch_hist_peaks_f32(d_bins, B, len_x, len_y, len_z, k, kernel_size, A, Bv, d_votes, d_idx,
+                                      (hipStream_t)stream));
+    return 0;
+}
+
+int icpflow_nn_batch(const float *d_Q, const float *d_T, int B, int NQ, int NT, int q_stride,
+                     int t_stride, const int32_t *d_len_q, const int32_t *d_len_t, int sqrt_dist,
+                     int64_t *d_idx, float *d_dist, icpflow_stream_t stream)
+{
+    if (!d_Q || !d_T || !d_idx || !d_dist) return fail(ICPFLOW_E_ARG, "icpflow_nn_batch: null pointer");
+    if (int r = check_batch("icpflow_nn_batch", B, NQ)) return r;
+    if (int r = check_batch("icpflow_nn_batch", B, NT)) return r;
+    if (q_stride < 3 || t_stride < 3)
+        return fail(ICPFLOW_E_ARG, "icpflow_nn_batch: row strides must be >= 3 floats (got %d, %d)", q_stride, t_stride);
+    if ((q_stride == 4 && ((uintptr_t)d_Q & 15)) || (t_stride == 4 && ((uintptr_t)d_T & 15)))
+        return fail(ICPFLOW_E_ARG, "icpflow_nn_batch: stride-4 clouds must be 16-byte aligned");
+    ICPFLOW_TRY(launch_scan_nn(d_Q, d_T, B, NQ, NT, q_stride, t_stride, d_len_q, d_len_t, sqrt_dist, d_idx,
+                               d_dist, (hipStream_t)stream));
+    return 0;
+}
+
+int icpflow_transform_points(const float *d_xyz, const float *d_pose, int B, int N, float *d_out,
+                             icpflow_stream_t stream)
+{
+    if (!d_xyz || !d_pose || !d_out) return fail(ICPFLOW_E_ARG, "icpflow_transform_points: null pointer");
+    if (int r = check_batch("icpflow_transform_points", B, N)) return r;
+    ICPFLOW_TRY(launch_transform_points(d_xyz, d_pose, B, N, d_out, (hipStream_t)stream));
+    return 0;
+}
+
+int icpflow_count_valid(const float *d_pts, int B, int N, int32_t *d_len, icpflow_stream_t stream)
+{
+    if (!d_pts || !d_len) return fail(ICPFLOW_E_ARG, "icpflow_count_valid: null pointer");
+    if (int r = check_batch("icpflow_count_valid", B, N)) return r;
+    launch_count_valid(d_pts, B, N, d_len, (hipStream_t)stream);
+    ICPFLOW_TRY(hipGetLastError());
+    return 0;
+}
+
+int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, int N,
+                               const float *d_edges_x, int len_x, const float *d_edges_y, int len_y,
+                               const float *d_edges_z, int len_z, float decode_shift, float *d_T_out,
+                               void *d_ws, size_t ws_bytes, icpflow_stream_t stream)
+{
+    if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
+        return fail(ICPFLOW_E_ARG, "icpflow_estimate_init_pose: null pointer");
+    if (int r = check_batch("icpflow_estimate_init_pose", B, N)) return r;
+    if (int r = check_hist_dims("icpflow_estimate_init_pose", len_x, len_y, len_z)) return r;
+    const size_t L = (size_t)len_x * len_y * len_z;
+    if (L < (size_t)kTopK) return fail(ICPFLOW_E_ARG, "icpflow_estimate_init_pose: fewer than 5 bins");
+    Workspace w(d_ws, B, N, L);
+    if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    launch_count_valid(d_src, B, N, w.lenA, s);
+    launch_count_valid(d_dst, B, N, w.lenC, s);
+    return run_init_pose(d_src, d_dst, w, nullptr, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
+                         len_z, decode_shift, d_T_out, s);
+}
+
+int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int B, int N, double thres,
+                int max_iterations, double relative_rmse_thr, int stop_mode, float *d_R, float *d_T,
+                float *d_rmse, int32_t *d_iters, int32_t *d_converged, void *d_ws, size_t ws_bytes,
+                icpflow_stream_t stream)
+{
+    if (!d_X || !d_Y) return fail(ICPFLOW_E_ARG, "icpflow_icp: null pointer");
+    if (int r = check_batch("icpflow_icp", B, N)) return r;
+    if (max_iterations <= 0 || max_iterations > kMaxIterCap)
+        return fail(ICPFLOW_E_ARG, "icpflow_icp: max_iterations must be in 1..%d (got %d)", kMaxIterCap, max_iterations);
+    if (stop_mode != ICPFLOW_STOP_REFERENCE && stop_mode != ICPFLOW_STOP_PER_PAIR)
+        return fail(ICPFLOW_E_ARG, "icpflow_icp: unknown stop_mode %d", stop_mode);
+    Workspace w(d_ws, B, N, 0);
+    if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    launch_count_valid(d_X, B, N, w.lenA, s);
+    launch_count_valid(d_Y, B, N, w.lenC, s);
+    ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
+                           relative_rmse_thr, stop_mode, w.state, w.ctrl, w.nnj, s));
+    ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
+    return 0;
+}
+
+int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_init, int B, int N,
+                      double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
+                      float *d_T_out, int32_t *d_iters, void *d_ws, size_t ws_bytes,
+                      icpflow_stream_t stream)
+{
+    if (!d_src || !d_dst || !d_init || !d_T_out) return fail(ICPFLOW_E_ARG, "icpflow_apply_icp: null pointer");
+    if (int r = check_batch("icpflow_apply_icp", B, N)) return r;
+    if (max_iterations <= 0 || max_iterations > kMaxIterCap)
+        return fail(ICPFLOW_E_ARG, "icpflow_apply_icp: max_iterations must be in 1..%d", kMaxIterCap);
+    if (stop_mode != ICPFLOW_STOP_REFERENCE && stop_mode != ICPFLOW_STOP_PER_PAIR)
+        return fail(ICPFLOW_E_ARG, "icpflow_apply_icp: unknown stop_mode %d", stop_mode);
+    Workspace w(d_ws, B, N, 0);
+    if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    launch_count_valid(d_src, B, N, w.lenA, s);
+    launch_count_valid(d_dst, B, N, w.lenC, s);
+    // d_T_out may alias d_init: keep a private copy of the init poses
+    ICPFLOW_TRY(hipMemcpyAsync(w.Tinit, d_init, (size_t)B * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return run_icp_and_select(d_src, d_dst, w, nullptr, w.Tinit, B, N, thres_dist, max_iterations,
+                              relative_rmse_thr, stop_mode, 0, d_T_out, d_iters, s);
+}
+
+int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x,
+                     int len_x, const float *d_edges_y, int len_y, const float *d_edges_z, int len_z,
+                     float decode_shift, double thres_dist, int max_iterations, double relative_rmse_thr,
+                     int stop_mode, float *d_T_out, int32_t *d_iters, void *d_ws, size_t ws_bytes,
+                     icpflow_stream_t stream)
+{
+    if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: null pointer");
+    if (int r = check_batch("icpflow_hist_icp", B, N)) return r;
+    if (int r = check_hist_dims("icpflow_hist_icp", len_x, len_y, len_z)) return r;
+    if (max_iterations <= 0 || max_iterations > kMaxIterCap)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: max_iterations must be in 1..%d", kMaxIterCap);
+    if (stop_mode != ICPFLOW_STOP_REFERENCE && stop_mode != ICPFLOW_STOP_PER_PAIR)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: unknown stop_mode %d", stop_mode);
+    const size_t L = (size_t)len_x * len_y * len_z;
+    if (L < (size_t)kTopK) return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: fewer than 5 bins");
+    Workspace w(d_ws, B, N, L);
+    if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    launch_count_valid(d_src, B, N, w.lenA, s);
+    launch_count_valid(d_dst, B, N, w.lenC, s);
+    ICPFLOW_TRY(launch_swap_flags(w.lenA, w.lenC, B, w.swap, s));  // utils_match.py:139-146
+    if (int r = run_init_pose(d_src, d_dst, w, w.swap, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
+                              len_z, decode_shift, w.Tinit, s))
+        return r;
+    return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
+                              relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, s);
+}
+
+int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_T, int B, int N,
+                       double thres_dist, float *d_errors, float *d_inliers, float *d_ratios,
+                       float *d_ious, float *d_translations, float *d_rotations, void *d_ws,
+                       size_t ws_bytes, icpflow_stream_t stream)
+{
+    if (!d_pcd1 || !d_pcd2 || !d_T || !d_errors || !d_inliers || !d_ratios || !d_ious || !d_translations ||
+        !d_rotations)
+        return fail(ICPFLOW_E_ARG, "icpflow_match_eval: null pointer");
+    if (int r = check_batch("icpflow_match_eval", B, N)) return r;
+    Workspace w(d_ws, B, N, 0);
+    if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    launch_count_valid(d_pcd1, B, N, w.lenA, s);
+    launch_count_valid(d_pcd2, B, N, w.lenC, s);
+    ICPFLOW_TRY(launch_scan_eval(d_pcd1, d_pcd2, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.partial, s));
+    ICPFLOW_TRY(launch_eval_epilogue(w.partial, scan_qblocks(N), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
+                                     d_ratios, d_ious, d_translations, d_rotations, s));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// common.hpp -- shared device helpers for the gfx950 kernels of libicpflow_hip.so.
+// wave = 64 lanes everywhere; compile with -ffp-contract=off: every FMA in this
+// library is an explicit fmaf()/fma() so that the arithmetic is the one written.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icpflow {
+
+constexpr int kWave = 64;
+constexpr float kInf = __builtin_huge_valf();
+
+// ---- 3x4 affine map applied to points ------------------------------------------
+// p' = M p + t, evaluated as the reference's bmm([x y z 1], pose^T) does it:
+// a left-to-right fp32 dot product per output coordinate (utils_helper.py:85).
+struct Affine {
+    float m[9];
+    float t[3];
+};
+
+__device__ __forceinline__ Affine affine_identity()
+{
+    Affine a;
+    a.m[0] = 1.f; a.m[1] = 0.f; a.m[2] = 0.f;
+    a.m[3] = 0.f; a.m[4] = 1.f; a.m[5] = 0.f;
+    a.m[6] = 0.f; a.m[7] = 0.f; a.m[8] = 1.f;
+    a.t[0] = a.t[1] = a.t[2] = 0.f;
+    return a;
+}
+
+// rows 0..2 of a row-major 4x4
+__device__ __forceinline__ Affine affine_from_pose(const float *__restrict__ pose)
+{
+    Affine a;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        a.m[r * 3 + 0] = pose[r * 4 + 0];
+        a.m[r * 3 + 1] = pose[r * 4 + 1];
+        a.m[r * 3 + 2] = pose[r * 4 + 2];
+        a.t[r] = pose[r * 4 + 3];
+    }
+    return a;
+}
+
+__device__ __forceinline__ void affine_apply(const Affine &a, float x, float y, float z,
+                                             float &ox, float &oy, float &oz)
+{
+    ox = fmaf(z, a.m[2], fmaf(y, a.m[1], x * a.m[0])) + a.t[0];
+    oy = fmaf(z, a.m[5], fmaf(y, a.m[4], x * a.m[3])) + a.t[1];
+    oz = fmaf(z, a.m[8], fmaf(y, a.m[7], x * a.m[6])) + a.t[2];
+}
+
+// ---- how a cloud is presented to a scan ------------------------------------------
+enum XfKind : int { XF_NONE = 0, XF_TRANSLATE = 1, XF_AFFINE = 2 };
+
+struct PointXf {
+    int kind;
+    Affine a;  // XF_TRANSLATE uses a.t only: p' = p + t (utils_hist.py:86)
+};
+
+__device__ __forceinline__ void xf_apply(const PointXf &x, float px, float py, float pz,
+                                         float &ox, float &oy, float &oz)
+{
+    if (x.kind == XF_NONE) {
+        ox = px; oy = py; oz = pz;
+    } else if (x.kind == XF_TRANSLATE) {
+        ox = px + x.a.t[0]; oy = py + x.a.t[1]; oz = pz + x.a.t[2];
+    } else {
+        affine_apply(x.a, px, py, pz, ox, oy, oz);
+    }
+}
+
+// ---- squared distance, the pytorch3d CUDA order: diff; dist = fma chain ------------
+__device__ __forceinline__ float sqdist(float qx, float qy, float qz, float tx, float ty, float tz)
+{
+    const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+// ---- wave / block reductions (deterministic order) ---------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, kWave);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// Sum K values per thread over the whole block.  `scratch` holds at least
+// (blockDim.x/64)*K elements of T.  On return every thread has the totals in v[].
+// Contains two __syncthreads(); all threads of the block must call it.
+template <int K, typename T>
+__device__ __forceinline__ void block_sum(T (&v)[K], T *scratch)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int nwave = (blockDim.x + kWave - 1) >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    if (nwave == 1) return;
+    __syncthreads();  // scratch may still be read by a previous reduction
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) scratch[wave * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        T s = scratch[k];
+        for (int w = 1; w < nwave; ++w) s += scratch[w * K + k];
+        v[k] = s;
+    }
+}
+
+}  // namespace icpflow

@@ -1,0 +1,93 @@
+// kernels.hpp -- internal launcher interface between the translation units of
+// libicpflow_hip.so (each .hip file owns its kernels; api.hip sequences them).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/icpflow_hip.h"
+
+namespace icpflow {
+
+constexpr int ICPFLOW_STOP_REFERENCE_ = ICPFLOW_STOP_REFERENCE;
+constexpr int ICPFLOW_STOP_PER_PAIR_ = ICPFLOW_STOP_PER_PAIR;
+
+constexpr int kPartial = 8;       // doubles per (job, query block) partial record
+constexpr int kMaxIterCap = 1024; // upper bound on max_iterations
+constexpr int kCand = 6;          // 5 peaks + the zero translation (utils_hist.py:83)
+constexpr int kTopK = 5;          // utils_hist.py:21
+constexpr int kNmsKernel = 11;    // utils_hist.py:21
+
+struct IcpState {
+    float R[9];
+    float T[3];
+    float rmse;
+    int active;
+    int iters;
+    int pad;
+};
+
+struct IcpCtrl {
+    int done;
+    int iters;
+    int pad[2];
+    int notconv[kMaxIterCap];
+};
+
+// hist.hip
+void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s);
+hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int NY,
+                            const float mins[3], const float maxs[3], const int lens[3],
+                            const float *ex, const float *ey, const float *ez,
+                            const uint8_t *swap, uint32_t *bins_u32, hipStream_t s);
+hipError_t launch_u32_to_f32(const uint32_t *in, float *out, size_t n, hipStream_t s);
+hipError_t launch_hist_peaks_f32(const float *bins, int B, int Lx, int Ly, int Lz, int k,
+                                 int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
+                                 int64_t *idx, hipStream_t s);
+hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, int Lz, int k,
+                                 int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
+                                 int64_t *idx, hipStream_t s);
+
+// nn.hip
+int scan_qblocks(int maxRows);
+hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
+                             const uint8_t *swap, int B, int N, const float *cand, double *partial,
+                             hipStream_t s);
+hipError_t launch_scan_check(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
+                             const uint8_t *swap, int B, int N, const float *poseInit,
+                             const float *poseFinal, double *partial, hipStream_t s);
+hipError_t launch_scan_eval(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
+                            int B, int N, const float *pose, float thres, double *partial, hipStream_t s);
+hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int NT, int strideQ,
+                          int strideT, const int32_t *lenQ, const int32_t *lenT, int sqrt_dist,
+                          int64_t *idx, float *dist, hipStream_t s);
+
+// icp.hip
+hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
+                      const uint8_t *swap, const float *prePose, int B, int N, double thres,
+                      int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
+                      int32_t *nnj, hipStream_t s);
+hipError_t launch_icp_export(const IcpState *state, const IcpCtrl *ctrl, int B, int stopMode, float *R,
+                             float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s);
+
+// pose.hip
+hipError_t launch_swap_flags(const int32_t *lenSrc, const int32_t *lenDst, int B, uint8_t *swap,
+                             hipStream_t s);
+hipError_t launch_decode_candidates(const int64_t *peakIdx, int B, const float *ex, const float *ey,
+                                    const float *ez, int Lx, int Ly, int Lz, float shift, float *cand,
+                                    hipStream_t s);
+hipError_t launch_score_pick(const double *partial, int qblocks, const int32_t *lenA,
+                             const int32_t *lenC, const uint8_t *swap, const float *cand, int B,
+                             float *Tinit, hipStream_t s);
+hipError_t launch_compose(const IcpState *state, const float *init, int B, float *M, hipStream_t s);
+hipError_t launch_select(const double *partial, int qblocks, const int32_t *lenA, const int32_t *lenC,
+                         const uint8_t *swap, const float *init, const float *M, int B, int invertSwapped,
+                         float *out, hipStream_t s);
+hipError_t launch_eval_epilogue(const double *partial, int qblocks, const int32_t *len1,
+                                const int32_t *len2, const float *T, int B, float *errors,
+                                float *inliers, float *ratios, float *ious, float *translations,
+                                float *rotations, hipStream_t s);
+hipError_t launch_transform_points(const float *xyz, const float *pose, int B, int N, float *out,
+                                   hipStream_t s);
+
+}  // namespace icpflow

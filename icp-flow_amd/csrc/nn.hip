@@ -1,0 +1,234 @@
+// nn.hip -- batched nearest-neighbour scans with fused epilogues (gfx950).
+//
+// One kernel template, four uses:
+//   MODE_SCORE : 6 candidate translations x 2 directions per pair (utils_hist.py:86-104)
+//   MODE_CHECK : mean NN error of src under the init pose and under the ICP pose
+//                (utils_icp.py:27-33)
+//   MODE_EVAL  : match_eval's two directions with inlier counts and centroid sums
+//                (utils_match.py:160-183)
+//   MODE_NN    : plain nearest_neighbor_batch (utils_helper.py:20-30), idx + dist out
+// Unlike the reference's un-lengthed knn over the padded N x N grid, the fused modes
+// scan only the valid prefixes -- identical results for valid queries.
+//
+// Grid: 1-D, XCD-aware.  Consecutive workgroup ids land on consecutive XCDs (id % 8), so
+// ids are laid out as [group][qblock][job-in-group(8)]: all query blocks of one job share
+// an XCD and therefore the L2 copy of that job's target cloud.
+#include "scan.hpp"
+#include "kernels.hpp"
+
+namespace icpflow {
+
+enum ScanMode : int { MODE_SCORE = 0, MODE_CHECK = 1, MODE_EVAL = 2, MODE_NN = 3 };
+
+struct ScanParams {
+    // clouds [B,N,4]; `swap[b]` exchanges the roles of A and C for that pair
+    const float *A;        // "src" role (queries in the forward direction)
+    const float *C;        // "dst" role
+    const int32_t *lenA;   // valid prefixes per pair (may be NULL in MODE_NN)
+    const int32_t *lenC;
+    const uint8_t *swap;   // optional
+    int N;                 // rows per pair in A and C (MODE_NN: NQ)
+    int NT;                // MODE_NN: rows per pair of the target cloud
+    int strideQ, strideT;  // MODE_NN: floats per row
+    int njobs;             // jobs in this launch
+    int qblocks;           // query blocks per job
+    // MODE_SCORE: candidate translations [B,6,3]
+    const float *cand;
+    // MODE_CHECK: poseA = init [B,4,4], poseB = final [B,4,4];  MODE_EVAL: poseA = T
+    const float *poseA;
+    const float *poseB;
+    float thres;           // MODE_EVAL inlier threshold on the Euclidean distance
+    // outputs
+    double *partial;       // [njobs, qblocks, kPartial]
+    int64_t *idx;          // MODE_NN
+    float *dist;           // MODE_NN
+    int sqrt_dist;         // MODE_NN
+};
+
+template <int Q, int MODE>
+__global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
+{
+    __shared__ ScanTile tileMem;
+    ScanTile *tile = &tileMem;
+    __shared__ double red[(kScanBlock / kWave) * kPartial];
+
+    // ---- XCD-aware decode of the linear workgroup id --------------------------------
+    const int lin = blockIdx.x;
+    const int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);
+    const int qb = (lin >> 3) % p.qblocks;
+    if (job >= p.njobs) return;
+
+    // ---- job -> (query cloud, target cloud, maps) -------------------------------------
+    int b, sub;
+    if (MODE == MODE_SCORE) { b = job / 12; sub = job % 12; }
+    else if (MODE == MODE_NN) { b = job; sub = 0; }
+    else { b = job >> 1; sub = job & 1; }
+
+    CloudView qc, tc;
+    PointXf qxf, txf;
+    qxf.kind = XF_NONE; txf.kind = XF_NONE;
+    qxf.a = affine_identity(); txf.a = qxf.a;
+
+    if (MODE == MODE_NN) {
+        qc.base = p.A + (size_t)b * p.N * p.strideQ; qc.stride = p.strideQ;
+        qc.n = p.lenA ? p.lenA[b] : p.N;
+        tc.base = p.C + (size_t)b * p.NT * p.strideT; tc.stride = p.strideT;
+        tc.n = p.lenC ? p.lenC[b] : p.NT;
+    } else {
+        const bool sw = p.swap != nullptr && p.swap[b] != 0;
+        CloudView a, c;
+        a.base = (sw ? p.C : p.A) + (size_t)b * p.N * 4; a.stride = 4; a.n = (sw ? p.lenC : p.lenA)[b];
+        c.base = (sw ? p.A : p.C) + (size_t)b * p.N * 4; c.stride = 4; c.n = (sw ? p.lenA : p.lenC)[b];
+        PointXf axf;
+        axf.a = affine_identity();
+        if (MODE == MODE_SCORE) {
+            const int k = sub >> 1;
+            axf.kind = XF_TRANSLATE;
+            const float *t = p.cand + ((size_t)b * 6 + k) * 3;
+            axf.a.t[0] = t[0]; axf.a.t[1] = t[1]; axf.a.t[2] = t[2];
+        } else if (MODE == MODE_CHECK) {
+            axf.kind = XF_AFFINE;
+            axf.a = affine_from_pose((sub == 0 ? p.poseA : p.poseB) + (size_t)b * 16);
+        } else {  // MODE_EVAL
+            axf.kind = XF_AFFINE;
+            axf.a = affine_from_pose(p.poseA + (size_t)b * 16);
+        }
+        const bool backward = (MODE == MODE_SCORE) ? (sub & 1) : (MODE == MODE_EVAL ? (sub == 1) : false);
+        if (!backward) { qc = a; qxf = axf; tc = c; }
+        else           { qc = c; tc = a; txf = axf; }
+    }
+
+    const int q0 = qb * (kScanBlock * Q);
+    const int nq_rows = (MODE == MODE_NN) ? p.N : qc.n;  // rows that get an output / a sum
+    if (q0 >= nq_rows) {                                 // whole block beyond the cloud
+        // its partial record is still summed by the epilogue kernels: publish zeros
+        if (MODE != MODE_NN && threadIdx.x < kPartial)
+            p.partial[((size_t)job * p.qblocks + qb) * kPartial + threadIdx.x] = 0.0;
+        return;
+    }
+
+    // ---- load this lane's queries -----------------------------------------------------
+    float qx[Q], qy[Q], qz[Q], ox[Q], oy[Q], oz[Q];
+    bool live[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int i = q0 + q * kScanBlock + threadIdx.x;
+        live[q] = i < qc.n;
+        qx[q] = qy[q] = qz[q] = 0.f;
+        ox[q] = oy[q] = oz[q] = 0.f;
+        if (live[q]) {
+            cloud_load(qc, i, ox[q], oy[q], oz[q]);
+            xf_apply(qxf, ox[q], oy[q], oz[q], qx[q], qy[q], qz[q]);
+        }
+    }
+
+    ScanAcc<Q> acc;
+    scan_cloud<Q>(tc, txf, tile, qx, qy, qz, acc);
+
+    if (MODE == MODE_NN) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int i = q0 + q * kScanBlock + threadIdx.x;
+            if (i >= p.N) continue;
+            int64_t j = 0;
+            float d = 0.f;  // rows >= len keep idx 0 / dist 0 (pytorch3d)
+            if (live[q] && tc.n > 0) {
+                float nx, ny, nz;
+                j = scan_resolve(tc, txf, qx[q], qy[q], qz[q], acc.best[q], acc.chunk[q], nx, ny, nz);
+                d = p.sqrt_dist ? sqrtf(acc.best[q]) : acc.best[q];
+            }
+            p.idx[(size_t)b * p.N + i] = j;
+            p.dist[(size_t)b * p.N + i] = d;
+        }
+        return;
+    }
+
+    // ---- fused epilogue: masked sums over this block's queries ---------------------------
+    double v[kPartial];
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) v[k] = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (!live[q]) continue;
+        const float d = sqrtf(acc.best[q]);  // utils_helper.py:30
+        v[0] += (double)d;
+        if (MODE == MODE_EVAL) {
+            v[1] += (d < p.thres) ? 1.0 : 0.0;  // utils_match.py:168 (strict <)
+            if (sub == 0) {
+                v[2] += (double)qx[q]; v[3] += (double)qy[q]; v[4] += (double)qz[q];
+                v[5] += (double)ox[q]; v[6] += (double)oy[q]; v[7] += (double)oz[q];
+            }
+        }
+    }
+    block_sum<kPartial, double>(v, red);
+    if (threadIdx.x == 0) {
+        double *o = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
+#pragma unroll
+        for (int k = 0; k < kPartial; ++k) o[k] = v[k];
+    }
+}
+
+template <int MODE>
+static hipError_t launch_scan(ScanParams p, int maxRows, hipStream_t s)
+{
+    int Q = 4;
+    if (maxRows <= 512) Q = 1;
+    else if (maxRows <= 1024) Q = 2;
+    p.qblocks = (maxRows + kScanBlock * Q - 1) / (kScanBlock * Q);
+    const int groups = (p.njobs + 7) / 8;
+    const dim3 grid((unsigned)(groups * 8 * p.qblocks));
+    if (Q == 1) hipLaunchKernelGGL((nn_scan_kernel<1, MODE>), grid, dim3(kScanBlock), 0, s, p);
+    else if (Q == 2) hipLaunchKernelGGL((nn_scan_kernel<2, MODE>), grid, dim3(kScanBlock), 0, s, p);
+    else hipLaunchKernelGGL((nn_scan_kernel<4, MODE>), grid, dim3(kScanBlock), 0, s, p);
+    return hipGetLastError();
+}
+
+int scan_qblocks(int maxRows)
+{
+    int Q = 4;
+    if (maxRows <= 512) Q = 1;
+    else if (maxRows <= 1024) Q = 2;
+    return (maxRows + kScanBlock * Q - 1) / (kScanBlock * Q);
+}
+
+hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
+                             const uint8_t *swap, int B, int N, const float *cand, double *partial,
+                             hipStream_t s)
+{
+    ScanParams p{};
+    p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.N = N;
+    p.njobs = B * 12; p.cand = cand; p.partial = partial;
+    return launch_scan<MODE_SCORE>(p, N, s);
+}
+
+hipError_t launch_scan_check(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
+                             const uint8_t *swap, int B, int N, const float *poseInit,
+                             const float *poseFinal, double *partial, hipStream_t s)
+{
+    ScanParams p{};
+    p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.N = N;
+    p.njobs = B * 2; p.poseA = poseInit; p.poseB = poseFinal; p.partial = partial;
+    return launch_scan<MODE_CHECK>(p, N, s);
+}
+
+hipError_t launch_scan_eval(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
+                            int B, int N, const float *pose, float thres, double *partial, hipStream_t s)
+{
+    ScanParams p{};
+    p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = nullptr; p.N = N;
+    p.njobs = B * 2; p.poseA = pose; p.thres = thres; p.partial = partial;
+    return launch_scan<MODE_EVAL>(p, N, s);
+}
+
+hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int NT, int strideQ,
+                          int strideT, const int32_t *lenQ, const int32_t *lenT, int sqrt_dist,
+                          int64_t *idx, float *dist, hipStream_t s)
+{
+    ScanParams p{};
+    p.A = Qp; p.C = Tp; p.lenA = lenQ; p.lenC = lenT; p.N = NQ; p.NT = NT;
+    p.strideQ = strideQ; p.strideT = strideT; p.njobs = B; p.idx = idx; p.dist = dist;
+    p.sqrt_dist = sqrt_dist;
+    return launch_scan<MODE_NN>(p, NQ, s);
+}
+
+}  // namespace icpflow

@@ -1,0 +1,244 @@
+// pose.hip -- the small per-pair kernels between the scans: candidate decoding and
+// scoring (utils_hist.py:78-121), 4x4 assembly / roll-back / inverse
+// (utils_icp.py:24-35,60-65; utils_match.py:139-156), match_eval's epilogue
+// (utils_match.py:168-184) and transform_points_batch (utils_helper.py:76-87).
+// One lane per pair: these are latency-trivial next to the O(n^2) scans.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace icpflow {
+
+// swap[b] = n_src > n_dst  (strict; utils_match.py:142)
+__global__ void swap_flags_kernel(const int32_t *__restrict__ ls, const int32_t *__restrict__ ld, int B,
+                                  uint8_t *__restrict__ swap)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) swap[b] = ls[b] > ld[b] ? 1 : 0;
+}
+
+hipError_t launch_swap_flags(const int32_t *lenSrc, const int32_t *lenDst, int B, uint8_t *swap,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(swap_flags_kernel, dim3((B + 255) / 256), dim3(256), 0, s, lenSrc, lenDst, B, swap);
+    return hipGetLastError();
+}
+
+// flat peak index -> translation (left bin edges + shift), zero translation LAST
+// (utils_hist.py:78, :83)
+__global__ void decode_candidates_kernel(const int64_t *__restrict__ peakIdx, int B,
+                                         const float *__restrict__ ex, const float *__restrict__ ey,
+                                         const float *__restrict__ ez, int Lx, int Ly, int Lz,
+                                         float shift, float *__restrict__ cand)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * kCand) return;
+    const int b = t / kCand, k = t % kCand;
+    float *o = cand + (size_t)t * 3;
+    if (k == kCand - 1) { o[0] = o[1] = o[2] = 0.f; return; }
+    const int64_t f = peakIdx[(size_t)b * kTopK + k];
+    const int ix = (int)(f / Lz / Ly % Lx), iy = (int)(f / Lz % Ly), iz = (int)(f % Lz);
+    o[0] = ex[ix] + shift;
+    o[1] = ey[iy] + shift;
+    o[2] = ez[iz] + shift;
+}
+
+hipError_t launch_decode_candidates(const int64_t *peakIdx, int B, const float *ex, const float *ey,
+                                    const float *ez, int Lx, int Ly, int Lz, float shift, float *cand,
+                                    hipStream_t s)
+{
+    const int n = B * kCand;
+    hipLaunchKernelGGL(decode_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, s, peakIdx, B, ex, ey,
+                       ez, Lx, Ly, Lz, shift, cand);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ double partial_total(const double *partial, int job, int qblocks, int k)
+{
+    double s = 0.0;
+    for (int q = 0; q < qblocks; ++q) s += partial[((size_t)job * qblocks + q) * kPartial + k];
+    return s;
+}
+
+// score_k = min(mean fwd, mean bwd); first arg-min; T = I with that translation
+// (utils_hist.py:101-106, :121-122)
+__global__ void score_pick_kernel(const double *__restrict__ partial, int qblocks,
+                                  const int32_t *__restrict__ lenA, const int32_t *__restrict__ lenC,
+                                  const uint8_t *__restrict__ swap, const float *__restrict__ cand, int B,
+                                  float *__restrict__ Tinit)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool sw = swap != nullptr && swap[b] != 0;
+    const float na = (float)(sw ? lenC[b] : lenA[b]);
+    const float nc = (float)(sw ? lenA[b] : lenC[b]);
+    int pick = 0;
+    float best = 0.f;
+    for (int k = 0; k < kCand; ++k) {
+        const float fwd = (float)partial_total(partial, b * 12 + k * 2 + 0, qblocks, 0) / na;
+        const float bwd = (float)partial_total(partial, b * 12 + k * 2 + 1, qblocks, 0) / nc;
+        const float sc = fminf(fwd, bwd);
+        if (k == 0 || sc < best) { best = sc; pick = k; }
+    }
+    float *T = Tinit + (size_t)b * 16;
+    for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.f : 0.f;
+    const float *t = cand + ((size_t)b * kCand + pick) * 3;
+    T[3] = t[0]; T[7] = t[1]; T[11] = t[2];
+}
+
+hipError_t launch_score_pick(const double *partial, int qblocks, const int32_t *lenA,
+                             const int32_t *lenC, const uint8_t *swap, const float *cand, int B,
+                             float *Tinit, hipStream_t s)
+{
+    hipLaunchKernelGGL(score_pick_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, qblocks, lenA,
+                       lenC, swap, cand, B, Tinit);
+    return hipGetLastError();
+}
+
+// M = [[R^T, T],[0 0 0 1]] * init   (utils_icp.py:60-65, :24; fp32 bmm order)
+__global__ void compose_kernel(const IcpState *__restrict__ st, const float *__restrict__ init, int B,
+                               float *__restrict__ M)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float A[16];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) A[i * 4 + j] = st[b].R[j * 3 + i];
+        A[i * 4 + 3] = st[b].T[i];
+    }
+    A[12] = A[13] = A[14] = 0.f; A[15] = 1.f;
+    const float *I = init + (size_t)b * 16;
+    float *o = M + (size_t)b * 16;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = A[i * 4 + 0] * I[0 * 4 + j];
+            acc = fmaf(A[i * 4 + 1], I[1 * 4 + j], acc);
+            acc = fmaf(A[i * 4 + 2], I[2 * 4 + j], acc);
+            acc = fmaf(A[i * 4 + 3], I[3 * 4 + j], acc);
+            o[i * 4 + j] = acc;
+        }
+}
+
+hipError_t launch_compose(const IcpState *state, const float *init, int B, float *M, hipStream_t s)
+{
+    hipLaunchKernelGGL(compose_kernel, dim3((B + 127) / 128), dim3(128), 0, s, state, init, B, M);
+    return hipGetLastError();
+}
+
+// roll back where the ICP pose did not lower the mean NN error (utils_icp.py:27-35), then
+// invert the pose of swapped pairs (utils_match.py:152-154; exact affine inverse in fp64)
+__global__ void select_kernel(const double *__restrict__ partial, int qblocks,
+                              const int32_t *__restrict__ lenA, const int32_t *__restrict__ lenC,
+                              const uint8_t *__restrict__ swap, const float *__restrict__ init,
+                              const float *__restrict__ M, int B, int invertSwapped, float *__restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool sw = swap != nullptr && swap[b] != 0;
+    const float na = (float)(sw ? lenC[b] : lenA[b]);
+    const float e0 = (float)partial_total(partial, b * 2 + 0, qblocks, 0) / na;
+    const float e1 = (float)partial_total(partial, b * 2 + 1, qblocks, 0) / na;
+    const float *src = (e1 >= e0) ? init + (size_t)b * 16 : M + (size_t)b * 16;  // NaN keeps ICP
+    float P[16];
+    for (int k = 0; k < 16; ++k) P[k] = src[k];
+    if (sw && invertSwapped) {
+        const double a = P[0], bb = P[1], c = P[2], d = P[4], e = P[5], f = P[6], g = P[8], h = P[9],
+                     i = P[10];
+        const double tx = P[3], ty = P[7], tz = P[11];
+        const double c00 = e * i - f * h, c01 = c * h - bb * i, c02 = bb * f - c * e;
+        const double c10 = f * g - d * i, c11 = a * i - c * g, c12 = c * d - a * f;
+        const double c20 = d * h - e * g, c21 = bb * g - a * h, c22 = a * e - bb * d;
+        const double det = a * c00 + bb * c10 + c * c20;
+        const double r = 1.0 / det;
+        const double I00 = c00 * r, I01 = c01 * r, I02 = c02 * r;
+        const double I10 = c10 * r, I11 = c11 * r, I12 = c12 * r;
+        const double I20 = c20 * r, I21 = c21 * r, I22 = c22 * r;
+        P[0] = (float)I00; P[1] = (float)I01; P[2] = (float)I02;
+        P[4] = (float)I10; P[5] = (float)I11; P[6] = (float)I12;
+        P[8] = (float)I20; P[9] = (float)I21; P[10] = (float)I22;
+        P[3] = (float)(-(I00 * tx + I01 * ty + I02 * tz));
+        P[7] = (float)(-(I10 * tx + I11 * ty + I12 * tz));
+        P[11] = (float)(-(I20 * tx + I21 * ty + I22 * tz));
+        P[12] = P[13] = P[14] = 0.f; P[15] = 1.f;
+    }
+    float *o = out + (size_t)b * 16;
+    for (int k = 0; k < 16; ++k) o[k] = P[k];
+}
+
+hipError_t launch_select(const double *partial, int qblocks, const int32_t *lenA, const int32_t *lenC,
+                         const uint8_t *swap, const float *init, const float *M, int B, int invertSwapped,
+                         float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(select_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, qblocks, lenA, lenC,
+                       swap, init, M, B, invertSwapped, out);
+    return hipGetLastError();
+}
+
+// match_eval epilogue (utils_match.py:168-184)
+__global__ void eval_epilogue_kernel(const double *__restrict__ partial, int qblocks,
+                                     const int32_t *__restrict__ len1, const int32_t *__restrict__ len2,
+                                     const float *__restrict__ T, int B, float *__restrict__ errors,
+                                     float *__restrict__ inliers, float *__restrict__ ratios,
+                                     float *__restrict__ ious, float *__restrict__ translations,
+                                     float *__restrict__ rotations)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int j1 = b * 2, j2 = b * 2 + 1;
+    const float n1 = (float)len1[b], n2 = (float)len2[b];
+    const float n12 = (float)(len1[b] + len2[b]);
+    const float in1 = (float)partial_total(partial, j1, qblocks, 1);
+    const float in2 = (float)partial_total(partial, j2, qblocks, 1);
+    errors[b * 2 + 0] = (float)partial_total(partial, j1, qblocks, 0) / n1;  // :177
+    errors[b * 2 + 1] = (float)partial_total(partial, j2, qblocks, 0) / n2;  // :178
+    inliers[b * 2 + 0] = in1;
+    inliers[b * 2 + 1] = in2;
+    ratios[b * 2 + 0] = in1 / n1;                                            // :171
+    ratios[b * 2 + 1] = in2 / n2;                                            // :172
+    ious[b * 2 + 0] = in1 / (n12 - in2);                                     // :174
+    ious[b * 2 + 1] = in2 / (n12 - in1);                                     // :175
+    for (int k = 0; k < 3; ++k) {
+        const float moved = (float)partial_total(partial, j1, qblocks, 2 + k) / n1;  // :180
+        const float orig = (float)partial_total(partial, j1, qblocks, 5 + k) / n1;   // :181
+        translations[b * 3 + k] = moved - orig;                                      // :183
+    }
+    const float *M = T + (size_t)b * 16;
+    // pytorch3d matrix_to_euler_angles(M[0:3,0:3], 'ZYX'), then * 180. / np.pi  (:184)
+    const float pi = 3.14159265358979323846f;
+    rotations[b * 3 + 0] = (atan2f(M[4], M[0]) * 180.0f) / pi;
+    rotations[b * 3 + 1] = (asinf(-M[8]) * 180.0f) / pi;
+    rotations[b * 3 + 2] = (atan2f(M[9], M[10]) * 180.0f) / pi;
+}
+
+hipError_t launch_eval_epilogue(const double *partial, int qblocks, const int32_t *len1,
+                                const int32_t *len2, const float *T, int B, float *errors,
+                                float *inliers, float *ratios, float *ious, float *translations,
+                                float *rotations, hipStream_t s)
+{
+    hipLaunchKernelGGL(eval_epilogue_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, qblocks, len1,
+                       len2, T, B, errors, inliers, ratios, ious, translations, rotations);
+    return hipGetLastError();
+}
+
+// transform_points_batch (utils_helper.py:76-87); in-place safe (one thread per row)
+__global__ void transform_points_kernel(const float4 *xyz, const float *__restrict__ pose, int N, float4 *out)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const Affine a = affine_from_pose(pose + (size_t)b * 16);
+    const float4 p = xyz[(size_t)b * N + i];
+    float4 o;
+    affine_apply(a, p.x, p.y, p.z, o.x, o.y, o.z);
+    o.w = p.w;
+    out[(size_t)b * N + i] = o;
+}
+
+hipError_t launch_transform_points(const float *xyz, const float *pose, int B, int N, float *out,
+                                   hipStream_t s)
+{
+    hipLaunchKernelGGL(transform_points_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s,
+                       (const float4 *)xyz, pose, N, (float4 *)out);
+    return hipGetLastError();
+}
+
+}  // namespace icpflow

@@ -1,0 +1,209 @@
+/*
+ * icpflow_hip.h -- C ABI of libicpflow_hip.so: the MI355X (gfx950) drop-in for
+ * ICP-Flow's cluster-pair registration hot path.
+ *
+ * Every pointer named d_* is a DEVICE pointer owned by the caller (e.g. the
+ * data_ptr() of a torch-ROCm tensor); the library never allocates or frees
+ * caller memory and keeps no global state besides a thread-local error string.
+ * Scratch comes from a caller-provided workspace (icpflow_workspace_bytes()).
+ * All work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ * void*; NULL = the default stream); no entry point synchronises the device.
+ *
+ * Return value: 0 = ok, negative = argument error (ICPFLOW_E_*), positive = the
+ * hipError_t of a failed runtime call / kernel launch.  icpflow_last_error()
+ * returns the message of the calling thread's last failure.  (The reference
+ * only printf()s launch errors, hist_cuda_core.cuh:94-98; here they surface.)
+ *
+ * Data contract (reference: utils_helper.py:185-196 `pad_segment`):
+ *   clouds are float32 [B, N, 4] contiguous, columns (x, y, z, flag);
+ *   a point is valid iff flag > 0.  The NN / ICP / evaluation entry points
+ *   additionally require the layout pad_segment produces -- valid rows first,
+ *   then pads -- because, like pytorch3d's `lengths`, they scan the first
+ *   n = count(flag > 0) rows.  icpflow_hist_vote accepts arbitrary flag patterns
+ *   (the reference's own hist_cuda/test.py uses random flags).
+ *
+ * All citations `file:line` are into the reference repository
+ * (yanconglin/ICP-Flow).
+ */
+#ifndef ICPFLOW_HIP_H
+#define ICPFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICPFLOW_VERSION 100 /* 0.1.0 */
+
+#define ICPFLOW_OK 0
+#define ICPFLOW_E_ARG (-1)       /* bad pointer / size / enum                      */
+#define ICPFLOW_E_WORKSPACE (-2) /* workspace pointer NULL or too small            */
+#define ICPFLOW_E_LIMIT (-3)     /* size beyond what the kernels index (see docs)  */
+
+/* ICP stopping rule */
+#define ICPFLOW_STOP_REFERENCE 0 /* batch-global: stop when EVERY pair has rel<=thr
+                                    (utils_icp_pytorch3d.py:209); bit-for-bit the
+                                    reference's iteration count, no host sync      */
+#define ICPFLOW_STOP_PER_PAIR 1  /* each pair stops on its own rel<=thr (or NaN)   */
+
+typedef void *icpflow_stream_t; /* hipStream_t */
+
+int icpflow_version(void);
+const char *icpflow_last_error(void);
+
+/* Bytes of device scratch the fused entry points below need for a batch of B
+ * pairs padded to N points with a translation histogram of Lx*Ly*Lz bins.
+ * (Pass Lx=Ly=Lz=0 for entry points that do not vote.) */
+size_t icpflow_workspace_bytes(int B, int N, int Lx, int Ly, int Lz);
+
+/* ---------------------------------------------------------------------------
+ * a-1  translation-histogram vote.
+ * Replaces: HIST.hist / hist_cuda() -- hist_cuda/hist.py:39-51, cpp/hist.cpp:4-27,
+ * cpp/hist_cuda.cu:19-90, kernel cpp/hist_cuda_core.cuh:23-64.
+ * For every valid i in X[b], valid j in Y[b]: v = X_i - Y_j; if min <= v < max on
+ * all axes, p = floor((v-min)/(max-min)*float(len)) and bins[b,px,py,pz] += 1.
+ * d_bins: float32 [B, len_x, len_y, len_z], fully overwritten (the reference
+ * returns a fresh zero-initialised tensor, hist_cuda.cu:59).  Bit-exact with the
+ * reference's integer-valued float counters; `mini_batch` of the reference only
+ * chunks launches (hist_cuda.cu:61-85) and has no equivalent here.
+ * ------------------------------------------------------------------------- */
+int icpflow_hist_vote(const float *d_X, const float *d_Y, int B, int NX, int NY,
+                      float min_x, float min_y, float min_z,
+                      float max_x, float max_y, float max_z,
+                      int len_x, int len_y, int len_z,
+                      float *d_bins, icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-2  3-D non-maximum suppression + top-k peaks.
+ * Replaces: topk_nms -- utils_hist.py:21-29 (max_pool3d(kernel, stride 1,
+ * pad (kernel-1)/2) == x, then topk over the flattened surviving votes).
+ * d_votes float32 [B,k], d_idx int64 [B,k] (flat index into [Lx,Ly,Lz]).
+ * Order: vote descending, ties by ascending flat index (torch.topk's order among
+ * equal votes is implementation-defined; this rule is deterministic).
+ * d_ws: at least 2 * B*Lx*Ly*Lz * 4 bytes of scratch.
+ * ------------------------------------------------------------------------- */
+int icpflow_hist_peaks(const float *d_bins, int B, int len_x, int len_y, int len_z,
+                       int k, int kernel_size, float *d_votes, int64_t *d_idx,
+                       void *d_ws, size_t ws_bytes, icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-4  brute-force K=1 nearest neighbour, both clouds scanned in full.
+ * Replaces: nearest_neighbor_batch -- utils_helper.py:20-30, i.e.
+ * pytorch3d.ops.knn_points(src[:,:,0:3], dst[:,:,0:3], K=1) followed by sqrt.
+ * d_Q float32 [B,NQ,q_stride], d_T float32 [B,NT,t_stride] (strides in floats,
+ * >= 3; the first three columns are x,y,z).  d_len_q / d_len_t: optional int32
+ * [B] valid prefixes (pytorch3d `lengths1/2`, utils_icp_pytorch3d.py:154-156);
+ * NULL = all NQ / NT rows, pads included, exactly like the reference's
+ * un-lengthed call.  Rows >= len_q get idx 0 / dist 0 (pytorch3d convention).
+ * d_idx int64 [B,NQ]; d_dist float32 [B,NQ]: Euclidean distance if
+ * sqrt_dist != 0, squared distance otherwise.  First minimum wins ties.
+ * ------------------------------------------------------------------------- */
+int icpflow_nn_batch(const float *d_Q, const float *d_T, int B, int NQ, int NT,
+                     int q_stride, int t_stride, const int32_t *d_len_q,
+                     const int32_t *d_len_t, int sqrt_dist, int64_t *d_idx,
+                     float *d_dist, icpflow_stream_t stream);
+
+/* a-10  transform_points_batch -- utils_helper.py:76-87:
+ * out[b,i,0:3] = [x y z 1] * pose[b]^T, flag column copied.  In-place allowed. */
+int icpflow_transform_points(const float *d_xyz, const float *d_pose, int B, int N,
+                             float *d_out, icpflow_stream_t stream);
+
+/* Number of valid points per pair: d_len[b] = count(flag > 0) (int32 [B]). */
+int icpflow_count_valid(const float *d_pts, int B, int N, int32_t *d_len,
+                        icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-3  initial pose from the translation histogram.
+ * Replaces: estimate_init_pose / estimate_init_pose_batch -- utils_hist.py:33-124
+ * (vote with X=dst, Y=src; NMS + top-5; decode to left bin edges; append the zero
+ * translation; score the 6 candidates by min(mean fwd NN dist, mean bwd NN dist)
+ * over valid points; first arg-min).  `chunk_size` of the reference only bounds
+ * memory and does not change results, so it has no equivalent.
+ * d_edges_{x,y,z}: float32 left bin edges exactly as the reference builds them
+ * (torch.arange, utils_hist.py:63-65); vote box = [edges[0], edges[L-1]) with L bins
+ * (the reference passes bins.min()/bins.max()/len(bins), utils_hist.py:69-72).
+ * decode_shift = thres_dist // 2 (utils_hist.py:78; 0.0 for thres_dist 0.1).
+ * d_T_out float32 [B,4,4]: identity with the winning translation in column 3.
+ * ------------------------------------------------------------------------- */
+int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, int N,
+                               const float *d_edges_x, int len_x,
+                               const float *d_edges_y, int len_y,
+                               const float *d_edges_z, int len_z,
+                               float decode_shift, float *d_T_out,
+                               void *d_ws, size_t ws_bytes, icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-5..a-7  masked batched point-to-point ICP.
+ * Replaces: iterative_closest_point -- utils_icp_pytorch3d.py:37-225 with
+ * corresponding_points_alignment (:233-382) and _apply_similarity_transform
+ * (:385-396), estimate_scale=False, allow_reflection=False.
+ * Per iteration: NN of the current X in Y (valid prefixes), gate d^2 <= thres^2,
+ * Kabsch on the gated pairs FROM THE ORIGINAL X (absolute, not incremental),
+ * rmse, relative-rmse stop (see ICPFLOW_STOP_*).  Row-vector convention
+ * y = x R + T as in the reference.
+ * d_pre_pose: optional float32 [B,4,4]; when non-NULL the ICP input is
+ * transform_points_batch(X, pre_pose) (utils_icp.py:21) computed on the fly.
+ * Thresholds are passed as the reference's Python doubles and narrowed exactly where
+ * torch narrows them: the gate compares the fp32 squared distance with
+ * (float)(thres*thres) (= 0x3C23D70A for 0.1; squaring the fp32 value 0.1f instead would
+ * give the next float up), the stop compares with (float)relative_rmse_thr.
+ * Outputs (any may be NULL): d_R [B,3,3], d_T [B,3], d_rmse [B],
+ * d_iters int32 [1] (loop bodies executed; per-pair mode: max over pairs),
+ * d_converged int32 [1].
+ * ------------------------------------------------------------------------- */
+int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int B, int N,
+                double thres, int max_iterations, double relative_rmse_thr, int stop_mode,
+                float *d_R, float *d_T, float *d_rmse, int32_t *d_iters,
+                int32_t *d_converged, void *d_ws, size_t ws_bytes,
+                icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-8, a-9  ICP from an initial pose with roll-back.
+ * Replaces: apply_icp + pytorch3d_icp -- utils_icp.py:20-73 (pre-transform src,
+ * ICP with max_iterations / relative_rmse_thr (reference: 100 / 1e-6), 4x4 =
+ * [[R^T, T],[0,0,0,1]] * init, mean NN error of valid src before / after, and
+ * `Rts[error_icp >= error_init] = init`).
+ * d_T_out float32 [B,4,4]; may alias d_init.
+ * ------------------------------------------------------------------------- */
+int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_init,
+                      int B, int N, double thres_dist, int max_iterations,
+                      double relative_rmse_thr, int stop_mode, float *d_T_out,
+                      int32_t *d_iters, void *d_ws, size_t ws_bytes,
+                      icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-11  one full registration per cluster pair.
+ * Replaces: hist_icp -- utils_match.py:138-157 (register the cloud with fewer
+ * valid points onto the other (strict >, ties not swapped), a-3 then a-9, and
+ * invert the 4x4 of swapped pairs).  The swap is done by pointer selection, the
+ * inputs are never copied.  The inverse is the analytic rigid inverse (the
+ * reference's general torch.linalg.inv leaves ~1e-8 noise in the bottom row).
+ * d_T_out float32 [B,4,4] maps the ORIGINAL src onto dst.
+ * ------------------------------------------------------------------------- */
+int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N,
+                     const float *d_edges_x, int len_x,
+                     const float *d_edges_y, int len_y,
+                     const float *d_edges_z, int len_z,
+                     float decode_shift, double thres_dist, int max_iterations,
+                     double relative_rmse_thr, int stop_mode, float *d_T_out,
+                     int32_t *d_iters, void *d_ws, size_t ws_bytes,
+                     icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-12  registration quality metrics.
+ * Replaces: match_eval -- utils_match.py:159-213.  All outputs float32:
+ * d_errors, d_inliers, d_ratios, d_ious [B,2] (src direction, dst direction);
+ * d_translations [B,3]; d_rotations [B,3] (Euler ZYX, degrees).
+ * ------------------------------------------------------------------------- */
+int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_T,
+                       int B, int N, double thres_dist, float *d_errors,
+                       float *d_inliers, float *d_ratios, float *d_ious,
+                       float *d_translations, float *d_rotations, void *d_ws,
+                       size_t ws_bytes, icpflow_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICPFLOW_HIP_H */

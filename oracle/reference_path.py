@@ -174,9 +174,17 @@ def estimate_init_pose(args, src, dst):
 # --------------------------------------------------------------------------
 # ICP, utils_icp_pytorch3d.py
 # --------------------------------------------------------------------------
-def corresponding_points_alignment(X, Y, weights, eps=1e-9):
+def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None):
     """utils_icp_pytorch3d.py:303-382 (estimate_scale=False, allow_reflection=False).
-    X, Y [B,N,3] already mask-multiplied, weights bool [B,N].  y = x R + T."""
+    X, Y [B,N,3] already mask-multiplied, weights bool [B,N].  y = x R + T.
+
+    dtype=torch.float64 is NOT the reference: it evaluates the same formulas on the same
+    fp32 inputs in double (centroids, covariance, SVD) and rounds R, T to fp32 at the end.
+    Tests use it to separate "the kernel implements this algorithm" (tight tolerance against
+    the fp64 evaluation) from "how far the reference's own fp32 reductions are from it"."""
+    out_dtype = X.dtype
+    if dtype is not None:
+        X, Y = X.to(dtype), Y.to(dtype)
     b = X.shape[0]
     mu_x = wmean(X, weights, eps)                                             # :314
     mu_y = wmean(Y, weights, eps)                                             # :315
@@ -190,14 +198,15 @@ def corresponding_points_alignment(X, Y, weights, eps=1e-9):
     E[:, -1, -1] = torch.det(torch.bmm(U, V.transpose(2, 1)))                 # :358-359
     R = torch.bmm(torch.bmm(U, E), V.transpose(2, 1))                         # :362
     T = mu_y[:, 0, :] - torch.bmm(mu_x, R)[:, 0, :]                           # :376
-    return R, T
+    return R.to(out_dtype), T.to(out_dtype)
 
 
 def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
-                            relative_rmse_thr=ICP_REL_RMSE, trace=False):
+                            relative_rmse_thr=ICP_REL_RMSE, trace=False, kabsch_dtype=None):
     """utils_icp_pytorch3d.py:100-225.  Returns a namespace with
     converged, rmse, Xt, R, T, iterations (number of loop bodies executed) and,
-    with trace=True, the per-iteration (R, T, rmse) history."""
+    with trace=True, the per-iteration (R, T, rmse, inlier count) history.
+    kabsch_dtype: see corresponding_points_alignment (None = the reference's fp32)."""
     X0 = X[:, :, 0:3].clone()                                                 # :100,115
     Yt = Y[:, :, 0:3]
     b = X0.shape[0]
@@ -216,10 +225,13 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
     for it in range(max_iterations):                                          # :153
         d2, _, nn = knn_points(Xt, Yt, n_x, n_y, return_nn=True)              # :154-157
         w = torch.logical_and(m0, d2 <= thr2)                                 # :160-161
-        R, T = corresponding_points_alignment(X0 * w[:, :, None], nn * w[:, :, None], w)
+        R, T = corresponding_points_alignment(X0 * w[:, :, None], nn * w[:, :, None], w,
+                                              dtype=kabsch_dtype)
         Xt = torch.bmm(X0, R) + T[:, None, :]                                 # :177,395
         sq = ((Xt - nn) ** 2).sum(2)                                          # :191
-        rmse = wmean(sq[:, :, None], w).sqrt()[:, 0, 0]                       # :192
+        if kabsch_dtype is not None:
+            sq = sq.to(kabsch_dtype)
+        rmse = wmean(sq[:, :, None], w).sqrt()[:, 0, 0].to(X0.dtype)          # :192
         rel = rmse.new_ones(b) if prev is None else (prev - rmse) / prev      # :195-198
         if trace:
             history.append((R.clone(), T.clone(), rmse.clone(), w.sum(-1).clone()))

@@ -1,0 +1,375 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+Tolerances (BASELINE.json north_star): histogram bins / indices bit-exact; transforms and
+per-point motion within 1e-4 m of the reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import dense_from_sparse, load_golden
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from icp_flow_amd import synthetic  # noqa: E402
+from icp_flow_amd import hist as hip_hist  # noqa: E402
+from icp_flow_amd import utils_helper, utils_hist, utils_icp, utils_icp_pytorch3d, utils_match  # noqa: E402
+from oracle import reference_path as rp  # noqa: E402
+
+DEV = torch.device("cuda:0")
+TOL_M = 1e-4      # metres, on translations and moved points
+
+
+def G(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def C(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def moved(T, pts):
+    """apply [B,4,4] to [B,N,3] in float64"""
+    T = np.asarray(T, np.float64)
+    return np.einsum("bij,bnj->bni", T[:, :3, :3], np.asarray(pts, np.float64)) + T[:, None, :3, 3]
+
+
+def assert_pose_close(got, want, clouds, mask=None, tol=TOL_M):
+    """Transforms agree when they move every valid point of the cluster to within tol."""
+    got, want = np.asarray(got), np.asarray(want)
+    valid = clouds[:, :, 3] > 0
+    diff = np.abs(moved(got, clouds[:, :, :3]) - moved(want, clouds[:, :, :3])).max(-1)
+    diff = np.where(valid, diff, 0.0).max(1)
+    if mask is not None:
+        diff = diff[mask]
+    assert diff.max() <= tol, f"max point displacement between poses {diff.max():.3e} m (per pair {diff})"
+
+
+def assert_sqrt_close(got, want):
+    """Euclidean distances: the squared distances are bit-identical (checked separately via
+    knn_points_lengths); the device sqrt is correctly rounded (as CUDA's sqrtf is), while
+    torch-CPU's vectorised sqrt -- used by the oracle and the golden vectors -- is off by
+    one ulp on ~1 % of inputs.  Hence: at most 1 ulp."""
+    np.testing.assert_array_max_ulp(np.asarray(got, np.float32), np.asarray(want, np.float32), maxulp=1)
+
+
+# ------------------------------------------------------------------ a-1 vote
+def test_hist_known_answer_bit_exact():
+    g = load_golden("g1_hist_testpy")
+    h = hip_hist.hist(G(g["X"]), G(g["Y"]), *[float(v) for v in g["mins"]], *[float(v) for v in g["maxs"]],
+                      *[int(v) for v in g["lens"]])
+    want = dense_from_sparse(g["bins_shape"], g["bins_nz"], g["bins_val"])
+    assert np.array_equal(h.cpu().numpy(), want)
+    assert [int(x.argmax()) for x in h] == [111987] * 3          # (50,130,7): X-Y = (-5, 3, 0.2)
+
+
+@pytest.mark.parametrize("tag", ["tf2p0", "tf3p34"])
+def test_hist_reference_style_bit_exact(tag):
+    g = load_golden("g1_hist_ref_" + tag)
+    a = rp.default_args(translation_frame=float(g["translation_frame"]))
+    ex, ey, ez = utils_hist.bin_edges(a)
+    assert np.array_equal(ex.numpy(), g["edges_x"])
+    h = hip_hist.hist(G(g["dst"]), G(g["src"]), ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(),
+                      len(ex), len(ey), len(ez))
+    want = dense_from_sparse(g["bins_shape"], g["bins_nz"], g["bins_val"])
+    assert np.array_equal(h.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("tf,N", [(2.0, 1024), (6.68, 300), (13.36, 700)])
+def test_hist_vs_oracle_random_flags_and_big_histograms(tf, N):
+    """LDS-private path (41x41x3) and the global-atomic path (135 / 269 bins per side);
+    random (non-prefix) flags like the reference's own test script."""
+    S, D, _ = synthetic.make_batch(5, N, seed=101, ragged=True)
+    rng = np.random.default_rng(5)
+    S[1, :, 3] = rng.integers(0, 2, N)          # interleaved flags
+    D[1, :, 3] = rng.integers(0, 2, N)
+    a = rp.default_args(translation_frame=tf)
+    ex, ey, ez = rp.bin_edges(a)
+    args = (ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), len(ex), len(ey), len(ez))
+    want = rp.hist(C(D), C(S), *args)
+    got = hip_hist.hist(G(D), G(S), *args)
+    assert np.array_equal(got.cpu().numpy(), want.numpy())
+    assert want.sum() > 0
+
+
+def test_hist_argument_errors_like_the_reference():
+    x = torch.zeros(2, 8, 4, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip_hist.hist(x[:, :, :3], x, -1, -1, -1, 1, 1, 1, 3, 3, 3)          # dim != 4
+    with pytest.raises(RuntimeError):
+        hip_hist.hist(x, x[:1], -1, -1, -1, 1, 1, 1, 3, 3, 3)                # batch mismatch
+    with pytest.raises(RuntimeError):
+        hip_hist.hist(x.cpu(), x.cpu(), -1, -1, -1, 1, 1, 1, 3, 3, 3)        # "Not implemented on the CPU"
+    with pytest.raises(RuntimeError):
+        hip_hist.hist(x.transpose(0, 1), x.transpose(0, 1), -1, -1, -1, 1, 1, 1, 3, 3, 3)   # contiguity
+
+
+# ------------------------------------------------------------------ a-2 peaks
+@pytest.mark.parametrize("tag", ["tf2p0", "tf3p34"])
+def test_topk_nms_exact_vs_oracle(tag):
+    g = load_golden("g1_hist_ref_" + tag)
+    bins = dense_from_sparse(g["bins_shape"], g["bins_nz"], g["bins_val"])
+    v, i = utils_hist.topk_nms(G(bins))
+    wv, wi = rp.topk_nms(C(bins))
+    assert np.array_equal(v.cpu().numpy(), wv.numpy())
+    assert np.array_equal(i.cpu().numpy(), wi.numpy())
+    assert np.array_equal(v.cpu().numpy(), g["peak_votes"])      # reference's vote values
+
+
+def test_topk_nms_generic_shape_and_kernel():
+    rng = np.random.default_rng(3)
+    bins = rng.integers(0, 40, size=(3, 23, 17, 11)).astype(np.float32)   # deep z: window smaller than Lz
+    for ks in (11, 5, 3):
+        v, i = utils_hist.topk_nms(G(bins), k=5, kernel_size=ks)
+        wv, wi = rp.topk_nms(C(bins), k=5, kernel_size=ks)
+        assert np.array_equal(v.cpu().numpy(), wv.numpy())
+        assert np.array_equal(i.cpu().numpy(), wi.numpy())
+
+
+# ------------------------------------------------------------------ a-4 NN
+def test_nearest_neighbor_batch_golden_exact():
+    g = load_golden("g3_nn")
+    for a, b, tag in ((g["src"], g["dst"], "fwd"), (g["dst"], g["src"], "bwd")):
+        idx, dist = utils_helper.nearest_neighbor_batch(G(a), G(b))
+        assert np.array_equal(idx.cpu().numpy(), g["idx_" + tag])
+        assert_sqrt_close(dist.cpu().numpy(), g["dist_" + tag])
+
+
+@pytest.mark.parametrize("N,M", [(37, 700), (1500, 900), (2500, 2048)])
+def test_nearest_neighbor_batch_vs_oracle_shapes(N, M):
+    """ragged sizes, more than one LDS tile, Q=1/2/4 variants, xyz-only (stride 3) input"""
+    rng = np.random.default_rng(N + M)
+    q = rng.normal(size=(3, N, 4)).astype(np.float32) * 5
+    t = rng.normal(size=(3, M, 4)).astype(np.float32) * 5
+    t[0, 5] = t[0, 3]                                   # exact duplicate target: first index wins
+    q[0, 0, :3] = t[0, 3, :3]
+    idx, dist = utils_helper.nearest_neighbor_batch(G(q), G(t))
+    widx, wdist = rp.nearest_neighbor_batch(C(q), C(t))
+    assert np.array_equal(idx.cpu().numpy(), widx.numpy())
+    assert_sqrt_close(dist.cpu().numpy(), wdist.numpy())
+    assert int(idx[0, 0]) == 3 and float(dist[0, 0]) == 0.0
+    idx3, dist3 = utils_helper.nearest_neighbor_batch(G(q[:, :, :3].copy()), G(t[:, :, :3].copy()))
+    assert torch.equal(idx3, idx) and torch.equal(dist3, dist)
+
+
+def test_knn_with_lengths_matches_pytorch3d_convention():
+    S, D, _ = synthetic.make_batch(4, 300, seed=7, ragged=True)
+    ls = torch.from_numpy((S[:, :, 3] > 0).sum(1))
+    ld = torch.from_numpy((D[:, :, 3] > 0).sum(1))
+    d2, idx = utils_helper.knn_points_lengths(G(S), G(D), ls.to(DEV), ld.to(DEV))
+    wd2, widx, _ = rp.knn_points(C(S)[:, :, :3], C(D)[:, :, :3], ls, ld)
+    assert np.array_equal(idx.cpu().numpy(), widx.numpy())
+    assert np.array_equal(d2.cpu().numpy(), wd2.numpy())
+    for b in range(4):                                   # rows >= length: idx 0, dist 0
+        assert (idx[b, int(ls[b]):] == 0).all() and (d2[b, int(ls[b]):] == 0).all()
+
+
+def test_transform_points_batch():
+    S, _, Tt = synthetic.make_batch(3, 200, seed=9, ragged=True)
+    got = utils_helper.transform_points_batch(G(S), G(Tt)).cpu()
+    want = rp.transform_points_batch(C(S), C(Tt))
+    v = S[:, :, 3] > 0
+    np.testing.assert_allclose(got.numpy()[v], want.numpy()[v], atol=2e-5, rtol=0)
+    assert np.array_equal(got.numpy()[:, :, 3], S[:, :, 3])
+
+
+# ------------------------------------------------------------------ a-3 initial pose
+def test_estimate_init_pose_vs_oracle_and_golden():
+    g = load_golden("g4_init_pose")
+    a = rp.default_args(translation_frame=float(g["translation_frame"]))
+    got = utils_hist.estimate_init_pose(a, G(g["src"]), G(g["dst"])).cpu().numpy()
+    want = rp.estimate_init_pose(a, C(g["src"]), C(g["dst"])).numpy()
+    assert np.array_equal(got, want)                      # same deterministic tie rule: exact
+    same_ref = np.abs(got - g["T_init"]).reshape(len(got), -1).max(1) == 0
+    assert (same_ref | g["cut_tied"]).all() and same_ref.mean() >= 0.75
+
+
+# ------------------------------------------------------------------ a-5 ICP
+# Tolerances for the ICP family.  The reference (and therefore the oracle and the golden
+# vectors) reduces centroids / covariance in fp32 and calls an fp32 SVD; evaluating the SAME
+# formulas in fp64 moves its rotation entries by up to ~5e-6 for clusters of a few thousand
+# points (measured: test below), i.e. the reference carries that much rounding noise itself.
+# The kernels accumulate in fp64, so they are compared (a) tightly against the fp64
+# evaluation of the oracle and (b) against the fp32 reference within its own noise; the
+# quantity the north star bounds -- where the cluster's points end up -- must agree to 1e-4 m.
+TOL_R_REF = 1e-5     # rotation entries vs the fp32 reference / golden
+TOL_R_HP = 5e-7      # rotation entries vs the fp64 evaluation of the oracle
+TOL_M_HP = 1e-5      # moved points vs the fp64 evaluation (fp32 coordinates at ~50 m: ulp 4e-6)
+
+
+@pytest.mark.parametrize("case", list("abcde"))
+def test_icp_vs_golden(case):
+    g = load_golden("g5_icp")
+    X, Y = g[case + "_src"], g[case + "_dst"]
+    sol = utils_icp_pytorch3d.iterative_closest_point(G(X), G(Y), thres=0.1, max_iterations=100,
+                                                      relative_rmse_thr=1e-6)
+    R, T = sol.RTs.R.cpu().numpy(), sol.RTs.T.cpu().numpy()
+    assert sol.converged.iterations == int(g[case + "_iterations"])
+    assert bool(sol.converged) == bool(g[case + "_converged"])
+    # < 3 gated correspondences => rank-deficient covariance, rotation backend-dependent
+    ok = g[case + "_min_inliers"] >= 3
+    if case == "d":      # zero-inlier pair: exact identity, and the batch never "converges"
+        assert np.array_equal(R[1], np.eye(3, dtype=np.float32)) and np.array_equal(T[1], np.zeros(3, np.float32))
+        assert sol.converged.iterations == 100
+        ok[1] = True
+    assert ok.sum() >= len(ok) - 1
+    np.testing.assert_allclose(R[ok], g[case + "_R"][ok], atol=TOL_R_REF, rtol=0)
+    np.testing.assert_allclose(sol.rmse.cpu().numpy()[ok], g[case + "_rmse"][ok], atol=2e-6, rtol=0)
+    # y = x R + T on the valid points, against the reference's transformed cloud
+    v = (X[:, :, 3] > 0) & ok[:, None]
+    np.testing.assert_allclose(sol.Xt.cpu().numpy()[v], g[case + "_Xt"][v], atol=TOL_M, rtol=0)
+    assert np.isfinite(R).all() and np.isfinite(T).all()
+    np.testing.assert_allclose(np.linalg.det(R.astype(np.float64)), 1.0, atol=1e-5)   # proper rotations
+
+
+@pytest.mark.parametrize("case", list("bce"))
+def test_icp_vs_fp64_evaluation_of_the_oracle(case):
+    g = load_golden("g5_icp")
+    X, Y = g[case + "_src"], g[case + "_dst"]
+    want = rp.iterative_closest_point(C(X), C(Y), kabsch_dtype=torch.float64)
+    got = utils_icp_pytorch3d.iterative_closest_point(G(X), G(Y))
+    ok = g[case + "_min_inliers"] >= 3
+    assert got.converged.iterations == want.iterations
+    np.testing.assert_allclose(got.RTs.R.cpu().numpy()[ok], want.R.numpy()[ok], atol=TOL_R_HP, rtol=0)
+    v = (X[:, :, 3] > 0) & ok[:, None]
+    np.testing.assert_allclose(got.Xt.cpu().numpy()[v], want.Xt.numpy()[v], atol=TOL_M_HP, rtol=0)
+
+
+def test_icp_per_pair_stop_stays_within_tolerance():
+    """Per-pair stopping is NOT the reference's rule: each pair leaves the loop at
+    its own convergence instead of iterating until the whole batch satisfies the test.  On
+    pairs that really converge the end state must still agree to the 1e-4 m tolerance."""
+    g = load_golden("g5_icp")
+    X, Y = g["c_src"], g["c_dst"]
+    fast = utils_icp_pytorch3d.iterative_closest_point(G(X), G(Y), stop_mode="per_pair")
+    v = X[:, :, 3] > 0
+    np.testing.assert_allclose(fast.Xt.cpu().numpy()[v], g["c_Xt"][v], atol=TOL_M, rtol=0)
+    assert fast.converged.iterations <= int(g["c_iterations"]) and bool(fast.converged)
+
+
+def test_icp_multi_group_path_vs_oracle():
+    """n_src > 2048 exercises the several-query-groups (scratch) path of the ICP kernel."""
+    S, D, Tt = synthetic.make_batch(2, 2600, seed=77)
+    src, dst = C(S), C(D)
+    for i in range(2):                       # pre-align so that ICP has inliers
+        Ti = C(Tt[i])
+        src[i, :, 0:3] = src[i, :, 0:3] @ Ti[:3, :3].T + Ti[:3, 3] + torch.tensor([0.03, -0.02, 0.01])
+    ref = rp.iterative_closest_point(src, dst)
+    hp = rp.iterative_closest_point(src, dst, kabsch_dtype=torch.float64)
+    got = utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV))
+    assert got.converged.iterations == ref.iterations == hp.iterations
+    R = got.RTs.R.cpu().numpy()
+    np.testing.assert_allclose(R, hp.R.numpy(), atol=TOL_R_HP, rtol=0)
+    np.testing.assert_allclose(got.Xt.cpu().numpy(), hp.Xt.numpy(), atol=TOL_M_HP, rtol=0)
+    # the fp32 reference sits further from its own fp64 evaluation than the kernel does
+    assert np.abs(R - hp.R.numpy()).max() <= np.abs(ref.R.numpy() - hp.R.numpy()).max()
+    np.testing.assert_allclose(R, ref.R.numpy(), atol=TOL_R_REF, rtol=0)
+    np.testing.assert_allclose(got.Xt.cpu().numpy(), ref.Xt.numpy(), atol=TOL_M, rtol=0)
+
+
+# ------------------------------------------------------------------ a-9 / a-11 / a-12
+def test_apply_icp_from_reference_init_poses():
+    g = load_golden("g6_hist_icp")
+    a = rp.default_args(translation_frame=float(g["translation_frame"]))
+    got, iters = utils_icp.apply_icp(a, G(g["src"]), G(g["dst"]), G(g["T_init_noswap"]), return_iterations=True)
+    assert int(iters) == int(g["icp_iterations_noswap"])
+    assert_pose_close(got.cpu().numpy(), g["T_apply_icp_noswap"], g["src"])
+    rb = g["rolled_back_noswap"]                 # rolled-back pairs return the init pose exactly
+    assert np.array_equal(got.cpu().numpy()[rb], g["T_init_noswap"][rb])
+
+
+def test_rollback_on_identical_clouds():
+    g = load_golden("g6_rollback")
+    a = rp.default_args(translation_frame=float(g["translation_frame"]))
+    got = utils_match.hist_icp(a, G(g["src"]), G(g["dst"])).cpu().numpy()
+    assert np.array_equal(got, g["T_hist_icp"])
+
+
+def test_hist_icp_ragged_vs_oracle_and_golden():
+    g = load_golden("g6_hist_icp")
+    a = rp.default_args(translation_frame=float(g["translation_frame"]))
+    got = utils_match.hist_icp(a, G(g["src"]), G(g["dst"])).cpu().numpy()
+    want = rp.hist_icp(a, C(g["src"]), C(g["dst"])).numpy()
+    assert_pose_close(got, want, g["src"])                            # vs oracle: every pair
+    ok = ~g["cut_tied"]
+    assert ok.sum() >= 6
+    assert_pose_close(got, g["T_hist_icp"], g["src"], mask=ok)        # vs reference: tie-free pairs
+    swapped = g["n_src"] > g["n_dst"]
+    assert (swapped & ok).any() and (~swapped & ok).any()
+    np.testing.assert_array_equal(got[:, 3], np.tile(np.array([0, 0, 0, 1], np.float32), (len(got), 1)))
+
+
+def test_hist_icp_dense_vs_golden_and_match_eval():
+    g = load_golden("g6_hist_icp_dense")
+    S, D, _ = synthetic.make_batch(int(g["num_pairs"]), int(g["max_points"]), seed=int(g["seed"]))
+    a = rp.default_args(max_points=int(g["max_points"]))
+    T = utils_match.hist_icp(a, G(S), G(D))
+    assert_pose_close(T.cpu().numpy(), g["T_hist_icp"], S)
+    ev = utils_match.match_eval(a, G(S), G(D), G(g["T_hist_icp"]))
+    for got, key, tol in zip(ev, ("errors", "inliers", "ratios", "ious", "translations", "rotations"),
+                             (1e-5, 0, 1e-6, 1e-6, 1e-4, 1e-4)):
+        np.testing.assert_allclose(got.cpu().numpy(), g["ev_" + key], atol=tol, rtol=1e-5)
+
+
+def test_match_eval_ragged_vs_golden():
+    g = load_golden("g6_hist_icp")
+    a = rp.default_args(translation_frame=float(g["translation_frame"]))
+    ev = utils_match.match_eval(a, G(g["src"]), G(g["dst"]), G(g["T_hist_icp"]))
+    for got, key, tol in zip(ev, ("errors", "inliers", "ratios", "ious", "translations", "rotations"),
+                             (1e-5, 0, 1e-6, 1e-6, 1e-4, 1e-4)):
+        np.testing.assert_allclose(got.cpu().numpy(), g["ev_" + key], atol=tol, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE config 2)
+@pytest.fixture(scope="module")
+def config2():
+    S, D, Tt = synthetic.make_batch(256, 1024, seed=0)
+    return S, D, Tt
+
+
+def test_full_size_hist_vote_count_property(config2):
+    """sum(bins[b]) == number of (i,j) whose difference falls inside the box, counted with
+    plain torch ops on the device (same fp32 subtract / compare)."""
+    S, D, _ = config2
+    a = rp.default_args()
+    ex, ey, ez = utils_hist.bin_edges(a)
+    s, d = G(S[:32]), G(D[:32])
+    h = hip_hist.hist(d, s, ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), len(ex), len(ey), len(ez))
+    v = d[:, :, None, 0:3] - s[:, None, :, 0:3]
+    lo = torch.tensor([float(ex.min()), float(ey.min()), float(ez.min())], device=DEV)
+    hi = torch.tensor([float(ex.max()), float(ey.max()), float(ez.max())], device=DEV)
+    inside = ((v >= lo) & (v < hi)).all(-1).sum((1, 2))
+    assert torch.equal(h.sum((1, 2, 3)).long(), inside)
+
+
+def test_full_size_nn_self_match_and_gather_property(config2):
+    S, D, _ = config2
+    s, d = G(S[:64]), G(D[:64])
+    idx, dist = utils_helper.nearest_neighbor_batch(s, s)               # idempotence: own index, 0 m
+    assert torch.equal(idx, torch.arange(1024, device=DEV)[None].expand(64, -1)) and float(dist.max()) == 0.0
+    idx, dist = utils_helper.nearest_neighbor_batch(s, d)
+    nn = torch.gather(d[:, :, 0:3], 1, idx[:, :, None].expand(-1, -1, 3))
+    re = (s[:, :, 0:3] - nn).pow(2).sum(-1).sqrt()
+    assert torch.allclose(re, dist, atol=1e-6)
+    probe = d[:, torch.randint(0, 1024, (64,), device=DEV), 0:3]         # no probe target is closer
+    other = (s[:, :, None, 0:3] - probe[:, None]).pow(2).sum(-1).sqrt().min(-1)[0]
+    assert bool((dist <= other + 1e-6).all())
+
+
+def test_full_size_registration_recovers_motion(config2):
+    S, D, Tt = config2
+    a = rp.default_args(max_points=1024, icp_max_iterations=50)
+    T, iters = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+    T = T.cpu().numpy()
+    assert 1 <= int(iters) <= 50
+    err = np.abs(moved(T, S[:, :, :3]) - moved(Tt, S[:, :, :3])).max((1, 2))
+    assert np.median(err[0::2]) < 0.005 and err[0::2].max() < 0.02      # shared-sample pairs
+    assert np.isfinite(T).all()
+    # oracle on a bounded sample of the same batch (first 4 pairs), same iteration cap
+    want = rp.hist_icp(a, C(S[:4]), C(D[:4]), max_iterations=50).numpy()
+    got = utils_match.hist_icp(a, G(S[:4]), G(D[:4])).cpu().numpy()
+    assert_pose_close(got, want, S[:4])

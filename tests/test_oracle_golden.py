@@ -113,16 +113,27 @@ def test_hist_icp_and_match_eval_ragged():
     same = _pairs_equal(Tm.numpy(), g["T_hist_icp"], 1e-5)
     assert (same | g["cut_tied"]).all() and same.mean() >= 0.75
     assert same[g["n_src"] > g["n_dst"]].any(), "a swapped (inverted) pair must be pinned"
-    assert bool(aux["rolled_back"][9]) and same[9], "identical clouds roll back to the init pose"
+    assert aux["iterations"] >= 2
     init = rp.estimate_init_pose(a, src, dst)
     same_i = _pairs_equal(init.numpy(), g["T_init_noswap"], 0.0)
     assert (same_i | g["cut_tied_noswap"]).all() and same_i.mean() >= 0.75
     # apply_icp from the REFERENCE's init poses: no tie dependence left
-    Ti = rp.apply_icp(a, src, dst, T(g["T_init_noswap"]).clone())
+    Ti, aux2 = rp.apply_icp(a, src, dst, T(g["T_init_noswap"]).clone(), return_aux=True)
     np.testing.assert_allclose(Ti.numpy(), g["T_apply_icp_noswap"], atol=1e-5)
+    assert aux2["iterations"] == int(g["icp_iterations_noswap"])
+    assert np.array_equal(aux2["rolled_back"].numpy(), g["rolled_back_noswap"])
     ev = rp.match_eval(a, src, dst, T(g["T_hist_icp"]))
     for got, key in zip(ev, ("errors", "inliers", "ratios", "ious", "translations", "rotations")):
         np.testing.assert_allclose(got.numpy(), g["ev_" + key], atol=1e-5, rtol=1e-5)
+
+
+def test_rollback_on_identical_clouds():
+    """e_icp >= e_init (utils_icp.py:34): identical clouds keep the histogram's pose."""
+    g = load_golden("g6_rollback")
+    a = rp.default_args(translation_frame=float(g["translation_frame"]))
+    Tm, aux = rp.hist_icp(a, T(g["src"]), T(g["dst"]), return_aux=True)
+    assert bool(aux["rolled_back"].all())
+    assert np.array_equal(Tm.numpy(), g["T_hist_icp"]) and np.array_equal(g["T_hist_icp"], g["T_init"])
 
 
 def test_hist_icp_dense_config2_shape():
