@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- cluster-pair ICP registrations / second on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full registration (`hist_icp`: translation-histogram vote, NMS + top-5,
+6-candidate scoring, <= 50 ICP iterations with the reference's batch-global stop, roll-back
+check) of every pair of one synthetic batch.  Workload = BASELINE config 2: 256 cluster pairs
+x 1024 points, 50 ICP iterations, thres_dist 0.1, translation_frame 2.0, inputs resident in
+HBM before the timed region.  With N > 1 every rank registers its own 256 pairs (weak
+scaling; pair k of rank r is synthetic pair r*256+k) and the [B,4,4] transforms are
+all-gathered over RCCL inside the timed region -- the path has no other exchange step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_LANE_OPS = 78.6e12    # 256 CU x 128 lanes x 2.4 GHz (157.3 TFLOP/s fp32 vector)
+SCAN_LANE_OPS_PER_EVAL = 6.5    # 3 sub + 1 mul + 2 fma + 1/2 min3 (scan.hpp)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=256, help="cluster pairs per GPU per step")
+    ap.add_argument("--points", type=int, default=1024, help="points per cluster (= padded length)")
+    ap.add_argument("--iters", type=int, default=50, help="ICP iteration cap (BASELINE: 50)")
+    ap.add_argument("--stop-mode", default="reference", choices=["reference", "per_pair"])
+    ap.add_argument("--cpu-pairs", type=int, default=64, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from icp_flow_amd import _lib, synthetic, utils_match
+    from icp_flow_amd.sharding import gather_results, shard_range
+
+    B, N = a.pairs, a.points
+    first, count = shard_range(rank, world, B * world)          # contiguous block of B pairs
+    assert count == B
+    S, D, _ = synthetic.make_batch(B, N, seed=0, first=first)
+    src = torch.from_numpy(S).to(dev)
+    dst = torch.from_numpy(D).to(dev)
+    from types import SimpleNamespace
+    args = SimpleNamespace(thres_dist=0.1, translation_frame=2.0, chunk_size=50, max_points=N,
+                           icp_max_iterations=a.iters, icp_stop_mode=a.stop_mode)
+
+    def step():
+        T, iters = utils_match.hist_icp(args, src, dst, return_iterations=True)
+        if world > 1:
+            T = gather_results(T, world)                         # RCCL all_gather over xGMI
+        return T, iters
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    # ---- timed region: exactly K steps, HIP-event timing of the dominant kernel inside ------
+    _lib.profile_enable(a.steps * a.iters)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        T, iters = step()
+    sync()
+    dt = time.perf_counter() - t0
+    icp_ms, icp_launches = _lib.profile_collect()
+    _lib.profile_enable(0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    iters_done = int(iters.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    regs = B * world * a.steps
+    value = regs / dt
+    # ---- roofline of the dominant kernel (icp_kernel: one launch = one ICP iteration of all
+    # B pairs; launches after the batch-global stop return immediately and are included) ------
+    P = (N + N) * 16                                   # bytes of both clouds of one pair, SURVEY 8(d)
+    alg_bytes_per_iter = B * P                          # one iteration streams both clouds once
+    executed = iters_done * a.steps                     # iterations that did work (same every step)
+    avg_launch_ms = icp_ms / max(icp_launches, 1)
+    achieved_gbs = (alg_bytes_per_iter * executed) / (icp_ms * 1e-3) / 1e9 if icp_ms > 0 else 0.0
+    evals_per_s = (B * N * N * executed) / (icp_ms * 1e-3) if icp_ms > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(REPO, "profiles", "r01_icp_kernel_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": "icp_kernel<512,2>" if N > 512 and N <= 1024 else "icp_kernel",
+        "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "algorithmic_bytes_per_launch": alg_bytes_per_iter,
+        "avg_launch_ms": round(avg_launch_ms, 5), "launches_timed": icp_launches,
+        "icp_iterations_executed_per_step": iters_done,
+        "icp_share_of_step": round(icp_ms / (dt * 1e3), 4),
+        # the scan is FP32-VALU bound (arithmetic intensity ~256 lane-op/B), reported next to HBM:
+        "valu": {"pair_evals_per_s": round(evals_per_s, 1),
+                 "lane_ops_per_eval": SCAN_LANE_OPS_PER_EVAL,
+                 "achieved_lane_ops_per_s": round(evals_per_s * SCAN_LANE_OPS_PER_EVAL, 1),
+                 "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                 "frac": round(evals_per_s * SCAN_LANE_OPS_PER_EVAL / VALU_PEAK_LANE_OPS, 4)},
+    }
+
+    extras = {}
+    if not a.no_extras:
+        extras = extra_measurements(args, src, dst, T if world == 1 else T[:B], dev, a)
+
+    cpu = cpu_baseline(S, D, a) if (a.cpu_pairs > 0 and world == 1) else None
+
+    out = {
+        "metric": "cluster-pair ICP registrations/sec", "value": round(value, 2), "unit": "registrations/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE config 2: synthetic {B} cluster pairs x {N} pts per GPU, "
+                               f"<= {a.iters} ICP iters ({a.stop_mode} stop), thres_dist 0.1, "
+                               f"translation_frame 2.0 (41x41x3 bins)",
+                   "pairs_per_gpu": B, "points": N, "icp_iteration_cap": a.iters,
+                   "stop_mode": a.stop_mode, "sharding": f"pairs/{world} contiguous, all_gather of [B,4,4]"},
+        "ms_per_frame_pair_equivalent": round(dt / a.steps * 1e3, 4),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "extras": extras,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extra_measurements(args, src, dst, T, dev, a):
+    """Untimed-region extras (not part of `value`): match_eval, per-pair stop mode, ICP only."""
+    from types import SimpleNamespace
+    from icp_flow_amd import utils_icp, utils_match
+
+    def timeit(fn, reps=10):
+        fn()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / reps * 1e3
+
+    B = src.shape[0]
+    out = {"match_eval_ms_per_batch": round(timeit(lambda: utils_match.match_eval(args, src, dst, T)), 4)}
+    fast = SimpleNamespace(**{**vars(args), "icp_stop_mode": "per_pair"})
+    ms = timeit(lambda: utils_match.hist_icp(fast, src, dst))
+    out["per_pair_stop_registrations_per_s"] = round(B / ms * 1e3, 1)
+    init = torch.eye(4, device=dev)[None].repeat(B, 1, 1).contiguous()
+    ms = timeit(lambda: utils_icp.apply_icp(args, src, dst, init))
+    out["icp_only_apply_icp_registrations_per_s"] = round(B / ms * 1e3, 1)
+    return out
+
+
+def cpu_baseline(S, D, a):
+    """The oracle (CPU port of the reference's algorithm: padded [B,N,4] clouds, 1 vote + 12
+    scoring scans + I ICP iterations + 2 roll-back scans) on a bounded sample of the SAME batch,
+    all host cores (OpenMP over pairs inside oracle_core.c + torch-CPU threads)."""
+    from oracle import core as ocore
+    from oracle import reference_path as rp
+    # threads actually used: all host cores up to 32 (the sample is 64 pairs of ~1 MB each;
+    # on a 256-core box more threads only add fork/join overhead to the many small torch ops)
+    ncpu = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(ncpu)
+    ocore.set_num_threads(ncpu)
+    n = min(a.cpu_pairs, S.shape[0])
+    s, d = torch.from_numpy(S[:n]), torch.from_numpy(D[:n])
+    args = rp.default_args(max_points=S.shape[1])
+    rp.hist_icp(args, s[:2], d[:2], max_iterations=a.iters)              # warm-up (page-in, threads)
+    t = time.perf_counter()
+    _, aux = rp.hist_icp(args, s, d, max_iterations=a.iters, return_aux=True)
+    dt = time.perf_counter() - t
+    return {"value": round(n / dt, 3), "unit": "registrations/s", "cores": ncpu,
+            "host_cores_available": os.cpu_count(), "kind": "port",
+            "sample": f"first {n} of the {S.shape[0]} pairs of the same batch, same {a.iters}-iteration cap "
+                      f"(batch-global stop inside the sample after {aux['iterations']} iterations), "
+                      f"{dt:.2f} s wall",
+            "threads": ocore.num_threads()}
+
+
+if __name__ == "__main__":
+    main()

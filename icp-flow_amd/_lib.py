@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicpflow_hip.so")
+# ICPFLOW_HIP_LIB: developer override to load an instrumented build of the same ABI
+LIB_PATH = os.environ.get("ICPFLOW_HIP_LIB") or os.path.join(_HERE, "libicpflow_hip.so")
 
 STOP_REFERENCE = 0
 STOP_PER_PAIR = 1
@@ -43,6 +44,8 @@ SIGNATURES = {
     "icpflow_apply_icp": (_i, [_p, _p, _p, _i, _i, _d, _i, _d, _i, _p, _p, _p, _sz, _p]),
     "icpflow_hist_icp": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _sz, _p]),
     "icpflow_match_eval": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "icpflow_profile_enable": (_i, [_i]),
+    "icpflow_profile_collect": (_i, [ctypes.POINTER(_d), ctypes.POINTER(_i)]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_L, _name)          # AttributeError here = header/library mismatch
@@ -58,6 +61,17 @@ def call(name, *args):
     if rc != 0:
         msg = _L.icpflow_last_error()
         raise RuntimeError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def profile_enable(capacity):
+    call("icpflow_profile_enable", int(capacity))
+
+
+def profile_collect():
+    """-> (summed duration in ms, number of launches) of the ICP-iteration kernel."""
+    ms, n = _d(0.0), _i(0)
+    call("icpflow_profile_collect", ctypes.byref(ms), ctypes.byref(n))
+    return float(ms.value), int(n.value)
 
 
 def workspace_bytes(B, N, lens=(0, 0, 0)):

@@ -147,6 +147,19 @@ size_t icpflow_workspace_bytes(int B, int N, int Lx, int Ly, int Lz)
     return Workspace(nullptr, B, N, L).bytes;
 }
 
+int icpflow_profile_enable(int capacity)
+{
+    if (capacity < 0 || capacity > (1 << 20)) return fail(ICPFLOW_E_ARG, "icpflow_profile_enable: bad capacity %d", capacity);
+    ICPFLOW_TRY(profile_enable(capacity));
+    return 0;
+}
+
+int icpflow_profile_collect(double *total_ms, int *launches)
+{
+    ICPFLOW_TRY(profile_collect(total_ms, launches));
+    return 0;
+}
+
 int icpflow_hist_vote(const float *d_X, const float *d_Y, int B, int NX, int NY, float min_x,
                       float min_y, float min_z, float max_x, float max_y, float max_z, int len_x,
                       int len_y, int len_z, float *d_bins, icpflow_stream_t stream)

@@ -13,6 +13,8 @@
 // front; each pair that is not converged bumps ctrl->notconv[it]; the launch of iteration
 // it+1 returns immediately when notconv[it] == 0.  ICPFLOW_STOP_PER_PAIR loops inside one
 // launch and lets every pair stop on its own.
+#include <vector>
+
 #include "scan.hpp"
 #include "kernels.hpp"
 
@@ -142,9 +144,18 @@ struct IcpParams {
     int32_t *nnj;          // [B,N] scratch, used when a pair needs more than one query group
 };
 
+#ifdef ICPFLOW_PHASE_TIMING
+// debug builds only (tools/dbg/phase_timing.py): shader-clock stamps of workgroup 0
+__device__ long long g_phase_stamps[16];
+#define ICPFLOW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamps[k] = clock64(); } while (0)
+#else
+#define ICPFLOW_STAMP(k) do { } while (0)
+#endif
+
 template <int BLOCK, int Q>
 __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
+    ICPFLOW_STAMP(0);
     __shared__ ScanTile tileMem;
     ScanTile *tile = &tileMem;
     __shared__ double red[(BLOCK / kWave) * 9];
@@ -220,7 +231,9 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 }
             }
             ScanAcc<Q> acc;
+            ICPFLOW_STAMP(1);
             scan_cloud<Q>(yc, none, tile, qx, qy, qz, acc);  // :154-157
+            ICPFLOW_STAMP(2);
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 w[q] = live[q] && (acc.best[q] <= p.thr2);  // :160-161
@@ -239,7 +252,9 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 }
             }
         }
+        ICPFLOW_STAMP(3);
         block_sum<7, double>(s7, red);
+        ICPFLOW_STAMP(4);
         const double wsum = s7[0] > 1e-9 ? s7[0] : 1e-9;  // clamp(eps), :314-315, :326
         const double mux = s7[1] / wsum, muy = s7[2] / wsum, muz = s7[3] / wsum;
         const double nux = s7[4] / wsum, nuy = s7[5] / wsum, nuz = s7[6] / wsum;
@@ -275,11 +290,13 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             }
         }
         block_sum<9, double>(h9, red);
+        ICPFLOW_STAMP(5);
 #pragma unroll
         for (int k = 0; k < 9; ++k) h9[k] /= wsum;
         // every thread holds the same H: solve redundantly, no broadcast needed
         double Rd[9];
         kabsch_rotation(h9, Rd);
+        ICPFLOW_STAMP(6);
         // T = mu_y - mu_x R, :376
         const double Td0 = nux - (mux * Rd[0] + muy * Rd[3] + muz * Rd[6]);
         const double Td1 = nuy - (mux * Rd[1] + muy * Rd[4] + muz * Rd[7]);
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             }
         }
         block_sum<1, double>(e1, red);
+        ICPFLOW_STAMP(7);
         rmse = (float)sqrt(e1[0] / wsum);
         // relative rmse, :195-198 (fp32 like the reference's tensors)
         const float rel = (it == 0) ? 1.0f : (prev - rmse) / prev;
@@ -335,6 +353,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         }
         prev = rmse;  // :213
     }
+    ICPFLOW_STAMP(8);
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) st->R[k] = Rf[k];
@@ -379,12 +398,65 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
     hipLaunchKernelGGL((icp_kernel<BLOCK, Q>), dim3(B), dim3(BLOCK), 0, s, p, itBegin, itEnd);
 }
 
+// ---- optional per-launch timing of this (dominant) kernel with HIP events ---------------------
+// bench.py needs the average launch duration of the dominant kernel measured on the stream it
+// runs on; the events are recorded by the library because only it sees the individual launches.
+namespace {
+struct LaunchProfile {
+    std::vector<hipEvent_t> start, stop;
+    int used = 0;
+} g_prof;
+}  // namespace
+
+#ifdef ICPFLOW_PHASE_TIMING
+extern "C" int icpflow_debug_phase_stamps(long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_stamps), sizeof(long long) * 16);
+}
+#endif
+
+hipError_t profile_enable(int capacity)
+{
+    for (hipEvent_t e : g_prof.start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g_prof.stop) (void)hipEventDestroy(e);
+    g_prof.start.clear(); g_prof.stop.clear(); g_prof.used = 0;
+    for (int i = 0; i < capacity; ++i) {
+        hipEvent_t a, b;
+        hipError_t e = hipEventCreate(&a);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&b);
+        if (e != hipSuccess) return e;
+        g_prof.start.push_back(a); g_prof.stop.push_back(b);
+    }
+    return hipSuccess;
+}
+
+hipError_t profile_collect(double *total_ms, int *launches)
+{
+    double sum = 0.0;
+    for (int i = 0; i < g_prof.used; ++i) {
+        hipError_t e = hipEventSynchronize(g_prof.stop[i]);
+        if (e != hipSuccess) return e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]);
+        if (e != hipSuccess) return e;
+        sum += ms;
+    }
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = g_prof.used;
+    g_prof.used = 0;
+    return hipSuccess;
+}
+
 static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
+    const bool timed = g_prof.used < (int)g_prof.start.size();
+    if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
     if (p.N <= 256) launch_icp_variant<256, 1>(p, B, itBegin, itEnd, s);
     else if (p.N <= 512) launch_icp_variant<512, 1>(p, B, itBegin, itEnd, s);
     else if (p.N <= 1024) launch_icp_variant<512, 2>(p, B, itBegin, itEnd, s);
     else launch_icp_variant<512, 4>(p, B, itBegin, itEnd, s);
+    if (timed) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
 }
 
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,

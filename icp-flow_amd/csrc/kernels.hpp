@@ -67,6 +67,8 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
                       int32_t *nnj, hipStream_t s);
+hipError_t profile_enable(int capacity);
+hipError_t profile_collect(double *total_ms, int *launches);
 hipError_t launch_icp_export(const IcpState *state, const IcpCtrl *ctrl, int B, int stopMode, float *R,
                              float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s);
 

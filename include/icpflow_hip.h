@@ -4,7 +4,8 @@
  *
  * Every pointer named d_* is a DEVICE pointer owned by the caller (e.g. the
  * data_ptr() of a torch-ROCm tensor); the library never allocates or frees
- * caller memory and keeps no global state besides a thread-local error string.
+ * caller memory and keeps no global state besides a thread-local error string
+ * (and the optional launch-timing recorder at the end of this header).
  * Scratch comes from a caller-provided workspace (icpflow_workspace_bytes()).
  * All work is enqueued asynchronously on `stream` (a hipStream_t passed as
  * void*; NULL = the default stream); no entry point synchronises the device.
@@ -202,6 +203,17 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
                        float *d_inliers, float *d_ratios, float *d_ious,
                        float *d_translations, float *d_rotations, void *d_ws,
                        size_t ws_bytes, icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart): per-launch timing of the dominant kernel,
+ * the ICP iteration.  After icpflow_profile_enable(capacity) every launch of that kernel
+ * (up to `capacity` of them) is bracketed by HIP events recorded on the caller's stream;
+ * icpflow_profile_collect() waits for the recorded events, returns the summed duration in
+ * milliseconds and the number of launches, and re-arms the recorder.  capacity 0 disables
+ * and frees the events.  This recorder is process-global and not thread-safe.
+ * ------------------------------------------------------------------------- */
+int icpflow_profile_enable(int capacity);
+int icpflow_profile_collect(double *total_ms, int *launches);
 
 #ifdef __cplusplus
 }
