@@ -48,7 +48,6 @@ struct Workspace {
     float *Tinit = nullptr, *M = nullptr;
     IcpState *state = nullptr;
     IcpCtrl *ctrl = nullptr;
-    int32_t *nnj = nullptr;
     size_t bytes = 0;
 
     Workspace(void *base, int B, int N, size_t L)
@@ -74,7 +73,6 @@ struct Workspace {
         M = (float *)take(b * 16 * 4);
         state = (IcpState *)take(b * sizeof(IcpState));
         ctrl = (IcpCtrl *)take(sizeof(IcpCtrl));
-        nnj = (int32_t *)take(b * (size_t)N * 4);
         bytes = off;
     }
 };
@@ -108,7 +106,7 @@ int run_icp_and_select(const float *src, const float *dst, const Workspace &w, c
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, hipStream_t s)
 {
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, w.nnj, s));
+                           w.state, w.ctrl, s));
     if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
     ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
@@ -270,7 +268,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     launch_count_valid(d_X, B, N, w.lenA, s);
     launch_count_valid(d_Y, B, N, w.lenC, s);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
-                           relative_rmse_thr, stop_mode, w.state, w.ctrl, w.nnj, s));
+                           relative_rmse_thr, stop_mode, w.state, w.ctrl, s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
     return 0;
 }

@@ -86,6 +86,31 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
+// fp64 wave sum on the VALU only (DPP row shifts + row broadcasts, no LDS traffic): after
+// the six steps lane 63 holds the total, which is returned wave-uniform via readlane.
+// dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143 (GFX9 encodings).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(h2, l2);
+}
+
+__device__ __forceinline__ double wave_sum_uniform(double v)
+{
+    v = dpp_add_f64<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add_f64<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add_f64<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add_f64<0x118, 0xf>(v);  // row_shr:8  -> inclusive scan inside each row of 16
+    v = dpp_add_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
 #pragma unroll

@@ -5,8 +5,8 @@
 // NN scan of the moved source against the LDS-staged target (scan.hpp), inlier gate,
 // weighted centroids, centred 3x3 covariance, closed-form rotation, rmse -- so the 15-odd
 // torch kernels, the cuSOLVER call and the host sync of one reference iteration collapse
-// into one launch with three block reductions.  All sums and the 3x3 solve are fp64
-// (fp32 inputs), i.e. at least as accurate as the reference's fp32 torch reductions.
+// into one launch with ONE block reduction of 18 raw moments.  All sums and the 3x3 solve are
+// fp64 (fp32 inputs), i.e. at least as accurate as the reference's fp32 torch reductions.
 //
 // Stopping: ICPFLOW_STOP_REFERENCE reproduces the batch-global rule (stop when every pair
 // has rel <= thr, :209) WITHOUT a host round trip: one launch per iteration is enqueued up
@@ -31,17 +31,24 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-__device__ void kabsch_rotation(const double (&Hin)[9], double (&R)[9])
+// Vw (in/out): right singular vectors of the previous iteration of this pair (identity at
+// the start).  H changes little between ICP iterations, so A = H Vw is already nearly
+// column-orthogonal and the Jacobi sweeps below converge in 1-2 rounds instead of 5-6.
+__device__ void kabsch_rotation(const double (&Hin)[9], double *Vw, double (&R)[9])
 {
-    // columns of A (A = H V  ->  U S) and of V, stored column-major: a[c][r]
+    // columns of A (A = H V  ->  U S) and of V, stored column-major: a[c][r], v[c][r]
     double a[3][3], v[3][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            a[c][r] = Hin[r * 3 + c];
-            v[c][r] = (r == c) ? 1.0 : 0.0;
+            v[c][r] = Vw[r * 3 + c];
         }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            a[c][r] = Hin[r * 3 + 0] * v[c][0] + Hin[r * 3 + 1] * v[c][1] + Hin[r * 3 + 2] * v[c][2];
     for (int sweep = 0; sweep < 16; ++sweep) {
         bool rotated = false;
 #pragma unroll
@@ -51,11 +58,12 @@ __device__ void kabsch_rotation(const double (&Hin)[9], double (&R)[9])
             const double al = a[p][0] * a[p][0] + a[p][1] * a[p][1] + a[p][2] * a[p][2];
             const double be = a[q][0] * a[q][0] + a[q][1] * a[q][1] + a[q][2] * a[q][2];
             const double ga = a[p][0] * a[q][0] + a[p][1] * a[q][1] + a[p][2] * a[q][2];
-            if (ga == 0.0 || fabs(ga) <= 1e-16 * sqrt(al * be)) continue;
+            // converged for this pair of columns: |cos(angle)| <= 1e-15
+            if (ga == 0.0 || ga * ga <= 1e-30 * (al * be)) continue;
             rotated = true;
             const double zeta = (be - al) / (2.0 * ga);
             const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double cs = 1.0 / sqrt(1.0 + t * t);
+            const double cs = rsqrt(1.0 + t * t);
             const double sn = cs * t;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -72,9 +80,7 @@ __device__ void kabsch_rotation(const double (&Hin)[9], double (&R)[9])
     double s[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) s[c] = sqrt(a[c][0] * a[c][0] + a[c][1] * a[c][1] + a[c][2] * a[c][2]);
-    // order singular values descending (the reflection fix acts on the SMALLEST one);
-    // an odd permutation flips det(V)
-    double detV = 1.0;
+    // order singular values descending (the reflection fix acts on the SMALLEST one)
 #define ICPFLOW_SWAP_COLS(i, j)                                                            \
     if (s[i] < s[j]) {                                                                      \
         const double ts = s[i]; s[i] = s[j]; s[j] = ts;                                     \
@@ -82,17 +88,24 @@ __device__ void kabsch_rotation(const double (&Hin)[9], double (&R)[9])
             const double ta = a[i][r]; a[i][r] = a[j][r]; a[j][r] = ta;                     \
             const double tv = v[i][r]; v[i][r] = v[j][r]; v[j][r] = tv;                     \
         }                                                                                   \
-        detV = -detV;                                                                       \
     }
     ICPFLOW_SWAP_COLS(0, 1)
     ICPFLOW_SWAP_COLS(0, 2)
     ICPFLOW_SWAP_COLS(1, 2)
 #undef ICPFLOW_SWAP_COLS
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Vw[r * 3 + c] = v[c][r];
     if (!(s[0] > 0.0)) {  // H == 0 (no inliers): torch.svd(0) gives U = V = I  ->  R = I
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < 9; ++k) { R[k] = (k % 4 == 0) ? 1.0 : 0.0; Vw[k] = R[k]; }
         return;
     }
+    // det V = +-1 (V is a product of rotations and column swaps)
+    double cv[3];
+    cross3(v[0], v[1], cv);
+    const double detV = (cv[0] * v[2][0] + cv[1] * v[2][1] + cv[2] * v[2][2]) < 0.0 ? -1.0 : 1.0;
     double u0[3], u1[3], u2[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) u0[r] = a[0][r] / s[0];
@@ -141,7 +154,6 @@ struct IcpParams {
     int maxIter;
     IcpState *state;       // [B]
     IcpCtrl *ctrl;
-    int32_t *nnj;          // [B,N] scratch, used when a pair needs more than one query group
 };
 
 #ifdef ICPFLOW_PHASE_TIMING
@@ -152,16 +164,48 @@ __device__ long long g_phase_stamps[16];
 #define ICPFLOW_STAMP(k) do { } while (0)
 #endif
 
-template <int BLOCK, int Q>
+// Moments accumulated per iteration (one block reduction, fp64).  With x' = x0 - o and
+// y' = y_nn - o for a per-pair origin o (the first source point; keeps |x'|,|y'| at the cluster
+// extent so that the raw-moment identities below lose nothing in fp64):
+//   0      sum w                     1..3   sum w x'          4..6   sum w y'
+//   7..15  sum w x'_i y'_j           16     sum w |x'|^2      17     sum w |y'|^2
+// Centred covariance  H W = sum w x'y'^T - W mx' my'^T  (== :318-336 of the reference) and
+// sum w |x R + T - y|^2 = (Sxx - W|mx'|^2) + (Syy - W|my'|^2) - 2 W sum_ij R_ij H_ij  (== :191,
+// evaluated without rounding X R + T to fp32 first), so one pass over the points suffices.
+constexpr int kMoments = 18;
+
+// Work decomposition inside the workgroup (one pair): the NWAVE waves form NWAVE/TS query
+// groups x TS target shares.  The TS waves of a query group hold the SAME Q x 64 queries and
+// each scans 1/TS of every target tile; their partial (distance, chunk) results meet in LDS
+// and query slot q is finished (resolve, gate, moments) by the wave with share q % TS.
+// This keeps 16 waves (4 per SIMD) busy on a 1024-point pair with Q = 4 queries per lane, i.e.
+// 12 LDS cycles of broadcast reads per 144 VALU issue cycles per wave, where a plain
+// one-query-set-per-wave split would leave either the LDS pipe (Q = 1) or the latency hiding
+// (4 waves per CU at Q = 4) as the limiter.  Register budget: 128 VGPRs (4 waves per SIMD),
+// hence the moments are reduced per query slot straight into LDS and the Jacobi state lives
+// in LDS instead of being carried in registers across the scan.
+template <int BLOCK, int Q, int TS>
 __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
     ICPFLOW_STAMP(0);
+    constexpr int NWAVE = BLOCK / kWave;
+    constexpr int NQG = NWAVE / TS;          // query groups
+    static_assert((NWAVE % TS == 0 && Q % TS == 0) || TS == 1, "Q slots are dealt round-robin to the TS waves");
     __shared__ ScanTile tileMem;
     ScanTile *tile = &tileMem;
-    __shared__ double red[(BLOCK / kWave) * 9];
+    __shared__ double red[NWAVE * kMoments];  // per-wave moment sums of the current iteration
+    __shared__ double Vsh[9];                 // right singular vectors (Jacobi warm start)
+    __shared__ double ksh[17];                // centroids, second moments and H parked across the solve
+    __shared__ float bcast[16];               // R (9), T (3), active flag, prev rmse, rmse
+    __shared__ float combD[TS > 1 ? NWAVE * Q * kWave : 1];   // [wave][q][lane]
+    __shared__ int combC[TS > 1 ? NWAVE * Q * kWave : 1];
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    const int ts = wave % TS;                // target share of this wave
+    const int qg = wave / TS;                // query group of this wave
     IcpCtrl *ctrl = p.ctrl;
     if (p.stopMode == ICPFLOW_STOP_REFERENCE_ && itBegin > 0) {
         // previous iteration satisfied the batch-global rule (or an earlier one did)
@@ -182,184 +226,215 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     none.a = affine_identity();
 
     IcpState *st = p.state + b;
-    float Rf[9], Tf[3], prev;
-    int active;
+    float Rf[9], Tf[3];
+    int active = 1;
     if (itBegin == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rf[k] = (k % 4 == 0) ? 1.f : 0.f;  // :140
         Tf[0] = Tf[1] = Tf[2] = 0.f;
-        prev = 0.f;
-        active = 1;
+        if (tid < 9) Vsh[tid] = (tid % 4 == 0) ? 1.0 : 0.0;
+        if (tid == 0) { bcast[13] = 0.f; bcast[14] = 0.f; }
     } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rf[k] = st->R[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) Tf[k] = st->T[k];
-        prev = st->rmse;
         active = st->active;
+        if (tid < 9) Vsh[tid] = st->V[tid];
+        if (tid == 0) { bcast[13] = st->rmse; bcast[14] = st->rmse; }
     }
-    float rmse = prev;
     int itersDone = (itBegin == 0) ? 0 : st->iters;
 
-    const int per = BLOCK * Q;
+    // per-pair origin of the moment accumulation: the first (pre-posed) source point
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    if (xc.n > 0) {
+        float rx, ry, rz;
+        cloud_load(xc, 0, rx, ry, rz);
+        xf_apply(pre, rx, ry, rz, ox, oy, oz);
+    }
+
+    const int per = NQG * kWave * Q;         // queries per pass of the workgroup
     const int ngroups = (xc.n + per - 1) / per;
-    int32_t *nnj = p.nnj + (size_t)b * p.N;
 
     for (int it = itBegin; it < itEnd; ++it) {
         if (p.stopMode == ICPFLOW_STOP_PER_PAIR_ && !active) break;
-        // ---------------- pass 1: NN + gate + first moments ---------------------------
-        double s7[7] = {0, 0, 0, 0, 0, 0, 0};
-        float x0x[Q], x0y[Q], x0z[Q], ynx[Q], yny[Q], ynz[Q];
-        bool w[Q];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < kMoments; ++k) red[wave * kMoments + k] = 0.0;
+        }
+        // ------------- NN + gate + moments (one pass over the source points) ---------------
         for (int g = 0; g < ngroups; ++g) {
+            ScanAcc<Q> acc;
             float qx[Q], qy[Q], qz[Q];
-            bool live[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const int i = g * per + q * BLOCK + tid;
-                live[q] = i < xc.n;
-                x0x[q] = x0y[q] = x0z[q] = 0.f;
+                const int i = g * per + (q * NQG + qg) * kWave + lane;
                 qx[q] = qy[q] = qz[q] = 0.f;
-                if (live[q]) {
-                    float rx, ry, rz;
+                if (i < xc.n) {
+                    float rx, ry, rz, x0x, x0y, x0z;
                     cloud_load(xc, i, rx, ry, rz);
-                    xf_apply(pre, rx, ry, rz, x0x[q], x0y[q], x0z[q]);  // utils_icp.py:21
+                    xf_apply(pre, rx, ry, rz, x0x, x0y, x0z);  // utils_icp.py:21
                     // Xt = X0 R + T  (:177, :395), bmm order
-                    qx[q] = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0])) + Tf[0];
-                    qy[q] = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1])) + Tf[1];
-                    qz[q] = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2])) + Tf[2];
+                    qx[q] = fmaf(x0z, Rf[6], fmaf(x0y, Rf[3], x0x * Rf[0])) + Tf[0];
+                    qy[q] = fmaf(x0z, Rf[7], fmaf(x0y, Rf[4], x0x * Rf[1])) + Tf[1];
+                    qz[q] = fmaf(x0z, Rf[8], fmaf(x0y, Rf[5], x0x * Rf[2])) + Tf[2];
                 }
             }
-            ScanAcc<Q> acc;
             ICPFLOW_STAMP(1);
-            scan_cloud<Q>(yc, none, tile, qx, qy, qz, acc);  // :154-157
+            scan_cloud<Q>(yc, none, tile, qx, qy, qz, acc, ts, TS);  // :154-157
             ICPFLOW_STAMP(2);
+            if (TS > 1) {
+                __syncthreads();  // combD/combC of the previous pass fully consumed
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    combD[(wave * Q + q) * kWave + lane] = acc.best[q];
+                    combC[(wave * Q + q) * kWave + lane] = acc.chunk[q];
+                }
+                __syncthreads();
+            }
+            ICPFLOW_STAMP(9);
+            // finish the query slots owned by this wave (q % TS == ts)
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                w[q] = live[q] && (acc.best[q] <= p.thr2);  // :160-161
-                ynx[q] = yny[q] = ynz[q] = 0.f;
-                int j = -1;
-                if (w[q]) {
-                    j = scan_resolve(yc, none, qx[q], qy[q], qz[q], acc.best[q], acc.chunk[q],
-                                     ynx[q], yny[q], ynz[q]);
-                    s7[0] += 1.0;
-                    s7[1] += (double)x0x[q]; s7[2] += (double)x0y[q]; s7[3] += (double)x0z[q];
-                    s7[4] += (double)ynx[q]; s7[5] += (double)yny[q]; s7[6] += (double)ynz[q];
+                if (TS > 1 && (q % TS) != ts) continue;  // wave-uniform
+                float bd = acc.best[q];
+                int bc = acc.chunk[q];
+                if (TS > 1) {
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) {
+                        const float d = combD[((qg * TS + t) * Q + q) * kWave + lane];
+                        const int c = combC[((qg * TS + t) * Q + q) * kWave + lane];
+                        if (t == 0 || scan_better(bd, bc, d, c)) { bd = d; bc = c; }
+                    }
                 }
-                if (ngroups > 1) {
-                    const int i = g * per + q * BLOCK + tid;
-                    if (live[q]) nnj[i] = j;
+                const int i = g * per + (q * NQG + qg) * kWave + lane;
+                const bool inl = (i < xc.n) && (bd <= p.thr2);  // :160-161
+                double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0;
+                if (inl) {
+                    float ynx, yny, ynz, rx, ry, rz, x0x, x0y, x0z;
+                    scan_resolve(yc, none, qx[q], qy[q], qz[q], bd, bc, ynx, yny, ynz);
+                    cloud_load(xc, i, rx, ry, rz);
+                    xf_apply(pre, rx, ry, rz, x0x, x0y, x0z);
+                    ax = (double)(x0x - ox); ay = (double)(x0y - oy); az = (double)(x0z - oz);
+                    bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
                 }
+                ICPFLOW_STAMP(10);
+                // 18 moments, each reduced over the wave on the VALU and added to this wave's
+                // LDS row by lane 0 (non-inliers contribute exact zeros)
+                double *row = red + wave * kMoments;
+#define ICPFLOW_ACC(k, expr)                                  \
+                {                                             \
+                    const double t_ = wave_sum_uniform(expr); \
+                    if (lane == 0) row[k] += t_;              \
+                }
+                ICPFLOW_ACC(0, inl ? 1.0 : 0.0)
+                ICPFLOW_ACC(1, ax) ICPFLOW_ACC(2, ay) ICPFLOW_ACC(3, az)
+                ICPFLOW_ACC(4, bx) ICPFLOW_ACC(5, by) ICPFLOW_ACC(6, bz)
+                ICPFLOW_ACC(7, ax * bx) ICPFLOW_ACC(8, ax * by) ICPFLOW_ACC(9, ax * bz)
+                ICPFLOW_ACC(10, ay * bx) ICPFLOW_ACC(11, ay * by) ICPFLOW_ACC(12, ay * bz)
+                ICPFLOW_ACC(13, az * bx) ICPFLOW_ACC(14, az * by) ICPFLOW_ACC(15, az * bz)
+                ICPFLOW_ACC(16, ax * ax + ay * ay + az * az)
+                ICPFLOW_ACC(17, bx * bx + by * by + bz * bz)
+#undef ICPFLOW_ACC
             }
         }
         ICPFLOW_STAMP(3);
-        block_sum<7, double>(s7, red);
+        __syncthreads();  // every wave's row is complete
         ICPFLOW_STAMP(4);
-        const double wsum = s7[0] > 1e-9 ? s7[0] : 1e-9;  // clamp(eps), :314-315, :326
-        const double mux = s7[1] / wsum, muy = s7[2] / wsum, muz = s7[3] / wsum;
-        const double nux = s7[4] / wsum, nuy = s7[5] / wsum, nuz = s7[6] / wsum;
-
-        // ---------------- pass 2: centred covariance, :318-336 ---------------------------
-        double h9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int g = 0; g < ngroups; ++g) {
-            if (ngroups > 1) {
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const int i = g * per + q * BLOCK + tid;
-                    w[q] = false;
-                    if (i < xc.n) {
-                        const int j = nnj[i];
-                        if (j >= 0) {
-                            float rx, ry, rz;
-                            cloud_load(xc, i, rx, ry, rz);
-                            xf_apply(pre, rx, ry, rz, x0x[q], x0y[q], x0z[q]);
-                            cloud_load(yc, j, ynx[q], yny[q], ynz[q]);
-                            w[q] = true;
-                        }
-                    }
-                }
+        // ------------- wave 0 solves for (R, T, rmse) ---------------------------------------
+        if (wave == 0) {
+            // lane k < 18 sums moment k over the waves; totals are then wave-uniform via readlane
+            double mine = 0.0;
+            if (lane < kMoments) {
+                mine = red[lane];
+                for (int w = 1; w < NWAVE; ++w) mine += red[w * kMoments + lane];
             }
+            double mom[kMoments];
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                if (!w[q]) continue;
-                const double cx = (double)x0x[q] - mux, cy = (double)x0y[q] - muy, cz = (double)x0z[q] - muz;
-                const double ex = (double)ynx[q] - nux, ey = (double)yny[q] - nuy, ez = (double)ynz[q] - nuz;
-                h9[0] += cx * ex; h9[1] += cx * ey; h9[2] += cx * ez;
-                h9[3] += cy * ex; h9[4] += cy * ey; h9[5] += cy * ez;
-                h9[6] += cz * ex; h9[7] += cz * ey; h9[8] += cz * ez;
+            for (int k = 0; k < kMoments; ++k) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(mine), k);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(mine), k);
+                mom[k] = __hiloint2double(hi, lo);
             }
-        }
-        block_sum<9, double>(h9, red);
-        ICPFLOW_STAMP(5);
+            const double W = mom[0] > 1e-9 ? mom[0] : 1e-9;  // clamp(eps), :314-315, :326
+            double h9[9];
+            {
+                const double mx0 = mom[1] / W, mx1 = mom[2] / W, mx2 = mom[3] / W;
+                const double my0 = mom[4] / W, my1 = mom[5] / W, my2 = mom[6] / W;
+                const double mxv[3] = {mx0, mx1, mx2}, myv[3] = {my0, my1, my2};
 #pragma unroll
-        for (int k = 0; k < 9; ++k) h9[k] /= wsum;
-        // every thread holds the same H: solve redundantly, no broadcast needed
-        double Rd[9];
-        kabsch_rotation(h9, Rd);
-        ICPFLOW_STAMP(6);
-        // T = mu_y - mu_x R, :376
-        const double Td0 = nux - (mux * Rd[0] + muy * Rd[3] + muz * Rd[6]);
-        const double Td1 = nuy - (mux * Rd[1] + muy * Rd[4] + muz * Rd[7]);
-        const double Td2 = nuz - (mux * Rd[2] + muy * Rd[5] + muz * Rd[8]);
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rf[k] = (float)Rd[k];
-        Tf[0] = (float)Td0; Tf[1] = (float)Td1; Tf[2] = (float)Td2;
-
-        // ---------------- pass 3: rmse with the updated transform, :191-192 -----------------
-        double e1[1] = {0.0};
-        for (int g = 0; g < ngroups; ++g) {
-            if (ngroups > 1) {
+                    for (int j = 0; j < 3; ++j) h9[i * 3 + j] = mom[7 + i * 3 + j] / W - mxv[i] * myv[j];  // :318-336
+                // park what is needed after the solve in LDS: the Jacobi sweeps want the registers
+                // (every lane writes the same value to the same address and reads its own write)
+                ksh[0] = mx0; ksh[1] = mx1; ksh[2] = mx2; ksh[3] = my0; ksh[4] = my1; ksh[5] = my2;
+                ksh[6] = mom[16] / W - (mx0 * mx0 + mx1 * mx1 + mx2 * mx2);   // sum w |x_c|^2 / W
+                ksh[7] = mom[17] / W - (my0 * my0 + my1 * my1 + my2 * my2);   // sum w |y_c|^2 / W
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const int i = g * per + q * BLOCK + tid;
-                    w[q] = false;
-                    if (i < xc.n) {
-                        const int j = nnj[i];
-                        if (j >= 0) {
-                            float rx, ry, rz;
-                            cloud_load(xc, i, rx, ry, rz);
-                            xf_apply(pre, rx, ry, rz, x0x[q], x0y[q], x0z[q]);
-                            cloud_load(yc, j, ynx[q], yny[q], ynz[q]);
-                            w[q] = true;
-                        }
-                    }
-                }
+                for (int k = 0; k < 9; ++k) ksh[8 + k] = h9[k];
             }
+            ICPFLOW_STAMP(5);
+            double Rd[9];
+            kabsch_rotation(h9, Vsh, Rd);
+            ICPFLOW_STAMP(6);
+            // T = mu_y - mu_x R with mu = o + m', :376
+            const double mux[3] = {(double)ox + ksh[0], (double)oy + ksh[1], (double)oz + ksh[2]};
+            const double muy[3] = {(double)ox + ksh[3], (double)oy + ksh[4], (double)oz + ksh[5]};
+            const double Td0 = muy[0] - (mux[0] * Rd[0] + mux[1] * Rd[3] + mux[2] * Rd[6]);
+            const double Td1 = muy[1] - (mux[0] * Rd[1] + mux[1] * Rd[4] + mux[2] * Rd[7]);
+            const double Td2 = muy[2] - (mux[0] * Rd[2] + mux[1] * Rd[5] + mux[2] * Rd[8]);
+            // rmse^2 = (Sxx_c + Syy_c)/W - 2 sum_ij R_ij H_ij, :191-192
+            double rh = 0.0;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                if (!w[q]) continue;
-                const float tx = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0])) + Tf[0];
-                const float ty = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1])) + Tf[1];
-                const float tz = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2])) + Tf[2];
-                const float dx = tx - ynx[q], dy = ty - yny[q], dz = tz - ynz[q];
-                e1[0] += (double)(dx * dx + dy * dy + dz * dz);
+            for (int k = 0; k < 9; ++k) rh += Rd[k] * ksh[8 + k];
+            const double ms = ksh[6] + ksh[7] - 2.0 * rh;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rf[k] = (float)Rd[k];
+            Tf[0] = (float)Td0; Tf[1] = (float)Td1; Tf[2] = (float)Td2;
+            const float rmse = (float)sqrt(ms > 0.0 ? ms : 0.0);
+            const float prev = bcast[14];
+            // relative rmse, :195-198 (fp32 like the reference's tensors)
+            const float rel = (it == 0) ? 1.0f : (prev - rmse) / prev;
+            const bool conv = rel <= p.relThr;  // NaN -> false, :209
+            if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
+                if (lane == 0 && !conv) atomicAdd(&ctrl->notconv[it], 1);
+            } else {
+                // per-pair rule: retire a pair once its rmse has stopped DEcreasing by more than
+                // thr (0 <= rel <= thr).  A negative rel (rmse went up: the inlier set is still
+                // changing) satisfies the reference's batch test but is not convergence of this
+                // pair.  A constant (zero-inlier) pair has rel = NaN and is retired too.
+                if (it > 0 && ((conv && rel >= 0.0f) || rel != rel)) active = 0;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) bcast[k] = Rf[k];
+                bcast[9] = Tf[0]; bcast[10] = Tf[1]; bcast[11] = Tf[2];
+                bcast[12] = active ? 1.f : 0.f;
+                bcast[14] = rmse;  // :213 prev_rmse = rmse
             }
         }
-        block_sum<1, double>(e1, red);
-        ICPFLOW_STAMP(7);
-        rmse = (float)sqrt(e1[0] / wsum);
-        // relative rmse, :195-198 (fp32 like the reference's tensors)
-        const float rel = (it == 0) ? 1.0f : (prev - rmse) / prev;
-        const bool conv = rel <= p.relThr;  // NaN -> false, :209
         itersDone = it + 1;
-        if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
-            if (tid == 0 && !conv) atomicAdd(&ctrl->notconv[it], 1);
-        } else {
-            // per-pair rule: retire a pair once its rmse has stopped DEcreasing by more than
-            // thr (0 <= rel <= thr).  A negative rel (rmse went up: the inlier set is still
-            // changing) satisfies the reference's batch test but is not convergence of this
-            // pair.  A constant (zero-inlier) pair has rel = NaN and is retired too.
-            if (it > 0 && ((conv && rel >= 0.0f) || rel != rel)) active = 0;
+        ICPFLOW_STAMP(7);
+        if (it + 1 < itEnd) {  // more iterations inside this launch: publish (R, T) to the block
+            __syncthreads();
+            if (wave != 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Rf[k] = bcast[k];
+                Tf[0] = bcast[9]; Tf[1] = bcast[10]; Tf[2] = bcast[11];
+                active = bcast[12] != 0.f;
+            }
         }
-        prev = rmse;  // :213
     }
     ICPFLOW_STAMP(8);
-    if (tid == 0) {
+    __syncthreads();
+    if (tid < 9) st->V[tid] = Vsh[tid];
+    if (tid == 0) {  // wave 0 holds the final state
 #pragma unroll
         for (int k = 0; k < 9; ++k) st->R[k] = Rf[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) st->T[k] = Tf[k];
-        st->rmse = rmse;
+        st->rmse = bcast[14];
         st->active = active;
         st->iters = itersDone;
         if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
@@ -392,10 +467,10 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
     }
 }
 
-template <int BLOCK, int Q>
+template <int BLOCK, int Q, int TS>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
-    hipLaunchKernelGGL((icp_kernel<BLOCK, Q>), dim3(B), dim3(BLOCK), 0, s, p, itBegin, itEnd);
+    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS>), dim3(B), dim3(BLOCK), 0, s, p, itBegin, itEnd);
 }
 
 // ---- optional per-launch timing of this (dominant) kernel with HIP events ---------------------
@@ -452,23 +527,24 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
 {
     const bool timed = g_prof.used < (int)g_prof.start.size();
     if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
-    if (p.N <= 256) launch_icp_variant<256, 1>(p, B, itBegin, itEnd, s);
-    else if (p.N <= 512) launch_icp_variant<512, 1>(p, B, itBegin, itEnd, s);
-    else if (p.N <= 1024) launch_icp_variant<512, 2>(p, B, itBegin, itEnd, s);
-    else launch_icp_variant<512, 4>(p, B, itBegin, itEnd, s);
+    // queries per pass = (BLOCK/64/TS) * 64 * Q
+    if (p.N <= 256) launch_icp_variant<256, 2, 2>(p, B, itBegin, itEnd, s);         // 256
+    else if (p.N <= 512) launch_icp_variant<512, 2, 2>(p, B, itBegin, itEnd, s);    // 512
+    else if (p.N <= 1024) launch_icp_variant<1024, 4, 4>(p, B, itBegin, itEnd, s);  // 1024
+    else launch_icp_variant<1024, 4, 2>(p, B, itBegin, itEnd, s);                   // 2048 per pass
     if (timed) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
 }
 
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      int32_t *nnj, hipStream_t s)
+                      hipStream_t s)
 {
     IcpParams p{};
     p.X = X; p.Y = Y; p.lenX = lenX; p.lenY = lenY; p.swap = swap; p.prePose = prePose; p.N = N;
     p.thr2 = (float)(thres * thres);
     p.relThr = (float)relThr;
-    p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl; p.nnj = nnj;
+    p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(IcpCtrl), s);
     if (e != hipSuccess) return e;
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {

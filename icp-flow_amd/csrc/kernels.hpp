@@ -19,6 +19,7 @@ constexpr int kTopK = 5;          // utils_hist.py:21
 constexpr int kNmsKernel = 11;    // utils_hist.py:21
 
 struct IcpState {
+    double V[9];   // right singular vectors of the last Kabsch solve (Jacobi warm start)
     float R[9];
     float T[3];
     float rmse;
@@ -66,7 +67,7 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      int32_t *nnj, hipStream_t s);
+                      hipStream_t s);
 hipError_t profile_enable(int capacity);
 hipError_t profile_collect(double *total_ms, int *launches);
 hipError_t launch_icp_export(const IcpState *state, const IcpCtrl *ctrl, int B, int stopMode, float *R,

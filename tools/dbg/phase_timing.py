@@ -18,7 +18,13 @@ for k in (1, 2, 3):
     torch.cuda.synchronize()
     st = (ctypes.c_longlong * 16)()
     rc = _lib._L.icpflow_debug_phase_stamps(st)
-    v = np.array(st[:9], dtype=np.int64)
-    d = np.diff(v)
-    print(f"max_iterations={k} (stamps of the LAST iteration), total {v[8]-v[0]} clk")
-    for n, x in zip(names, d): print(f"   {n:22s} {x:8d} clk  {x/100.0:8.2f} us@100MHz")
+    v = np.array(st[:16], dtype=np.int64)
+    order = [(0, "kernel entry"), (1, "queries loaded, scan starts"), (2, "own scan share done"),
+             (9, "all shares merged (barrier)"), (10, "resolve + x0 reload done"), (3, "moments reduced into LDS"),
+             (4, "block barrier passed"), (5, "totals + H formed"), (6, "kabsch done"), (7, "R,T,rmse published"), (8, "loop exit")]
+    print(f"max_iterations={k} (stamps of the LAST iteration, workgroup 0 thread 0), total {v[8]-v[0]} shader clocks")
+    prev = v[0]
+    for idx, name in order:
+        if v[idx] == 0: continue
+        print(f"   +{v[idx]-prev:8d}  {name}")
+        prev = v[idx]
