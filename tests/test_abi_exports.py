@@ -1,0 +1,74 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/icpflow_hip.h declares,
+argument errors come back as status codes + messages (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(REPO, "include", "icpflow_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(icpflow_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as entry
+    so = entry.build()
+    lib = ctypes.CDLL(so)
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in icpflow_hip.h but not exported"
+
+
+def test_python_binding_covers_the_header():
+    from icp_flow_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    assert _lib.VERSION == 100
+
+
+def test_argument_errors_are_status_codes_with_messages():
+    from icp_flow_amd import _lib
+    L = _lib._L
+    assert L.icpflow_workspace_bytes(0, 10, 0, 0, 0) == 0
+    assert L.icpflow_workspace_bytes(256, 1024, 41, 41, 3) > 3 * 256 * 41 * 41 * 3 * 4
+    rc = L.icpflow_hist_vote(None, None, 1, 1, 1, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1, 1, 1, None, None)
+    assert rc == -1 and b"null pointer" in L.icpflow_last_error()
+    one = ctypes.c_void_p(16)
+    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 5000, 1e-6, 0, None, None, None, None, None, one, 1 << 30, None)
+    assert rc == -1 and b"max_iterations" in L.icpflow_last_error()
+    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 10, 1e-6, 7, None, None, None, None, None, one, 1 << 30, None)
+    assert rc == -1 and b"stop_mode" in L.icpflow_last_error()
+    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 10, 1e-6, 0, None, None, None, None, None, one, 16, None)
+    assert rc == -2 and b"workspace" in L.icpflow_last_error()
+    rc = L.icpflow_nn_batch(one, one, 1, 4, 4, 2, 4, None, None, 1, one, one, None)
+    assert rc == -1 and b"stride" in L.icpflow_last_error()
+
+
+def test_product_refuses_cpu_tensors_no_fallback():
+    from icp_flow_amd import hist, utils_helper, utils_match
+    from types import SimpleNamespace
+    x = torch.zeros(2, 8, 4)
+    a = SimpleNamespace(thres_dist=0.1, translation_frame=2.0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        utils_match.hist_icp(a, x, x)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        hist.hist(x, x, -1, -1, -1, 1, 1, 1, 3, 3, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        utils_helper.nearest_neighbor_batch(x, x)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is the checker: nothing under icp-flow_amd/ may reference it."""
+    pkg = os.path.join(REPO, "icp-flow_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "liboracle" not in txt, f
