@@ -44,6 +44,7 @@ SIGNATURES = {
     "icpflow_apply_icp": (_i, [_p, _p, _p, _i, _i, _d, _i, _d, _i, _p, _p, _p, _sz, _p]),
     "icpflow_hist_icp": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _sz, _p]),
     "icpflow_match_eval": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "icpflow_set_icp_search": (_i, [_i]),
     "icpflow_profile_enable": (_i, [_i]),
     "icpflow_profile_collect": (_i, [ctypes.POINTER(_d), ctypes.POINTER(_i)]),
 }
@@ -61,6 +62,15 @@ def call(name, *args):
     if rc != 0:
         msg = _L.icpflow_last_error()
         raise RuntimeError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+SEARCH_AUTO, SEARCH_SCAN, SEARCH_GRID = 0, 1, 2
+
+
+def set_icp_search(mode):
+    """'auto' | 'scan' | 'grid' (or 0/1/2): correspondence search inside the ICP loop."""
+    mode = {"auto": 0, "scan": 1, "grid": 2}.get(mode, mode)
+    call("icpflow_set_icp_search", int(mode))
 
 
 def profile_enable(capacity):

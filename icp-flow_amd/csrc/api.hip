@@ -33,6 +33,10 @@ int hipfail(hipError_t e, const char *what)
         if (e__ != hipSuccess) return hipfail(e__, #expr); \
     } while (0)
 
+// ICP correspondence search: 0 = auto, 1 = all-pairs LDS scan, 2 = exact grid (icp.hip)
+int g_icp_search = 0;
+bool use_grid(int N) { return g_icp_search == 2 || (g_icp_search == 0 && N >= 64); }
+
 constexpr size_t kAlign = 256;
 size_t up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
 
@@ -48,6 +52,7 @@ struct Workspace {
     float *Tinit = nullptr, *M = nullptr;
     IcpState *state = nullptr;
     IcpCtrl *ctrl = nullptr;
+    GridScratch grid{};
     size_t bytes = 0;
 
     Workspace(void *base, int B, int N, size_t L)
@@ -73,6 +78,11 @@ struct Workspace {
         M = (float *)take(b * 16 * 4);
         state = (IcpState *)take(b * sizeof(IcpState));
         ctrl = (IcpCtrl *)take(sizeof(IcpCtrl));
+        grid.H = grid_buckets(N);
+        grid.origin = (float *)take(b * 4 * 4);
+        grid.start = (int32_t *)take(b * ((size_t)grid.H + 1) * 4);
+        grid.cursor = (int32_t *)take(b * (size_t)grid.H * 4);
+        grid.pts = (float *)take(b * (size_t)N * 16);
         bytes = off;
     }
 };
@@ -106,7 +116,7 @@ int run_icp_and_select(const float *src, const float *dst, const Workspace &w, c
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, hipStream_t s)
 {
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, s));
+                           w.state, w.ctrl, use_grid(N) ? &w.grid : nullptr, s));
     if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
     ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
@@ -143,6 +153,13 @@ size_t icpflow_workspace_bytes(int B, int N, int Lx, int Ly, int Lz)
     if (B <= 0 || N <= 0) return 0;
     const size_t L = (size_t)(Lx > 0 ? Lx : 0) * (size_t)(Ly > 0 ? Ly : 0) * (size_t)(Lz > 0 ? Lz : 0);
     return Workspace(nullptr, B, N, L).bytes;
+}
+
+int icpflow_set_icp_search(int mode)
+{
+    if (mode < 0 || mode > 2) return fail(ICPFLOW_E_ARG, "icpflow_set_icp_search: mode must be 0, 1 or 2 (got %d)", mode);
+    g_icp_search = mode;
+    return 0;
 }
 
 int icpflow_profile_enable(int capacity)
@@ -268,7 +285,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     launch_count_valid(d_X, B, N, w.lenA, s);
     launch_count_valid(d_Y, B, N, w.lenC, s);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
-                           relative_rmse_thr, stop_mode, w.state, w.ctrl, s));
+                           relative_rmse_thr, stop_mode, w.state, w.ctrl, use_grid(N) ? &w.grid : nullptr, s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
     return 0;
 }

@@ -154,6 +154,12 @@ struct IcpParams {
     int maxIter;
     IcpState *state;       // [B]
     IcpCtrl *ctrl;
+    // exact uniform-grid search (GRID kernels): built once per registration by grid_build_kernel
+    const float4 *gridPts;   // [B,N]   fixed-cloud points sorted by bucket, w = original index bits
+    const int32_t *gridStart;// [B,H+1] bucket -> first slot in gridPts
+    const float *gridOrigin; // [B,4]   cell origin (the first fixed-cloud point)
+    int gridH;               // buckets per pair (power of two)
+    float gridInvH;          // 1 / cell edge
 };
 
 #ifdef ICPFLOW_PHASE_TIMING
@@ -163,6 +169,93 @@ __device__ long long g_phase_stamps[16];
 #else
 #define ICPFLOW_STAMP(k) do { } while (0)
 #endif
+
+// ---------------------------------------------------------------------------------
+// Exact nearest neighbour within the gate radius through a hashed uniform grid.
+//
+// The ICP loop consumes the NN search only through the gate d^2 <= thres^2 and the neighbour of
+// gated points (utils_icp_pytorch3d.py:160-164), and the fixed cloud never changes during a
+// registration.  So the fixed cloud is binned ONCE into cells of edge h = 1.01 * thres (hashed
+// into H = 2^k >= 2N buckets, counting sort); a query then evaluates only the points of the 27
+// cells around it.  Every point within the gate radius of the query lies in those cells
+// (|coordinate difference| <= thres < h  =>  cell index difference <= 1; the cell index is a
+// monotone function of the coordinate), distances are evaluated with the SAME fp32 instruction
+// sequence as the brute-force scan and ties go to the lowest original index, so gate decisions
+// and neighbours -- hence every transform -- are bit-identical to the all-pairs search, at
+// ~30 instead of n distance evaluations per query.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int grid_cell(float v, float o, float invh)
+{
+    return (int)floorf((v - o) * invh);
+}
+
+__device__ __forceinline__ unsigned grid_hash(int cx, int cy, int cz, unsigned mask)
+{
+    return ((unsigned)cx * 73856093u ^ (unsigned)cy * 19349663u ^ (unsigned)cz * 83492791u) & mask;
+}
+
+constexpr int kGridBlock = 256;
+
+int grid_buckets(int N)
+{
+    int H = 64;
+    while (H < 2 * N) H <<= 1;
+    return H;
+}
+
+// One workgroup per pair.  counts/starts live in global scratch (L2 resident).
+__global__ __launch_bounds__(kGridBlock) void grid_build_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const int32_t *__restrict__ lenX,
+    const int32_t *__restrict__ lenY, const uint8_t *__restrict__ swap, int N, int H, float invh,
+    float *__restrict__ origin, int32_t *__restrict__ start, int32_t *__restrict__ cursor,
+    float4 *__restrict__ pts)
+{
+    __shared__ int part[kGridBlock];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool sw = swap != nullptr && swap[b] != 0;
+    const float4 *yb = reinterpret_cast<const float4 *>(sw ? X : Y) + (size_t)b * N;
+    const int n = (sw ? lenX : lenY)[b];
+    int32_t *st = start + (size_t)b * (H + 1);
+    int32_t *cu = cursor + (size_t)b * H;
+    float4 *out = pts + (size_t)b * N;
+    const unsigned mask = (unsigned)H - 1u;
+    float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n > 0) o4 = yb[0];
+    if (tid == 0) { origin[b * 4 + 0] = o4.x; origin[b * 4 + 1] = o4.y; origin[b * 4 + 2] = o4.z; origin[b * 4 + 3] = 0.f; }
+    for (int k = tid; k <= H; k += kGridBlock) st[k] = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += kGridBlock) {
+        const float4 q = yb[j];
+        const unsigned h = grid_hash(grid_cell(q.x, o4.x, invh), grid_cell(q.y, o4.y, invh),
+                                     grid_cell(q.z, o4.z, invh), mask);
+        atomicAdd(&st[h + 1], 1);
+    }
+    __syncthreads();
+    // exclusive scan of st[1..H] in place: thread t owns a contiguous slice
+    const int per = (H + kGridBlock - 1) / kGridBlock;
+    const int lo = 1 + tid * per, hi = min(1 + (tid + 1) * per, H + 1);
+    int sum = 0;
+    for (int k = lo; k < hi; ++k) sum += st[k];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int k = 0; k < kGridBlock; ++k) { const int v = part[k]; part[k] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int k = lo; k < hi; ++k) { run += st[k]; st[k] = run; }   // st[k] = #points in buckets < k
+    __syncthreads();
+    for (int k = tid; k < H; k += kGridBlock) cu[k] = st[k];
+    __syncthreads();
+    for (int j = tid; j < n; j += kGridBlock) {
+        const float4 q = yb[j];
+        const unsigned h = grid_hash(grid_cell(q.x, o4.x, invh), grid_cell(q.y, o4.y, invh),
+                                     grid_cell(q.z, o4.z, invh), mask);
+        const int pos = atomicAdd(&cu[h], 1);
+        out[pos] = make_float4(q.x, q.y, q.z, __int_as_float(j));
+    }
+}
 
 // Moments accumulated per iteration (one block reduction, fp64).  With x' = x0 - o and
 // y' = y_nn - o for a per-pair origin o (the first source point; keeps |x'|,|y'| at the cluster
@@ -184,15 +277,19 @@ constexpr int kMoments = 18;
 // (4 waves per CU at Q = 4) as the limiter.  Register budget: 128 VGPRs (4 waves per SIMD),
 // hence the moments are reduced per query slot straight into LDS and the Jacobi state lives
 // in LDS instead of being carried in registers across the scan.
-template <int BLOCK, int Q, int TS>
+// GRID: 0 = all-pairs LDS scan, 1 = exact grid read from global memory (L2), 2 = exact grid staged
+// into LDS at kernel entry (dynamic shared memory: (H+1) ints + n float4)
+template <int BLOCK, int Q, int TS, int GRID>
 __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
     ICPFLOW_STAMP(0);
+    static_assert(!GRID || (Q == 1 && TS == 1), "grid search: one query per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     constexpr int NWAVE = BLOCK / kWave;
     constexpr int NQG = NWAVE / TS;          // query groups
     static_assert((NWAVE % TS == 0 && Q % TS == 0) || TS == 1, "Q slots are dealt round-robin to the TS waves");
-    __shared__ ScanTile tileMem;
-    ScanTile *tile = &tileMem;
+    __shared__ __attribute__((aligned(16))) unsigned char tileMem[GRID ? 16 : sizeof(ScanTile)];
+    ScanTile *tile = reinterpret_cast<ScanTile *>(tileMem);
     __shared__ double red[NWAVE * kMoments];  // per-wave moment sums of the current iteration
     __shared__ double Vsh[9];                 // right singular vectors (Jacobi warm start)
     __shared__ double ksh[17];                // centroids, second moments and H parked across the solve
@@ -263,6 +360,99 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             for (int k = 0; k < kMoments; ++k) red[wave * kMoments + k] = 0.0;
         }
         // ------------- NN + gate + moments (one pass over the source points) ---------------
+        // 18 moments of one query slot, each reduced over the wave on the VALU and added to this
+        // wave's LDS row by lane 0 (non-inliers contribute exact zeros)
+#define ICPFLOW_ACC(k, expr)                                  \
+        {                                                     \
+            const double t_ = wave_sum_uniform(expr);         \
+            if (lane == 0) row[k] += t_;                      \
+        }
+#define ICPFLOW_ACC_ALL()                                                                     \
+        {                                                                                     \
+            double *row = red + wave * kMoments;                                              \
+            ICPFLOW_ACC(0, inl ? 1.0 : 0.0)                                                   \
+            ICPFLOW_ACC(1, ax) ICPFLOW_ACC(2, ay) ICPFLOW_ACC(3, az)                          \
+            ICPFLOW_ACC(4, bx) ICPFLOW_ACC(5, by) ICPFLOW_ACC(6, bz)                          \
+            ICPFLOW_ACC(7, ax * bx) ICPFLOW_ACC(8, ax * by) ICPFLOW_ACC(9, ax * bz)           \
+            ICPFLOW_ACC(10, ay * bx) ICPFLOW_ACC(11, ay * by) ICPFLOW_ACC(12, ay * bz)        \
+            ICPFLOW_ACC(13, az * bx) ICPFLOW_ACC(14, az * by) ICPFLOW_ACC(15, az * bz)        \
+            ICPFLOW_ACC(16, ax * ax + ay * ay + az * az)                                      \
+            ICPFLOW_ACC(17, bx * bx + by * by + bz * bz)                                      \
+        }
+        if constexpr (GRID != 0) {
+            const float4 *gpG = p.gridPts + (size_t)b * p.N;
+            const int32_t *gsG = p.gridStart + (size_t)b * (p.gridH + 1);
+            // LDS copies (GRID == 2): staged once per launch, before the first iteration
+            int32_t *gsL = reinterpret_cast<int32_t *>(dynLds);
+            float4 *gpL = reinterpret_cast<float4 *>(dynLds + (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16);
+            if (GRID == 2 && it == itBegin) {
+                for (int k = tid; k <= p.gridH; k += BLOCK) gsL[k] = gsG[k];
+                for (int k = tid; k < yc.n; k += BLOCK) gpL[k] = gpG[k];
+                __syncthreads();
+            }
+            const float gox = p.gridOrigin[b * 4 + 0], goy = p.gridOrigin[b * 4 + 1], goz = p.gridOrigin[b * 4 + 2];
+            const unsigned mask = (unsigned)p.gridH - 1u;
+            const int ngr = (xc.n + BLOCK - 1) / BLOCK;
+            for (int g = 0; g < ngr; ++g) {
+                const int i = g * BLOCK + tid;
+                float x0x = 0.f, x0y = 0.f, x0z = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+                float bd = kInf, ynx = 0.f, yny = 0.f, ynz = 0.f;
+                int bj = 0x7fffffff;
+                ICPFLOW_STAMP(1);
+                if (i < xc.n && yc.n > 0) {
+                    float rx, ry, rz;
+                    cloud_load(xc, i, rx, ry, rz);
+                    xf_apply(pre, rx, ry, rz, x0x, x0y, x0z);  // utils_icp.py:21
+                    qx = fmaf(x0z, Rf[6], fmaf(x0y, Rf[3], x0x * Rf[0])) + Tf[0];  // :177, :395
+                    qy = fmaf(x0z, Rf[7], fmaf(x0y, Rf[4], x0x * Rf[1])) + Tf[1];
+                    qz = fmaf(x0z, Rf[8], fmaf(x0y, Rf[5], x0x * Rf[2])) + Tf[2];
+                    const int cx = grid_cell(qx, gox, p.gridInvH), cy = grid_cell(qy, goy, p.gridInvH),
+                              cz = grid_cell(qz, goz, p.gridInvH);
+                    // One z-plane of 9 cells at a time: first all nine (start, count) look-ups, then
+                    // rounds r = 0, 1, ... in which every non-exhausted cell contributes its r-th
+                    // point.  All loads of a round are unconditional (an exhausted cell re-reads
+                    // slot 0 and its distance is discarded), so they are in flight together instead
+                    // of forming a chain of dependent LDS/L2 round trips.
+                    for (int dz = -1; dz <= 1; ++dz) {
+                        int s9[9], c9[9], maxc = 0;
+#pragma unroll
+                        for (int u = 0; u < 9; ++u) {
+                            const unsigned h = grid_hash(cx + (u % 3) - 1, cy + (u / 3) - 1, cz + dz, mask);
+                            const int sb = (GRID == 2) ? gsL[h] : gsG[h];
+                            const int eb = (GRID == 2) ? gsL[h + 1] : gsG[h + 1];
+                            s9[u] = sb;
+                            c9[u] = eb - sb;
+                            maxc = max(maxc, eb - sb);
+                        }
+                        for (int r = 0; r < maxc; ++r) {
+                            float4 t9[9];
+#pragma unroll
+                            for (int u = 0; u < 9; ++u) {
+                                const int k = (r < c9[u]) ? s9[u] + r : 0;
+                                t9[u] = (GRID == 2) ? gpL[k] : gpG[k];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 9; ++u) {
+                                const float d = (r < c9[u]) ? sqdist(qx, qy, qz, t9[u].x, t9[u].y, t9[u].z) : kInf;
+                                const int j = __float_as_int(t9[u].w);
+                                if (d < bd || (d == bd && j < bj && d < kInf)) {
+                                    bd = d; bj = j; ynx = t9[u].x; yny = t9[u].y; ynz = t9[u].z;
+                                }
+                            }
+                        }
+                    }
+                }
+                ICPFLOW_STAMP(2);
+                const bool inl = (i < xc.n) && (bd <= p.thr2);  // :160-161
+                double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0;
+                if (inl) {
+                    ax = (double)(x0x - ox); ay = (double)(x0y - oy); az = (double)(x0z - oz);
+                    bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
+                }
+                ICPFLOW_STAMP(10);
+                ICPFLOW_ACC_ALL()
+            }
+        } else {
         for (int g = 0; g < ngroups; ++g) {
             ScanAcc<Q> acc;
             float qx[Q], qy[Q], qz[Q];
@@ -319,25 +509,12 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
                 }
                 ICPFLOW_STAMP(10);
-                // 18 moments, each reduced over the wave on the VALU and added to this wave's
-                // LDS row by lane 0 (non-inliers contribute exact zeros)
-                double *row = red + wave * kMoments;
-#define ICPFLOW_ACC(k, expr)                                  \
-                {                                             \
-                    const double t_ = wave_sum_uniform(expr); \
-                    if (lane == 0) row[k] += t_;              \
-                }
-                ICPFLOW_ACC(0, inl ? 1.0 : 0.0)
-                ICPFLOW_ACC(1, ax) ICPFLOW_ACC(2, ay) ICPFLOW_ACC(3, az)
-                ICPFLOW_ACC(4, bx) ICPFLOW_ACC(5, by) ICPFLOW_ACC(6, bz)
-                ICPFLOW_ACC(7, ax * bx) ICPFLOW_ACC(8, ax * by) ICPFLOW_ACC(9, ax * bz)
-                ICPFLOW_ACC(10, ay * bx) ICPFLOW_ACC(11, ay * by) ICPFLOW_ACC(12, ay * bz)
-                ICPFLOW_ACC(13, az * bx) ICPFLOW_ACC(14, az * by) ICPFLOW_ACC(15, az * bz)
-                ICPFLOW_ACC(16, ax * ax + ay * ay + az * az)
-                ICPFLOW_ACC(17, bx * bx + by * by + bz * bz)
-#undef ICPFLOW_ACC
+                ICPFLOW_ACC_ALL()
             }
         }
+        }
+#undef ICPFLOW_ACC_ALL
+#undef ICPFLOW_ACC
         ICPFLOW_STAMP(3);
         __syncthreads();  // every wave's row is complete
         ICPFLOW_STAMP(4);
@@ -467,10 +644,11 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
     }
 }
 
-template <int BLOCK, int Q, int TS>
+template <int BLOCK, int Q, int TS, int GRID>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
-    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS>), dim3(B), dim3(BLOCK), 0, s, p, itBegin, itEnd);
+    const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16 : 0;
+    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID>), dim3(B), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
 }
 
 // ---- optional per-launch timing of this (dominant) kernel with HIP events ---------------------
@@ -527,18 +705,23 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
 {
     const bool timed = g_prof.used < (int)g_prof.start.size();
     if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
-    // queries per pass = (BLOCK/64/TS) * 64 * Q
-    if (p.N <= 256) launch_icp_variant<256, 2, 2>(p, B, itBegin, itEnd, s);         // 256
-    else if (p.N <= 512) launch_icp_variant<512, 2, 2>(p, B, itBegin, itEnd, s);    // 512
-    else if (p.N <= 1024) launch_icp_variant<1024, 4, 4>(p, B, itBegin, itEnd, s);  // 1024
-    else launch_icp_variant<1024, 4, 2>(p, B, itBegin, itEnd, s);                   // 2048 per pass
+    if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
+        if (p.N <= 256) launch_icp_variant<256, 1, 1, 2>(p, B, itBegin, itEnd, s);
+        else if (p.N <= 2048) launch_icp_variant<1024, 1, 1, 2>(p, B, itBegin, itEnd, s);
+        else launch_icp_variant<1024, 1, 1, 1>(p, B, itBegin, itEnd, s);
+    } else {                     // all-pairs LDS scan; queries per pass = (BLOCK/64/TS) * 64 * Q
+        if (p.N <= 256) launch_icp_variant<256, 2, 2, 0>(p, B, itBegin, itEnd, s);         // 256
+        else if (p.N <= 512) launch_icp_variant<512, 2, 2, 0>(p, B, itBegin, itEnd, s);    // 512
+        else if (p.N <= 1024) launch_icp_variant<1024, 4, 4, 0>(p, B, itBegin, itEnd, s);  // 1024
+        else launch_icp_variant<1024, 4, 2, 0>(p, B, itBegin, itEnd, s);                   // 2048 per pass
+    }
     if (timed) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
 }
 
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      hipStream_t s)
+                      const GridScratch *grid, hipStream_t s)
 {
     IcpParams p{};
     p.X = X; p.Y = Y; p.lenX = lenX; p.lenY = lenY; p.swap = swap; p.prePose = prePose; p.N = N;
@@ -547,6 +730,14 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(IcpCtrl), s);
     if (e != hipSuccess) return e;
+    if (grid != nullptr) {
+        // bin the fixed cloud once: cell edge 1 % above the gate radius (rounding head-room)
+        const float invh = (float)(1.0 / (1.01 * thres));
+        hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(kGridBlock), 0, s, X, Y, lenX, lenY, swap, N,
+                           grid->H, invh, grid->origin, grid->start, grid->cursor, (float4 *)grid->pts);
+        p.gridPts = (const float4 *)grid->pts; p.gridStart = grid->start; p.gridOrigin = grid->origin;
+        p.gridH = grid->H; p.gridInvH = invh;
+    }
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {
         for (int it = 0; it < maxIter; ++it) launch_icp_iters(p, B, it, it + 1, s);
     } else {

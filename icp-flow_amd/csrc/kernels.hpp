@@ -64,10 +64,18 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
                           int64_t *idx, float *dist, hipStream_t s);
 
 // icp.hip
+struct GridScratch {   // exact-grid NN search of the ICP loop (see icp.hip)
+    int H;             // buckets per pair, power of two >= 2N
+    float *origin;     // [B,4]
+    int32_t *start;    // [B,H+1]
+    int32_t *cursor;   // [B,H]
+    float *pts;        // [B,N,4]
+};
+int grid_buckets(int N);
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      hipStream_t s);
+                      const GridScratch *grid, hipStream_t s);
 hipError_t profile_enable(int capacity);
 hipError_t profile_collect(double *total_ms, int *launches);
 hipError_t launch_icp_export(const IcpState *state, const IcpCtrl *ctrl, int B, int stopMode, float *R,

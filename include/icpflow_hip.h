@@ -205,6 +205,19 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
                        size_t ws_bytes, icpflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Correspondence search used inside the ICP loop (process-global tuning knob, results are
+ * bit-identical in every mode):
+ *   ICPFLOW_SEARCH_AUTO (0)   exact grid when N >= 64, else the all-pairs scan
+ *   ICPFLOW_SEARCH_SCAN (1)   all-pairs LDS-tiled scan of the fixed cloud every iteration
+ *   ICPFLOW_SEARCH_GRID (2)   exact hashed uniform grid of the fixed cloud, built once per
+ *                             registration: only the 27 cells within the gate radius are evaluated
+ * ------------------------------------------------------------------------- */
+#define ICPFLOW_SEARCH_AUTO 0
+#define ICPFLOW_SEARCH_SCAN 1
+#define ICPFLOW_SEARCH_GRID 2
+int icpflow_set_icp_search(int mode);
+
+/* ---------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): per-launch timing of the dominant kernel,
  * the ICP iteration.  After icpflow_profile_enable(capacity) every launch of that kernel
  * (up to `capacity` of them) is bracketed by HIP events recorded on the caller's stream;

@@ -20,7 +20,19 @@ from icp_flow_amd import hist as hip_hist  # noqa: E402
 from icp_flow_amd import utils_helper, utils_hist, utils_icp, utils_icp_pytorch3d, utils_match  # noqa: E402
 from oracle import reference_path as rp  # noqa: E402
 
+from icp_flow_amd import _lib  # noqa: E402
+
 DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True, params=["scan", "grid"])
+def icp_search_mode(request):
+    """Every test runs with both correspondence searches of the ICP loop: the all-pairs LDS scan
+    and the exact hashed grid must be indistinguishable (same tolerances, same iteration counts)."""
+    _lib.set_icp_search(request.param)
+    yield request.param
+    _lib.set_icp_search("auto")
+
 TOL_M = 1e-4      # metres, on translations and moved points
 
 
@@ -237,6 +249,24 @@ def test_icp_vs_fp64_evaluation_of_the_oracle(case):
     np.testing.assert_allclose(got.RTs.R.cpu().numpy()[ok], want.R.numpy()[ok], atol=TOL_R_HP, rtol=0)
     v = (X[:, :, 3] > 0) & ok[:, None]
     np.testing.assert_allclose(got.Xt.cpu().numpy()[v], want.Xt.numpy()[v], atol=TOL_M_HP, rtol=0)
+
+
+def test_grid_and_scan_searches_are_bit_identical():
+    """Same gate decisions and neighbours => bit-identical R, T, rmse and iteration count."""
+    S, D, Tt = synthetic.make_batch(12, 700, seed=123, ragged=True)
+    src, dst = C(S), C(D)
+    for i in range(12):
+        v = src[i, :, 3] > 0
+        Ti = C(Tt[i])
+        src[i, v, 0:3] = src[i, v, 0:3] @ Ti[:3, :3].T + Ti[:3, 3] + torch.tensor([0.04, -0.03, 0.02])
+    out = {}
+    for mode in ("scan", "grid"):
+        _lib.set_icp_search(mode)
+        sol = utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV))
+        out[mode] = (sol.RTs.R.cpu().numpy(), sol.RTs.T.cpu().numpy(), sol.rmse.cpu().numpy(), sol.converged.iterations)
+    assert out["scan"][3] == out["grid"][3]
+    for a, b in zip(out["scan"][:3], out["grid"][:3]):
+        assert np.array_equal(a, b)
 
 
 def test_icp_per_pair_stop_stays_within_tolerance():
