@@ -64,12 +64,12 @@ def call(name, *args):
         raise RuntimeError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
 
 
-SEARCH_AUTO, SEARCH_SCAN, SEARCH_GRID = 0, 1, 2
+SEARCH_AUTO, SEARCH_SCAN, SEARCH_GRID, SEARCH_SWEEP = 0, 1, 2, 3
 
 
 def set_icp_search(mode):
-    """'auto' | 'scan' | 'grid' (or 0/1/2): correspondence search inside the ICP loop."""
-    mode = {"auto": 0, "scan": 1, "grid": 2}.get(mode, mode)
+    """'auto' | 'scan' | 'grid' | 'sweep' (or 0..3): correspondence search inside the ICP loop."""
+    mode = {"auto": 0, "scan": 1, "grid": 2, "sweep": 3}.get(mode, mode)
     call("icpflow_set_icp_search", int(mode))
 
 

@@ -33,9 +33,9 @@ int hipfail(hipError_t e, const char *what)
         if (e__ != hipSuccess) return hipfail(e__, #expr); \
     } while (0)
 
-// ICP correspondence search: 0 = auto, 1 = all-pairs LDS scan, 2 = exact grid (icp.hip)
+// ICP correspondence search: 0 = auto, 1 = all-pairs LDS scan, 2 = exact hashed grid,
+// 3 = sorted sweep (icp.hip)
 int g_icp_search = 0;
-bool use_grid(int N) { return g_icp_search == 2 || (g_icp_search == 0 && N >= 64); }
 
 constexpr size_t kAlign = 256;
 size_t up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
@@ -83,9 +83,21 @@ struct Workspace {
         grid.start = (int32_t *)take(b * ((size_t)grid.H + 1) * 4);
         grid.cursor = (int32_t *)take(b * (size_t)grid.H * 4);
         grid.pts = (float *)take(b * (size_t)N * 16);
+        grid.sortX = (float *)take(b * (size_t)N * 16);
+        grid.axis = (int32_t *)take(b * 4);
         bytes = off;
     }
 };
+
+const GridScratch *search_scratch(Workspace &w, int N)
+{
+    int mode = g_icp_search;
+    if (mode == 0) mode = (N >= 64 && N <= 4096) ? 3 : 1;
+    if (mode == 3 && N > 4096) mode = 1;   // sorted fixed cloud must fit LDS
+    if (mode == 1) return nullptr;
+    w.grid.mode = mode;
+    return &w.grid;
+}
 
 int check_ws(void *ws, size_t have, size_t need)
 {
@@ -111,12 +123,12 @@ int check_hist_dims(const char *fn, int lx, int ly, int lz)
 }
 
 // shared tail of apply_icp / hist_icp: ICP from Tinit, compose, check, select
-int run_icp_and_select(const float *src, const float *dst, const Workspace &w, const uint8_t *swap,
+int run_icp_and_select(const float *src, const float *dst, Workspace &w, const uint8_t *swap,
                        const float *init, int B, int N, double thres, int maxIter, double relThr,
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, hipStream_t s)
 {
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, use_grid(N) ? &w.grid : nullptr, s));
+                           w.state, w.ctrl, search_scratch(w, N), s));
     if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
     ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
@@ -157,7 +169,7 @@ size_t icpflow_workspace_bytes(int B, int N, int Lx, int Ly, int Lz)
 
 int icpflow_set_icp_search(int mode)
 {
-    if (mode < 0 || mode > 2) return fail(ICPFLOW_E_ARG, "icpflow_set_icp_search: mode must be 0, 1 or 2 (got %d)", mode);
+    if (mode < 0 || mode > 3) return fail(ICPFLOW_E_ARG, "icpflow_set_icp_search: mode must be 0..3 (got %d)", mode);
     g_icp_search = mode;
     return 0;
 }
@@ -285,7 +297,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     launch_count_valid(d_X, B, N, w.lenA, s);
     launch_count_valid(d_Y, B, N, w.lenC, s);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
-                           relative_rmse_thr, stop_mode, w.state, w.ctrl, use_grid(N) ? &w.grid : nullptr, s));
+                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N), s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
     return 0;
 }

@@ -160,6 +160,12 @@ struct IcpParams {
     const float *gridOrigin; // [B,4]   cell origin (the first fixed-cloud point)
     int gridH;               // buckets per pair (power of two)
     float gridInvH;          // 1 / cell edge
+    // sorted sweep (SWEEP kernels): both clouds sorted once per registration along the fixed
+    // cloud's longest axis by sort_clouds_kernel; w = original index bits
+    const float4 *sortX;     // [B,N] moving cloud, pre-pose already applied
+    const float4 *sortY;     // [B,N] fixed cloud
+    const int32_t *sortAxis; // [B]
+    float sweepMargin;       // window half-width beyond the wave's query span (1.01 * thres)
 };
 
 #ifdef ICPFLOW_PHASE_TIMING
@@ -257,6 +263,131 @@ __global__ __launch_bounds__(kGridBlock) void grid_build_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Sorted sweep: exact gated nearest neighbour with BROADCAST target reads.
+//
+// Both clouds are sorted once per registration along the longest axis a of the fixed cloud.
+// In every iteration a wave (64 consecutive sorted queries) computes the span [lo, hi] of its
+// CURRENT query coordinates along a (exact, from the moved points) and scans only the fixed
+// points with coordinate in [lo - m, hi + m], m = 1.01 * thres: a contiguous range of the sorted
+// array, read through LDS at one address for the whole wave (the same broadcast scan core as the
+// all-pairs search, just over ~1/10 of the targets).  A point outside that window is farther than
+// the gate radius from every query of the wave, so gate decisions and gated neighbours are the
+// ones of the all-pairs search; equal-distance ties are resolved to the lowest ORIGINAL index.
+// ---------------------------------------------------------------------------------
+constexpr int kSortBlock = 256;
+
+// grid (B, 2): blockIdx.y == 0 sorts the fixed cloud, 1 the moving cloud (pre-pose applied)
+__global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const int32_t *__restrict__ lenX,
+    const int32_t *__restrict__ lenY, const uint8_t *__restrict__ swap, const float *__restrict__ prePose,
+    int N, int NP2, int32_t *__restrict__ axisOut, float4 *__restrict__ Xs, float4 *__restrict__ Ys)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
+    float *key = reinterpret_cast<float *>(dynLds);
+    int *idx = reinterpret_cast<int *>(dynLds + sizeof(float) * NP2);
+    __shared__ float bb[6 * (kSortBlock / kWave)];
+    __shared__ int axisSh;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool moving = blockIdx.y == 1;
+    const bool sw = swap != nullptr && swap[b] != 0;
+    const float4 *xb = reinterpret_cast<const float4 *>(sw ? Y : X) + (size_t)b * N;  // moving role
+    const float4 *yb = reinterpret_cast<const float4 *>(sw ? X : Y) + (size_t)b * N;  // fixed role
+    const int nx = (sw ? lenY : lenX)[b], ny = (sw ? lenX : lenY)[b];
+    // axis of largest extent of the fixed cloud (both blocks compute it the same way)
+    float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
+    for (int j = tid; j < ny; j += kSortBlock) {
+        const float4 q = yb[j];
+        mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+        mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], o, kWave));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o, kWave));
+        }
+    if ((tid & (kWave - 1)) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { bb[(tid >> 6) * 6 + k] = mn[k]; bb[(tid >> 6) * 6 + 3 + k] = mx[k]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float e[3];
+        for (int k = 0; k < 3; ++k) {
+            float lo = bb[k], hi = bb[3 + k];
+            for (int w = 1; w < kSortBlock / kWave; ++w) { lo = fminf(lo, bb[w * 6 + k]); hi = fmaxf(hi, bb[w * 6 + 3 + k]); }
+            e[k] = hi - lo;
+        }
+        const int a = (e[0] >= e[1] && e[0] >= e[2]) ? 0 : (e[1] >= e[2] ? 1 : 2);
+        axisSh = a;
+        if (!moving) axisOut[b] = a;
+    }
+    __syncthreads();
+    const int axis = axisSh;
+    const int n = moving ? nx : ny;
+    const float4 *cloud = moving ? xb : yb;
+    PointXf pre;
+    pre.kind = (moving && prePose) ? XF_AFFINE : XF_NONE;
+    pre.a = (moving && prePose) ? affine_from_pose(prePose + (size_t)b * 16) : affine_identity();
+    for (int j = tid; j < NP2; j += kSortBlock) {
+        float k = kInf;
+        if (j < n) {
+            const float4 q = cloud[j];
+            float px, py, pz;
+            xf_apply(pre, q.x, q.y, q.z, px, py, pz);
+            k = axis == 0 ? px : (axis == 1 ? py : pz);
+        }
+        key[j] = k;
+        idx[j] = j;
+    }
+    __syncthreads();
+    // bitonic sort of (key, idx) pairs, ascending; ties by index so the order is deterministic
+    for (int k = 2; k <= NP2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < NP2; i += kSortBlock) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float ki = key[i], kl = key[l];
+                    const int ii = idx[i], il = idx[l];
+                    const bool up = (i & k) == 0;
+                    const bool gt = ki > kl || (ki == kl && ii > il);
+                    if (gt == up) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float4 *out = (moving ? Xs : Ys) + (size_t)b * N;
+    for (int r = tid; r < n; r += kSortBlock) {
+        const int j = idx[r];
+        const float4 q = cloud[j];
+        float px, py, pz;
+        xf_apply(pre, q.x, q.y, q.z, px, py, pz);
+        out[r] = make_float4(px, py, pz, __int_as_float(j));
+    }
+}
+
+// number of sorted keys (LDS, ascending, n of them) that are < v (strict) or <= v: two
+// 64-way ballot steps instead of a dependent binary search.  Wave-uniform result.
+template <bool INCLUSIVE>
+__device__ __forceinline__ int sorted_count_below(const float *__restrict__ key, int n, float v, int lane)
+{
+    const int step = (n + kWave - 1) / kWave;  // <= 64 for n <= 4096
+    if (step == 0) return 0;
+    const int s0 = lane * step;
+    const float k0 = s0 < n ? key[s0] : kInf;
+    const unsigned long long m0 = __ballot(INCLUSIVE ? (k0 <= v) : (k0 < v));
+    const int cnt = __popcll(m0);
+    if (cnt == 0) return 0;
+    const int base = (cnt - 1) * step;
+    const int s1 = base + lane;
+    const float k1 = (lane < step && s1 < n) ? key[s1] : kInf;
+    const unsigned long long m1 = __ballot(INCLUSIVE ? (k1 <= v) : (k1 < v));
+    return base + __popcll(m1);
+}
+
 // Moments accumulated per iteration (one block reduction, fp64).  With x' = x0 - o and
 // y' = y_nn - o for a per-pair origin o (the first source point; keeps |x'|,|y'| at the cluster
 // extent so that the raw-moment identities below lose nothing in fp64):
@@ -278,7 +409,8 @@ constexpr int kMoments = 18;
 // hence the moments are reduced per query slot straight into LDS and the Jacobi state lives
 // in LDS instead of being carried in registers across the scan.
 // GRID: 0 = all-pairs LDS scan, 1 = exact grid read from global memory (L2), 2 = exact grid staged
-// into LDS at kernel entry (dynamic shared memory: (H+1) ints + n float4)
+// into LDS at kernel entry (dynamic shared memory: (H+1) ints + n float4), 3 = sorted sweep
+// (dynamic shared memory: the whole sorted fixed cloud as three float arrays)
 template <int BLOCK, int Q, int TS, int GRID>
 __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
@@ -379,7 +511,84 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             ICPFLOW_ACC(16, ax * ax + ay * ay + az * az)                                      \
             ICPFLOW_ACC(17, bx * bx + by * by + bz * bz)                                      \
         }
-        if constexpr (GRID != 0) {
+        if constexpr (GRID == 3) {
+            const int np16 = (yc.n + kChunk - 1) / kChunk * kChunk;
+            const int NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
+            float *sxf = reinterpret_cast<float *>(dynLds);
+            float *syf = sxf + NP16;
+            float *szf = syf + NP16;
+            const float4 *ys = p.sortY + (size_t)b * p.N;
+            const float4 *xs = p.sortX + (size_t)b * p.N;
+            const int axis = p.sortAxis[b];
+            if (it == itBegin) {  // stage the sorted fixed cloud once per launch (+inf tail)
+                for (int k = tid; k < np16; k += BLOCK) {
+                    float4 t = make_float4(kInf, kInf, kInf, 0.f);
+                    if (k < yc.n) t = ys[k];
+                    sxf[k] = t.x; syf[k] = t.y; szf[k] = t.z;
+                }
+                __syncthreads();
+            }
+            const float *keyf = axis == 0 ? sxf : (axis == 1 ? syf : szf);
+            const float4 *sx4 = reinterpret_cast<const float4 *>(sxf);
+            const float4 *sy4 = reinterpret_cast<const float4 *>(syf);
+            const float4 *sz4 = reinterpret_cast<const float4 *>(szf);
+            const int ngr = (xc.n + BLOCK - 1) / BLOCK;
+            for (int g = 0; g < ngr; ++g) {
+                const int i = g * BLOCK + tid;
+                const bool live = i < xc.n;
+                float x0x = 0.f, x0y = 0.f, x0z = 0.f;
+                float qx[1] = {0.f}, qy[1] = {0.f}, qz[1] = {0.f};
+                ICPFLOW_STAMP(1);
+                if (live) {
+                    const float4 s4 = xs[i];   // sorted, pre-pose already applied (utils_icp.py:21)
+                    x0x = s4.x; x0y = s4.y; x0z = s4.z;
+                    qx[0] = fmaf(x0z, Rf[6], fmaf(x0y, Rf[3], x0x * Rf[0])) + Tf[0];  // :177, :395
+                    qy[0] = fmaf(x0z, Rf[7], fmaf(x0y, Rf[4], x0x * Rf[1])) + Tf[1];
+                    qz[0] = fmaf(x0z, Rf[8], fmaf(x0y, Rf[5], x0x * Rf[2])) + Tf[2];
+                }
+                // span of this wave's live queries along the sort axis
+                const float qa = axis == 0 ? qx[0] : (axis == 1 ? qy[0] : qz[0]);
+                float lo = live ? qa : kInf, hi = live ? qa : -kInf;
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) {
+                    lo = fminf(lo, __shfl_xor(lo, o, kWave));
+                    hi = fmaxf(hi, __shfl_xor(hi, o, kWave));
+                }
+                ScanAcc<1> acc;
+                bool tie[1] = {false};
+                scan_init(acc);
+                int cb = 0, ce = 0;
+                if (lo <= hi) {  // wave has live queries
+                    const int jlo = sorted_count_below<false>(keyf, yc.n, lo - p.sweepMargin, lane);
+                    const int jhi = sorted_count_below<true>(keyf, yc.n, hi + p.sweepMargin, lane);
+                    cb = (jlo / kChunk) * kChunk;
+                    ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
+                    scan_range_tie<1>(sx4, sy4, sz4, cb, ce, qx, qy, qz, acc, tie);
+                }
+                ICPFLOW_STAMP(2);
+                const bool inl = live && (acc.best[0] <= p.thr2);  // :160-161
+                double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0;
+                if (inl) {
+                    // neighbour = lowest ORIGINAL index among the targets at distance `best`:
+                    // inside the winning chunk, or (bit-equal minima in several chunks: rare)
+                    // over the whole window
+                    const int r0 = tie[0] ? cb : acc.chunk[0];
+                    const int r1 = tie[0] ? ce : acc.chunk[0] + kChunk;
+                    int bj = 0x7fffffff;
+                    float ynx = 0.f, yny = 0.f, ynz = 0.f;
+                    for (int k = r0; k < min(r1, yc.n); ++k) {
+                        const float4 t = ys[k];
+                        const float d = sqdist(qx[0], qy[0], qz[0], t.x, t.y, t.z);
+                        const int j = __float_as_int(t.w);
+                        if (d == acc.best[0] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
+                    }
+                    ax = (double)(x0x - ox); ay = (double)(x0y - oy); az = (double)(x0z - oz);
+                    bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
+                }
+                ICPFLOW_STAMP(10);
+                ICPFLOW_ACC_ALL()
+            }
+        } else if constexpr (GRID != 0) {
             const float4 *gpG = p.gridPts + (size_t)b * p.N;
             const int32_t *gsG = p.gridStart + (size_t)b * (p.gridH + 1);
             // LDS copies (GRID == 2): staged once per launch, before the first iteration
@@ -647,7 +856,8 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
 template <int BLOCK, int Q, int TS, int GRID>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
-    const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16 : 0;
+    const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
+                       : (GRID == 3) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 : 0;
     hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID>), dim3(B), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
 }
 
@@ -705,7 +915,10 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
 {
     const bool timed = g_prof.used < (int)g_prof.start.size();
     if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
-    if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
+    if (p.sortY != nullptr) {    // sorted sweep (N <= 4096: sorted fixed cloud resident in LDS)
+        if (p.N <= 256) launch_icp_variant<256, 1, 1, 3>(p, B, itBegin, itEnd, s);
+        else launch_icp_variant<1024, 1, 1, 3>(p, B, itBegin, itEnd, s);
+    } else if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 2>(p, B, itBegin, itEnd, s);
         else if (p.N <= 2048) launch_icp_variant<1024, 1, 1, 2>(p, B, itBegin, itEnd, s);
         else launch_icp_variant<1024, 1, 1, 1>(p, B, itBegin, itEnd, s);
@@ -730,7 +943,14 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(IcpCtrl), s);
     if (e != hipSuccess) return e;
-    if (grid != nullptr) {
+    if (grid != nullptr && grid->mode == 3) {
+        int NP2 = 64;
+        while (NP2 < N) NP2 <<= 1;
+        hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY,
+                           swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts);
+        p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
+        p.sweepMargin = (float)(1.01 * thres);
+    } else if (grid != nullptr) {
         // bin the fixed cloud once: cell edge 1 % above the gate radius (rounding head-room)
         const float invh = (float)(1.0 / (1.01 * thres));
         hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(kGridBlock), 0, s, X, Y, lenX, lenY, swap, N,

@@ -64,12 +64,15 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
                           int64_t *idx, float *dist, hipStream_t s);
 
 // icp.hip
-struct GridScratch {   // exact-grid NN search of the ICP loop (see icp.hip)
-    int H;             // buckets per pair, power of two >= 2N
-    float *origin;     // [B,4]
-    int32_t *start;    // [B,H+1]
-    int32_t *cursor;   // [B,H]
-    float *pts;        // [B,N,4]
+struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop (see icp.hip)
+    int mode;          // 2 = hashed grid, 3 = sorted sweep
+    int H;             // grid: buckets per pair, power of two >= 2N
+    float *origin;     // grid: [B,4]
+    int32_t *start;    // grid: [B,H+1]
+    int32_t *cursor;   // grid: [B,H]
+    float *pts;        // grid: fixed cloud sorted by bucket; sweep: fixed cloud sorted by axis [B,N,4]
+    float *sortX;      // sweep: moving cloud sorted by axis, pre-pose applied [B,N,4]
+    int32_t *axis;     // sweep: [B]
 };
 int grid_buckets(int N);
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,

@@ -167,6 +167,43 @@ __device__ __forceinline__ int scan_resolve(const CloudView &tg, const PointXf &
     return idx < 0 ? 0 : idx;
 }
 
+// Range scan over an arbitrary SoA image (three float4 arrays in LDS) that also reports
+// whether the running minimum was attained (bit-equal) by more than one chunk: used by the
+// sorted sweep of the ICP loop, where scan order is not index order and the first-index rule
+// has to be restored explicitly in the (rare) tie case.
+template <int Q>
+__device__ __forceinline__ void scan_range_tie(const float4 *__restrict__ sx, const float4 *__restrict__ sy,
+                                               const float4 *__restrict__ sz, int cBegin, int cEnd,
+                                               const float (&qx)[Q], const float (&qy)[Q],
+                                               const float (&qz)[Q], ScanAcc<Q> &acc, bool (&tie)[Q])
+{
+    for (int c = cBegin; c < cEnd; c += kChunk) {
+        float m[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) m[q] = kInf;
+#pragma unroll
+        for (int u = 0; u < kChunk / 4; ++u) {
+            const float4 tx = sx[(c >> 2) + u];  // same address in every lane: broadcast
+            const float4 ty = sy[(c >> 2) + u];
+            const float4 tz = sz[(c >> 2) + u];
+            const v2f txa = {tx.x, tx.y}, txb = {tx.z, tx.w};
+            const v2f tya = {ty.x, ty.y}, tyb = {ty.z, ty.w};
+            const v2f tza = {tz.x, tz.y}, tzb = {tz.z, tz.w};
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const v2f da = sqdist2(qx[q], qy[q], qz[q], txa, tya, tza);
+                const v2f db = sqdist2(qx[q], qy[q], qz[q], txb, tyb, tzb);
+                m[q] = min3f(min3f(m[q], da.x, da.y), db.x, db.y);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (m[q] < acc.best[q]) { acc.best[q] = m[q]; acc.chunk[q] = c; tie[q] = false; }
+            else if (m[q] == acc.best[q]) tie[q] = true;
+        }
+    }
+}
+
 // Full scan of one target cloud for this lane's Q queries.  All threads of the block
 // must call it (it contains barriers).  With TS > 1 the caller's wave scans only share `ts`
 // of every tile (contiguous chunk ranges); the TS partial (best, chunk) results of a query

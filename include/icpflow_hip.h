@@ -207,14 +207,17 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
 /* ---------------------------------------------------------------------------
  * Correspondence search used inside the ICP loop (process-global tuning knob, results are
  * bit-identical in every mode):
- *   ICPFLOW_SEARCH_AUTO (0)   exact grid when N >= 64, else the all-pairs scan
+ *   ICPFLOW_SEARCH_AUTO (0)   sorted sweep when 64 <= N <= 4096, else the all-pairs scan
  *   ICPFLOW_SEARCH_SCAN (1)   all-pairs LDS-tiled scan of the fixed cloud every iteration
  *   ICPFLOW_SEARCH_GRID (2)   exact hashed uniform grid of the fixed cloud, built once per
  *                             registration: only the 27 cells within the gate radius are evaluated
+ *   ICPFLOW_SEARCH_SWEEP (3)  both clouds sorted once along the fixed cloud's longest axis; each
+ *                             wave scans (LDS broadcast) only the window its queries can gate
  * ------------------------------------------------------------------------- */
 #define ICPFLOW_SEARCH_AUTO 0
 #define ICPFLOW_SEARCH_SCAN 1
 #define ICPFLOW_SEARCH_GRID 2
+#define ICPFLOW_SEARCH_SWEEP 3
 int icpflow_set_icp_search(int mode);
 
 /* ---------------------------------------------------------------------------

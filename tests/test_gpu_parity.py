@@ -25,10 +25,11 @@ from icp_flow_amd import _lib  # noqa: E402
 DEV = torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True, params=["scan", "grid"])
+@pytest.fixture(autouse=True, params=["scan", "grid", "sweep"])
 def icp_search_mode(request):
-    """Every test runs with both correspondence searches of the ICP loop: the all-pairs LDS scan
-    and the exact hashed grid must be indistinguishable (same tolerances, same iteration counts)."""
+    """Every test runs with all correspondence searches of the ICP loop: the all-pairs LDS scan,
+    the exact hashed grid and the sorted sweep must be indistinguishable (same tolerances, same
+    iteration counts)."""
     _lib.set_icp_search(request.param)
     yield request.param
     _lib.set_icp_search("auto")
@@ -251,22 +252,29 @@ def test_icp_vs_fp64_evaluation_of_the_oracle(case):
     np.testing.assert_allclose(got.Xt.cpu().numpy()[v], want.Xt.numpy()[v], atol=TOL_M_HP, rtol=0)
 
 
-def test_grid_and_scan_searches_are_bit_identical():
-    """Same gate decisions and neighbours => bit-identical R, T, rmse and iteration count."""
+def test_search_modes_agree():
+    """Same gate decisions and neighbours in every mode.  scan and grid visit the source points
+    in the same order => bit-identical R, T, rmse; the sweep sums the same fp64 moments in sorted
+    order => identical up to the last fp32 bit."""
     S, D, Tt = synthetic.make_batch(12, 700, seed=123, ragged=True)
     src, dst = C(S), C(D)
     for i in range(12):
         v = src[i, :, 3] > 0
         Ti = C(Tt[i])
         src[i, v, 0:3] = src[i, v, 0:3] @ Ti[:3, :3].T + Ti[:3, 3] + torch.tensor([0.04, -0.03, 0.02])
+    dst[3, 5] = dst[3, 4]                    # duplicate target points (distance ties)
+    dst[3, 40] = dst[3, 4]
     out = {}
-    for mode in ("scan", "grid"):
+    for mode in ("scan", "grid", "sweep"):
         _lib.set_icp_search(mode)
         sol = utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV))
         out[mode] = (sol.RTs.R.cpu().numpy(), sol.RTs.T.cpu().numpy(), sol.rmse.cpu().numpy(), sol.converged.iterations)
-    assert out["scan"][3] == out["grid"][3]
+    assert out["scan"][3] == out["grid"][3] == out["sweep"][3]
     for a, b in zip(out["scan"][:3], out["grid"][:3]):
         assert np.array_equal(a, b)
+    np.testing.assert_allclose(out["sweep"][0], out["scan"][0], atol=2e-7, rtol=0)
+    np.testing.assert_allclose(out["sweep"][1], out["scan"][1], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(out["sweep"][2], out["scan"][2], atol=1e-7, rtol=0)
 
 
 def test_icp_per_pair_stop_stays_within_tolerance():
