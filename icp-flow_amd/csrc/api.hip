@@ -2,6 +2,7 @@
 // workspace carving and kernel sequencing.  No device synchronisation anywhere.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.hpp"
@@ -36,6 +37,7 @@ int hipfail(hipError_t e, const char *what)
 // ICP correspondence search: 0 = auto, 1 = all-pairs LDS scan, 2 = exact hashed grid,
 // 3 = sorted sweep (icp.hip)
 int g_icp_search = 0;
+int g_hist_sorted = 1;   // developer knob (ICPFLOW_HIST_SORTED=0 selects the all-pairs vote)
 
 constexpr size_t kAlign = 256;
 size_t up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
@@ -53,6 +55,7 @@ struct Workspace {
     IcpState *state = nullptr;
     IcpCtrl *ctrl = nullptr;
     GridScratch grid{};
+    float *history = nullptr;
     size_t bytes = 0;
 
     Workspace(void *base, int B, int N, size_t L)
@@ -85,6 +88,7 @@ struct Workspace {
         grid.pts = (float *)take(b * (size_t)N * 16);
         grid.sortX = (float *)take(b * (size_t)N * 16);
         grid.axis = (int32_t *)take(b * 4);
+        history = (float *)take(b * (size_t)kHistIters * kHistStride * 4);
         bytes = off;
     }
 };
@@ -128,7 +132,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, hipStream_t s)
 {
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, search_scratch(w, N), s));
+                           w.state, w.ctrl, search_scratch(w, N), w.history, s));
     if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
     ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
@@ -137,13 +141,18 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     return 0;
 }
 
-int run_init_pose(const float *src, const float *dst, const Workspace &w, const uint8_t *swap, int B,
+int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_t *swap, int B,
                   int N, const float *ex, int lx, const float *ey, int ly, const float *ez, int lz,
                   float shift, float *Tout, hipStream_t s)
 {
     const int lens[3] = {lx, ly, lz};
-    // vote with X = dst role, Y = src role (utils_hist.py:69)
-    ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
+    // vote with X = dst role, Y = src role (utils_hist.py:69); z-sorted sweep while a sorted cloud
+    // fits the ballot search (N <= 4096), all-pairs otherwise -- identical bins either way
+    if (N <= 4096 && g_hist_sorted)
+        ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.grid.pts,
+                                            w.grid.sortX, w.bins, s));
+    else
+        ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
     ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,
                                       w.peakVotes, w.peakIdx, s));
     ICPFLOW_TRY(launch_decode_candidates(w.peakIdx, B, ex, ey, ez, lx, ly, lz, shift, w.cand, s));
@@ -156,7 +165,18 @@ int run_init_pose(const float *src, const float *dst, const Workspace &w, const 
 
 extern "C" {
 
-int icpflow_version(void) { return ICPFLOW_VERSION; }
+int icpflow_version(void)
+{
+    static bool once = false;
+    if (!once) {
+        once = true;
+        const char *e = getenv("ICPFLOW_HIST_SORTED");
+        if (e && e[0] == '0') g_hist_sorted = 0;
+        e = getenv("ICPFLOW_ICP_SPECULATIVE");
+        if (e && e[0] == '0') icpflow::g_icp_speculative = 0;
+    }
+    return ICPFLOW_VERSION;
+}
 
 const char *icpflow_last_error(void) { return g_err; }
 
@@ -297,7 +317,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     launch_count_valid(d_X, B, N, w.lenA, s);
     launch_count_valid(d_Y, B, N, w.lenC, s);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
-                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N), s));
+                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N), w.history, s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
     return 0;
 }

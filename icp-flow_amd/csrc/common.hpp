@@ -121,6 +121,47 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+// Bitonic sort of NP2 (power of two) (key, index) pairs held in LDS, ascending by key, ties by
+// index (deterministic).  All threads of the block must call it.
+__device__ __forceinline__ void bitonic_sort_lds(float *key, int *idx, int NP2)
+{
+    const int half = NP2 >> 1;  // one compare-exchange per thread and step
+    for (int k = 2; k <= NP2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < half; t += blockDim.x) {
+                const int i = ((t / j) * (j << 1)) + (t % j);
+                const int l = i + j;
+                const float ki = key[i], kl = key[l];
+                const int ii = idx[i], il = idx[l];
+                const bool up = (i & k) == 0;
+                const bool gt = ki > kl || (ki == kl && ii > il);
+                if (gt == up) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Number of sorted keys (ascending, n <= 4096 of them, `stride` floats apart, in LDS) that are
+// < v (or <= v): two 64-way ballot steps instead of a dependent binary search.  Wave-uniform.
+template <bool INCLUSIVE>
+__device__ __forceinline__ int sorted_count_below(const float *__restrict__ key, int stride, int n, float v,
+                                                  int lane)
+{
+    const int step = (n + kWave - 1) / kWave;
+    if (step == 0) return 0;
+    const int s0 = lane * step;
+    const float k0 = s0 < n ? key[(size_t)s0 * stride] : kInf;
+    const unsigned long long m0 = __ballot(INCLUSIVE ? (k0 <= v) : (k0 < v));
+    const int cnt = __popcll(m0);
+    if (cnt == 0) return 0;
+    const int base = (cnt - 1) * step;
+    const int s1 = base + lane;
+    const float k1 = (lane < step && s1 < n) ? key[(size_t)s1 * stride] : kInf;
+    const unsigned long long m1 = __ballot(INCLUSIVE ? (k1 <= v) : (k1 < v));
+    return base + __popcll(m1);
+}
+
 // Sum K values per thread over the whole block.  `scratch` holds at least
 // (blockDim.x/64)*K elements of T.  On return every thread has the totals in v[].
 // Contains two __syncthreads(); all threads of the block must call it.

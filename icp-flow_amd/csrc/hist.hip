@@ -118,6 +118,140 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------
+// z-sorted vote (fused registration path).  The vote box is thin in z (three 0.1 m bins,
+// utils_hist.py:65), so of the n_x * n_y differences only those with |dz| < 0.1 can vote.
+// Both clouds are sorted by z once (zsort_kernel); a wave of 64 consecutive sorted X rows then
+// visits only the Y rows whose z lies in (z_lo - max_z, z_hi - min_z]: a contiguous range of the
+// staged tile, read at one LDS address per step.  Every (i, j) that can pass the exact box test
+// is still visited and the same test decides the vote: bins are bit-identical.
+// ---------------------------------------------------------------------------------
+constexpr int kZsortBlock = 512;
+
+// grid (B, 2): y = 0 sorts cloud P, y = 1 cloud Q; valid rows (flag > 0) first, ascending z
+__global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__restrict__ P,
+                                                           const float4 *__restrict__ Qc, int N, int NP2,
+                                                           float4 *__restrict__ Ps, float4 *__restrict__ Qs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
+    float *key = reinterpret_cast<float *>(dynLds);
+    int *idx = reinterpret_cast<int *>(dynLds + sizeof(float) * NP2);
+    const int b = blockIdx.x;
+    const float4 *in = (blockIdx.y == 0 ? P : Qc) + (size_t)b * N;
+    float4 *out = (blockIdx.y == 0 ? Ps : Qs) + (size_t)b * N;
+    for (int j = threadIdx.x; j < NP2; j += kZsortBlock) {
+        float k = kInf;
+        if (j < N) {
+            const float4 q = in[j];
+            if (q.w > 0.0f) k = q.z;
+        }
+        key[j] = k;
+        idx[j] = j;
+    }
+    __syncthreads();
+    bitonic_sort_lds(key, idx, NP2);
+    for (int r = threadIdx.x; r < N; r += kZsortBlock) {
+        // rows beyond the valid count carry +inf keys: emit them as invalid rows
+        float4 o = make_float4(0.f, 0.f, kInf, 0.f);
+        if (key[r] < kInf) o = in[idx[r]];
+        out[r] = o;
+    }
+}
+
+__global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
+    const float4 *__restrict__ Xs, const float4 *__restrict__ Ys, const int32_t *__restrict__ nXv,
+    const int32_t *__restrict__ nYv, int N, int len_x, int len_y, int len_z,
+    const float *__restrict__ ex, const float *__restrict__ ey, const float *__restrict__ ez,
+    const uint8_t *__restrict__ swap, int useLds, uint32_t *__restrict__ bins_u32)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *tile = reinterpret_cast<float4 *>(smem);
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + sizeof(float4) * kVoteTile);
+    const int b = blockIdx.y;
+    const bool sw = swap != nullptr && swap[b] != 0;
+    const float4 *xb = (sw ? Ys : Xs) + (size_t)b * N;
+    const float4 *yb = (sw ? Xs : Ys) + (size_t)b * N;
+    const int nx = (sw ? nYv : nXv)[b], ny = (sw ? nXv : nYv)[b];
+    const int row0 = blockIdx.x * kVoteBlock;
+    if (row0 >= nx) return;  // sorted: valid rows first
+    const float min_x = ex[0], max_x = ex[len_x - 1];
+    const float min_y = ey[0], max_y = ey[len_y - 1];
+    const float min_z = ez[0], max_z = ez[len_z - 1];
+    const int L = len_x * len_y * len_z;
+    uint32_t *gb = bins_u32 + (size_t)b * L;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int i = row0 + threadIdx.x;
+    const bool xvalid = i < nx;
+    float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xvalid) xi = xb[i];
+    if (useLds) {
+        for (int k = threadIdx.x; k < L; k += kVoteBlock) lhist[k] = 0u;
+    }
+    const float rx = max_x - min_x, ry = max_y - min_y, rz = max_z - min_z;
+    const float flx = (float)len_x, fly = (float)len_y, flz = (float)len_z;
+    // z window of this wave's rows: y.z in (zlo - max_z, zhi - min_z], widened by a rounding slack
+    float zlo = xvalid ? xi.z : kInf, zhi = xvalid ? xi.z : -kInf;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        zlo = fminf(zlo, __shfl_xor(zlo, o, kWave));
+        zhi = fmaxf(zhi, __shfl_xor(zhi, o, kWave));
+    }
+    const float slack = 1e-3f * (fabsf(max_z) + fabsf(min_z)) + 1e-5f * (fabsf(zlo) + fabsf(zhi)) + 1e-6f;
+    const float wlo = zlo - max_z - slack, whi = zhi - min_z + slack;
+    for (int j0 = 0; j0 < ny; j0 += kVoteTile) {
+        const int tn = min(kVoteTile, ny - j0);
+        __syncthreads();  // previous tile fully consumed (and lhist zeroed)
+        for (int k = threadIdx.x; k < tn; k += kVoteBlock) tile[k] = yb[j0 + k];
+        __syncthreads();
+        if (!(zlo <= zhi)) continue;  // wave without valid rows (wave-uniform)
+        const float *zkey = reinterpret_cast<const float *>(tile) + 2;
+        const int r0 = sorted_count_below<false>(zkey, 4, tn, wlo, lane);
+        const int r1 = sorted_count_below<true>(zkey, 4, tn, whi, lane);
+        if (!xvalid) continue;
+        for (int k = r0; k < r1; ++k) {
+            const float4 t = tile[k];  // same address in every lane: LDS broadcast
+            const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
+            if (vx >= min_x && vx < max_x && vy >= min_y && vy < max_y && vz >= min_z && vz < max_z) {
+                const int px = (int)floorf(((vx - min_x) / rx) * flx);
+                const int py = (int)floorf(((vy - min_y) / ry) * fly);
+                const int pz = (int)floorf(((vz - min_z) / rz) * flz);
+                const int bin = (px * len_y + py) * len_z + pz;
+                if (useLds) atomicAdd(&lhist[bin], 1u);
+                else atomicAdd(&gb[bin], 1u);
+            }
+        }
+    }
+    if (useLds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < L; k += kVoteBlock) {
+            const uint32_t v = lhist[k];
+            if (v) atomicAdd(&gb[k], v);
+        }
+    }
+}
+
+hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t *nX, const int32_t *nY,
+                                   int B, int N, const int lens[3], const float *ex, const float *ey,
+                                   const float *ez, const uint8_t *swap, float *sortX, float *sortY,
+                                   uint32_t *bins_u32, hipStream_t s)
+{
+    const size_t L = (size_t)lens[0] * lens[1] * lens[2];
+    hipError_t e = hipMemsetAsync(bins_u32, 0, sizeof(uint32_t) * L * (size_t)B, s);
+    if (e != hipSuccess) return e;
+    int NP2 = 64;
+    while (NP2 < N) NP2 <<= 1;
+    hipLaunchKernelGGL(zsort_kernel, dim3(B, 2), dim3(kZsortBlock), (size_t)NP2 * 8, s, (const float4 *)X,
+                       (const float4 *)Y, N, NP2, (float4 *)sortX, (float4 *)sortY);
+    const size_t tile_bytes = sizeof(float4) * kVoteTile;
+    const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
+    const int useLds = lds_hist <= 64 * 1024;
+    dim3 grid((N + kVoteBlock - 1) / kVoteBlock, B);
+    hipLaunchKernelGGL(hist_vote_sorted_kernel, grid, dim3(kVoteBlock), useLds ? lds_hist : tile_bytes, s,
+                       (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
+                       ez, swap, useLds, bins_u32);
+    return hipGetLastError();
+}
+
 __global__ void u32_to_f32_kernel(const uint32_t *__restrict__ in, float *__restrict__ out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,30 +298,37 @@ hipError_t launch_u32_to_f32(const uint32_t *in, float *out, size_t n, hipStream
 // One workgroup per pair; the volumes live in global scratch (L2 resident: a demo
 // histogram is 20 KiB, the largest Waymo one 868 KiB) so every size takes the same path.
 // ---------------------------------------------------------------------------------
-constexpr int kPeakBlock = 256;
+constexpr int kPeakBlock = 1024;
 constexpr int kPeakMaxK = 8;
 
-template <typename BinT>
+// MEM = 0: scratch volumes in global memory (any size); MEM = 1: three volumes in dynamic LDS
+// (3 * L * 4 bytes <= 150 KiB, i.e. up to 113 x 113 x 3 bins)
+template <typename BinT, int MEM>
 __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
     const BinT *__restrict__ bins, int Lx, int Ly, int Lz, int k, int radius,
     uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB, float *__restrict__ votes,
     int64_t *__restrict__ idx_out)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[kPeakBlock / kWave];
     __shared__ unsigned long long chosen[kPeakMaxK];
     const int b = blockIdx.x;
     const int L = Lx * Ly * Lz;
     const BinT *h = bins + (size_t)b * L;
-    uint32_t *A = wsA + (size_t)b * L;
-    uint32_t *Bv = wsB + (size_t)b * L;
+    uint32_t *H0 = reinterpret_cast<uint32_t *>(smem);           // MEM = 1: the votes themselves
+    uint32_t *A = MEM ? H0 + L : wsA + (size_t)b * L;
+    uint32_t *Bv = MEM ? H0 + 2 * (size_t)L : wsB + (size_t)b * L;
     const int tid = threadIdx.x;
-
+    if (MEM) {
+        for (int f = tid; f < L; f += kPeakBlock) H0[f] = (uint32_t)h[f];
+        __syncthreads();
+    }
     // pass z: A = max over |dz| <= r of h   (-inf padding == ignore out of range)
     for (int f = tid; f < L; f += kPeakBlock) {
         const int z = f % Lz, base = f - z;
         const int lo = max(0, z - radius), hi = min(Lz - 1, z + radius);
         uint32_t m = 0;
-        for (int q = lo; q <= hi; ++q) m = max(m, (uint32_t)h[base + q]);
+        for (int q = lo; q <= hi; ++q) m = max(m, MEM ? H0[base + q] : (uint32_t)h[base + q]);
         A[f] = m;
     }
     __syncthreads();
@@ -215,7 +356,7 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
         unsigned long long best = 0ull;
         bool have = false;
         for (int f = tid; f < L; f += kPeakBlock) {
-            const uint32_t v = (uint32_t)h[f];
+            const uint32_t v = MEM ? H0[f] : (uint32_t)h[f];
             const uint32_t s = (v == A[f]) ? v : 0u;
             const unsigned long long key =
                 ((unsigned long long)s << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)f);
@@ -243,8 +384,20 @@ static hipError_t launch_peaks_t(const BinT *bins, int B, int Lx, int Ly, int Lz
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
                                  int64_t *idx, hipStream_t s)
 {
-    hipLaunchKernelGGL(hist_peaks_kernel<BinT>, dim3(B), dim3(kPeakBlock), 0, s, bins, Lx, Ly, Lz, k,
-                       (kernel_size - 1) / 2, wsA, wsB, votes, idx);
+    const size_t lds = 3 * sizeof(uint32_t) * (size_t)Lx * Ly * Lz;
+    if (lds <= 150 * 1024) {
+        static bool attr = false;   // dynamic LDS above 64 KiB needs the attribute once per kernel
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_peaks_kernel<BinT, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL((hist_peaks_kernel<BinT, 1>), dim3(B), dim3(kPeakBlock), lds, s, bins, Lx, Ly, Lz, k,
+                           (kernel_size - 1) / 2, wsA, wsB, votes, idx);
+    } else {
+        hipLaunchKernelGGL((hist_peaks_kernel<BinT, 0>), dim3(B), dim3(kPeakBlock), 0, s, bins, Lx, Ly, Lz, k,
+                           (kernel_size - 1) / 2, wsA, wsB, votes, idx);
+    }
     return hipGetLastError();
 }
 

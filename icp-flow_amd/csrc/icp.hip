@@ -58,8 +58,9 @@ __device__ void kabsch_rotation(const double (&Hin)[9], double *Vw, double (&R)[
             const double al = a[p][0] * a[p][0] + a[p][1] * a[p][1] + a[p][2] * a[p][2];
             const double be = a[q][0] * a[q][0] + a[q][1] * a[q][1] + a[q][2] * a[q][2];
             const double ga = a[p][0] * a[q][0] + a[p][1] * a[q][1] + a[p][2] * a[q][2];
-            // converged for this pair of columns: |cos(angle)| <= 1e-15
-            if (ga == 0.0 || ga * ga <= 1e-30 * (al * be)) continue;
+            // converged for this pair of columns: |cos(angle)| <= 1e-12 (the result is rounded to
+            // fp32; with the warm start one or two sweeps get there)
+            if (ga == 0.0 || ga * ga <= 1e-24 * (al * be)) continue;
             rotated = true;
             const double zeta = (be - al) / (2.0 * ga);
             const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -166,12 +167,17 @@ struct IcpParams {
     const float4 *sortY;     // [B,N] fixed cloud
     const int32_t *sortAxis; // [B]
     float sweepMargin;       // window half-width beyond the wave's query span (1.01 * thres)
+    // speculative single-launch execution of the batch-global stop rule (see launch_icp)
+    float *history;          // [kHistIters, B, kHistStride] or NULL
+    int B;
 };
 
 #ifdef ICPFLOW_PHASE_TIMING
 // debug builds only (tools/dbg/phase_timing.py): shader-clock stamps of workgroup 0
 __device__ long long g_phase_stamps[16];
-#define ICPFLOW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamps[k] = clock64(); } while (0)
+__device__ long long g_wave_stamps[16 * 16];   // [wave][k] of workgroup 0
+#define ICPFLOW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamps[k] = clock64(); \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_wave_stamps[(threadIdx.x >> 6) * 16 + (k)] = clock64(); } while (0)
 #else
 #define ICPFLOW_STAMP(k) do { } while (0)
 #endif
@@ -275,7 +281,8 @@ __global__ __launch_bounds__(kGridBlock) void grid_build_kernel(
 // the gate radius from every query of the wave, so gate decisions and gated neighbours are the
 // ones of the all-pairs search; equal-distance ties are resolved to the lowest ORIGINAL index.
 // ---------------------------------------------------------------------------------
-constexpr int kSortBlock = 256;
+constexpr int kSortBlock = 512;
+int g_icp_speculative = 1;   // developer knob (api.hip: ICPFLOW_ICP_SPECULATIVE=0 forces one launch per iteration)
 
 // grid (B, 2): blockIdx.y == 0 sorts the fixed cloud, 1 the moving cloud (pre-pose applied)
 __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
@@ -343,22 +350,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
         idx[j] = j;
     }
     __syncthreads();
-    // bitonic sort of (key, idx) pairs, ascending; ties by index so the order is deterministic
-    for (int k = 2; k <= NP2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < NP2; i += kSortBlock) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const float ki = key[i], kl = key[l];
-                    const int ii = idx[i], il = idx[l];
-                    const bool up = (i & k) == 0;
-                    const bool gt = ki > kl || (ki == kl && ii > il);
-                    if (gt == up) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_lds(key, idx, NP2);
     float4 *out = (moving ? Xs : Ys) + (size_t)b * N;
     for (int r = tid; r < n; r += kSortBlock) {
         const int j = idx[r];
@@ -367,25 +359,6 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
         xf_apply(pre, q.x, q.y, q.z, px, py, pz);
         out[r] = make_float4(px, py, pz, __int_as_float(j));
     }
-}
-
-// number of sorted keys (LDS, ascending, n of them) that are < v (strict) or <= v: two
-// 64-way ballot steps instead of a dependent binary search.  Wave-uniform result.
-template <bool INCLUSIVE>
-__device__ __forceinline__ int sorted_count_below(const float *__restrict__ key, int n, float v, int lane)
-{
-    const int step = (n + kWave - 1) / kWave;  // <= 64 for n <= 4096
-    if (step == 0) return 0;
-    const int s0 = lane * step;
-    const float k0 = s0 < n ? key[s0] : kInf;
-    const unsigned long long m0 = __ballot(INCLUSIVE ? (k0 <= v) : (k0 < v));
-    const int cnt = __popcll(m0);
-    if (cnt == 0) return 0;
-    const int base = (cnt - 1) * step;
-    const int s1 = base + lane;
-    const float k1 = (lane < step && s1 < n) ? key[s1] : kInf;
-    const unsigned long long m1 = __ballot(INCLUSIVE ? (k1 <= v) : (k1 < v));
-    return base + __popcll(m1);
 }
 
 // Moments accumulated per iteration (one block reduction, fp64).  With x' = x0 - o and
@@ -485,23 +458,18 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     const int per = NQG * kWave * Q;         // queries per pass of the workgroup
     const int ngroups = (xc.n + per - 1) / per;
 
+    int specChk = 0;  // speculative mode: first iteration not yet known to be complete-and-unconverged
     for (int it = itBegin; it < itEnd; ++it) {
-        if (p.stopMode == ICPFLOW_STOP_PER_PAIR_ && !active) break;
-        if (lane == 0) {
+        if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) break;
+        double macc[kMoments];  // wave-uniform running totals of this wave's query slots
 #pragma unroll
-            for (int k = 0; k < kMoments; ++k) red[wave * kMoments + k] = 0.0;
-        }
+        for (int k = 0; k < kMoments; ++k) macc[k] = 0.0;
         // ------------- NN + gate + moments (one pass over the source points) ---------------
-        // 18 moments of one query slot, each reduced over the wave on the VALU and added to this
-        // wave's LDS row by lane 0 (non-inliers contribute exact zeros)
-#define ICPFLOW_ACC(k, expr)                                  \
-        {                                                     \
-            const double t_ = wave_sum_uniform(expr);         \
-            if (lane == 0) row[k] += t_;                      \
-        }
+        // 18 moments of one query slot, each reduced over the wave on the VALU (non-inliers
+        // contribute exact zeros) and accumulated wave-uniformly
+#define ICPFLOW_ACC(k, expr) macc[k] += wave_sum_uniform(expr);
 #define ICPFLOW_ACC_ALL()                                                                     \
         {                                                                                     \
-            double *row = red + wave * kMoments;                                              \
             ICPFLOW_ACC(0, inl ? 1.0 : 0.0)                                                   \
             ICPFLOW_ACC(1, ax) ICPFLOW_ACC(2, ay) ICPFLOW_ACC(3, az)                          \
             ICPFLOW_ACC(4, bx) ICPFLOW_ACC(5, by) ICPFLOW_ACC(6, bz)                          \
@@ -559,8 +527,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 scan_init(acc);
                 int cb = 0, ce = 0;
                 if (lo <= hi) {  // wave has live queries
-                    const int jlo = sorted_count_below<false>(keyf, yc.n, lo - p.sweepMargin, lane);
-                    const int jhi = sorted_count_below<true>(keyf, yc.n, hi + p.sweepMargin, lane);
+                    const int jlo = sorted_count_below<false>(keyf, 1, yc.n, lo - p.sweepMargin, lane);
+                    const int jhi = sorted_count_below<true>(keyf, 1, yc.n, hi + p.sweepMargin, lane);
                     cb = (jlo / kChunk) * kChunk;
                     ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
                     scan_range_tie<1>(sx4, sy4, sz4, cb, ce, qx, qy, qz, acc, tie);
@@ -569,18 +537,37 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 const bool inl = live && (acc.best[0] <= p.thr2);  // :160-161
                 double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0;
                 if (inl) {
-                    // neighbour = lowest ORIGINAL index among the targets at distance `best`:
-                    // inside the winning chunk, or (bit-equal minima in several chunks: rare)
-                    // over the whole window
-                    const int r0 = tie[0] ? cb : acc.chunk[0];
-                    const int r1 = tie[0] ? ce : acc.chunk[0] + kChunk;
-                    int bj = 0x7fffffff;
+                    // neighbour = the target at distance `best` (bit-equal re-evaluation from the LDS
+                    // image of the winning chunk).  If several targets tie -- in that chunk or, flagged
+                    // by the scan, in another one -- the lowest ORIGINAL index wins: only then are the
+                    // original indices fetched (w component of the sorted array in global memory).
                     float ynx = 0.f, yny = 0.f, ynz = 0.f;
-                    for (int k = r0; k < min(r1, yc.n); ++k) {
-                        const float4 t = ys[k];
-                        const float d = sqdist(qx[0], qy[0], qz[0], t.x, t.y, t.z);
-                        const int j = __float_as_int(t.w);
-                        if (d == acc.best[0] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
+                    int matches = tie[0] ? 2 : 0;
+                    if (!tie[0]) {
+                        const int c4 = acc.chunk[0] >> 2;
+#pragma unroll
+                        for (int u = 0; u < kChunk / 4; ++u) {
+                            const float4 tx = sx4[c4 + u], ty = sy4[c4 + u], tz = sz4[c4 + u];
+                            const float txs[4] = {tx.x, tx.y, tx.z, tx.w};
+                            const float tys[4] = {ty.x, ty.y, ty.z, ty.w};
+                            const float tzs[4] = {tz.x, tz.y, tz.z, tz.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float d = sqdist(qx[0], qy[0], qz[0], txs[e], tys[e], tzs[e]);
+                                if (d == acc.best[0]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; }
+                            }
+                        }
+                    }
+                    if (matches != 1) {
+                        const int r0 = tie[0] ? cb : acc.chunk[0];
+                        const int r1 = tie[0] ? ce : acc.chunk[0] + kChunk;
+                        int bj = 0x7fffffff;
+                        for (int k = r0; k < min(r1, yc.n); ++k) {
+                            const float4 t = ys[k];
+                            const float d = sqdist(qx[0], qy[0], qz[0], t.x, t.y, t.z);
+                            const int j = __float_as_int(t.w);
+                            if (d == acc.best[0] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
+                        }
                     }
                     ax = (double)(x0x - ox); ay = (double)(x0y - oy); az = (double)(x0z - oz);
                     bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
@@ -724,11 +711,20 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         }
 #undef ICPFLOW_ACC_ALL
 #undef ICPFLOW_ACC
+        if (lane < kMoments) {  // lane k publishes moment k of this wave
+            double mine = 0.0;
+#pragma unroll
+            for (int k = 0; k < kMoments; ++k) mine = (lane == k) ? macc[k] : mine;
+            red[wave * kMoments + lane] = mine;
+        }
         ICPFLOW_STAMP(3);
         __syncthreads();  // every wave's row is complete
         ICPFLOW_STAMP(4);
         // ------------- wave 0 solves for (R, T, rmse) ---------------------------------------
         if (wave == 0) {
+            unsigned long long specTally = 0ull;
+            if (p.history != nullptr && specChk < it)
+                specTally = __hip_atomic_load(&ctrl->tally[specChk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // lane k < 18 sums moment k over the waves; totals are then wave-uniform via readlane
             double mine = 0.0;
             if (lane < kMoments) {
@@ -783,7 +779,27 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             // relative rmse, :195-198 (fp32 like the reference's tensors)
             const float rel = (it == 0) ? 1.0f : (prev - rmse) / prev;
             const bool conv = rel <= p.relThr;  // NaN -> false, :209
-            if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
+            if (p.stopMode == ICPFLOW_STOP_REFERENCE_ && p.history != nullptr) {
+                // speculative mode: record this iteration, publish (arrived, not converged) with one
+                // atomic, and leave once SOME iteration s <= it is known to satisfy the batch rule
+                // (every pair arrived at s, none unconverged).  Nobody ever waits.
+                if (lane == 0) {
+                    float *h = p.history + ((size_t)it * p.B + b) * kHistStride;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) h[k] = Rf[k];
+                    h[9] = Tf[0]; h[10] = Tf[1]; h[11] = Tf[2]; h[12] = rmse;
+                    __hip_atomic_fetch_add(&ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // specTally was loaded before the solve (its latency hides behind the Jacobi sweeps):
+                // it describes iteration specChk <= it - 1
+                if (specChk < it) {
+                    if ((int)(specTally & 0xffffffffull) >= p.B) {   // everybody has been there
+                        if ((specTally >> 32) == 0ull) active = 0;   // the batch stops at specChk
+                        else ++specChk;
+                    }
+                }
+            } else if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
                 if (lane == 0 && !conv) atomicAdd(&ctrl->notconv[it], 1);
             } else {
                 // per-pair rule: retire a pair once its rmse has stopped DEcreasing by more than
@@ -832,6 +848,38 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     }
 }
 
+// speculative mode epilogue: the reference's stopping iteration is the first one at which every
+// pair had arrived and none was unconverged; every pair's state is taken from its history there.
+__global__ void icp_resolve_history_kernel(IcpState *__restrict__ st, IcpCtrl *__restrict__ ctrl,
+                                           const float *__restrict__ history, int B, int maxIter)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = maxIter;
+    for (int s = 0; s < maxIter; ++s) {
+        const unsigned long long t = ctrl->tally[s];
+        if ((int)(t & 0xffffffffull) == B && (t >> 32) == 0ull) { n = s + 1; break; }
+    }
+    const float *h = history + ((size_t)(n - 1) * B + b) * kHistStride;
+    for (int k = 0; k < 9; ++k) st[b].R[k] = h[k];
+    for (int k = 0; k < 3; ++k) st[b].T[k] = h[9 + k];
+    st[b].rmse = h[12];
+    st[b].iters = n;
+    if (b == 0) {
+        ctrl->iters = n;
+        // same convention as the per-iteration path: notconv[n-1] == 0 <=> converged
+        ctrl->notconv[n - 1] = (int)(ctrl->tally[n - 1] >> 32);
+    }
+}
+
+hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const float *history, int B, int maxIter,
+                                      hipStream_t s)
+{
+    hipLaunchKernelGGL(icp_resolve_history_kernel, dim3((B + 127) / 128), dim3(128), 0, s, state, ctrl, history, B,
+                       maxIter);
+    return hipGetLastError();
+}
+
 __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl *__restrict__ ctrl,
                                   int B, int stopMode, float *__restrict__ R, float *__restrict__ T,
                                   float *__restrict__ rmse, int32_t *__restrict__ iters,
@@ -875,6 +923,10 @@ struct LaunchProfile {
 extern "C" int icpflow_debug_phase_stamps(long long *out16)
 {
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_stamps), sizeof(long long) * 16);
+}
+extern "C" int icpflow_debug_wave_stamps(long long *out256)
+{
+    return (int)hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_wave_stamps), sizeof(long long) * 256);
 }
 #endif
 
@@ -934,9 +986,10 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      const GridScratch *grid, hipStream_t s)
+                      const GridScratch *grid, float *history, hipStream_t s)
 {
     IcpParams p{};
+    p.B = B;
     p.X = X; p.Y = Y; p.lenX = lenX; p.lenY = lenY; p.swap = swap; p.prePose = prePose; p.N = N;
     p.thr2 = (float)(thres * thres);
     p.relThr = (float)relThr;
@@ -959,14 +1012,36 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.gridH = grid->H; p.gridInvH = invh;
     }
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {
-        for (int it = 0; it < maxIter; ++it) launch_icp_iters(p, B, it, it + 1, s);
+        // Batch-global stop rule.  While all workgroups of the batch can be resident at once
+        // (B <= CUs: one 1024-thread, <=128-VGPR workgroup per CU) ONE launch runs every pair through
+        // all iterations speculatively, keeping a per-iteration history; pairs leave as soon as
+        // they observe that some iteration satisfied the batch rule, and the epilogue picks every
+        // pair's state at exactly the reference's stopping iteration.  Larger batches (late
+        // workgroups would hold the early ones at the iteration cap) use one launch per iteration.
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 1;
+        }
+        const bool speculative = history != nullptr && g_icp_speculative && maxIter > 1 && maxIter <= kHistIters &&
+                                 B <= cus;
+        if (speculative) {
+            p.history = history;
+            launch_icp_iters(p, B, 0, maxIter, s);
+            e = launch_icp_resolve_history(state, ctrl, history, B, maxIter, s);
+            if (e != hipSuccess) return e;
+        } else {
+            for (int it = 0; it < maxIter; ++it) launch_icp_iters(p, B, it, it + 1, s);
+        }
     } else {
         launch_icp_iters(p, B, 0, maxIter, s);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_icp_export(const IcpState *state, const IcpCtrl *ctrl, int B, int stopMode, float *R,
+hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,
                              float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s)
 {
     hipLaunchKernelGGL(icp_export_kernel, dim3((B + 127) / 128), dim3(128), 0, s, state, ctrl, B,

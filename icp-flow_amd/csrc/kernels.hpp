@@ -33,7 +33,13 @@ struct IcpCtrl {
     int iters;
     int pad[2];
     int notconv[kMaxIterCap];
+    // speculative single-launch mode: per iteration, pairs arrived (low 32 bits) and pairs not
+    // converged (high 32 bits), updated by ONE 64-bit atomic per pair so both are read consistently
+    unsigned long long tally[kMaxIterCap];
 };
+
+constexpr int kHistIters = 128;   // iterations of per-pair history kept in the workspace
+constexpr int kHistStride = 16;   // floats per (iteration, pair): R (9), T (3), rmse
 
 // hist.hip
 void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s);
@@ -41,6 +47,10 @@ hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int N
                             const float mins[3], const float maxs[3], const int lens[3],
                             const float *ex, const float *ey, const float *ez,
                             const uint8_t *swap, uint32_t *bins_u32, hipStream_t s);
+hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t *nX, const int32_t *nY,
+                                   int B, int N, const int lens[3], const float *ex, const float *ey,
+                                   const float *ez, const uint8_t *swap, float *sortX, float *sortY,
+                                   uint32_t *bins_u32, hipStream_t s);
 hipError_t launch_u32_to_f32(const uint32_t *in, float *out, size_t n, hipStream_t s);
 hipError_t launch_hist_peaks_f32(const float *bins, int B, int Lx, int Ly, int Lz, int k,
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
@@ -75,14 +85,17 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     int32_t *axis;     // sweep: [B]
 };
 int grid_buckets(int N);
+extern int g_icp_speculative;
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      const GridScratch *grid, hipStream_t s);
+                      const GridScratch *grid, float *history, hipStream_t s);
 hipError_t profile_enable(int capacity);
 hipError_t profile_collect(double *total_ms, int *launches);
-hipError_t launch_icp_export(const IcpState *state, const IcpCtrl *ctrl, int B, int stopMode, float *R,
+hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,
                              float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s);
+hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const float *history, int B, int maxIter,
+                                      hipStream_t s);
 
 // pose.hip
 hipError_t launch_swap_flags(const int32_t *lenSrc, const int32_t *lenDst, int B, uint8_t *swap,

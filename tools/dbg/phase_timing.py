@@ -29,3 +29,12 @@ for k in (1, 2, 3):
         if v[idx] == 0: continue
         print(f"   +{v[idx]-prev:8d}  {name}")
         prev = v[idx]
+
+    if k == 3:
+        ws = (ctypes.c_longlong * 256)()
+        _lib._L.icpflow_debug_wave_stamps(ws)
+        w = np.array(ws[:], dtype=np.int64).reshape(16, 16)
+        t0 = w[:, 1].min()
+        print("   per wave (relative to the earliest scan start): start, search done(2), resolved(10), moments(3), barrier passed(4)")
+        for i in range(16):
+            print(f"   wave {i:2d}: {w[i,1]-t0:7d} {w[i,2]-t0:7d} {w[i,10]-t0:7d} {w[i,3]-t0:7d} {w[i,4]-t0:7d}")
