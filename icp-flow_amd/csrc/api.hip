@@ -87,6 +87,7 @@ struct Workspace {
         grid.cursor = (int32_t *)take(b * (size_t)grid.H * 4);
         grid.pts = (float *)take(b * (size_t)N * 16);
         grid.sortX = (float *)take(b * (size_t)N * 16);
+        grid.sortYsoa = (float *)take(b * 3 * (size_t)((N + 15) / 16 * 16) * 4 + 256);  // + prefetch slack
         grid.axis = (int32_t *)take(b * 4);
         history = (float *)take(b * (size_t)kHistIters * kHistStride * 4);
         bytes = off;

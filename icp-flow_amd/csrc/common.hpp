@@ -111,6 +111,45 @@ __device__ __forceinline__ double wave_sum_uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
+// fp32 wave min / max on the VALU (same DPP pattern), wave-uniform results
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v, float identity)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK,
+                                                      0xf, false));
+}
+
+__device__ __forceinline__ float wave_min_uniform(float v)
+{
+    v = fminf(v, dpp_f32<0x111, 0xf>(v, kInf));
+    v = fminf(v, dpp_f32<0x112, 0xf>(v, kInf));
+    v = fminf(v, dpp_f32<0x114, 0xf>(v, kInf));
+    v = fminf(v, dpp_f32<0x118, 0xf>(v, kInf));
+    v = fminf(v, dpp_f32<0x142, 0xa>(v, kInf));
+    v = fminf(v, dpp_f32<0x143, 0xc>(v, kInf));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ float wave_max_uniform(float v)
+{
+    v = fmaxf(v, dpp_f32<0x111, 0xf>(v, -kInf));
+    v = fmaxf(v, dpp_f32<0x112, 0xf>(v, -kInf));
+    v = fmaxf(v, dpp_f32<0x114, 0xf>(v, -kInf));
+    v = fmaxf(v, dpp_f32<0x118, 0xf>(v, -kInf));
+    v = fmaxf(v, dpp_f32<0x142, 0xa>(v, -kInf));
+    v = fmaxf(v, dpp_f32<0x143, 0xc>(v, -kInf));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
+// outstanding global stores / atomics (vmcnt), which would put an L2 round trip on the path.
+__device__ __forceinline__ void barrier_lds_only()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
 #pragma unroll
@@ -160,6 +199,26 @@ __device__ __forceinline__ int sorted_count_below(const float *__restrict__ key,
     const float k1 = (lane < step && s1 < n) ? key[(size_t)s1 * stride] : kInf;
     const unsigned long long m1 = __ballot(INCLUSIVE ? (k1 <= v) : (k1 < v));
     return base + __popcll(m1);
+}
+
+// Window [count(keys < vlo), count(keys <= vhi)) with ONE shared first-level sample load and two
+// independent second-level loads (two memory latencies instead of four).  Wave-uniform results.
+__device__ __forceinline__ void sorted_window(const float *__restrict__ key, int n, float vlo, float vhi, int lane,
+                                              int &jlo, int &jhi)
+{
+    const int step = (n + kWave - 1) / kWave;
+    jlo = jhi = 0;
+    if (step == 0) return;
+    const int s0 = lane * step;
+    const float k0 = s0 < n ? key[s0] : kInf;
+    const int cl = __popcll(__ballot(k0 < vlo));
+    const int ch = __popcll(__ballot(k0 <= vhi));
+    const int bl = (cl > 0 ? cl - 1 : 0) * step, bh = (ch > 0 ? ch - 1 : 0) * step;
+    const float kl = (lane < step && bl + lane < n) ? key[bl + lane] : kInf;
+    const float kh = (lane < step && bh + lane < n) ? key[bh + lane] : kInf;
+    const int pl = __popcll(__ballot(kl < vlo)), ph = __popcll(__ballot(kh <= vhi));
+    jlo = cl > 0 ? bl + pl : 0;
+    jhi = ch > 0 ? bh + ph : 0;
 }
 
 // Sum K values per thread over the whole block.  `scratch` holds at least

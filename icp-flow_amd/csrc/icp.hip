@@ -165,6 +165,7 @@ struct IcpParams {
     // cloud's longest axis by sort_clouds_kernel; w = original index bits
     const float4 *sortX;     // [B,N] moving cloud, pre-pose already applied
     const float4 *sortY;     // [B,N] fixed cloud
+    const float *sortYsoa;   // [B,3,NP16] fixed cloud as x[], y[], z[] padded with +inf to 16
     const int32_t *sortAxis; // [B]
     float sweepMargin;       // window half-width beyond the wave's query span (1.01 * thres)
     // speculative single-launch execution of the batch-global stop rule (see launch_icp)
@@ -288,7 +289,8 @@ int g_icp_speculative = 1;   // developer knob (api.hip: ICPFLOW_ICP_SPECULATIVE
 __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const int32_t *__restrict__ lenX,
     const int32_t *__restrict__ lenY, const uint8_t *__restrict__ swap, const float *__restrict__ prePose,
-    int N, int NP2, int32_t *__restrict__ axisOut, float4 *__restrict__ Xs, float4 *__restrict__ Ys)
+    int N, int NP2, int32_t *__restrict__ axisOut, float4 *__restrict__ Xs, float4 *__restrict__ Ys,
+    float *__restrict__ Ysoa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     float *key = reinterpret_cast<float *>(dynLds);
@@ -352,12 +354,17 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     __syncthreads();
     bitonic_sort_lds(key, idx, NP2);
     float4 *out = (moving ? Xs : Ys) + (size_t)b * N;
-    for (int r = tid; r < n; r += kSortBlock) {
-        const int j = idx[r];
-        const float4 q = cloud[j];
-        float px, py, pz;
-        xf_apply(pre, q.x, q.y, q.z, px, py, pz);
-        out[r] = make_float4(px, py, pz, __int_as_float(j));
+    const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
+    float *soa = Ysoa + (size_t)b * 3 * NP16;
+    for (int r = tid; r < (moving ? n : NP16); r += kSortBlock) {
+        float px = kInf, py = kInf, pz = kInf;
+        if (r < n) {
+            const int j = idx[r];
+            const float4 q = cloud[j];
+            xf_apply(pre, q.x, q.y, q.z, px, py, pz);
+            out[r] = make_float4(px, py, pz, __int_as_float(j));
+        }
+        if (!moving) { soa[r] = px; soa[NP16 + r] = py; soa[2 * NP16 + r] = pz; }
     }
 }
 
@@ -383,12 +390,13 @@ constexpr int kMoments = 18;
 // in LDS instead of being carried in registers across the scan.
 // GRID: 0 = all-pairs LDS scan, 1 = exact grid read from global memory (L2), 2 = exact grid staged
 // into LDS at kernel entry (dynamic shared memory: (H+1) ints + n float4), 3 = sorted sweep
-// (dynamic shared memory: the whole sorted fixed cloud as three float arrays)
+// (targets streamed through scalar loads, no LDS image)
 template <int BLOCK, int Q, int TS, int GRID>
 __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
     ICPFLOW_STAMP(0);
-    static_assert(!GRID || (Q == 1 && TS == 1), "grid search: one query per thread");
+    static_assert(GRID == 0 || TS == 1, "grid / sweep searches do not split targets over waves");
+    static_assert(GRID == 0 || GRID >= 3 || Q == 1, "grid search: one query per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     constexpr int NWAVE = BLOCK / kWave;
     constexpr int NQG = NWAVE / TS;          // query groups
@@ -479,101 +487,128 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             ICPFLOW_ACC(16, ax * ax + ay * ay + az * az)                                      \
             ICPFLOW_ACC(17, bx * bx + by * by + bz * bz)                                      \
         }
-        if constexpr (GRID == 3) {
-            const int np16 = (yc.n + kChunk - 1) / kChunk * kChunk;
+        if constexpr (GRID == 3 || GRID == 4) {
             const int NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
-            float *sxf = reinterpret_cast<float *>(dynLds);
-            float *syf = sxf + NP16;
-            float *szf = syf + NP16;
+            const int np16 = (yc.n + kChunk - 1) / kChunk * kChunk;
+            const float *gx = p.sortYsoa + (size_t)b * 3 * NP16;
+            const float *gy = gx + NP16;
+            const float *gz = gy + NP16;
             const float4 *ys = p.sortY + (size_t)b * p.N;
             const float4 *xs = p.sortX + (size_t)b * p.N;
             const int axis = p.sortAxis[b];
-            if (it == itBegin) {  // stage the sorted fixed cloud once per launch (+inf tail)
-                for (int k = tid; k < np16; k += BLOCK) {
-                    float4 t = make_float4(kInf, kInf, kInf, 0.f);
-                    if (k < yc.n) t = ys[k];
-                    sxf[k] = t.x; syf[k] = t.y; szf[k] = t.z;
-                }
+            // GRID == 4: the sorted fixed cloud is staged into LDS once per launch and every
+            // per-iteration access (window search, scan, resolve) stays on chip
+            float *lx = reinterpret_cast<float *>(dynLds), *ly = lx + NP16, *lz = ly + NP16;
+            if (GRID == 4 && it == itBegin) {
+                for (int k = tid; k < np16; k += BLOCK) { lx[k] = gx[k]; ly[k] = gy[k]; lz[k] = gz[k]; }
                 __syncthreads();
             }
-            const float *keyf = axis == 0 ? sxf : (axis == 1 ? syf : szf);
-            const float4 *sx4 = reinterpret_cast<const float4 *>(sxf);
-            const float4 *sy4 = reinterpret_cast<const float4 *>(syf);
-            const float4 *sz4 = reinterpret_cast<const float4 *>(szf);
-            const int ngr = (xc.n + BLOCK - 1) / BLOCK;
+            const float *keyf = (GRID == 4) ? (axis == 0 ? lx : (axis == 1 ? ly : lz))
+                                            : (axis == 0 ? gx : (axis == 1 ? gy : gz));
+            constexpr int PER = BLOCK * Q;            // a wave owns 64*Q CONSECUTIVE sorted queries
+            const int ngr = (xc.n + PER - 1) / PER;
             for (int g = 0; g < ngr; ++g) {
-                const int i = g * BLOCK + tid;
-                const bool live = i < xc.n;
-                float x0x = 0.f, x0y = 0.f, x0z = 0.f;
-                float qx[1] = {0.f}, qy[1] = {0.f}, qz[1] = {0.f};
+                float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
+                bool live[Q];
+                float lo = kInf, hi = -kInf;
                 ICPFLOW_STAMP(1);
-                if (live) {
-                    const float4 s4 = xs[i];   // sorted, pre-pose already applied (utils_icp.py:21)
-                    x0x = s4.x; x0y = s4.y; x0z = s4.z;
-                    qx[0] = fmaf(x0z, Rf[6], fmaf(x0y, Rf[3], x0x * Rf[0])) + Tf[0];  // :177, :395
-                    qy[0] = fmaf(x0z, Rf[7], fmaf(x0y, Rf[4], x0x * Rf[1])) + Tf[1];
-                    qz[0] = fmaf(x0z, Rf[8], fmaf(x0y, Rf[5], x0x * Rf[2])) + Tf[2];
-                }
-                // span of this wave's live queries along the sort axis
-                const float qa = axis == 0 ? qx[0] : (axis == 1 ? qy[0] : qz[0]);
-                float lo = live ? qa : kInf, hi = live ? qa : -kInf;
 #pragma unroll
-                for (int o = kWave / 2; o > 0; o >>= 1) {
-                    lo = fminf(lo, __shfl_xor(lo, o, kWave));
-                    hi = fmaxf(hi, __shfl_xor(hi, o, kWave));
+                for (int q = 0; q < Q; ++q) {
+                    const int i = g * PER + (wave * Q + q) * kWave + lane;
+                    live[q] = i < xc.n;
+                    x0x[q] = x0y[q] = x0z[q] = 0.f;
+                    qx[q] = qy[q] = qz[q] = 0.f;
+                    if (live[q]) {
+                        const float4 s4 = xs[i];   // sorted, pre-pose already applied (utils_icp.py:21)
+                        x0x[q] = s4.x; x0y[q] = s4.y; x0z[q] = s4.z;
+                        qx[q] = fmaf(s4.z, Rf[6], fmaf(s4.y, Rf[3], s4.x * Rf[0])) + Tf[0];  // :177, :395
+                        qy[q] = fmaf(s4.z, Rf[7], fmaf(s4.y, Rf[4], s4.x * Rf[1])) + Tf[1];
+                        qz[q] = fmaf(s4.z, Rf[8], fmaf(s4.y, Rf[5], s4.x * Rf[2])) + Tf[2];
+                        const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
+                        lo = fminf(lo, qa); hi = fmaxf(hi, qa);
+                    }
                 }
-                ScanAcc<1> acc;
-                bool tie[1] = {false};
+                ICPFLOW_STAMP(11);
+                // span of this wave's live queries along the sort axis
+                lo = wave_min_uniform(lo);
+                hi = wave_max_uniform(hi);
+                ScanAcc<Q> acc;
+                bool tie[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) tie[q] = false;
                 scan_init(acc);
                 int cb = 0, ce = 0;
-                if (lo <= hi) {  // wave has live queries
-                    const int jlo = sorted_count_below<false>(keyf, 1, yc.n, lo - p.sweepMargin, lane);
-                    const int jhi = sorted_count_below<true>(keyf, 1, yc.n, hi + p.sweepMargin, lane);
+                if (lo <= hi) {  // wave has live queries (wave-uniform)
+                    int jlo, jhi;
+                    sorted_window(keyf, yc.n, lo - p.sweepMargin, hi + p.sweepMargin, lane, jlo, jhi);
                     cb = (jlo / kChunk) * kChunk;
                     ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
-                    scan_range_tie<1>(sx4, sy4, sz4, cb, ce, qx, qy, qz, acc, tie);
+                    ICPFLOW_STAMP(12);
+#ifdef ICPFLOW_PHASE_TIMING
+                    if (blockIdx.x == 0 && lane == 0) g_wave_stamps[wave * 16 + 15] = ce - cb;
+#endif
+                    if (GRID == 4)
+                        scan_range_tie<Q>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
+                                          reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie);
+                    else
+                        scan_range_tie_uniform<Q>(gx, gy, gz, cb, ce, qx, qy, qz, acc, tie);
                 }
                 ICPFLOW_STAMP(2);
-                const bool inl = live && (acc.best[0] <= p.thr2);  // :160-161
-                double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0;
-                if (inl) {
-                    // neighbour = the target at distance `best` (bit-equal re-evaluation from the LDS
-                    // image of the winning chunk).  If several targets tie -- in that chunk or, flagged
-                    // by the scan, in another one -- the lowest ORIGINAL index wins: only then are the
-                    // original indices fetched (w component of the sorted array in global memory).
+                // lane-local moments of this lane's Q queries, then ONE set of wave reductions
+                double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0, l4 = 0.0, l5 = 0.0, l6 = 0.0, l7 = 0.0, l8 = 0.0,
+                       l9 = 0.0, l10 = 0.0, l11 = 0.0, l12 = 0.0, l13 = 0.0, l14 = 0.0, l15 = 0.0, l16 = 0.0, l17 = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    if (!(live[q] && acc.best[q] <= p.thr2)) continue;  // :160-161
+                    // neighbour = the target at distance `best` (bit-equal re-evaluation of the winning
+                    // chunk).  If several targets tie -- in that chunk or, flagged by the scan, in another
+                    // one -- the lowest ORIGINAL index wins: only then are the original indices fetched
+                    // (w component of the sorted array).
                     float ynx = 0.f, yny = 0.f, ynz = 0.f;
-                    int matches = tie[0] ? 2 : 0;
-                    if (!tie[0]) {
-                        const int c4 = acc.chunk[0] >> 2;
+                    int matches = tie[q] ? 2 : 0;
+                    if (!tie[q]) {
+                        const int c0 = acc.chunk[q];
 #pragma unroll
                         for (int u = 0; u < kChunk / 4; ++u) {
-                            const float4 tx = sx4[c4 + u], ty = sy4[c4 + u], tz = sz4[c4 + u];
+                            const float4 tx = *reinterpret_cast<const float4 *>((GRID == 4 ? lx : gx) + c0 + 4 * u);
+                            const float4 ty = *reinterpret_cast<const float4 *>((GRID == 4 ? ly : gy) + c0 + 4 * u);
+                            const float4 tz = *reinterpret_cast<const float4 *>((GRID == 4 ? lz : gz) + c0 + 4 * u);
                             const float txs[4] = {tx.x, tx.y, tx.z, tx.w};
                             const float tys[4] = {ty.x, ty.y, ty.z, ty.w};
                             const float tzs[4] = {tz.x, tz.y, tz.z, tz.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float d = sqdist(qx[0], qy[0], qz[0], txs[e], tys[e], tzs[e]);
-                                if (d == acc.best[0]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; }
+                                const float d = sqdist(qx[q], qy[q], qz[q], txs[e], tys[e], tzs[e]);
+                                if (d == acc.best[q]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; }
                             }
                         }
                     }
                     if (matches != 1) {
-                        const int r0 = tie[0] ? cb : acc.chunk[0];
-                        const int r1 = tie[0] ? ce : acc.chunk[0] + kChunk;
+                        const int r0 = tie[q] ? cb : acc.chunk[q];
+                        const int r1 = tie[q] ? ce : acc.chunk[q] + kChunk;
                         int bj = 0x7fffffff;
                         for (int k = r0; k < min(r1, yc.n); ++k) {
                             const float4 t = ys[k];
-                            const float d = sqdist(qx[0], qy[0], qz[0], t.x, t.y, t.z);
+                            const float d = sqdist(qx[q], qy[q], qz[q], t.x, t.y, t.z);
                             const int j = __float_as_int(t.w);
-                            if (d == acc.best[0] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
+                            if (d == acc.best[q] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
                         }
                     }
-                    ax = (double)(x0x - ox); ay = (double)(x0y - oy); az = (double)(x0z - oz);
-                    bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
+                    const double ax = (double)(x0x[q] - ox), ay = (double)(x0y[q] - oy), az = (double)(x0z[q] - oz);
+                    const double bx = (double)(ynx - ox), by = (double)(yny - oy), bz = (double)(ynz - oz);
+                    l0 += 1.0;
+                    l1 += ax; l2 += ay; l3 += az; l4 += bx; l5 += by; l6 += bz;
+                    l7 += ax * bx; l8 += ax * by; l9 += ax * bz;
+                    l10 += ay * bx; l11 += ay * by; l12 += ay * bz;
+                    l13 += az * bx; l14 += az * by; l15 += az * bz;
+                    l16 += ax * ax + ay * ay + az * az;
+                    l17 += bx * bx + by * by + bz * bz;
                 }
                 ICPFLOW_STAMP(10);
-                ICPFLOW_ACC_ALL()
+                ICPFLOW_ACC(0, l0) ICPFLOW_ACC(1, l1) ICPFLOW_ACC(2, l2) ICPFLOW_ACC(3, l3) ICPFLOW_ACC(4, l4)
+                ICPFLOW_ACC(5, l5) ICPFLOW_ACC(6, l6) ICPFLOW_ACC(7, l7) ICPFLOW_ACC(8, l8) ICPFLOW_ACC(9, l9)
+                ICPFLOW_ACC(10, l10) ICPFLOW_ACC(11, l11) ICPFLOW_ACC(12, l12) ICPFLOW_ACC(13, l13)
+                ICPFLOW_ACC(14, l14) ICPFLOW_ACC(15, l15) ICPFLOW_ACC(16, l16) ICPFLOW_ACC(17, l17)
             }
         } else if constexpr (GRID != 0) {
             const float4 *gpG = p.gridPts + (size_t)b * p.N;
@@ -819,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         itersDone = it + 1;
         ICPFLOW_STAMP(7);
         if (it + 1 < itEnd) {  // more iterations inside this launch: publish (R, T) to the block
-            __syncthreads();
+            barrier_lds_only();   // the history stores / tally atomic of wave 0 stay in flight
             if (wave != 0) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) Rf[k] = bcast[k];
@@ -905,7 +940,7 @@ template <int BLOCK, int Q, int TS, int GRID>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
-                       : (GRID == 3) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 : 0;
+                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 : 0;
     hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID>), dim3(B), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
 }
 
@@ -967,9 +1002,12 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
 {
     const bool timed = g_prof.used < (int)g_prof.start.size();
     if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
-    if (p.sortY != nullptr) {    // sorted sweep (N <= 4096: sorted fixed cloud resident in LDS)
-        if (p.N <= 256) launch_icp_variant<256, 1, 1, 3>(p, B, itBegin, itEnd, s);
-        else launch_icp_variant<1024, 1, 1, 3>(p, B, itBegin, itEnd, s);
+    if (p.sortY != nullptr) {    // sorted sweep (N <= 4096: two-level ballot search of the window)
+        // GRID 4: sorted fixed cloud resident in LDS (12 B/point: 48 KiB at N = 4096)
+        if (p.N <= 256) launch_icp_variant<256, 1, 1, 4>(p, B, itBegin, itEnd, s);
+        else if (p.N <= 512) launch_icp_variant<512, 1, 1, 4>(p, B, itBegin, itEnd, s);
+        else if (p.N <= 1024) launch_icp_variant<512, 2, 1, 4>(p, B, itBegin, itEnd, s);
+        else launch_icp_variant<1024, 2, 1, 4>(p, B, itBegin, itEnd, s);
     } else if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 2>(p, B, itBegin, itEnd, s);
         else if (p.N <= 2048) launch_icp_variant<1024, 1, 1, 2>(p, B, itBegin, itEnd, s);
@@ -1000,8 +1038,9 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         int NP2 = 64;
         while (NP2 < N) NP2 <<= 1;
         hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY,
-                           swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts);
+                           swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts, grid->sortYsoa);
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
+        p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
     } else if (grid != nullptr) {
         // bin the fixed cloud once: cell edge 1 % above the gate radius (rounding head-room)

@@ -82,6 +82,7 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     int32_t *cursor;   // grid: [B,H]
     float *pts;        // grid: fixed cloud sorted by bucket; sweep: fixed cloud sorted by axis [B,N,4]
     float *sortX;      // sweep: moving cloud sorted by axis, pre-pose applied [B,N,4]
+    float *sortYsoa;   // sweep: fixed cloud sorted, x[] y[] z[] padded with +inf [B,3,NP16]
     int32_t *axis;     // sweep: [B]
 };
 int grid_buckets(int N);

@@ -204,6 +204,65 @@ __device__ __forceinline__ void scan_range_tie(const float4 *__restrict__ sx, co
     }
 }
 
+// The same range scan with the targets streamed from GLOBAL memory at wave-uniform addresses:
+// the compiler turns these loads into scalar loads (s_load_dwordx4 into SGPRs), the VALU
+// instructions take the coordinates as scalar operands, and neither LDS nor the vector memory
+// pipe is touched by the hot loop.  gx/gy/gz: the sorted cloud as three float arrays, padded
+// with +inf to a multiple of kChunk.  cBegin/cEnd must be wave-uniform.
+typedef float v4f __attribute__((ext_vector_type(4)));
+// constant address space: tells the compiler the data is invariant for the kernel, which is what
+// lets it select scalar loads for wave-uniform addresses (it emits s_load_dwordx16 here)
+typedef const __attribute__((address_space(4))) v4f *ConstV4;
+
+template <int Q>
+__device__ __forceinline__ void scan_range_tie_uniform(const float *__restrict__ gx, const float *__restrict__ gy,
+                                                       const float *__restrict__ gz, int cBegin, int cEnd,
+                                                       const float (&qx)[Q], const float (&qy)[Q],
+                                                       const float (&qz)[Q], ScanAcc<Q> &acc, bool (&tie)[Q])
+{
+    cBegin = __builtin_amdgcn_readfirstlane(cBegin);
+    cEnd = __builtin_amdgcn_readfirstlane(cEnd);
+    if (cBegin >= cEnd) return;
+    // software pipeline in half chunks (8 targets = 24 SGPRs per buffer): the scalar loads of the
+    // next half are issued before the current half is evaluated, so their latency hides behind
+    // ~30 VALU instructions per query.  Reading one half past cEnd stays inside the allocation
+    // (+inf padding, then the next coordinate array).
+    constexpr int HALF = kChunk / 2;
+    v4f nx0 = *(ConstV4)(gx + cBegin), nx1 = *(ConstV4)(gx + cBegin + 4);
+    v4f ny0 = *(ConstV4)(gy + cBegin), ny1 = *(ConstV4)(gy + cBegin + 4);
+    v4f nz0 = *(ConstV4)(gz + cBegin), nz1 = *(ConstV4)(gz + cBegin + 4);
+    for (int c = cBegin; c < cEnd; c += kChunk) {
+        float m[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) m[q] = kInf;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const v4f tx0 = nx0, tx1 = nx1, ty0 = ny0, ty1 = ny1, tz0 = nz0, tz1 = nz1;
+            const int cn = c + (hh + 1) * HALF;
+            nx0 = *(ConstV4)(gx + cn); nx1 = *(ConstV4)(gx + cn + 4);
+            ny0 = *(ConstV4)(gy + cn); ny1 = *(ConstV4)(gy + cn + 4);
+            nz0 = *(ConstV4)(gz + cn); nz1 = *(ConstV4)(gz + cn + 4);
+            const v2f xa = {tx0.x, tx0.y}, xb = {tx0.z, tx0.w}, xc = {tx1.x, tx1.y}, xd = {tx1.z, tx1.w};
+            const v2f ya = {ty0.x, ty0.y}, yb = {ty0.z, ty0.w}, yc = {ty1.x, ty1.y}, yd = {ty1.z, ty1.w};
+            const v2f za = {tz0.x, tz0.y}, zb = {tz0.z, tz0.w}, zc = {tz1.x, tz1.y}, zd = {tz1.z, tz1.w};
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const v2f da = sqdist2(qx[q], qy[q], qz[q], xa, ya, za);
+                const v2f db = sqdist2(qx[q], qy[q], qz[q], xb, yb, zb);
+                const v2f dc = sqdist2(qx[q], qy[q], qz[q], xc, yc, zc);
+                const v2f dd = sqdist2(qx[q], qy[q], qz[q], xd, yd, zd);
+                m[q] = min3f(min3f(m[q], da.x, da.y), db.x, db.y);
+                m[q] = min3f(min3f(m[q], dc.x, dc.y), dd.x, dd.y);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (m[q] < acc.best[q]) { acc.best[q] = m[q]; acc.chunk[q] = c; tie[q] = false; }
+            else if (m[q] == acc.best[q]) tie[q] = true;
+        }
+    }
+}
+
 // Full scan of one target cloud for this lane's Q queries.  All threads of the block
 // must call it (it contains barriers).  With TS > 1 the caller's wave scans only share `ts`
 // of every tile (contiguous chunk ranges); the TS partial (best, chunk) results of a query

@@ -35,6 +35,7 @@ for k in (1, 2, 3):
         _lib._L.icpflow_debug_wave_stamps(ws)
         w = np.array(ws[:], dtype=np.int64).reshape(16, 16)
         t0 = w[:, 1].min()
-        print("   per wave (relative to the earliest scan start): start, search done(2), resolved(10), moments(3), barrier passed(4)")
+        print("   per wave (relative to the earliest scan start): start(1), queries loaded(11), window known(12), search done(2), resolved(10), moments(3), barrier passed(4), window size")
         for i in range(16):
-            print(f"   wave {i:2d}: {w[i,1]-t0:7d} {w[i,2]-t0:7d} {w[i,10]-t0:7d} {w[i,3]-t0:7d} {w[i,4]-t0:7d}")
+            if w[i,1] == 0: continue
+            print(f"   wave {i:2d}: " + " ".join(f"{w[i,k]-t0:7d}" for k in (1, 11, 12, 2, 10, 3, 4)) + f"   targets {w[i,15]}")
