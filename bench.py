@@ -29,8 +29,6 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_LANE_OPS = 78.6e12    # 256 CU x 128 lanes x 2.4 GHz (157.3 TFLOP/s fp32 vector)
-SCAN_LANE_OPS_PER_EVAL = 6.5    # 3 sub + 1 mul + 2 fma + 1/2 min3 (scan.hpp)
 
 
 def parse():
@@ -113,35 +111,38 @@ def main():
 
     regs = B * world * a.steps
     value = regs / dt
-    # ---- roofline of the dominant kernel (icp_kernel: one launch = one ICP iteration of all
-    # B pairs; launches after the batch-global stop return immediately and are included) ------
-    P = (N + N) * 16                                   # bytes of both clouds of one pair, SURVEY 8(d)
-    alg_bytes_per_iter = B * P                          # one iteration streams both clouds once
+    # ---- roofline of the dominant kernel: icp_kernel.  With B <= #CUs one launch runs ALL ICP
+    # iterations of the batch (speculative execution of the batch-global stop rule);
+    # otherwise one launch per iteration.  Either way the algorithmic traffic is one pass over both
+    # clouds per executed iteration: P = (n_s + n_d) * 16 B per pair and iteration.
+    P = (N + N) * 16
+    alg_bytes_per_iter = B * P
     executed = iters_done * a.steps                     # iterations that did work (same every step)
+    alg_bytes_per_launch = alg_bytes_per_iter * executed / max(icp_launches, 1)
     avg_launch_ms = icp_ms / max(icp_launches, 1)
     achieved_gbs = (alg_bytes_per_iter * executed) / (icp_ms * 1e-3) / 1e9 if icp_ms > 0 else 0.0
-    evals_per_s = (B * N * N * executed) / (icp_ms * 1e-3) if icp_ms > 0 else 0.0
     traffic = None
     tfile = os.path.join(REPO, "profiles", "r01_icp_kernel_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            shape = "all_iterations" if icp_launches == a.steps else "one_iteration"
+            if tj.get("launch_shape") == shape:
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "icp_kernel<512,2>" if N > 512 and N <= 1024 else "icp_kernel",
+        "bound": "hbm", "kernel": "icp_kernel (all ICP iterations of the batch per launch)" if icp_launches == a.steps
+        else "icp_kernel (one ICP iteration of the batch per launch)",
         "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-        "algorithmic_bytes_per_launch": alg_bytes_per_iter,
+        "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+        "algorithmic_bytes_per_iteration": alg_bytes_per_iter,
         "avg_launch_ms": round(avg_launch_ms, 5), "launches_timed": icp_launches,
         "icp_iterations_executed_per_step": iters_done,
         "icp_share_of_step": round(icp_ms / (dt * 1e3), 4),
-        # the scan is FP32-VALU bound (arithmetic intensity ~256 lane-op/B), reported next to HBM:
-        "valu": {"pair_evals_per_s": round(evals_per_s, 1),
-                 "lane_ops_per_eval": SCAN_LANE_OPS_PER_EVAL,
-                 "achieved_lane_ops_per_s": round(evals_per_s * SCAN_LANE_OPS_PER_EVAL, 1),
-                 "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                 "frac": round(evals_per_s * SCAN_LANE_OPS_PER_EVAL / VALU_PEAK_LANE_OPS, 4)},
+        "note": "the correspondence search is FP32-VALU / latency bound, not HBM bound: the exact sorted sweep "
+                "evaluates ~15-20 % of the n^2 point pairs of a brute-force scan; see DESIGN.md 6",
     }
 
     extras = {}
@@ -184,8 +185,15 @@ def extra_measurements(args, src, dst, T, dev, a):
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t) / reps * 1e3
 
+    from icp_flow_amd import _lib
     B = src.shape[0]
     out = {"match_eval_ms_per_batch": round(timeit(lambda: utils_match.match_eval(args, src, dst, T)), 4)}
+    # the same registration with the ICP loop's correspondence search forced to the all-pairs LDS scan
+    # (the north star's brute-force formulation; identical results)
+    _lib.set_icp_search("scan")
+    ms = timeit(lambda: utils_match.hist_icp(args, src, dst), reps=5)
+    out["all_pairs_scan_search_registrations_per_s"] = round(B / ms * 1e3, 1)
+    _lib.set_icp_search("auto")
     fast = SimpleNamespace(**{**vars(args), "icp_stop_mode": "per_pair"})
     ms = timeit(lambda: utils_match.hist_icp(fast, src, dst))
     out["per_pair_stop_registrations_per_s"] = round(B / ms * 1e3, 1)

@@ -54,6 +54,8 @@ if dom:
                       "(FETCH_SIZE = TCC_EA0_RDREQ x 64 B with 128-B requests tallied at 64 B): read side x2; "
                       "WRITE_SIZE uncalibrated, taken as is (it is 0.2 % of the total)",
         "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024)),
+        "launch_shape": "all_iterations" if e["dispatches"] <= 16 else "one_iteration",
+        "dispatches_profiled": e["dispatches"],
         "note": "average over all launches of the profiled run, including the few launches after the "
                 "batch-global stop that return immediately",
     }
