@@ -39,6 +39,7 @@ int hipfail(hipError_t e, const char *what)
 int g_icp_search = 0;
 int g_hist_sorted = 1;   // developer knob (ICPFLOW_HIST_SORTED=0 selects the all-pairs vote)
 
+constexpr int kMaxSortN = 16384;   // bitonic sort of (key, index) pairs in 128 KiB of LDS
 constexpr size_t kAlign = 256;
 size_t up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
 
@@ -97,8 +98,8 @@ struct Workspace {
 const GridScratch *search_scratch(Workspace &w, int N)
 {
     int mode = g_icp_search;
-    if (mode == 0) mode = (N >= 64 && N <= 4096) ? 3 : 1;
-    if (mode == 3 && N > 4096) mode = 1;   // sorted fixed cloud must fit LDS
+    if (mode == 0) mode = (N >= 64 && N <= kMaxSortN) ? 3 : 1;
+    if (mode == 3 && N > kMaxSortN) mode = 1;   // the bitonic sort holds (key, index) pairs in LDS
     if (mode == 1) return nullptr;
     w.grid.mode = mode;
     return &w.grid;
@@ -147,9 +148,9 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
                   float shift, float *Tout, hipStream_t s)
 {
     const int lens[3] = {lx, ly, lz};
-    // vote with X = dst role, Y = src role (utils_hist.py:69); z-sorted sweep while a sorted cloud
-    // fits the ballot search (N <= 4096), all-pairs otherwise -- identical bins either way
-    if (N <= 4096 && g_hist_sorted)
+    // vote with X = dst role, Y = src role (utils_hist.py:69); z-sorted sweep while the sort fits LDS
+    // (N <= 16384), all-pairs otherwise -- identical bins either way
+    if (N <= kMaxSortN && g_hist_sorted)
         ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.grid.pts,
                                             w.grid.sortX, w.bins, s));
     else

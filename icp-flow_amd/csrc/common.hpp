@@ -201,24 +201,35 @@ __device__ __forceinline__ int sorted_count_below(const float *__restrict__ key,
     return base + __popcll(m1);
 }
 
-// Window [count(keys < vlo), count(keys <= vhi)) with ONE shared first-level sample load and two
-// independent second-level loads (two memory latencies instead of four).  Wave-uniform results.
+// Window [count(keys < vlo), count(keys <= vhi)) over n ascending keys by 64-way ballot steps
+// (one step per factor of 64 in n: two for n <= 4096, three up to 262144).  The first level shares
+// its sample load between both bounds.  Wave-uniform results.
+template <bool INCLUSIVE>
+__device__ __forceinline__ int sorted_refine(const float *__restrict__ key, int n, float v, int lane, int base,
+                                             int span)
+{
+    // invariant: the answer lies in [base, base + span]; all keys before `base` compare true
+    while (span > 0) {
+        const int step = (span + kWave - 1) / kWave;
+        const int s = base + lane * step;
+        const float k = (lane * step < span && s < n) ? key[s] : kInf;
+        const int cnt = __popcll(__ballot(INCLUSIVE ? (k <= v) : (k < v)));
+        if (cnt == 0) return base;
+        if (step == 1) return base + cnt;
+        base += (cnt - 1) * step;   // key[base] compares true, key[base + step] (if any) does not
+        span = min(step, n - base);
+        // the sample at `base` itself is known true: search strictly after it
+        base += 1; span -= 1;
+        if (span <= 0) return base;
+    }
+    return base;
+}
+
 __device__ __forceinline__ void sorted_window(const float *__restrict__ key, int n, float vlo, float vhi, int lane,
                                               int &jlo, int &jhi)
 {
-    const int step = (n + kWave - 1) / kWave;
-    jlo = jhi = 0;
-    if (step == 0) return;
-    const int s0 = lane * step;
-    const float k0 = s0 < n ? key[s0] : kInf;
-    const int cl = __popcll(__ballot(k0 < vlo));
-    const int ch = __popcll(__ballot(k0 <= vhi));
-    const int bl = (cl > 0 ? cl - 1 : 0) * step, bh = (ch > 0 ? ch - 1 : 0) * step;
-    const float kl = (lane < step && bl + lane < n) ? key[bl + lane] : kInf;
-    const float kh = (lane < step && bh + lane < n) ? key[bh + lane] : kInf;
-    const int pl = __popcll(__ballot(kl < vlo)), ph = __popcll(__ballot(kh <= vhi));
-    jlo = cl > 0 ? bl + pl : 0;
-    jhi = ch > 0 ? bh + ph : 0;
+    jlo = sorted_refine<false>(key, n, vlo, lane, 0, n);
+    jhi = sorted_refine<true>(key, n, vhi, lane, 0, n);
 }
 
 // Sum K values per thread over the whole block.  `scratch` holds at least

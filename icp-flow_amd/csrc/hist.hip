@@ -240,6 +240,14 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
     if (e != hipSuccess) return e;
     int NP2 = 64;
     while (NP2 < N) NP2 <<= 1;
+    if ((size_t)NP2 * 8 > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&zsort_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr = true;
+        }
+    }
     hipLaunchKernelGGL(zsort_kernel, dim3(B, 2), dim3(kZsortBlock), (size_t)NP2 * 8, s, (const float4 *)X,
                        (const float4 *)Y, N, NP2, (float4 *)sortX, (float4 *)sortY);
     const size_t tile_bytes = sizeof(float4) * kVoteTile;

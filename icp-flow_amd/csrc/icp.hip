@@ -1002,12 +1002,14 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
 {
     const bool timed = g_prof.used < (int)g_prof.start.size();
     if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
-    if (p.sortY != nullptr) {    // sorted sweep (N <= 4096: two-level ballot search of the window)
-        // GRID 4: sorted fixed cloud resident in LDS (12 B/point: 48 KiB at N = 4096)
+    if (p.sortY != nullptr) {    // sorted sweep
+        // GRID 4: sorted fixed cloud resident in LDS (12 B/point: 48 KiB at N = 4096); beyond that
+        // GRID 3 streams it through scalar loads (no LDS image, any N the sort can handle)
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.N <= 512) launch_icp_variant<512, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.N <= 1024) launch_icp_variant<512, 2, 1, 4>(p, B, itBegin, itEnd, s);
-        else launch_icp_variant<1024, 2, 1, 4>(p, B, itBegin, itEnd, s);
+        else if (p.N <= 4096) launch_icp_variant<1024, 2, 1, 4>(p, B, itBegin, itEnd, s);
+        else launch_icp_variant<1024, 2, 1, 3>(p, B, itBegin, itEnd, s);
     } else if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 2>(p, B, itBegin, itEnd, s);
         else if (p.N <= 2048) launch_icp_variant<1024, 1, 1, 2>(p, B, itBegin, itEnd, s);
@@ -1037,6 +1039,14 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     if (grid != nullptr && grid->mode == 3) {
         int NP2 = 64;
         while (NP2 < N) NP2 <<= 1;
+        if ((size_t)NP2 * 8 > 64 * 1024) {   // dynamic LDS above 64 KiB needs the attribute (N > 8192)
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_clouds_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                attr = true;
+            }
+        }
         hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY,
                            swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts, grid->sortYsoa);
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;

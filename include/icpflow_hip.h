@@ -207,7 +207,7 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
 /* ---------------------------------------------------------------------------
  * Correspondence search used inside the ICP loop (process-global tuning knob, results are
  * bit-identical in every mode):
- *   ICPFLOW_SEARCH_AUTO (0)   sorted sweep when 64 <= N <= 4096, else the all-pairs scan
+ *   ICPFLOW_SEARCH_AUTO (0)   sorted sweep when 64 <= N <= 16384, else the all-pairs scan
  *   ICPFLOW_SEARCH_SCAN (1)   all-pairs LDS-tiled scan of the fixed cloud every iteration
  *   ICPFLOW_SEARCH_GRID (2)   exact hashed uniform grid of the fixed cloud, built once per
  *                             registration: only the 27 cells within the gate radius are evaluated

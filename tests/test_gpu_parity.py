@@ -362,6 +362,28 @@ def test_match_eval_ragged_vs_golden():
         np.testing.assert_allclose(got.cpu().numpy(), g["ev_" + key], atol=tol, rtol=1e-5)
 
 
+def test_hist_icp_real_data_shape_large_padding():
+    """max_points = 10000 like demo.sh / main.sh: mostly tiny clusters plus a few thousand-point
+    ones in the same padded batch (three-level window search, scalar-load sweep, sorts in 128 KiB
+    of LDS, several query groups per pair)."""
+    N = 10000
+    sizes = [(25, 31), (80, 64), (300, 420), (2300, 1900), (6000, 9000), (10000, 10000)]
+    S = np.empty((len(sizes), N, 4), np.float32)
+    D = np.empty((len(sizes), N, 4), np.float32)
+    Tt = np.empty((len(sizes), 4, 4), np.float32)
+    for i, (ns, nd) in enumerate(sizes):
+        S[i], D[i], Tt[i] = synthetic.make_pair(2 * i, ns, nd, N, seed=900)     # shared-sample pairs
+    a = rp.default_args(max_points=N, icp_max_iterations=12)
+    got, iters = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+    want, aux = rp.hist_icp(a, C(S), C(D), max_iterations=12, return_aux=True)
+    assert int(iters) == aux["iterations"]
+    assert_pose_close(got.cpu().numpy(), want.numpy(), S, tol=2e-4)   # 10^4-point fp32 reductions in the oracle
+    ev = utils_match.match_eval(a, G(S), G(D), got)
+    wv = rp.match_eval(a, C(S), C(D), got.cpu())
+    np.testing.assert_allclose(ev[0].cpu().numpy(), wv[0].numpy(), atol=1e-5, rtol=1e-4)
+    np.testing.assert_array_equal(ev[1].cpu().numpy(), wv[1].numpy())
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE config 2)
 @pytest.fixture(scope="module")
 def config2():
