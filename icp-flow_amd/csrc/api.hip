@@ -273,6 +273,29 @@ int icpflow_transform_points(const float *d_xyz, const float *d_pose, int B, int
     return 0;
 }
 
+int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int N, float *d_out,
+                       icpflow_stream_t stream)
+{
+    if (!d_points || !d_rows || !d_out) return fail(ICPFLOW_E_ARG, "icpflow_gather_pad: null pointer");
+    if (int r = check_batch("icpflow_gather_pad", B, N)) return r;
+    ICPFLOW_TRY(launch_gather_pad(d_points, d_rows, B, N, d_out, (hipStream_t)stream));
+    return 0;
+}
+
+int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
+                       const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws, size_t ws_bytes,
+                       icpflow_stream_t stream)
+{
+    if (!d_points || !d_labels || !d_pose || !d_flow) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: null pointer");
+    if (N <= 0) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: N must be positive");
+    if (P < 0 || P > 2048) return fail(ICPFLOW_E_LIMIT, "icpflow_flow_rigid: 0 <= P <= 2048 pairs (got %d)", P);
+    if (P > 0 && (!d_pair_labels || !d_T)) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: null pair arrays");
+    if (int r = check_ws(d_ws, ws_bytes, (size_t)(P + 1) * 16 * sizeof(float))) return r;
+    ICPFLOW_TRY(launch_flow_rigid(d_points, d_labels, N, d_pair_labels, d_T, P, d_pose, (float *)d_ws, d_flow,
+                                  (hipStream_t)stream));
+    return 0;
+}
+
 int icpflow_count_valid(const float *d_pts, int B, int N, int32_t *d_len, icpflow_stream_t stream)
 {
     if (!d_pts || !d_len) return fail(ICPFLOW_E_ARG, "icpflow_count_valid: null pointer");

@@ -241,4 +241,81 @@ hipError_t launch_transform_points(const float *xyz, const float *pose, int B, i
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// host-association helpers: build the padded [B,N,4] batch of match_pairs
+// (utils_match.py:81-91, pad_segment utils_helper.py:185-196) and the per-point flow
+// (utils_flow.py:57-69) on the device.
+// ---------------------------------------------------------------------------------
+// rows[b,i] = row of `points` ([M,3]) that becomes point i of pair b, or -1 for a pad row
+__global__ void gather_pad_kernel(const float *__restrict__ points, const int32_t *__restrict__ rows,
+                                  size_t total, float4 *__restrict__ out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int r = rows[t];
+    float4 o = make_float4(1e8f, 1e8f, 1e8f, 0.f);                    // utils_helper.py:191-192
+    if (r >= 0) o = make_float4(points[(size_t)r * 3 + 0], points[(size_t)r * 3 + 1], points[(size_t)r * 3 + 2], 1.f);
+    out[t] = o;
+}
+
+hipError_t launch_gather_pad(const float *points, const int32_t *rows, int B, int N, float *out, hipStream_t s)
+{
+    const size_t total = (size_t)B * N;
+    hipLaunchKernelGGL(gather_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, points, rows,
+                       total, (float4 *)out);
+    return hipGetLastError();
+}
+
+// M[p] = T[p] * pose for p < P, M[P] = pose (points of unmatched clusters move with the ego pose
+// only: T_per_point starts as the identity, utils_flow.py:62-65); fp32 bmm order
+__global__ void flow_compose_kernel(const float *__restrict__ T, const float *__restrict__ pose, int P,
+                                    float *__restrict__ M)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > P) return;
+    float A[16];
+    for (int k = 0; k < 16; ++k) A[k] = (p < P) ? T[(size_t)p * 16 + k] : ((k % 5 == 0) ? 1.f : 0.f);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = A[i * 4 + 0] * pose[0 * 4 + j];
+            acc = fmaf(A[i * 4 + 1], pose[1 * 4 + j], acc);
+            acc = fmaf(A[i * 4 + 2], pose[2 * 4 + j], acc);
+            acc = fmaf(A[i * 4 + 3], pose[3 * 4 + j], acc);
+            M[(size_t)p * 16 + i * 4 + j] = acc;
+        }
+}
+
+constexpr int kFlowBlock = 256;
+constexpr int kFlowMaxPairs = 2048;   // pair labels cached in LDS
+
+__global__ __launch_bounds__(kFlowBlock) void flow_rigid_kernel(
+    const float *__restrict__ points, const float *__restrict__ labels, int N,
+    const float *__restrict__ pairLabels, int P, const float *__restrict__ M, float *__restrict__ flow)
+{
+    __shared__ float lab[kFlowMaxPairs];
+    for (int k = threadIdx.x; k < P; k += kFlowBlock) lab[k] = pairLabels[k];
+    __syncthreads();
+    const int i = blockIdx.x * kFlowBlock + threadIdx.x;
+    if (i >= N) return;
+    const float l = labels[i];
+    int p = P;                                   // not matched: pose only
+    for (int k = 0; k < P; ++k)
+        if (lab[k] == l) p = k;                  // pairs[:,0] holds each source label at most once
+    const float *m = M + (size_t)p * 16;
+    const float x = points[(size_t)i * 3 + 0], y = points[(size_t)i * 3 + 1], z = points[(size_t)i * 3 + 2];
+    // (T pose [x y z 1]^T)[0:3] - p, utils_flow.py:67-68
+    flow[(size_t)i * 3 + 0] = fmaf(1.f, m[3], fmaf(z, m[2], fmaf(y, m[1], x * m[0]))) - x;
+    flow[(size_t)i * 3 + 1] = fmaf(1.f, m[7], fmaf(z, m[6], fmaf(y, m[5], x * m[4]))) - y;
+    flow[(size_t)i * 3 + 2] = fmaf(1.f, m[11], fmaf(z, m[10], fmaf(y, m[9], x * m[8]))) - z;
+}
+
+hipError_t launch_flow_rigid(const float *points, const float *labels, int N, const float *pairLabels,
+                             const float *T, int P, const float *pose, float *M, float *flow, hipStream_t s)
+{
+    hipLaunchKernelGGL(flow_compose_kernel, dim3((P + 1 + 127) / 128), dim3(128), 0, s, T, pose, P, M);
+    hipLaunchKernelGGL(flow_rigid_kernel, dim3((N + kFlowBlock - 1) / kFlowBlock), dim3(kFlowBlock), 0, s, points,
+                       labels, N, pairLabels, P, M, flow);
+    return hipGetLastError();
+}
+
 }  // namespace icpflow

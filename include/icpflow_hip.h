@@ -205,6 +205,24 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
                        size_t ws_bytes, icpflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * a-15 / 8(f)  helpers of the host association around the path.
+ *
+ * icpflow_gather_pad builds the padded batch of match_pairs (utils_match.py:81-91 with
+ * pad_segment, utils_helper.py:185-196): d_rows int32 [B,N] holds, per pair and slot, the row of
+ * d_points ([M,3] float32) to copy (flag 1) or -1 for a pad row (1e8,1e8,1e8,0).  The caller
+ * decides the rows (cluster order, random subsample of over-long clusters).
+ *
+ * icpflow_flow_rigid replaces flow_estimation_torch (utils_flow.py:57-69): every point whose
+ * float label equals d_pair_labels[p] moves with T[p]*pose, every other point with pose alone;
+ * flow = moved - point.  d_ws: (P+1)*64 bytes of scratch.
+ * ------------------------------------------------------------------------- */
+int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int N, float *d_out,
+                       icpflow_stream_t stream);
+int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
+                       const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws,
+                       size_t ws_bytes, icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Correspondence search used inside the ICP loop (process-global tuning knob, results are
  * bit-identical in every mode):
  *   ICPFLOW_SEARCH_AUTO (0)   sorted sweep when 64 <= N <= 16384, else the all-pairs scan

@@ -322,3 +322,127 @@ def match_eval(args, pcd1, pcd2, transformations):
     return (torch.stack([err1, err2], 1), torch.stack([in1.sum(1), in2.sum(1)], 1),
             torch.stack([ratio1, ratio2], 1), torch.stack([iou1, iou2], 1),
             translations, rotations)
+
+
+# --------------------------------------------------------------------------
+# the caller of the path: cluster association and per-point flow
+# utils_check.py, utils_match.py:24-136, utils_helper.py:108-115,166-183, utils_flow.py:57-69
+# --------------------------------------------------------------------------
+def get_bbox_tensor(points):
+    """utils_helper.py:166-170: sorted axis-aligned extents."""
+    ext = [torch.abs(points[:, k].max() - points[:, k].min()) for k in range(3)]
+    return sorted(ext)
+
+
+def sanity_check(args, src_points, dst_points, src_labels, dst_labels, pairs):
+    """utils_check.py:21-49."""
+    keep = []
+    for pair in pairs:
+        src = src_points[src_labels == pair[0]]
+        dst = dst_points[dst_labels == pair[1]]
+        if min(len(src), len(dst)) < args.min_cluster_size:                       # :31
+            continue
+        if min(pair[0], pair[1]) < 0:                                             # :32
+            continue
+        if torch.linalg.norm((dst.mean(0) - src.mean(0))[0:2]) > args.translation_frame:   # :36
+            continue
+        bs, bd = get_bbox_tensor(src), get_bbox_tensor(dst)
+        if any(min(bs[k], bd[k]) < args.thres_box * max(bs[k], bd[k]) for k in range(3)):  # :41-43
+            continue
+        keep.append(pair)
+    return torch.vstack(keep) if keep else torch.zeros((0, 2))
+
+
+def check_transformation(args, translation, rotation, iou):
+    """utils_check.py:51-66."""
+    if torch.linalg.norm(translation) > args.translation_frame:
+        return False
+    if iou < args.thres_iou:
+        return False
+    if torch.abs(rotation[1:3]).max() > args.thres_rot * 90.0:
+        return False
+    return True
+
+
+def match_pairs(args, src_points, dst_points, src_labels, dst_labels, pairs):
+    """utils_match.py:69-136."""
+    su, du = torch.unique(src_labels), torch.unique(dst_labels)
+    m_err = torch.zeros((len(su), len(du), 2)) + 1e8
+    m_inl = torch.zeros((len(su), len(du), 2))
+    m_rat = torch.zeros((len(su), len(du), 2))
+    m_iou = torch.zeros((len(su), len(du), 2))
+    m_T = torch.zeros((len(su), len(du), 4, 4))
+    assert len(pairs) > 0
+    segs_src, segs_dst = [], []
+    for pair in pairs:                                                            # :81-91
+        segs_src.append(pad_segment(src_points[src_labels == pair[0], 0:3], args.max_points))
+        segs_dst.append(pad_segment(dst_points[dst_labels == pair[1], 0:3], args.max_points))
+    segs_src, segs_dst = torch.stack(segs_src), torch.stack(segs_dst)
+    T = hist_icp(args, segs_src, segs_dst)                                        # :92
+    errors, inliers, ratios, ious, translations, rotations = match_eval(args, segs_src, segs_dst, T)   # :93
+    matches = 0
+    for k, pair in enumerate(pairs):                                              # :96-108
+        if not check_transformation(args, translations[k], rotations[k], min(ious[k])):
+            continue
+        i = torch.nonzero(su == pair[0])
+        j = torch.nonzero(du == pair[1])
+        m_err[i, j, :] = errors[k]
+        m_inl[i, j, :] = inliers[k]
+        m_rat[i, j, :] = ratios[k]
+        m_iou[i, j, :] = ious[k]
+        m_T[i, j] = T[k]
+        matches += 1
+    if matches == 0:
+        return torch.zeros((0, 10)), torch.zeros((0, 4, 4))
+    err_min = m_err.min(-1)[0]
+    rows = torch.arange(0, len(err_min))                                          # utils_helper.py:108-110
+    cols = torch.argmin(err_min, dim=1)
+    ok = err_min[rows, cols] < args.thres_error                                   # :112
+    rows, cols = rows[ok], cols[ok]
+    out = torch.cat([su[rows][:, None], du[cols][:, None], m_err[rows, cols], m_inl[rows, cols],
+                     m_rat[rows, cols], m_iou[rows, cols]], dim=1)                # :123-128
+    return out, m_T[rows, cols]
+
+
+def setdiff1d(t1, t2):
+    """utils_helper.py:172-183."""
+    t12, counts = torch.cat([torch.unique(t1), torch.unique(t2)]).unique(return_counts=True)
+    return t12[torch.where(counts.eq(1))]
+
+
+def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
+    """utils_match.py:24-66."""
+    su = torch.unique(src_labels).long()
+    du = torch.unique(dst_labels).long()
+    lu = torch.unique(torch.cat([su, du]))
+    pairs = torch.stack([lu, lu], dim=1)
+    pairs = pairs[pairs.min(dim=1)[0] >= 0]                                       # :30-31
+    true = sanity_check(args, src_points, dst_points, src_labels, dst_labels, pairs)
+    if len(true) > 0:
+        p_sta, T_sta = match_pairs(args, src_points, dst_points, src_labels, dst_labels, true)
+    else:
+        p_sta, T_sta = torch.zeros((0, 10)), torch.zeros((0, 4, 4))
+    if len(p_sta) < len(lu):                                                      # :45
+        if len(p_sta) > 0:
+            su = setdiff1d(su, p_sta[:, 0])
+            du = setdiff1d(du, p_sta[:, 1])
+        pairs = torch.stack([su.repeat_interleave(len(du)), du.repeat(len(su))], dim=1)
+        true = sanity_check(args, src_points, dst_points, src_labels, dst_labels, pairs)
+    else:
+        true = torch.zeros(0, 2)
+    if len(true) > 0:
+        p_dyn, T_dyn = match_pairs(args, src_points, dst_points, src_labels, dst_labels, true)
+    else:
+        p_dyn, T_dyn = torch.zeros((0, 10)), torch.zeros((0, 4, 4))
+    return torch.cat([p_sta, p_dyn], dim=0), torch.cat([T_sta, T_dyn], dim=0)
+
+
+def flow_estimation_torch(src_points, src_labels, pairs, transformations, pose):
+    """utils_flow.py:57-69."""
+    n = len(src_points)
+    T = torch.eye(4)[None].repeat(n, 1, 1)
+    rows, cols = torch.nonzero((src_labels[:, None] - pairs[:, 0][None, :]) == 0, as_tuple=True)
+    T[rows] = transformations[cols]
+    T = torch.bmm(T, pose[None].expand(n, 4, 4))
+    hom = torch.cat([src_points, src_points.new_ones(n, 1)], dim=-1)
+    return torch.bmm(T, hom[:, :, None])[:, 0:3, 0] - src_points

@@ -384,6 +384,41 @@ def test_hist_icp_real_data_shape_large_padding():
     np.testing.assert_array_equal(ev[1].cpu().numpy(), wv[1].numpy())
 
 
+# ------------------------------------------------------------------ 8(f): association + flow on the demo frame
+def test_demo_frame_pair_track_and_flow_vs_reference():
+    """BASELINE config 1 (G8): demo.npz frame pair through the HIP path -- match_pcds (both stages:
+    sanity_check, gather/pad, hist_icp, match_eval, reject, arg-min) and the flow kernel -- against
+    the reference's own pairs / transforms / per-point flow (63 276 points)."""
+    from icp_flow_amd import utils_flow, utils_track
+    g = load_golden("g8_demo")
+    lab = load_golden("g8_demo_labels")
+    a = rp.default_args(max_points=int(g["max_points"]), min_cluster_size=20, translation_frame=2.0,
+                        thres_box=0.1, thres_rot=0.1, thres_error=0.2, thres_iou=0.2)
+    torch.manual_seed(0)
+    ps, pd = G(g["point_src"]), G(g["point_dst"])
+    ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
+    pairs, Tm = utils_track.track(a, ps, pd, ls, ld)
+    flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, torch.eye(4, device=DEV))
+    pairs, Tm, flow = pairs.cpu().numpy(), Tm.cpu().numpy(), flow.cpu().numpy()
+    ref_pairs, ref_T, ref_flow = g["pairs"], g["transformations"], g["flow"]
+    got = {int(p[0]): (int(p[1]), k) for k, p in enumerate(pairs)}
+    ref = {int(p[0]): (int(p[1]), k) for k, p in enumerate(ref_pairs)}
+    assert set(got) == set(ref), (sorted(set(got) ^ set(ref)))
+    assert all(got[s][0] == ref[s][0] for s in ref)
+    order = [got[int(p[0])][1] for p in ref_pairs]
+    np.testing.assert_allclose(pairs[order][:, 2:4], ref_pairs[:, 2:4], atol=2e-4)        # errors
+    np.testing.assert_allclose(pairs[order][:, 4:6], ref_pairs[:, 4:6], atol=2)            # inlier counts
+    err = np.linalg.norm(flow - ref_flow, axis=1)
+    frac = float(np.mean(err < TOL_M))
+    assert frac >= 0.97, f"per-point flow within 1e-4 m of the reference on {frac:.4f} of the points, max {err.max():.3e}"
+    # the flow kernel alone, fed with the reference's pairs / transforms
+    flow2 = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, G(ref_pairs), G(ref_T), torch.eye(4, device=DEV))
+    np.testing.assert_allclose(flow2.cpu().numpy(), ref_flow, atol=2e-5)
+    # EPE against ground truth equals the reference's (utils_eval.py:137-182 epe3d)
+    epe = float(np.linalg.norm(flow - g["gt_flow"], axis=1).mean())
+    assert abs(epe - float(g["epe"])) < 2e-4
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE config 2)
 @pytest.fixture(scope="module")
 def config2():

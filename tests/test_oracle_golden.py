@@ -152,3 +152,27 @@ def test_hist_icp_dense_config2_shape():
     ref = np.einsum("bij,bnj->bni", g["T_hist_icp"][:, :3, :3], p) + g["T_hist_icp"][:, None, :3, 3]
     tru = np.einsum("bij,bnj->bni", Tt[:, :3, :3], p) + Tt[:, None, :3, 3]
     assert np.abs(ref - tru).max(axis=(1, 2))[0::2].max() < 0.01
+
+
+def test_demo_frame_pair_match_pcds_and_flow():
+    """G8 (BASELINE config 1): the oracle's restatement of match_pcds (both association stages,
+    sanity_check, reject + row arg-min) and of flow_estimation_torch on the reference's demo frame,
+    against the reference's own output (81 matched clusters, per-point flow of 63 276 points)."""
+    g = load_golden("g8_demo")
+    lab = load_golden("g8_demo_labels")
+    a = rp.default_args(max_points=int(g["max_points"]), min_cluster_size=20, translation_frame=2.0,
+                        thres_box=0.1, thres_rot=0.1, thres_error=0.2, thres_iou=0.2)
+    torch.manual_seed(0)
+    ps, pd = T(g["point_src"]), T(g["point_dst"])
+    ls, ld = T(lab["label_src"]).float(), T(lab["label_dst"]).float()
+    pairs, Tm = rp.match_pcds(a, ps, pd, ls, ld)
+    ref_pairs, ref_T = g["pairs"], g["transformations"]
+    # the restatement reproduces the reference's run exactly: same pairs, bit-equal transforms / flow
+    assert np.array_equal(pairs[:, 0:2].numpy(), ref_pairs[:, 0:2])
+    np.testing.assert_allclose(pairs.numpy(), ref_pairs, atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(Tm.numpy(), ref_T, atol=1e-6)
+    flow = rp.flow_estimation_torch(ps, ls, pairs, Tm, torch.eye(4))
+    np.testing.assert_allclose(flow.numpy(), g["flow"], atol=1e-6)
+    # flow kernel restatement alone, from the reference's pairs / transforms: exact
+    flow2 = rp.flow_estimation_torch(ps, ls, T(ref_pairs), T(ref_T), torch.eye(4))
+    np.testing.assert_allclose(flow2.numpy(), g["flow"], atol=1e-6)
