@@ -282,6 +282,16 @@ int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int 
     return 0;
 }
 
+int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
+                          const int64_t *d_count, int L, float *d_mean, float *d_extent, icpflow_stream_t stream)
+{
+    if (!d_points || !d_order || !d_start || !d_count || !d_mean || !d_extent)
+        return fail(ICPFLOW_E_ARG, "icpflow_cluster_stats: null pointer");
+    if (L <= 0) return fail(ICPFLOW_E_ARG, "icpflow_cluster_stats: L must be positive (got %d)", L);
+    ICPFLOW_TRY(launch_cluster_stats(d_points, d_order, d_start, d_count, L, d_mean, d_extent, (hipStream_t)stream));
+    return 0;
+}
+
 int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
                        const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws, size_t ws_bytes,
                        icpflow_stream_t stream)

@@ -266,6 +266,71 @@ hipError_t launch_gather_pad(const float *points, const int32_t *rows, int B, in
     return hipGetLastError();
 }
 
+// per-cluster statistics consumed by sanity_check (utils_check.py:34-43): centroid and the
+// ascending-sorted axis-aligned bbox extents (get_bbox_tensor, utils_helper.py:166-170) of every
+// cluster of a labelled cloud.  order = rows sorted by label; cluster c owns order[start[c] ..
+// start[c]+count[c]).  One workgroup per cluster, sums in fp64 (order independent to fp32 rounding).
+constexpr int kStatsBlock = 256;
+__global__ __launch_bounds__(kStatsBlock) void cluster_stats_kernel(
+    const float *__restrict__ points, const int64_t *__restrict__ order, const int64_t *__restrict__ start,
+    const int64_t *__restrict__ count, float *__restrict__ mean, float *__restrict__ extent)
+{
+    __shared__ double ssum[kStatsBlock / kWave][3];
+    __shared__ float smin[kStatsBlock / kWave][3], smax[kStatsBlock / kWave][3];
+    const int c = blockIdx.x;
+    const int64_t s0 = start[c], n = count[c];
+    double sum[3] = {0.0, 0.0, 0.0};
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = threadIdx.x; i < n; i += kStatsBlock) {
+        const int64_t r = order[s0 + i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = points[r * 3 + k];
+            sum[k] += (double)v;
+            mn[k] = fminf(mn[k], v);
+            mx[k] = fmaxf(mx[k], v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        sum[k] = wave_sum(sum[k]);
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], o));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o));
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        for (int k = 0; k < 3; ++k) { ssum[wave][k] = sum[k]; smin[wave][k] = mn[k]; smax[wave][k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float e[3];
+        for (int k = 0; k < 3; ++k) {
+            double t = ssum[0][k];
+            float lo = smin[0][k], hi = smax[0][k];
+            for (int w = 1; w < kStatsBlock / kWave; ++w) {
+                t += ssum[w][k];
+                lo = fminf(lo, smin[w][k]);
+                hi = fmaxf(hi, smax[w][k]);
+            }
+            mean[(size_t)c * 3 + k] = (float)(t / (double)n);
+            e[k] = fabsf(hi - lo);
+        }
+        if (e[0] > e[1]) { const float t = e[0]; e[0] = e[1]; e[1] = t; }
+        if (e[1] > e[2]) { const float t = e[1]; e[1] = e[2]; e[2] = t; }
+        if (e[0] > e[1]) { const float t = e[0]; e[0] = e[1]; e[1] = t; }
+        for (int k = 0; k < 3; ++k) extent[(size_t)c * 3 + k] = e[k];
+    }
+}
+
+hipError_t launch_cluster_stats(const float *points, const int64_t *order, const int64_t *start,
+                                const int64_t *count, int L, float *mean, float *extent, hipStream_t s)
+{
+    hipLaunchKernelGGL(cluster_stats_kernel, dim3(L), dim3(kStatsBlock), 0, s, points, order, start, count, mean,
+                       extent);
+    return hipGetLastError();
+}
+
 // M[p] = T[p] * pose for p < P, M[P] = pose (points of unmatched clusters move with the ego pose
 // only: T_per_point starts as the identity, utils_flow.py:62-65); fp32 bmm order
 __global__ void flow_compose_kernel(const float *__restrict__ T, const float *__restrict__ pose, int P,

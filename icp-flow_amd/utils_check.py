@@ -2,9 +2,11 @@
 
 The reference loops over candidate pairs in Python and reads device scalars one by one
 (utils_check.py:21-49, implicit syncs); here per-cluster statistics are reduced once per cloud
-(`ClusterTable`) and the three tests are a handful of vectorised comparisons.
+(`ClusterTable`, one workgroup per cluster: `icpflow_cluster_stats`) and the three tests are a handful of vectorised comparisons.
 """
 import torch
+
+from . import _lib
 
 
 class ClusterTable:
@@ -26,14 +28,11 @@ class ClusterTable:
         self.labels_unq, self.count = torch.unique_consecutive(sorted_labels, return_counts=True)
         self.start = torch.cumsum(self.count, 0) - self.count
         L = len(self.labels_unq)
-        seg = torch.repeat_interleave(torch.arange(L, device=labels.device), self.count)
-        pts = self.points[self.order]
-        s = torch.zeros((L, 3), dtype=torch.float32, device=labels.device).index_add_(0, seg, pts)
-        self.mean = s / self.count[:, None].float()
-        idx = seg[:, None].expand(-1, 3)
-        mn = torch.full((L, 3), float("inf"), device=labels.device).scatter_reduce_(0, idx, pts, "amin")
-        mx = torch.full((L, 3), float("-inf"), device=labels.device).scatter_reduce_(0, idx, pts, "amax")
-        self.extent = torch.sort((mx - mn).abs(), dim=1)[0]
+        self.mean = torch.empty((L, 3), dtype=torch.float32, device=labels.device)
+        self.extent = torch.empty((L, 3), dtype=torch.float32, device=labels.device)
+        _lib.require_gpu(self.points, labels)
+        _lib.call("icpflow_cluster_stats", _lib.ptr(self.points), _lib.ptr(self.order), _lib.ptr(self.start),
+                  _lib.ptr(self.count), L, _lib.ptr(self.mean), _lib.ptr(self.extent), _lib.stream(labels.device))
 
     def find(self, wanted):
         """Index of each wanted label in labels_unq, or -1 where the cloud has no such cluster."""

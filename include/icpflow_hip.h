@@ -212,12 +212,20 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
  * d_points ([M,3] float32) to copy (flag 1) or -1 for a pad row (1e8,1e8,1e8,0).  The caller
  * decides the rows (cluster order, random subsample of over-long clusters).
  *
+ * icpflow_cluster_stats reduces what sanity_check reads per cluster (utils_check.py:34-43,
+ * get_bbox_tensor utils_helper.py:166-170): d_order int64 [M] = rows of d_points ([M,3]) sorted by
+ * label, cluster c = d_order[d_start[c] .. d_start[c]+d_count[c]) (int64 [L] each); outputs the
+ * centroid d_mean [L,3] and the ascending-sorted bbox extents d_extent [L,3] (float32).
+ *
  * icpflow_flow_rigid replaces flow_estimation_torch (utils_flow.py:57-69): every point whose
  * float label equals d_pair_labels[p] moves with T[p]*pose, every other point with pose alone;
  * flow = moved - point.  d_ws: (P+1)*64 bytes of scratch.
  * ------------------------------------------------------------------------- */
 int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int N, float *d_out,
                        icpflow_stream_t stream);
+int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
+                          const int64_t *d_count, int L, float *d_mean, float *d_extent,
+                          icpflow_stream_t stream);
 int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
                        const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws,
                        size_t ws_bytes, icpflow_stream_t stream);

@@ -1,4 +1,6 @@
-import sys, time; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from conftest import load_golden
 from icp_flow_amd import utils_flow, utils_track
