@@ -1,0 +1,209 @@
+"""Frame-pair stream: the unit of work above the registration path.
+
+A frame pair is what the reference's loop hands to `track` (main.py:184-215, demo.py:37-71): two
+ego-compensated, ground-free clouds with precomputed cluster labels (ground -1e8, noise -1,
+clusters >= 0), the relative ego pose and -- for evaluation -- the ground-truth flow of the source
+points.  On disk: one .npz per pair with keys
+
+    points_src [Ns,3]  points_dst [Nd,3]  labels_src [Ns]  labels_dst [Nd]
+    pose [4,4] (optional, identity)       gt_flow [Ns,3] (optional)     mask [Ns] (optional)
+
+or the reference's Argoverse/demo keys (dataset_argo.py:34-45: pc1, pc2, pc1_flows_valid_idx,
+pc2_flows_valid_idx, gt_flow_0_1) plus labels_src / labels_dst (clustering is precomputed: BASELINE
+configs).
+
+`run_stream` registers every pair of a directory (round-robin over ranks: frame pairs are
+independent, main.py:184), and reports ms / frame pair and the reference's accuracy metrics.
+
+    python -m icp_flow_amd.frame_pairs DIR [--max-points 10000] [--speed 1.0] [--repeat 3]
+"""
+import argparse
+import glob
+import json
+import os
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import utils_eval, utils_flow, utils_track
+
+# demo.sh:9-13 / main.sh flags of the registration stage
+DEFAULT_ARGS = dict(max_points=10000, min_cluster_size=20, translation_frame=2.0, thres_dist=0.1, thres_box=0.1,
+                    thres_rot=0.1, thres_error=0.2, thres_iou=0.2, chunk_size=50, speed=None)
+
+
+def default_args(**over):
+    d = dict(DEFAULT_ARGS)
+    d.update(over)
+    return SimpleNamespace(**d)
+
+
+class FramePair:
+    def __init__(self, points_src, points_dst, labels_src, labels_dst, pose=None, gt_flow=None, mask=None,
+                 name=""):
+        self.points_src = np.ascontiguousarray(points_src, dtype=np.float32)[:, 0:3]
+        self.points_dst = np.ascontiguousarray(points_dst, dtype=np.float32)[:, 0:3]
+        self.labels_src = np.ascontiguousarray(labels_src, dtype=np.float32)
+        self.labels_dst = np.ascontiguousarray(labels_dst, dtype=np.float32)
+        if len(self.labels_src) != len(self.points_src) or len(self.labels_dst) != len(self.points_dst):
+            raise ValueError(f"frame pair {name!r}: one label per point required "
+                             f"({len(self.labels_src)}/{len(self.points_src)} src, "
+                             f"{len(self.labels_dst)}/{len(self.points_dst)} dst)")
+        self.pose = np.eye(4, dtype=np.float32) if pose is None else np.asarray(pose, dtype=np.float32).reshape(4, 4)
+        self.gt_flow = None if gt_flow is None else np.asarray(gt_flow, dtype=np.float32)
+        if self.gt_flow is not None and self.gt_flow.shape != self.points_src.shape:
+            raise ValueError(f"frame pair {name!r}: gt_flow must be [Ns,3]")
+        self.mask = None if mask is None else np.asarray(mask)
+        self.name = name
+
+
+def save_frame_pair(path, fp):
+    arrays = dict(points_src=fp.points_src, points_dst=fp.points_dst, labels_src=fp.labels_src,
+                  labels_dst=fp.labels_dst, pose=fp.pose)
+    if fp.gt_flow is not None:
+        arrays["gt_flow"] = fp.gt_flow
+    if fp.mask is not None:
+        arrays["mask"] = fp.mask
+    np.savez_compressed(path, **arrays)
+
+
+def load_frame_pair(path):
+    with np.load(path) as z:
+        keys = set(z.files)
+
+        def first(*names):
+            for n in names:
+                if n in keys:
+                    return z[n]
+            return None
+
+        labels_src, labels_dst = first("labels_src", "label_src"), first("labels_dst", "label_dst")
+        if labels_src is None or labels_dst is None:
+            raise ValueError(f"{path}: cluster labels (labels_src / labels_dst) are required -- clustering is "
+                             "precomputed, not part of this path")
+        if "points_src" in keys:
+            return FramePair(z["points_src"], z["points_dst"], labels_src, labels_dst, first("pose"),
+                             first("gt_flow"), first("mask"), name=os.path.basename(path))
+        if "pc1" in keys:                                   # dataset_argo.py:34-53, demo.py:37-51
+            v0, v1 = z["pc1_flows_valid_idx"], z["pc2_flows_valid_idx"]
+            gt = z["gt_flow_0_1"][v0] if "gt_flow_0_1" in keys else None
+            return FramePair(z["pc1"][v0], z["pc2"][v1], labels_src, labels_dst, first("pose"), gt, first("mask"),
+                             name=os.path.basename(path))
+        raise ValueError(f"{path}: neither points_src/points_dst nor pc1/pc2 present")
+
+
+def list_frame_pairs(directory):
+    return sorted(glob.glob(os.path.join(directory, "**", "*.npz"), recursive=True))
+
+
+def shard_round_robin(items, rank, world):
+    """frame pairs are dealt round-robin to ranks (keeps the association of a frame
+    pair on one GPU)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return list(items[rank::world])
+
+
+def frame_translation(args, pose, gap=1):
+    """main.py:200: translation_frame = 2 * max(speed * gap, |ego translation|); unchanged when the
+    caller fixed translation_frame (speed None), as demo.py:205 does."""
+    if getattr(args, "speed", None) is None:
+        return float(args.translation_frame)
+    return float(max(args.speed * gap, float(np.linalg.norm(np.asarray(pose)[0:3, 3])))) * 2.0
+
+
+def register_frame_pair(args, fp, device, gap=1):
+    """One frame pair through track() + flow_estimation_torch() on `device`.
+    -> dict(pairs [P,10], transformations [P,4,4], flow [Ns,3]) of device tensors."""
+    a = SimpleNamespace(**vars(args))
+    a.translation_frame = frame_translation(args, fp.pose, gap)
+    ps = torch.from_numpy(fp.points_src).to(device)
+    pd = torch.from_numpy(fp.points_dst).to(device)
+    ls = torch.from_numpy(fp.labels_src).to(device)
+    ld = torch.from_numpy(fp.labels_dst).to(device)
+    pose = torch.from_numpy(fp.pose).to(device)
+    torch.manual_seed(0)                                    # main.py:139 (random subsampling of over-long clusters)
+    pairs, T = utils_track.track(a, ps, pd, ls, ld)
+    flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, T, pose)
+    return dict(pairs=pairs, transformations=T, flow=flow)
+
+
+def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, register_fn=None):
+    """Register this rank's share of `paths`; -> summary dict (identical on every rank).
+    ms / frame pair is the mean wall time per pair, host -> device upload of the clouds included
+    (the stream hands over host buffers); frame_pairs_per_s uses the slowest rank's total.
+    `register_fn(args, fp, device) -> dict(pairs, transformations, flow)` defaults to the HIP path
+    (`register_frame_pair`); the CPU tests of the sharding logic pass the oracle here."""
+    import torch.distributed as dist
+    device = torch.device(device)
+    register_fn = register_fn or register_frame_pair
+
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    mine = shard_round_robin(paths, rank, world)
+    meter = utils_eval.AverageMeter()
+    times, matched = [], 0
+    for path in mine:
+        fp = load_frame_pair(path)
+        if repeat > 1:
+            register_fn(args, fp, device)                   # untimed pass: page-in, allocator
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(repeat):
+            out = register_fn(args, fp, device)
+        sync()
+        times.append((time.perf_counter() - t0) / repeat * 1e3)
+        matched += int(out["pairs"].shape[0])
+        if fp.gt_flow is not None:
+            m = utils_eval.compute_epe_test(out["flow"].cpu().numpy(), fp.gt_flow, fp.mask)
+            n = int((np.asarray(fp.mask) > 0).sum()) if fp.mask is not None else len(fp.gt_flow)
+            meter.update(*m, n)
+    # five weighted sums + point count + time + frame pairs + matches: one small all_reduce
+    local = [getattr(meter, m + "_sum") for m in utils_eval.METRIC_NAMES] + [meter.num, sum(times), len(times), matched]
+    on_gpu = world > 1 and dist.get_backend(group) == "nccl"
+    tot = torch.tensor(local, dtype=torch.float64, device=device if on_gpu else "cpu")
+    tmax = torch.tensor([sum(times)], dtype=torch.float64, device=tot.device)
+    if world > 1:
+        dist.all_reduce(tot, group=group)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+    tot = tot.tolist()
+    n_pts, n_fp = tot[5], int(tot[7])
+    out = {"frame_pairs": n_fp, "matched_cluster_pairs": int(tot[8]), "n_gpus": world,
+           "ms_per_frame_pair": tot[6] / max(n_fp, 1),
+           "frame_pairs_per_s": n_fp / (float(tmax.item()) * 1e-3) if n_fp else 0.0,
+           "evaluated_points": int(n_pts)}
+    if n_pts > 0:
+        out.update({m: tot[k] / n_pts for k, m in enumerate(utils_eval.METRIC_NAMES)})
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("directory")
+    ap.add_argument("--repeat", type=int, default=1)
+    for k, v in DEFAULT_ARGS.items():
+        ap.add_argument("--" + k.replace("_", "-"), type=float if isinstance(v, float) or v is None else type(v), default=v)
+    ns = ap.parse_args(argv)
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    args = SimpleNamespace(**{k: getattr(ns, k) for k in DEFAULT_ARGS})
+    args.max_points, args.min_cluster_size, args.chunk_size = int(args.max_points), int(args.min_cluster_size), int(args.chunk_size)
+    summary = run_stream(args, list_frame_pairs(ns.directory), device, rank, world, ns.repeat)
+    if rank == 0:
+        print(json.dumps(summary))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

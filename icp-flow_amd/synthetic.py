@@ -74,3 +74,55 @@ def make_batch(num_pairs, max_points, seed=0, first=0, ragged=False, n_min=20):
             ns = nd = max_points
         S[i], D[i], T[i] = make_pair(k, ns, nd, max_points, seed)
     return S, D, T
+
+
+def make_frame_pair(seed=0, n_objects=24, n_min=30, n_max=1500, relabel=0.25, n_background=4000, noise=0.01):
+    """A labelled synthetic frame pair in the format of the frame-pair stream (frame_pairs.py).
+
+    n_objects vehicle-like shells on a jittered 14 m grid, object k with n_k ~ logUniform(n_min,
+    n_max) source points (the destination frame sees 0.8-1.25x as many of the same surface samples,
+    plus sensor noise), each moved by a small
+    rigid motion (yaw <= 3 deg, |t_xy| <= 0.8 m).  Source label of object k is k; in the destination
+    frame a fraction `relabel` of the objects carries a fresh label (their association has to come
+    from stage 2 of match_pcds).  Background: static points labelled ground (-1e8) and noise (-1).
+    -> dict(points_src, points_dst, labels_src, labels_dst, pose, gt_flow, T_true [n_objects,4,4])."""
+    rng = np.random.default_rng(77_000_003 + seed)
+    side = int(np.ceil(np.sqrt(n_objects)))
+    ps, pd, ls, ld, gt, Ts = [], [], [], [], [], []
+    fresh = 1000
+    for k in range(n_objects):
+        ns = int(round(np.exp(rng.uniform(np.log(n_min), np.log(n_max)))))
+        nd = int(round(ns * rng.uniform(0.8, 1.25)))
+        ext = np.array([rng.uniform(1.5, 5.0), rng.uniform(1.0, 2.2), rng.uniform(1.0, 2.0)])
+        centre = np.array([(k % side - side / 2) * 14.0 + rng.uniform(-2, 2), (k // side - side / 2) * 14.0 + rng.uniform(-2, 2),
+                           rng.uniform(0.5, 1.2)])
+        yaw = np.deg2rad(rng.uniform(-3.0, 3.0))
+        t = np.array([rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(-0.03, 0.03)])
+        c, s = np.cos(yaw), np.sin(yaw)
+        Rz = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+        h = rng.uniform(-np.pi, np.pi)
+        Rh = np.array([[np.cos(h), -np.sin(h), 0.0], [np.sin(h), np.cos(h), 0.0], [0.0, 0.0, 1.0]])
+        shared = _shell_points(rng, ext, max(ns, nd))     # sparse clusters: both frames see the same samples
+        src = shared[:ns] @ Rh.T + centre
+        dst = (shared[:nd] @ Rh.T) @ Rz.T + centre + t + rng.normal(0.0, noise, size=(nd, 3))
+        T = np.eye(4)
+        T[:3, :3] = Rz
+        T[:3, 3] = centre + t - Rz @ centre
+        ps.append(src); pd.append(dst)
+        ls.append(np.full(ns, float(k)))
+        moved = rng.uniform() < relabel
+        ld.append(np.full(nd, float(fresh if moved else k)))
+        fresh += 1 if moved else 0
+        gt.append(src @ Rz.T + T[:3, 3] - src)
+        Ts.append(T)
+    span = side * 7.0 + 10.0
+    for lab, frac in ((-1e8, 0.8), (-1.0, 0.2)):
+        n = int(n_background * frac)
+        bg = np.stack([rng.uniform(-span, span, n), rng.uniform(-span, span, n), rng.uniform(-0.2, 0.1, n)], axis=1)
+        ps.append(bg); ls.append(np.full(n, lab)); gt.append(np.zeros((n, 3)))
+        pd.append(bg + rng.normal(0.0, noise, size=bg.shape)); ld.append(np.full(n, lab))
+    perm_s, perm_d = rng.permutation(sum(map(len, ps))), rng.permutation(sum(map(len, pd)))
+    f32 = lambda parts, perm: np.concatenate(parts, axis=0).astype(np.float32)[perm]
+    return dict(points_src=f32(ps, perm_s), points_dst=f32(pd, perm_d), labels_src=f32(ls, perm_s),
+                labels_dst=f32(ld, perm_d), pose=np.eye(4, dtype=np.float32), gt_flow=f32(gt, perm_s),
+                T_true=np.stack(Ts).astype(np.float32))

@@ -1,0 +1,128 @@
+"""accuracy metrics (G9) and the frame-pair stream (format, sharding)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+from icp_flow_amd import frame_pairs, synthetic, utils_eval
+
+
+def test_compute_epe_matches_reference_golden():
+    g8, g9 = load_golden("g8_demo"), load_golden("g9_epe")
+    flow, gt = g8["flow"], g8["gt_flow"]
+    assert np.allclose(utils_eval.compute_epe_test(flow, gt), g9["whole"], rtol=0, atol=1e-12)
+    assert np.allclose(utils_eval.compute_epe_test(flow, gt, g9["mask"]), g9["masked"], rtol=0, atol=1e-12)
+    assert np.allclose(utils_eval.compute_epe_test(g9["tiny_pred"], g9["tiny_gt"]), g9["tiny"], rtol=0, atol=1e-12)
+    h = int(g9["split"])
+    meter = utils_eval.AverageMeter()
+    per = []
+    for sl in (slice(0, h), slice(h, len(flow))):
+        m = utils_eval.compute_epe_test(flow[sl], gt[sl])
+        per.append(m)
+        meter.update(*m, sl.stop - sl.start)
+    assert np.allclose(np.array(per, dtype=np.float64), g9["per_frame"], rtol=0, atol=1e-12)
+    assert np.allclose(list(meter.averages().values()), g9["meter_avg"], rtol=0, atol=1e-12)
+    assert np.isclose(utils_eval.average_meter([p[0] for p in per], [h, len(flow) - h]), float(g9["average_meter_epe"]),
+                      rtol=0, atol=1e-12)
+    assert meter.num == len(flow) and meter.num_data == [h, len(flow) - h]
+
+
+def _tiny_stream(tmp_path, n=3):
+    paths = []
+    for k in range(n):
+        d = synthetic.make_frame_pair(seed=k, n_objects=4, n_max=200, n_background=200)
+        fp = frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"],
+                                   d["gt_flow"])
+        path = os.path.join(tmp_path, f"fp_{k:03d}.npz")
+        frame_pairs.save_frame_pair(path, fp)
+        paths.append(path)
+    return paths
+
+
+def test_frame_pair_formats_round_trip(tmp_path):
+    d = synthetic.make_frame_pair(seed=3, n_objects=3, n_max=100, n_background=100)
+    fp = frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"],
+                               d["gt_flow"])
+    p = os.path.join(tmp_path, "a.npz")
+    frame_pairs.save_frame_pair(p, fp)
+    back = frame_pairs.load_frame_pair(p)
+    for k in ("points_src", "points_dst", "labels_src", "labels_dst", "pose", "gt_flow"):
+        assert np.array_equal(getattr(back, k), getattr(fp, k)), k
+    # the reference's Argoverse / demo keys (dataset_argo.py:34-53): valid-index selection applies
+    ns, nd = len(fp.points_src), len(fp.points_dst)
+    v0 = np.arange(0, ns, 2)
+    v1 = np.arange(1, nd, 3)
+    q = os.path.join(tmp_path, "b.npz")
+    np.savez(q, pc1=fp.points_src, pc2=fp.points_dst, pc1_flows_valid_idx=v0, pc2_flows_valid_idx=v1,
+             gt_flow_0_1=fp.gt_flow, labels_src=fp.labels_src[v0], labels_dst=fp.labels_dst[v1])
+    argo = frame_pairs.load_frame_pair(q)
+    assert np.array_equal(argo.points_src, fp.points_src[v0]) and np.array_equal(argo.points_dst, fp.points_dst[v1])
+    assert np.array_equal(argo.gt_flow, fp.gt_flow[v0]) and np.array_equal(argo.pose, np.eye(4, dtype=np.float32))
+    # labels are mandatory and must be one per point
+    np.savez(os.path.join(tmp_path, "c.npz"), points_src=fp.points_src, points_dst=fp.points_dst)
+    with pytest.raises(ValueError):
+        frame_pairs.load_frame_pair(os.path.join(tmp_path, "c.npz"))
+    with pytest.raises(ValueError):
+        frame_pairs.FramePair(fp.points_src, fp.points_dst, fp.labels_src[:-1], fp.labels_dst)
+    assert frame_pairs.list_frame_pairs(str(tmp_path)) == sorted(os.path.join(tmp_path, f) for f in ("a.npz", "b.npz", "c.npz"))
+
+
+def test_round_robin_and_translation_frame():
+    items = list(range(7))
+    parts = [frame_pairs.shard_round_robin(items, r, 3) for r in range(3)]
+    assert parts == [[0, 3, 6], [1, 4], [2, 5]]
+    assert sorted(sum(parts, [])) == items
+    with pytest.raises(ValueError):
+        frame_pairs.shard_round_robin(items, 3, 3)
+    pose = np.eye(4)
+    pose[0:3, 3] = (3.0, 4.0, 0.0)
+    a = frame_pairs.default_args(translation_frame=2.0)
+    assert frame_pairs.frame_translation(a, pose) == 2.0                   # fixed (demo.py:205)
+    a.speed = 1.67
+    assert frame_pairs.frame_translation(a, pose) == 10.0                  # ego motion dominates (main.py:200)
+    assert frame_pairs.frame_translation(a, np.eye(4), gap=2) == pytest.approx(6.68)
+
+
+def _oracle_register(args, fp, device):
+    from oracle import reference_path as rp
+    G = torch.from_numpy
+    torch.manual_seed(0)
+    pairs, T = rp.match_pcds(args, G(fp.points_src), G(fp.points_dst), G(fp.labels_src), G(fp.labels_dst))
+    flow = rp.flow_estimation_torch(G(fp.points_src), G(fp.labels_src), pairs, T, G(fp.pose))
+    return dict(pairs=pairs, transformations=T, flow=flow)
+
+
+def _stream_worker(rank, world, port, paths, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    args = frame_pairs.default_args(max_points=256)
+    s = frame_pairs.run_stream(args, paths, "cpu", rank, world, register_fn=_oracle_register)
+    if rank == 0:
+        np.save(out, np.array([s[k] for k in ("frame_pairs", "matched_cluster_pairs", "evaluated_points", "epe", "accs",
+                                              "accr", "outlier", "Routlier")], dtype=np.float64))
+    dist.destroy_process_group()
+
+
+def test_stream_two_ranks_equals_single_process(tmp_path):
+    """Round-robin sharding + the one all_reduce of the summary (gloo, world 2) reproduce the
+    single-process accuracy summary; registration itself is the oracle here (no GPU)."""
+    paths = _tiny_stream(str(tmp_path), 3)
+    torch.set_num_threads(2)
+    one = frame_pairs.run_stream(frame_pairs.default_args(max_points=256), paths, "cpu", register_fn=_oracle_register)
+    assert one["frame_pairs"] == 3 and one["matched_cluster_pairs"] >= 9 and one["epe"] < 0.02
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = os.path.join(tmp_path, "two.npy")
+    mp.spawn(_stream_worker, args=(2, port, paths, out), nprocs=2, join=True)
+    two = np.load(out)
+    want = np.array([one[k] for k in ("frame_pairs", "matched_cluster_pairs", "evaluated_points", "epe", "accs", "accr",
+                                      "outlier", "Routlier")], dtype=np.float64)
+    assert np.allclose(two, want, rtol=1e-12, atol=0)

@@ -419,6 +419,59 @@ def test_demo_frame_pair_track_and_flow_vs_reference():
     assert abs(epe - float(g["epe"])) < 2e-4
 
 
+def test_cluster_stats_kernel_vs_torch():
+    """icpflow_cluster_stats (centroid, sorted bbox extents per label) against plain torch per cluster."""
+    from icp_flow_amd.utils_check import ClusterTable
+    rng = np.random.default_rng(12)
+    pts = rng.normal(0, 20, size=(20000, 3)).astype(np.float32)
+    lab = rng.choice(np.array([-1e8, -1.0, 0, 1, 2, 7, 19, 300], dtype=np.float32), size=len(pts),
+                     p=[0.6, 0.1, 0.05, 0.05, 0.1, 0.05, 0.049, 0.001])
+    t = ClusterTable(G(pts), G(lab))
+    uniq = np.unique(lab)
+    assert np.array_equal(t.labels_unq.cpu().numpy(), uniq)
+    for k, l in enumerate(uniq):
+        sel = pts[lab == l]
+        assert int(t.count[k]) == len(sel)
+        np.testing.assert_allclose(t.mean[k].cpu().numpy(), sel.astype(np.float64).mean(0), rtol=0, atol=2e-6)
+        want = np.sort(np.abs(sel.max(0) - sel.min(0)))                 # get_bbox_tensor, utils_helper.py:166-170
+        assert np.array_equal(t.extent[k].cpu().numpy(), want)
+
+
+def test_synthetic_frame_pair_vs_oracle():
+    """A labelled synthetic frame pair (ragged clusters, relabelled objects -> both association
+    stages) through track() + flow kernel against the oracle's match_pcds / flow."""
+    from icp_flow_amd import frame_pairs
+    d = synthetic.make_frame_pair(seed=2, n_objects=9, n_max=400, n_background=1500)
+    fp = frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"], d["gt_flow"])
+    a = frame_pairs.default_args(max_points=512)
+    out = frame_pairs.register_frame_pair(a, fp, DEV)
+    torch.manual_seed(0)
+    want_pairs, want_T = rp.match_pcds(a, C(fp.points_src), C(fp.points_dst), C(fp.labels_src), C(fp.labels_dst))
+    want_flow = rp.flow_estimation_torch(C(fp.points_src), C(fp.labels_src), want_pairs, want_T, C(fp.pose)).numpy()
+    pairs = out["pairs"].cpu().numpy()
+    assert np.array_equal(pairs[:, 0:2], want_pairs.numpy()[:, 0:2])
+    assert len(pairs) == 9 and (pairs[:, 1] >= 1000).sum() >= 1            # some objects matched by stage 2
+    np.testing.assert_allclose(pairs[:, 2:4], want_pairs.numpy()[:, 2:4], atol=2e-4)
+    err = np.linalg.norm(out["flow"].cpu().numpy() - want_flow, axis=1)
+    assert err.max() < TOL_M, f"per-point flow differs from the oracle by up to {err.max():.3e} m"
+    assert np.linalg.norm(out["flow"].cpu().numpy() - fp.gt_flow, axis=1).mean() < 0.02
+
+
+def test_frame_pair_stream_on_demo_frame_matches_reference_metrics(tmp_path):
+    """The stream harness on BASELINE config 1 (demo frame pair written in the stream format):
+    EPE / accuracy metrics equal the reference's compute_epe_test on the reference's own flow (G9)."""
+    from icp_flow_amd import frame_pairs
+    g, lab, g9 = load_golden("g8_demo"), load_golden("g8_demo_labels"), load_golden("g9_epe")
+    fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
+    frame_pairs.save_frame_pair(str(tmp_path / "demo.npz"), fp)
+    a = frame_pairs.default_args(max_points=int(g["max_points"]))
+    s = frame_pairs.run_stream(a, frame_pairs.list_frame_pairs(str(tmp_path)), DEV)
+    assert s["frame_pairs"] == 1 and s["matched_cluster_pairs"] == len(g["pairs"]) and s["evaluated_points"] == len(g["flow"])
+    got = np.array([s[m] for m in ("epe", "accs", "accr", "outlier", "Routlier")])
+    np.testing.assert_allclose(got, g9["whole"], rtol=0, atol=5e-4)
+    assert s["ms_per_frame_pair"] > 0
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE config 2)
 @pytest.fixture(scope="module")
 def config2():

@@ -317,7 +317,36 @@ def g8_demo():
          flow=flow.numpy(), max_points=np.array(a.max_points), epe=np.array(epe))
 
 
-GENS = dict(g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
+def g9_epe():
+    """Scene-flow metrics of the accuracy harness: the reference's own
+    compute_epe_test / AverageMeter / average_meter (utils_eval.py:65-182) on the G8 flow vs the demo
+    frame's ground truth, unmasked, masked, and accumulated over two 'frames' (the two halves)."""
+    import utils_eval  # noqa: E402  (reference)
+    g = np.load(os.path.join(OUT, "g8_demo.npz"))
+    flow, gt = g["flow"], g["gt_flow"]
+    rng = np.random.default_rng(9)
+    mask = (rng.random(len(flow)) < 0.37).astype(np.float32)
+    whole = np.array(utils_eval.compute_epe_test(flow, gt), dtype=np.float64)
+    masked = np.array(utils_eval.compute_epe_test(flow, gt, mask), dtype=np.float64)
+    h = len(flow) // 3
+    meter = utils_eval.AverageMeter()
+    per_frame = []
+    for sl in (slice(0, h), slice(h, len(flow))):
+        m = utils_eval.compute_epe_test(flow[sl], gt[sl])
+        per_frame.append(m)
+        meter.update(*m, sl.stop - sl.start)
+    avg = np.array([meter.epe_avg, meter.accs_avg, meter.accr_avg, meter.outlier_avg, meter.Routlier_avg], dtype=np.float64)
+    am = utils_eval.average_meter([m[0] for m in per_frame], [h, len(flow) - h])
+    # a tiny hand case incl. zero ground-truth flow (relative error against 1e-20)
+    tg = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 0.1], [3, 4, 0]], dtype=np.float32)
+    tp = np.array([[0, 0, 0], [1.04, 0, 0], [0, 2.5, 0], [0, 0, 0.16], [3, 4, 0.31]], dtype=np.float32)
+    tiny = np.array(utils_eval.compute_epe_test(tp, tg), dtype=np.float64)
+    save("g9_epe", mask=mask, whole=whole, masked=masked, split=np.array(h), per_frame=np.array(per_frame, dtype=np.float64),
+         meter_avg=avg, average_meter_epe=np.array(am), tiny_gt=tg, tiny_pred=tp, tiny=tiny)
+    print("  epe/accs/accr/outlier/Routlier:", whole)
+
+
+GENS = dict(g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -325,7 +354,7 @@ if __name__ == "__main__":
     ns = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k != "g8"]   # g8: ~3 min, on request
+    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g9")]   # g8: ~3 min, on request
     for k in want:
         print(f"== {k}")
         GENS[k]()
