@@ -111,6 +111,34 @@ __device__ __forceinline__ double wave_sum_uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
+// Folding reductions for MANY values per lane (gfx950 v_permlane32_swap / v_permlane16_swap): one
+// swap pair + one add reduce TWO values by one level each -- after swap32_sum lanes 0..31 hold
+// a(l) + a(l+32) and lanes 32..63 hold b(l-32) + b(l); after swap16_sum the four rows of 16 lanes
+// hold  a: rows 0+1,  b: rows 0+1,  a: rows 2+3,  b: rows 2+3.
+__device__ __forceinline__ double swap32_sum(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+__device__ __forceinline__ double swap16_sum(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// inclusive scan inside each row of 16 lanes: lane 15 of every row ends with the row total
+__device__ __forceinline__ double row_sum_f64(double v)
+{
+    v = dpp_add_f64<0x111, 0xf>(v);
+    v = dpp_add_f64<0x112, 0xf>(v);
+    v = dpp_add_f64<0x114, 0xf>(v);
+    v = dpp_add_f64<0x118, 0xf>(v);
+    return v;
+}
+
 // fp32 wave min / max on the VALU (same DPP pattern), wave-uniform results
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f32(float v, float identity)

@@ -21,123 +21,161 @@
 namespace icpflow {
 
 // ---------------------------------------------------------------------------------
-// 3x3 Kabsch rotation, row-vector convention y = x R (R = U diag(1,1,det(U V^T)) V^T for
-// H = U S V^T, utils_icp_pytorch3d.py:339-362).  One-sided Jacobi in fp64.
+// 3x3 Kabsch rotation, row-vector convention y = x R:  R = U diag(1,1,det(U V^T)) V^T for
+// H = U S V^T (utils_icp_pytorch3d.py:339-362), computed WITHOUT an SVD.  That R is the proper
+// rotation maximising sum_ij R_ij H_ij, i.e. Horn's closed-form absolute orientation: the unit
+// quaternion q that is the eigenvector of the largest eigenvalue of the symmetric 4x4 matrix N(H)
+// below (reflection case included).  lambda_max comes from Newton's method on the characteristic
+// quartic started at the upper bound (|Xc|^2 + |Yc|^2) / 2W (monotone from above: every root is
+// real), the eigenvector from the adjugate of N - lambda I, whose sixteen 3x3 minors are evaluated
+// side by side on sixteen lanes.  A dozen dependent fp64 operations per Newton step replace the
+// div / sqrt / rsqrt chains of a Jacobi SVD (three rotations per sweep) in the serial tail of an
+// ICP iteration.  horn_rotation returns false when the maximiser is numerically not unique
+// (rank(H) <= 1: fewer than three non-collinear correspondences; the reference's answer is then an
+// accident of its SVD backend) -- the caller then takes rank1_rotation.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void cross3(const double *a, const double *b, double *c)
+__device__ __forceinline__ double det3(double a, double b, double c, double d, double e, double f, double g,
+                                       double h, double i)
 {
-    c[0] = a[1] * b[2] - a[2] * b[1];
-    c[1] = a[2] * b[0] - a[0] * b[2];
-    c[2] = a[0] * b[1] - a[1] * b[0];
+    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
 }
 
-// Vw (in/out): right singular vectors of the previous iteration of this pair (identity at
-// the start).  H changes little between ICP iterations, so A = H Vw is already nearly
-// column-orthogonal and the Jacobi sweeps below converge in 1-2 rounds instead of 5-6.
-__device__ void kabsch_rotation(const double (&Hin)[9], double *Vw, double (&R)[9])
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
-    // columns of A (A = H V  ->  U S) and of V, stored column-major: a[c][r], v[c][r]
-    double a[3][3], v[3][3];
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Lane l < 16 returns cofactor (l / 4, l % 4) of the 4x4 matrix M (row-major, LDS): the sixteen 3x3
+// minors are evaluated side by side on sixteen lanes instead of one after the other, which also
+// keeps the register footprint of the solve at nine doubles.
+__device__ __forceinline__ double cofactor16(const double *M, int lane)
+{
+    const int i = (lane >> 2) & 3, j = lane & 3;
+    const int r0 = (0 >= i) ? 1 : 0, r1 = (1 >= i) ? 2 : 1, r2 = (2 >= i) ? 3 : 2;
+    const int c0 = (0 >= j) ? 1 : 0, c1 = (1 >= j) ? 2 : 1, c2 = (2 >= j) ? 3 : 2;
+    const double d = det3(M[r0 * 4 + c0], M[r0 * 4 + c1], M[r0 * 4 + c2], M[r1 * 4 + c0], M[r1 * 4 + c1],
+                          M[r1 * 4 + c2], M[r2 * 4 + c0], M[r2 * 4 + c1], M[r2 * 4 + c2]);
+    return ((i + j) & 1) ? -d : d;
+}
+
+// Called by all 64 lanes of ONE wave with wave-uniform arguments; Nsh: 16 doubles of LDS scratch.
+__device__ bool horn_rotation(const double *S, double gsum, double *Nsh, int lane, double (&R)[9])
+{
+    double frob2 = 0.0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            v[c][r] = Vw[r * 3 + c];
-        }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            a[c][r] = Hin[r * 3 + 0] * v[c][0] + Hin[r * 3 + 1] * v[c][1] + Hin[r * 3 + 2] * v[c][2];
-    for (int sweep = 0; sweep < 16; ++sweep) {
-        bool rotated = false;
-#pragma unroll
-        for (int pq = 0; pq < 3; ++pq) {
-            const int p = (pq == 2) ? 1 : 0;
-            const int q = (pq == 0) ? 1 : 2;
-            const double al = a[p][0] * a[p][0] + a[p][1] * a[p][1] + a[p][2] * a[p][2];
-            const double be = a[q][0] * a[q][0] + a[q][1] * a[q][1] + a[q][2] * a[q][2];
-            const double ga = a[p][0] * a[q][0] + a[p][1] * a[q][1] + a[p][2] * a[q][2];
-            // converged for this pair of columns: |cos(angle)| <= 1e-12 (the result is rounded to
-            // fp32; with the warm start one or two sweeps get there)
-            if (ga == 0.0 || ga * ga <= 1e-24 * (al * be)) continue;
-            rotated = true;
-            const double zeta = (be - al) / (2.0 * ga);
-            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double cs = rsqrt(1.0 + t * t);
-            const double sn = cs * t;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double ap = a[p][r], aq = a[q][r];
-                a[p][r] = cs * ap - sn * aq;
-                a[q][r] = sn * ap + cs * aq;
-                const double vp = v[p][r], vq = v[q][r];
-                v[p][r] = cs * vp - sn * vq;
-                v[q][r] = sn * vp + cs * vq;
-            }
-        }
-        if (!rotated) break;
+    for (int k = 0; k < 9; ++k) frob2 += S[k] * S[k];
+    if (!(frob2 > 0.0)) return false;
+    // characteristic polynomial  l^4 + c2 l^2 + c1 l + c0  (N is traceless)
+    const double c2 = -2.0 * frob2;
+    const double c1 = -8.0 * det3(S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8]);
+    {
+        // every lane stores the same values (and later reads what it stored itself)
+        const double n01 = S[5] - S[7], n02 = S[6] - S[2], n03 = S[1] - S[3];
+        const double n12 = S[1] + S[3], n13 = S[6] + S[2], n23 = S[5] + S[7];
+        Nsh[0] = S[0] + S[4] + S[8]; Nsh[1] = n01; Nsh[2] = n02; Nsh[3] = n03;
+        Nsh[4] = n01; Nsh[5] = S[0] - S[4] - S[8]; Nsh[6] = n12; Nsh[7] = n13;
+        Nsh[8] = n02; Nsh[9] = n12; Nsh[10] = -S[0] + S[4] - S[8]; Nsh[11] = n23;
+        Nsh[12] = n03; Nsh[13] = n13; Nsh[14] = n23; Nsh[15] = -S[0] - S[4] + S[8];
     }
-    double s[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) s[c] = sqrt(a[c][0] * a[c][0] + a[c][1] * a[c][1] + a[c][2] * a[c][2]);
-    // order singular values descending (the reflection fix acts on the SMALLEST one)
-#define ICPFLOW_SWAP_COLS(i, j)                                                            \
-    if (s[i] < s[j]) {                                                                      \
-        const double ts = s[i]; s[i] = s[j]; s[j] = ts;                                     \
-        for (int r = 0; r < 3; ++r) {                                                       \
-            const double ta = a[i][r]; a[i][r] = a[j][r]; a[j][r] = ta;                     \
-            const double tv = v[i][r]; v[i][r] = v[j][r]; v[j][r] = tv;                     \
-        }                                                                                   \
+    const double n00 = Nsh[0], n11 = Nsh[5], n22 = Nsh[10], n33 = Nsh[15];
+    // c0 = det N: expansion along row 0, the four cofactors on lanes 0..3
+    const double term = Nsh[lane & 3] * cofactor16(Nsh, lane & 3);
+    const double c0 = (readlane_f64(term, 0) + readlane_f64(term, 1)) + (readlane_f64(term, 2) + readlane_f64(term, 3));
+    double lam = 0.5 * gsum, prevStep = 1e300;
+    for (int it = 0; it < 40; ++it) {
+        const double x2 = lam * lam;
+        const double b = (x2 + c2) * lam;
+        const double a = b + c1;
+        const double den = 2.0 * x2 * lam + b + a;
+        if (den == 0.0) break;
+        const double step = (a * lam + c0) / den;
+        lam -= step;
+        const double as = fabs(step);
+        // steps shrink monotonically above the largest root (real-rooted quartic): the first one
+        // that does not is rounding noise
+        if (as <= 1e-16 * fabs(lam) || as >= prevStep) break;
+        prevStep = as;
     }
-    ICPFLOW_SWAP_COLS(0, 1)
-    ICPFLOW_SWAP_COLS(0, 2)
-    ICPFLOW_SWAP_COLS(1, 2)
-#undef ICPFLOW_SWAP_COLS
+    // adjugate of A = N - lam I (symmetric, rank 3): adj = c q q^T, entry (i, j) on lane 4 i + j
+    Nsh[0] = n00 - lam; Nsh[5] = n11 - lam; Nsh[10] = n22 - lam; Nsh[15] = n33 - lam;
+    const double C = cofactor16(Nsh, lane);
+    // column of the largest diagonal entry (c q_k^2): the best conditioned one
+    int k = 0;
+    double big = fabs(readlane_f64(C, 0));
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Vw[r * 3 + c] = v[c][r];
-    if (!(s[0] > 0.0)) {  // H == 0 (no inliers): torch.svd(0) gives U = V = I  ->  R = I
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { R[k] = (k % 4 == 0) ? 1.0 : 0.0; Vw[k] = R[k]; }
-        return;
+    for (int d = 1; d < 4; ++d) {
+        const double v = fabs(readlane_f64(C, 5 * d));
+        if (v > big) { big = v; k = d; }
     }
-    // det V = +-1 (V is a product of rotations and column swaps)
-    double cv[3];
-    cross3(v[0], v[1], cv);
-    const double detV = (cv[0] * v[2][0] + cv[1] * v[2][1] + cv[2] * v[2][2]) < 0.0 ? -1.0 : 1.0;
-    double u0[3], u1[3], u2[3];
+    if (!(big > 1e-9 * frob2 * sqrt(frob2))) return false;   // (nearly) double top eigenvalue
+    k = __builtin_amdgcn_readfirstlane(k);
+    double q0 = readlane_f64(C, 4 * k + 0), q1 = readlane_f64(C, 4 * k + 1), q2 = readlane_f64(C, 4 * k + 2),
+           q3 = readlane_f64(C, 4 * k + 3);
+    const double inv = rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    q0 *= inv; q1 *= inv; q2 *= inv; q3 *= inv;
+    // column-convention rotation Rc (y = Rc x) of the quaternion; the row convention wants Rc^T
+    const double ww = q0 * q0, xx = q1 * q1, yy = q2 * q2, zz = q3 * q3;
+    const double xy = q1 * q2, xz = q1 * q3, yz = q2 * q3, wx = q0 * q1, wy = q0 * q2, wz = q0 * q3;
+    R[0] = ww + xx - yy - zz; R[3] = 2.0 * (xy - wz);     R[6] = 2.0 * (xz + wy);
+    R[1] = 2.0 * (xy + wz);     R[4] = ww - xx + yy - zz; R[7] = 2.0 * (yz - wx);
+    R[2] = 2.0 * (xz - wy);     R[5] = 2.0 * (yz + wx);     R[8] = ww - xx - yy + zz;
+    return true;
+}
+
+// rank(H) <= 1:  H = sigma u v^T (or 0).  Every rotation with u R = v maximises sum R_ij H_ij; take the
+// smallest one (Rodrigues from u to v).  H = 0 (no gated correspondence): R = I, like torch.svd(0).
+__device__ void rank1_rotation(const double *S, double (&R)[9])
+{
 #pragma unroll
-    for (int r = 0; r < 3; ++r) u0[r] = a[0][r] / s[0];
-    if (s[1] > 1e-300 && s[1] > 1e-14 * s[0]) {
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    // v = direction of the largest row of H;  u = H v / |H v|  (signs consistent by construction)
+    int r = 0;
+    double best = -1.0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) u1[r] = a[1][r] / s[1];
-    } else {  // rank 1: rotation not unique (reference: backend dependent); any unit vector _|_ u0
-        const int k = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0
-                      : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+    for (int i = 0; i < 3; ++i) {
+        const double n2 = S[i * 3] * S[i * 3] + S[i * 3 + 1] * S[i * 3 + 1] + S[i * 3 + 2] * S[i * 3 + 2];
+        if (n2 > best) { best = n2; r = i; }
+    }
+    if (!(best > 0.0)) return;
+    const double iv = rsqrt(best);
+    const double v[3] = {S[r * 3] * iv, S[r * 3 + 1] * iv, S[r * 3 + 2] * iv};
+    double u[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[i] = S[i * 3] * v[0] + S[i * 3 + 1] * v[1] + S[i * 3 + 2] * v[2];
+    const double un2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+    if (!(un2 > 0.0)) return;
+    const double iu = rsqrt(un2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[i] *= iu;
+    // column-convention Rc with Rc u = v:  Rc = c I + [w]x + w w^T / (1 + c),  w = u x v, c = u . v
+    const double c = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+    double w[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+    double Rc[9];
+    if (c > -1.0 + 1e-12) {
+        const double k = 1.0 / (1.0 + c);
+        Rc[0] = c + k * w[0] * w[0];    Rc[1] = k * w[0] * w[1] - w[2]; Rc[2] = k * w[0] * w[2] + w[1];
+        Rc[3] = k * w[1] * w[0] + w[2]; Rc[4] = c + k * w[1] * w[1];    Rc[5] = k * w[1] * w[2] - w[0];
+        Rc[6] = k * w[2] * w[0] - w[1]; Rc[7] = k * w[2] * w[1] + w[0]; Rc[8] = c + k * w[2] * w[2];
+    } else {
+        // v = -u: half turn about any axis a perpendicular to u,  Rc = 2 a a^T - I
+        const int m = (fabs(u[0]) <= fabs(u[1]) && fabs(u[0]) <= fabs(u[2])) ? 0 : (fabs(u[1]) <= fabs(u[2]) ? 1 : 2);
         double e[3] = {0.0, 0.0, 0.0};
-        e[k] = 1.0;
-        cross3(u0, e, u1);
-        const double n = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+        e[m] = 1.0;
+        double a[3] = {u[1] * e[2] - u[2] * e[1], u[2] * e[0] - u[0] * e[2], u[0] * e[1] - u[1] * e[0]};
+        const double ia = rsqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) u1[r] /= n;
-    }
-    // third left vector: +-(u0 x u1); the sign (= det U) follows the computed column when
-    // it carries information, and cancels in R either way
-    cross3(u0, u1, u2);
-    double detU = 1.0;
-    if (a[2][0] * u2[0] + a[2][1] * u2[1] + a[2][2] * u2[2] < 0.0) {
-        detU = -1.0;
+        for (int i = 0; i < 3; ++i) a[i] *= ia;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) u2[r] = -u2[r];
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Rc[i * 3 + j] = 2.0 * a[i] * a[j] - (i == j ? 1.0 : 0.0);
     }
-    const double d = detU * detV;  // det(U V^T), :358-359
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            R[i * 3 + j] = u0[i] * v[0][j] + u1[i] * v[1][j] + d * u2[i] * v[2][j];  // :362
+        for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rc[j * 3 + i];   // row convention
 }
 
 // ---------------------------------------------------------------------------------
@@ -404,7 +442,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     __shared__ __attribute__((aligned(16))) unsigned char tileMem[GRID ? 16 : sizeof(ScanTile)];
     ScanTile *tile = reinterpret_cast<ScanTile *>(tileMem);
     __shared__ double red[NWAVE * kMoments];  // per-wave moment sums of the current iteration
-    __shared__ double Vsh[9];                 // right singular vectors (Jacobi warm start)
+    __shared__ double tot[kMoments];          // block totals of the 18 moments
+    __shared__ double Nsh[16];                // 4x4 scratch of the closed-form rotation
     __shared__ double ksh[17];                // centroids, second moments and H parked across the solve
     __shared__ float bcast[16];               // R (9), T (3), active flag, prev rmse, rmse
     __shared__ float combD[TS > 1 ? NWAVE * Q * kWave : 1];   // [wave][q][lane]
@@ -442,7 +481,6 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rf[k] = (k % 4 == 0) ? 1.f : 0.f;  // :140
         Tf[0] = Tf[1] = Tf[2] = 0.f;
-        if (tid < 9) Vsh[tid] = (tid % 4 == 0) ? 1.0 : 0.0;
         if (tid == 0) { bcast[13] = 0.f; bcast[14] = 0.f; }
     } else {
 #pragma unroll
@@ -450,7 +488,6 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 #pragma unroll
         for (int k = 0; k < 3; ++k) Tf[k] = st->T[k];
         active = st->active;
-        if (tid < 9) Vsh[tid] = st->V[tid];
         if (tid == 0) { bcast[13] = st->rmse; bcast[14] = st->rmse; }
     }
     int itersDone = (itBegin == 0) ? 0 : st->iters;
@@ -505,8 +542,10 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             }
             const float *keyf = (GRID == 4) ? (axis == 0 ? lx : (axis == 1 ? ly : lz))
                                             : (axis == 0 ? gx : (axis == 1 ? gy : gz));
-            constexpr int PER = BLOCK * Q;            // a wave owns 64*Q CONSECUTIVE sorted queries
+            static_assert(Q == 1, "sorted sweep: one query per lane");
+            constexpr int PER = BLOCK * Q;            // a wave owns 64 CONSECUTIVE sorted queries
             const int ngr = (xc.n + PER - 1) / PER;
+            double fold[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
             for (int g = 0; g < ngr; ++g) {
                 float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
                 bool live[Q];
@@ -554,20 +593,16 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                         scan_range_tie_uniform<Q>(gx, gy, gz, cb, ce, qx, qy, qz, acc, tie);
                 }
                 ICPFLOW_STAMP(2);
-                // lane-local moments of this lane's Q queries, then ONE set of wave reductions
-                double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0, l4 = 0.0, l5 = 0.0, l6 = 0.0, l7 = 0.0, l8 = 0.0,
-                       l9 = 0.0, l10 = 0.0, l11 = 0.0, l12 = 0.0, l13 = 0.0, l14 = 0.0, l15 = 0.0, l16 = 0.0, l17 = 0.0;
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    if (!(live[q] && acc.best[q] <= p.thr2)) continue;  // :160-161
-                    // neighbour = the target at distance `best` (bit-equal re-evaluation of the winning
-                    // chunk).  If several targets tie -- in that chunk or, flagged by the scan, in another
-                    // one -- the lowest ORIGINAL index wins: only then are the original indices fetched
-                    // (w component of the sorted array).
+                // neighbour = the target at distance `best` (bit-equal re-evaluation of the winning
+                // chunk).  If several targets tie -- in that chunk or, flagged by the scan, in another
+                // one -- the lowest ORIGINAL index wins: only then are the original indices fetched
+                // (w component of the sorted array).
+                double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0, wq = 0.0;
+                if (live[0] && acc.best[0] <= p.thr2) {  // :160-161
                     float ynx = 0.f, yny = 0.f, ynz = 0.f;
-                    int matches = tie[q] ? 2 : 0;
-                    if (!tie[q]) {
-                        const int c0 = acc.chunk[q];
+                    int matches = tie[0] ? 2 : 0;
+                    if (!tie[0]) {
+                        const int c0 = acc.chunk[0];
 #pragma unroll
                         for (int u = 0; u < kChunk / 4; ++u) {
                             const float4 tx = *reinterpret_cast<const float4 *>((GRID == 4 ? lx : gx) + c0 + 4 * u);
@@ -578,37 +613,49 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             const float tzs[4] = {tz.x, tz.y, tz.z, tz.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float d = sqdist(qx[q], qy[q], qz[q], txs[e], tys[e], tzs[e]);
-                                if (d == acc.best[q]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; }
+                                const float d = sqdist(qx[0], qy[0], qz[0], txs[e], tys[e], tzs[e]);
+                                if (d == acc.best[0]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; }
                             }
                         }
                     }
                     if (matches != 1) {
-                        const int r0 = tie[q] ? cb : acc.chunk[q];
-                        const int r1 = tie[q] ? ce : acc.chunk[q] + kChunk;
+                        const int r0 = tie[0] ? cb : acc.chunk[0];
+                        const int r1 = tie[0] ? ce : acc.chunk[0] + kChunk;
                         int bj = 0x7fffffff;
                         for (int k = r0; k < min(r1, yc.n); ++k) {
                             const float4 t = ys[k];
-                            const float d = sqdist(qx[q], qy[q], qz[q], t.x, t.y, t.z);
+                            const float d = sqdist(qx[0], qy[0], qz[0], t.x, t.y, t.z);
                             const int j = __float_as_int(t.w);
-                            if (d == acc.best[q] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
+                            if (d == acc.best[0] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
                         }
                     }
-                    const double ax = (double)(x0x[q] - ox), ay = (double)(x0y[q] - oy), az = (double)(x0z[q] - oz);
-                    const double bx = (double)(ynx - ox), by = (double)(yny - oy), bz = (double)(ynz - oz);
-                    l0 += 1.0;
-                    l1 += ax; l2 += ay; l3 += az; l4 += bx; l5 += by; l6 += bz;
-                    l7 += ax * bx; l8 += ax * by; l9 += ax * bz;
-                    l10 += ay * bx; l11 += ay * by; l12 += ay * bz;
-                    l13 += az * bx; l14 += az * by; l15 += az * bz;
-                    l16 += ax * ax + ay * ay + az * az;
-                    l17 += bx * bx + by * by + bz * bz;
+                    wq = 1.0;
+                    ax = (double)(x0x[0] - ox); ay = (double)(x0y[0] - oy); az = (double)(x0z[0] - oz);
+                    bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
                 }
                 ICPFLOW_STAMP(10);
-                ICPFLOW_ACC(0, l0) ICPFLOW_ACC(1, l1) ICPFLOW_ACC(2, l2) ICPFLOW_ACC(3, l3) ICPFLOW_ACC(4, l4)
-                ICPFLOW_ACC(5, l5) ICPFLOW_ACC(6, l6) ICPFLOW_ACC(7, l7) ICPFLOW_ACC(8, l8) ICPFLOW_ACC(9, l9)
-                ICPFLOW_ACC(10, l10) ICPFLOW_ACC(11, l11) ICPFLOW_ACC(12, l12) ICPFLOW_ACC(13, l13)
-                ICPFLOW_ACC(14, l14) ICPFLOW_ACC(15, l15) ICPFLOW_ACC(16, l16) ICPFLOW_ACC(17, l17)
+                // 18 moments -> 5 registers by two folding levels (see common.hpp): fold[j] holds, per
+                // row of 16 lanes, partial sums of moments (4j, 4j+2, 4j+1, 4j+3); fold[4]: 16,16,17,17
+                {
+                    const double a0 = swap32_sum(wq, ax), a1 = swap32_sum(ay, az);
+                    fold[0] += swap16_sum(a0, a1);
+                    const double a2 = swap32_sum(bx, by), a3 = swap32_sum(bz, ax * bx);
+                    fold[1] += swap16_sum(a2, a3);
+                    const double a4 = swap32_sum(ax * by, ax * bz), a5 = swap32_sum(ay * bx, ay * by);
+                    fold[2] += swap16_sum(a4, a5);
+                    const double a6 = swap32_sum(ay * bz, az * bx), a7 = swap32_sum(az * by, az * bz);
+                    fold[3] += swap16_sum(a6, a7);
+                    const double a8 = swap32_sum(ax * ax + ay * ay + az * az, bx * bx + by * by + bz * bz);
+                    fold[4] += swap16_sum(a8, a8);
+                }
+            }
+            // rows of 16 lanes -> lane 15 of each row holds the wave total of "its" moment
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const double r = row_sum_f64(fold[j]);
+                const int row = lane >> 4;
+                const int m = (j < 4) ? 4 * j + ((row & 1) * 2 + (row >> 1)) : 16 + (row >> 1);
+                if ((lane & 15) == 15) red[wave * kMoments + m] = r;
             }
         } else if constexpr (GRID != 0) {
             const float4 *gpG = p.gridPts + (size_t)b * p.N;
@@ -746,11 +793,13 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         }
 #undef ICPFLOW_ACC_ALL
 #undef ICPFLOW_ACC
-        if (lane < kMoments) {  // lane k publishes moment k of this wave
-            double mine = 0.0;
+        if constexpr (GRID < 3) {
+            if (lane < kMoments) {  // lane k publishes moment k of this wave
+                double mine = 0.0;
 #pragma unroll
-            for (int k = 0; k < kMoments; ++k) mine = (lane == k) ? macc[k] : mine;
-            red[wave * kMoments + lane] = mine;
+                for (int k = 0; k < kMoments; ++k) mine = (lane == k) ? macc[k] : mine;
+                red[wave * kMoments + lane] = mine;
+            }
         }
         ICPFLOW_STAMP(3);
         __syncthreads();  // every wave's row is complete
@@ -766,34 +815,32 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 mine = red[lane];
                 for (int w = 1; w < NWAVE; ++w) mine += red[w * kMoments + lane];
             }
-            double mom[kMoments];
-#pragma unroll
-            for (int k = 0; k < kMoments; ++k) {
-                const int lo = __builtin_amdgcn_readlane(__double2loint(mine), k);
-                const int hi = __builtin_amdgcn_readlane(__double2hiint(mine), k);
-                mom[k] = __hiloint2double(hi, lo);
-            }
+            // totals go through LDS (lane k stores moment k, every lane reads what it needs): the
+            // values stay out of the register file while the solve runs
+            if (lane < kMoments) tot[lane] = mine;
+            const double *mom = tot;
             const double W = mom[0] > 1e-9 ? mom[0] : 1e-9;  // clamp(eps), :314-315, :326
             double h9[9];
             {
-                const double mx0 = mom[1] / W, mx1 = mom[2] / W, mx2 = mom[3] / W;
-                const double my0 = mom[4] / W, my1 = mom[5] / W, my2 = mom[6] / W;
+                const double iW = 1.0 / W;
+                const double mx0 = mom[1] * iW, mx1 = mom[2] * iW, mx2 = mom[3] * iW;
+                const double my0 = mom[4] * iW, my1 = mom[5] * iW, my2 = mom[6] * iW;
                 const double mxv[3] = {mx0, mx1, mx2}, myv[3] = {my0, my1, my2};
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) h9[i * 3 + j] = mom[7 + i * 3 + j] / W - mxv[i] * myv[j];  // :318-336
+                    for (int j = 0; j < 3; ++j) h9[i * 3 + j] = mom[7 + i * 3 + j] * iW - mxv[i] * myv[j];  // :318-336
                 // park what is needed after the solve in LDS: the Jacobi sweeps want the registers
                 // (every lane writes the same value to the same address and reads its own write)
                 ksh[0] = mx0; ksh[1] = mx1; ksh[2] = mx2; ksh[3] = my0; ksh[4] = my1; ksh[5] = my2;
-                ksh[6] = mom[16] / W - (mx0 * mx0 + mx1 * mx1 + mx2 * mx2);   // sum w |x_c|^2 / W
-                ksh[7] = mom[17] / W - (my0 * my0 + my1 * my1 + my2 * my2);   // sum w |y_c|^2 / W
+                ksh[6] = mom[16] * iW - (mx0 * mx0 + mx1 * mx1 + mx2 * mx2);   // sum w |x_c|^2 / W
+                ksh[7] = mom[17] * iW - (my0 * my0 + my1 * my1 + my2 * my2);   // sum w |y_c|^2 / W
 #pragma unroll
                 for (int k = 0; k < 9; ++k) ksh[8 + k] = h9[k];
             }
             ICPFLOW_STAMP(5);
             double Rd[9];
-            kabsch_rotation(h9, Vsh, Rd);
+            if (!horn_rotation(ksh + 8, ksh[6] + ksh[7], Nsh, lane, Rd)) rank1_rotation(ksh + 8, Rd);
             ICPFLOW_STAMP(6);
             // T = mu_y - mu_x R with mu = o + m', :376
             const double mux[3] = {(double)ox + ksh[0], (double)oy + ksh[1], (double)oz + ksh[2]};
@@ -865,7 +912,6 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     }
     ICPFLOW_STAMP(8);
     __syncthreads();
-    if (tid < 9) st->V[tid] = Vsh[tid];
     if (tid == 0) {  // wave 0 holds the final state
 #pragma unroll
         for (int k = 0; k < 9; ++k) st->R[k] = Rf[k];
@@ -941,6 +987,14 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
 {
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
                        : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 : 0;
+    if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID>), dim3(B), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
 }
 
@@ -1003,13 +1057,14 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
     const bool timed = g_prof.used < (int)g_prof.start.size();
     if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
     if (p.sortY != nullptr) {    // sorted sweep
-        // GRID 4: sorted fixed cloud resident in LDS (12 B/point: 48 KiB at N = 4096); beyond that
-        // GRID 3 streams it through scalar loads (no LDS image, any N the sort can handle)
+        // one query per lane (Q = 1): a wave's 64 consecutive sorted queries span the narrowest window;
+        // clouds longer than the workgroup take several passes.  GRID 4 keeps the sorted fixed cloud
+        // in LDS (12 B/point, up to 144 KiB of the CU's 160 KiB at N = 12288); beyond that GRID 3
+        // streams it through scalar loads (no LDS image, any N the sort can handle).
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.N <= 512) launch_icp_variant<512, 1, 1, 4>(p, B, itBegin, itEnd, s);
-        else if (p.N <= 1024) launch_icp_variant<512, 2, 1, 4>(p, B, itBegin, itEnd, s);
-        else if (p.N <= 4096) launch_icp_variant<1024, 2, 1, 4>(p, B, itBegin, itEnd, s);
-        else launch_icp_variant<1024, 2, 1, 3>(p, B, itBegin, itEnd, s);
+        else if (p.N <= 12288) launch_icp_variant<1024, 1, 1, 4>(p, B, itBegin, itEnd, s);
+        else launch_icp_variant<1024, 1, 1, 3>(p, B, itBegin, itEnd, s);
     } else if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 2>(p, B, itBegin, itEnd, s);
         else if (p.N <= 2048) launch_icp_variant<1024, 1, 1, 2>(p, B, itBegin, itEnd, s);

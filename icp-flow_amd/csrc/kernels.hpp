@@ -19,7 +19,6 @@ constexpr int kTopK = 5;          // utils_hist.py:21
 constexpr int kNmsKernel = 11;    // utils_hist.py:21
 
 struct IcpState {
-    double V[9];   // right singular vectors of the last Kabsch solve (Jacobi warm start)
     float R[9];
     float T[3];
     float rmse;
