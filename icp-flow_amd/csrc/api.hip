@@ -209,6 +209,15 @@ int icpflow_profile_collect(double *total_ms, int *launches)
     return 0;
 }
 
+int icpflow_selftest_vote_quotient(const float *d_a, int n, float min_v, float max_v, float *d_fast,
+                                   float *d_ieee, icpflow_stream_t stream)
+{
+    if (!d_a || !d_fast || !d_ieee) return fail(ICPFLOW_E_ARG, "icpflow_selftest_vote_quotient: null pointer");
+    if (n <= 0) return fail(ICPFLOW_E_ARG, "icpflow_selftest_vote_quotient: n must be positive");
+    ICPFLOW_TRY(launch_vote_quotient_probe(d_a, n, min_v, max_v, d_fast, d_ieee, (hipStream_t)stream));
+    return 0;
+}
+
 int icpflow_hist_vote(const float *d_X, const float *d_Y, int B, int NX, int NY, float min_x,
                       float min_y, float min_z, float max_x, float max_y, float max_z, int len_x,
                       int len_y, int len_z, float *d_bins, icpflow_stream_t stream)

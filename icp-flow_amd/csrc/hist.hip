@@ -39,6 +39,58 @@ struct VoteBox {
     int len_x, len_y, len_z;
 };
 
+// (v - min) / (max - min) with the loop-invariant denominator: the compiler expands an IEEE fp32
+// division into  div_scale, rcp, two Newton steps on the reciprocal, a quotient, two residual
+// corrections, div_fmas, div_fixup.  Scale and fixup are identities for operands in the normal
+// range, and everything that depends only on the denominator is invariant: hoisting it leaves five
+// dependent FMAs per quotient that reproduce the expansion's arithmetic bit for bit
+// (tests: test_vote_quotient_is_the_ieee_quotient).  `fast` is false -- plain division -- when the
+// box could put a numerator or the denominator near the ends of the exponent range.
+struct AxisQuot {
+    float r, y1;
+    bool fast;
+};
+
+__device__ __forceinline__ AxisQuot axis_quot_make(float mn, float mx)
+{
+    AxisQuot d;
+    d.r = mx - mn;
+    const float y0 = __builtin_amdgcn_rcpf(d.r);
+    const float e0 = fmaf(-d.r, y0, 1.0f);
+    d.y1 = fmaf(e0, y0, y0);
+    // a nonzero numerator v - mn is at least half an ulp of mn: normal range guaranteed by |mn|
+    d.fast = d.r > 1e-18f && d.r < 1e18f && fabsf(mn) > 1e-18f && fabsf(mn) < 1e18f;
+    return d;
+}
+
+__device__ __forceinline__ float axis_quot(float a, const AxisQuot &d)
+{
+    if (!d.fast) return a / d.r;   // wave-uniform
+    const float q0 = a * d.y1;
+    const float e1 = fmaf(-d.r, q0, a);
+    const float q1 = fmaf(e1, d.y1, q0);
+    const float e2 = fmaf(-d.r, q1, a);
+    return fmaf(e2, d.y1, q1);
+}
+
+// debug / test entry: out[i] = axis_quot(a[i]) next to the compiler's a[i] / r
+__global__ void vote_quotient_probe_kernel(const float *__restrict__ a, int n, float mn, float mx,
+                                           float *__restrict__ fast, float *__restrict__ ieee)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AxisQuot d = axis_quot_make(mn, mx);
+    fast[i] = axis_quot(a[i], d);
+    ieee[i] = a[i] / (mx - mn);
+}
+
+hipError_t launch_vote_quotient_probe(const float *a, int n, float mn, float mx, float *fast, float *ieee,
+                                      hipStream_t s)
+{
+    hipLaunchKernelGGL(vote_quotient_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, n, mn, mx, fast, ieee);
+    return hipGetLastError();
+}
+
 constexpr int kVoteBlock = 256;  // threads; one X row per thread per slice
 constexpr int kVoteTile = 1024;  // Y points staged in LDS per step (16 KiB)
 
@@ -80,7 +132,8 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
     }
     // hist_cuda_core.cuh:52-54: (v-min)/(max-min) * float(len); the denominators
     // and float(len) are loop invariants
-    const float rx = box.max_x - box.min_x, ry = box.max_y - box.min_y, rz = box.max_z - box.min_z;
+    const AxisQuot dqx = axis_quot_make(box.min_x, box.max_x), dqy = axis_quot_make(box.min_y, box.max_y),
+                   dqz = axis_quot_make(box.min_z, box.max_z);
     const float flx = (float)box.len_x, fly = (float)box.len_y, flz = (float)box.len_z;
 
     for (int j0 = 0; j0 < ny; j0 += kVoteTile) {
@@ -100,9 +153,9 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
             const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
             if (vx >= box.min_x && vx < box.max_x && vy >= box.min_y && vy < box.max_y &&
                 vz >= box.min_z && vz < box.max_z) {
-                const int px = (int)floorf(((vx - box.min_x) / rx) * flx);
-                const int py = (int)floorf(((vy - box.min_y) / ry) * fly);
-                const int pz = (int)floorf(((vz - box.min_z) / rz) * flz);
+                const int px = (int)floorf(axis_quot(vx - box.min_x, dqx) * flx);
+                const int py = (int)floorf(axis_quot(vy - box.min_y, dqy) * fly);
+                const int pz = (int)floorf(axis_quot(vz - box.min_z, dqz) * flz);
                 const int bin = (px * box.len_y + py) * box.len_z + pz;
                 if (LDS_HIST) atomicAdd(&lhist[bin], 1u);
                 else atomicAdd(&gb[bin], 1u);
@@ -187,7 +240,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     if (useLds) {
         for (int k = threadIdx.x; k < L; k += kVoteBlock) lhist[k] = 0u;
     }
-    const float rx = max_x - min_x, ry = max_y - min_y, rz = max_z - min_z;
+    const AxisQuot dqx = axis_quot_make(min_x, max_x), dqy = axis_quot_make(min_y, max_y), dqz = axis_quot_make(min_z, max_z);
     const float flx = (float)len_x, fly = (float)len_y, flz = (float)len_z;
     // z window of this wave's rows: y.z in (zlo - max_z, zhi - min_z], widened by a rounding slack
     float zlo = xvalid ? xi.z : kInf, zhi = xvalid ? xi.z : -kInf;
@@ -212,9 +265,9 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
             const float4 t = tile[k];  // same address in every lane: LDS broadcast
             const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
             if (vx >= min_x && vx < max_x && vy >= min_y && vy < max_y && vz >= min_z && vz < max_z) {
-                const int px = (int)floorf(((vx - min_x) / rx) * flx);
-                const int py = (int)floorf(((vy - min_y) / ry) * fly);
-                const int pz = (int)floorf(((vz - min_z) / rz) * flz);
+                const int px = (int)floorf(axis_quot(vx - min_x, dqx) * flx);
+                const int py = (int)floorf(axis_quot(vy - min_y, dqy) * fly);
+                const int pz = (int)floorf(axis_quot(vz - min_z, dqz) * flz);
                 const int bin = (px * len_y + py) * len_z + pz;
                 if (useLds) atomicAdd(&lhist[bin], 1u);
                 else atomicAdd(&gb[bin], 1u);

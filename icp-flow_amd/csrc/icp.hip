@@ -20,6 +20,16 @@
 
 namespace icpflow {
 
+#ifdef ICPFLOW_PHASE_TIMING
+// debug builds only (tools/dbg/phase_timing.py): shader-clock stamps of workgroup 0
+__device__ long long g_phase_stamps[16];
+__device__ long long g_wave_stamps[16 * 16];   // [wave][k] of workgroup 0
+#define ICPFLOW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamps[k] = clock64(); \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_wave_stamps[(threadIdx.x >> 6) * 16 + (k)] = clock64(); } while (0)
+#else
+#define ICPFLOW_STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------
 // 3x3 Kabsch rotation, row-vector convention y = x R:  R = U diag(1,1,det(U V^T)) V^T for
 // H = U S V^T (utils_icp_pytorch3d.py:339-362), computed WITHOUT an SVD.  That R is the proper
@@ -83,6 +93,7 @@ __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, int lan
     // c0 = det N: expansion along row 0, the four cofactors on lanes 0..3
     const double term = Nsh[lane & 3] * cofactor16(Nsh, lane & 3);
     const double c0 = (readlane_f64(term, 0) + readlane_f64(term, 1)) + (readlane_f64(term, 2) + readlane_f64(term, 3));
+    ICPFLOW_STAMP(13);
     double lam = 0.5 * gsum, prevStep = 1e300;
     for (int it = 0; it < 40; ++it) {
         const double x2 = lam * lam;
@@ -98,6 +109,7 @@ __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, int lan
         if (as <= 1e-16 * fabs(lam) || as >= prevStep) break;
         prevStep = as;
     }
+    ICPFLOW_STAMP(14);
     // adjugate of A = N - lam I (symmetric, rank 3): adj = c q q^T, entry (i, j) on lane 4 i + j
     Nsh[0] = n00 - lam; Nsh[5] = n11 - lam; Nsh[10] = n22 - lam; Nsh[15] = n33 - lam;
     const double C = cofactor16(Nsh, lane);
@@ -211,15 +223,6 @@ struct IcpParams {
     int B;
 };
 
-#ifdef ICPFLOW_PHASE_TIMING
-// debug builds only (tools/dbg/phase_timing.py): shader-clock stamps of workgroup 0
-__device__ long long g_phase_stamps[16];
-__device__ long long g_wave_stamps[16 * 16];   // [wave][k] of workgroup 0
-#define ICPFLOW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamps[k] = clock64(); \
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_wave_stamps[(threadIdx.x >> 6) * 16 + (k)] = clock64(); } while (0)
-#else
-#define ICPFLOW_STAMP(k) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------------
 // Exact nearest neighbour within the gate radius through a hashed uniform grid.

@@ -114,6 +114,8 @@ hipError_t launch_eval_epilogue(const double *partial, int qblocks, const int32_
                                 const int32_t *len2, const float *T, int B, float *errors,
                                 float *inliers, float *ratios, float *ious, float *translations,
                                 float *rotations, hipStream_t s);
+hipError_t launch_vote_quotient_probe(const float *a, int n, float mn, float mx, float *fast, float *ieee,
+                                      hipStream_t s);
 hipError_t launch_gather_pad(const float *points, const int32_t *rows, int B, int N, float *out, hipStream_t s);
 hipError_t launch_cluster_stats(const float *points, const int64_t *order, const int64_t *start,
                                 const int64_t *count, int L, float *mean, float *extent, hipStream_t s);

@@ -231,6 +231,15 @@ int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, cons
                        size_t ws_bytes, icpflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Diagnostics: the vote kernels evaluate (v - min) / (max - min) with the loop-invariant part of
+ * the IEEE division hoisted (hist.hip, AxisQuot).  For numerators d_a [n] this returns that
+ * quotient (d_fast) next to the compiler's correctly rounded a / (max - min) (d_ieee); the two
+ * must be bit-identical (hist_cuda_core.cuh:52-54 is an IEEE division).
+ * ------------------------------------------------------------------------- */
+int icpflow_selftest_vote_quotient(const float *d_a, int n, float min_v, float max_v, float *d_fast,
+                                   float *d_ieee, icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Correspondence search used inside the ICP loop (process-global tuning knob, results are
  * bit-identical in every mode):
  *   ICPFLOW_SEARCH_AUTO (0)   sorted sweep when 64 <= N <= 16384, else the all-pairs scan

@@ -109,6 +109,35 @@ def test_hist_vs_oracle_random_flags_and_big_histograms(tf, N):
     assert want.sum() > 0
 
 
+def test_vote_quotient_is_the_ieee_quotient(icp_search_mode):
+    """The vote's (v - min) / (max - min) with the hoisted reciprocal equals the IEEE quotient bit for
+    bit: 2^24 numerators per box (dense sweep of [0, r) plus the float neighbours of every bin
+    boundary k * r / len), for the boxes of SURVEY A.1 and hist_cuda/test.py."""
+    if icp_search_mode != "scan":
+        pytest.skip("independent of the ICP search")
+    boxes = [(-2.0, 2.0, 41), (-0.1, 0.1, 3), (-3.34, 3.36, 68), (-6.68, 6.72, 135), (-13.36, 13.44, 269),
+             (-16.667, 16.733, 335), (-10.0, 10.0, 201), (-0.5, 0.5, 11), (-1.667, 1.733, 35)]
+    rng = np.random.default_rng(5)
+    for mn, mx, ln in boxes:
+        mn32, mx32 = np.float32(mn), np.float32(mx)
+        r = np.float32(mx32 - mn32)
+        a = (rng.random(1 << 24, dtype=np.float32) * r).astype(np.float32)
+        edges = (np.arange(ln + 1, dtype=np.float64) * float(r) / ln).astype(np.float32)
+        near = np.concatenate([np.nextafter(edges, np.float32(np.inf)), edges, np.nextafter(edges, np.float32(-np.inf))])
+        for _ in range(4):
+            near = np.concatenate([near, np.nextafter(near, np.float32(np.inf)), np.nextafter(near, np.float32(-np.inf))])
+        a[: len(near)] = np.clip(near, 0, None)
+        a[len(near): len(near) + 4] = [0.0, np.nextafter(r, np.float32(0)), 1e-7, 2.4e-7]
+        da = G(a)
+        fast, ieee = torch.empty_like(da), torch.empty_like(da)
+        _lib.call("icpflow_selftest_vote_quotient", _lib.ptr(da), len(a), float(mn32), float(mx32), _lib.ptr(fast),
+                  _lib.ptr(ieee), _lib.stream(DEV))
+        fast, ieee = fast.cpu().numpy(), ieee.cpu().numpy()
+        assert np.array_equal(fast.view(np.uint32), ieee.view(np.uint32)), (mn, mx)
+        want = (a.astype(np.float64) / np.float64(r)).astype(np.float32)      # correctly rounded (double quotient
+        assert np.array_equal(ieee, want), (mn, mx)                            # of two floats rounds once: 53 >= 2*24+2)
+
+
 def test_hist_argument_errors_like_the_reference():
     x = torch.zeros(2, 8, 4, device=DEV)
     with pytest.raises(RuntimeError):
