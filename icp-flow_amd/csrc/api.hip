@@ -57,6 +57,7 @@ struct Workspace {
     IcpCtrl *ctrl = nullptr;
     GridScratch grid{};
     float *history = nullptr;
+    IcpTeam team{};
     size_t bytes = 0;
 
     Workspace(void *base, int B, int N, size_t L)
@@ -91,6 +92,12 @@ struct Workspace {
         grid.sortYsoa = (float *)take(b * 3 * (size_t)((N + 15) / 16 * 16) * 4 + 256);  // + prefetch slack
         grid.axis = (int32_t *)take(b * 4);
         history = (float *)take(b * (size_t)kHistIters * kHistStride * 4);
+        team.maxWG = 1024;
+        team.wgPair = (int32_t *)take((size_t)team.maxWG * 4);
+        team.wgRank = (int32_t *)take((size_t)team.maxWG * 4);
+        team.teamSize = (int32_t *)take(b * 4);
+        team.arrived = (unsigned int *)take(b * 4);
+        team.mom = (double *)take((b < 256 ? b : 256) * 2 * (size_t)kMaxTeam * kTeamStride * 8);
         bytes = off;
     }
 };
@@ -134,7 +141,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, hipStream_t s)
 {
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, search_scratch(w, N), w.history, s));
+                           w.state, w.ctrl, search_scratch(w, N), w.history, &w.team, s));
     if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
     ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
@@ -174,6 +181,8 @@ int icpflow_version(void)
         once = true;
         const char *e = getenv("ICPFLOW_HIST_SORTED");
         if (e && e[0] == '0') g_hist_sorted = 0;
+        e = getenv("ICPFLOW_ICP_TEAMS");
+        if (e && e[0] == '0') icpflow::g_icp_teams = 0;
         e = getenv("ICPFLOW_ICP_SPECULATIVE");
         if (e && e[0] == '0') icpflow::g_icp_speculative = 0;
     }
@@ -361,7 +370,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     launch_count_valid(d_X, B, N, w.lenA, s);
     launch_count_valid(d_Y, B, N, w.lenC, s);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
-                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N), w.history, s));
+                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N), w.history, &w.team, s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
     return 0;
 }

@@ -221,6 +221,7 @@ struct IcpParams {
     // speculative single-launch execution of the batch-global stop rule (see launch_icp)
     float *history;          // [kHistIters, B, kHistStride] or NULL
     int B;
+    IcpTeam team;            // wgPair == NULL: one workgroup per pair (blockIdx.x = pair)
 };
 
 
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(kGridBlock) void grid_build_kernel(
 // ones of the all-pairs search; equal-distance ties are resolved to the lowest ORIGINAL index.
 // ---------------------------------------------------------------------------------
 constexpr int kSortBlock = 512;
+int g_icp_teams = 1;         // developer knob (ICPFLOW_ICP_TEAMS=0: always one workgroup per pair)
 int g_icp_speculative = 1;   // developer knob (api.hip: ICPFLOW_ICP_SPECULATIVE=0 forces one launch per iteration)
 
 // grid (B, 2): blockIdx.y == 0 sorts the fixed cloud, 1 the moving cloud (pre-pose applied)
@@ -419,6 +421,53 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
 // evaluated without rounding X R + T to fp32 first), so one pass over the points suffices.
 constexpr int kMoments = 18;
 
+// ---------------------------------------------------------------------------------
+// Teams: several workgroups serve one pair (IcpTeam, kernels.hpp).  Per iteration every member
+// publishes its 18 partial moments (+ member 0's stop flag) into the record of (pair, it & 1, rank),
+// bumps the pair's arrival counter and waits until the whole team has arrived; two record sets
+// suffice because nobody can be more than one exchange ahead of the slowest member.  All accesses
+// to the records are device-scope atomics, ordered by the release / acquire pair around the counter.
+// The wait is bounded: a member that is not being scheduled (workgroups of the team not co-resident)
+// makes its peers give up after kTeamTimeoutTicks; the registration is then poisoned, not hung.
+// ---------------------------------------------------------------------------------
+constexpr long long kTeamTimeoutTicks = 200000000ll;   // 2 s of the 100 MHz wall clock
+
+__device__ __forceinline__ void team_publish(const IcpTeam &t, int b, int it, int rank, double mine, double stop,
+                                             int lane)
+{
+    double *slot = t.mom + (((size_t)b * 2 + (it & 1)) * kMaxTeam + rank) * kTeamStride;
+    if (lane <= kMoments)
+        __hip_atomic_store(&slot[lane], lane < kMoments ? mine : stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_fetch_add(&t.arrived[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// -> true when the team has to stop (member 0 said so, or the wait timed out); otherwise `mine` of
+// lane k < 18 is the team total of moment k, added in member order
+__device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, int b, int it, int itBegin, int G,
+                                             int lane, double &mine)
+{
+    const unsigned want = (unsigned)G * (unsigned)(it - itBegin + 1);
+    const long long t0 = wall_clock64();
+    bool timeout = false;
+    while (__hip_atomic_load(&t.arrived[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > kTeamTimeoutTicks) { timeout = true; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (timeout) {
+        if (lane == 0) __hip_atomic_store(&ctrl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
+    const double *base = t.mom + ((size_t)b * 2 + (it & 1)) * kMaxTeam * kTeamStride;
+    double sum = 0.0;
+    if (lane < kMoments)
+        for (int r = 0; r < G; ++r)
+            sum += __hip_atomic_load(&base[r * kTeamStride + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mine = sum;
+    return __hip_atomic_load(&base[kMoments], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
+}
+
 // Work decomposition inside the workgroup (one pair): the NWAVE waves form NWAVE/TS query
 // groups x TS target shares.  The TS waves of a query group hold the SAME Q x 64 queries and
 // each scans 1/TS of every target tile; their partial (distance, chunk) results meet in LDS
@@ -432,7 +481,7 @@ constexpr int kMoments = 18;
 // GRID: 0 = all-pairs LDS scan, 1 = exact grid read from global memory (L2), 2 = exact grid staged
 // into LDS at kernel entry (dynamic shared memory: (H+1) ints + n float4), 3 = sorted sweep
 // (targets streamed through scalar loads, no LDS image)
-template <int BLOCK, int Q, int TS, int GRID>
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM>
 __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
     ICPFLOW_STAMP(0);
@@ -452,7 +501,14 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     __shared__ float combD[TS > 1 ? NWAVE * Q * kWave : 1];   // [wave][q][lane]
     __shared__ int combC[TS > 1 ? NWAVE * Q * kWave : 1];
 
-    const int b = blockIdx.x;
+    int b = blockIdx.x, rank = 0, G = 1;     // pair, member and size of the team serving it
+    if constexpr (TEAM) {
+        static_assert(!TEAM || GRID >= 3, "teams: sorted sweep only");
+        b = p.team.wgPair[blockIdx.x];
+        if (b < 0) return;                   // spare workgroup
+        rank = p.team.wgRank[blockIdx.x];
+        G = p.team.teamSize[b];
+    }
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
@@ -508,7 +564,13 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 
     int specChk = 0;  // speculative mode: first iteration not yet known to be complete-and-unconverged
     for (int it = itBegin; it < itEnd; ++it) {
-        if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) break;
+        if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
+            // speculative mode: only member 0 watches the batch tally; it tells its team to stop
+            // through the record of the iteration the others are about to exchange
+            if (TEAM && G > 1 && rank == 0 && p.stopMode == ICPFLOW_STOP_REFERENCE_ && wave == 0)
+                team_publish(p.team, b, it, 0, 0.0, 1.0, lane);
+            break;
+        }
         double macc[kMoments];  // wave-uniform running totals of this wave's query slots
 #pragma unroll
         for (int k = 0; k < kMoments; ++k) macc[k] = 0.0;
@@ -547,7 +609,10 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                                             : (axis == 0 ? gx : (axis == 1 ? gy : gz));
             static_assert(Q == 1, "sorted sweep: one query per lane");
             constexpr int PER = BLOCK * Q;            // a wave owns 64 CONSECUTIVE sorted queries
-            const int ngr = (xc.n + PER - 1) / PER;
+            // team member `rank` owns the sorted queries [qBegin, qEnd)
+            const int qShare = (TEAM && G > 1) ? ((xc.n + G - 1) / G + kWave - 1) / kWave * kWave : xc.n;
+            const int qBegin = min(rank * qShare, xc.n), qEnd = min(qBegin + qShare, xc.n);
+            const int ngr = (qEnd - qBegin + PER - 1) / PER;
             double fold[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
             for (int g = 0; g < ngr; ++g) {
                 float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
@@ -556,8 +621,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 ICPFLOW_STAMP(1);
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    const int i = g * PER + (wave * Q + q) * kWave + lane;
-                    live[q] = i < xc.n;
+                    const int i = qBegin + g * PER + (wave * Q + q) * kWave + lane;
+                    live[q] = i < qEnd;
                     x0x[q] = x0y[q] = x0z[q] = 0.f;
                     qx[q] = qy[q] = qz[q] = 0.f;
                     if (live[q]) {
@@ -810,7 +875,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         // ------------- wave 0 solves for (R, T, rmse) ---------------------------------------
         if (wave == 0) {
             unsigned long long specTally = 0ull;
-            if (p.history != nullptr && specChk < it)
+            if (p.history != nullptr && specChk < it && rank == 0)
                 specTally = __hip_atomic_load(&ctrl->tally[specChk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // lane k < 18 sums moment k over the waves; totals are then wave-uniform via readlane
             double mine = 0.0;
@@ -818,6 +883,18 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 mine = red[lane];
                 for (int w = 1; w < NWAVE; ++w) mine += red[w * kMoments + lane];
             }
+            bool teamStop = false;
+            if (TEAM && G > 1) {
+                // every member publishes its 18 partial moments, waits for the whole team and adds
+                // the records in member order: all members get bit-identical totals and solve for
+                // the same (R, T) on their own
+                team_publish(p.team, b, it, rank, mine, 0.0, lane);
+                teamStop = team_collect(p.team, ctrl, b, it, itBegin, G, lane, mine);
+            }
+            if (teamStop) {   // leave (R, T) as they are; every wave of this member stops
+                active = 0;
+                if (lane == 0) bcast[12] = 0.f;
+            } else {
             // totals go through LDS (lane k stores moment k, every lane reads what it needs): the
             // values stay out of the register file while the solve runs
             if (lane < kMoments) tot[lane] = mine;
@@ -868,7 +945,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 // speculative mode: record this iteration, publish (arrived, not converged) with one
                 // atomic, and leave once SOME iteration s <= it is known to satisfy the batch rule
                 // (every pair arrived at s, none unconverged).  Nobody ever waits.
-                if (lane == 0) {
+                if (lane == 0 && rank == 0) {
                     float *h = p.history + ((size_t)it * p.B + b) * kHistStride;
 #pragma unroll
                     for (int k = 0; k < 9; ++k) h[k] = Rf[k];
@@ -878,14 +955,14 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 }
                 // specTally was loaded before the solve (its latency hides behind the Jacobi sweeps):
                 // it describes iteration specChk <= it - 1
-                if (specChk < it) {
+                if (specChk < it && rank == 0) {
                     if ((int)(specTally & 0xffffffffull) >= p.B) {   // everybody has been there
                         if ((specTally >> 32) == 0ull) active = 0;   // the batch stops at specChk
                         else ++specChk;
                     }
                 }
             } else if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
-                if (lane == 0 && !conv) atomicAdd(&ctrl->notconv[it], 1);
+                if (lane == 0 && !conv && rank == 0) atomicAdd(&ctrl->notconv[it], 1);
             } else {
                 // per-pair rule: retire a pair once its rmse has stopped DEcreasing by more than
                 // thr (0 <= rel <= thr).  A negative rel (rmse went up: the inlier set is still
@@ -900,6 +977,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 bcast[12] = active ? 1.f : 0.f;
                 bcast[14] = rmse;  // :213 prev_rmse = rmse
             }
+            }  // !teamStop
         }
         itersDone = it + 1;
         ICPFLOW_STAMP(7);
@@ -915,7 +993,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     }
     ICPFLOW_STAMP(8);
     __syncthreads();
-    if (tid == 0) {  // wave 0 holds the final state
+    if (tid == 0 && rank == 0) {  // wave 0 (of member 0) holds the final state
 #pragma unroll
         for (int k = 0; k < 9; ++k) st->R[k] = Rf[k];
 #pragma unroll
@@ -949,6 +1027,7 @@ __global__ void icp_resolve_history_kernel(IcpState *__restrict__ st, IcpCtrl *_
     for (int k = 0; k < 3; ++k) st[b].T[k] = h[9 + k];
     st[b].rmse = h[12];
     st[b].iters = n;
+    if (ctrl->error) st[b].R[0] = __int_as_float(0x7fc00000);   // a team gave up waiting: poison
     if (b == 0) {
         ctrl->iters = n;
         // same convention as the per-iteration path: notconv[n-1] == 0 <=> converged
@@ -971,7 +1050,7 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
-        if (R) for (int k = 0; k < 9; ++k) R[(size_t)b * 9 + k] = st[b].R[k];
+        if (R) for (int k = 0; k < 9; ++k) R[(size_t)b * 9 + k] = ctrl->error ? __int_as_float(0x7fc00000) : st[b].R[k];
         if (T) for (int k = 0; k < 3; ++k) T[(size_t)b * 3 + k] = st[b].T[k];
         if (rmse) rmse[b] = st[b].rmse;
     }
@@ -985,7 +1064,73 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
     }
 }
 
-template <int BLOCK, int Q, int TS, int GRID>
+// Team sizes for one launch: every pair gets one workgroup, the spare ones go to the pairs whose
+// moving cloud needs more than one pass of a workgroup (1024 queries), in proportion to the excess;
+// a member keeps at least 256 queries.  One block; B <= 256.
+__global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__restrict__ lenX,
+                                                            const int32_t *__restrict__ lenY,
+                                                            const uint8_t *__restrict__ swap, int B, IcpTeam t)
+{
+    __shared__ int size[256];
+    __shared__ int first[257];
+    __shared__ long long total;
+    const int b = threadIdx.x;
+    int n = 0;
+    if (b < B) n = (swap != nullptr && swap[b] != 0) ? lenY[b] : lenX[b];
+    size[b] = max(n - 1024, 0);
+    for (int w = threadIdx.x; w < t.maxWG; w += blockDim.x) { t.wgPair[w] = -1; t.wgRank[w] = 0; }
+    __syncthreads();
+    if (b == 0) {
+        long long s = 0;
+        for (int k = 0; k < B; ++k) s += size[k];
+        total = s;
+    }
+    __syncthreads();
+    int G = 0;
+    if (b < B) {
+        const long long spare = t.maxWG - B;
+        G = 1 + (total > 0 ? (int)(spare * size[b] / total) : 0);
+        G = min(G, min(kMaxTeam, max(1, (n + 255) / 256)));
+    }
+    __syncthreads();
+    size[b] = G;
+    __syncthreads();
+    // Workgroup w is dispatched to XCD w % 8, so slot k = (w % 8) * per + w / 8 enumerates the
+    // workgroups XCD by XCD (per = maxWG / 8 of them each).  A team takes consecutive slots of ONE
+    // XCD (its exchange stays inside one L2); teams go to the XCD with the most free slots, which
+    // spreads the launch over all eight L2s.
+    const int per = (t.maxWG % 8 == 0) ? t.maxWG / 8 : t.maxWG;
+    if (b == 0) {
+        int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int nx = (per == t.maxWG) ? 1 : 8;
+        bool ok = true;
+        for (int k = 0; k < B && ok; ++k) {
+            int x = 0;
+            for (int c = 1; c < nx; ++c)
+                if (used[c] < used[x]) x = c;
+            if (used[x] + size[k] > per) ok = false;
+            first[k] = x * per + used[x];
+            used[x] += size[k];
+        }
+        if (!ok) {   // does not fit XCD by XCD: plain packing (teams may span two XCDs)
+            int acc = 0;
+            for (int k = 0; k < B; ++k) { first[k] = acc; acc += size[k]; }
+        }
+    }
+    __syncthreads();
+    if (b < B) {
+        t.teamSize[b] = G;
+        t.arrived[b] = 0u;
+        for (int r = 0; r < G; ++r) {
+            const int k = first[b] + r;
+            const int w = (per == t.maxWG) ? k : (k % per) * 8 + k / per;
+            t.wgPair[w] = b;
+            t.wgRank[w] = r;
+        }
+    }
+}
+
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM = false>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
@@ -993,12 +1138,13 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
     if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation
         static bool raised = false;
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
             raised = true;
         }
     }
-    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID>), dim3(B), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
+    const int wgs = TEAM ? p.team.maxWG : B;
+    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID, TEAM>), dim3(wgs), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
 }
 
 // ---- optional per-launch timing of this (dominant) kernel with HIP events ---------------------
@@ -1066,6 +1212,10 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
         // streams it through scalar loads (no LDS image, any N the sort can handle).
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.N <= 512) launch_icp_variant<512, 1, 1, 4>(p, B, itBegin, itEnd, s);
+        else if (p.team.wgPair != nullptr) {   // several workgroups per large pair (N > 1024)
+            if (p.N <= 12288) launch_icp_variant<1024, 1, 1, 4, true>(p, B, itBegin, itEnd, s);
+            else launch_icp_variant<1024, 1, 1, 3, true>(p, B, itBegin, itEnd, s);
+        }
         else if (p.N <= 12288) launch_icp_variant<1024, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else launch_icp_variant<1024, 1, 1, 3>(p, B, itBegin, itEnd, s);
     } else if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
@@ -1084,7 +1234,7 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      const GridScratch *grid, float *history, hipStream_t s)
+                      const GridScratch *grid, float *history, const IcpTeam *team, hipStream_t s)
 {
     IcpParams p{};
     p.B = B;
@@ -1118,6 +1268,24 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.gridPts = (const float4 *)grid->pts; p.gridStart = grid->start; p.gridOrigin = grid->origin;
         p.gridH = grid->H; p.gridInvH = invh;
     }
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 1;
+    }
+    const bool speculative = stopMode == ICPFLOW_STOP_REFERENCE_ && history != nullptr && g_icp_speculative &&
+                             maxIter > 1 && maxIter <= kHistIters && B <= cus;
+    // Teams: with at most half of the CUs taken by one workgroup per pair, the spare CUs join the pairs
+    // whose moving cloud needs several passes (real clusters, N > 1024).  Needs every workgroup of the
+    // launch resident at once (members wait for each other): single-launch modes only.
+    if (team != nullptr && g_icp_teams && grid != nullptr && grid->mode == 3 && N > 1024 && 2 * B <= cus &&
+        B <= 256 && (speculative || stopMode == ICPFLOW_STOP_PER_PAIR_)) {
+        p.team = *team;
+        p.team.maxWG = min(cus, team->maxWG);
+        hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, p.team);
+    }
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {
         // Batch-global stop rule.  While all workgroups of the batch can be resident at once
         // (B <= CUs: one 1024-thread, <=128-VGPR workgroup per CU) ONE launch runs every pair through
@@ -1125,15 +1293,6 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         // they observe that some iteration satisfied the batch rule, and the epilogue picks every
         // pair's state at exactly the reference's stopping iteration.  Larger batches (late
         // workgroups would hold the early ones at the iteration cap) use one launch per iteration.
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                cus = 1;
-        }
-        const bool speculative = history != nullptr && g_icp_speculative && maxIter > 1 && maxIter <= kHistIters &&
-                                 B <= cus;
         if (speculative) {
             p.history = history;
             launch_icp_iters(p, B, 0, maxIter, s);

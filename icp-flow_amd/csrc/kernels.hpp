@@ -30,11 +30,26 @@ struct IcpState {
 struct IcpCtrl {
     int done;
     int iters;
-    int pad[2];
+    int error;     // a team member waited too long for its peers (results are poisoned with NaN)
+    int pad;
     int notconv[kMaxIterCap];
     // speculative single-launch mode: per iteration, pairs arrived (low 32 bits) and pairs not
     // converged (high 32 bits), updated by ONE 64-bit atomic per pair so both are read consistently
     unsigned long long tally[kMaxIterCap];
+};
+
+// Teams (icp.hip): several workgroups share one LARGE pair.  Every member owns a contiguous range
+// of the sorted moving cloud, the 18 moments of an iteration are exchanged through `mom`, and each
+// member solves for the same (R, T) redundantly -- one exchange per iteration, nobody broadcasts.
+constexpr int kMaxTeam = 16;      // workgroups per pair, at most
+constexpr int kTeamStride = 20;   // doubles per (pair, parity, member): 18 moments, stop flag
+struct IcpTeam {
+    int32_t *wgPair;        // [maxWG] pair served by workgroup w, -1 = none
+    int32_t *wgRank;        // [maxWG] rank inside the team
+    int32_t *teamSize;      // [B]
+    unsigned int *arrived;  // [B] members that have published (monotone over the launch)
+    double *mom;            // [B, 2, kMaxTeam, kTeamStride]
+    int maxWG;
 };
 
 constexpr int kHistIters = 128;   // iterations of per-pair history kept in the workspace
@@ -86,10 +101,11 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
 };
 int grid_buckets(int N);
 extern int g_icp_speculative;
+extern int g_icp_teams;
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      const GridScratch *grid, float *history, hipStream_t s);
+                      const GridScratch *grid, float *history, const IcpTeam *team, hipStream_t s);
 hipError_t profile_enable(int capacity);
 hipError_t profile_collect(double *total_ms, int *launches);
 hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,

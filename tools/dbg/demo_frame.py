@@ -9,7 +9,7 @@ g = load_golden("g8_demo"); lab = load_golden("g8_demo_labels")
 dev = torch.device("cuda:0")
 G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 ps, pd = G(g["point_src"]), G(g["point_dst"]); ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
-for mp in (2048, 10000):
+for mp in [int(x) for x in os.environ.get("MP", "2048,10000").split(",")]:
     a = rp.default_args(max_points=mp, min_cluster_size=20, translation_frame=2.0, thres_box=0.1, thres_rot=0.1, thres_error=0.2, thres_iou=0.2)
     def run():
         torch.manual_seed(0)
