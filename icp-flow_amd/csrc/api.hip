@@ -78,7 +78,7 @@ struct Workspace {
         peakVotes = (float *)take(b * kTopK * 4);
         peakIdx = (int64_t *)take(b * kTopK * 8);
         cand = (float *)take(b * kCand * 3 * 4);
-        partial = (double *)take(b * 12 * (size_t)scan_qblocks(N) * kPartial * 8);
+        partial = (double *)take(b * 12 * (size_t)scan_qblocks(N, B) * kPartial * 8);
         Tinit = (float *)take(b * 16 * 4);
         M = (float *)take(b * 16 * 4);
         state = (IcpState *)take(b * sizeof(IcpState));
@@ -145,7 +145,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
     ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
-    ICPFLOW_TRY(launch_select(w.partial, scan_qblocks(N), w.lenA, w.lenC, swap, init, w.M, B,
+    ICPFLOW_TRY(launch_select(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, swap, init, w.M, B,
                               invertSwapped, Tout, s));
     return 0;
 }
@@ -166,7 +166,7 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
                                       w.peakVotes, w.peakIdx, s));
     ICPFLOW_TRY(launch_decode_candidates(w.peakIdx, B, ex, ey, ez, lx, ly, lz, shift, w.cand, s));
     ICPFLOW_TRY(launch_scan_score(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
-    ICPFLOW_TRY(launch_score_pick(w.partial, scan_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
+    ICPFLOW_TRY(launch_score_pick(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
     return 0;
 }
 
@@ -441,7 +441,7 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
     launch_count_valid(d_pcd1, B, N, w.lenA, s);
     launch_count_valid(d_pcd2, B, N, w.lenC, s);
     ICPFLOW_TRY(launch_scan_eval(d_pcd1, d_pcd2, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.partial, s));
-    ICPFLOW_TRY(launch_eval_epilogue(w.partial, scan_qblocks(N), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
+    ICPFLOW_TRY(launch_eval_epilogue(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
                                      d_ratios, d_ious, d_translations, d_rotations, s));
     return 0;
 }

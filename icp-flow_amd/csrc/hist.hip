@@ -183,18 +183,26 @@ constexpr int kZsortBlock = 512;
 
 // grid (B, 2): y = 0 sorts cloud P, y = 1 cloud Q; valid rows (flag > 0) first, ascending z
 __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__restrict__ P,
-                                                           const float4 *__restrict__ Qc, int N, int NP2,
+                                                           const float4 *__restrict__ Qc,
+                                                           const int32_t *__restrict__ nP,
+                                                           const int32_t *__restrict__ nQ, int N, int NP2full,
                                                            float4 *__restrict__ Ps, float4 *__restrict__ Qs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     float *key = reinterpret_cast<float *>(dynLds);
-    int *idx = reinterpret_cast<int *>(dynLds + sizeof(float) * NP2);
+    int *idx = reinterpret_cast<int *>(dynLds + sizeof(float) * NP2full);
     const int b = blockIdx.x;
     const float4 *in = (blockIdx.y == 0 ? P : Qc) + (size_t)b * N;
     float4 *out = (blockIdx.y == 0 ? Ps : Qs) + (size_t)b * N;
+    // pad_segment layout (valid rows first): only the first n rows can be valid, and the network
+    // only has to hold them -- next power of two >= n instead of >= N
+    const int n = min((blockIdx.y == 0 ? nP : nQ)[b], N);
+    int NP2 = kWave;
+    while (NP2 < n) NP2 <<= 1;
+    NP2 = min(NP2, NP2full);
     for (int j = threadIdx.x; j < NP2; j += kZsortBlock) {
         float k = kInf;
-        if (j < N) {
+        if (j < n) {
             const float4 q = in[j];
             if (q.w > 0.0f) k = q.z;
         }
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
     for (int r = threadIdx.x; r < N; r += kZsortBlock) {
         // rows beyond the valid count carry +inf keys: emit them as invalid rows
         float4 o = make_float4(0.f, 0.f, kInf, 0.f);
-        if (key[r] < kInf) o = in[idx[r]];
+        if (r < NP2 && key[r] < kInf) o = in[idx[r]];
         out[r] = o;
     }
 }
@@ -302,7 +310,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
         }
     }
     hipLaunchKernelGGL(zsort_kernel, dim3(B, 2), dim3(kZsortBlock), (size_t)NP2 * 8, s, (const float4 *)X,
-                       (const float4 *)Y, N, NP2, (float4 *)sortX, (float4 *)sortY);
+                       (const float4 *)Y, nX, nY, N, NP2, (float4 *)sortX, (float4 *)sortY);
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
     const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
     const int useLds = lds_hist <= 64 * 1024;

@@ -383,7 +383,12 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     PointXf pre;
     pre.kind = (moving && prePose) ? XF_AFFINE : XF_NONE;
     pre.a = (moving && prePose) ? affine_from_pose(prePose + (size_t)b * 16) : affine_identity();
-    for (int j = tid; j < NP2; j += kSortBlock) {
+    // the sorting network only has to hold THIS cloud: next power of two >= n (ragged batches are
+    // padded to the largest cluster, most clusters are far smaller)
+    int np2 = kWave;
+    while (np2 < n) np2 <<= 1;
+    np2 = min(np2, NP2);
+    for (int j = tid; j < np2; j += kSortBlock) {
         float k = kInf;
         if (j < n) {
             const float4 q = cloud[j];
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
         idx[j] = j;
     }
     __syncthreads();
-    bitonic_sort_lds(key, idx, NP2);
+    bitonic_sort_lds(key, idx, np2);
     float4 *out = (moving ? Xs : Ys) + (size_t)b * N;
     const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
     float *soa = Ysoa + (size_t)b * 3 * NP16;

@@ -74,7 +74,7 @@ hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, in
                                  int64_t *idx, hipStream_t s);
 
 // nn.hip
-int scan_qblocks(int maxRows);
+int scan_qblocks(int maxRows, int batch);
 hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                              const uint8_t *swap, int B, int N, const float *cand, double *partial,
                              hipStream_t s);

@@ -168,12 +168,20 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
     }
 }
 
-template <int MODE>
-static hipError_t launch_scan(ScanParams p, int maxRows, hipStream_t s)
+// Queries per lane.  More queries per lane amortise the LDS broadcast reads (Q = 4: VALU bound), but a
+// workgroup then owns 256 Q queries against the WHOLE target cloud, and on small (frame-level) batches
+// of ragged clusters the few workgroups of the largest pair are the critical path: stay at Q = 2 there.
+static int scan_queries_per_lane(int maxRows, int batch)
 {
-    int Q = 4;
-    if (maxRows <= 512) Q = 1;
-    else if (maxRows <= 1024) Q = 2;
+    if (maxRows <= 512) return 1;
+    if (maxRows <= 1024 || batch <= 128) return 2;
+    return 4;
+}
+
+template <int MODE>
+static hipError_t launch_scan(ScanParams p, int maxRows, int batch, hipStream_t s)
+{
+    const int Q = scan_queries_per_lane(maxRows, batch);
     p.qblocks = (maxRows + kScanBlock * Q - 1) / (kScanBlock * Q);
     const int groups = (p.njobs + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * p.qblocks));
@@ -183,11 +191,9 @@ static hipError_t launch_scan(ScanParams p, int maxRows, hipStream_t s)
     return hipGetLastError();
 }
 
-int scan_qblocks(int maxRows)
+int scan_qblocks(int maxRows, int batch)
 {
-    int Q = 4;
-    if (maxRows <= 512) Q = 1;
-    else if (maxRows <= 1024) Q = 2;
+    const int Q = scan_queries_per_lane(maxRows, batch);
     return (maxRows + kScanBlock * Q - 1) / (kScanBlock * Q);
 }
 
@@ -198,7 +204,7 @@ hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA
     ScanParams p{};
     p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.N = N;
     p.njobs = B * 12; p.cand = cand; p.partial = partial;
-    return launch_scan<MODE_SCORE>(p, N, s);
+    return launch_scan<MODE_SCORE>(p, N, B, s);
 }
 
 hipError_t launch_scan_check(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
@@ -208,7 +214,7 @@ hipError_t launch_scan_check(const float *A, const float *C, const int32_t *lenA
     ScanParams p{};
     p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.N = N;
     p.njobs = B * 2; p.poseA = poseInit; p.poseB = poseFinal; p.partial = partial;
-    return launch_scan<MODE_CHECK>(p, N, s);
+    return launch_scan<MODE_CHECK>(p, N, B, s);
 }
 
 hipError_t launch_scan_eval(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
@@ -217,7 +223,7 @@ hipError_t launch_scan_eval(const float *A, const float *C, const int32_t *lenA,
     ScanParams p{};
     p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = nullptr; p.N = N;
     p.njobs = B * 2; p.poseA = pose; p.thres = thres; p.partial = partial;
-    return launch_scan<MODE_EVAL>(p, N, s);
+    return launch_scan<MODE_EVAL>(p, N, B, s);
 }
 
 hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int NT, int strideQ,
@@ -228,7 +234,7 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
     p.A = Qp; p.C = Tp; p.lenA = lenQ; p.lenC = lenT; p.N = NQ; p.NT = NT;
     p.strideQ = strideQ; p.strideT = strideT; p.njobs = B; p.idx = idx; p.dist = dist;
     p.sqrt_dist = sqrt_dist;
-    return launch_scan<MODE_NN>(p, NQ, s);
+    return launch_scan<MODE_NN>(p, NQ, 1 << 30, s);
 }
 
 }  // namespace icpflow
