@@ -37,8 +37,12 @@ int hipfail(hipError_t e, const char *what)
 // ICP correspondence search: 0 = auto, 1 = all-pairs LDS scan, 2 = exact hashed grid,
 // 3 = sorted sweep (icp.hip)
 int g_icp_search = 0;
+int g_score_sweep = 1;   // developer knob (ICPFLOW_SCORE_SWEEP=0 selects the all-pairs scoring scan)
 int g_hist_sorted = 1;   // developer knob (ICPFLOW_HIST_SORTED=0 selects the all-pairs vote)
 
+// the scoring sweep prunes by the largest NN distance inside a wave: it pays on large clusters (real
+// data, hundreds of queries per metre along the sort axis), not on ~1000-point vehicles
+constexpr int kScoreSweepMinN = 2048;
 constexpr int kMaxSortN = 16384;   // bitonic sort of (key, index) pairs in 128 KiB of LDS
 constexpr size_t kAlign = 256;
 size_t up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
@@ -78,7 +82,10 @@ struct Workspace {
         peakVotes = (float *)take(b * kTopK * 4);
         peakIdx = (int64_t *)take(b * kTopK * 8);
         cand = (float *)take(b * kCand * 3 * 4);
-        partial = (double *)take(b * 12 * (size_t)scan_qblocks(N, B) * kPartial * 8);
+        {
+            const size_t qb = (size_t)(scan_qblocks(N, B) > sweep_qblocks(N) ? scan_qblocks(N, B) : sweep_qblocks(N));
+            partial = (double *)take(b * 12 * qb * kPartial * 8);
+        }
         Tinit = (float *)take(b * 16 * 4);
         M = (float *)take(b * 16 * 4);
         state = (IcpState *)take(b * sizeof(IcpState));
@@ -90,6 +97,7 @@ struct Workspace {
         grid.pts = (float *)take(b * (size_t)N * 16);
         grid.sortX = (float *)take(b * (size_t)N * 16);
         grid.sortYsoa = (float *)take(b * 3 * (size_t)((N + 15) / 16 * 16) * 4 + 256);  // + prefetch slack
+        grid.sortXsoa = (float *)take(b * 3 * (size_t)((N + 15) / 16 * 16) * 4 + 256);
         grid.axis = (int32_t *)take(b * 4);
         history = (float *)take(b * (size_t)kHistIters * kHistStride * 4);
         team.maxWG = 1024;
@@ -165,8 +173,16 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
     ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,
                                       w.peakVotes, w.peakIdx, s));
     ICPFLOW_TRY(launch_decode_candidates(w.peakIdx, B, ex, ey, ez, lx, ly, lz, shift, w.cand, s));
-    ICPFLOW_TRY(launch_scan_score(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
-    ICPFLOW_TRY(launch_score_pick(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
+    // candidate scoring: sorted sweep while the sort fits LDS, all-pairs scan otherwise (same sums)
+    if (N > kScoreSweepMinN && N <= kMaxSortN && g_score_sweep) {
+        ICPFLOW_TRY(launch_sort_clouds_soa(src, dst, w.lenA, w.lenC, swap, B, N, &w.grid, s));
+        w.grid.presorted = 1;   // hist_icp: the ICP that follows reuses this sort
+        ICPFLOW_TRY(launch_sweep_score(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
+        ICPFLOW_TRY(launch_score_pick(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
+    } else {
+        ICPFLOW_TRY(launch_scan_score(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
+        ICPFLOW_TRY(launch_score_pick(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
+    }
     return 0;
 }
 
@@ -181,6 +197,8 @@ int icpflow_version(void)
         once = true;
         const char *e = getenv("ICPFLOW_HIST_SORTED");
         if (e && e[0] == '0') g_hist_sorted = 0;
+        e = getenv("ICPFLOW_SCORE_SWEEP");
+        if (e && e[0] == '0') g_score_sweep = 0;
         e = getenv("ICPFLOW_ICP_TEAMS");
         if (e && e[0] == '0') icpflow::g_icp_teams = 0;
         e = getenv("ICPFLOW_ICP_SPECULATIVE");

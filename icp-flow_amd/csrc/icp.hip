@@ -218,6 +218,7 @@ struct IcpParams {
     const float *sortYsoa;   // [B,3,NP16] fixed cloud as x[], y[], z[] padded with +inf to 16
     const int32_t *sortAxis; // [B]
     float sweepMargin;       // window half-width beyond the wave's query span (1.01 * thres)
+    int sortedRaw;           // sortX holds the moving cloud WITHOUT the pre-pose: apply it at load
     // speculative single-launch execution of the batch-global stop rule (see launch_icp)
     float *history;          // [kHistIters, B, kHistStride] or NULL
     int B;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const int32_t *__restrict__ lenX,
     const int32_t *__restrict__ lenY, const uint8_t *__restrict__ swap, const float *__restrict__ prePose,
     int N, int NP2, int32_t *__restrict__ axisOut, float4 *__restrict__ Xs, float4 *__restrict__ Ys,
-    float *__restrict__ Ysoa)
+    float *__restrict__ Ysoa, float *__restrict__ Xsoa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     float *key = reinterpret_cast<float *>(dynLds);
@@ -403,8 +404,10 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     bitonic_sort_lds(key, idx, np2);
     float4 *out = (moving ? Xs : Ys) + (size_t)b * N;
     const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
-    float *soa = Ysoa + (size_t)b * 3 * NP16;
-    for (int r = tid; r < (moving ? n : NP16); r += kSortBlock) {
+    // structure-of-arrays image (x[], y[], z[], padded with +inf to a multiple of 16): always for the
+    // fixed cloud, for the moving cloud when the caller wants to sweep in both directions (Xsoa)
+    float *soa = moving ? (Xsoa ? Xsoa + (size_t)b * 3 * NP16 : nullptr) : Ysoa + (size_t)b * 3 * NP16;
+    for (int r = tid; r < (soa ? NP16 : n); r += kSortBlock) {
         float px = kInf, py = kInf, pz = kInf;
         if (r < n) {
             const int j = idx[r];
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
             xf_apply(pre, q.x, q.y, q.z, px, py, pz);
             out[r] = make_float4(px, py, pz, __int_as_float(j));
         }
-        if (!moving) { soa[r] = px; soa[NP16 + r] = py; soa[2 * NP16 + r] = pz; }
+        if (soa) { soa[r] = px; soa[NP16 + r] = py; soa[2 * NP16 + r] = pz; }
     }
 }
 
@@ -631,11 +634,12 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     x0x[q] = x0y[q] = x0z[q] = 0.f;
                     qx[q] = qy[q] = qz[q] = 0.f;
                     if (live[q]) {
-                        const float4 s4 = xs[i];   // sorted, pre-pose already applied (utils_icp.py:21)
+                        const float4 s4 = xs[i];   // sorted; pre-pose (utils_icp.py:21) applied by the sort or here
                         x0x[q] = s4.x; x0y[q] = s4.y; x0z[q] = s4.z;
-                        qx[q] = fmaf(s4.z, Rf[6], fmaf(s4.y, Rf[3], s4.x * Rf[0])) + Tf[0];  // :177, :395
-                        qy[q] = fmaf(s4.z, Rf[7], fmaf(s4.y, Rf[4], s4.x * Rf[1])) + Tf[1];
-                        qz[q] = fmaf(s4.z, Rf[8], fmaf(s4.y, Rf[5], s4.x * Rf[2])) + Tf[2];
+                        if (p.sortedRaw) xf_apply(pre, s4.x, s4.y, s4.z, x0x[q], x0y[q], x0z[q]);
+                        qx[q] = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0])) + Tf[0];  // :177, :395
+                        qy[q] = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1])) + Tf[1];
+                        qz[q] = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2])) + Tf[2];
                         const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
                         lo = fminf(lo, qa); hi = fmaxf(hi, qa);
                     }
@@ -1249,7 +1253,14 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(IcpCtrl), s);
     if (e != hipSuccess) return e;
-    if (grid != nullptr && grid->mode == 3) {
+    if (grid != nullptr && grid->mode == 3 && grid->presorted) {
+        // the scoring sweep of this batch left both clouds sorted along the fixed cloud's longest axis;
+        // a translation-only pre-pose (hist_icp) keeps that order
+        p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
+        p.sortYsoa = grid->sortYsoa;
+        p.sweepMargin = (float)(1.01 * thres);
+        p.sortedRaw = 1;
+    } else if (grid != nullptr && grid->mode == 3) {
         int NP2 = 64;
         while (NP2 < N) NP2 <<= 1;
         if ((size_t)NP2 * 8 > 64 * 1024) {   // dynamic LDS above 64 KiB needs the attribute (N > 8192)
@@ -1261,7 +1272,8 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
             }
         }
         hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY,
-                           swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts, grid->sortYsoa);
+                           swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts, grid->sortYsoa,
+                           (float *)nullptr);
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
@@ -1309,6 +1321,27 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     } else {
         launch_icp_iters(p, B, 0, maxIter, s);
     }
+    return hipGetLastError();
+}
+
+// both clouds of every pair sorted along the fixed cloud's longest axis, without a pre-pose, with
+// structure-of-arrays images of BOTH: input of the scoring sweep (nn.hip)
+hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
+                                  const uint8_t *swap, int B, int N, const GridScratch *grid, hipStream_t s)
+{
+    int NP2 = 64;
+    while (NP2 < N) NP2 <<= 1;
+    if ((size_t)NP2 * 8 > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_clouds_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr = true;
+        }
+    }
+    hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY, swap,
+                       (const float *)nullptr, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts,
+                       grid->sortYsoa, grid->sortXsoa);
     return hipGetLastError();
 }
 

@@ -74,7 +74,11 @@ hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, in
                                  int64_t *idx, hipStream_t s);
 
 // nn.hip
+struct GridScratch;
 int scan_qblocks(int maxRows, int batch);
+int sweep_qblocks(int maxRows);
+hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
+                              int B, int N, const float *cand, double *partial, hipStream_t s);
 hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                              const uint8_t *swap, int B, int N, const float *cand, double *partial,
                              hipStream_t s);
@@ -97,7 +101,10 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     float *pts;        // grid: fixed cloud sorted by bucket; sweep: fixed cloud sorted by axis [B,N,4]
     float *sortX;      // sweep: moving cloud sorted by axis, pre-pose applied [B,N,4]
     float *sortYsoa;   // sweep: fixed cloud sorted, x[] y[] z[] padded with +inf [B,3,NP16]
+    float *sortXsoa;   // scoring sweep: moving cloud sorted (no pre-pose), same layout
     int32_t *axis;     // sweep: [B]
+    int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose
+                       // (scoring sweep ran on this batch): the ICP applies the pre-pose when it loads
 };
 int grid_buckets(int N);
 extern int g_icp_speculative;
@@ -106,6 +113,8 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
                       const GridScratch *grid, float *history, const IcpTeam *team, hipStream_t s);
+hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
+                                  const uint8_t *swap, int B, int N, const GridScratch *grid, hipStream_t s);
 hipError_t profile_enable(int capacity);
 hipError_t profile_collect(double *total_ms, int *launches);
 hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,

@@ -197,6 +197,133 @@ int scan_qblocks(int maxRows, int batch)
     return (maxRows + kScanBlock * Q - 1) / (kScanBlock * Q);
 }
 
+// ---------------------------------------------------------------------------------
+// Candidate scoring as a sorted SWEEP (a-3): the same sums as MODE_SCORE above -- for each of the
+// 6 candidate translations the sum of nearest-neighbour distances src + t -> dst and dst -> src + t
+// -- but a wave of 64 consecutive sorted queries only visits the targets that can be anybody's
+// nearest neighbour.  Both clouds are sorted along the dst role's longest axis u (a translation
+// does not change the order).  Pass 1 scans the targets whose u lies within r0 of the wave's
+// queries; that yields an upper bound R on every lane's NN distance (R = the largest minimum found,
+// infinite if some lane saw no target at all); if R > r0, pass 2 scans the rest of the window of
+// radius R.  A target outside that window differs from every query of the wave by more than R along
+// u alone, so the minima -- evaluated with the same instruction sequence as the all-pairs scan --
+// are bit-identical; only the order of the (fp64) sum over queries changes.
+// One query per lane, targets streamed through scalar loads, no LDS, no barriers in the scan.
+// ---------------------------------------------------------------------------------
+struct SweepParams {
+    const float *Asoa;      // [B,3,NP16] src role sorted along axis[b], +inf padded
+    const float *Csoa;      // [B,3,NP16] dst role
+    const int32_t *lenA, *lenC;
+    const uint8_t *swap;
+    const int32_t *axis;
+    const float *cand;      // [B,6,3]
+    int N, NP16, njobs, qblocks;
+    float r0;
+    double *partial;        // [njobs, qblocks, kPartial]
+};
+
+constexpr int kSweepBlock = 256;
+
+__global__ __launch_bounds__(kSweepBlock) void sweep_score_kernel(SweepParams p)
+{
+    __shared__ double red[kSweepBlock / kWave];
+    extern __shared__ __attribute__((aligned(16))) float keyLds[];   // the targets' sort keys (window searches)
+    const int lin = blockIdx.x;
+    const int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);   // XCD-aware: the 8 XCDs take 8 jobs
+    const int qb = (lin >> 3) % p.qblocks;
+    if (job >= p.njobs) return;
+    const int b = job / 12, sub = job % 12, k = sub >> 1;
+    const bool backward = sub & 1;
+    const bool sw = p.swap != nullptr && p.swap[b] != 0;
+    const int na = (sw ? p.lenC : p.lenA)[b], nc = (sw ? p.lenA : p.lenC)[b];
+    const float *as = p.Asoa + (size_t)b * 3 * p.NP16, *cs = p.Csoa + (size_t)b * 3 * p.NP16;
+    const float *qs = backward ? cs : as, *ts = backward ? as : cs;
+    const int nq = backward ? nc : na, nt = backward ? na : nc;
+    double *out = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (qb * kSweepBlock >= nq) {   // block beyond the cloud: its record is still summed
+        if (threadIdx.x < kPartial) out[threadIdx.x] = 0.0;
+        return;
+    }
+    const float *t3 = p.cand + ((size_t)b * 6 + k) * 3;
+    const float tx = t3[0], ty = t3[1], tz = t3[2];
+    const int axis = p.axis[b];
+    const float tu = axis == 0 ? tx : (axis == 1 ? ty : tz);
+    const int i = qb * kSweepBlock + wave * kWave + lane;
+    const bool live = i < nq;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (live) {
+        qx = qs[i]; qy = qs[p.NP16 + i]; qz = qs[2 * p.NP16 + i];
+        if (!backward) { qx += tx; qy += ty; qz += tz; }     // the moved source cloud, as the reference forms it
+    }
+    // position of the query along u in the frame of the (unshifted) target keys
+    float cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
+    if (backward) cu -= tu;
+    const float lo = wave_min_uniform(live ? cu : kInf), hi = wave_max_uniform(live ? cu : -kInf);
+    float best = kInf;
+    const float *tkx = ts, *tky = ts + p.NP16, *tkz = ts + 2 * p.NP16;
+    const int np16 = (nt + kChunk - 1) / kChunk * kChunk;
+    {
+        const float *gkey = axis == 0 ? tkx : (axis == 1 ? tky : tkz);
+        for (int j = threadIdx.x; j < np16; j += kSweepBlock) keyLds[j] = gkey[j];
+        __syncthreads();
+    }
+    if (lo <= hi && nt > 0) {   // wave-uniform
+        const float *key = keyLds;
+        // slack: rounding of src + t (an ulp of the coordinates) and of the window arithmetic
+        const float slack = 1e-4f + 2e-6f * (fabsf(lo) + fabsf(hi) + fabsf(tu));
+        int j0, j1;
+        sorted_window(key, nt, lo - p.r0 - slack, hi + p.r0 + slack, lane, j0, j1);
+        int cb = (j0 / kChunk) * kChunk, ce = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
+        if (backward) scan_range_min_uniform<true>(tkx, tky, tkz, cb, ce, qx, qy, qz, tx, ty, tz, best);
+        else scan_range_min_uniform<false>(tkx, tky, tkz, cb, ce, qx, qy, qz, 0.f, 0.f, 0.f, best);
+        const float worst = wave_max_uniform(live ? best : 0.f);
+        if (worst > p.r0 * p.r0) {
+            int k0 = 0, k1 = np16;
+            if (worst < kInf) {
+                const float R = sqrtf(worst) * 1.000002f;
+                sorted_window(key, nt, lo - R - slack, hi + R + slack, lane, j0, j1);
+                k0 = (j0 / kChunk) * kChunk;
+                k1 = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
+            }
+            if (ce <= cb) { cb = k0; ce = k0; }   // nothing scanned yet
+            if (backward) {
+                scan_range_min_uniform<true>(tkx, tky, tkz, k0, min(cb, k1), qx, qy, qz, tx, ty, tz, best);
+                scan_range_min_uniform<true>(tkx, tky, tkz, max(ce, k0), k1, qx, qy, qz, tx, ty, tz, best);
+            } else {
+                scan_range_min_uniform<false>(tkx, tky, tkz, k0, min(cb, k1), qx, qy, qz, 0.f, 0.f, 0.f, best);
+                scan_range_min_uniform<false>(tkx, tky, tkz, max(ce, k0), k1, qx, qy, qz, 0.f, 0.f, 0.f, best);
+            }
+        }
+    }
+    // sum of Euclidean NN distances of this block's queries (utils_helper.py:30, utils_hist.py:89-95)
+    double v = (live && nt > 0) ? (double)sqrtf(best) : 0.0;
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ssum = red[0];
+        for (int w = 1; w < kSweepBlock / kWave; ++w) ssum += red[w];
+        out[0] = ssum;
+        for (int q = 1; q < kPartial; ++q) out[q] = 0.0;
+    }
+}
+
+int sweep_qblocks(int maxRows) { return (maxRows + kSweepBlock - 1) / kSweepBlock; }
+
+hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
+                              int B, int N, const float *cand, double *partial, hipStream_t s)
+{
+    SweepParams p{};
+    p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
+    p.axis = grid->axis; p.cand = cand; p.N = N; p.NP16 = (N + kChunk - 1) / kChunk * kChunk;
+    p.njobs = B * 12; p.qblocks = sweep_qblocks(N); p.r0 = 0.15f; p.partial = partial;
+    const int groups = (p.njobs + 7) / 8;
+    const size_t lds = (size_t)p.NP16 * sizeof(float);   // <= 64 KiB at N = 16384
+    hipLaunchKernelGGL(sweep_score_kernel, dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                              const uint8_t *swap, int B, int N, const float *cand, double *partial,
                              hipStream_t s)

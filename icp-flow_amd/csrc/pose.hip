@@ -61,36 +61,42 @@ __device__ __forceinline__ double partial_total(const double *partial, int job, 
 
 // score_k = min(mean fwd, mean bwd); first arg-min; T = I with that translation
 // (utils_hist.py:101-106, :121-122)
-__global__ void score_pick_kernel(const double *__restrict__ partial, int qblocks,
-                                  const int32_t *__restrict__ lenA, const int32_t *__restrict__ lenC,
-                                  const uint8_t *__restrict__ swap, const float *__restrict__ cand, int B,
-                                  float *__restrict__ Tinit)
+// one wave per pair: lane j < 12 totals job j (candidate j / 2, direction j % 2) over the query blocks
+__global__ __launch_bounds__(kWave) void score_pick_kernel(const double *__restrict__ partial, int qblocks,
+                                                           const int32_t *__restrict__ lenA,
+                                                           const int32_t *__restrict__ lenC,
+                                                           const uint8_t *__restrict__ swap,
+                                                           const float *__restrict__ cand, int B,
+                                                           float *__restrict__ Tinit)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const int b = blockIdx.x, lane = threadIdx.x;
     const bool sw = swap != nullptr && swap[b] != 0;
     const float na = (float)(sw ? lenC[b] : lenA[b]);
     const float nc = (float)(sw ? lenA[b] : lenC[b]);
+    float mean = 0.f;
+    if (lane < 2 * kCand) mean = (float)partial_total(partial, b * 12 + lane, qblocks, 0) / ((lane & 1) ? nc : na);
     int pick = 0;
     float best = 0.f;
     for (int k = 0; k < kCand; ++k) {
-        const float fwd = (float)partial_total(partial, b * 12 + k * 2 + 0, qblocks, 0) / na;
-        const float bwd = (float)partial_total(partial, b * 12 + k * 2 + 1, qblocks, 0) / nc;
-        const float sc = fminf(fwd, bwd);
+        const float sc = fminf(__shfl(mean, 2 * k, kWave), __shfl(mean, 2 * k + 1, kWave));
         if (k == 0 || sc < best) { best = sc; pick = k; }
     }
-    float *T = Tinit + (size_t)b * 16;
-    for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.f : 0.f;
-    const float *t = cand + ((size_t)b * kCand + pick) * 3;
-    T[3] = t[0]; T[7] = t[1]; T[11] = t[2];
+    if (lane < 16) {
+        const float *t = cand + ((size_t)b * kCand + pick) * 3;
+        float v = (lane % 5 == 0) ? 1.f : 0.f;
+        if (lane == 3) v = t[0];
+        if (lane == 7) v = t[1];
+        if (lane == 11) v = t[2];
+        Tinit[(size_t)b * 16 + lane] = v;
+    }
 }
 
 hipError_t launch_score_pick(const double *partial, int qblocks, const int32_t *lenA,
                              const int32_t *lenC, const uint8_t *swap, const float *cand, int B,
                              float *Tinit, hipStream_t s)
 {
-    hipLaunchKernelGGL(score_pick_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, qblocks, lenA,
-                       lenC, swap, cand, B, Tinit);
+    hipLaunchKernelGGL(score_pick_kernel, dim3(B), dim3(kWave), 0, s, partial, qblocks, lenA, lenC, swap, cand, B,
+                       Tinit);
     return hipGetLastError();
 }
 

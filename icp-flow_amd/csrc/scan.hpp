@@ -263,6 +263,49 @@ __device__ __forceinline__ void scan_range_tie_uniform(const float *__restrict__
     }
 }
 
+// Minimum squared distance only (no arg-min) over the chunks [cBegin, cEnd) of a sorted SoA image
+// streamed through scalar loads, for the unbounded-NN sweeps of the scoring / check scans (nn.hip).
+// SHIFT: the targets are the image translated by (sx, sy, sz); the sum is formed first, in fp32, like
+// the reference's transformed cloud, so distances are bit-identical to scanning a translated copy.
+template <bool SHIFT>
+__device__ __forceinline__ void scan_range_min_uniform(const float *__restrict__ gx, const float *__restrict__ gy,
+                                                       const float *__restrict__ gz, int cBegin, int cEnd,
+                                                       float qx, float qy, float qz, float sx, float sy, float sz,
+                                                       float &best)
+{
+    cBegin = __builtin_amdgcn_readfirstlane(cBegin);
+    cEnd = __builtin_amdgcn_readfirstlane(cEnd);
+    if (cBegin >= cEnd) return;
+    constexpr int HALF = kChunk / 2;
+    const v2f shx = {sx, sx}, shy = {sy, sy}, shz = {sz, sz};
+    v4f nx0 = *(ConstV4)(gx + cBegin), nx1 = *(ConstV4)(gx + cBegin + 4);
+    v4f ny0 = *(ConstV4)(gy + cBegin), ny1 = *(ConstV4)(gy + cBegin + 4);
+    v4f nz0 = *(ConstV4)(gz + cBegin), nz1 = *(ConstV4)(gz + cBegin + 4);
+    float m = best;
+    for (int c = cBegin; c < cEnd; c += HALF) {
+        const v4f tx0 = nx0, tx1 = nx1, ty0 = ny0, ty1 = ny1, tz0 = nz0, tz1 = nz1;
+        const int cn = c + HALF;   // one half past cEnd stays inside the allocation (+inf padding)
+        nx0 = *(ConstV4)(gx + cn); nx1 = *(ConstV4)(gx + cn + 4);
+        ny0 = *(ConstV4)(gy + cn); ny1 = *(ConstV4)(gy + cn + 4);
+        nz0 = *(ConstV4)(gz + cn); nz1 = *(ConstV4)(gz + cn + 4);
+        v2f xa = {tx0.x, tx0.y}, xb = {tx0.z, tx0.w}, xc = {tx1.x, tx1.y}, xd = {tx1.z, tx1.w};
+        v2f ya = {ty0.x, ty0.y}, yb = {ty0.z, ty0.w}, yc = {ty1.x, ty1.y}, yd = {ty1.z, ty1.w};
+        v2f za = {tz0.x, tz0.y}, zb = {tz0.z, tz0.w}, zc = {tz1.x, tz1.y}, zd = {tz1.z, tz1.w};
+        if (SHIFT) {
+            xa += shx; xb += shx; xc += shx; xd += shx;
+            ya += shy; yb += shy; yc += shy; yd += shy;
+            za += shz; zb += shz; zc += shz; zd += shz;
+        }
+        const v2f da = sqdist2(qx, qy, qz, xa, ya, za);
+        const v2f db = sqdist2(qx, qy, qz, xb, yb, zb);
+        const v2f dc = sqdist2(qx, qy, qz, xc, yc, zc);
+        const v2f dd = sqdist2(qx, qy, qz, xd, yd, zd);
+        m = min3f(min3f(m, da.x, da.y), db.x, db.y);
+        m = min3f(min3f(m, dc.x, dc.y), dd.x, dd.y);
+    }
+    best = m;
+}
+
 // Full scan of one target cloud for this lane's Q queries.  All threads of the block
 // must call it (it contains barriers).  With TS > 1 the caller's wave scans only share `ts`
 // of every tile (contiguous chunk ranges); the TS partial (best, chunk) results of a query
