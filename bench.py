@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--points", type=int, default=1024, help="points per cluster (= padded length)")
     ap.add_argument("--iters", type=int, default=50, help="ICP iteration cap (BASELINE: 50)")
     ap.add_argument("--stop-mode", default="reference", choices=["reference", "per_pair"])
-    ap.add_argument("--cpu-pairs", type=int, default=64, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements")
     return ap.parse_args()
 
@@ -141,8 +141,9 @@ def main():
         "avg_launch_ms": round(avg_launch_ms, 5), "launches_timed": icp_launches,
         "icp_iterations_executed_per_step": iters_done,
         "icp_share_of_step": round(icp_ms / (dt * 1e3), 4),
-        "note": "the correspondence search is FP32-VALU / latency bound, not HBM bound: the exact sorted sweep "
-                "evaluates ~15-20 % of the n^2 point pairs of a brute-force scan; see DESIGN.md 6",
+        "note": "the correspondence search is LDS-broadcast / FP32-VALU / latency bound, not HBM bound: the exact "
+                "sorted sweep evaluates ~12 % of the n^2 point pairs of a brute-force scan and both clouds stay "
+                "on chip for all iterations; see DESIGN.md 6",
     }
 
     extras = {}
@@ -209,8 +210,8 @@ def cpu_baseline(S, D, a):
     all host cores (OpenMP over pairs inside oracle_core.c + torch-CPU threads)."""
     from oracle import core as ocore
     from oracle import reference_path as rp
-    # threads actually used: all host cores up to 32 (the sample is 64 pairs of ~1 MB each;
-    # on a 256-core box more threads only add fork/join overhead to the many small torch ops)
+    # threads actually used: all host cores up to 32 (on a 256-core box more threads only add fork/join
+    # overhead to the many small torch ops); sample = the whole batch by default (a few seconds of wall)
     ncpu = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(ncpu)
     ocore.set_num_threads(ncpu)
