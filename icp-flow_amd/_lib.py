@@ -45,6 +45,7 @@ SIGNATURES = {
     "icpflow_hist_icp": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _sz, _p]),
     "icpflow_match_eval": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "icpflow_gather_pad": (_i, [_p, _p, _i, _i, _p, _p]),
+    "icpflow_gather_segments": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
     "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),
     "icpflow_flow_rigid": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "icpflow_selftest_vote_quotient": (_i, [_p, _i, _f, _f, _p, _p, _p]),

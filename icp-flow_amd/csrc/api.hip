@@ -318,6 +318,15 @@ int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int 
     return 0;
 }
 
+int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const int64_t *d_seg,
+                            const int32_t *d_perm, int B, int N, float *d_out, icpflow_stream_t stream)
+{
+    if (!d_points || !d_order || !d_seg || !d_out) return fail(ICPFLOW_E_ARG, "icpflow_gather_segments: null pointer");
+    if (int r = check_batch("icpflow_gather_segments", B, N)) return r;
+    ICPFLOW_TRY(launch_gather_segments(d_points, d_order, d_seg, d_perm, B, N, d_out, (hipStream_t)stream));
+    return 0;
+}
+
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
                           const int64_t *d_count, int L, float *d_mean, float *d_extent, icpflow_stream_t stream)
 {

@@ -142,6 +142,8 @@ hipError_t launch_eval_epilogue(const double *partial, int qblocks, const int32_
 hipError_t launch_vote_quotient_probe(const float *a, int n, float mn, float mx, float *fast, float *ieee,
                                       hipStream_t s);
 hipError_t launch_gather_pad(const float *points, const int32_t *rows, int B, int N, float *out, hipStream_t s);
+hipError_t launch_gather_segments(const float *points, const int64_t *order, const int64_t *seg, const int32_t *perm,
+                                  int B, int N, float *out, hipStream_t s);
 hipError_t launch_cluster_stats(const float *points, const int64_t *order, const int64_t *start,
                                 const int64_t *count, int L, float *mean, float *extent, hipStream_t s);
 hipError_t launch_flow_rigid(const float *points, const float *labels, int N, const float *pairLabels,

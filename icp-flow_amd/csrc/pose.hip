@@ -272,6 +272,35 @@ hipError_t launch_gather_pad(const float *points, const int32_t *rows, int B, in
     return hipGetLastError();
 }
 
+// pad_segment of whole clusters straight from the label-sorted row table (utils_match.py:81-91,
+// utils_helper.py:185-201): pair b takes `count` rows of its cluster, order[start + i] -- or, for a
+// cluster longer than N that the host subsampled (random_choice), order[start + perm[off + i]].
+// seg: int64 [3,B] = start, count (already clipped to N), offset into perm or -1.
+__global__ void gather_segments_kernel(const float *__restrict__ points, const int64_t *__restrict__ order,
+                                       const int64_t *__restrict__ seg, const int32_t *__restrict__ perm, int B,
+                                       int N, float4 *__restrict__ out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * N) return;
+    const int b = (int)(t / N), i = (int)(t % N);
+    const int64_t start = seg[b], count = seg[B + b], off = seg[2 * B + b];
+    float4 o = make_float4(1e8f, 1e8f, 1e8f, 0.f);                    // utils_helper.py:191-192
+    if (i < count) {
+        const int64_t r = order[start + (off >= 0 ? (int64_t)perm[off + i] : (int64_t)i)];
+        o = make_float4(points[r * 3 + 0], points[r * 3 + 1], points[r * 3 + 2], 1.f);
+    }
+    out[t] = o;
+}
+
+hipError_t launch_gather_segments(const float *points, const int64_t *order, const int64_t *seg, const int32_t *perm,
+                                  int B, int N, float *out, hipStream_t s)
+{
+    const size_t total = (size_t)B * N;
+    hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, points, order,
+                       seg, perm, B, N, (float4 *)out);
+    return hipGetLastError();
+}
+
 // per-cluster statistics consumed by sanity_check (utils_check.py:34-43): centroid and the
 // ascending-sorted axis-aligned bbox extents (get_bbox_tensor, utils_helper.py:166-170) of every
 // cluster of a labelled cloud.  order = rows sorted by label; cluster c owns order[start[c] ..

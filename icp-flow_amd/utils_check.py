@@ -1,71 +1,102 @@
 """Drop-ins for the reference's utils_check.py, evaluated for all candidate pairs at once.
 
 The reference loops over candidate pairs in Python and reads device scalars one by one
-(utils_check.py:21-49, implicit syncs); here per-cluster statistics are reduced once per cloud
-(`ClusterTable`, one workgroup per cluster: `icpflow_cluster_stats`) and the three tests are a handful of vectorised comparisons.
+(utils_check.py:21-49, implicit syncs).  Here the per-cluster statistics are reduced once per cloud
+on the device (`ClusterTable`, one workgroup per cluster: `icpflow_cluster_stats`) and come to the
+host in ONE transfer (a few hundred clusters x 9 numbers); candidate lists and the three tests are
+then a handful of vectorised numpy comparisons, without further device round trips.
 """
+import numpy as np
 import torch
 
 from . import _lib
 
 
-class ClusterTable:
-    """Per-label statistics of one labelled cloud, all on the cloud's device.
+def _np(x, dtype=None):
+    a = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    return a if dtype is None else a.astype(dtype, copy=False)
 
-    labels_unq  [L]    sorted unique labels (float, like the reference: ground -1e8, noise -1)
-    count       [L]    points per label
-    start       [L]    first row of the label in `order`
-    order       [M]    stable argsort of the labels: rows of a cluster in original order
-    mean        [L,3]  centroid (fp32 mean, utils_check.py:34-35)
-    extent      [L,3]  sorted axis-aligned bbox extents (get_bbox_tensor, utils_helper.py:166-170)
+
+class ClusterTable:
+    """Per-label statistics of one labelled cloud.
+
+    device:  points [M,3] float32, order [M] (stable argsort of the labels: rows of a cluster in original
+             order), labels_unq / count / start [L], mean / extent [L,3]
+    host:    h_labels (float32), h_count, h_start (int64), h_mean, h_extent (float32) -- the same numbers
+    mean     centroid (utils_check.py:34-35);  extent: sorted bbox extents (get_bbox_tensor,
+             utils_helper.py:166-170)
     """
 
     def __init__(self, points, labels):
+        _lib.require_gpu(points, labels)
         self.points = points[:, 0:3].contiguous().float()
         self.labels = labels
+        dev = labels.device
         self.order = torch.argsort(labels, stable=True)
-        sorted_labels = labels[self.order]
-        self.labels_unq, self.count = torch.unique_consecutive(sorted_labels, return_counts=True)
+        self.labels_unq, self.count = torch.unique_consecutive(labels[self.order], return_counts=True)
         self.start = torch.cumsum(self.count, 0) - self.count
         L = len(self.labels_unq)
-        self.mean = torch.empty((L, 3), dtype=torch.float32, device=labels.device)
-        self.extent = torch.empty((L, 3), dtype=torch.float32, device=labels.device)
-        _lib.require_gpu(self.points, labels)
+        self.mean = torch.empty((L, 3), dtype=torch.float32, device=dev)
+        self.extent = torch.empty((L, 3), dtype=torch.float32, device=dev)
         _lib.call("icpflow_cluster_stats", _lib.ptr(self.points), _lib.ptr(self.order), _lib.ptr(self.start),
-                  _lib.ptr(self.count), L, _lib.ptr(self.mean), _lib.ptr(self.extent), _lib.stream(labels.device))
+                  _lib.ptr(self.count), L, _lib.ptr(self.mean), _lib.ptr(self.extent), _lib.stream(dev))
+        # one device -> host transfer (float64 holds the float32 values and the counts exactly)
+        packed = torch.cat([self.labels_unq.double()[:, None], self.count.double()[:, None],
+                            self.start.double()[:, None], self.mean.double(), self.extent.double()], dim=1).cpu().numpy()
+        self.h_labels = packed[:, 0].astype(np.float32)
+        self.h_count = packed[:, 1].astype(np.int64)
+        self.h_start = packed[:, 2].astype(np.int64)
+        self.h_mean = packed[:, 3:6].astype(np.float32)
+        self.h_extent = packed[:, 6:9].astype(np.float32)
 
     def find(self, wanted):
-        """Index of each wanted label in labels_unq, or -1 where the cloud has no such cluster."""
+        """Index of each wanted label in labels_unq, or -1 where the cloud has no such cluster
+        (device tensors)."""
         pos = torch.searchsorted(self.labels_unq, wanted.to(self.labels_unq.dtype))
         pos = pos.clamp(max=len(self.labels_unq) - 1)
         hit = self.labels_unq[pos] == wanted.to(self.labels_unq.dtype)
         return torch.where(hit, pos, torch.full_like(pos, -1))
+
+    def find_host(self, wanted):
+        """The same on the host copy: numpy in, numpy out."""
+        w = np.asarray(wanted, dtype=np.float32)
+        pos = np.minimum(np.searchsorted(self.h_labels, w), len(self.h_labels) - 1)
+        return np.where(self.h_labels[pos] == w, pos, -1)
+
+
+def _sanity_mask(args, st, dt, pairs):
+    si, di = st.find_host(pairs[:, 0]), dt.find_host(pairs[:, 1])
+    ok = (si >= 0) & (di >= 0)
+    s, d = np.maximum(si, 0), np.maximum(di, 0)
+    ok &= np.minimum(st.h_count[s], dt.h_count[d]) >= args.min_cluster_size                   # :31
+    ok &= pairs.min(axis=1) >= 0                                                               # :32
+    dxy = (dt.h_mean[d] - st.h_mean[s])[:, 0:2]
+    ok &= ~(np.sqrt(dxy[:, 0] * dxy[:, 0] + dxy[:, 1] * dxy[:, 1]) > np.float32(args.translation_frame))   # :36
+    es, ed = st.h_extent[s], dt.h_extent[d]
+    ok &= ~(np.minimum(es, ed) < np.float32(args.thres_box) * np.maximum(es, ed)).any(axis=1)  # :41-43
+    return ok
 
 
 def sanity_check(args, src_table, dst_table, pairs):
     """utils_check.py:21-49 for all candidate `pairs` [K,2] at once -> the surviving rows, in order.
     A pair survives iff both clusters exist with >= min_cluster_size points, both labels are >= 0,
     the xy distance of the centroids is <= translation_frame and, axis by sorted axis, the smaller
-    bbox extent is >= thres_box times the larger one."""
+    bbox extent is >= thres_box times the larger one.  numpy in -> numpy out, tensor in -> tensor out."""
     if len(pairs) == 0:
         return pairs.reshape(0, 2)
-    si = src_table.find(pairs[:, 0])
-    di = dst_table.find(pairs[:, 1])
-    ok = (si >= 0) & (di >= 0)
-    s = si.clamp(min=0)
-    d = di.clamp(min=0)
-    ok &= torch.minimum(src_table.count[s], dst_table.count[d]) >= args.min_cluster_size   # :31
-    ok &= pairs.min(dim=1)[0] >= 0                                                           # :32
-    dxy = (dst_table.mean[d] - src_table.mean[s])[:, 0:2]
-    ok &= ~(torch.linalg.norm(dxy, dim=1) > args.translation_frame)                          # :36
-    es, ed = src_table.extent[s], dst_table.extent[d]
-    ok &= ~(torch.minimum(es, ed) < args.thres_box * torch.maximum(es, ed)).any(dim=1)       # :41-43
-    return pairs[ok]
+    ok = _sanity_mask(args, src_table, dst_table, _np(pairs, np.float32))
+    return pairs[torch.from_numpy(ok).to(pairs.device)] if isinstance(pairs, torch.Tensor) else pairs[ok]
 
 
 def check_transformation(args, translations, rotations, ious_min):
-    """utils_check.py:51-66, vectorised: -> bool [B] (True = keep the match)."""
-    ok = ~(torch.linalg.norm(translations, dim=1) > args.translation_frame)                  # :54
-    ok &= ~(ious_min < args.thres_iou)                                                       # :58
-    ok &= ~(rotations[:, 1:3].abs().max(dim=1)[0] > args.thres_rot * 90.0)                   # :62-64
+    """utils_check.py:51-66, vectorised: -> bool [B] (True = keep the match); numpy or tensors."""
+    if isinstance(translations, torch.Tensor):
+        ok = ~(torch.linalg.norm(translations, dim=1) > args.translation_frame)               # :54
+        ok &= ~(ious_min < args.thres_iou)                                                     # :58
+        ok &= ~(rotations[:, 1:3].abs().max(dim=1)[0] > args.thres_rot * 90.0)                 # :62-64
+        return ok
+    t = np.asarray(translations, np.float32)
+    ok = ~(np.sqrt((t * t).sum(axis=1, dtype=np.float32)) > np.float32(args.translation_frame))
+    ok &= ~(np.asarray(ious_min, np.float32) < np.float32(args.thres_iou))
+    ok &= ~(np.abs(np.asarray(rotations, np.float32)[:, 1:3]).max(axis=1) > np.float32(args.thres_rot * 90.0))
     return ok

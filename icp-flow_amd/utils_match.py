@@ -1,8 +1,9 @@
 """Drop-ins for the registration entry points of the reference's utils_match.py."""
+import numpy as np
 import torch
 
 from . import _lib
-from .utils_check import ClusterTable, check_transformation, sanity_check
+from .utils_check import ClusterTable, _sanity_mask, check_transformation, sanity_check
 from .utils_hist import bin_edges
 from .utils_icp import _icp_options
 
@@ -48,80 +49,88 @@ def match_eval(args, pcd1, pcd2, transformations):
 
 # --------------------------------------------------------------------------------------
 # the caller of the registration path: cluster association
+#
+# Device work per association stage: one gather of the candidate clusters into the padded batch,
+# hist_icp, match_eval.  Everything else -- candidate lists, sanity_check, the reject test, the S x D
+# matrices and the row arg-min -- involves a few hundred numbers and runs on the host copy of the
+# cluster tables (utils_check.ClusterTable) in numpy; a stage costs ONE device -> host transfer of the
+# [B, 29] results instead of the reference's per-pair scalar reads.
 # --------------------------------------------------------------------------------------
-def _padded_batch(args, table, labels_wanted):
-    """pad_segment (utils_helper.py:185-196) of every requested cluster, as one gather:
-    -> [B, max_points, 4] on the device.  Over-long clusters are subsampled with
-    torch.randperm on the host generator, one draw per cluster in request order -- the same
-    stream of draws the reference makes (utils_helper.py:198-201)."""
+def _gather_pair_batches(args, st, dt, si, di):
+    """pad_segment (utils_helper.py:185-196) of the candidate clusters (rows si / di of the tables), one
+    kernel per cloud: -> two [B, max_points, 4] device tensors.  Over-long clusters are subsampled with
+    torch.randperm on the host generator, src then dst, pair by pair -- the reference's stream of draws
+    (utils_match.py:84-89, utils_helper.py:198-201)."""
     N = int(args.max_points)
-    idx = table.find(labels_wanted)
-    assert bool((idx >= 0).all())
-    start = table.start[idx]
-    count = table.count[idx]
-    dev = table.points.device
-    slot = torch.arange(N, device=dev)[None, :]
-    rows = torch.where(slot < count[:, None], start[:, None] + slot, torch.full_like(slot, -1))
-    return rows, count
+    dev = st.points.device
+    B = len(si)
+    cs, cd = st.h_count[si], dt.h_count[di]
+    seg = np.empty((2, 3, B), dtype=np.int64)
+    seg[0, 0], seg[0, 1], seg[0, 2] = st.h_start[si], np.minimum(cs, N), -1
+    seg[1, 0], seg[1, 1], seg[1, 2] = dt.h_start[di], np.minimum(cd, N), -1
+    perms = []
+    for k in np.nonzero((cs > N) | (cd > N))[0]:            # random_choice, utils_helper.py:198-201
+        for which, c in ((0, cs), (1, cd)):
+            if c[k] > N:
+                seg[which, 2, k] = len(perms) * N
+                perms.append(torch.randperm(int(c[k]))[0:N].to(torch.int32))
+    d_seg = torch.from_numpy(seg).to(dev)
+    d_perm = torch.cat(perms).to(dev) if perms else None
+    segs = torch.empty((2, B, N, 4), dtype=torch.float32, device=dev)
+    for which, table in enumerate((st, dt)):
+        _lib.call("icpflow_gather_segments", _lib.ptr(table.points), _lib.ptr(table.order), _lib.ptr(d_seg[which]),
+                  _lib.ptr(d_perm), B, N, _lib.ptr(segs[which]), _lib.stream(dev))
+    return segs[0], segs[1]
+
+
+def _match_pairs_host(args, st, dt, pairs):
+    """utils_match.py:69-136 on numpy candidate `pairs` [K,2] -> (pairs [P,10], transforms [P,4,4]) numpy."""
+    si, di = st.find_host(pairs[:, 0]), dt.find_host(pairs[:, 1])
+    assert (si >= 0).all() and (di >= 0).all()
+    segs_src, segs_dst = _gather_pair_batches(args, st, dt, si, di)
+    T = hist_icp(args, segs_src, segs_dst)
+    ev = match_eval(args, segs_src, segs_dst, T)
+    B = len(pairs)
+    r = torch.cat([T.reshape(B, 16)] + [e.reshape(B, -1) for e in ev], dim=1).cpu().numpy()      # the one sync
+    T_h, errors, inliers, ratios, ious = r[:, 0:16].reshape(B, 4, 4), r[:, 16:18], r[:, 18:20], r[:, 20:22], r[:, 22:24]
+    keep = check_transformation(args, r[:, 24:27], r[:, 27:30], ious.min(axis=1))
+    S, D = len(st.h_labels), len(dt.h_labels)
+    if not keep.any():
+        return np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32)
+    m_err = np.full((S, D, 2), 1e8, np.float32)
+    m_idx = np.full((S, D), -1, np.int64)
+    ks = np.nonzero(keep)[0]
+    m_err[si[ks], di[ks]] = errors[ks]
+    m_idx[si[ks], di[ks]] = ks
+    err_min = m_err.min(axis=-1)
+    rows = np.arange(S)
+    best = np.argmin(err_min, axis=1)                                     # utils_helper.py:108-110
+    valid = err_min[rows, best] < np.float32(args.thres_error)            # utils_match.py:112
+    rows, best = rows[valid], best[valid]
+    k = m_idx[rows, best]
+    out = np.concatenate([st.h_labels[rows][:, None], dt.h_labels[best][:, None], errors[k], inliers[k], ratios[k],
+                          ious[k]], axis=1).astype(np.float32)
+    return out, T_h[k].astype(np.float32)
 
 
 def match_pairs(args, src_points, dst_points, src_labels, dst_labels, pairs, tables=None):
     """utils_match.py:69-136: register every candidate pair, reject implausible transforms
     (check_transformation), assign each source cluster its best destination cluster (row arg-min
-    of min(err_src, err_dst) below thres_error).  -> pairs [P,10], transformations [P,4,4]."""
+    of min(err_src, err_dst) below thres_error).  -> pairs [P,10], transformations [P,4,4] (device)."""
     assert len(pairs) > 0
     dev = src_points.device
     st, dt = tables if tables is not None else (ClusterTable(src_points, src_labels), ClusterTable(dst_points, dst_labels))
-    N = int(args.max_points)
-    rows_s, cnt_s = _padded_batch(args, st, pairs[:, 0])
-    rows_d, cnt_d = _padded_batch(args, dt, pairs[:, 1])
-    # random subsample of over-long clusters: src then dst, pair by pair (reference order)
-    over_s, over_d = (cnt_s > N).tolist(), (cnt_d > N).tolist()
-    if any(over_s) or any(over_d):
-        cs, cd = cnt_s.tolist(), cnt_d.tolist()
-        ss, sd = st.start[st.find(pairs[:, 0])].tolist(), dt.start[dt.find(pairs[:, 1])].tolist()
-        for k in range(len(pairs)):
-            if over_s[k]:
-                rows_s[k] = ss[k] + torch.randperm(cs[k])[0:N].to(dev)
-            if over_d[k]:
-                rows_d[k] = sd[k] + torch.randperm(cd[k])[0:N].to(dev)
-    B = len(pairs)
-    segs = torch.empty((2, B, N, 4), dtype=torch.float32, device=dev)
-    for which, (table, rows) in enumerate(((st, rows_s), (dt, rows_d))):
-        src_rows = torch.where(rows >= 0, table.order[rows.clamp(min=0)], rows).to(torch.int32).contiguous()
-        _lib.call("icpflow_gather_pad", _lib.ptr(table.points), _lib.ptr(src_rows), B, N, _lib.ptr(segs[which]),
-                  _lib.stream(dev))
-    segs_src, segs_dst = segs[0], segs[1]
-    transformations = hist_icp(args, segs_src, segs_dst)
-    errors, inliers, ratios, ious, translations, rotations = match_eval(args, segs_src, segs_dst, transformations)
-    keep = check_transformation(args, translations, rotations, ious.min(dim=1)[0])
-    S, D = len(st.labels_unq), len(dt.labels_unq)
-    m_err = torch.full((S, D, 2), 1e8, device=dev)
-    m_inl = torch.zeros((S, D, 2), device=dev)
-    m_rat = torch.zeros((S, D, 2), device=dev)
-    m_iou = torch.zeros((S, D, 2), device=dev)
-    m_T = torch.zeros((S, D, 4, 4), device=dev)
-    si, di = st.find(pairs[:, 0])[keep], dt.find(pairs[:, 1])[keep]
-    if len(si) == 0:
-        return torch.zeros((0, 10), device=dev), torch.zeros((0, 4, 4), device=dev)
-    m_err[si, di] = errors[keep]
-    m_inl[si, di] = inliers[keep]
-    m_rat[si, di] = ratios[keep]
-    m_iou[si, di] = ious[keep]
-    m_T[si, di] = transformations[keep]
-    err_min = m_err.min(-1)[0]
-    rows = torch.arange(S, device=dev)
-    best = torch.argmin(err_min, dim=1)                                   # utils_helper.py:108-110
-    valid = err_min[rows, best] < args.thres_error                       # utils_match.py:112
-    rows, best = rows[valid], best[valid]
-    out = torch.cat([st.labels_unq[rows][:, None], dt.labels_unq[best][:, None], m_err[rows, best],
-                     m_inl[rows, best], m_rat[rows, best], m_iou[rows, best]], dim=1)
-    return out, m_T[rows, best]
+    p = pairs.detach().cpu().numpy() if isinstance(pairs, torch.Tensor) else np.asarray(pairs)
+    out, T = _match_pairs_host(args, st, dt, p.astype(np.float32))
+    return torch.from_numpy(out).to(dev), torch.from_numpy(T).to(dev)
 
 
 def setdiff1d(t1, t2):
-    """utils_helper.py:172-183: labels of t1 not in t2 (t2 a subset of t1), sorted."""
-    t12, counts = torch.cat([torch.unique(t1), torch.unique(t2)]).unique(return_counts=True)
+    """utils_helper.py:172-183: labels of t1 not in t2 (t2 a subset of t1), sorted; numpy or tensors."""
+    if isinstance(t1, torch.Tensor):
+        t12, counts = torch.cat([torch.unique(t1), torch.unique(t2)]).unique(return_counts=True)
+        return t12[counts == 1]
+    t12, counts = np.unique(np.concatenate([np.unique(t1), np.unique(t2)]), return_counts=True)
     return t12[counts == 1]
 
 
@@ -132,24 +141,24 @@ def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
     _lib.require_gpu(src_points, dst_points, src_labels, dst_labels)
     dev = src_points.device
     st, dt = ClusterTable(src_points, src_labels), ClusterTable(dst_points, dst_labels)
-    src_unq, dst_unq = st.labels_unq.long(), dt.labels_unq.long()
-    labels_unq = torch.unique(torch.cat([src_unq, dst_unq]))
-    empty = (torch.zeros((0, 10), device=dev), torch.zeros((0, 4, 4), device=dev))
+    src_unq, dst_unq = st.h_labels.astype(np.int64), dt.h_labels.astype(np.int64)
+    labels_unq = np.unique(np.concatenate([src_unq, dst_unq]))
+    empty = (np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32))
 
-    pairs = torch.stack([labels_unq, labels_unq], dim=1)
-    pairs = pairs[pairs.min(dim=1)[0] >= 0]
-    pairs_true = sanity_check(args, st, dt, pairs)
-    pairs_sta, T_sta = match_pairs(args, src_points, dst_points, src_labels, dst_labels, pairs_true, (st, dt)) \
-        if len(pairs_true) > 0 else empty
+    pairs = np.stack([labels_unq, labels_unq], axis=1)
+    pairs = pairs[pairs.min(axis=1) >= 0].astype(np.float32)                                     # :30-31
+    pairs_true = pairs[_sanity_mask(args, st, dt, pairs)] if len(pairs) else pairs
+    pairs_sta, T_sta = _match_pairs_host(args, st, dt, pairs_true) if len(pairs_true) > 0 else empty
 
-    if len(pairs_sta) < len(labels_unq):
+    if len(pairs_sta) < len(labels_unq):                                                          # :42
         if len(pairs_sta) > 0:
-            src_unq = setdiff1d(src_unq, pairs_sta[:, 0].long())
-            dst_unq = setdiff1d(dst_unq, pairs_sta[:, 1].long())
-        pairs = torch.stack([src_unq.repeat_interleave(len(dst_unq)), dst_unq.repeat(len(src_unq))], dim=1)
-        pairs_true = sanity_check(args, st, dt, pairs)
+            src_unq = setdiff1d(src_unq, pairs_sta[:, 0].astype(np.int64))
+            dst_unq = setdiff1d(dst_unq, pairs_sta[:, 1].astype(np.int64))
+        pairs = np.stack([np.repeat(src_unq, len(dst_unq)), np.tile(dst_unq, len(src_unq))], axis=1).astype(np.float32)
+        pairs_true = pairs[_sanity_mask(args, st, dt, pairs)] if len(pairs) else pairs.reshape(0, 2)
     else:
         pairs_true = pairs[:0]
-    pairs_dyn, T_dyn = match_pairs(args, src_points, dst_points, src_labels, dst_labels, pairs_true, (st, dt)) \
-        if len(pairs_true) > 0 else empty
-    return torch.cat([pairs_sta, pairs_dyn], dim=0), torch.cat([T_sta, T_dyn], dim=0)
+    pairs_dyn, T_dyn = _match_pairs_host(args, st, dt, pairs_true) if len(pairs_true) > 0 else empty
+    out = np.concatenate([pairs_sta, pairs_dyn], axis=0)
+    T = np.concatenate([T_sta, T_dyn], axis=0)
+    return torch.from_numpy(out).to(dev), torch.from_numpy(T).to(dev)

@@ -212,6 +212,11 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
  * d_points ([M,3] float32) to copy (flag 1) or -1 for a pad row (1e8,1e8,1e8,0).  The caller
  * decides the rows (cluster order, random subsample of over-long clusters).
  *
+ * icpflow_gather_segments builds the same batch straight from the label-sorted row table d_order
+ * (int64 [M]): d_seg int64 [3,B] holds per pair the first row of its cluster in d_order, the number of
+ * rows to take (<= N) and -1 or an offset into d_perm (int32) when the host subsampled an over-long
+ * cluster (random_choice, utils_helper.py:198-201): row i = d_order[start + d_perm[off + i]].
+ *
  * icpflow_cluster_stats reduces what sanity_check reads per cluster (utils_check.py:34-43,
  * get_bbox_tensor utils_helper.py:166-170): d_order int64 [M] = rows of d_points ([M,3]) sorted by
  * label, cluster c = d_order[d_start[c] .. d_start[c]+d_count[c]) (int64 [L] each); outputs the
@@ -223,6 +228,8 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
  * ------------------------------------------------------------------------- */
 int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int N, float *d_out,
                        icpflow_stream_t stream);
+int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const int64_t *d_seg,
+                            const int32_t *d_perm, int B, int N, float *d_out, icpflow_stream_t stream);
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
                           const int64_t *d_count, int L, float *d_mean, float *d_extent,
                           icpflow_stream_t stream);
