@@ -428,6 +428,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
 // sum w |x R + T - y|^2 = (Sxx - W|mx'|^2) + (Syy - W|my'|^2) - 2 W sum_ij R_ij H_ij  (== :191,
 // evaluated without rounding X R + T to fp32 first), so one pass over the points suffices.
 constexpr int kMoments = 18;
+constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
 // ---------------------------------------------------------------------------------
 // Teams: several workgroups serve one pair (IcpTeam, kernels.hpp).  Per iteration every member
@@ -506,6 +507,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     __shared__ double Nsh[16];                // 4x4 scratch of the closed-form rotation
     __shared__ double ksh[17];                // centroids, second moments and H parked across the solve
     __shared__ float bcast[16];               // R (9), T (3), active flag, prev rmse, rmse
+    __shared__ float ring[kRing * 16];        // the last kRing states (R, T) and their rmse (cycle detection)
     __shared__ float combD[TS > 1 ? NWAVE * Q * kWave : 1];   // [wave][q][lane]
     __shared__ int combC[TS > 1 ? NWAVE * Q * kWave : 1];
 
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         for (int k = 0; k < 9; ++k) Rf[k] = (k % 4 == 0) ? 1.f : 0.f;  // :140
         Tf[0] = Tf[1] = Tf[2] = 0.f;
         if (tid == 0) { bcast[13] = 0.f; bcast[14] = 0.f; }
+        if (tid < 16) ring[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.f : 0.f) : 0.f;   // state 0 = identity
     } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rf[k] = st->R[k];
@@ -962,13 +965,59 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     __hip_atomic_fetch_add(&ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // specTally was loaded before the solve (its latency hides behind the Jacobi sweeps):
+                // specTally was loaded before the solve (its latency hides behind the rotation solve):
                 // it describes iteration specChk <= it - 1
                 if (specChk < it && rank == 0) {
                     if ((int)(specTally & 0xffffffffull) >= p.B) {   // everybody has been there
                         if ((specTally >> 32) == 0ull) active = 0;   // the batch stops at specChk
                         else ++specChk;
                     }
+                }
+                // Periodic trajectory: the next state is a function of (R, T) alone, so once the new
+                // state (number it + 1) equals, bit for bit, one of the last kRing states, everything
+                // that follows repeats with that period (1 = the usual convergence by exact repetition,
+                // 2 = a pair flipping between two inlier sets, which never satisfies the stop test and
+                // would hold the whole batch at the iteration cap).  The pair then writes its history
+                // and its tallies for ALL remaining iterations from the cycle and leaves: the outcome of
+                // the batch rule is unchanged, the iterations are not executed.
+                int period = 0;
+                {
+                    float cur = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) cur = (lane == k) ? Rf[k] : cur;
+                    cur = (lane == 9) ? Tf[0] : (lane == 10) ? Tf[1] : (lane == 11) ? Tf[2] : cur;
+                    const int newest = it + 1;   // number of the new state
+                    for (int k = 1; k <= kRing && k <= newest - itBegin; ++k) {
+                        const float old = ring[((newest - k) % kRing) * 16 + (lane & 15)];
+                        const bool same = lane >= 12 || __float_as_int(old) == __float_as_int(cur);
+                        if (__all(same)) { period = k; break; }
+                    }
+                    if (lane < 12) ring[(newest % kRing) * 16 + lane] = cur;
+                    if (lane == 12) ring[(newest % kRing) * 16 + 12] = rmse;
+                }
+                if (period > 0 && active) {
+                    if (rank == 0) {
+                        // remaining iterations k = it+1 .. itEnd-1, one per lane and round; row k repeats
+                        // row j(k) = it - period + 1 + ((k - it - 1) mod period)  (a row is stored in the
+                        // ring under the number of the state it produced, row + 1)
+                        for (int k0 = it + 1; k0 < itEnd; k0 += kWave) {
+                            const int k = k0 + lane;
+                            if (k < itEnd) {
+                                const int j = it - period + 1 + ((k - it - 1) % period);
+                                const int jp = (k - 1 == it) ? it : it - period + 1 + ((k - it - 2) % period);
+                                const float *rj = ring + ((j + 1) % kRing) * 16;
+                                const float rm = rj[12], rmPrev = ring[((jp + 1) % kRing) * 16 + 12];
+                                float *h = p.history + ((size_t)k * p.B + b) * kHistStride;
+                                for (int c = 0; c < 12; ++c) h[c] = rj[c];
+                                h[12] = rm;
+                                const float relk = (rmPrev - rm) / rmPrev;
+                                const bool convk = relk <= p.relThr;
+                                __hip_atomic_fetch_add(&ctrl->tally[k], 1ull | (convk ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+                    active = 0;
                 }
             } else if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
                 if (lane == 0 && !conv && rank == 0) atomicAdd(&ctrl->notconv[it], 1);
