@@ -46,7 +46,7 @@ SIGNATURES = {
     "icpflow_match_eval": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "icpflow_gather_pad": (_i, [_p, _p, _i, _i, _p, _p]),
     "icpflow_gather_segments": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
-    "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),
+    "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "icpflow_flow_rigid": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "icpflow_selftest_vote_quotient": (_i, [_p, _i, _f, _f, _p, _p, _p]),
     "icpflow_set_icp_search": (_i, [_i]),

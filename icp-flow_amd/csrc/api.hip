@@ -328,12 +328,14 @@ int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const
 }
 
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
-                          const int64_t *d_count, int L, float *d_mean, float *d_extent, icpflow_stream_t stream)
+                          const int64_t *d_count, const float *d_labels, int L, float *d_mean, float *d_extent,
+                          icpflow_stream_t stream)
 {
     if (!d_points || !d_order || !d_start || !d_count || !d_mean || !d_extent)
         return fail(ICPFLOW_E_ARG, "icpflow_cluster_stats: null pointer");
     if (L <= 0) return fail(ICPFLOW_E_ARG, "icpflow_cluster_stats: L must be positive (got %d)", L);
-    ICPFLOW_TRY(launch_cluster_stats(d_points, d_order, d_start, d_count, L, d_mean, d_extent, (hipStream_t)stream));
+    ICPFLOW_TRY(launch_cluster_stats(d_points, d_order, d_start, d_count, d_labels, L, d_mean, d_extent,
+                                     (hipStream_t)stream));
     return 0;
 }
 

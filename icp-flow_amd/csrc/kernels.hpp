@@ -145,7 +145,8 @@ hipError_t launch_gather_pad(const float *points, const int32_t *rows, int B, in
 hipError_t launch_gather_segments(const float *points, const int64_t *order, const int64_t *seg, const int32_t *perm,
                                   int B, int N, float *out, hipStream_t s);
 hipError_t launch_cluster_stats(const float *points, const int64_t *order, const int64_t *start,
-                                const int64_t *count, int L, float *mean, float *extent, hipStream_t s);
+                                const int64_t *count, const float *labels, int L, float *mean, float *extent,
+                                hipStream_t s);
 hipError_t launch_flow_rigid(const float *points, const float *labels, int N, const float *pairLabels,
                              const float *T, int P, const float *pose, float *M, float *flow, hipStream_t s);
 hipError_t launch_transform_points(const float *xyz, const float *pose, int B, int N, float *out,

@@ -308,12 +308,19 @@ hipError_t launch_gather_segments(const float *points, const int64_t *order, con
 constexpr int kStatsBlock = 256;
 __global__ __launch_bounds__(kStatsBlock) void cluster_stats_kernel(
     const float *__restrict__ points, const int64_t *__restrict__ order, const int64_t *__restrict__ start,
-    const int64_t *__restrict__ count, float *__restrict__ mean, float *__restrict__ extent)
+    const int64_t *__restrict__ count, const float *__restrict__ labels, float *__restrict__ mean,
+    float *__restrict__ extent)
 {
     __shared__ double ssum[kStatsBlock / kWave][3];
     __shared__ float smin[kStatsBlock / kWave][3], smax[kStatsBlock / kWave][3];
     const int c = blockIdx.x;
     const int64_t s0 = start[c], n = count[c];
+    // ground (-1e8) and noise (-1) are never candidates (utils_check.py:32) -- and by far the largest
+    // "clusters" of a frame: skip them
+    if (labels != nullptr && labels[c] < 0.0f) {
+        if (threadIdx.x < 3) { mean[(size_t)c * 3 + threadIdx.x] = 0.f; extent[(size_t)c * 3 + threadIdx.x] = 0.f; }
+        return;
+    }
     double sum[3] = {0.0, 0.0, 0.0};
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = threadIdx.x; i < n; i += kStatsBlock) {
@@ -359,10 +366,11 @@ __global__ __launch_bounds__(kStatsBlock) void cluster_stats_kernel(
 }
 
 hipError_t launch_cluster_stats(const float *points, const int64_t *order, const int64_t *start,
-                                const int64_t *count, int L, float *mean, float *extent, hipStream_t s)
+                                const int64_t *count, const float *labels, int L, float *mean, float *extent,
+                                hipStream_t s)
 {
-    hipLaunchKernelGGL(cluster_stats_kernel, dim3(L), dim3(kStatsBlock), 0, s, points, order, start, count, mean,
-                       extent);
+    hipLaunchKernelGGL(cluster_stats_kernel, dim3(L), dim3(kStatsBlock), 0, s, points, order, start, count, labels,
+                       mean, extent);
     return hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ class ClusterTable:
              utils_helper.py:166-170)
     """
 
-    def __init__(self, points, labels):
+    def __init__(self, points, labels, fetch=True):
         _lib.require_gpu(points, labels)
         self.points = points[:, 0:3].contiguous().float()
         self.labels = labels
@@ -36,18 +36,35 @@ class ClusterTable:
         self.labels_unq, self.count = torch.unique_consecutive(labels[self.order], return_counts=True)
         self.start = torch.cumsum(self.count, 0) - self.count
         L = len(self.labels_unq)
+        self.labels_unq = self.labels_unq.float().contiguous()
         self.mean = torch.empty((L, 3), dtype=torch.float32, device=dev)
         self.extent = torch.empty((L, 3), dtype=torch.float32, device=dev)
         _lib.call("icpflow_cluster_stats", _lib.ptr(self.points), _lib.ptr(self.order), _lib.ptr(self.start),
-                  _lib.ptr(self.count), L, _lib.ptr(self.mean), _lib.ptr(self.extent), _lib.stream(dev))
-        # one device -> host transfer (float64 holds the float32 values and the counts exactly)
-        packed = torch.cat([self.labels_unq.double()[:, None], self.count.double()[:, None],
-                            self.start.double()[:, None], self.mean.double(), self.extent.double()], dim=1).cpu().numpy()
+                  _lib.ptr(self.count), _lib.ptr(self.labels_unq), L, _lib.ptr(self.mean), _lib.ptr(self.extent),
+                  _lib.stream(dev))
+        self._packed = torch.cat([self.labels_unq.double()[:, None], self.count.double()[:, None],
+                                  self.start.double()[:, None], self.mean.double(), self.extent.double()], dim=1)
+        if fetch:
+            self.fetch()
+
+    def fetch(self, packed=None):
+        """Bring the table to the host: one device -> host transfer (float64 holds the float32 values
+        and the counts exactly).  `packed`: this table's rows of a transfer shared with other tables."""
+        packed = self._packed.cpu().numpy() if packed is None else packed
         self.h_labels = packed[:, 0].astype(np.float32)
         self.h_count = packed[:, 1].astype(np.int64)
         self.h_start = packed[:, 2].astype(np.int64)
         self.h_mean = packed[:, 3:6].astype(np.float32)
         self.h_extent = packed[:, 6:9].astype(np.float32)
+
+    @staticmethod
+    def pair(src_points, src_labels, dst_points, dst_labels):
+        """Both tables of a frame pair with ONE device -> host transfer."""
+        st, dt = ClusterTable(src_points, src_labels, fetch=False), ClusterTable(dst_points, dst_labels, fetch=False)
+        both = torch.cat([st._packed, dt._packed], dim=0).cpu().numpy()
+        st.fetch(both[: len(st._packed)])
+        dt.fetch(both[len(st._packed):])
+        return st, dt
 
     def find(self, wanted):
         """Index of each wanted label in labels_unq, or -1 where the cloud has no such cluster
@@ -69,7 +86,7 @@ def _sanity_mask(args, st, dt, pairs):
     ok = (si >= 0) & (di >= 0)
     s, d = np.maximum(si, 0), np.maximum(di, 0)
     ok &= np.minimum(st.h_count[s], dt.h_count[d]) >= args.min_cluster_size                   # :31
-    ok &= pairs.min(axis=1) >= 0                                                               # :32
+    ok &= np.minimum(pairs[:, 0], pairs[:, 1]) >= 0                                            # :32
     dxy = (dt.h_mean[d] - st.h_mean[s])[:, 0:2]
     ok &= ~(np.sqrt(dxy[:, 0] * dxy[:, 0] + dxy[:, 1] * dxy[:, 1]) > np.float32(args.translation_frame))   # :36
     es, ed = st.h_extent[s], dt.h_extent[d]

@@ -93,7 +93,7 @@ def _match_pairs_host(args, st, dt, pairs):
     B = len(pairs)
     r = torch.cat([T.reshape(B, 16)] + [e.reshape(B, -1) for e in ev], dim=1).cpu().numpy()      # the one sync
     T_h, errors, inliers, ratios, ious = r[:, 0:16].reshape(B, 4, 4), r[:, 16:18], r[:, 18:20], r[:, 20:22], r[:, 22:24]
-    keep = check_transformation(args, r[:, 24:27], r[:, 27:30], ious.min(axis=1))
+    keep = check_transformation(args, r[:, 24:27], r[:, 27:30], np.minimum(ious[:, 0], ious[:, 1]))
     S, D = len(st.h_labels), len(dt.h_labels)
     if not keep.any():
         return np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32)
@@ -102,7 +102,7 @@ def _match_pairs_host(args, st, dt, pairs):
     ks = np.nonzero(keep)[0]
     m_err[si[ks], di[ks]] = errors[ks]
     m_idx[si[ks], di[ks]] = ks
-    err_min = m_err.min(axis=-1)
+    err_min = np.minimum(m_err[:, :, 0], m_err[:, :, 1])
     rows = np.arange(S)
     best = np.argmin(err_min, axis=1)                                     # utils_helper.py:108-110
     valid = err_min[rows, best] < np.float32(args.thres_error)            # utils_match.py:112
@@ -119,7 +119,7 @@ def match_pairs(args, src_points, dst_points, src_labels, dst_labels, pairs, tab
     of min(err_src, err_dst) below thres_error).  -> pairs [P,10], transformations [P,4,4] (device)."""
     assert len(pairs) > 0
     dev = src_points.device
-    st, dt = tables if tables is not None else (ClusterTable(src_points, src_labels), ClusterTable(dst_points, dst_labels))
+    st, dt = tables if tables is not None else ClusterTable.pair(src_points, src_labels, dst_points, dst_labels)
     p = pairs.detach().cpu().numpy() if isinstance(pairs, torch.Tensor) else np.asarray(pairs)
     out, T = _match_pairs_host(args, st, dt, p.astype(np.float32))
     return torch.from_numpy(out).to(dev), torch.from_numpy(T).to(dev)
@@ -140,13 +140,13 @@ def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
     destination cluster.  -> pairs [P,10] (labels, errors, inliers, ratios, ious), transforms [P,4,4]."""
     _lib.require_gpu(src_points, dst_points, src_labels, dst_labels)
     dev = src_points.device
-    st, dt = ClusterTable(src_points, src_labels), ClusterTable(dst_points, dst_labels)
+    st, dt = ClusterTable.pair(src_points, src_labels, dst_points, dst_labels)
     src_unq, dst_unq = st.h_labels.astype(np.int64), dt.h_labels.astype(np.int64)
     labels_unq = np.unique(np.concatenate([src_unq, dst_unq]))
     empty = (np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32))
 
     pairs = np.stack([labels_unq, labels_unq], axis=1)
-    pairs = pairs[pairs.min(axis=1) >= 0].astype(np.float32)                                     # :30-31
+    pairs = pairs[np.minimum(pairs[:, 0], pairs[:, 1]) >= 0].astype(np.float32)                  # :30-31
     pairs_true = pairs[_sanity_mask(args, st, dt, pairs)] if len(pairs) else pairs
     pairs_sta, T_sta = _match_pairs_host(args, st, dt, pairs_true) if len(pairs_true) > 0 else empty
 

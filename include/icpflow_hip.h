@@ -220,7 +220,9 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
  * icpflow_cluster_stats reduces what sanity_check reads per cluster (utils_check.py:34-43,
  * get_bbox_tensor utils_helper.py:166-170): d_order int64 [M] = rows of d_points ([M,3]) sorted by
  * label, cluster c = d_order[d_start[c] .. d_start[c]+d_count[c]) (int64 [L] each); outputs the
- * centroid d_mean [L,3] and the ascending-sorted bbox extents d_extent [L,3] (float32).
+ * centroid d_mean [L,3] and the ascending-sorted bbox extents d_extent [L,3] (float32).  d_labels
+ * (float32 [L], optional): clusters with a negative label (ground, noise -- never candidates,
+ * utils_check.py:32) are skipped and report zeros.
  *
  * icpflow_flow_rigid replaces flow_estimation_torch (utils_flow.py:57-69): every point whose
  * float label equals d_pair_labels[p] moves with T[p]*pose, every other point with pose alone;
@@ -231,8 +233,8 @@ int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int 
 int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const int64_t *d_seg,
                             const int32_t *d_perm, int B, int N, float *d_out, icpflow_stream_t stream);
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
-                          const int64_t *d_count, int L, float *d_mean, float *d_extent,
-                          icpflow_stream_t stream);
+                          const int64_t *d_count, const float *d_labels, int L, float *d_mean,
+                          float *d_extent, icpflow_stream_t stream);
 int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
                        const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws,
                        size_t ws_bytes, icpflow_stream_t stream);

@@ -460,7 +460,10 @@ def test_cluster_stats_kernel_vs_torch():
     assert np.array_equal(t.labels_unq.cpu().numpy(), uniq)
     for k, l in enumerate(uniq):
         sel = pts[lab == l]
-        assert int(t.count[k]) == len(sel)
+        assert int(t.count[k]) == len(sel) == int(t.h_count[k])
+        if l < 0:      # ground / noise are never candidates (utils_check.py:32): statistics skipped
+            assert not t.mean[k].any() and not t.extent[k].any()
+            continue
         np.testing.assert_allclose(t.mean[k].cpu().numpy(), sel.astype(np.float64).mean(0), rtol=0, atol=2e-6)
         want = np.sort(np.abs(sel.max(0) - sel.min(0)))                 # get_bbox_tensor, utils_helper.py:166-170
         assert np.array_equal(t.extent[k].cpu().numpy(), want)
