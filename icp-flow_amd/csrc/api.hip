@@ -37,6 +37,7 @@ int hipfail(hipError_t e, const char *what)
 // ICP correspondence search: 0 = auto, 1 = all-pairs LDS scan, 2 = exact hashed grid,
 // 3 = sorted sweep (icp.hip)
 int g_icp_search = 0;
+int g_check_sweep = 1;   // developer knob (ICPFLOW_CHECK_SWEEP=0 selects the all-pairs roll-back check)
 int g_score_sweep = 1;   // developer knob (ICPFLOW_SCORE_SWEEP=0 selects the all-pairs scoring scan)
 int g_hist_sorted = 1;   // developer knob (ICPFLOW_HIST_SORTED=0 selects the all-pairs vote)
 
@@ -148,13 +149,21 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
                        const float *init, int B, int N, double thres, int maxIter, double relThr,
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, hipStream_t s)
 {
+    const GridScratch *search = search_scratch(w, N);
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, search_scratch(w, N), w.history, &w.team, s));
+                           w.state, w.ctrl, search, w.history, &w.team, s));
     if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
-    ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
-    ICPFLOW_TRY(launch_select(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, swap, init, w.M, B,
-                              invertSwapped, Tout, s));
+    // roll-back check: sweeps over the sorted clouds the ICP left behind, or the all-pairs scan
+    if (search != nullptr && search->mode == 3 && g_check_sweep) {
+        ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
+        ICPFLOW_TRY(launch_select(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, init, w.M, B, invertSwapped,
+                                  Tout, s));
+    } else {
+        ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
+        ICPFLOW_TRY(launch_select(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, swap, init, w.M, B,
+                                  invertSwapped, Tout, s));
+    }
     return 0;
 }
 
@@ -197,6 +206,8 @@ int icpflow_version(void)
         once = true;
         const char *e = getenv("ICPFLOW_HIST_SORTED");
         if (e && e[0] == '0') g_hist_sorted = 0;
+        e = getenv("ICPFLOW_CHECK_SWEEP");
+        if (e && e[0] == '0') g_check_sweep = 0;
         e = getenv("ICPFLOW_SCORE_SWEEP");
         if (e && e[0] == '0') g_score_sweep = 0;
         e = getenv("ICPFLOW_ICP_TEAMS");

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
 // staged tile, read at one LDS address per step.  Every (i, j) that can pass the exact box test
 // is still visited and the same test decides the vote: bins are bit-identical.
 // ---------------------------------------------------------------------------------
-constexpr int kZsortBlock = 512;
+constexpr int kZsortBlock = 1024;
 
 // grid (B, 2): y = 0 sorts cloud P, y = 1 cloud Q; valid rows (flag > 0) first, ascending z
 __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__restrict__ P,

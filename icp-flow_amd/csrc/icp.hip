@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kGridBlock) void grid_build_kernel(
 // the gate radius from every query of the wave, so gate decisions and gated neighbours are the
 // ones of the all-pairs search; equal-distance ties are resolved to the lowest ORIGINAL index.
 // ---------------------------------------------------------------------------------
-constexpr int kSortBlock = 512;
+constexpr int kSortBlock = 1024;
 int g_icp_teams = 1;         // developer knob (ICPFLOW_ICP_TEAMS=0: always one workgroup per pair)
 int g_icp_speculative = 1;   // developer knob (api.hip: ICPFLOW_ICP_SPECULATIVE=0 forces one launch per iteration)
 

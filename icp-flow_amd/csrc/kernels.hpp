@@ -77,6 +77,9 @@ hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, in
 struct GridScratch;
 int scan_qblocks(int maxRows, int batch);
 int sweep_qblocks(int maxRows);
+hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
+                              const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
+                              const float *poseFinal, double *partial, hipStream_t s);
 hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
                               int B, int N, const float *cand, double *partial, hipStream_t s);
 hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,

@@ -211,20 +211,29 @@ int scan_qblocks(int maxRows, int batch)
 // One query per lane, targets streamed through scalar loads, no LDS, no barriers in the scan.
 // ---------------------------------------------------------------------------------
 struct SweepParams {
-    const float *Asoa;      // [B,3,NP16] src role sorted along axis[b], +inf padded
+    const float *Asoa;      // [B,3,NP16] src role sorted along axis[b], +inf padded (SWEEP_SCORE)
     const float *Csoa;      // [B,3,NP16] dst role
     const int32_t *lenA, *lenC;
     const uint8_t *swap;
     const int32_t *axis;
-    const float *cand;      // [B,6,3]
+    const float *cand;      // SWEEP_SCORE: [B,6,3]
+    // SWEEP_CHECK: the sorted moving cloud of the ICP (float4: point, original row in w) and the clouds
+    // themselves; rawSorted != 0: the sorted points are the raw cloud, else they carry the ICP's pre-pose
+    // and the raw point is fetched through w
+    const float4 *sortX;
+    const float *X, *Y;     // [B,N,4] as passed to the registration (src, dst)
+    const float *poseA, *poseB;   // [B,4,4] init pose and composed final pose
+    int rawSorted;
     int N, NP16, njobs, qblocks;
     float r0;
     double *partial;        // [njobs, qblocks, kPartial]
 };
 
 constexpr int kSweepBlock = 256;
+enum SweepMode : int { SWEEP_SCORE = 0, SWEEP_CHECK = 1 };
 
-__global__ __launch_bounds__(kSweepBlock) void sweep_score_kernel(SweepParams p)
+template <int MODE>
+__global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
 {
     __shared__ double red[kSweepBlock / kWave];
     extern __shared__ __attribute__((aligned(16))) float keyLds[];   // the targets' sort keys (window searches)
@@ -232,8 +241,9 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_score_kernel(SweepParams p)
     const int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);   // XCD-aware: the 8 XCDs take 8 jobs
     const int qb = (lin >> 3) % p.qblocks;
     if (job >= p.njobs) return;
-    const int b = job / 12, sub = job % 12, k = sub >> 1;
-    const bool backward = sub & 1;
+    const int b = (MODE == SWEEP_SCORE) ? job / 12 : job >> 1;
+    const int sub = (MODE == SWEEP_SCORE) ? job % 12 : (job & 1);
+    const bool backward = (MODE == SWEEP_SCORE) && (sub & 1);
     const bool sw = p.swap != nullptr && p.swap[b] != 0;
     const int na = (sw ? p.lenC : p.lenA)[b], nc = (sw ? p.lenA : p.lenC)[b];
     const float *as = p.Asoa + (size_t)b * 3 * p.NP16, *cs = p.Csoa + (size_t)b * 3 * p.NP16;
@@ -245,16 +255,32 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_score_kernel(SweepParams p)
         if (threadIdx.x < kPartial) out[threadIdx.x] = 0.0;
         return;
     }
-    const float *t3 = p.cand + ((size_t)b * 6 + k) * 3;
-    const float tx = t3[0], ty = t3[1], tz = t3[2];
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (MODE == SWEEP_SCORE) {
+        const float *t3 = p.cand + ((size_t)b * 6 + (sub >> 1)) * 3;
+        tx = t3[0]; ty = t3[1]; tz = t3[2];
+    }
     const int axis = p.axis[b];
     const float tu = axis == 0 ? tx : (axis == 1 ? ty : tz);
     const int i = qb * kSweepBlock + wave * kWave + lane;
     const bool live = i < nq;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (live) {
-        qx = qs[i]; qy = qs[p.NP16 + i]; qz = qs[2 * p.NP16 + i];
-        if (!backward) { qx += tx; qy += ty; qz += tz; }     // the moved source cloud, as the reference forms it
+        if (MODE == SWEEP_SCORE) {
+            qx = qs[i]; qy = qs[p.NP16 + i]; qz = qs[2 * p.NP16 + i];
+            if (!backward) { qx += tx; qy += ty; qz += tz; }     // the moved source cloud, as the reference forms it
+        } else {
+            // src role point i of the ICP's sorted order, moved by the init (sub 0) or final (sub 1) pose
+            // exactly as transform_points_batch does (utils_icp.py:21,27-33)
+            const float4 s4 = p.sortX[(size_t)b * p.N + i];
+            float rx = s4.x, ry = s4.y, rz = s4.z;
+            if (!p.rawSorted) {
+                const float4 r4 = reinterpret_cast<const float4 *>(sw ? p.Y : p.X)[(size_t)b * p.N + __float_as_int(s4.w)];
+                rx = r4.x; ry = r4.y; rz = r4.z;
+            }
+            const Affine pose = affine_from_pose((sub == 0 ? p.poseA : p.poseB) + (size_t)b * 16);
+            affine_apply(pose, rx, ry, rz, qx, qy, qz);
+        }
     }
     // position of the query along u in the frame of the (unshifted) target keys
     float cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
@@ -311,17 +337,39 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_score_kernel(SweepParams p)
 
 int sweep_qblocks(int maxRows) { return (maxRows + kSweepBlock - 1) / kSweepBlock; }
 
+template <int MODE>
+static hipError_t launch_sweep(SweepParams p, hipStream_t s)
+{
+    p.NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
+    p.qblocks = sweep_qblocks(p.N);
+    p.r0 = 0.15f;
+    const int groups = (p.njobs + 7) / 8;
+    const size_t lds = (size_t)p.NP16 * sizeof(float);   // <= 64 KiB at N = 16384
+    hipLaunchKernelGGL(sweep_scan_kernel<MODE>, dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
                               int B, int N, const float *cand, double *partial, hipStream_t s)
 {
     SweepParams p{};
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
-    p.axis = grid->axis; p.cand = cand; p.N = N; p.NP16 = (N + kChunk - 1) / kChunk * kChunk;
-    p.njobs = B * 12; p.qblocks = sweep_qblocks(N); p.r0 = 0.15f; p.partial = partial;
-    const int groups = (p.njobs + 7) / 8;
-    const size_t lds = (size_t)p.NP16 * sizeof(float);   // <= 64 KiB at N = 16384
-    hipLaunchKernelGGL(sweep_score_kernel, dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
-    return hipGetLastError();
+    p.axis = grid->axis; p.cand = cand; p.N = N; p.njobs = B * 12; p.partial = partial;
+    return launch_sweep<SWEEP_SCORE>(p, s);
+}
+
+// roll-back check (utils_icp.py:27-33): mean NN distance of the src role under the init pose and under
+// the composed final pose, as sweeps over the sorted clouds the ICP left in `grid`
+hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
+                              const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
+                              const float *poseFinal, double *partial, hipStream_t s)
+{
+    SweepParams p{};
+    p.Asoa = grid->sortYsoa;   // unused in this mode (valid pointer for the address arithmetic)
+    p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.axis = grid->axis;
+    p.sortX = (const float4 *)grid->sortX; p.X = X; p.Y = Y; p.poseA = poseInit; p.poseB = poseFinal;
+    p.rawSorted = grid->presorted; p.N = N; p.njobs = B * 2; p.partial = partial;
+    return launch_sweep<SWEEP_CHECK>(p, s);
 }
 
 hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,

@@ -305,7 +305,7 @@ hipError_t launch_gather_segments(const float *points, const int64_t *order, con
 // ascending-sorted axis-aligned bbox extents (get_bbox_tensor, utils_helper.py:166-170) of every
 // cluster of a labelled cloud.  order = rows sorted by label; cluster c owns order[start[c] ..
 // start[c]+count[c]).  One workgroup per cluster, sums in fp64 (order independent to fp32 rounding).
-constexpr int kStatsBlock = 256;
+constexpr int kStatsBlock = 1024;
 __global__ __launch_bounds__(kStatsBlock) void cluster_stats_kernel(
     const float *__restrict__ points, const int64_t *__restrict__ order, const int64_t *__restrict__ start,
     const int64_t *__restrict__ count, const float *__restrict__ labels, float *__restrict__ mean,
