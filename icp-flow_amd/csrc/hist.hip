@@ -93,6 +93,7 @@ hipError_t launch_vote_quotient_probe(const float *a, int n, float mn, float mx,
 
 constexpr int kVoteBlock = 256;  // threads; one X row per thread per slice
 constexpr int kVoteTile = 1024;  // Y points staged in LDS per step (16 KiB)
+constexpr int kVoteSpan = 2;     // sorted vote: Y tiles per workgroup
 
 // bins_u32: [B, L] zero-initialised.  swap (optional, per pair): vote with X and Y
 // exchanged -- used by the fused registration path where "src" is the smaller cloud.
@@ -233,8 +234,12 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     const float4 *xb = (sw ? Ys : Xs) + (size_t)b * N;
     const float4 *yb = (sw ? Xs : Ys) + (size_t)b * N;
     const int nx = (sw ? nYv : nXv)[b], ny = (sw ? nXv : nYv)[b];
-    const int row0 = blockIdx.x * kVoteBlock;
-    if (row0 >= nx) return;  // sorted: valid rows first
+    // blockIdx.x = row block * tsplit + share: on long clouds the Y tiles are dealt to `tsplit` workgroups
+    // per row block (kVoteSpan tiles each), so that one huge pair does not pace the launch
+    const int tsplit = (N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile);
+    const int row0 = (blockIdx.x / tsplit) * kVoteBlock;
+    const int jBegin = (blockIdx.x % tsplit) * kVoteSpan * kVoteTile;
+    if (row0 >= nx || jBegin >= ny) return;  // sorted: valid rows first
     const float min_x = ex[0], max_x = ex[len_x - 1];
     const float min_y = ey[0], max_y = ey[len_y - 1];
     const float min_z = ez[0], max_z = ez[len_z - 1];
@@ -259,8 +264,9 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     }
     const float slack = 1e-3f * (fabsf(max_z) + fabsf(min_z)) + 1e-5f * (fabsf(zlo) + fabsf(zhi)) + 1e-6f;
     const float wlo = zlo - max_z - slack, whi = zhi - min_z + slack;
-    for (int j0 = 0; j0 < ny; j0 += kVoteTile) {
-        const int tn = min(kVoteTile, ny - j0);
+    const int jEnd = min(ny, jBegin + kVoteSpan * kVoteTile);
+    for (int j0 = jBegin; j0 < jEnd; j0 += kVoteTile) {
+        const int tn = min(kVoteTile, jEnd - j0);
         __syncthreads();  // previous tile fully consumed (and lhist zeroed)
         for (int k = threadIdx.x; k < tn; k += kVoteBlock) tile[k] = yb[j0 + k];
         __syncthreads();
@@ -269,16 +275,25 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
         const int r0 = sorted_count_below<false>(zkey, 4, tn, wlo, lane);
         const int r1 = sorted_count_below<true>(zkey, 4, tn, whi, lane);
         if (!xvalid) continue;
-        for (int k = r0; k < r1; ++k) {
-            const float4 t = tile[k];  // same address in every lane: LDS broadcast
-            const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
-            if (vx >= min_x && vx < max_x && vy >= min_y && vy < max_y && vz >= min_z && vz < max_z) {
-                const int px = (int)floorf(axis_quot(vx - min_x, dqx) * flx);
-                const int py = (int)floorf(axis_quot(vy - min_y, dqy) * fly);
-                const int pz = (int)floorf(axis_quot(vz - min_z, dqz) * flz);
-                const int bin = (px * len_y + py) * len_z + pz;
-                if (useLds) atomicAdd(&lhist[bin], 1u);
-                else atomicAdd(&gb[bin], 1u);
+        // four targets per round, all four LDS reads issued before the first test: with one workgroup
+        // per CU (a frame-level batch) nothing else hides the LDS latency of a one-target loop
+        for (int k = r0; k < r1; k += 4) {
+            float4 t4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t4[u] = tile[min(k + u, r1 - 1)];  // same address in every lane: broadcast
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k + u >= r1) break;   // wave-uniform
+                const float4 t = t4[u];
+                const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
+                if (vx >= min_x && vx < max_x && vy >= min_y && vy < max_y && vz >= min_z && vz < max_z) {
+                    const int px = (int)floorf(axis_quot(vx - min_x, dqx) * flx);
+                    const int py = (int)floorf(axis_quot(vy - min_y, dqy) * fly);
+                    const int pz = (int)floorf(axis_quot(vz - min_z, dqz) * flz);
+                    const int bin = (px * len_y + py) * len_z + pz;
+                    if (useLds) atomicAdd(&lhist[bin], 1u);
+                    else atomicAdd(&gb[bin], 1u);
+                }
             }
         }
     }
@@ -314,7 +329,8 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
     const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
     const int useLds = lds_hist <= 64 * 1024;
-    dim3 grid((N + kVoteBlock - 1) / kVoteBlock, B);
+    const int tsplit = (N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile);
+    dim3 grid(((N + kVoteBlock - 1) / kVoteBlock) * tsplit, B);
     hipLaunchKernelGGL(hist_vote_sorted_kernel, grid, dim3(kVoteBlock), useLds ? lds_hist : tile_bytes, s,
                        (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
                        ez, swap, useLds, bins_u32);

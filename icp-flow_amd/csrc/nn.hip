@@ -230,6 +230,7 @@ struct SweepParams {
 };
 
 constexpr int kSweepBlock = 256;
+constexpr int kSweepStage = 4096;   // sort keys staged in LDS up to this many targets
 enum SweepMode : int { SWEEP_SCORE = 0, SWEEP_CHECK = 1 };
 
 template <int MODE>
@@ -289,13 +290,17 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     float best = kInf;
     const float *tkx = ts, *tky = ts + p.NP16, *tkz = ts + 2 * p.NP16;
     const int np16 = (nt + kChunk - 1) / kChunk * kChunk;
-    {
-        const float *gkey = axis == 0 ? tkx : (axis == 1 ? tky : tkz);
+    // window searches: keys staged in LDS while that is cheap (<= 16 KiB per workgroup), read from
+    // global memory (L2) on long clouds, where staging the whole key array would cost more than the
+    // two or three dependent probes of a search
+    const float *gkey = axis == 0 ? tkx : (axis == 1 ? tky : tkz);
+    const bool stage = np16 <= kSweepStage;
+    if (stage) {
         for (int j = threadIdx.x; j < np16; j += kSweepBlock) keyLds[j] = gkey[j];
         __syncthreads();
     }
     if (lo <= hi && nt > 0) {   // wave-uniform
-        const float *key = keyLds;
+        const float *key = stage ? keyLds : gkey;
         // slack: rounding of src + t (an ulp of the coordinates) and of the window arithmetic
         const float slack = 1e-4f + 2e-6f * (fabsf(lo) + fabsf(hi) + fabsf(tu));
         int j0, j1;
@@ -344,7 +349,7 @@ static hipError_t launch_sweep(SweepParams p, hipStream_t s)
     p.qblocks = sweep_qblocks(p.N);
     p.r0 = 0.15f;
     const int groups = (p.njobs + 7) / 8;
-    const size_t lds = (size_t)p.NP16 * sizeof(float);   // <= 64 KiB at N = 16384
+    const size_t lds = (size_t)(p.NP16 < kSweepStage ? p.NP16 : kSweepStage) * sizeof(float);
     hipLaunchKernelGGL(sweep_scan_kernel<MODE>, dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
     return hipGetLastError();
 }
