@@ -1342,7 +1342,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
             cus = 1;
     }
     const bool speculative = stopMode == ICPFLOW_STOP_REFERENCE_ && history != nullptr && g_icp_speculative &&
-                             maxIter > 1 && maxIter <= kHistIters && B <= cus;
+                             maxIter > 1 && maxIter <= kHistIters;
     // Teams: with at most half of the CUs taken by one workgroup per pair, the spare CUs join the pairs
     // whose moving cloud needs several passes (real clusters, N > 1024).  Needs every workgroup of the
     // launch resident at once (members wait for each other): single-launch modes only.
@@ -1353,12 +1353,13 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, p.team);
     }
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {
-        // Batch-global stop rule.  While all workgroups of the batch can be resident at once
-        // (B <= CUs: one 1024-thread, <=128-VGPR workgroup per CU) ONE launch runs every pair through
-        // all iterations speculatively, keeping a per-iteration history; pairs leave as soon as
-        // they observe that some iteration satisfied the batch rule, and the epilogue picks every
-        // pair's state at exactly the reference's stopping iteration.  Larger batches (late
-        // workgroups would hold the early ones at the iteration cap) use one launch per iteration.
+        // Batch-global stop rule.  ONE launch runs every pair through all iterations speculatively,
+        // keeping a per-iteration history; a pair leaves as soon as its trajectory is periodic (it then
+        // publishes the rest of its history) or it observes that some iteration satisfied the batch
+        // rule, and the epilogue picks every pair's state at exactly the reference's stopping iteration.
+        // Nobody waits, so batches larger than the GPU are fine: late workgroups start as early pairs
+        // leave (a pair that is neither periodic nor done by then iterates to the cap, <= kHistIters).
+        // Beyond kHistIters iterations: one launch per iteration.
         if (speculative) {
             p.history = history;
             launch_icp_iters(p, B, 0, maxIter, s);

@@ -338,6 +338,30 @@ def test_icp_multi_group_path_vs_oracle():
     np.testing.assert_allclose(got.Xt.cpu().numpy(), ref.Xt.numpy(), atol=TOL_M, rtol=0)
 
 
+def test_icp_batch_larger_than_the_gpu_vs_oracle():
+    """More pairs than compute units: the single-launch form of the batch-global stop rule has to work
+    while late workgroups only start when early pairs have left (periodic pairs publish the rest of their
+    history and go; nobody waits).  Same stopping iteration and poses as the oracle, and as the
+    one-launch-per-iteration form."""
+    B, N = 600, 128
+    S, D, Tt = synthetic.make_batch(B, N, seed=31, ragged=True, n_min=40)
+    src, dst = C(S), C(D)
+    for i in range(B):
+        Ti = C(Tt[i])
+        src[i, :, 0:3] = torch.where(src[i, :, 3:4] > 0, src[i, :, 0:3] @ Ti[:3, :3].T + Ti[:3, 3] + torch.tensor([0.02, -0.01, 0.01]),
+                                     src[i, :, 0:3])
+    hp = rp.iterative_closest_point(src, dst, kabsch_dtype=torch.float64, max_iterations=60)
+    got = utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), max_iterations=60)
+    assert got.converged.iterations == hp.iterations
+    inl = (torch.cdist(hp.Xt, dst[:, :, 0:3]).min(dim=2)[0] <= 0.1) & (src[:, :, 3] > 0)
+    ok = (inl.sum(dim=1) >= 6).numpy()          # rank-deficient pairs are not pinned (DESIGN 4.6)
+    assert ok.sum() > 0.9 * B
+    np.testing.assert_allclose(got.RTs.R.cpu().numpy()[ok], hp.R.numpy()[ok], atol=TOL_R_HP * 4, rtol=0)
+    valid = (src[:, :, 3] > 0).numpy()[ok]
+    diff = np.abs(got.Xt.cpu().numpy()[ok] - hp.Xt.numpy()[ok]).max(-1)
+    assert np.where(valid, diff, 0).max() <= TOL_M
+
+
 # ------------------------------------------------------------------ a-9 / a-11 / a-12
 def test_apply_icp_from_reference_init_poses():
     g = load_golden("g6_hist_icp")
