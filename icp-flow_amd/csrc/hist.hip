@@ -154,9 +154,9 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
             const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
             if (vx >= box.min_x && vx < box.max_x && vy >= box.min_y && vy < box.max_y &&
                 vz >= box.min_z && vz < box.max_z) {
-                const int px = (int)floorf(axis_quot(vx - box.min_x, dqx) * flx);
-                const int py = (int)floorf(axis_quot(vy - box.min_y, dqy) * fly);
-                const int pz = (int)floorf(axis_quot(vz - box.min_z, dqz) * flz);
+                const int px = (int)(axis_quot(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor (:52-57)
+                const int py = (int)(axis_quot(vy - box.min_y, dqy) * fly);
+                const int pz = (int)(axis_quot(vz - box.min_z, dqz) * flz);
                 const int bin = (px * box.len_y + py) * box.len_z + pz;
                 if (LDS_HIST) atomicAdd(&lhist[bin], 1u);
                 else atomicAdd(&gb[bin], 1u);
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
                 const float4 t = t4[u];
                 const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
                 if (vx >= min_x && vx < max_x && vy >= min_y && vy < max_y && vz >= min_z && vz < max_z) {
-                    const int px = (int)floorf(axis_quot(vx - min_x, dqx) * flx);
-                    const int py = (int)floorf(axis_quot(vy - min_y, dqy) * fly);
-                    const int pz = (int)floorf(axis_quot(vz - min_z, dqz) * flz);
+                    const int px = (int)(axis_quot(vx - min_x, dqx) * flx);   // >= 0: truncation == floor
+                    const int py = (int)(axis_quot(vy - min_y, dqy) * fly);
+                    const int pz = (int)(axis_quot(vz - min_z, dqz) * flz);
                     const int bin = (px * len_y + py) * len_z + pz;
                     if (useLds) atomicAdd(&lhist[bin], 1u);
                     else atomicAdd(&gb[bin], 1u);

@@ -121,7 +121,7 @@ __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, int lan
         const double v = fabs(readlane_f64(C, 5 * d));
         if (v > big) { big = v; k = d; }
     }
-    if (!(big > 1e-9 * frob2 * sqrt(frob2))) return false;   // (nearly) double top eigenvalue
+    if (!(big * big > 1e-18 * frob2 * frob2 * frob2)) return false;   // (nearly) double top eigenvalue
     k = __builtin_amdgcn_readfirstlane(k);
     double q0 = readlane_f64(C, 4 * k + 0), q1 = readlane_f64(C, 4 * k + 1), q2 = readlane_f64(C, 4 * k + 2),
            q3 = readlane_f64(C, 4 * k + 3);
