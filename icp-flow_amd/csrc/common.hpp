@@ -253,6 +253,28 @@ __device__ __forceinline__ int sorted_refine(const float *__restrict__ key, int 
     return base;
 }
 
+// The same count with a hint (the answer of a nearby earlier query, e.g. the previous ICP iteration):
+// ONE probe of the 64 keys around the hint settles it whenever the answer moved by less than 32
+// positions; otherwise the full search runs.
+template <bool INCLUSIVE>
+__device__ __forceinline__ int sorted_refine_hint(const float *__restrict__ key, int n, float v, int lane, int hint)
+{
+    const int base = max(0, min(hint, n) - kWave / 2);
+    const int s = base + lane;
+    const float k = s < n ? key[s] : kInf;
+    const int cnt = __popcll(__ballot(INCLUSIVE ? (k <= v) : (k < v)));
+    // cnt in 1..63: key[base] compares true (so does everything before it), key[base + 63] does not
+    if ((cnt > 0 || base == 0) && cnt < kWave) return base + cnt;
+    return sorted_refine<INCLUSIVE>(key, n, v, lane, 0, n);
+}
+
+__device__ __forceinline__ void sorted_window_hint(const float *__restrict__ key, int n, float vlo, float vhi, int lane,
+                                                   int &jlo, int &jhi)
+{
+    jlo = sorted_refine_hint<false>(key, n, vlo, lane, jlo);
+    jhi = sorted_refine_hint<true>(key, n, vhi, lane, jhi);
+}
+
 __device__ __forceinline__ void sorted_window(const float *__restrict__ key, int n, float vlo, float vhi, int lane,
                                               int &jlo, int &jhi)
 {

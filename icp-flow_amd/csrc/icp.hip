@@ -574,6 +574,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     const int ngroups = (xc.n + per - 1) / per;
 
     int specChk = 0;  // speculative mode: first iteration not yet known to be complete-and-unconverged
+    int winLo = -1, winHi = -1;   // sorted sweep: this wave's target window of the previous iteration
     for (int it = itBegin; it < itEnd; ++it) {
         if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
             // speculative mode: only member 0 watches the batch tally; it tells its team to stop
@@ -658,8 +659,13 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 scan_init(acc);
                 int cb = 0, ce = 0;
                 if (lo <= hi) {  // wave has live queries (wave-uniform)
-                    int jlo, jhi;
-                    sorted_window(keyf, yc.n, lo - p.sweepMargin, hi + p.sweepMargin, lane, jlo, jhi);
+                    // single pass: this wave's window of the previous iteration is the hint
+                    int jlo = winLo, jhi = winHi;
+                    if (ngr == 1 && winHi >= 0)
+                        sorted_window_hint(keyf, yc.n, lo - p.sweepMargin, hi + p.sweepMargin, lane, jlo, jhi);
+                    else
+                        sorted_window(keyf, yc.n, lo - p.sweepMargin, hi + p.sweepMargin, lane, jlo, jhi);
+                    winLo = jlo; winHi = jhi;
                     cb = (jlo / kChunk) * kChunk;
                     ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
                     ICPFLOW_STAMP(12);
