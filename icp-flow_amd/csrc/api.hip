@@ -37,6 +37,7 @@ int hipfail(hipError_t e, const char *what)
 // ICP correspondence search: 0 = auto, 1 = all-pairs LDS scan, 2 = exact hashed grid,
 // 3 = sorted sweep (icp.hip)
 int g_icp_search = 0;
+int g_side_stream = 1;   // developer knob (ICPFLOW_SIDE_STREAM=0: everything on the caller's stream)
 int g_check_sweep = 1;   // developer knob (ICPFLOW_CHECK_SWEEP=0 selects the all-pairs roll-back check)
 int g_score_sweep = 1;   // developer knob (ICPFLOW_SCORE_SWEEP=0 selects the all-pairs scoring scan)
 int g_hist_sorted = 1;   // developer knob (ICPFLOW_HIST_SORTED=0 selects the all-pairs vote)
@@ -62,6 +63,7 @@ struct Workspace {
     IcpCtrl *ctrl = nullptr;
     GridScratch grid{};
     float *history = nullptr;
+    float *zsortA = nullptr, *zsortC = nullptr;   // z-sorted copies of both clouds (vote)
     IcpTeam team{};
     size_t bytes = 0;
 
@@ -99,6 +101,8 @@ struct Workspace {
         grid.sortX = (float *)take(b * (size_t)N * 16);
         grid.sortYsoa = (float *)take(b * 3 * (size_t)((N + 15) / 16 * 16) * 4 + 256);  // + prefetch slack
         grid.sortXsoa = (float *)take(b * 3 * (size_t)((N + 15) / 16 * 16) * 4 + 256);
+        zsortA = (float *)take(b * (size_t)N * 16);
+        zsortC = (float *)take(b * (size_t)N * 16);
         grid.axis = (int32_t *)take(b * 4);
         history = (float *)take(b * (size_t)kHistIters * kHistStride * 4);
         team.maxWG = 1024;
@@ -144,6 +148,29 @@ int check_hist_dims(const char *fn, int lx, int ly, int lz)
     return 0;
 }
 
+// Fork / join on a private side stream: in hist_icp the axis sort of both clouds (input of the scoring
+// sweep and of the ICP) depends only on the inputs, so it runs next to the vote / peaks chain instead of
+// in front of it.  One side stream and event pair per host thread (entry points are re-entrant for
+// distinct streams and workspaces); the join makes the side work part of the caller's stream order, so
+// stream capture by the caller still sees one connected graph.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+    SideStream()
+    {
+        ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+    }
+};
+
+SideStream &side_stream()
+{
+    static thread_local SideStream s;
+    return s;
+}
+
 // shared tail of apply_icp / hist_icp: ICP from Tinit, compose, check, select
 int run_icp_and_select(const float *src, const float *dst, Workspace &w, const uint8_t *swap,
                        const float *init, int B, int N, double thres, int maxIter, double relThr,
@@ -167,16 +194,17 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     return 0;
 }
 
+// joinBefore (hist_icp): event after which the side stream has both clouds sorted (w.grid.presorted)
 int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_t *swap, int B,
                   int N, const float *ex, int lx, const float *ey, int ly, const float *ez, int lz,
-                  float shift, float *Tout, hipStream_t s)
+                  float shift, float *Tout, hipStream_t s, hipEvent_t joinBefore = nullptr)
 {
     const int lens[3] = {lx, ly, lz};
     // vote with X = dst role, Y = src role (utils_hist.py:69); z-sorted sweep while the sort fits LDS
     // (N <= 16384), all-pairs otherwise -- identical bins either way
     if (N <= kMaxSortN && g_hist_sorted)
-        ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.grid.pts,
-                                            w.grid.sortX, w.bins, s));
+        ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.zsortC,
+                                            w.zsortA, w.bins, s));
     else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
     ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,
@@ -184,8 +212,12 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
     ICPFLOW_TRY(launch_decode_candidates(w.peakIdx, B, ex, ey, ez, lx, ly, lz, shift, w.cand, s));
     // candidate scoring: sorted sweep while the sort fits LDS, all-pairs scan otherwise (same sums)
     if (N > kScoreSweepMinN && N <= kMaxSortN && g_score_sweep) {
-        ICPFLOW_TRY(launch_sort_clouds_soa(src, dst, w.lenA, w.lenC, swap, B, N, &w.grid, s));
-        w.grid.presorted = 1;   // hist_icp: the ICP that follows reuses this sort
+        if (joinBefore != nullptr) {
+            ICPFLOW_TRY(hipStreamWaitEvent(s, joinBefore, 0));
+        } else if (!w.grid.presorted) {
+            ICPFLOW_TRY(launch_sort_clouds_soa(src, dst, w.lenA, w.lenC, swap, B, N, &w.grid, s));
+            w.grid.presorted = 1;
+        }
         ICPFLOW_TRY(launch_sweep_score(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
         ICPFLOW_TRY(launch_score_pick(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
     } else {
@@ -206,6 +238,8 @@ int icpflow_version(void)
         once = true;
         const char *e = getenv("ICPFLOW_HIST_SORTED");
         if (e && e[0] == '0') g_hist_sorted = 0;
+        e = getenv("ICPFLOW_SIDE_STREAM");
+        if (e && e[0] == '0') g_side_stream = 0;
         e = getenv("ICPFLOW_CHECK_SWEEP");
         if (e && e[0] == '0') g_check_sweep = 0;
         e = getenv("ICPFLOW_SCORE_SWEEP");
@@ -387,8 +421,7 @@ int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, in
     Workspace w(d_ws, B, N, L);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_valid(d_src, B, N, w.lenA, s);
-    launch_count_valid(d_dst, B, N, w.lenC, s);
+    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s);
     return run_init_pose(d_src, d_dst, w, nullptr, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
                          len_z, decode_shift, d_T_out, s);
 }
@@ -407,8 +440,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     Workspace w(d_ws, B, N, 0);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_valid(d_X, B, N, w.lenA, s);
-    launch_count_valid(d_Y, B, N, w.lenC, s);
+    launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
                            relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N), w.history, &w.team, s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
@@ -429,8 +461,7 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
     Workspace w(d_ws, B, N, 0);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_valid(d_src, B, N, w.lenA, s);
-    launch_count_valid(d_dst, B, N, w.lenC, s);
+    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s);
     // d_T_out may alias d_init: keep a private copy of the init poses
     ICPFLOW_TRY(hipMemcpyAsync(w.Tinit, d_init, (size_t)B * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return run_icp_and_select(d_src, d_dst, w, nullptr, w.Tinit, B, N, thres_dist, max_iterations,
@@ -456,12 +487,26 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     Workspace w(d_ws, B, N, L);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_valid(d_src, B, N, w.lenA, s);
-    launch_count_valid(d_dst, B, N, w.lenC, s);
-    ICPFLOW_TRY(launch_swap_flags(w.lenA, w.lenC, B, w.swap, s));  // utils_match.py:139-146
+    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s);   // lengths + swap, utils_match.py:139-146
+    // the axis sort of both clouds (scoring sweep, ICP) runs on the side stream next to the vote
+    hipEvent_t join = nullptr;
+    const GridScratch *search = search_scratch(w, N);
+    if (search != nullptr && search->mode == 3 && N >= 64 && g_side_stream) {
+        SideStream &side = side_stream();
+        if (side.ok) {
+            ICPFLOW_TRY(hipEventRecord(side.fork, s));
+            ICPFLOW_TRY(hipStreamWaitEvent(side.stream, side.fork, 0));
+            ICPFLOW_TRY(launch_sort_clouds_soa(d_src, d_dst, w.lenA, w.lenC, w.swap, B, N, &w.grid, side.stream));
+            ICPFLOW_TRY(hipEventRecord(side.join, side.stream));
+            w.grid.presorted = 1;
+            join = side.join;
+        }
+    }
+    const bool sweepScore = N > kScoreSweepMinN && N <= kMaxSortN && g_score_sweep;
     if (int r = run_init_pose(d_src, d_dst, w, w.swap, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
-                              len_z, decode_shift, w.Tinit, s))
+                              len_z, decode_shift, w.Tinit, s, sweepScore ? join : nullptr))
         return r;
+    if (join != nullptr && !sweepScore) ICPFLOW_TRY(hipStreamWaitEvent(s, join, 0));
     return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
                               relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, s);
 }
@@ -478,8 +523,7 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
     Workspace w(d_ws, B, N, 0);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_valid(d_pcd1, B, N, w.lenA, s);
-    launch_count_valid(d_pcd2, B, N, w.lenC, s);
+    launch_count_pair(d_pcd1, d_pcd2, B, N, w.lenA, w.lenC, nullptr, s);
     ICPFLOW_TRY(launch_scan_eval(d_pcd1, d_pcd2, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.partial, s));
     ICPFLOW_TRY(launch_eval_epilogue(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
                                      d_ratios, d_ious, d_translations, d_rotations, s));

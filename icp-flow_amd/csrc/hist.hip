@@ -26,6 +26,35 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const float4 *__restri
     if (threadIdx.x == 0) len[b] = c[0];
 }
 
+// both clouds of a pair in one launch, plus the smaller-cloud-first flag of hist_icp
+// (swap[b] = n_src > n_dst, strict: utils_match.py:139-146); swap may be NULL
+__global__ __launch_bounds__(256) void count_pair_kernel(const float4 *__restrict__ A, const float4 *__restrict__ C,
+                                                         int N, int32_t *__restrict__ lenA,
+                                                         int32_t *__restrict__ lenC, uint8_t *__restrict__ swap)
+{
+    __shared__ int scratch[2 * 4];
+    const int b = blockIdx.x;
+    const float4 *pa = A + (size_t)b * N, *pc = C + (size_t)b * N;
+    int c[2] = {0, 0};
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        c[0] += (pa[i].w > 0.0f) ? 1 : 0;
+        c[1] += (pc[i].w > 0.0f) ? 1 : 0;
+    }
+    block_sum<2, int>(c, scratch);
+    if (threadIdx.x == 0) {
+        lenA[b] = c[0];
+        lenC[b] = c[1];
+        if (swap != nullptr) swap[b] = c[0] > c[1] ? 1 : 0;
+    }
+}
+
+void launch_count_pair(const float *A, const float *C, int B, int N, int32_t *lenA, int32_t *lenC, uint8_t *swap,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(count_pair_kernel, dim3(B), dim3(256), 0, s, (const float4 *)A, (const float4 *)C, N, lenA,
+                       lenC, swap);
+}
+
 void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s)
 {
     hipLaunchKernelGGL(count_valid_kernel, dim3(B), dim3(256), 0, s, (const float4 *)pts, N, len);
@@ -187,7 +216,8 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
                                                            const float4 *__restrict__ Qc,
                                                            const int32_t *__restrict__ nP,
                                                            const int32_t *__restrict__ nQ, int N, int NP2full,
-                                                           float4 *__restrict__ Ps, float4 *__restrict__ Qs)
+                                                           float4 *__restrict__ Ps, float4 *__restrict__ Qs,
+                                                           uint32_t *__restrict__ bins, int L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     float *key = reinterpret_cast<float *>(dynLds);
@@ -195,6 +225,14 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
     const int b = blockIdx.x;
     const float4 *in = (blockIdx.y == 0 ? P : Qc) + (size_t)b * N;
     float4 *out = (blockIdx.y == 0 ? Ps : Qs) + (size_t)b * N;
+    // the vote that follows wants zeroed counters: each of the pair's two blocks clears one half
+    // (hist_cuda.cu:59 at::zeros)
+    {
+        const int half = (L + 1) / 2;
+        uint32_t *h = bins + (size_t)b * L + (size_t)blockIdx.y * half;
+        const int cnt = blockIdx.y == 0 ? half : L - half;
+        for (int k = threadIdx.x; k < cnt; k += kZsortBlock) h[k] = 0u;
+    }
     // pad_segment layout (valid rows first): only the first n rows can be valid, and the network
     // only has to hold them -- next power of two >= n instead of >= N
     const int n = min((blockIdx.y == 0 ? nP : nQ)[b], N);
@@ -312,8 +350,6 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
                                    uint32_t *bins_u32, hipStream_t s)
 {
     const size_t L = (size_t)lens[0] * lens[1] * lens[2];
-    hipError_t e = hipMemsetAsync(bins_u32, 0, sizeof(uint32_t) * L * (size_t)B, s);
-    if (e != hipSuccess) return e;
     int NP2 = 64;
     while (NP2 < N) NP2 <<= 1;
     if ((size_t)NP2 * 8 > 64 * 1024) {
@@ -325,7 +361,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
         }
     }
     hipLaunchKernelGGL(zsort_kernel, dim3(B, 2), dim3(kZsortBlock), (size_t)NP2 * 8, s, (const float4 *)X,
-                       (const float4 *)Y, nX, nY, N, NP2, (float4 *)sortX, (float4 *)sortY);
+                       (const float4 *)Y, nX, nY, N, NP2, (float4 *)sortX, (float4 *)sortY, bins_u32, (int)L);
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
     const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
     const int useLds = lds_hist <= 64 * 1024;

@@ -57,6 +57,8 @@ constexpr int kHistStride = 16;   // floats per (iteration, pair): R (9), T (3),
 
 // hist.hip
 void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s);
+void launch_count_pair(const float *A, const float *C, int B, int N, int32_t *lenA, int32_t *lenC, uint8_t *swap,
+                       hipStream_t s);
 hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int NY,
                             const float mins[3], const float maxs[3], const int lens[3],
                             const float *ex, const float *ey, const float *ez,
