@@ -993,10 +993,21 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     for (int k = 0; k < 9; ++k) cur = (lane == k) ? Rf[k] : cur;
                     cur = (lane == 9) ? Tf[0] : (lane == 10) ? Tf[1] : (lane == 11) ? Tf[2] : cur;
                     const int newest = it + 1;   // number of the new state
-                    for (int k = 1; k <= kRing && k <= newest - itBegin; ++k) {
-                        const float old = ring[((newest - k) % kRing) * 16 + (lane & 15)];
-                        const bool same = lane >= 12 || __float_as_int(old) == __float_as_int(cur);
-                        if (__all(same)) { period = k; break; }
+                    // four candidate periods per round: quarter q of the wave compares the new state
+                    // (replicated into every quarter) with state newest - (k0 + q)
+                    const float cur16 = __shfl(cur, lane & 15, kWave);
+                    for (int k0 = 1; k0 <= kRing && period == 0; k0 += 4) {
+                        const int k = k0 + (lane >> 4);
+                        const bool valid = k <= kRing && k <= newest - itBegin;
+                        const float old = ring[(((newest - (valid ? k : 0)) % kRing + kRing) % kRing) * 16 + (lane & 15)];
+                        const bool same = (lane & 15) >= 12 || __float_as_int(old) == __float_as_int(cur16);
+                        const unsigned long long m = __ballot(same);
+#pragma unroll
+                        for (int q = 3; q >= 0; --q) {
+                            const bool okq = ((m >> (16 * q)) & 0xffffull) == 0xffffull;
+                            const int kq = k0 + q;
+                            if (okq && kq <= kRing && kq <= newest - itBegin) period = kq;   // smallest period wins
+                        }
                     }
                     if (lane < 12) ring[(newest % kRing) * 16 + lane] = cur;
                     if (lane == 12) ring[(newest % kRing) * 16 + 12] = rmse;
@@ -1090,6 +1101,9 @@ __global__ void icp_resolve_history_kernel(IcpState *__restrict__ st, IcpCtrl *_
     for (int k = 0; k < 9; ++k) st[b].R[k] = h[k];
     for (int k = 0; k < 3; ++k) st[b].T[k] = h[9 + k];
     st[b].rmse = h[12];
+#ifdef ICPFLOW_DEBUG_EXECUTED
+    st[b].rmse = (float)st[b].iters;   // developer builds: iterations this pair actually executed
+#endif
     st[b].iters = n;
     if (ctrl->error) st[b].R[0] = __int_as_float(0x7fc00000);   // a team gave up waiting: poison
     if (b == 0) {
