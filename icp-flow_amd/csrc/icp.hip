@@ -62,6 +62,10 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // keeps the register footprint of the solve at nine doubles.
 __device__ __forceinline__ double cofactor16(const double *M, int lane)
 {
+    // the nine element addresses depend on the lane only; recompute them here every time (an opaque copy
+    // of the lane index keeps the compiler from hoisting them out of the ICP loop, where they would be
+    // spilled and come back through nine dependent scratch loads per iteration)
+    asm volatile("" : "+v"(lane));
     const int i = (lane >> 2) & 3, j = lane & 3;
     const int r0 = (0 >= i) ? 1 : 0, r1 = (1 >= i) ? 2 : 1, r2 = (2 >= i) ? 3 : 2;
     const int c0 = (0 >= j) ? 1 : 0, c1 = (1 >= j) ? 2 : 1, c2 = (2 >= j) ? 3 : 2;
@@ -506,7 +510,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     __shared__ double tot[kMoments];          // block totals of the 18 moments
     __shared__ double Nsh[16];                // 4x4 scratch of the closed-form rotation
     __shared__ double ksh[17];                // centroids, second moments and H parked across the solve
-    __shared__ float bcast[16];               // R (9), T (3), active flag, prev rmse, rmse
+    __shared__ float bcast[20];               // R (9), T (3), active flag, prev rmse, rmse, -, origin (3)
+    __shared__ float preL[12];                // pre-pose (R row-major 9, t 3), read back where it is applied
     __shared__ float ring[kRing * 16];        // the last kRing states (R, T) and their rmse (cycle detection)
     __shared__ float combD[TS > 1 ? NWAVE * Q * kWave : 1];   // [wave][q][lane]
     __shared__ int combC[TS > 1 ? NWAVE * Q * kWave : 1];
@@ -544,31 +549,38 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     none.a = affine_identity();
 
     IcpState *st = p.state + b;
-    float Rf[9], Tf[3];
+    // The current (R, T), the origin of the moments and the pre-pose live in LDS and are read back by
+    // every wave where they are needed: nothing of it stays in registers across the rotation solve
+    // (the 1024-thread kernel has 128 VGPRs; spilled values came back one dependent scratch load
+    // at a time in the serial tail of every iteration).
     int active = 1;
     if (itBegin == 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rf[k] = (k % 4 == 0) ? 1.f : 0.f;  // :140
-        Tf[0] = Tf[1] = Tf[2] = 0.f;
-        if (tid == 0) { bcast[13] = 0.f; bcast[14] = 0.f; }
+        if (tid < 12) bcast[tid] = (tid < 9 && tid % 4 == 0) ? 1.f : 0.f;  // :140
+        if (tid == 0) { bcast[12] = 1.f; bcast[13] = 0.f; bcast[14] = 0.f; }
         if (tid < 16) ring[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.f : 0.f) : 0.f;   // state 0 = identity
     } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rf[k] = st->R[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) Tf[k] = st->T[k];
+        if (tid < 9) bcast[tid] = st->R[tid];
+        if (tid < 3) bcast[9 + tid] = st->T[tid];
         active = st->active;
-        if (tid == 0) { bcast[13] = st->rmse; bcast[14] = st->rmse; }
+        if (tid == 0) { bcast[12] = active ? 1.f : 0.f; bcast[13] = st->rmse; bcast[14] = st->rmse; }
     }
     int itersDone = (itBegin == 0) ? 0 : st->iters;
 
     // per-pair origin of the moment accumulation: the first (pre-posed) source point
-    float ox = 0.f, oy = 0.f, oz = 0.f;
-    if (xc.n > 0) {
-        float rx, ry, rz;
-        cloud_load(xc, 0, rx, ry, rz);
-        xf_apply(pre, rx, ry, rz, ox, oy, oz);
+    if (tid == 0) {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        if (xc.n > 0) {
+            float rx, ry, rz;
+            cloud_load(xc, 0, rx, ry, rz);
+            xf_apply(pre, rx, ry, rz, o0, o1, o2);
+        }
+        bcast[16] = o0; bcast[17] = o1; bcast[18] = o2;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) preL[k] = pre.a.m[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) preL[9 + k] = pre.a.t[k];
     }
+    __syncthreads();
 
     const int per = NQG * kWave * Q;         // queries per pass of the workgroup
     const int ngroups = (xc.n + per - 1) / per;
@@ -583,6 +595,12 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 team_publish(p.team, b, it, 0, 0.0, 1.0, lane);
             break;
         }
+        // this iteration's (R, T) and the origin of the moments, from LDS (dead after the search phase)
+        float Rf[9], Tf[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rf[k] = bcast[k];
+        Tf[0] = bcast[9]; Tf[1] = bcast[10]; Tf[2] = bcast[11];
+        const float ox = bcast[16], oy = bcast[17], oz = bcast[18];
         double macc[kMoments];  // wave-uniform running totals of this wave's query slots
 #pragma unroll
         for (int k = 0; k < kMoments; ++k) macc[k] = 0.0;
@@ -640,7 +658,11 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     if (live[q]) {
                         const float4 s4 = xs[i];   // sorted; pre-pose (utils_icp.py:21) applied by the sort or here
                         x0x[q] = s4.x; x0y[q] = s4.y; x0z[q] = s4.z;
-                        if (p.sortedRaw) xf_apply(pre, s4.x, s4.y, s4.z, x0x[q], x0y[q], x0z[q]);
+                        if (p.sortedRaw) {   // pre-pose (row-major rotation, translation) parked in LDS
+                            x0x[q] = fmaf(s4.z, preL[2], fmaf(s4.y, preL[1], s4.x * preL[0])) + preL[9];
+                            x0y[q] = fmaf(s4.z, preL[5], fmaf(s4.y, preL[4], s4.x * preL[3])) + preL[10];
+                            x0z[q] = fmaf(s4.z, preL[8], fmaf(s4.y, preL[7], s4.x * preL[6])) + preL[11];
+                        }
                         qx[q] = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0])) + Tf[0];  // :177, :395
                         qy[q] = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1])) + Tf[1];
                         qz[q] = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2])) + Tf[2];
@@ -941,8 +963,9 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             if (!horn_rotation(ksh + 8, ksh[6] + ksh[7], Nsh, lane, Rd)) rank1_rotation(ksh + 8, Rd);
             ICPFLOW_STAMP(6);
             // T = mu_y - mu_x R with mu = o + m', :376
-            const double mux[3] = {(double)ox + ksh[0], (double)oy + ksh[1], (double)oz + ksh[2]};
-            const double muy[3] = {(double)ox + ksh[3], (double)oy + ksh[4], (double)oz + ksh[5]};
+            const double o0 = (double)bcast[16], o1 = (double)bcast[17], o2 = (double)bcast[18];
+            const double mux[3] = {o0 + ksh[0], o1 + ksh[1], o2 + ksh[2]};
+            const double muy[3] = {o0 + ksh[3], o1 + ksh[4], o2 + ksh[5]};
             const double Td0 = muy[0] - (mux[0] * Rd[0] + mux[1] * Rd[3] + mux[2] * Rd[6]);
             const double Td1 = muy[1] - (mux[0] * Rd[1] + mux[1] * Rd[4] + mux[2] * Rd[7]);
             const double Td2 = muy[2] - (mux[0] * Rd[2] + mux[1] * Rd[5] + mux[2] * Rd[8]);
@@ -951,10 +974,12 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 #pragma unroll
             for (int k = 0; k < 9; ++k) rh += Rd[k] * ksh[8 + k];
             const double ms = ksh[6] + ksh[7] - 2.0 * rh;
+            float Rn[9], Tn[3];   // the new state
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Rf[k] = (float)Rd[k];
-            Tf[0] = (float)Td0; Tf[1] = (float)Td1; Tf[2] = (float)Td2;
+            for (int k = 0; k < 9; ++k) Rn[k] = (float)Rd[k];
+            Tn[0] = (float)Td0; Tn[1] = (float)Td1; Tn[2] = (float)Td2;
             const float rmse = (float)sqrt(ms > 0.0 ? ms : 0.0);
+            ICPFLOW_STAMP(15);
             const float prev = bcast[14];
             // relative rmse, :195-198 (fp32 like the reference's tensors)
             const float rel = (it == 0) ? 1.0f : (prev - rmse) / prev;
@@ -966,8 +991,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 if (lane == 0 && rank == 0) {
                     float *h = p.history + ((size_t)it * p.B + b) * kHistStride;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) h[k] = Rf[k];
-                    h[9] = Tf[0]; h[10] = Tf[1]; h[11] = Tf[2]; h[12] = rmse;
+                    for (int k = 0; k < 9; ++k) h[k] = Rn[k];
+                    h[9] = Tn[0]; h[10] = Tn[1]; h[11] = Tn[2]; h[12] = rmse;
                     __hip_atomic_fetch_add(&ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -979,6 +1004,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                         else ++specChk;
                     }
                 }
+                ICPFLOW_STAMP(9);
                 // Periodic trajectory: the next state is a function of (R, T) alone, so once the new
                 // state (number it + 1) equals, bit for bit, one of the last kRing states, everything
                 // that follows repeats with that period (1 = the usual convergence by exact repetition,
@@ -990,8 +1016,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 {
                     float cur = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) cur = (lane == k) ? Rf[k] : cur;
-                    cur = (lane == 9) ? Tf[0] : (lane == 10) ? Tf[1] : (lane == 11) ? Tf[2] : cur;
+                    for (int k = 0; k < 9; ++k) cur = (lane == k) ? Rn[k] : cur;
+                    cur = (lane == 9) ? Tn[0] : (lane == 10) ? Tn[1] : (lane == 11) ? Tn[2] : cur;
                     const int newest = it + 1;   // number of the new state
                     // four candidate periods per round: quarter q of the wave compares the new state
                     // (replicated into every quarter) with state newest - (k0 + q)
@@ -1047,8 +1073,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             }
             if (lane == 0) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) bcast[k] = Rf[k];
-                bcast[9] = Tf[0]; bcast[10] = Tf[1]; bcast[11] = Tf[2];
+                for (int k = 0; k < 9; ++k) bcast[k] = Rn[k];
+                bcast[9] = Tn[0]; bcast[10] = Tn[1]; bcast[11] = Tn[2];
                 bcast[12] = active ? 1.f : 0.f;
                 bcast[14] = rmse;  // :213 prev_rmse = rmse
             }
@@ -1058,21 +1084,16 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         ICPFLOW_STAMP(7);
         if (it + 1 < itEnd) {  // more iterations inside this launch: publish (R, T) to the block
             barrier_lds_only();   // the history stores / tally atomic of wave 0 stay in flight
-            if (wave != 0) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) Rf[k] = bcast[k];
-                Tf[0] = bcast[9]; Tf[1] = bcast[10]; Tf[2] = bcast[11];
-                active = bcast[12] != 0.f;
-            }
+            if (wave != 0) active = bcast[12] != 0.f;   // (R, T) are read back at the top of the loop
         }
     }
     ICPFLOW_STAMP(8);
     __syncthreads();
     if (tid == 0 && rank == 0) {  // wave 0 (of member 0) holds the final state
 #pragma unroll
-        for (int k = 0; k < 9; ++k) st->R[k] = Rf[k];
+        for (int k = 0; k < 9; ++k) st->R[k] = bcast[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) st->T[k] = Tf[k];
+        for (int k = 0; k < 3; ++k) st->T[k] = bcast[9 + k];
         st->rmse = bcast[14];
         st->active = active;
         st->iters = itersDone;

@@ -21,8 +21,8 @@ for k in (1, 2, 3):
     rc = _lib._L.icpflow_debug_phase_stamps(st)
     v = np.array(st[:16], dtype=np.int64)
     order = [(0, "kernel entry"), (1, "queries loaded, scan starts"), (2, "own scan share done"),
-             (9, "all shares merged (barrier)"), (10, "resolve + x0 reload done"), (3, "moments reduced into LDS"),
-             (4, "block barrier passed"), (5, "totals + H formed"), (13, "quartic coefficients"), (14, "newton done"), (6, "kabsch done"), (7, "R,T,rmse published"), (8, "loop exit")]
+             (10, "resolve + x0 reload done"), (3, "moments reduced into LDS"),
+             (4, "block barrier passed"), (5, "totals + H formed"), (13, "quartic coefficients"), (14, "newton done"), (6, "kabsch done"), (15, "T, rmse formed"), (9, "history + tally + stop check"), (7, "ring compare, R,T,rmse published"), (8, "loop exit")]
     print(f"max_iterations={k} (stamps of the LAST iteration, workgroup 0 thread 0), total {v[8]-v[0]} shader clocks")
     prev = v[0]
     for idx, name in order:
