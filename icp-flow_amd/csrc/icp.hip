@@ -587,6 +587,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 
     int specChk = 0;  // speculative mode: first iteration not yet known to be complete-and-unconverged
     int winLo = -1, winHi = -1;   // sorted sweep: this wave's target window of the previous iteration
+    unsigned long long ownConvLo = 0ull, ownConvHi = 0ull;   // iterations at which this pair was converged
     for (int it = itBegin; it < itEnd; ++it) {
         if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
             // speculative mode: only member 0 watches the batch tally; it tells its team to stop
@@ -914,6 +915,10 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         ICPFLOW_STAMP(4);
         // ------------- wave 0 solves for (R, T, rmse) ---------------------------------------
         if (wave == 0) {
+            // the batch rule cannot hold at an iteration at which THIS pair was not converged: skip those
+            // without looking at the tally (pairs that do converge leave through the periodic
+            // fast-forward, so the shared tally line is read only in the rare in-between cases)
+            while (specChk < it && !((specChk < 64 ? ownConvLo >> specChk : ownConvHi >> (specChk - 64)) & 1ull)) ++specChk;
             unsigned long long specTally = 0ull;
             if (p.history != nullptr && specChk < it && rank == 0)
                 specTally = __hip_atomic_load(&ctrl->tally[specChk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -988,6 +993,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 // speculative mode: record this iteration, publish (arrived, not converged) with one
                 // atomic, and leave once SOME iteration s <= it is known to satisfy the batch rule
                 // (every pair arrived at s, none unconverged).  Nobody ever waits.
+                if (conv) { if (it < 64) ownConvLo |= 1ull << it; else if (it < 128) ownConvHi |= 1ull << (it - 64); }
                 if (lane == 0 && rank == 0) {
                     float *h = p.history + ((size_t)it * p.B + b) * kHistStride;
 #pragma unroll
