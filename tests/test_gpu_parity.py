@@ -362,6 +362,30 @@ def test_icp_batch_larger_than_the_gpu_vs_oracle():
     assert np.where(valid, diff, 0).max() <= TOL_M
 
 
+def test_degenerate_pairs_do_not_disturb_their_neighbours():
+    """A pair whose src role is empty (all pads) and a pair of two single points share a batch with normal
+    pairs: the call returns, the normal pairs come out exactly as without the degenerate ones, the
+    degenerate ones are finite-or-NaN but never garbage from a neighbour."""
+    S, D, _ = synthetic.make_batch(4, 256, seed=9, ragged=True, n_min=60)
+    # per-pair stopping: with the reference's batch-global rule the never-converging degenerate pairs would
+    # (correctly) hold the whole batch at the iteration cap and change the neighbours' stopping iteration
+    a = rp.default_args(max_points=256, icp_stop_mode="per_pair")
+    base = utils_match.hist_icp(a, G(S), G(D)).cpu().numpy()
+    S2, D2 = S.copy(), D.copy()
+    S2[1, :, 0:3] = 1e8; S2[1, :, 3] = 0.0                       # empty src role
+    S2[2, 1:, 0:3] = 1e8; S2[2, 1:, 3] = 0.0                     # one point each
+    D2[2, 1:, 0:3] = 1e8; D2[2, 1:, 3] = 0.0
+    got = utils_match.hist_icp(a, G(S2), G(D2)).cpu().numpy()
+    assert np.array_equal(got[[0, 3]], base[[0, 3]])
+    ev = utils_match.match_eval(a, G(S2), G(D2), G(got))
+    torch.cuda.synchronize()
+    for k in (1, 2):
+        T = got[k]
+        assert np.all(np.isfinite(T) | np.isnan(T))
+    # single point on single point: the histogram proposes the exact translation (on the bin grid) or zero
+    assert np.isfinite(got[2]).all() and np.allclose(got[2][:3, :3], np.eye(3), atol=1e-6)
+
+
 # ------------------------------------------------------------------ a-9 / a-11 / a-12
 def test_apply_icp_from_reference_init_poses():
     g = load_golden("g6_hist_icp")
