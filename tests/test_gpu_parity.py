@@ -418,6 +418,21 @@ def test_hist_icp_ragged_vs_oracle_and_golden():
     np.testing.assert_array_equal(got[:, 3], np.tile(np.array([0, 0, 0, 1], np.float32), (len(got), 1)))
 
 
+@pytest.mark.parametrize("tf", [3.34, 6.68])
+def test_hist_icp_larger_translation_frames_vs_oracle(tf):
+    """Waymo gap 1 / gap 2 histogram geometry (68 and 135 bins per axis, 55 and 219 KB per pair):
+    the vote's bins no longer fit LDS next to the tile (global atomics) and, at 135 bins, the peaks kernel
+    works through global scratch volumes.  Initial pose and full registration against the oracle."""
+    S, D, _ = synthetic.make_batch(6, 256, seed=41, ragged=True, n_min=80)
+    a = rp.default_args(max_points=256, translation_frame=tf)
+    got0 = utils_hist.estimate_init_pose(a, G(S), G(D)).cpu().numpy()
+    want0 = rp.estimate_init_pose(a, C(S), C(D)).numpy()
+    assert np.array_equal(got0, want0)           # (seed chosen without a tie at the 5th / 6th peak)
+    got = utils_match.hist_icp(a, G(S), G(D)).cpu().numpy()
+    want = rp.hist_icp(a, C(S), C(D)).numpy()
+    assert_pose_close(got, want, S)
+
+
 def test_hist_icp_dense_vs_golden_and_match_eval():
     g = load_golden("g6_hist_icp_dense")
     S, D, _ = synthetic.make_batch(int(g["num_pairs"]), int(g["max_points"]), seed=int(g["seed"]))
