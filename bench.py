@@ -162,7 +162,6 @@ def main():
                                f"translation_frame 2.0 (41x41x3 bins)",
                    "pairs_per_gpu": B, "points": N, "icp_iteration_cap": a.iters,
                    "stop_mode": a.stop_mode, "sharding": f"pairs/{world} contiguous, all_gather of [B,4,4]"},
-        "ms_per_frame_pair_equivalent": round(dt / a.steps * 1e3, 4),
         "roofline": roofline,
         "cpu_baseline": cpu,
         "extras": extras,
@@ -201,7 +200,46 @@ def extra_measurements(args, src, dst, T, dev, a):
     init = torch.eye(4, device=dev)[None].repeat(B, 1, 1).contiguous()
     ms = timeit(lambda: utils_icp.apply_icp(args, src, dst, init))
     out["icp_only_apply_icp_registrations_per_s"] = round(B / ms * 1e3, 1)
+    fp = frame_pair_measurement(dev)
+    if fp is not None:
+        out["frame_pair"] = fp
     return out
+
+
+def frame_pair_measurement(dev):
+    """BASELINE config 1: ms / frame pair on the reference's demo frame pair (tests/golden/g8_demo*.npz:
+    63 k points per frame, labels of the fixture, both association stages + per-point flow; clouds
+    resident, flags of demo.sh) and the agreement of the flow with the reference's own run."""
+    gdir = os.path.join(REPO, "tests", "golden")
+    try:
+        g, lab = np.load(os.path.join(gdir, "g8_demo.npz")), np.load(os.path.join(gdir, "g8_demo_labels.npz"))
+    except OSError:
+        return None
+    from icp_flow_amd import frame_pairs, utils_flow, utils_track
+    G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    ps, pd = G(g["point_src"]), G(g["point_dst"])
+    ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
+    res = {"data": "demo.npz frame pair of the reference, labels from the G8 fixture", "points": [len(ps), len(pd)]}
+    for mp in (int(g["max_points"]), 10000):
+        a = frame_pairs.default_args(max_points=mp)
+
+        def run():
+            torch.manual_seed(0)
+            pairs, Tm = utils_track.track(a, ps, pd, ls, ld)
+            return pairs, utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, torch.eye(4, device=dev))
+
+        run()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(5):
+            pairs, flow = run()
+        torch.cuda.synchronize(dev)
+        entry = {"ms_per_frame_pair": round((time.perf_counter() - t) / 5 * 1e3, 3), "matched_cluster_pairs": int(len(pairs)),
+                 "epe_vs_ground_truth_m": round(float(np.linalg.norm(flow.cpu().numpy() - g["gt_flow"], axis=1).mean()), 5)}
+        if mp == int(g["max_points"]):      # the setting the reference's own run was captured with
+            entry["max_flow_difference_to_reference_m"] = float(np.abs(flow.cpu().numpy() - g["flow"]).max())
+        res[f"max_points_{mp}"] = entry
+    return res
 
 
 def cpu_baseline(S, D, a):
