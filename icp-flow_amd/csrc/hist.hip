@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
 hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t *nX, const int32_t *nY,
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
-                                   uint32_t *bins_u32, hipStream_t s)
+                                   uint32_t *bins_u32, float *ckey, int *cidx, hipStream_t s)
 {
     const size_t L = (size_t)lens[0] * lens[1] * lens[2];
     int NP2 = 64;
@@ -360,8 +360,13 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
             attr = true;
         }
     }
-    hipLaunchKernelGGL(zsort_kernel, dim3(B, 2), dim3(kZsortBlock), (size_t)NP2 * 8, s, (const float4 *)X,
-                       (const float4 *)Y, nX, nY, N, NP2, (float4 *)sortX, (float4 *)sortY, bins_u32, (int)L);
+    if (N > kChunkSortMinN && ckey != nullptr) {   // long clouds: several workgroups per sort (sort.hip)
+        hipError_t e = launch_zsort_chunked(X, Y, nX, nY, B, N, sortX, sortY, bins_u32, (int)L, ckey, cidx, s);
+        if (e != hipSuccess) return e;
+    } else {
+        hipLaunchKernelGGL(zsort_kernel, dim3(B, 2), dim3(kZsortBlock), (size_t)NP2 * 8, s, (const float4 *)X,
+                           (const float4 *)Y, nX, nY, N, NP2, (float4 *)sortX, (float4 *)sortY, bins_u32, (int)L);
+    }
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
     const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
     const int useLds = lds_hist <= 64 * 1024;

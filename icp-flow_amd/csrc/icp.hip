@@ -1367,6 +1367,11 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
                 attr = true;
             }
         }
+        if (N > kChunkSortMinN && grid->ckey != nullptr) {   // long clouds: several workgroups per sort
+            e = launch_sort_clouds_chunked(X, Y, lenX, lenY, swap, prePose, B, N, grid->axis, grid->sortX, grid->pts,
+                                           grid->sortYsoa, nullptr, grid->ckey, grid->cidx, s);
+            if (e != hipSuccess) return e;
+        } else
         hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY,
                            swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts, grid->sortYsoa,
                            (float *)nullptr);
@@ -1436,6 +1441,9 @@ hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t 
             attr = true;
         }
     }
+    if (N > kChunkSortMinN && grid->ckey != nullptr)   // long clouds: several workgroups per sort (sort.hip)
+        return launch_sort_clouds_chunked(X, Y, lenX, lenY, swap, nullptr, B, N, grid->axis, grid->sortX, grid->pts,
+                                          grid->sortYsoa, grid->sortXsoa, grid->ckey, grid->cidx, s);
     hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY, swap,
                        (const float *)nullptr, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts,
                        grid->sortYsoa, grid->sortXsoa);

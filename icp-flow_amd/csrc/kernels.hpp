@@ -66,7 +66,17 @@ hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int N
 hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t *nX, const int32_t *nY,
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
-                                   uint32_t *bins_u32, hipStream_t s);
+                                   uint32_t *bins_u32, float *ckey, int *cidx, hipStream_t s);
+// sort.hip: several workgroups per long cloud; same outputs as zsort_kernel / sort_clouds_kernel
+constexpr int kChunkSortMinN = 4096;
+int chunk_sort_length(int N);
+hipError_t launch_zsort_chunked(const float *P, const float *Q, const int32_t *nP, const int32_t *nQ, int B, int N,
+                                float *outP, float *outQ, uint32_t *bins, int L, float *ckey, int *cidx,
+                                hipStream_t s);
+hipError_t launch_sort_clouds_chunked(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
+                                      const uint8_t *swap, const float *prePose, int B, int N, int32_t *axisOut,
+                                      float *Xs, float *Ys, float *Ysoa, float *Xsoa, float *ckey, int *cidx,
+                                      hipStream_t s);
 hipError_t launch_u32_to_f32(const uint32_t *in, float *out, size_t n, hipStream_t s);
 hipError_t launch_hist_peaks_f32(const float *bins, int B, int Lx, int Ly, int Lz, int k,
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
@@ -108,6 +118,8 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     float *sortYsoa;   // sweep: fixed cloud sorted, x[] y[] z[] padded with +inf [B,3,NP16]
     float *sortXsoa;   // scoring sweep: moving cloud sorted (no pre-pose), same layout
     int32_t *axis;     // sweep: [B]
+    float *ckey;       // long clouds (N > kChunkSortMinN): chunk-sorted keys / rows of the multi-workgroup sort
+    int *cidx;         //   [B,2,chunk_sort_length(N)] each (sort.hip), else NULL
     int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose
                        // (scoring sweep ran on this batch): the ICP applies the pre-pose when it loads
 };

@@ -1,0 +1,238 @@
+// sort.hip -- sorting LONG clouds (N > 4096) with several workgroups per cloud.
+//
+// The per-pair sorts of the path (by z for the vote, along the fixed cloud's longest axis for the
+// sweeps) run as one bitonic network in the LDS of one workgroup (hist.hip: zsort_kernel, icp.hip:
+// sort_clouds_kernel).  That is the right shape for vehicle-sized clusters, but a 16 384-key network
+// has 105 stages of 8 dependent LDS exchanges per thread (~240 us) and a frame with one wall-sized
+// cluster waits for it twice.  Here a long cloud is cut into chunks of 2048 keys; every chunk is sorted
+// by its own workgroup (66 stages, one exchange per thread), and a second kernel gives every element
+// its final rank = rank inside its chunk + the number of smaller elements in every other chunk (binary
+// searches; ties broken by the original index, so the order is the same total order the single-workgroup
+// network produces) and writes it straight into the consumer's layout.  Outputs are identical to the
+// single-workgroup kernels'.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "scan.hpp"
+#include "kernels.hpp"
+
+namespace icpflow {
+
+constexpr int kCsChunk = 2048;   // keys per chunk (one 1024-thread workgroup, 16 KiB of LDS)
+constexpr int kCsBlock = 1024;
+
+struct ChunkSortParams {
+    int mode;                 // 0: by z (vote), 1: along the fixed cloud's longest axis (sweeps)
+    const float4 *P, *Q;      // mode 0: the two clouds;  mode 1: X (src), Y (dst) as passed to the registration
+    const int32_t *nP, *nQ;   // valid counts of P / Q (mode 1: lenX, lenY)
+    const uint8_t *swap;      // mode 1
+    const float *prePose;     // mode 1, optional [B,4,4]
+    int N, NPc;               // rows per cloud, chunked length (multiple of kCsChunk)
+    float *ckey;              // [B, 2, NPc] sorted keys of every chunk
+    int *cidx;                // [B, 2, NPc] original rows
+    // outputs
+    float4 *outP, *outQ;      // mode 0: z-sorted rows;  mode 1: Xs (moving) / Ys (fixed): posed point + row
+    float *Ysoa, *Xsoa;       // mode 1 (Xsoa optional)
+    int32_t *axisOut;         // mode 1
+    uint32_t *bins;           // mode 0: counters to clear (L per pair)
+    int L;
+};
+
+// cloud roles of mode 1 exactly as sort_clouds_kernel resolves them
+struct Roles {
+    const float4 *cloud;
+    int n;
+    bool moving;
+};
+
+__device__ __forceinline__ Roles roles_of(const ChunkSortParams &p, int b, int which)
+{
+    Roles r;
+    if (p.mode == 0) {
+        r.cloud = (which == 0 ? p.P : p.Q) + (size_t)b * p.N;
+        r.n = min((which == 0 ? p.nP : p.nQ)[b], p.N);
+        r.moving = false;
+    } else {
+        const bool sw = p.swap != nullptr && p.swap[b] != 0;
+        r.moving = which == 1;
+        const bool takeY = r.moving ? sw : !sw;          // moving role = sw ? Y : X;  fixed role = sw ? X : Y
+        r.cloud = (takeY ? p.Q : p.P) + (size_t)b * p.N;
+        r.n = (takeY ? p.nQ : p.nP)[b];
+    }
+    return r;
+}
+
+// longest axis of the FIXED cloud of pair b (all threads of the block take part)
+__device__ int fixed_axis(const ChunkSortParams &p, int b, float *bb, int *axisSh)
+{
+    const Roles f = roles_of(p, b, 0);
+    float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
+    for (int j = threadIdx.x; j < f.n; j += kCsBlock) {
+        const float4 q = f.cloud[j];
+        mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+        mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], o, kWave));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o, kWave));
+        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        for (int k = 0; k < 3; ++k) { bb[wave * 6 + k] = mn[k]; bb[wave * 6 + 3 + k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float e[3];
+        for (int k = 0; k < 3; ++k) {
+            float lo = bb[k], hi = bb[3 + k];
+            for (int w = 1; w < kCsBlock / kWave; ++w) { lo = fminf(lo, bb[w * 6 + k]); hi = fmaxf(hi, bb[w * 6 + 3 + k]); }
+            e[k] = hi - lo;
+        }
+        *axisSh = (e[0] >= e[1] && e[0] >= e[2]) ? 0 : (e[1] >= e[2] ? 1 : 2);   // same rule as sort_clouds_kernel
+    }
+    __syncthreads();
+    return *axisSh;
+}
+
+__device__ __forceinline__ float sort_key(const ChunkSortParams &p, const Roles &r, int b, int axis, int j, float &px,
+                                          float &py, float &pz)
+{
+    const float4 q = r.cloud[j];
+    if (p.mode == 0) {
+        px = q.x; py = q.y; pz = q.z;
+        return q.w > 0.0f ? q.z : kInf;
+    }
+    PointXf pre;
+    pre.kind = (r.moving && p.prePose) ? XF_AFFINE : XF_NONE;
+    pre.a = (r.moving && p.prePose) ? affine_from_pose(p.prePose + (size_t)b * 16) : affine_identity();
+    xf_apply(pre, q.x, q.y, q.z, px, py, pz);
+    return axis == 0 ? px : (axis == 1 ? py : pz);
+}
+
+// grid (B, 2, NPc / kCsChunk)
+__global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
+{
+    __shared__ float key[kCsChunk];
+    __shared__ int idx[kCsChunk];
+    __shared__ float bb[6 * (kCsBlock / kWave)];
+    __shared__ int axisSh;
+    const int b = blockIdx.x, which = blockIdx.y, c = blockIdx.z;
+    const Roles r = roles_of(p, b, which);
+    const int base = c * kCsChunk;
+    if (p.mode == 0 && c == 0) {   // clear this pair's counters (each of its two clouds takes one half)
+        const int half = (p.L + 1) / 2;
+        uint32_t *h = p.bins + (size_t)b * p.L + (size_t)which * half;
+        const int cnt = which == 0 ? half : p.L - half;
+        for (int k = threadIdx.x; k < cnt; k += kCsBlock) h[k] = 0u;
+    }
+    if (base >= r.n && !(p.mode == 1 && c == 0)) return;
+    int axis = 0;
+    if (p.mode == 1) {
+        axis = fixed_axis(p, b, bb, &axisSh);
+        if (c == 0 && which == 0 && threadIdx.x == 0) p.axisOut[b] = axis;
+        if (base >= r.n) return;
+    }
+    for (int j = threadIdx.x; j < kCsChunk; j += kCsBlock) {
+        float k = kInf, px, py, pz;
+        if (base + j < r.n) k = sort_key(p, r, b, axis, base + j, px, py, pz);
+        key[j] = k;
+        idx[j] = base + j;
+    }
+    __syncthreads();
+    bitonic_sort_lds(key, idx, kCsChunk);
+    float *ck = p.ckey + ((size_t)b * 2 + which) * p.NPc + base;
+    int *ci = p.cidx + ((size_t)b * 2 + which) * p.NPc + base;
+    for (int j = threadIdx.x; j < kCsChunk; j += kCsBlock) { ck[j] = key[j]; ci[j] = idx[j]; }
+}
+
+// number of elements (k, i) of a sorted chunk with (k, i) < (key, id), lexicographic
+__device__ __forceinline__ int count_less(const float *__restrict__ ck, const int *__restrict__ ci, int len, float key,
+                                          int id)
+{
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float k = ck[mid];
+        const bool less = k < key || (k == key && ci[mid] < id);
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// grid (B, 2, ceil(NPc / kCsBlock)): one element per thread
+__global__ __launch_bounds__(kCsBlock) void chunk_merge_kernel(ChunkSortParams p)
+{
+    const int b = blockIdx.x, which = blockIdx.y;
+    const int e = blockIdx.z * kCsBlock + threadIdx.x;
+    const Roles r = roles_of(p, b, which);
+    const int NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
+    float4 *out = (p.mode == 0) ? ((which == 0 ? p.outP : p.outQ) + (size_t)b * p.N)
+                                : ((r.moving ? p.outP : p.outQ) + (size_t)b * p.N);
+    float *soa = nullptr;
+    if (p.mode == 1) soa = r.moving ? (p.Xsoa ? p.Xsoa + (size_t)b * 3 * NP16 : nullptr) : p.Ysoa + (size_t)b * 3 * NP16;
+    if (e >= r.n) {   // beyond the valid rows: padding of the consumer's layout
+        if (p.mode == 0) { if (e < p.N) out[e] = make_float4(0.f, 0.f, kInf, 0.f); }
+        else if (soa != nullptr && e < NP16) { soa[e] = kInf; soa[NP16 + e] = kInf; soa[2 * NP16 + e] = kInf; }
+        return;
+    }
+    const float *ckAll = p.ckey + ((size_t)b * 2 + which) * p.NPc;
+    const int *ciAll = p.cidx + ((size_t)b * 2 + which) * p.NPc;
+    const float key = ckAll[e];
+    const int id = ciAll[e];
+    const int c = e / kCsChunk;
+    int rank = e - c * kCsChunk;
+    const int nchunks = (r.n + kCsChunk - 1) / kCsChunk;
+    for (int o = 0; o < nchunks; ++o) {
+        if (o == c) continue;
+        const int len = min(kCsChunk, r.n - o * kCsChunk);
+        rank += count_less(ckAll + (size_t)o * kCsChunk, ciAll + (size_t)o * kCsChunk, len, key, id);
+    }
+    if (p.mode == 0) {
+        // rows whose flag is not set carry +inf keys and sort behind the valid ones: emitted as invalid rows
+        out[rank] = key < kInf ? r.cloud[id] : make_float4(0.f, 0.f, kInf, 0.f);
+        return;
+    }
+    const int axis = p.axisOut[b];
+    float px, py, pz;
+    (void)sort_key(p, r, b, axis, id, px, py, pz);
+    out[rank] = make_float4(px, py, pz, __int_as_float(id));
+    if (soa != nullptr) { soa[rank] = px; soa[NP16 + rank] = py; soa[2 * NP16 + rank] = pz; }
+}
+
+static hipError_t run_chunk_sort(ChunkSortParams p, int B, hipStream_t s)
+{
+    const int NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
+    const int span = NP16 > p.NPc ? NP16 : p.NPc;
+    hipLaunchKernelGGL(chunk_sort_kernel, dim3(B, 2, p.NPc / kCsChunk), dim3(kCsBlock), 0, s, p);
+    hipLaunchKernelGGL(chunk_merge_kernel, dim3(B, 2, (span + kCsBlock - 1) / kCsBlock), dim3(kCsBlock), 0, s, p);
+    return hipGetLastError();
+}
+
+int chunk_sort_length(int N) { return (N + kCsChunk - 1) / kCsChunk * kCsChunk; }
+
+hipError_t launch_zsort_chunked(const float *P, const float *Q, const int32_t *nP, const int32_t *nQ, int B, int N,
+                                float *outP, float *outQ, uint32_t *bins, int L, float *ckey, int *cidx,
+                                hipStream_t s)
+{
+    ChunkSortParams p{};
+    p.mode = 0; p.P = (const float4 *)P; p.Q = (const float4 *)Q; p.nP = nP; p.nQ = nQ; p.N = N;
+    p.NPc = chunk_sort_length(N); p.ckey = ckey; p.cidx = cidx; p.outP = (float4 *)outP; p.outQ = (float4 *)outQ;
+    p.bins = bins; p.L = L;
+    return run_chunk_sort(p, B, s);
+}
+
+hipError_t launch_sort_clouds_chunked(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
+                                      const uint8_t *swap, const float *prePose, int B, int N, int32_t *axisOut,
+                                      float *Xs, float *Ys, float *Ysoa, float *Xsoa, float *ckey, int *cidx,
+                                      hipStream_t s)
+{
+    ChunkSortParams p{};
+    p.mode = 1; p.P = (const float4 *)X; p.Q = (const float4 *)Y; p.nP = lenX; p.nQ = lenY; p.swap = swap;
+    p.prePose = prePose; p.N = N; p.NPc = chunk_sort_length(N); p.ckey = ckey; p.cidx = cidx;
+    p.outP = (float4 *)Xs; p.outQ = (float4 *)Ys; p.Ysoa = Ysoa; p.Xsoa = Xsoa; p.axisOut = axisOut;
+    return run_chunk_sort(p, B, s);
+}
+
+}  // namespace icpflow
