@@ -65,6 +65,7 @@ struct Workspace {
     float *history = nullptr;
     float *zsortA = nullptr, *zsortC = nullptr;   // z-sorted copies of both clouds (vote)
     float *zckey = nullptr;
+    float *voteKey = nullptr;   // per-pair sort-key parameters of the vote (votekey.hpp)
     int *zcidx = nullptr;
     IcpTeam team{};
     size_t bytes = 0;
@@ -105,6 +106,7 @@ struct Workspace {
         grid.sortXsoa = (float *)take(b * 3 * (size_t)((N + 15) / 16 * 16) * 4 + 256);
         zsortA = (float *)take(b * (size_t)N * 16);
         zsortC = (float *)take(b * (size_t)N * 16);
+        voteKey = (float *)take(b * 8 * 4);
         if (N > kChunkSortMinN) {   // scratch of the multi-workgroup sorts (one set per concurrent sort)
             const size_t cs = b * 2 * (size_t)chunk_sort_length(N) * 4;
             grid.ckey = (float *)take(cs);
@@ -213,7 +215,7 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
     // (N <= 16384), all-pairs otherwise -- identical bins either way
     if (N <= kMaxSortN && g_hist_sorted)
         ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.zsortC,
-                                            w.zsortA, w.bins, w.zckey, w.zcidx, s));
+                                            w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s));
     else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
     ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,

@@ -8,6 +8,7 @@
 // and flushes the non-zero bins once.  Counters are uint32 (exact beyond 2^24).
 #include "common.hpp"
 #include "kernels.hpp"
+#include "votekey.hpp"
 
 namespace icpflow {
 
@@ -217,11 +218,15 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
                                                            const int32_t *__restrict__ nP,
                                                            const int32_t *__restrict__ nQ, int N, int NP2full,
                                                            float4 *__restrict__ Ps, float4 *__restrict__ Qs,
-                                                           uint32_t *__restrict__ bins, int L)
+                                                           uint32_t *__restrict__ bins, int L,
+                                                           const float *__restrict__ ez, int len_z,
+                                                           float *__restrict__ keyRec)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     float *key = reinterpret_cast<float *>(dynLds);
     int *idx = reinterpret_cast<int *>(dynLds + sizeof(float) * NP2full);
+    __shared__ float bbScratch[6 * (kZsortBlock / kWave)];
+    __shared__ float keyShared[kVoteKeyStride];
     const int b = blockIdx.x;
     const float4 *in = (blockIdx.y == 0 ? P : Qc) + (size_t)b * N;
     float4 *out = (blockIdx.y == 0 ? Ps : Qs) + (size_t)b * N;
@@ -236,6 +241,10 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
     // pad_segment layout (valid rows first): only the first n rows can be valid, and the network
     // only has to hold them -- next power of two >= n instead of >= N
     const int n = min((blockIdx.y == 0 ? nP : nQ)[b], N);
+    // sort key of this pair (votekey.hpp): z, or (z slab, long horizontal axis) for wide clusters
+    const VoteKey vk = vote_key_params(P + (size_t)b * N, min(nP[b], N), Qc + (size_t)b * N, min(nQ[b], N),
+                                       ez[len_z - 1] - ez[0], bbScratch, keyShared);
+    if (blockIdx.y == 0 && threadIdx.x < kVoteKeyStride) keyRec[(size_t)b * kVoteKeyStride + threadIdx.x] = keyShared[threadIdx.x];
     int NP2 = kWave;
     while (NP2 < n) NP2 <<= 1;
     NP2 = min(NP2, NP2full);
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
         float k = kInf;
         if (j < n) {
             const float4 q = in[j];
-            if (q.w > 0.0f) k = q.z;
+            if (q.w > 0.0f) k = vote_key(vk, q.x, q.y, q.z);
         }
         key[j] = k;
         idx[j] = j;
@@ -251,9 +260,10 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
     __syncthreads();
     bitonic_sort_lds(key, idx, NP2);
     for (int r = threadIdx.x; r < N; r += kZsortBlock) {
-        // rows beyond the valid count carry +inf keys: emit them as invalid rows
-        float4 o = make_float4(0.f, 0.f, kInf, 0.f);
-        if (r < NP2 && key[r] < kInf) o = in[idx[r]];
+        // valid rows carry their key in w (the flag of a valid row is implied by its position below the
+        // count); rows beyond the valid count have +inf keys
+        float4 o = make_float4(0.f, 0.f, kInf, kInf);
+        if (r < NP2 && key[r] < kInf) { o = in[idx[r]]; o.w = key[r]; }
         out[r] = o;
     }
 }
@@ -262,12 +272,14 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     const float4 *__restrict__ Xs, const float4 *__restrict__ Ys, const int32_t *__restrict__ nXv,
     const int32_t *__restrict__ nYv, int N, int len_x, int len_y, int len_z,
     const float *__restrict__ ex, const float *__restrict__ ey, const float *__restrict__ ez,
-    const uint8_t *__restrict__ swap, int useLds, uint32_t *__restrict__ bins_u32)
+    const uint8_t *__restrict__ swap, int useLds, uint32_t *__restrict__ bins_u32,
+    const float *__restrict__ keyRec)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + sizeof(float4) * kVoteTile);
     const int b = blockIdx.y;
+    const VoteKey vk = vote_key_load(keyRec + (size_t)b * kVoteKeyStride);
     const bool sw = swap != nullptr && swap[b] != 0;
     const float4 *xb = (sw ? Ys : Xs) + (size_t)b * N;
     const float4 *yb = (sw ? Xs : Ys) + (size_t)b * N;
@@ -302,6 +314,25 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     }
     const float slack = 1e-3f * (fabsf(max_z) + fabsf(min_z)) + 1e-5f * (fabsf(zlo) + fabsf(zhi)) + 1e-6f;
     const float wlo = zlo - max_z - slack, whi = zhi - min_z + slack;
+    // wide pairs: the rows of this wave also share a neighbourhood along u; targets are visited slab by
+    // slab, inside each slab only those whose u can fall into the box (u' = u - u0 is the key's minor part)
+    float ulo = kInf, uhi = -kInf;
+    int slabLo = 0, slabHi = 0;
+    if (vk.wide) {
+        const float xu = vk.uaxis == 0 ? xi.x : xi.y;
+        ulo = xvalid ? xu : kInf; uhi = xvalid ? xu : -kInf;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            ulo = fminf(ulo, __shfl_xor(ulo, o, kWave));
+            uhi = fmaxf(uhi, __shfl_xor(uhi, o, kWave));
+        }
+        const float minu = vk.uaxis == 0 ? min_x : min_y, maxu = vk.uaxis == 0 ? max_x : max_y;
+        const float su = 0.0625f + 1e-5f * (fabsf(ulo) + fabsf(uhi) + fabsf(vk.u0));   // two ulps of K, rounding
+        ulo = ulo - maxu - vk.u0 - su;      // window of u' inside a slab
+        uhi = uhi - minu - vk.u0 + su;
+        slabLo = (int)floorf((wlo - vk.z0) / vk.h);
+        slabHi = (int)floorf((whi - vk.z0) / vk.h);
+    }
     const int jEnd = min(ny, jBegin + kVoteSpan * kVoteTile);
     for (int j0 = jBegin; j0 < jEnd; j0 += kVoteTile) {
         const int tn = min(kVoteTile, jEnd - j0);
@@ -309,9 +340,20 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
         for (int k = threadIdx.x; k < tn; k += kVoteBlock) tile[k] = yb[j0 + k];
         __syncthreads();
         if (!(zlo <= zhi)) continue;  // wave without valid rows (wave-uniform)
-        const float *zkey = reinterpret_cast<const float *>(tile) + 2;
-        const int r0 = sorted_count_below<false>(zkey, 4, tn, wlo, lane);
-        const int r1 = sorted_count_below<true>(zkey, 4, tn, whi, lane);
+        const float *zkey = reinterpret_cast<const float *>(tile) + 3;   // the sort key rides in w
+        const int nwin = vk.wide ? max(slabHi - slabLo + 1, 0) : 1;
+        for (int win = 0; win < nwin; ++win) {
+        int r0, r1;
+        if (vk.wide) {
+            const float sbase = (float)(slabLo + win) * kSlabStride;
+            const float klo = sbase + fmaxf(ulo, 0.f), khi = sbase + fminf(uhi, kSlabStride - 0.5f);
+            if (!(klo <= khi)) continue;
+            r0 = sorted_count_below<false>(zkey, 4, tn, klo, lane);
+            r1 = sorted_count_below<true>(zkey, 4, tn, khi, lane);
+        } else {
+            r0 = sorted_count_below<false>(zkey, 4, tn, wlo, lane);
+            r1 = sorted_count_below<true>(zkey, 4, tn, whi, lane);
+        }
         if (!xvalid) continue;
         // four targets per round, all four LDS reads issued before the first test: with one workgroup
         // per CU (a frame-level batch) nothing else hides the LDS latency of a one-target loop
@@ -334,6 +376,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
                 }
             }
         }
+        }  // windows
     }
     if (useLds) {
         __syncthreads();
@@ -347,7 +390,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
 hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t *nX, const int32_t *nY,
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
-                                   uint32_t *bins_u32, float *ckey, int *cidx, hipStream_t s)
+                                   uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s)
 {
     const size_t L = (size_t)lens[0] * lens[1] * lens[2];
     int NP2 = 64;
@@ -361,11 +404,13 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
         }
     }
     if (N > kChunkSortMinN && ckey != nullptr) {   // long clouds: several workgroups per sort (sort.hip)
-        hipError_t e = launch_zsort_chunked(X, Y, nX, nY, B, N, sortX, sortY, bins_u32, (int)L, ckey, cidx, s);
+        hipError_t e = launch_zsort_chunked(X, Y, nX, nY, B, N, sortX, sortY, bins_u32, (int)L, ckey, cidx, ez, lens[2],
+                                            keyRec, s);
         if (e != hipSuccess) return e;
     } else {
         hipLaunchKernelGGL(zsort_kernel, dim3(B, 2), dim3(kZsortBlock), (size_t)NP2 * 8, s, (const float4 *)X,
-                           (const float4 *)Y, nX, nY, N, NP2, (float4 *)sortX, (float4 *)sortY, bins_u32, (int)L);
+                           (const float4 *)Y, nX, nY, N, NP2, (float4 *)sortX, (float4 *)sortY, bins_u32, (int)L, ez,
+                           lens[2], keyRec);
     }
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
     const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
@@ -374,7 +419,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
     dim3 grid(((N + kVoteBlock - 1) / kVoteBlock) * tsplit, B);
     hipLaunchKernelGGL(hist_vote_sorted_kernel, grid, dim3(kVoteBlock), useLds ? lds_hist : tile_bytes, s,
                        (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                       ez, swap, useLds, bins_u32);
+                       ez, swap, useLds, bins_u32, keyRec);
     return hipGetLastError();
 }
 

@@ -66,13 +66,13 @@ hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int N
 hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t *nX, const int32_t *nY,
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
-                                   uint32_t *bins_u32, float *ckey, int *cidx, hipStream_t s);
+                                   uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s);
 // sort.hip: several workgroups per long cloud; same outputs as zsort_kernel / sort_clouds_kernel
 constexpr int kChunkSortMinN = 4096;
 int chunk_sort_length(int N);
 hipError_t launch_zsort_chunked(const float *P, const float *Q, const int32_t *nP, const int32_t *nQ, int B, int N,
                                 float *outP, float *outQ, uint32_t *bins, int L, float *ckey, int *cidx,
-                                hipStream_t s);
+                                const float *ez, int len_z, float *keyRec, hipStream_t s);
 hipError_t launch_sort_clouds_chunked(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                                       const uint8_t *swap, const float *prePose, int B, int N, int32_t *axisOut,
                                       float *Xs, float *Ys, float *Ysoa, float *Xsoa, float *ckey, int *cidx,

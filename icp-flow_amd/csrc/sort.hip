@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "scan.hpp"
 #include "kernels.hpp"
+#include "votekey.hpp"
 
 namespace icpflow {
 
@@ -36,6 +37,9 @@ struct ChunkSortParams {
     int32_t *axisOut;         // mode 1
     uint32_t *bins;           // mode 0: counters to clear (L per pair)
     int L;
+    const float *ez;          // mode 0: z edges of the vote box (slab thickness of the composite key)
+    int len_z;
+    float *keyRec;            // mode 0: [B, kVoteKeyStride] key parameters, written here, read by the vote
 };
 
 // cloud roles of mode 1 exactly as sort_clouds_kernel resolves them
@@ -96,13 +100,13 @@ __device__ int fixed_axis(const ChunkSortParams &p, int b, float *bb, int *axisS
     return *axisSh;
 }
 
-__device__ __forceinline__ float sort_key(const ChunkSortParams &p, const Roles &r, int b, int axis, int j, float &px,
-                                          float &py, float &pz)
+__device__ __forceinline__ float sort_key(const ChunkSortParams &p, const Roles &r, int b, int axis, const VoteKey &vk,
+                                          int j, float &px, float &py, float &pz)
 {
     const float4 q = r.cloud[j];
     if (p.mode == 0) {
         px = q.x; py = q.y; pz = q.z;
-        return q.w > 0.0f ? q.z : kInf;
+        return q.w > 0.0f ? vote_key(vk, q.x, q.y, q.z) : kInf;
     }
     PointXf pre;
     pre.kind = (r.moving && p.prePose) ? XF_AFFINE : XF_NONE;
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
     __shared__ int idx[kCsChunk];
     __shared__ float bb[6 * (kCsBlock / kWave)];
     __shared__ int axisSh;
+    __shared__ float keySh[kVoteKeyStride];
     const int b = blockIdx.x, which = blockIdx.y, c = blockIdx.z;
     const Roles r = roles_of(p, b, which);
     const int base = c * kCsChunk;
@@ -127,16 +132,22 @@ __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
         const int cnt = which == 0 ? half : p.L - half;
         for (int k = threadIdx.x; k < cnt; k += kCsBlock) h[k] = 0u;
     }
-    if (base >= r.n && !(p.mode == 1 && c == 0)) return;
+    if (base >= r.n && c != 0) return;   // (chunk 0 still publishes the pair's axis / key parameters)
     int axis = 0;
+    VoteKey vk{};
     if (p.mode == 1) {
         axis = fixed_axis(p, b, bb, &axisSh);
         if (c == 0 && which == 0 && threadIdx.x == 0) p.axisOut[b] = axis;
         if (base >= r.n) return;
+    } else {
+        vk = vote_key_params(p.P + (size_t)b * p.N, min(p.nP[b], p.N), p.Q + (size_t)b * p.N, min(p.nQ[b], p.N),
+                             p.ez[p.len_z - 1] - p.ez[0], bb, keySh);
+        if (c == 0 && which == 0 && threadIdx.x < kVoteKeyStride) p.keyRec[(size_t)b * kVoteKeyStride + threadIdx.x] = keySh[threadIdx.x];
+        if (base >= r.n) return;
     }
     for (int j = threadIdx.x; j < kCsChunk; j += kCsBlock) {
         float k = kInf, px, py, pz;
-        if (base + j < r.n) k = sort_key(p, r, b, axis, base + j, px, py, pz);
+        if (base + j < r.n) k = sort_key(p, r, b, axis, vk, base + j, px, py, pz);
         key[j] = k;
         idx[j] = base + j;
     }
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(kCsBlock) void chunk_merge_kernel(ChunkSortParams p
     float *soa = nullptr;
     if (p.mode == 1) soa = r.moving ? (p.Xsoa ? p.Xsoa + (size_t)b * 3 * NP16 : nullptr) : p.Ysoa + (size_t)b * 3 * NP16;
     if (e >= r.n) {   // beyond the valid rows: padding of the consumer's layout
-        if (p.mode == 0) { if (e < p.N) out[e] = make_float4(0.f, 0.f, kInf, 0.f); }
+        if (p.mode == 0) { if (e < p.N) out[e] = make_float4(0.f, 0.f, kInf, kInf); }
         else if (soa != nullptr && e < NP16) { soa[e] = kInf; soa[NP16 + e] = kInf; soa[2 * NP16 + e] = kInf; }
         return;
     }
@@ -191,12 +202,14 @@ __global__ __launch_bounds__(kCsBlock) void chunk_merge_kernel(ChunkSortParams p
     }
     if (p.mode == 0) {
         // rows whose flag is not set carry +inf keys and sort behind the valid ones: emitted as invalid rows
-        out[rank] = key < kInf ? r.cloud[id] : make_float4(0.f, 0.f, kInf, 0.f);
+        float4 o = make_float4(0.f, 0.f, kInf, kInf);
+        if (key < kInf) { o = r.cloud[id]; o.w = key; }   // the sort key rides in w (votekey.hpp)
+        out[rank] = o;
         return;
     }
     const int axis = p.axisOut[b];
     float px, py, pz;
-    (void)sort_key(p, r, b, axis, id, px, py, pz);
+    (void)sort_key(p, r, b, axis, VoteKey{}, id, px, py, pz);
     out[rank] = make_float4(px, py, pz, __int_as_float(id));
     if (soa != nullptr) { soa[rank] = px; soa[NP16 + rank] = py; soa[2 * NP16 + rank] = pz; }
 }
@@ -214,12 +227,12 @@ int chunk_sort_length(int N) { return (N + kCsChunk - 1) / kCsChunk * kCsChunk; 
 
 hipError_t launch_zsort_chunked(const float *P, const float *Q, const int32_t *nP, const int32_t *nQ, int B, int N,
                                 float *outP, float *outQ, uint32_t *bins, int L, float *ckey, int *cidx,
-                                hipStream_t s)
+                                const float *ez, int len_z, float *keyRec, hipStream_t s)
 {
     ChunkSortParams p{};
     p.mode = 0; p.P = (const float4 *)P; p.Q = (const float4 *)Q; p.nP = nP; p.nQ = nQ; p.N = N;
     p.NPc = chunk_sort_length(N); p.ckey = ckey; p.cidx = cidx; p.outP = (float4 *)outP; p.outQ = (float4 *)outQ;
-    p.bins = bins; p.L = L;
+    p.bins = bins; p.L = L; p.ez = ez; p.len_z = len_z; p.keyRec = keyRec;
     return run_chunk_sort(p, B, s);
 }
 
