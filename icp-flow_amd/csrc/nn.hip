@@ -303,20 +303,17 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         const float *key = stage ? keyLds : gkey;
         // slack: rounding of src + t (an ulp of the coordinates) and of the window arithmetic
         const float slack = 1e-4f + 2e-6f * (fabsf(lo) + fabsf(hi) + fabsf(tu));
-        int j0, j1;
-        sorted_window(key, nt, lo - p.r0 - slack, hi + p.r0 + slack, lane, j0, j1);
-        int cb = (j0 / kChunk) * kChunk, ce = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
-        if (backward) scan_range_min_uniform<true>(tkx, tky, tkz, cb, ce, qx, qy, qz, tx, ty, tz, best);
-        else scan_range_min_uniform<false>(tkx, tky, tkz, cb, ce, qx, qy, qz, 0.f, 0.f, 0.f, best);
-        const float worst = wave_max_uniform(live ? best : 0.f);
-        if (worst > p.r0 * p.r0) {
-            int k0 = 0, k1 = np16;
-            if (worst < kInf) {
-                const float R = sqrtf(worst) * 1.000002f;
-                sorted_window(key, nt, lo - R - slack, hi + R + slack, lane, j0, j1);
-                k0 = (j0 / kChunk) * kChunk;
-                k1 = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
-            }
+        // Grow the window until it provably holds every lane's nearest neighbour: scan the targets within
+        // r of the wave's queries along u (only the parts not scanned yet); if every lane's minimum is
+        // within r, done.  Otherwise the largest minimum R bounds every NN distance -- one more round with
+        // r = R settles it -- unless some lane has not seen any target yet (r quadruples: a query beyond the
+        // end of the other cloud must not cost a scan of the whole cloud).
+        int cb = 0, ce = 0;          // chunk range scanned so far
+        float r = p.r0;
+        for (int round = 0; round < 24; ++round) {
+            int j0, j1;
+            sorted_window(key, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
+            const int k0 = (j0 / kChunk) * kChunk, k1 = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
             if (ce <= cb) { cb = k0; ce = k0; }   // nothing scanned yet
             if (backward) {
                 scan_range_min_uniform<true>(tkx, tky, tkz, k0, min(cb, k1), qx, qy, qz, tx, ty, tz, best);
@@ -325,6 +322,10 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
                 scan_range_min_uniform<false>(tkx, tky, tkz, k0, min(cb, k1), qx, qy, qz, 0.f, 0.f, 0.f, best);
                 scan_range_min_uniform<false>(tkx, tky, tkz, max(ce, k0), k1, qx, qy, qz, 0.f, 0.f, 0.f, best);
             }
+            cb = min(cb, k0); ce = max(ce, k1);
+            const float worst = wave_max_uniform(live ? best : 0.f);
+            if (worst <= r * r || (cb == 0 && ce == np16)) break;   // proven, or everything scanned
+            r = (worst < kInf) ? sqrtf(worst) * 1.000002f : r * 4.0f;
         }
     }
     // sum of Euclidean NN distances of this block's queries (utils_helper.py:30, utils_hist.py:89-95)
