@@ -38,6 +38,7 @@ int hipfail(hipError_t e, const char *what)
 // 3 = sorted sweep (icp.hip)
 int g_icp_search = 0;
 int g_side_stream = 1;   // developer knob (ICPFLOW_SIDE_STREAM=0: everything on the caller's stream)
+int g_eval_sweep = 1;    // developer knob (ICPFLOW_EVAL_SWEEP=0 selects the all-pairs match_eval scans)
 int g_check_sweep = 1;   // developer knob (ICPFLOW_CHECK_SWEEP=0 selects the all-pairs roll-back check)
 int g_score_sweep = 1;   // developer knob (ICPFLOW_SCORE_SWEEP=0 selects the all-pairs scoring scan)
 int g_hist_sorted = 1;   // developer knob (ICPFLOW_HIST_SORTED=0 selects the all-pairs vote)
@@ -251,6 +252,8 @@ int icpflow_version(void)
         if (e && e[0] == '0') g_hist_sorted = 0;
         e = getenv("ICPFLOW_SIDE_STREAM");
         if (e && e[0] == '0') g_side_stream = 0;
+        e = getenv("ICPFLOW_EVAL_SWEEP");
+        if (e && e[0] == '0') g_eval_sweep = 0;
         e = getenv("ICPFLOW_CHECK_SWEEP");
         if (e && e[0] == '0') g_check_sweep = 0;
         e = getenv("ICPFLOW_SCORE_SWEEP");
@@ -535,6 +538,14 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
     launch_count_pair(d_pcd1, d_pcd2, B, N, w.lenA, w.lenC, nullptr, s);
+    // long clouds: both directions as sorted sweeps (the sort pays for itself above ~2000 points)
+    if (N > kScoreSweepMinN && N <= kMaxSortN && g_eval_sweep) {
+        ICPFLOW_TRY(launch_sort_clouds_soa(d_pcd1, d_pcd2, w.lenA, w.lenC, nullptr, B, N, &w.grid, s));
+        ICPFLOW_TRY(launch_sweep_eval(&w.grid, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.zsortA, w.partial, s));
+        ICPFLOW_TRY(launch_eval_epilogue(w.partial, sweep_qblocks(N), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
+                                         d_ratios, d_ious, d_translations, d_rotations, s));
+        return 0;
+    }
     ICPFLOW_TRY(launch_scan_eval(d_pcd1, d_pcd2, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.partial, s));
     ICPFLOW_TRY(launch_eval_epilogue(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
                                      d_ratios, d_ious, d_translations, d_rotations, s));

@@ -89,6 +89,8 @@ hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, in
 struct GridScratch;
 int scan_qblocks(int maxRows, int batch);
 int sweep_qblocks(int maxRows);
+hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const int32_t *len2, int B, int N,
+                             const float *pose, float thres, float *srcT, double *partial, hipStream_t s);
 hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
                               const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
                               const float *poseFinal, double *partial, hipStream_t s);

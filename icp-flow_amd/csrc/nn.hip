@@ -224,6 +224,10 @@ struct SweepParams {
     const float *X, *Y;     // [B,N,4] as passed to the registration (src, dst)
     const float *poseA, *poseB;   // [B,4,4] init pose and composed final pose
     int rawSorted;
+    // SWEEP_EVAL (match_eval): Asoa = pcd1 sorted (raw), Csoa = pcd2 sorted, srcT = pcd1 * T in pcd1's sorted
+    // order (transform_soa_kernel), poseA = T, thres = inlier threshold on the Euclidean distance
+    const float *srcT;
+    float thres;
     int N, NP16, njobs, qblocks;
     float r0;
     double *partial;        // [njobs, qblocks, kPartial]
@@ -231,12 +235,12 @@ struct SweepParams {
 
 constexpr int kSweepBlock = 256;
 constexpr int kSweepStage = 4096;   // sort keys staged in LDS up to this many targets
-enum SweepMode : int { SWEEP_SCORE = 0, SWEEP_CHECK = 1 };
+enum SweepMode : int { SWEEP_SCORE = 0, SWEEP_CHECK = 1, SWEEP_EVAL = 2 };
 
 template <int MODE>
 __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
 {
-    __shared__ double red[kSweepBlock / kWave];
+    __shared__ double red[(kSweepBlock / kWave) * kPartial];
     extern __shared__ __attribute__((aligned(16))) float keyLds[];   // the targets' sort keys (window searches)
     const int lin = blockIdx.x;
     const int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);   // XCD-aware: the 8 XCDs take 8 jobs
@@ -244,11 +248,17 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     if (job >= p.njobs) return;
     const int b = (MODE == SWEEP_SCORE) ? job / 12 : job >> 1;
     const int sub = (MODE == SWEEP_SCORE) ? job % 12 : (job & 1);
-    const bool backward = (MODE == SWEEP_SCORE) && (sub & 1);
+    const bool backward = (MODE == SWEEP_SCORE) ? (sub & 1) : (MODE == SWEEP_EVAL ? sub == 1 : false);
     const bool sw = p.swap != nullptr && p.swap[b] != 0;
     const int na = (sw ? p.lenC : p.lenA)[b], nc = (sw ? p.lenA : p.lenC)[b];
     const float *as = p.Asoa + (size_t)b * 3 * p.NP16, *cs = p.Csoa + (size_t)b * 3 * p.NP16;
-    const float *qs = backward ? cs : as, *ts = backward ? as : cs;
+    // queries come from qs; the scan reads ts; the window searches read the (exactly sorted) key row of ks
+    const float *qs = backward ? cs : as, *ts = backward ? as : cs, *ks = ts;
+    if (MODE == SWEEP_EVAL) {
+        const float *st = p.srcT + (size_t)b * 3 * p.NP16;
+        if (!backward) qs = st;            // src * T against dst
+        else { ts = st; ks = as; }          // dst against src * T, windows in the raw frame of src
+    }
     const int nq = backward ? nc : na, nt = backward ? na : nc;
     double *out = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -265,12 +275,18 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     const float tu = axis == 0 ? tx : (axis == 1 ? ty : tz);
     const int i = qb * kSweepBlock + wave * kWave + lane;
     const bool live = i < nq;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (live) {
-        if (MODE == SWEEP_SCORE) {
+    float qx = 0.f, qy = 0.f, qz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
+    float r = p.r0, shrink = 1.0f;   // shrink: the proof radius along u relative to the search radius
+    float cu = 0.f;                  // position of the query along u in the frame of the target keys
+    if (MODE == SWEEP_SCORE) {
+        if (live) {
             qx = qs[i]; qy = qs[p.NP16 + i]; qz = qs[2 * p.NP16 + i];
             if (!backward) { qx += tx; qy += ty; qz += tz; }     // the moved source cloud, as the reference forms it
-        } else {
+        }
+        cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
+        if (backward) cu -= tu;
+    } else if (MODE == SWEEP_CHECK) {
+        if (live) {
             // src role point i of the ICP's sorted order, moved by the init (sub 0) or final (sub 1) pose
             // exactly as transform_points_batch does (utils_icp.py:21,27-33)
             const float4 s4 = p.sortX[(size_t)b * p.N + i];
@@ -282,10 +298,31 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             const Affine pose = affine_from_pose((sub == 0 ? p.poseA : p.poseB) + (size_t)b * 16);
             affine_apply(pose, rx, ry, rz, qx, qy, qz);
         }
+        cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
+    } else {   // SWEEP_EVAL
+        if (live) {
+            qx = qs[i]; qy = qs[p.NP16 + i]; qz = qs[2 * p.NP16 + i];
+            if (!backward) { ox = as[i]; oy = as[p.NP16 + i]; oz = as[2 * p.NP16 + i]; }   // the untransformed src point
+        }
+        cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
+        if (backward) {
+            // the targets src * T are ordered by their RAW coordinate along u: look for the query where it
+            // sits in that frame, c' = R^T (c - t) (T rigid: distances are the same in both frames up to the
+            // rounding of R, covered by `shrink`); a non-rigid T makes the window the whole cloud
+            const float *M = p.poseA + (size_t)b * 16;
+            float dev = 0.f;
+#pragma unroll
+            for (int a0 = 0; a0 < 3; ++a0)
+#pragma unroll
+                for (int a1 = 0; a1 < 3; ++a1) {
+                    const float g = M[0 * 4 + a0] * M[0 * 4 + a1] + M[1 * 4 + a0] * M[1 * 4 + a1] + M[2 * 4 + a0] * M[2 * 4 + a1];
+                    dev = fmaxf(dev, fabsf(g - (a0 == a1 ? 1.f : 0.f)));
+                }
+            if (!(dev <= 1e-4f)) r = 3e37f;
+            shrink = 0.9995f;
+            cu = M[0 * 4 + axis] * (qx - M[3]) + M[1 * 4 + axis] * (qy - M[7]) + M[2 * 4 + axis] * (qz - M[11]);
+        }
     }
-    // position of the query along u in the frame of the (unshifted) target keys
-    float cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
-    if (backward) cu -= tu;
     const float lo = wave_min_uniform(live ? cu : kInf), hi = wave_max_uniform(live ? cu : -kInf);
     float best = kInf;
     const float *tkx = ts, *tky = ts + p.NP16, *tkz = ts + 2 * p.NP16;
@@ -293,7 +330,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     // window searches: keys staged in LDS while that is cheap (<= 16 KiB per workgroup), read from
     // global memory (L2) on long clouds, where staging the whole key array would cost more than the
     // two or three dependent probes of a search
-    const float *gkey = axis == 0 ? tkx : (axis == 1 ? tky : tkz);
+    const float *gkey = ks + (size_t)axis * p.NP16;
     const bool stage = np16 <= kSweepStage;
     if (stage) {
         for (int j = threadIdx.x; j < np16; j += kSweepBlock) keyLds[j] = gkey[j];
@@ -301,21 +338,20 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     }
     if (lo <= hi && nt > 0) {   // wave-uniform
         const float *key = stage ? keyLds : gkey;
-        // slack: rounding of src + t (an ulp of the coordinates) and of the window arithmetic
-        const float slack = 1e-4f + 2e-6f * (fabsf(lo) + fabsf(hi) + fabsf(tu));
+        // slack: rounding of src + t / of the inverse map (ulps of the coordinates) and of the window arithmetic
+        const float slack = (MODE == SWEEP_EVAL ? 2e-3f : 1e-4f) + (MODE == SWEEP_EVAL ? 2e-5f : 2e-6f) * (fabsf(lo) + fabsf(hi) + fabsf(tu));
         // Grow the window until it provably holds every lane's nearest neighbour: scan the targets within
         // r of the wave's queries along u (only the parts not scanned yet); if every lane's minimum is
         // within r, done.  Otherwise the largest minimum R bounds every NN distance -- one more round with
         // r = R settles it -- unless some lane has not seen any target yet (r quadruples: a query beyond the
         // end of the other cloud must not cost a scan of the whole cloud).
         int cb = 0, ce = 0;          // chunk range scanned so far
-        float r = p.r0;
         for (int round = 0; round < 24; ++round) {
             int j0, j1;
             sorted_window(key, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
             const int k0 = (j0 / kChunk) * kChunk, k1 = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
             if (ce <= cb) { cb = k0; ce = k0; }   // nothing scanned yet
-            if (backward) {
+            if (MODE == SWEEP_SCORE && backward) {
                 scan_range_min_uniform<true>(tkx, tky, tkz, k0, min(cb, k1), qx, qy, qz, tx, ty, tz, best);
                 scan_range_min_uniform<true>(tkx, tky, tkz, max(ce, k0), k1, qx, qy, qz, tx, ty, tz, best);
             } else {
@@ -324,21 +360,52 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             }
             cb = min(cb, k0); ce = max(ce, k1);
             const float worst = wave_max_uniform(live ? best : 0.f);
-            if (worst <= r * r || (cb == 0 && ce == np16)) break;   // proven, or everything scanned
-            r = (worst < kInf) ? sqrtf(worst) * 1.000002f : r * 4.0f;
+            const float proven = r * shrink;
+            if (worst <= proven * proven || (cb == 0 && ce == np16)) break;   // proven, or everything scanned
+            r = (worst < kInf) ? sqrtf(worst) * (MODE == SWEEP_EVAL ? 1.001f : 1.000002f) : r * 4.0f;
         }
     }
-    // sum of Euclidean NN distances of this block's queries (utils_helper.py:30, utils_hist.py:89-95)
-    double v = (live && nt > 0) ? (double)sqrtf(best) : 0.0;
-    v = wave_sum(v);
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ssum = red[0];
-        for (int w = 1; w < kSweepBlock / kWave; ++w) ssum += red[w];
-        out[0] = ssum;
-        for (int q = 1; q < kPartial; ++q) out[q] = 0.0;
+    // masked sums over this block's queries: sum of Euclidean NN distances (utils_helper.py:30,
+    // utils_hist.py:89-95); match_eval adds inlier counts and, forward, the centroids (utils_match.py:168-181)
+    double v[kPartial];
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) v[k] = 0.0;
+    if (live && nt > 0) {
+        const float d = sqrtf(best);
+        v[0] = (double)d;
+        if (MODE == SWEEP_EVAL) {
+            v[1] = (d < p.thres) ? 1.0 : 0.0;  // utils_match.py:168 (strict <)
+            if (!backward) { v[2] = qx; v[3] = qy; v[4] = qz; v[5] = ox; v[6] = oy; v[7] = oz; }
+        }
     }
+    constexpr int NV = (MODE == SWEEP_EVAL) ? kPartial : 1;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0)
+        for (int k = 0; k < NV; ++k) red[wave * kPartial + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < kPartial) {
+        double ssum = 0.0;
+        if (threadIdx.x < NV)
+            for (int w = 0; w < kSweepBlock / kWave; ++w) ssum += red[w * kPartial + threadIdx.x];
+        out[threadIdx.x] = ssum;
+    }
+}
+
+// pcd1 * T in pcd1's sorted order, as transform_points_batch forms it (utils_match.py:162), +inf padded
+__global__ void transform_soa_kernel(const float *__restrict__ soa, const int32_t *__restrict__ len,
+                                     const float *__restrict__ pose, int NP16, float *__restrict__ out)
+{
+    const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= NP16) return;
+    const float *in = soa + (size_t)b * 3 * NP16;
+    float *o = out + (size_t)b * 3 * NP16;
+    float x = kInf, y = kInf, z = kInf;
+    if (k < len[b]) {
+        const Affine a = affine_from_pose(pose + (size_t)b * 16);
+        affine_apply(a, in[k], in[NP16 + k], in[2 * NP16 + k], x, y, z);
+    }
+    o[k] = x; o[NP16 + k] = y; o[2 * NP16 + k] = z;
 }
 
 int sweep_qblocks(int maxRows) { return (maxRows + kSweepBlock - 1) / kSweepBlock; }
@@ -362,6 +429,20 @@ hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, cons
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.njobs = B * 12; p.partial = partial;
     return launch_sweep<SWEEP_SCORE>(p, s);
+}
+
+// match_eval (utils_match.py:159-213) on clouds sorted by launch_sort_clouds_soa(pcd1, pcd2, no swap);
+// srcT: scratch of B * 3 * NP16 floats (+ 64 of slack)
+hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const int32_t *len2, int B, int N,
+                             const float *pose, float thres, float *srcT, double *partial, hipStream_t s)
+{
+    SweepParams p{};
+    p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = len1; p.lenC = len2; p.axis = grid->axis;
+    p.poseA = pose; p.thres = thres; p.srcT = srcT; p.N = N; p.njobs = B * 2; p.partial = partial;
+    const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
+    hipLaunchKernelGGL(transform_soa_kernel, dim3((NP16 + 255) / 256, B), dim3(256), 0, s, grid->sortXsoa, len1, pose,
+                       NP16, srcT);
+    return launch_sweep<SWEEP_EVAL>(p, s);
 }
 
 // roll-back check (utils_icp.py:27-33): mean NN distance of the src role under the init pose and under

@@ -180,33 +180,39 @@ hipError_t launch_select(const double *partial, int qblocks, const int32_t *lenA
 }
 
 // match_eval epilogue (utils_match.py:168-184)
-__global__ void eval_epilogue_kernel(const double *__restrict__ partial, int qblocks,
-                                     const int32_t *__restrict__ len1, const int32_t *__restrict__ len2,
-                                     const float *__restrict__ T, int B, float *__restrict__ errors,
-                                     float *__restrict__ inliers, float *__restrict__ ratios,
-                                     float *__restrict__ ious, float *__restrict__ translations,
-                                     float *__restrict__ rotations)
+// one wave per pair: lane j < 16 totals column j % 8 of job j / 8 (forward, backward) over the query blocks
+__global__ __launch_bounds__(kWave) void eval_epilogue_kernel(const double *__restrict__ partial, int qblocks,
+                                                              const int32_t *__restrict__ len1,
+                                                              const int32_t *__restrict__ len2,
+                                                              const float *__restrict__ T, int B,
+                                                              float *__restrict__ errors, float *__restrict__ inliers,
+                                                              float *__restrict__ ratios, float *__restrict__ ious,
+                                                              float *__restrict__ translations,
+                                                              float *__restrict__ rotations)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int j1 = b * 2, j2 = b * 2 + 1;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double tot = 0.0;
+    if (lane < 2 * kPartial) tot = partial_total(partial, b * 2 + lane / kPartial, qblocks, lane % kPartial);
     const float n1 = (float)len1[b], n2 = (float)len2[b];
     const float n12 = (float)(len1[b] + len2[b]);
-    const float in1 = (float)partial_total(partial, j1, qblocks, 1);
-    const float in2 = (float)partial_total(partial, j2, qblocks, 1);
-    errors[b * 2 + 0] = (float)partial_total(partial, j1, qblocks, 0) / n1;  // :177
-    errors[b * 2 + 1] = (float)partial_total(partial, j2, qblocks, 0) / n2;  // :178
+    const float sum1 = (float)__shfl(tot, 0, kWave), sum2 = (float)__shfl(tot, kPartial, kWave);
+    const float in1 = (float)__shfl(tot, 1, kWave), in2 = (float)__shfl(tot, kPartial + 1, kWave);
+    float moved[3], orig[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        moved[k] = (float)__shfl(tot, 2 + k, kWave) / n1;   // :180
+        orig[k] = (float)__shfl(tot, 5 + k, kWave) / n1;    // :181
+    }
+    if (lane != 0) return;
+    errors[b * 2 + 0] = sum1 / n1;                                           // :177
+    errors[b * 2 + 1] = sum2 / n2;                                           // :178
     inliers[b * 2 + 0] = in1;
     inliers[b * 2 + 1] = in2;
     ratios[b * 2 + 0] = in1 / n1;                                            // :171
     ratios[b * 2 + 1] = in2 / n2;                                            // :172
     ious[b * 2 + 0] = in1 / (n12 - in2);                                     // :174
     ious[b * 2 + 1] = in2 / (n12 - in1);                                     // :175
-    for (int k = 0; k < 3; ++k) {
-        const float moved = (float)partial_total(partial, j1, qblocks, 2 + k) / n1;  // :180
-        const float orig = (float)partial_total(partial, j1, qblocks, 5 + k) / n1;   // :181
-        translations[b * 3 + k] = moved - orig;                                      // :183
-    }
+    for (int k = 0; k < 3; ++k) translations[b * 3 + k] = moved[k] - orig[k];  // :183
     const float *M = T + (size_t)b * 16;
     // pytorch3d matrix_to_euler_angles(M[0:3,0:3], 'ZYX'), then * 180. / np.pi  (:184)
     const float pi = 3.14159265358979323846f;
@@ -220,8 +226,8 @@ hipError_t launch_eval_epilogue(const double *partial, int qblocks, const int32_
                                 float *inliers, float *ratios, float *ious, float *translations,
                                 float *rotations, hipStream_t s)
 {
-    hipLaunchKernelGGL(eval_epilogue_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, qblocks, len1,
-                       len2, T, B, errors, inliers, ratios, ious, translations, rotations);
+    hipLaunchKernelGGL(eval_epilogue_kernel, dim3(B), dim3(kWave), 0, s, partial, qblocks, len1, len2, T, B, errors,
+                       inliers, ratios, ious, translations, rotations);
     return hipGetLastError();
 }
 

@@ -474,6 +474,18 @@ def test_hist_icp_real_data_shape_large_padding():
     wv = rp.match_eval(a, C(S), C(D), got.cpu())
     np.testing.assert_allclose(ev[0].cpu().numpy(), wv[0].numpy(), atol=1e-5, rtol=1e-4)
     np.testing.assert_array_equal(ev[1].cpu().numpy(), wv[1].numpy())
+    np.testing.assert_allclose(ev[2].cpu().numpy(), wv[2].numpy(), atol=1e-6)       # ratios
+    np.testing.assert_allclose(ev[3].cpu().numpy(), wv[3].numpy(), atol=1e-6)       # ious
+    np.testing.assert_allclose(ev[4].cpu().numpy(), wv[4].numpy(), atol=2e-4)       # translations (fp32 centroids at ~40 m)
+    np.testing.assert_allclose(ev[5].cpu().numpy(), wv[5].numpy(), atol=1e-4)       # Euler angles, degrees
+    # a non-rigid "transform" (scaled): the backward windows cannot be trusted and must fall back to the
+    # whole cloud -- same numbers as the oracle again
+    Tn = got.clone()
+    Tn[:, 0:3, 0:3] *= 1.05
+    ev2 = utils_match.match_eval(a, G(S), G(D), Tn)
+    wv2 = rp.match_eval(a, C(S), C(D), Tn.cpu())
+    np.testing.assert_allclose(ev2[0].cpu().numpy(), wv2[0].numpy(), atol=1e-5, rtol=1e-4)
+    np.testing.assert_array_equal(ev2[1].cpu().numpy(), wv2[1].numpy())
 
 
 # ------------------------------------------------------------------ 8(f): association + flow on the demo frame
