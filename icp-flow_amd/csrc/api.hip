@@ -168,10 +168,12 @@ int check_hist_dims(const char *fn, int lx, int ly, int lz)
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
     bool ok = false;
-    SideStream()
+    void create()
     {
-        ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+        ok = hipGetDevice(&device) == hipSuccess &&
+             hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
     }
@@ -180,6 +182,12 @@ struct SideStream {
 SideStream &side_stream()
 {
     static thread_local SideStream s;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { s.ok = false; return s; }
+    if (s.device != dev) {   // first use on this thread, or the thread moved to another GPU
+        s = SideStream{};
+        s.create();
+    }
     return s;
 }
 
