@@ -142,8 +142,6 @@ hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const floa
                                       hipStream_t s);
 
 // pose.hip
-hipError_t launch_swap_flags(const int32_t *lenSrc, const int32_t *lenDst, int B, uint8_t *swap,
-                             hipStream_t s);
 hipError_t launch_decode_candidates(const int64_t *peakIdx, int B, const float *ex, const float *ey,
                                     const float *ez, int Lx, int Ly, int Lz, float shift, float *cand,
                                     hipStream_t s);

@@ -8,21 +8,6 @@
 
 namespace icpflow {
 
-// swap[b] = n_src > n_dst  (strict; utils_match.py:142)
-__global__ void swap_flags_kernel(const int32_t *__restrict__ ls, const int32_t *__restrict__ ld, int B,
-                                  uint8_t *__restrict__ swap)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) swap[b] = ls[b] > ld[b] ? 1 : 0;
-}
-
-hipError_t launch_swap_flags(const int32_t *lenSrc, const int32_t *lenDst, int B, uint8_t *swap,
-                             hipStream_t s)
-{
-    hipLaunchKernelGGL(swap_flags_kernel, dim3((B + 255) / 256), dim3(256), 0, s, lenSrc, lenDst, B, swap);
-    return hipGetLastError();
-}
-
 // flat peak index -> translation (left bin edges + shift), zero translation LAST
 // (utils_hist.py:78, :83)
 __global__ void decode_candidates_kernel(const int64_t *__restrict__ peakIdx, int B,
