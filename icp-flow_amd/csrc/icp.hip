@@ -1170,7 +1170,7 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
 }
 
 // Team sizes for one launch: every pair gets one workgroup, the spare ones go to the pairs whose
-// moving cloud needs more than one pass of a workgroup (1024 queries), in proportion to the excess;
+// moving cloud needs more than one pass of a workgroup (768 queries), in proportion to the excess;
 // a member keeps at least 256 queries.  One block; B <= 256.
 __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__restrict__ lenX,
                                                             const int32_t *__restrict__ lenY,
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     const int b = threadIdx.x;
     int n = 0;
     if (b < B) n = (swap != nullptr && swap[b] != 0) ? lenY[b] : lenX[b];
-    size[b] = max(n - 1024, 0);
+    size[b] = max(n - 768, 0);   // queries beyond one pass of a (768-thread) workgroup
     for (int w = threadIdx.x; w < t.maxWG; w += blockDim.x) { t.wgPair[w] = -1; t.wgRank[w] = 0; }
     __syncthreads();
     if (b == 0) {
@@ -1318,7 +1318,7 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.N <= 512) launch_icp_variant<512, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.team.wgPair != nullptr) {   // several workgroups per large pair (N > 1024)
-            if (p.N <= 12288) launch_icp_variant<1024, 1, 1, 4, true>(p, B, itBegin, itEnd, s);
+            if (p.N <= 12288) launch_icp_variant<768, 1, 1, 4, true>(p, B, itBegin, itEnd, s);
             else launch_icp_variant<1024, 1, 1, 3, true>(p, B, itBegin, itEnd, s);
         }
         // 768 threads = 12 waves = 3 per SIMD: 170 VGPRs per lane, which the kernel fits without spills
