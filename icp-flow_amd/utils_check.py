@@ -94,6 +94,20 @@ def _sanity_mask(args, st, dt, pairs):
     return ok
 
 
+def sanity_grid(args, st, dt, si, di):
+    """The same test for every combination of source clusters `si` and destination clusters `di` (rows of
+    the tables): -> bool [len(si), len(di)].  Stage 2 of match_pcds tests all remaining sources against all
+    remaining destinations (utils_match.py:45-53); on the grid the per-cluster numbers broadcast instead of
+    being gathered for each of the S x D candidate rows."""
+    ok = (np.minimum(st.h_count[si][:, None], dt.h_count[di][None, :]) >= args.min_cluster_size)      # :31
+    ok &= (st.h_labels[si] >= 0)[:, None] & (dt.h_labels[di] >= 0)[None, :]                            # :32
+    dxy = dt.h_mean[di][None, :, 0:2] - st.h_mean[si][:, None, 0:2]
+    ok &= ~(np.sqrt(dxy[:, :, 0] * dxy[:, :, 0] + dxy[:, :, 1] * dxy[:, :, 1]) > np.float32(args.translation_frame))   # :36
+    es, ed = st.h_extent[si][:, None, :], dt.h_extent[di][None, :, :]
+    ok &= ~(np.minimum(es, ed) < np.float32(args.thres_box) * np.maximum(es, ed)).any(axis=2)           # :41-43
+    return ok
+
+
 def sanity_check(args, src_table, dst_table, pairs):
     """utils_check.py:21-49 for all candidate `pairs` [K,2] at once -> the surviving rows, in order.
     A pair survives iff both clusters exist with >= min_cluster_size points, both labels are >= 0,

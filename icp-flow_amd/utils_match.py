@@ -3,7 +3,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .utils_check import ClusterTable, _sanity_mask, check_transformation, sanity_check
+from .utils_check import ClusterTable, _sanity_mask, check_transformation, sanity_check, sanity_grid
 from .utils_hist import bin_edges
 from .utils_icp import _icp_options
 
@@ -154,8 +154,11 @@ def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
         if len(pairs_sta) > 0:
             src_unq = setdiff1d(src_unq, pairs_sta[:, 0].astype(np.int64))
             dst_unq = setdiff1d(dst_unq, pairs_sta[:, 1].astype(np.int64))
-        pairs = np.stack([np.repeat(src_unq, len(dst_unq)), np.tile(dst_unq, len(src_unq))], axis=1).astype(np.float32)
-        pairs_true = pairs[_sanity_mask(args, st, dt, pairs)] if len(pairs) else pairs.reshape(0, 2)
+        # every remaining source against every remaining destination (:45-53), tested on the S x D grid;
+        # surviving candidates in the reference's order (source-major)
+        si, di = st.find_host(src_unq.astype(np.float32)), dt.find_host(dst_unq.astype(np.float32))
+        rs, rd = np.nonzero(sanity_grid(args, st, dt, si, di)) if len(si) and len(di) else (si[:0], di[:0])
+        pairs_true = np.stack([src_unq[rs], dst_unq[rd]], axis=1).astype(np.float32).reshape(-1, 2)
     else:
         pairs_true = pairs[:0]
     pairs_dyn, T_dyn = _match_pairs_host(args, st, dt, pairs_true) if len(pairs_true) > 0 else empty
