@@ -488,6 +488,31 @@ def test_hist_icp_real_data_shape_large_padding():
     np.testing.assert_array_equal(ev2[1].cpu().numpy(), wv2[1].numpy())
 
 
+def test_hist_icp_beyond_the_lds_image_and_beyond_the_sorts():
+    """Padded lengths above 12288 (the sorted fixed cloud no longer fits LDS: scalar-load sweep) and above
+    16384 (no sorts at all: all-pairs vote, scans and ICP search) must give the registration of the same
+    clouds padded to 4096 -- every path is exact, only fp64 summation orders differ."""
+    sizes = [(3000, 2600), (700, 900), (4000, 4000)]
+    a = rp.default_args(icp_max_iterations=20)
+    out = {}
+    for N in (4096, 13000, 20000):
+        S = np.empty((len(sizes), N, 4), np.float32)
+        D = np.empty((len(sizes), N, 4), np.float32)
+        for i, (ns, nd) in enumerate(sizes):
+            S[i], D[i], _ = synthetic.make_pair(2 * i, ns, nd, N, seed=1234)
+        a.max_points = N
+        T, it = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+        ev = utils_match.match_eval(a, G(S), G(D), T)
+        out[N] = (T.cpu().numpy(), int(it), [e.cpu().numpy() for e in ev], S[:, :4096].copy())
+    base = out[4096]
+    for N in (13000, 20000):
+        T, it, ev, _ = out[N]
+        assert it == base[1]
+        assert_pose_close(T, base[0], base[3], tol=2e-5)
+        np.testing.assert_array_equal(ev[1], base[2][1])                       # inlier counts
+        np.testing.assert_allclose(ev[0], base[2][0], atol=1e-6)               # mean errors
+
+
 # ------------------------------------------------------------------ 8(f): association + flow on the demo frame
 def test_demo_frame_pair_track_and_flow_vs_reference():
     """BASELINE config 1 (G8): demo.npz frame pair through the HIP path -- match_pcds (both stages:
