@@ -124,8 +124,9 @@ _ws_cache = {}
 
 
 def workspace(device, nbytes):
-    """A cached, grow-only scratch buffer per device (torch caching-allocator owned)."""
-    key = (device.type, device.index)
+    """A cached, grow-only scratch buffer per (device, current stream): calls issued on different streams
+    may overlap on the GPU and must not share scratch (torch caching-allocator owned)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

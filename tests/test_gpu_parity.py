@@ -513,6 +513,45 @@ def test_hist_icp_beyond_the_lds_image_and_beyond_the_sorts():
         np.testing.assert_allclose(ev[0], base[2][0], atol=1e-6)               # mean errors
 
 
+def test_hist_icp_under_stream_capture_and_on_two_streams():
+    """The fused registration can be captured into a HIP graph (the private side stream of the axis sort
+    forks from and joins the capturing stream) and replayed with identical results; two streams running
+    registrations concurrently do not share scratch."""
+    S, D, _ = synthetic.make_batch(64, 512, seed=3)
+    a = rp.default_args(max_points=512, icp_max_iterations=30)
+    src, dst = G(S), G(D)
+    want = utils_match.hist_icp(a, src, dst).clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            utils_match.hist_icp(a, src, dst)       # warm-up on the capturing stream (allocations, attributes)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = utils_match.hist_icp(a, src, dst)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    # two streams, interleaved calls, different inputs
+    S2, D2, _ = synthetic.make_batch(64, 512, seed=4)
+    src2, dst2 = G(S2), G(D2)
+    want2 = utils_match.hist_icp(a, src2, dst2).clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    res = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            r1 = utils_match.hist_icp(a, src, dst)
+        with torch.cuda.stream(s2):
+            r2 = utils_match.hist_icp(a, src2, dst2)
+        res.append((r1, r2))
+    torch.cuda.synchronize()
+    for r1, r2 in res:
+        assert torch.equal(r1, want) and torch.equal(r2, want2)
+
+
 # ------------------------------------------------------------------ 8(f): association + flow on the demo frame
 def test_demo_frame_pair_track_and_flow_vs_reference():
     """BASELINE config 1 (G8): demo.npz frame pair through the HIP path -- match_pcds (both stages:
