@@ -199,8 +199,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     const GridScratch *search = search_scratch(w, N);
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
                            w.state, w.ctrl, search, w.history, &w.team, s));
-    if (iters) ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stopMode, nullptr, nullptr, nullptr, iters, nullptr, s));
-    ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s));
+    ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s, w.ctrl, iters));   // also reports the iteration count
     // roll-back check: sweeps over the sorted clouds the ICP left behind, or the all-pairs scan
     if (search != nullptr && search->mode == 3 && g_check_sweep) {
         ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
@@ -227,9 +226,10 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
                                             w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s));
     else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
+    PeakDecode dec;
+    dec.ex = ex; dec.ey = ey; dec.ez = ez; dec.shift = shift; dec.cand = w.cand;   // peaks -> 6 candidate translations
     ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,
-                                      w.peakVotes, w.peakIdx, s));
-    ICPFLOW_TRY(launch_decode_candidates(w.peakIdx, B, ex, ey, ez, lx, ly, lz, shift, w.cand, s));
+                                      w.peakVotes, w.peakIdx, s, dec));
     // candidate scoring: sorted sweep while the sort fits LDS, all-pairs scan otherwise (same sums)
     if (N > kScoreSweepMinN && N <= kMaxSortN && g_score_sweep) {
         if (joinBefore != nullptr) {

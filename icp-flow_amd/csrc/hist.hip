@@ -478,7 +478,7 @@ template <typename BinT, int MEM>
 __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
     const BinT *__restrict__ bins, int Lx, int Ly, int Lz, int k, int radius,
     uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB, float *__restrict__ votes,
-    int64_t *__restrict__ idx_out)
+    int64_t *__restrict__ idx_out, PeakDecode dec)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[kPeakBlock / kWave];
@@ -544,7 +544,16 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
             for (int q = 1; q < kPeakBlock / kWave; ++q) m = red[q] > m ? red[q] : m;
             chosen[r] = m;
             votes[(size_t)b * k + r] = (float)(uint32_t)(m >> 32);
-            idx_out[(size_t)b * k + r] = (int64_t)(0xFFFFFFFFu - (uint32_t)(m & 0xFFFFFFFFull));
+            const uint32_t f = 0xFFFFFFFFu - (uint32_t)(m & 0xFFFFFFFFull);
+            idx_out[(size_t)b * k + r] = (int64_t)f;
+            if (dec.cand != nullptr) {
+                // fused path: flat peak index -> candidate translation (left bin edges + shift,
+                // utils_hist.py:78); the zero translation goes LAST (:83)
+                float *o = dec.cand + ((size_t)b * (k + 1) + r) * 3;
+                const int ix = (int)(f / Lz / Ly % Lx), iy = (int)(f / Lz % Ly), iz = (int)(f % Lz);
+                o[0] = dec.ex[ix] + dec.shift; o[1] = dec.ey[iy] + dec.shift; o[2] = dec.ez[iz] + dec.shift;
+                if (r == k - 1) { o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; }
+            }
         }
         __syncthreads();
     }
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
 template <typename BinT>
 static hipError_t launch_peaks_t(const BinT *bins, int B, int Lx, int Ly, int Lz, int k,
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
-                                 int64_t *idx, hipStream_t s)
+                                 int64_t *idx, PeakDecode dec, hipStream_t s)
 {
     const size_t lds = 3 * sizeof(uint32_t) * (size_t)Lx * Ly * Lz;
     if (lds <= 150 * 1024) {
@@ -564,10 +573,10 @@ static hipError_t launch_peaks_t(const BinT *bins, int B, int Lx, int Ly, int Lz
             attr = true;
         }
         hipLaunchKernelGGL((hist_peaks_kernel<BinT, 1>), dim3(B), dim3(kPeakBlock), lds, s, bins, Lx, Ly, Lz, k,
-                           (kernel_size - 1) / 2, wsA, wsB, votes, idx);
+                           (kernel_size - 1) / 2, wsA, wsB, votes, idx, dec);
     } else {
         hipLaunchKernelGGL((hist_peaks_kernel<BinT, 0>), dim3(B), dim3(kPeakBlock), 0, s, bins, Lx, Ly, Lz, k,
-                           (kernel_size - 1) / 2, wsA, wsB, votes, idx);
+                           (kernel_size - 1) / 2, wsA, wsB, votes, idx, dec);
     }
     return hipGetLastError();
 }
@@ -576,14 +585,14 @@ hipError_t launch_hist_peaks_f32(const float *bins, int B, int Lx, int Ly, int L
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
                                  int64_t *idx, hipStream_t s)
 {
-    return launch_peaks_t<float>(bins, B, Lx, Ly, Lz, k, kernel_size, wsA, wsB, votes, idx, s);
+    return launch_peaks_t<float>(bins, B, Lx, Ly, Lz, k, kernel_size, wsA, wsB, votes, idx, PeakDecode{}, s);
 }
 
 hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, int Lz, int k,
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
-                                 int64_t *idx, hipStream_t s)
+                                 int64_t *idx, hipStream_t s, PeakDecode dec)
 {
-    return launch_peaks_t<uint32_t>(bins, B, Lx, Ly, Lz, k, kernel_size, wsA, wsB, votes, idx, s);
+    return launch_peaks_t<uint32_t>(bins, B, Lx, Ly, Lz, k, kernel_size, wsA, wsB, votes, idx, dec, s);
 }
 
 }  // namespace icpflow

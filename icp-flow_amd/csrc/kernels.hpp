@@ -81,9 +81,15 @@ hipError_t launch_u32_to_f32(const uint32_t *in, float *out, size_t n, hipStream
 hipError_t launch_hist_peaks_f32(const float *bins, int B, int Lx, int Ly, int Lz, int k,
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
                                  int64_t *idx, hipStream_t s);
+// optional fused decode of the peaks into candidate translations [B, k + 1, 3] (zero translation last)
+struct PeakDecode {
+    const float *ex = nullptr, *ey = nullptr, *ez = nullptr;
+    float shift = 0.f;
+    float *cand = nullptr;
+};
 hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, int Lz, int k,
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
-                                 int64_t *idx, hipStream_t s);
+                                 int64_t *idx, hipStream_t s, PeakDecode dec = PeakDecode{});
 
 // nn.hip
 struct GridScratch;
@@ -142,13 +148,11 @@ hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const floa
                                       hipStream_t s);
 
 // pose.hip
-hipError_t launch_decode_candidates(const int64_t *peakIdx, int B, const float *ex, const float *ey,
-                                    const float *ez, int Lx, int Ly, int Lz, float shift, float *cand,
-                                    hipStream_t s);
 hipError_t launch_score_pick(const double *partial, int qblocks, const int32_t *lenA,
                              const int32_t *lenC, const uint8_t *swap, const float *cand, int B,
                              float *Tinit, hipStream_t s);
-hipError_t launch_compose(const IcpState *state, const float *init, int B, float *M, hipStream_t s);
+hipError_t launch_compose(const IcpState *state, const float *init, int B, float *M, hipStream_t s,
+                          const IcpCtrl *ctrl = nullptr, int32_t *iters = nullptr);
 hipError_t launch_select(const double *partial, int qblocks, const int32_t *lenA, const int32_t *lenC,
                          const uint8_t *swap, const float *init, const float *M, int B, int invertSwapped,
                          float *out, hipStream_t s);

@@ -8,35 +8,6 @@
 
 namespace icpflow {
 
-// flat peak index -> translation (left bin edges + shift), zero translation LAST
-// (utils_hist.py:78, :83)
-__global__ void decode_candidates_kernel(const int64_t *__restrict__ peakIdx, int B,
-                                         const float *__restrict__ ex, const float *__restrict__ ey,
-                                         const float *__restrict__ ez, int Lx, int Ly, int Lz,
-                                         float shift, float *__restrict__ cand)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * kCand) return;
-    const int b = t / kCand, k = t % kCand;
-    float *o = cand + (size_t)t * 3;
-    if (k == kCand - 1) { o[0] = o[1] = o[2] = 0.f; return; }
-    const int64_t f = peakIdx[(size_t)b * kTopK + k];
-    const int ix = (int)(f / Lz / Ly % Lx), iy = (int)(f / Lz % Ly), iz = (int)(f % Lz);
-    o[0] = ex[ix] + shift;
-    o[1] = ey[iy] + shift;
-    o[2] = ez[iz] + shift;
-}
-
-hipError_t launch_decode_candidates(const int64_t *peakIdx, int B, const float *ex, const float *ey,
-                                    const float *ez, int Lx, int Ly, int Lz, float shift, float *cand,
-                                    hipStream_t s)
-{
-    const int n = B * kCand;
-    hipLaunchKernelGGL(decode_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, s, peakIdx, B, ex, ey,
-                       ez, Lx, Ly, Lz, shift, cand);
-    return hipGetLastError();
-}
-
 __device__ __forceinline__ double partial_total(const double *partial, int job, int qblocks, int k)
 {
     double s = 0.0;
@@ -87,9 +58,10 @@ hipError_t launch_score_pick(const double *partial, int qblocks, const int32_t *
 
 // M = [[R^T, T],[0 0 0 1]] * init   (utils_icp.py:60-65, :24; fp32 bmm order)
 __global__ void compose_kernel(const IcpState *__restrict__ st, const float *__restrict__ init, int B,
-                               float *__restrict__ M)
+                               float *__restrict__ M, const IcpCtrl *__restrict__ ctrl, int32_t *__restrict__ iters)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && iters != nullptr) *iters = ctrl->iters;   // iterations of the batch (what icp_export reports)
     if (b >= B) return;
     float A[16];
     for (int i = 0; i < 3; ++i) {
@@ -109,9 +81,10 @@ __global__ void compose_kernel(const IcpState *__restrict__ st, const float *__r
         }
 }
 
-hipError_t launch_compose(const IcpState *state, const float *init, int B, float *M, hipStream_t s)
+hipError_t launch_compose(const IcpState *state, const float *init, int B, float *M, hipStream_t s,
+                          const IcpCtrl *ctrl, int32_t *iters)
 {
-    hipLaunchKernelGGL(compose_kernel, dim3((B + 127) / 128), dim3(128), 0, s, state, init, B, M);
+    hipLaunchKernelGGL(compose_kernel, dim3((B + 127) / 128), dim3(128), 0, s, state, init, B, M, ctrl, iters);
     return hipGetLastError();
 }
 
