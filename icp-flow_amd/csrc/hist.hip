@@ -93,9 +93,10 @@ __device__ __forceinline__ AxisQuot axis_quot_make(float mn, float mx)
     return d;
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ float axis_quot(float a, const AxisQuot &d)
 {
-    if (!d.fast) return a / d.r;   // wave-uniform
+    if (!FAST && !d.fast) return a / d.r;   // wave-uniform
     const float q0 = a * d.y1;
     const float e1 = fmaf(-d.r, q0, a);
     const float q1 = fmaf(e1, d.y1, q0);
@@ -268,6 +269,40 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
     }
 }
 
+// The votes of one X row (per lane) against the staged targets [r0, r1) (wave-uniform bounds): the exact
+// box test and bin arithmetic of hist_cuda_core.cuh:44-60.  FAST: all three quotients take the hoisted
+// division and the bin index fits 24-bit multiplies (decided once per launch); LDS_HIST: counters in LDS.  Four targets per round, all four LDS
+// reads issued before the first test: with one workgroup per CU (a frame-level batch) nothing else hides
+// the LDS latency of a one-target loop.
+template <bool FAST, bool LDS_HIST>
+__device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int r0, int r1, const float4 &xi,
+                                           const VoteBox &box, const AxisQuot &dqx, const AxisQuot &dqy,
+                                           const AxisQuot &dqz, uint32_t *__restrict__ counters)
+{
+    const float flx = (float)box.len_x, fly = (float)box.len_y, flz = (float)box.len_z;
+    for (int k = r0; k < r1; k += 4) {
+        float4 t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t4[u] = tile[min(k + u, r1 - 1)];  // same address in every lane: broadcast
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k + u >= r1) break;   // wave-uniform
+            const float4 t = t4[u];
+            const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
+            if (vx >= box.min_x && vx < box.max_x && vy >= box.min_y && vy < box.max_y && vz >= box.min_z &&
+                vz < box.max_z) {
+                const int px = (int)(axis_quot<FAST>(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor
+                const int py = (int)(axis_quot<FAST>(vy - box.min_y, dqy) * fly);
+                const int pz = (int)(axis_quot<FAST>(vz - box.min_z, dqz) * flz);
+                // FAST also promises len_x * len_y and len_z below 2^23: 24-bit multiplies (full rate) are exact
+                const int bin = FAST ? __mul24(__mul24(px, box.len_y) + py, box.len_z) + pz
+                                     : (px * box.len_y + py) * box.len_z + pz;
+                atomicAdd(&counters[bin], 1u);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     const float4 *__restrict__ Xs, const float4 *__restrict__ Ys, const int32_t *__restrict__ nXv,
     const int32_t *__restrict__ nYv, int N, int len_x, int len_y, int len_z,
@@ -304,7 +339,8 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
         for (int k = threadIdx.x; k < L; k += kVoteBlock) lhist[k] = 0u;
     }
     const AxisQuot dqx = axis_quot_make(min_x, max_x), dqy = axis_quot_make(min_y, max_y), dqz = axis_quot_make(min_z, max_z);
-    const float flx = (float)len_x, fly = (float)len_y, flz = (float)len_z;
+    const bool allFast = dqx.fast && dqy.fast && dqz.fast && (long long)len_x * len_y < (1 << 23) && len_z < (1 << 23);
+    const VoteBox box{min_x, min_y, min_z, max_x, max_y, max_z, len_x, len_y, len_z};
     // z window of this wave's rows: y.z in (zlo - max_z, zhi - min_z], widened by a rounding slack
     float zlo = xvalid ? xi.z : kInf, zhi = xvalid ? xi.z : -kInf;
 #pragma unroll
@@ -355,26 +391,15 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
             r1 = sorted_count_below<true>(zkey, 4, tn, whi, lane);
         }
         if (!xvalid) continue;
-        // four targets per round, all four LDS reads issued before the first test: with one workgroup
-        // per CU (a frame-level batch) nothing else hides the LDS latency of a one-target loop
-        for (int k = r0; k < r1; k += 4) {
-            float4 t4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t4[u] = tile[min(k + u, r1 - 1)];  // same address in every lane: broadcast
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (k + u >= r1) break;   // wave-uniform
-                const float4 t = t4[u];
-                const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
-                if (vx >= min_x && vx < max_x && vy >= min_y && vy < max_y && vz >= min_z && vz < max_z) {
-                    const int px = (int)(axis_quot(vx - min_x, dqx) * flx);   // >= 0: truncation == floor
-                    const int py = (int)(axis_quot(vy - min_y, dqy) * fly);
-                    const int pz = (int)(axis_quot(vz - min_z, dqz) * flz);
-                    const int bin = (px * len_y + py) * len_z + pz;
-                    if (useLds) atomicAdd(&lhist[bin], 1u);
-                    else atomicAdd(&gb[bin], 1u);
-                }
-            }
+        // (r0, r1 are wave-uniform: scalar loop control)
+        r0 = __builtin_amdgcn_readfirstlane(r0);
+        r1 = __builtin_amdgcn_readfirstlane(r1);
+        if (allFast) {
+            if (useLds) vote_range<true, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist);
+            else vote_range<true, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb);
+        } else {
+            if (useLds) vote_range<false, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist);
+            else vote_range<false, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb);
         }
         }  // windows
     }
