@@ -280,6 +280,13 @@ __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int 
                                            const AxisQuot &dqz, uint32_t *__restrict__ counters)
 {
     const float flx = (float)box.len_x, fly = (float)box.len_y, flz = (float)box.len_z;
+    // largest floats below the (exclusive) upper ends of the box; an empty axis (max <= min) stays empty
+    // because then pred(max) < min and the median is never v... unless v == pred(max) == min's neighbour:
+    // guard it explicitly
+    const bool empty = !(box.max_x > box.min_x && box.max_y > box.min_y && box.max_z > box.min_z);
+    if (empty) return;
+    const float hx = nextafterf(box.max_x, -INFINITY), hy = nextafterf(box.max_y, -INFINITY),
+                hz = nextafterf(box.max_z, -INFINITY);
     for (int k = r0; k < r1; k += 4) {
         float4 t4[4];
 #pragma unroll
@@ -289,8 +296,10 @@ __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int 
             if (k + u >= r1) break;   // wave-uniform
             const float4 t = t4[u];
             const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
-            if (vx >= box.min_x && vx < box.max_x && vy >= box.min_y && vy < box.max_y && vz >= box.min_z &&
-                vz < box.max_z) {
+            // min <= v < max  <=>  the median of (v, min, pred(max)) is v: one v_med3 + one compare per axis
+            // instead of two compares and a scalar AND (NaN fails both forms)
+            if (__builtin_amdgcn_fmed3f(vx, box.min_x, hx) == vx && __builtin_amdgcn_fmed3f(vy, box.min_y, hy) == vy &&
+                __builtin_amdgcn_fmed3f(vz, box.min_z, hz) == vz) {
                 const int px = (int)(axis_quot<FAST>(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor
                 const int py = (int)(axis_quot<FAST>(vy - box.min_y, dqy) * fly);
                 const int pz = (int)(axis_quot<FAST>(vz - box.min_z, dqz) * flz);
