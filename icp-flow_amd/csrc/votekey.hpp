@@ -17,6 +17,7 @@ namespace icpflow {
 
 constexpr float kWideMinExtent = 8.0f;     // metres along u above which the composite key pays
 constexpr float kSlabStride = 1024.0f;
+constexpr int kWideMinPoints = 4096;       // both clouds together; below, the key is plain z
 constexpr int kVoteKeyStride = 8;          // floats per pair in the parameter record
 
 struct VoteKey {
@@ -45,6 +46,11 @@ __device__ __forceinline__ VoteKey vote_key_load(const float *rec)
 __device__ inline VoteKey vote_key_params(const float4 *__restrict__ P, int nP, const float4 *__restrict__ Q,
                                           int nQ, float hBox, float *scratch, float *result)
 {
+    if (nP + nQ <= kWideMinPoints) {   // small pair: the plain z window is already short; skip the bounding box
+        if (threadIdx.x == 0) { result[0] = 0.f; result[1] = 0.f; result[2] = 0.f; result[3] = 0.f; result[4] = fmaxf(hBox, 1e-3f); }
+        __syncthreads();
+        return vote_key_load(result);
+    }
     float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
     for (int j = threadIdx.x; j < nP + nQ; j += blockDim.x) {
         const float4 q = j < nP ? P[j] : Q[j - nP];
