@@ -196,7 +196,7 @@ __device__ __forceinline__ void bitonic_sort_lds(float *key, int *idx, int NP2)
     for (int k = 2; k <= NP2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = threadIdx.x; t < half; t += blockDim.x) {
-                const int i = ((t / j) * (j << 1)) + (t % j);
+                const int i = (t << 1) - (t & (j - 1));   // = (t / j) * 2j + t % j for the power of two j, without the division
                 const int l = i + j;
                 const float ki = key[i], kl = key[l];
                 const int ii = idx[i], il = idx[l];
