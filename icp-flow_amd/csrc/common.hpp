@@ -217,12 +217,12 @@ __device__ __forceinline__ int sorted_count_below(const float *__restrict__ key,
 {
     const int step = (n + kWave - 1) / kWave;
     if (step == 0) return 0;
-    const int s0 = lane * step;
+    const int s0 = __mul24(lane, step);   // (24-bit multiply: full rate)
     const float k0 = s0 < n ? key[(size_t)s0 * stride] : kInf;
     const unsigned long long m0 = __ballot(INCLUSIVE ? (k0 <= v) : (k0 < v));
     const int cnt = __popcll(m0);
     if (cnt == 0) return 0;
-    const int base = (cnt - 1) * step;
+    const int base = __mul24(cnt - 1, step);
     const int s1 = base + lane;
     const float k1 = (lane < step && s1 < n) ? key[(size_t)s1 * stride] : kInf;
     const unsigned long long m1 = __ballot(INCLUSIVE ? (k1 <= v) : (k1 < v));
@@ -239,12 +239,13 @@ __device__ __forceinline__ int sorted_refine(const float *__restrict__ key, int 
     // invariant: the answer lies in [base, base + span]; all keys before `base` compare true
     while (span > 0) {
         const int step = (span + kWave - 1) / kWave;
-        const int s = base + lane * step;
-        const float k = (lane * step < span && s < n) ? key[s] : kInf;
+        const int ls = __mul24(lane, step);   // (24-bit multiply: full rate)
+        const int s = base + ls;
+        const float k = (ls < span && s < n) ? key[s] : kInf;
         const int cnt = __popcll(__ballot(INCLUSIVE ? (k <= v) : (k < v)));
         if (cnt == 0) return base;
         if (step == 1) return base + cnt;
-        base += (cnt - 1) * step;   // key[base] compares true, key[base + step] (if any) does not
+        base += __mul24(cnt - 1, step);   // key[base] compares true, key[base + step] (if any) does not
         span = min(step, n - base);
         // the sample at `base` itself is known true: search strictly after it
         base += 1; span -= 1;
