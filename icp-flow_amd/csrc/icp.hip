@@ -558,6 +558,10 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         if (tid < 12) bcast[tid] = (tid < 9 && tid % 4 == 0) ? 1.f : 0.f;  // :140
         if (tid == 0) { bcast[12] = 1.f; bcast[13] = 0.f; bcast[14] = 0.f; }
         if (tid < 16) ring[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.f : 0.f) : 0.f;   // state 0 = identity
+        if (tid == 13) {   // and its hash (same formula as in the loop)
+            const int one = __float_as_int(1.0f);
+            ring[13] = __int_as_float((one * 3) ^ (one * 11) ^ (one * 19));
+        }
     } else {
         if (tid < 9) bcast[tid] = st->R[tid];
         if (tid < 3) bcast[9 + tid] = st->T[tid];
@@ -1027,8 +1031,19 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     const int newest = it + 1;   // number of the new state
                     // four candidate periods per round: quarter q of the wave compares the new state
                     // (replicated into every quarter) with state newest - (k0 + q)
+                    // cheap first: a 32-bit hash of the state (xor of its twelve words) against the hashes of
+                    // the remembered states, all eight at once; the word-by-word comparison only runs on a hit
+                    int hash = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) hash ^= __float_as_int(Rn[k]) * (2 * k + 3);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) hash ^= __float_as_int(Tn[k]) * (2 * k + 23);
+                    const int kk = lane + 1;   // lane l < kRing looks at state newest - (l + 1)
+                    const bool cand = lane < kRing && kk <= newest - itBegin &&
+                                      __float_as_int(ring[((newest - kk) % kRing) * 16 + 13]) == hash;
+                    const bool anyCand = __ballot(cand) != 0ull;
                     const float cur16 = __shfl(cur, lane & 15, kWave);
-                    for (int k0 = 1; k0 <= kRing && period == 0; k0 += 4) {
+                    for (int k0 = 1; anyCand && k0 <= kRing && period == 0; k0 += 4) {
                         const int k = k0 + (lane >> 4);
                         const bool valid = k <= kRing && k <= newest - itBegin;
                         const float old = ring[(((newest - (valid ? k : 0)) % kRing + kRing) % kRing) * 16 + (lane & 15)];
@@ -1043,6 +1058,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     }
                     if (lane < 12) ring[(newest % kRing) * 16 + lane] = cur;
                     if (lane == 12) ring[(newest % kRing) * 16 + 12] = rmse;
+                    if (lane == 13) ring[(newest % kRing) * 16 + 13] = __int_as_float(hash);
                 }
                 if (period > 0 && active) {
                     if (rank == 0) {
