@@ -18,6 +18,10 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef ICPFLOW_SCAN_LOADS
+#define ICPFLOW_SCAN_LOADS 2
+#endif
+
 namespace icpflow {
 
 constexpr int kScanBlock = 256;  // threads per workgroup
@@ -183,6 +187,7 @@ __device__ __forceinline__ void scan_range_tie(const float4 *__restrict__ sx, co
         for (int q = 0; q < Q; ++q) m[q] = kInf;
 #pragma unroll
         for (int u = 0; u < kChunk / 4; ++u) {
+            if (u > 0 && (u % ICPFLOW_SCAN_LOADS) == 0) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight
             const float4 tx = sx[(c >> 2) + u];  // same address in every lane: broadcast
             const float4 ty = sy[(c >> 2) + u];
             const float4 tz = sz[(c >> 2) + u];
