@@ -1335,13 +1335,13 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
         else if (p.N <= 512) launch_icp_variant<512, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.team.wgPair != nullptr) {   // several workgroups per large pair (N > 1024)
             if (p.N <= 12288) launch_icp_variant<768, 1, 1, 4, true>(p, B, itBegin, itEnd, s);
-            else launch_icp_variant<1024, 1, 1, 3, true>(p, B, itBegin, itEnd, s);
+            else launch_icp_variant<768, 1, 1, 3, true>(p, B, itBegin, itEnd, s);
         }
         // 1024 threads (4 waves per SIMD, 128 VGPRs: the kernel fits but for three pointers spilled once
         // outside the loop) take a 1024-point cloud in one pass; up to 768 points 12 waves (170 VGPRs) do
         else if (p.N <= 768) launch_icp_variant<768, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.N <= 12288) launch_icp_variant<1024, 1, 1, 4>(p, B, itBegin, itEnd, s);
-        else launch_icp_variant<1024, 1, 1, 3>(p, B, itBegin, itEnd, s);
+        else launch_icp_variant<768, 1, 1, 3>(p, B, itBegin, itEnd, s);   // (the scalar-load sweep spills at 1024 threads)
     } else if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 2>(p, B, itBegin, itEnd, s);
         else if (p.N <= 2048) launch_icp_variant<1024, 1, 1, 2>(p, B, itBegin, itEnd, s);
