@@ -190,22 +190,39 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 
 // Bitonic sort of NP2 (power of two) (key, index) pairs held in LDS, ascending by key, ties by
 // index (deterministic).  All threads of the block must call it.
+__device__ __forceinline__ void bitonic_exchange(float *key, int *idx, int t, int j, int k)
+{
+    const int i = (t << 1) - (t & (j - 1));   // = (t / j) * 2j + t % j for the power of two j, without the division
+    const int l = i + j;
+    const float ki = key[i], kl = key[l];
+    const int ii = idx[i], il = idx[l];
+    const bool up = (i & k) == 0;
+    const bool gt = ki > kl || (ki == kl && ii > il);
+    if (gt == up) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+}
+
 __device__ __forceinline__ void bitonic_sort_lds(float *key, int *idx, int NP2)
 {
     const int half = NP2 >> 1;  // one compare-exchange per thread and step
     for (int k = 2; k <= NP2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < half; t += blockDim.x) {
-                const int i = (t << 1) - (t & (j - 1));   // = (t / j) * 2j + t % j for the power of two j, without the division
-                const int l = i + j;
-                const float ki = key[i], kl = key[l];
-                const int ii = idx[i], il = idx[l];
-                const bool up = (i & k) == 0;
-                const bool gt = ki > kl || (ki == kl && ii > il);
-                if (gt == up) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
-            }
+        // steps with partner distance >= 128 cross the 128-element blocks owned by single waves: barrier each
+        int j = k >> 1;
+        for (; j > kWave; j >>= 1) {
+            for (int t = threadIdx.x; t < half; t += blockDim.x) bitonic_exchange(key, idx, t, j, k);
             __syncthreads();
         }
+        // distance <= 64: the 64 exchanges of a wave stay inside one 128-element block for all remaining
+        // steps of the phase, so each wave runs them back to back (the LDS operations of a wave complete in
+        // order; the fences only keep the compiler from reordering them): 7 barriers per phase become 1
+        for (int t = threadIdx.x; t < half; t += blockDim.x) {
+            for (int jj = j; jj > 0; jj >>= 1) {
+                bitonic_exchange(key, idx, t, jj, k);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        __syncthreads();
     }
 }
 
