@@ -200,6 +200,14 @@ def extra_measurements(args, src, dst, T, dev, a):
     init = torch.eye(4, device=dev)[None].repeat(B, 1, 1).contiguous()
     ms = timeit(lambda: utils_icp.apply_icp(args, src, dst, init))
     out["icp_only_apply_icp_registrations_per_s"] = round(B / ms * 1e3, 1)
+    # the two drop-in primitives on their own (the reference's native boundaries: hist_cuda.hist, knn_points)
+    from icp_flow_amd import hist as hip_hist, utils_helper, utils_hist
+    ex, ey, ez = utils_hist.bin_edges(args)
+    ms = timeit(lambda: hip_hist.hist(dst, src, ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), len(ex),
+                                     len(ey), len(ez)))
+    out["hist_all_pairs_vote_ms_per_batch"] = round(ms, 4)
+    ms = timeit(lambda: utils_helper.nearest_neighbor_batch(src, dst))
+    out["nearest_neighbor_batch_ms_per_batch"] = round(ms, 4)
     fp = frame_pair_measurement(dev)
     if fp is not None:
         out["frame_pair"] = fp
