@@ -126,6 +126,49 @@ constexpr int kVoteBlock = 256;  // threads; one X row per thread per slice
 constexpr int kVoteTile = 1024;  // Y points staged in LDS per step (16 KiB)
 constexpr int kVoteSpan = 2;     // sorted vote: Y tiles per workgroup
 
+// The votes of one X row (per lane) against the staged targets [r0, r1) (wave-uniform bounds): the exact
+// box test and bin arithmetic of hist_cuda_core.cuh:44-60.  FAST: all three quotients take the hoisted
+// division and the bin index fits 24-bit multiplies (decided once per launch); LDS_HIST: counters in LDS.  Four targets per round, all four LDS
+// reads issued before the first test: with one workgroup per CU (a frame-level batch) nothing else hides
+// the LDS latency of a one-target loop.
+template <bool FAST, bool LDS_HIST>
+__device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int r0, int r1, const float4 &xi,
+                                           const VoteBox &box, const AxisQuot &dqx, const AxisQuot &dqy,
+                                           const AxisQuot &dqz, uint32_t *__restrict__ counters)
+{
+    const float flx = (float)box.len_x, fly = (float)box.len_y, flz = (float)box.len_z;
+    // largest floats below the (exclusive) upper ends of the box; an empty axis (max <= min) stays empty
+    // because then pred(max) < min and the median is never v... unless v == pred(max) == min's neighbour:
+    // guard it explicitly
+    const bool empty = !(box.max_x > box.min_x && box.max_y > box.min_y && box.max_z > box.min_z);
+    if (empty) return;
+    const float hx = nextafterf(box.max_x, -INFINITY), hy = nextafterf(box.max_y, -INFINITY),
+                hz = nextafterf(box.max_z, -INFINITY);
+    for (int k = r0; k < r1; k += 4) {
+        float4 t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t4[u] = tile[min(k + u, r1 - 1)];  // same address in every lane: broadcast
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k + u >= r1) break;   // wave-uniform
+            const float4 t = t4[u];
+            const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
+            // min <= v < max  <=>  the median of (v, min, pred(max)) is v: one v_med3 + one compare per axis
+            // instead of two compares and a scalar AND (NaN fails both forms)
+            if (__builtin_amdgcn_fmed3f(vx, box.min_x, hx) == vx && __builtin_amdgcn_fmed3f(vy, box.min_y, hy) == vy &&
+                __builtin_amdgcn_fmed3f(vz, box.min_z, hz) == vz) {
+                const int px = (int)(axis_quot<FAST>(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor
+                const int py = (int)(axis_quot<FAST>(vy - box.min_y, dqy) * fly);
+                const int pz = (int)(axis_quot<FAST>(vz - box.min_z, dqz) * flz);
+                // FAST also promises len_x * len_y and len_z below 2^23: 24-bit multiplies (full rate) are exact
+                const int bin = FAST ? __mul24(__mul24(px, box.len_y) + py, box.len_z) + pz
+                                     : (px * box.len_y + py) * box.len_z + pz;
+                atomicAdd(&counters[bin], 1u);
+            }
+        }
+    }
+}
+
 // bins_u32: [B, L] zero-initialised.  swap (optional, per pair): vote with X and Y
 // exchanged -- used by the fused registration path where "src" is the smaller cloud.
 // edges (optional, device): box taken from edges (min = e[0], max = e[L-1]).
@@ -166,33 +209,24 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
     // and float(len) are loop invariants
     const AxisQuot dqx = axis_quot_make(box.min_x, box.max_x), dqy = axis_quot_make(box.min_y, box.max_y),
                    dqz = axis_quot_make(box.min_z, box.max_z);
-    const float flx = (float)box.len_x, fly = (float)box.len_y, flz = (float)box.len_z;
+    const bool allFast = dqx.fast && dqy.fast && dqz.fast && (long long)box.len_x * box.len_y < (1 << 23) &&
+                         box.len_z < (1 << 23);
 
     for (int j0 = 0; j0 < ny; j0 += kVoteTile) {
         const int tn = min(kVoteTile, ny - j0);
         __syncthreads();  // previous tile fully consumed (and lhist zeroed)
         int any = 0;
         for (int k = threadIdx.x; k < tn; k += kVoteBlock) {
-            const float4 t = yb[j0 + k];
+            float4 t = yb[j0 + k];
+            const bool valid = t.w > 0.0f;               // hist_cuda_core.cuh:40-43: only flagged points vote
+            if (!valid) t.x = kInf;                      // an unflagged target fails the box test: v = x - inf
             tile[k] = t;
-            any |= (t.w > 0.0f) ? 1 : 0;
+            any |= valid ? 1 : 0;
         }
         if (!__syncthreads_or(any)) continue;  // a tile of pads
         if (!xvalid) continue;
-        for (int k = 0; k < tn; ++k) {
-            const float4 t = tile[k];  // same address in every lane: LDS broadcast
-            if (!(t.w > 0.0f)) continue;  // wave-uniform
-            const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
-            if (vx >= box.min_x && vx < box.max_x && vy >= box.min_y && vy < box.max_y &&
-                vz >= box.min_z && vz < box.max_z) {
-                const int px = (int)(axis_quot(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor (:52-57)
-                const int py = (int)(axis_quot(vy - box.min_y, dqy) * fly);
-                const int pz = (int)(axis_quot(vz - box.min_z, dqz) * flz);
-                const int bin = (px * box.len_y + py) * box.len_z + pz;
-                if (LDS_HIST) atomicAdd(&lhist[bin], 1u);
-                else atomicAdd(&gb[bin], 1u);
-            }
-        }
+        if (allFast) vote_range<true, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb);
+        else vote_range<false, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb);
     }
     if (LDS_HIST) {
         __syncthreads();
@@ -266,49 +300,6 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
         float4 o = make_float4(0.f, 0.f, kInf, kInf);
         if (r < NP2 && key[r] < kInf) { o = in[idx[r]]; o.w = key[r]; }
         out[r] = o;
-    }
-}
-
-// The votes of one X row (per lane) against the staged targets [r0, r1) (wave-uniform bounds): the exact
-// box test and bin arithmetic of hist_cuda_core.cuh:44-60.  FAST: all three quotients take the hoisted
-// division and the bin index fits 24-bit multiplies (decided once per launch); LDS_HIST: counters in LDS.  Four targets per round, all four LDS
-// reads issued before the first test: with one workgroup per CU (a frame-level batch) nothing else hides
-// the LDS latency of a one-target loop.
-template <bool FAST, bool LDS_HIST>
-__device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int r0, int r1, const float4 &xi,
-                                           const VoteBox &box, const AxisQuot &dqx, const AxisQuot &dqy,
-                                           const AxisQuot &dqz, uint32_t *__restrict__ counters)
-{
-    const float flx = (float)box.len_x, fly = (float)box.len_y, flz = (float)box.len_z;
-    // largest floats below the (exclusive) upper ends of the box; an empty axis (max <= min) stays empty
-    // because then pred(max) < min and the median is never v... unless v == pred(max) == min's neighbour:
-    // guard it explicitly
-    const bool empty = !(box.max_x > box.min_x && box.max_y > box.min_y && box.max_z > box.min_z);
-    if (empty) return;
-    const float hx = nextafterf(box.max_x, -INFINITY), hy = nextafterf(box.max_y, -INFINITY),
-                hz = nextafterf(box.max_z, -INFINITY);
-    for (int k = r0; k < r1; k += 4) {
-        float4 t4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t4[u] = tile[min(k + u, r1 - 1)];  // same address in every lane: broadcast
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (k + u >= r1) break;   // wave-uniform
-            const float4 t = t4[u];
-            const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
-            // min <= v < max  <=>  the median of (v, min, pred(max)) is v: one v_med3 + one compare per axis
-            // instead of two compares and a scalar AND (NaN fails both forms)
-            if (__builtin_amdgcn_fmed3f(vx, box.min_x, hx) == vx && __builtin_amdgcn_fmed3f(vy, box.min_y, hy) == vy &&
-                __builtin_amdgcn_fmed3f(vz, box.min_z, hz) == vz) {
-                const int px = (int)(axis_quot<FAST>(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor
-                const int py = (int)(axis_quot<FAST>(vy - box.min_y, dqy) * fly);
-                const int pz = (int)(axis_quot<FAST>(vz - box.min_z, dqz) * flz);
-                // FAST also promises len_x * len_y and len_z below 2^23: 24-bit multiplies (full rate) are exact
-                const int bin = FAST ? __mul24(__mul24(px, box.len_y) + py, box.len_z) + pz
-                                     : (px * box.len_y + py) * box.len_z + pz;
-                atomicAdd(&counters[bin], 1u);
-            }
-        }
     }
 }
 
