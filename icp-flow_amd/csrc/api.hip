@@ -394,6 +394,35 @@ int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const
     return 0;
 }
 
+size_t icpflow_dbscan_workspace_bytes(int n)
+{
+    if (n <= 0) return 0;
+    size_t bytes = 0;
+    if (dbscan_workspace_bytes(n, &bytes) != hipSuccess) return 0;
+    return bytes;
+}
+
+int icpflow_dbscan(const float *d_points, int stride, const uint8_t *d_mask, int n, double eps, int min_points,
+                   int32_t *d_labels, int32_t *d_counts, int32_t *d_num_clusters, void *d_ws, size_t ws_bytes,
+                   icpflow_stream_t stream)
+{
+    if (!d_points || !d_labels || !d_counts || !d_num_clusters)
+        return fail(ICPFLOW_E_ARG, "icpflow_dbscan: null pointer");
+    if (n <= 0) return fail(ICPFLOW_E_ARG, "icpflow_dbscan: n must be positive (got %d)", n);
+    if (stride < 3) return fail(ICPFLOW_E_ARG, "icpflow_dbscan: stride must be >= 3 floats (got %d)", stride);
+    if (!(eps > 0.0) || min_points < 1)
+        return fail(ICPFLOW_E_ARG, "icpflow_dbscan: eps must be positive and min_points >= 1 (got %g, %d)", eps,
+                    min_points);
+    if (!d_ws) return fail(ICPFLOW_E_WORKSPACE, "icpflow_dbscan: workspace is NULL");
+    bool tooSmall = false;
+    ICPFLOW_TRY(launch_dbscan(d_points, stride, d_mask, n, eps, min_points, d_labels, d_counts, d_num_clusters, d_ws,
+                              ws_bytes, &tooSmall, (hipStream_t)stream));
+    if (tooSmall)
+        return fail(ICPFLOW_E_WORKSPACE, "icpflow_dbscan: workspace too small (%zu bytes, need %zu)", ws_bytes,
+                    icpflow_dbscan_workspace_bytes(n));
+    return 0;
+}
+
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
                           const int64_t *d_count, const float *d_labels, int L, float *d_mean, float *d_extent,
                           icpflow_stream_t stream)

@@ -173,4 +173,11 @@ hipError_t launch_flow_rigid(const float *points, const float *labels, int N, co
 hipError_t launch_transform_points(const float *xyz, const float *pose, int B, int N, float *out,
                                    hipStream_t s);
 
+
+// cluster.hip: DBSCAN of a frame pair's points (labels int32 [n]: cluster id, -1 noise, -2 masked out)
+hipError_t dbscan_workspace_bytes(int n, size_t *bytes);
+hipError_t launch_dbscan(const float *pts, int stride, const uint8_t *mask, int n, double eps, int minPoints,
+                         int32_t *labels, int32_t *counts, int32_t *numClusters, void *ws, size_t wsBytes,
+                         bool *wsTooSmall, hipStream_t s);
+
 }  // namespace icpflow

@@ -240,6 +240,25 @@ int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, cons
                        size_t ws_bytes, icpflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * 8(f) row 4  density clustering of a frame pair's points -- the `cluster_dbscan` branch of
+ * cluster_pcd (utils_cluster.py:32-48, 50-63), i.e. open3d 0.17.0 PointCloud::cluster_dbscan(eps,
+ * min_points) (environment.yml:227; third-party, not in the reference tree).
+ *
+ * d_points float32 rows of `stride` floats (x, y, z first), n rows.  d_mask (uint8 [n], optional):
+ * rows with mask 0 are not clustered (the ground rows of cluster_pcd's idxs_nonground) and report -2.
+ * A neighbour is a point whose squared distance, evaluated in fp64, is STRICTLY below eps^2; a point
+ * with >= min_points neighbours (itself included) is a core point.
+ * Outputs: d_labels int32 [n]: cluster id 0..C-1 in order of each cluster's smallest core-point row
+ * (Open3D's numbering), -1 noise, -2 masked out;  d_counts int32 [n]: the first C entries are the
+ * cluster sizes;  d_num_clusters int32 [1] = C.  Keeping only the num_clusters largest clusters
+ * (utils_cluster.py:38-45) is host logic on d_counts (icp-flow_amd/utils_cluster.py).
+ * ------------------------------------------------------------------------- */
+size_t icpflow_dbscan_workspace_bytes(int n);
+int icpflow_dbscan(const float *d_points, int stride, const uint8_t *d_mask, int n, double eps, int min_points,
+                   int32_t *d_labels, int32_t *d_counts, int32_t *d_num_clusters, void *d_ws, size_t ws_bytes,
+                   icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Diagnostics: the vote kernels evaluate (v - min) / (max - min) with the loop-invariant part of
  * the IEEE division hoisted (hist.hip, AxisQuot).  For numerators d_a [n] this returns that
  * quotient (d_fast) next to the compiler's correctly rounded a / (max - min) (d_ieee); the two

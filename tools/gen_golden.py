@@ -346,7 +346,63 @@ def g9_epe():
     print("  epe/accs/accr/outlier/Routlier:", whole)
 
 
-GENS = dict(g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
+def g10_dbscan():
+    """the reference's cluster_dbscan / cluster_pcd (utils_cluster.py:32-63,
+    if_hdbscan False) on (a) the demo frame pair stacked as demo.py:210 does and (b) small synthetic
+    clouds incl. a ground mask, with open3d's cluster_dbscan backed by sklearn (tools/standins/open3d).
+    Also records that no point pair sits at distance == eps (where sklearn and nanoflann differ)."""
+    import utils_cluster  # noqa: E402  (reference)
+    from oracle import cluster as oc
+    data = np.load(os.path.join(REF, "demo.npz"))
+    src = data["pc1"][data["pc1_flows_valid_idx"]].astype(np.float32)
+    dst = data["pc2"][data["pc2_flows_valid_idx"]].astype(np.float32)
+    pts = np.concatenate([dst, src], axis=0)                                     # demo.py:210
+    out = {}
+
+    def ties(p, eps):
+        """pairs at exactly eps (excluded by nanoflann's strict test) and pairs between the stand-in's
+        radius and eps (must be none for the stand-in to equal the strict test)"""
+        P = p[:, :3].astype(np.float64)
+        from scipy.spatial import cKDTree
+        c = cKDTree(P).query_pairs(eps * (1 + 1e-9), output_type="ndarray")
+        d = P[c[:, 0]] - P[c[:, 1]]
+        d2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+        r = np.nextafter(eps, 0.0)
+        assert np.count_nonzero((d2 > r * r) & (d2 < eps * eps)) == 0
+        return int(np.count_nonzero(d2 == eps * eps))
+
+    for tag, (eps, mcs, ncl) in dict(a=(0.25, 20, 200), b=(0.25, 30, 100), c=(0.4, 10, 50)).items():
+        a = args_ns(epsilon=eps, min_cluster_size=mcs, num_clusters=ncl, if_hdbscan=False)
+        lab = utils_cluster.cluster_pcd(a, pts, np.ones(len(pts)).astype(bool))
+        mine = oc.cluster_pcd(a, pts, np.ones(len(pts)).astype(bool))
+        out[f"demo_{tag}_pairs_at_eps"] = np.array(ties(pts, eps))
+        print(f"  demo dbscan {tag}: eps {eps} min {mcs} keep {ncl}: {len(np.unique(lab)) - 1} clusters kept, "
+              f"{int((lab == -1).sum())} unclustered, oracle mismatches {int((lab != mine).sum())}")
+        out[f"demo_{tag}_params"] = np.array([eps, mcs, ncl], dtype=np.float64)
+        out[f"demo_{tag}_labels"] = lab.astype(np.int32)
+    # small clouds: blobs + bridges + noise, a ground mask (cluster_pcd's idxs_nonground)
+    rng = np.random.default_rng(10)
+    for k, n in enumerate((300, 2000, 9000)):
+        centers = rng.uniform(-8, 8, size=(12, 3)) * np.array([1, 1, 0.2])
+        p = centers[rng.integers(0, 12, n)] + rng.normal(0, 0.25, size=(n, 3)) * np.array([1, 1, 0.5])
+        p[: n // 6] = rng.uniform(-10, 10, size=(n // 6, 3)) * np.array([1, 1, 0.2])      # clutter
+        p = p.astype(np.float32)
+        nonground = p[:, 2] > -0.5
+        a = args_ns(epsilon=0.3, min_cluster_size=6, num_clusters=6, if_hdbscan=False)
+        lab = utils_cluster.cluster_pcd(a, p, nonground)
+        ties(p[nonground], 0.3)
+        mine = oc.cluster_pcd(a, p, nonground)
+        lit = oc.cluster_pcd(a, p, nonground, impl=oc.dbscan_index_order)
+        print(f"  small {k}: n {n}: kept {len(np.unique(lab[lab >= 0]))} clusters; oracle mismatches "
+              f"{int((lab != mine).sum())} / {int((lab != lit).sum())}")
+        out[f"small_{k}_points"] = p
+        out[f"small_{k}_nonground"] = nonground
+        out[f"small_{k}_params"] = np.array([0.3, 6, 6], dtype=np.float64)
+        out[f"small_{k}_labels"] = lab
+    save("g10_dbscan", **out)
+
+
+GENS = dict(g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -354,7 +410,7 @@ if __name__ == "__main__":
     ns = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g9")]   # g8: ~3 min, on request
+    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g9", "g10")]   # g8: ~3 min, on request
     for k in want:
         print(f"== {k}")
         GENS[k]()
