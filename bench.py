@@ -247,7 +247,47 @@ def frame_pair_measurement(dev):
         if mp == int(g["max_points"]):      # the setting the reference's own run was captured with
             entry["max_flow_difference_to_reference_m"] = float(np.abs(flow.cpu().numpy() - g["flow"]).max())
         res[f"max_points_{mp}"] = entry
+    res["cluster_dbscan"] = cluster_measurement(dev, g, gdir)
     return res
+
+
+def cluster_measurement(dev, g, gdir):
+    """cluster_pcd (DBSCAN branch, utils_cluster.py:32-63) of the stacked demo frame pair
+    (demo.py:210), points resident, labels checked against G10 (the reference's own cluster_pcd run with the
+    open3d stand-in) and the CPU restatement (oracle/cluster.py, one thread) timed beside it."""
+    from types import SimpleNamespace
+    from icp_flow_amd import utils_cluster
+    try:
+        g10 = np.load(os.path.join(gdir, "g10_dbscan.npz"))
+    except OSError:
+        return None
+    pts_h = np.concatenate([g["point_dst"], g["point_src"]], axis=0)
+    pts = torch.from_numpy(pts_h).to(dev)
+    eps, mcs, ncl = g10["demo_a_params"]
+    a = SimpleNamespace(epsilon=float(eps), min_cluster_size=int(mcs), num_clusters=int(ncl), if_hdbscan=False)
+    nonground = torch.ones(len(pts), dtype=torch.bool, device=dev)
+    lab = utils_cluster.cluster_pcd(a, pts, nonground)
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(10):
+        lab = utils_cluster.cluster_pcd(a, pts, nonground)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t) / 10 * 1e3
+    t = time.perf_counter()
+    for _ in range(10):
+        utils_cluster.dbscan(pts, a.epsilon, a.min_cluster_size)
+    torch.cuda.synchronize(dev)
+    ms_kernels = (time.perf_counter() - t) / 10 * 1e3
+    from oracle import cluster as oc
+    t = time.perf_counter()
+    want = oc.cluster_pcd(a, pts_h, np.ones(len(pts_h), dtype=bool))
+    cpu_ms = (time.perf_counter() - t) * 1e3
+    got = lab.cpu().numpy()
+    return {"points": int(len(pts)), "eps": float(eps), "min_points": int(mcs), "clusters_kept": int(len(np.unique(got[got >= 0]))),
+            "ms_per_frame_pair": round(ms, 3), "ms_icpflow_dbscan_only": round(ms_kernels, 3),
+            "labels_equal_reference_run_g10": bool(np.array_equal(got.astype(np.int32), g10["demo_a_labels"])),
+            "labels_equal_cpu_port": bool(np.array_equal(got, want)),
+            "cpu_port_ms": round(cpu_ms, 1), "cpu_port": "oracle/cluster.py (scipy cKDTree + connected_components), 1 thread"}
 
 
 def cpu_baseline(S, D, a):

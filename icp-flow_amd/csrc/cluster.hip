@@ -133,7 +133,8 @@ __global__ __launch_bounds__(kBlock) void dbscan_core_kernel(const float4 *__res
     if (lane < kRuns) runs[(size_t)lane * n + j] = make_int2(loOfLane, hiOfLane);
     const float4 p = sorted[j];
     int cnt = 0;
-    for (int r = 0; r < kRuns && cnt < minPoints; ++r) {
+    for (int k = 0; k < kRuns && cnt < minPoints; ++k) {
+        const int r = (int)((0x862075314ull >> (4 * k)) & 15);   // own column first, corners last: exits sooner
         const int lo = __shfl(bound, 2 * r), hi = __shfl(bound, 2 * r + 1);
         for (int q0 = lo; q0 < hi && cnt < minPoints; q0 += 64) {
             const int q = q0 + lane;
@@ -306,23 +307,39 @@ __global__ __launch_bounds__(1024) void dbscan_rank_kernel(const int *__restrict
                                                            int *__restrict__ rank, int *__restrict__ numClusters)
 {
     __shared__ int part[16];
+    constexpr int kU = 8;   // independent loads in flight per lane
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int per = ((n + 15) / 16 + 63) / 64 * 64;
+    const int per = ((n + 15) / 16 + 64 * kU - 1) / (64 * kU) * (64 * kU);
     const int lo = min(n, w * per), hi = min(n, lo + per);
     int sum = 0;
-    for (int i0 = lo; i0 < hi; i0 += 64) {
-        const int i = i0 + lane;
-        sum += __popcll(__ballot(i < hi && rootOf[i] == i));
+    for (int i0 = lo; i0 < hi; i0 += 64 * kU) {
+        int v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * 64 + lane;
+            v[u] = i < hi ? rootOf[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) sum += __popcll(__ballot(v[u] == i0 + u * 64 + lane));
     }
     if (lane == 0) part[w] = sum;
     __syncthreads();
     int base = 0;
     for (int v = 0; v < w; ++v) base += part[v];
-    for (int i0 = lo; i0 < hi; i0 += 64) {
-        const int i = i0 + lane;
-        const unsigned long long b = __ballot(i < hi && rootOf[i] == i);
-        if (i < hi) rank[i] = base + __popcll(b & ((1ull << lane) - 1));
-        base += __popcll(b);
+    for (int i0 = lo; i0 < hi; i0 += 64 * kU) {
+        int v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * 64 + lane;
+            v[u] = i < hi ? rootOf[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * 64 + lane;
+            const unsigned long long b = __ballot(v[u] == i);
+            if (i < hi) rank[i] = base + __popcll(b & ((1ull << lane) - 1));
+            base += __popcll(b);
+        }
     }
     if (threadIdx.x == 1023) *numClusters = base;
 }

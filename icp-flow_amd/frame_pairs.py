@@ -9,8 +9,11 @@ points.  On disk: one .npz per pair with keys
     pose [4,4] (optional, identity)       gt_flow [Ns,3] (optional)     mask [Ns] (optional)
 
 or the reference's Argoverse/demo keys (dataset_argo.py:34-45: pc1, pc2, pc1_flows_valid_idx,
-pc2_flows_valid_idx, gt_flow_0_1) plus labels_src / labels_dst (clustering is precomputed: BASELINE
-configs).
+pc2_flows_valid_idx, gt_flow_0_1) plus labels_src / labels_dst (clustering is precomputed in the BASELINE
+configs).  A pair WITHOUT labels is clustered on the GPU when the arguments say how (`cluster="dbscan"`
+with epsilon / min_cluster_size / num_clusters: both clouds stacked dst-first and clustered jointly as
+demo.py:210 / dataset_argo.py:119 do, utils_cluster.cluster_pcd's DBSCAN branch, SURVEY 8(f) rank 4;
+optional keys nonground_src / nonground_dst mark the rows to cluster).
 
 `run_stream` registers every pair of a directory (round-robin over ranks: frame pairs are
 independent, main.py:184), and reports ms / frame pair and the reference's accuracy metrics.
@@ -31,7 +34,8 @@ from . import utils_eval, utils_flow, utils_track
 
 # demo.sh:9-13 / main.sh flags of the registration stage
 DEFAULT_ARGS = dict(max_points=10000, min_cluster_size=20, translation_frame=2.0, thres_dist=0.1, thres_box=0.1,
-                    thres_rot=0.1, thres_error=0.2, thres_iou=0.2, chunk_size=50, speed=None)
+                    thres_rot=0.1, thres_error=0.2, thres_iou=0.2, chunk_size=50, speed=None,
+                    cluster=None, epsilon=0.25, num_clusters=200)
 
 
 def default_args(**over):
@@ -41,13 +45,21 @@ def default_args(**over):
 
 
 class FramePair:
-    def __init__(self, points_src, points_dst, labels_src, labels_dst, pose=None, gt_flow=None, mask=None,
-                 name=""):
+    def __init__(self, points_src, points_dst, labels_src=None, labels_dst=None, pose=None, gt_flow=None, mask=None,
+                 name="", nonground_src=None, nonground_dst=None):
         self.points_src = np.ascontiguousarray(points_src, dtype=np.float32)[:, 0:3]
         self.points_dst = np.ascontiguousarray(points_dst, dtype=np.float32)[:, 0:3]
-        self.labels_src = np.ascontiguousarray(labels_src, dtype=np.float32)
-        self.labels_dst = np.ascontiguousarray(labels_dst, dtype=np.float32)
-        if len(self.labels_src) != len(self.points_src) or len(self.labels_dst) != len(self.points_dst):
+        if (labels_src is None) != (labels_dst is None):
+            raise ValueError(f"frame pair {name!r}: labels of both clouds or of neither")
+        self.labels_src = None if labels_src is None else np.ascontiguousarray(labels_src, dtype=np.float32)
+        self.labels_dst = None if labels_dst is None else np.ascontiguousarray(labels_dst, dtype=np.float32)
+        self.nonground_src = None if nonground_src is None else np.asarray(nonground_src).astype(bool)
+        self.nonground_dst = None if nonground_dst is None else np.asarray(nonground_dst).astype(bool)
+        for m, pts in ((self.nonground_src, self.points_src), (self.nonground_dst, self.points_dst)):
+            if m is not None and m.shape != (len(pts),):
+                raise ValueError(f"frame pair {name!r}: one non-ground flag per point required")
+        if self.labels_src is not None and (
+                len(self.labels_src) != len(self.points_src) or len(self.labels_dst) != len(self.points_dst)):
             raise ValueError(f"frame pair {name!r}: one label per point required "
                              f"({len(self.labels_src)}/{len(self.points_src)} src, "
                              f"{len(self.labels_dst)}/{len(self.points_dst)} dst)")
@@ -60,8 +72,10 @@ class FramePair:
 
 
 def save_frame_pair(path, fp):
-    arrays = dict(points_src=fp.points_src, points_dst=fp.points_dst, labels_src=fp.labels_src,
-                  labels_dst=fp.labels_dst, pose=fp.pose)
+    arrays = dict(points_src=fp.points_src, points_dst=fp.points_dst, pose=fp.pose)
+    for k in ("labels_src", "labels_dst", "nonground_src", "nonground_dst"):
+        if getattr(fp, k) is not None:
+            arrays[k] = getattr(fp, k)
     if fp.gt_flow is not None:
         arrays["gt_flow"] = fp.gt_flow
     if fp.mask is not None:
@@ -80,17 +94,15 @@ def load_frame_pair(path):
             return None
 
         labels_src, labels_dst = first("labels_src", "label_src"), first("labels_dst", "label_dst")
-        if labels_src is None or labels_dst is None:
-            raise ValueError(f"{path}: cluster labels (labels_src / labels_dst) are required -- clustering is "
-                             "precomputed, not part of this path")
+        ng = dict(nonground_src=first("nonground_src"), nonground_dst=first("nonground_dst"))
         if "points_src" in keys:
             return FramePair(z["points_src"], z["points_dst"], labels_src, labels_dst, first("pose"),
-                             first("gt_flow"), first("mask"), name=os.path.basename(path))
+                             first("gt_flow"), first("mask"), name=os.path.basename(path), **ng)
         if "pc1" in keys:                                   # dataset_argo.py:34-53, demo.py:37-51
             v0, v1 = z["pc1_flows_valid_idx"], z["pc2_flows_valid_idx"]
             gt = z["gt_flow_0_1"][v0] if "gt_flow_0_1" in keys else None
             return FramePair(z["pc1"][v0], z["pc2"][v1], labels_src, labels_dst, first("pose"), gt, first("mask"),
-                             name=os.path.basename(path))
+                             name=os.path.basename(path), **ng)
         raise ValueError(f"{path}: neither points_src/points_dst nor pc1/pc2 present")
 
 
@@ -114,15 +126,35 @@ def frame_translation(args, pose, gap=1):
     return float(max(args.speed * gap, float(np.linalg.norm(np.asarray(pose)[0:3, 3])))) * 2.0
 
 
+def cluster_frame_pair(args, ps, pd, nonground_src=None, nonground_dst=None):
+    """Joint clustering of a frame pair as demo.py:210 / dataset_argo.py:112-121 do it: both clouds stacked
+    dst-first, one cluster_pcd call, labels split back.  -> (labels_src, labels_dst) float32 device tensors."""
+    if getattr(args, "cluster", None) != "dbscan":
+        raise ValueError("frame pair without cluster labels: pass precomputed labels_src / labels_dst or set "
+                         "args.cluster = 'dbscan' (the HDBSCAN branch is not built)")
+    from . import utils_cluster
+    dev = ps.device
+    ones = lambda n: torch.ones(n, dtype=torch.bool, device=dev)
+    m_src = ones(len(ps)) if nonground_src is None else torch.as_tensor(nonground_src, device=dev).bool()
+    m_dst = ones(len(pd)) if nonground_dst is None else torch.as_tensor(nonground_dst, device=dev).bool()
+    a = SimpleNamespace(epsilon=float(args.epsilon), min_cluster_size=int(args.min_cluster_size),
+                        num_clusters=int(args.num_clusters), if_hdbscan=False)
+    labels = utils_cluster.cluster_pcd(a, torch.cat([pd, ps], dim=0), torch.cat([m_dst, m_src], dim=0)).float()
+    return labels[len(pd):].contiguous(), labels[: len(pd)].contiguous()
+
+
 def register_frame_pair(args, fp, device, gap=1):
-    """One frame pair through track() + flow_estimation_torch() on `device`.
-    -> dict(pairs [P,10], transformations [P,4,4], flow [Ns,3]) of device tensors."""
+    """One frame pair through (cluster_pcd when it carries no labels +) track() + flow_estimation_torch() on
+    `device`.  -> dict(pairs [P,10], transformations [P,4,4], flow [Ns,3]) of device tensors."""
     a = SimpleNamespace(**vars(args))
     a.translation_frame = frame_translation(args, fp.pose, gap)
     ps = torch.from_numpy(fp.points_src).to(device)
     pd = torch.from_numpy(fp.points_dst).to(device)
-    ls = torch.from_numpy(fp.labels_src).to(device)
-    ld = torch.from_numpy(fp.labels_dst).to(device)
+    if fp.labels_src is None:
+        ls, ld = cluster_frame_pair(args, ps, pd, fp.nonground_src, fp.nonground_dst)
+    else:
+        ls = torch.from_numpy(fp.labels_src).to(device)
+        ld = torch.from_numpy(fp.labels_dst).to(device)
     pose = torch.from_numpy(fp.pose).to(device)
     torch.manual_seed(0)                                    # main.py:139 (random subsampling of over-long clusters)
     pairs, T = utils_track.track(a, ps, pd, ls, ld)
@@ -186,7 +218,8 @@ def main(argv=None):
     ap.add_argument("directory")
     ap.add_argument("--repeat", type=int, default=1)
     for k, v in DEFAULT_ARGS.items():
-        ap.add_argument("--" + k.replace("_", "-"), type=float if isinstance(v, float) or v is None else type(v), default=v)
+        kind = str if k == "cluster" else float if isinstance(v, float) or v is None else type(v)
+        ap.add_argument("--" + k.replace("_", "-"), type=kind, default=v)
     ns = ap.parse_args(argv)
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,6 +231,7 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     args = SimpleNamespace(**{k: getattr(ns, k) for k in DEFAULT_ARGS})
     args.max_points, args.min_cluster_size, args.chunk_size = int(args.max_points), int(args.min_cluster_size), int(args.chunk_size)
+    args.num_clusters = int(args.num_clusters)
     summary = run_stream(args, list_frame_pairs(ns.directory), device, rank, world, ns.repeat)
     if rank == 0:
         print(json.dumps(summary))

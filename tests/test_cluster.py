@@ -188,3 +188,29 @@ def test_gpu_ground_threshold_then_cluster_matches_reference_flow():
     ng = utils_ground.segment_ground_thres(a, p)
     assert np.array_equal(ng, g["small_2_nonground"])
     assert np.array_equal(_hip().cluster_pcd(a, p, ng), g["small_2_labels"])
+
+
+@gpu
+def test_gpu_unlabelled_frame_pair_is_clustered_then_registered(tmp_path):
+    """demo frame pair WITHOUT labels through the stream: joint DBSCAN on the GPU (demo.py:210) + track +
+    flow equals the same registration fed with the CPU port's labels; flow error against ground truth is
+    that of a sensible clustering."""
+    from icp_flow_amd import frame_pairs
+    g = load_golden("g8_demo")
+    fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], None, None, None, g["gt_flow"])
+    frame_pairs.save_frame_pair(str(tmp_path / "demo.npz"), fp)
+    back = frame_pairs.load_frame_pair(str(tmp_path / "demo.npz"))
+    assert back.labels_src is None
+    dev = torch.device("cuda", 0)
+    a = frame_pairs.default_args(max_points=2048, cluster="dbscan", epsilon=0.25, min_cluster_size=20, num_clusters=200)
+    got = frame_pairs.register_frame_pair(a, back, dev)
+    ca = SimpleNamespace(epsilon=0.25, min_cluster_size=20, num_clusters=200, if_hdbscan=False)
+    lab = oc.cluster_pcd(ca, _demo_points(), np.ones(len(g["point_src"]) + len(g["point_dst"]), dtype=bool))
+    nd = len(g["point_dst"])
+    want_fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab[nd:], lab[:nd], None, g["gt_flow"])
+    want = frame_pairs.register_frame_pair(frame_pairs.default_args(max_points=2048), want_fp, dev)
+    assert torch.equal(got["pairs"], want["pairs"]) and torch.equal(got["flow"], want["flow"])
+    epe = float(np.linalg.norm(got["flow"].cpu().numpy() - g["gt_flow"], axis=1).mean())
+    assert len(got["pairs"]) > 40 and epe < 0.12, (len(got["pairs"]), epe)
+    with pytest.raises(ValueError):
+        frame_pairs.register_frame_pair(frame_pairs.default_args(max_points=2048), back, dev)

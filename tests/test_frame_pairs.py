@@ -63,12 +63,21 @@ def test_frame_pair_formats_round_trip(tmp_path):
     argo = frame_pairs.load_frame_pair(q)
     assert np.array_equal(argo.points_src, fp.points_src[v0]) and np.array_equal(argo.points_dst, fp.points_dst[v1])
     assert np.array_equal(argo.gt_flow, fp.gt_flow[v0]) and np.array_equal(argo.pose, np.eye(4, dtype=np.float32))
-    # labels are mandatory and must be one per point
-    np.savez(os.path.join(tmp_path, "c.npz"), points_src=fp.points_src, points_dst=fp.points_dst)
+    # labels must be one per point; a pair without labels loads (it is clustered on the GPU when the
+    # arguments name a clustering, else registering it is an error) and keeps its non-ground flags
+    ng = np.arange(ns) % 3 != 0
+    np.savez(os.path.join(tmp_path, "c.npz"), points_src=fp.points_src, points_dst=fp.points_dst, nonground_src=ng)
+    bare = frame_pairs.load_frame_pair(os.path.join(tmp_path, "c.npz"))
+    assert bare.labels_src is None and bare.labels_dst is None and bare.nonground_dst is None
+    assert np.array_equal(bare.nonground_src, ng)
     with pytest.raises(ValueError):
-        frame_pairs.load_frame_pair(os.path.join(tmp_path, "c.npz"))
+        frame_pairs.cluster_frame_pair(frame_pairs.default_args(), None, None)
     with pytest.raises(ValueError):
         frame_pairs.FramePair(fp.points_src, fp.points_dst, fp.labels_src[:-1], fp.labels_dst)
+    with pytest.raises(ValueError):
+        frame_pairs.FramePair(fp.points_src, fp.points_dst, fp.labels_src, None)
+    with pytest.raises(ValueError):
+        frame_pairs.FramePair(fp.points_src, fp.points_dst, nonground_src=ng[:-1])
     assert frame_pairs.list_frame_pairs(str(tmp_path)) == sorted(os.path.join(tmp_path, f) for f in ("a.npz", "b.npz", "c.npz"))
 
 
