@@ -423,6 +423,37 @@ int icpflow_dbscan(const float *d_points, int stride, const uint8_t *d_mask, int
     return 0;
 }
 
+size_t icpflow_hdbscan_mst_workspace_bytes(int n)
+{
+    if (n <= 0) return 0;
+    size_t bytes = 0;
+    if (hdbscan_workspace_bytes(n, &bytes) != hipSuccess) return 0;
+    return bytes;
+}
+
+int icpflow_hdbscan_mst(const float *d_points, int stride, const uint8_t *d_mask, int n, int min_samples, double cell,
+                        double *d_core2, int32_t *d_edge_a, int32_t *d_edge_b, double *d_edge_w2,
+                        int32_t *d_num_edges, int32_t *d_num_live, void *d_ws, size_t ws_bytes,
+                        icpflow_stream_t stream)
+{
+    if (!d_points || !d_edge_a || !d_edge_b || !d_edge_w2 || !d_num_edges || !d_num_live)
+        return fail(ICPFLOW_E_ARG, "icpflow_hdbscan_mst: null pointer");
+    if (n <= 0) return fail(ICPFLOW_E_ARG, "icpflow_hdbscan_mst: n must be positive (got %d)", n);
+    if (stride < 3) return fail(ICPFLOW_E_ARG, "icpflow_hdbscan_mst: stride must be >= 3 floats (got %d)", stride);
+    if (min_samples < 1 || min_samples > 64)
+        return fail(ICPFLOW_E_LIMIT, "icpflow_hdbscan_mst: min_samples must be in 1..64 (got %d)", min_samples);
+    if (!(cell > 0.0)) return fail(ICPFLOW_E_ARG, "icpflow_hdbscan_mst: cell must be positive (got %g)", cell);
+    if (!d_ws) return fail(ICPFLOW_E_WORKSPACE, "icpflow_hdbscan_mst: workspace is NULL");
+    bool tooSmall = false;
+    ICPFLOW_TRY(launch_hdbscan_mst(d_points, stride, d_mask, n, min_samples, cell, d_core2, d_edge_a, d_edge_b,
+                                   d_edge_w2, d_num_edges, d_num_live, d_ws, ws_bytes, &tooSmall,
+                                   (hipStream_t)stream));
+    if (tooSmall)
+        return fail(ICPFLOW_E_WORKSPACE, "icpflow_hdbscan_mst: workspace too small (%zu bytes, need %zu)", ws_bytes,
+                    icpflow_hdbscan_mst_workspace_bytes(n));
+    return 0;
+}
+
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
                           const int64_t *d_count, const float *d_labels, int L, float *d_mean, float *d_extent,
                           icpflow_stream_t stream)

@@ -21,30 +21,14 @@
 #include <rocprim/rocprim.hpp>
 
 #include "kernels.hpp"
+#include "cluster_util.hpp"
 
 namespace icpflow {
 
 namespace {
 
-constexpr int kCellBits = 21;
-constexpr unsigned long long kMaskedKey = 0x7fffffffffffffffull;   // sorts after every real cell
-constexpr int kRuns = 9;                                            // (dx, dy) columns of neighbour cells
+constexpr int kRuns = 9;     // (dx, dy) columns of neighbour cells
 constexpr int kBlock = 256;
-
-__device__ inline long long cell_coord(float v, double invCell)
-{
-    // monotone in v; two points closer than eps fall into the same or adjacent cells (cell > eps).
-    // Clamped so that +-1 stays inside the 21-bit field (clamping keeps adjacency).
-    double q = floor((double)v * invCell) + (double)(1 << (kCellBits - 1));
-    q = fmin(fmax(q, 1.0), (double)((1 << kCellBits) - 2));
-    return (long long)q;
-}
-
-__device__ inline unsigned long long pack_key(long long cx, long long cy, long long cz)
-{
-    return ((unsigned long long)cx << (2 * kCellBits)) | ((unsigned long long)cy << kCellBits) |
-           (unsigned long long)cz;
-}
 
 __global__ __launch_bounds__(kBlock) void dbscan_key_kernel(const float *__restrict__ pts, int stride,
                                                             const uint8_t *__restrict__ mask, int n, double invCell,
@@ -143,39 +127,6 @@ __global__ __launch_bounds__(kBlock) void dbscan_core_kernel(const float4 *__res
         }
     }
     if (lane == 0) core[j] = cnt >= minPoints ? 1 : 0;   // the point itself is one of its neighbours (distance 0)
-}
-
-__device__ inline int uf_load(const int *parent, int i)
-{
-    return __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ inline int uf_find(int *parent, int i)
-{
-    int p = uf_load(parent, i);
-    while (p != i) {
-        const int g = uf_load(parent, p);
-        if (g != p) __hip_atomic_store(parent + i, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path splitting
-        i = p;
-        p = g;
-    }
-    return i;
-}
-
-// roots only ever move to SMALLER indices, so the root of a finished component is its smallest member
-__device__ inline void uf_union(int *parent, int a, int b)
-{
-    for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
-        if (a == b) return;
-        if (a < b) {
-            const int t = a;
-            a = b;
-            b = t;
-        }
-        if (atomicCAS(parent + a, a, b) == a) return;
-    }
 }
 
 // The union-find runs over SORTED positions (neighbours of a point are contiguous rows, so the parent
@@ -370,8 +321,6 @@ __global__ __launch_bounds__(kBlock) void dbscan_label_kernel(const float4 *__re
         if (l == lv) pending = false;
     }
 }
-
-size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 
 struct Carve {
     unsigned long long *keyIn, *keyOut;

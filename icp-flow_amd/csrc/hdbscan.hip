@@ -1,0 +1,578 @@
+// hdbscan.hip -- the O(n^2) part of HDBSCAN on the GPU: core distances and the minimum spanning tree of the
+// mutual-reachability graph (second half).
+//
+// Replaces what `cluster_hdbscan` (utils_cluster.py:10-29) spends its time in: hdbscan.HDBSCAN(min_cluster_size,
+// min_samples=None, metric='euclidean', alpha=1) computes, per point, the distance to its min_samples-th nearest
+// neighbour (itself included) = core distance, then a minimum spanning tree of the complete graph under
+//     d_mreach(a, b) = max(core(a), core(b), |a - b|),
+// and only then the (cheap, sequential) dendrogram / condensed tree / cluster selection, which stays host
+// logic (icp-flow_amd/utils_cluster.py).  The pinned library builds the tree with an approximate dual-tree
+// Boruvka; sklearn's port uses exact Prim, O(n^2) distance evaluations on one core.  Here: EXACT Boruvka.
+//
+//   * points are sorted by a uniform-grid cell key (x-major), so 64 consecutive rows ("chunk") are a compact
+//     box; per chunk: its bounding box, and running min/max of x over all later/earlier chunks;
+//   * every search is one WAVE per point walking chunks outward from its own: lanes test 64 chunk boxes at
+//     a time against the current bound, the wave visits only the chunks that can still matter, nearest box
+//     first, and a direction ends when the x gap alone exceeds the bound;
+//   * core distance: the wave keeps the 64 smallest squared distances sorted across its lanes (bitonic merge);
+//   * Boruvka round: nearest point of ANOTHER component under (weight, smaller row, larger row) -- a strict
+//     total order, so the chosen edges never close a cycle; chunks whose rows all belong to the query's
+//     component are skipped without being read; per component the lightest edge wins by two rounds of
+//     64-bit atomicMin; winners append their edge and hook the components (lock-free union-find).
+//   No host synchronisation: ceil(log2 n) + 1 rounds are enqueued, rounds after the last merge return at once.
+// Everything is evaluated on SQUARED distances in fp64 without contraction (the order of the weights is
+// that of their square roots; the host takes the roots of the n - 1 winners).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "kernels.hpp"
+#include "cluster_util.hpp"
+
+namespace icpflow {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr double kInfD = __builtin_huge_val();
+constexpr unsigned long long kNoKey = ~0ull;
+
+struct Chunks {
+    const float *bmin;      // [3][numChunks]
+    const float *bmax;      // [3][numChunks]
+    const double *sufMinX;  // min x over chunks >= t
+    const double *preMaxX;  // max x over chunks <= t
+};
+
+struct Hdb {
+    const float4 *sorted;   // (x, y, z, caller row) in cell-key order, live rows first
+    const int *nLive;       // rows that take part (finite, not masked)
+    Chunks ch;
+    double *core2;          // squared core distance
+    int *comp;              // component (root position) at the start of the round
+    int *parent;            // union-find over positions
+    int *chunkComp;         // component shared by all rows of the chunk, or -1
+    double *bestW2;         // per point: lightest edge to another component this round
+    unsigned long long *bestKey;
+    int *bestQ;
+    unsigned long long *compW;    // per root: bits of the lightest weight / its (row, row) key
+    unsigned long long *compKey;
+    int *numComp;           // [rounds + 1]
+    int32_t *edgeA, *edgeB;
+    double *edgeW2;
+    int *numEdges;
+};
+
+__global__ __launch_bounds__(kBlock) void hdb_key_kernel(const float *__restrict__ pts, int stride,
+                                                         const uint8_t *__restrict__ mask, int n, double invCell,
+                                                         unsigned long long *__restrict__ key, int *__restrict__ val)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float x = pts[(size_t)i * stride], y = pts[(size_t)i * stride + 1], z = pts[(size_t)i * stride + 2];
+    const bool live = (!mask || mask[i]) && isfinite(x) && isfinite(y) && isfinite(z);
+    key[i] = live ? pack_key(cell_coord(x, invCell), cell_coord(y, invCell), cell_coord(z, invCell)) : kMaskedKey;
+    val[i] = i;
+}
+
+__global__ __launch_bounds__(kBlock) void hdb_gather_kernel(const float *__restrict__ pts, int stride,
+                                                            const unsigned long long *__restrict__ key,
+                                                            const int *__restrict__ val, int n,
+                                                            float4 *__restrict__ sorted, int *__restrict__ nLive,
+                                                            int *__restrict__ parent, int *__restrict__ comp,
+                                                            int *__restrict__ numComp, int *__restrict__ numEdges,
+                                                            int rounds)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const int i = val[j];
+    sorted[j] = make_float4(pts[(size_t)i * stride], pts[(size_t)i * stride + 1], pts[(size_t)i * stride + 2],
+                            __int_as_float(i));
+    parent[j] = j;
+    comp[j] = j;
+    const bool live = key[j] != kMaskedKey;
+    if (live && (j + 1 == n || key[j + 1] == kMaskedKey)) {   // last live row
+        *nLive = j + 1;
+        numComp[0] = j + 1;
+    }
+    if (j == 0) {
+        if (!live) {
+            *nLive = 0;
+            numComp[0] = 0;
+        }
+        *numEdges = 0;
+        for (int r = 1; r <= rounds; ++r) numComp[r] = 0;
+    }
+}
+
+// bounding box of every chunk of 64 sorted rows (one wave each)
+__global__ __launch_bounds__(kBlock) void hdb_chunk_box_kernel(const float4 *__restrict__ sorted,
+                                                               const int *__restrict__ nLivePtr, int numChunks,
+                                                               float *__restrict__ bmin, float *__restrict__ bmax)
+{
+    const int t = blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (t >= numChunks) return;
+    const int lane = threadIdx.x & 63, nLive = *nLivePtr;
+    const int q = t * 64 + lane;
+    float lo[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()};
+    float hi[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    if (q < nLive) {
+        const float4 p = sorted[q];
+        lo[0] = hi[0] = p.x;
+        lo[1] = hi[1] = p.y;
+        lo[2] = hi[2] = p.z;
+    }
+    for (int d = 32; d > 0; d >>= 1)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], d));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d));
+        }
+    if (lane < 3) {
+        bmin[(size_t)lane * numChunks + t] = lo[lane];
+        bmax[(size_t)lane * numChunks + t] = hi[lane];
+    }
+}
+
+// running extremes of x over the chunks (one workgroup; a frame pair has a few thousand chunks)
+__global__ __launch_bounds__(1024) void hdb_chunk_runs_kernel(const float *__restrict__ bmin,
+                                                              const float *__restrict__ bmax, int numChunks,
+                                                              double *__restrict__ sufMinX,
+                                                              double *__restrict__ preMaxX)
+{
+    __shared__ double part[1024];
+    const int t = threadIdx.x;
+    const int per = (numChunks + 1023) / 1024;
+    const int lo = min(numChunks, t * per), hi = min(numChunks, lo + per);
+    // prefix max
+    double m = -kInfD;
+    for (int i = lo; i < hi; ++i) m = fmax(m, (double)bmax[i]);
+    part[t] = m;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const double v = t >= d ? part[t - d] : -kInfD;
+        __syncthreads();
+        part[t] = fmax(part[t], v);
+        __syncthreads();
+    }
+    double run = t > 0 ? part[t - 1] : -kInfD;
+    for (int i = lo; i < hi; ++i) {
+        run = fmax(run, (double)bmax[i]);
+        preMaxX[i] = run;
+    }
+    __syncthreads();
+    // suffix min
+    m = kInfD;
+    for (int i = lo; i < hi; ++i) m = fmin(m, (double)bmin[i]);
+    part[t] = m;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const double v = t + d < 1024 ? part[t + d] : kInfD;
+        __syncthreads();
+        part[t] = fmin(part[t], v);
+        __syncthreads();
+    }
+    run = t < 1023 ? part[t + 1] : kInfD;
+    for (int i = hi - 1; i >= lo; --i) {
+        run = fmin(run, (double)bmin[i]);
+        sufMinX[i] = run;
+    }
+}
+
+__device__ inline double shfl_xor_f64(double v, int d)
+{
+    const int lo = __shfl_xor(__double2loint(v), d), hi = __shfl_xor(__double2hiint(v), d);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double shfl_f64(double v, int src)
+{
+    const int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline unsigned long long shfl_xor_u64(unsigned long long v, int d)
+{
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, d), hi = (unsigned)__shfl_xor((int)(v >> 32), d);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ inline double wave_min_f64(double v)
+{
+    for (int d = 32; d > 0; d >>= 1) v = fmin(v, shfl_xor_f64(v, d));
+    return v;
+}
+
+__device__ inline double sq_dist(double px, double py, double pz, const float4 t)
+{
+    const double dx = px - (double)t.x, dy = py - (double)t.y, dz = pz - (double)t.z;
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+// Walk the chunks outward from chunk `own` of a point at (px, py, pz).  `bound()` is the wave-uniform
+// squared radius that can still matter; `skip(t)` (per lane) drops chunk t unread; `visit(t)` processes
+// it.  A chunk is visited when its box is within the bound, nearest box first inside a group of 64 chunks.
+template <class Bound, class Skip, class Visit>
+__device__ inline void walk_chunks(const Chunks &ch, int numChunks, int own, double px, double py, double pz,
+                                   Bound bound, Skip skip, Visit visit)
+{
+    const int lane = threadIdx.x & 63;
+    const int groups = (numChunks + 63) >> 6, g0 = own >> 6;
+    visit(own);
+    bool rightDone = false, leftDone = false;
+    for (int step = 0; step < 2 * groups; ++step) {
+        const int off = (step + 1) >> 1;
+        const int g = (step & 1) ? g0 - off : g0 + off;   // g0, g0 - 1, g0 + 1, g0 - 2, ...
+        if (g < 0 || g >= groups) continue;
+        if (g > g0 && rightDone) continue;
+        if (g < g0 && leftDone) continue;
+        const int t = g * 64 + lane;
+        const bool valid = t < numChunks && t != own;
+        double lb2 = kInfD;
+        bool termR = false, termL = false;
+        if (valid) {
+            const double gx = fmax(fmax((double)ch.bmin[t] - px, px - (double)ch.bmax[t]), 0.0);
+            const double gy = fmax(fmax((double)ch.bmin[numChunks + t] - py, py - (double)ch.bmax[numChunks + t]), 0.0);
+            const double gz = fmax(fmax((double)ch.bmin[2 * numChunks + t] - pz, pz - (double)ch.bmax[2 * numChunks + t]), 0.0);
+            lb2 = __dadd_rn(__dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy)), __dmul_rn(gz, gz));
+            const double b = bound();
+            if (t > own) {
+                const double d = ch.sufMinX[t] - px;
+                termR = d > 0.0 && __dmul_rn(d, d) > b;
+            } else {
+                const double d = px - ch.preMaxX[t];
+                termL = d > 0.0 && __dmul_rn(d, d) > b;
+            }
+        }
+        if (__ballot(termR)) rightDone = true;   // every later chunk is at least as far in x
+        if (__ballot(termL)) leftDone = true;
+        bool pending = valid && !skip(t);
+        for (;;) {
+            const double b = bound();
+            const bool cand = pending && lb2 <= b;
+            const unsigned long long any = __ballot(cand);
+            if (!any) break;
+            const double v = cand ? lb2 : kInfD;
+            const double vmin = wave_min_f64(v);
+            const int pick = __builtin_ctzll(__ballot(cand && v == vmin));
+            visit(g * 64 + pick);
+            if (lane == pick) pending = false;
+        }
+    }
+}
+
+// 64 smallest values seen so far, ascending across the lanes of the wave
+__device__ inline double wave_sort_asc(double x)
+{
+    const int lane = threadIdx.x & 63;
+    for (int k = 2; k <= 64; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const double o = shfl_xor_f64(x, j);
+            const bool up = (lane & k) == 0 || k == 64;
+            const bool lower = (lane & j) == 0;
+            x = (lower == up) ? fmin(x, o) : fmax(x, o);
+        }
+    return x;
+}
+
+__device__ inline double wave_merge_smallest(double best, double fresh)
+{
+    const int lane = threadIdx.x & 63;
+    fresh = wave_sort_asc(fresh);
+    double w = fmin(best, shfl_f64(fresh, 63 - lane));   // the 64 smallest of both, a bitonic sequence
+    for (int j = 32; j > 0; j >>= 1) {
+        const double o = shfl_xor_f64(w, j);
+        w = ((lane & j) == 0) ? fmin(w, o) : fmax(w, o);
+    }
+    return w;
+}
+
+__global__ __launch_bounds__(kBlock) void hdb_core_kernel(Hdb h, int numChunks, int k)
+{
+    const int nLive = *h.nLive;
+    const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (threadIdx.x >> 6));
+    if (j >= nLive) return;
+    const int lane = threadIdx.x & 63;
+    const float4 p = h.sorted[j];
+    const double px = p.x, py = p.y, pz = p.z;
+    double best = kInfD;
+    double kth = kInfD;
+    walk_chunks(
+        h.ch, numChunks, j >> 6, px, py, pz, [&]() { return kth; }, [&](int) { return false; },
+        [&](int t) {
+            const int q = t * 64 + lane;
+            double d2 = kInfD;
+            if (q < nLive) d2 = sq_dist(px, py, pz, h.sorted[q]);
+            if (__ballot(d2 < kth) == 0) return;
+            best = wave_merge_smallest(best, d2);
+            kth = shfl_f64(best, k - 1);
+        });
+    if (lane == 0) h.core2[j] = kth;
+}
+
+__global__ __launch_bounds__(kBlock) void hdb_scan_kernel(Hdb h, int numChunks, int round)
+{
+    if (h.numComp[round] <= 1) return;
+    const int nLive = *h.nLive;
+    const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (threadIdx.x >> 6));
+    if (j >= nLive) return;
+    const int lane = threadIdx.x & 63;
+    const float4 p = h.sorted[j];
+    const double px = p.x, py = p.y, pz = p.z;
+    const int me = __float_as_int(p.w);
+    const int myComp = h.comp[j];
+    const double myCore2 = h.core2[j];
+    double bw = kInfD;                 // lane-local lightest edge
+    unsigned long long bk = kNoKey;
+    int bq = -1;
+    double bnd = kInfD;                // wave-uniform min of bw
+    walk_chunks(
+        h.ch, numChunks, j >> 6, px, py, pz, [&]() { return bnd; },
+        [&](int t) { return h.chunkComp[t] == myComp; },
+        [&](int t) {
+            const int q = t * 64 + lane;
+            double w2 = kInfD;
+            if (q < nLive && h.comp[q] != myComp) {
+                const float4 c = h.sorted[q];
+                w2 = fmax(fmax(myCore2, h.core2[q]), sq_dist(px, py, pz, c));
+                const int other = __float_as_int(c.w);
+                const unsigned long long key =
+                    ((unsigned long long)(unsigned)min(me, other) << 32) | (unsigned)max(me, other);
+                if (w2 < bw || (w2 == bw && key < bk)) {
+                    bw = w2;
+                    bk = key;
+                    bq = q;
+                }
+            }
+            bnd = fmin(bnd, wave_min_f64(w2));
+        });
+    // lightest edge of the wave: (weight, key) lexicographic
+    const double wmin = wave_min_f64(bw);
+    unsigned long long kk = (bw == wmin) ? bk : kNoKey;
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o = shfl_xor_u64(kk, d);
+        kk = o < kk ? o : kk;
+    }
+    if (bw == wmin && bk == kk && bq >= 0) {   // exactly one lane: keys are unique
+        h.bestW2[j] = bw;
+        h.bestKey[j] = bk;
+        h.bestQ[j] = bq;
+    }
+    if (lane == 0 && !(wmin < kInfD)) {
+        h.bestW2[j] = kInfD;
+        h.bestKey[j] = kNoKey;
+        h.bestQ[j] = -1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void hdb_reduce_weight_kernel(Hdb h, int round)
+{
+    if (h.numComp[round] <= 1) return;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= *h.nLive) return;
+    const double w = h.bestW2[j];
+    if (w < kInfD) atomicMin(h.compW + h.comp[j], (unsigned long long)__double_as_longlong(w));
+}
+
+__global__ __launch_bounds__(kBlock) void hdb_reduce_key_kernel(Hdb h, int round)
+{
+    if (h.numComp[round] <= 1) return;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= *h.nLive) return;
+    const double w = h.bestW2[j];
+    if (w < kInfD && (unsigned long long)__double_as_longlong(w) == h.compW[h.comp[j]])
+        atomicMin(h.compKey + h.comp[j], h.bestKey[j]);
+}
+
+__global__ __launch_bounds__(kBlock) void hdb_select_kernel(Hdb h, int round)
+{
+    if (h.numComp[round] <= 1) return;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= *h.nLive) return;
+    const double w = h.bestW2[j];
+    if (!(w < kInfD)) return;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(w), key = h.bestKey[j];
+    const int c = h.comp[j];
+    if (bits != h.compW[c] || key != h.compKey[c]) return;
+    const int q = h.bestQ[j], cq = h.comp[q];
+    const bool mutual = h.compW[cq] == bits && h.compKey[cq] == key;   // the other side chose the same edge
+    const int a = __float_as_int(h.sorted[j].w), b = __float_as_int(h.sorted[q].w);
+    if (!mutual || a < b) {
+        const int e = atomicAdd(h.numEdges, 1);
+        h.edgeA[e] = a;
+        h.edgeB[e] = b;
+        h.edgeW2[e] = w;
+    }
+    uf_union(h.parent, c, cq);
+}
+
+// components of the next round; chunk-uniform components; reset of the per-round records
+__global__ __launch_bounds__(kBlock) void hdb_flatten_kernel(Hdb h, int round)
+{
+    if (h.numComp[round] <= 1) return;
+    const int nLive = *h.nLive;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int root = -1;
+    if (j < nLive) {
+        root = uf_find(h.parent, j);
+        h.parent[j] = root;
+        h.comp[j] = root;
+        h.compW[j] = ~0ull;
+        h.compKey[j] = kNoKey;
+    }
+    const unsigned long long live = __ballot(j < nLive);
+    if (live) {
+        const int first = __shfl(root, __builtin_ctzll(live));
+        const bool uniform = __ballot(j < nLive && root != first) == 0;
+        if (lane == 0) h.chunkComp[j >> 6] = uniform ? first : -1;
+    }
+    const unsigned long long roots = __ballot(j < nLive && root == j);
+    if (lane == 0 && roots) atomicAdd(h.numComp + round + 1, (int)__popcll(roots));
+}
+
+__global__ __launch_bounds__(kBlock) void hdb_round_init_kernel(Hdb h, int n)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    h.compW[j] = ~0ull;
+    h.compKey[j] = kNoKey;
+    if ((j & 63) == 0) h.chunkComp[j >> 6] = -1;   // singletons: no chunk is uniform
+}
+
+// squared core distances in the caller's row order (NaN for rows that took no part)
+__global__ __launch_bounds__(kBlock) void hdb_core_out_kernel(Hdb h, int n, double *__restrict__ out)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    out[__float_as_int(h.sorted[j].w)] = j < *h.nLive ? h.core2[j] : __longlong_as_double(0x7ff8000000000000ll);
+}
+
+struct Carve {
+    unsigned long long *keyIn, *keyOut;
+    int *valIn, *valOut;
+    double *core2;
+    float4 *sorted;
+    float *bmin, *bmax;
+    double *sufMinX, *preMaxX;
+    int *nLive, *numComp, *comp, *parent, *chunkComp, *bestQ;
+    double *bestW2;
+    unsigned long long *bestKey, *compW, *compKey;
+    void *sortTmp;
+    size_t sortTmpBytes, total;
+    int numChunks, rounds;
+};
+
+int boruvka_rounds(int n)
+{
+    int r = 1;
+    while ((1ll << r) < (long long)n) ++r;
+    return r + 1;
+}
+
+hipError_t carve(int n, void *ws, Carve *c, hipStream_t s)
+{
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (unsigned long long *)nullptr,
+                                             (unsigned long long *)nullptr, (int *)nullptr, (int *)nullptr,
+                                             (size_t)n, 0, 63, s);
+    if (e != hipSuccess) return e;
+    char *p = (char *)ws;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *q = p ? p + off : nullptr;
+        off += up256(bytes);
+        return q;
+    };
+    const size_t N = (size_t)n;
+    c->numChunks = (n + 63) / 64;
+    c->rounds = boruvka_rounds(n);
+    const size_t C = (size_t)c->numChunks;
+    c->keyIn = (unsigned long long *)take(N * 8);
+    c->keyOut = (unsigned long long *)take(N * 8);
+    c->valIn = (int *)take(N * 4);
+    c->valOut = (int *)take(N * 4);
+    c->sorted = (float4 *)take(N * 16);
+    c->core2 = (double *)take(N * 8);
+    c->bmin = (float *)take(C * 12);
+    c->bmax = (float *)take(C * 12);
+    c->sufMinX = (double *)take(C * 8);
+    c->preMaxX = (double *)take(C * 8);
+    c->nLive = (int *)take(4);
+    c->numComp = (int *)take((size_t)(c->rounds + 2) * 4);
+    c->comp = (int *)take(N * 4);
+    c->parent = (int *)take(N * 4);
+    c->chunkComp = (int *)take(C * 4);
+    c->bestQ = (int *)take(N * 4);
+    c->bestW2 = (double *)take(N * 8);
+    c->bestKey = (unsigned long long *)take(N * 8);
+    c->compW = (unsigned long long *)take(N * 8);
+    c->compKey = (unsigned long long *)take(N * 8);
+    c->sortTmp = take(tmp);
+    c->sortTmpBytes = tmp;
+    c->total = off;
+    return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t hdbscan_workspace_bytes(int n, size_t *bytes)
+{
+    Carve c;
+    hipError_t e = carve(n, nullptr, &c, nullptr);
+    *bytes = e == hipSuccess ? c.total : 0;
+    return e;
+}
+
+hipError_t launch_hdbscan_mst(const float *pts, int stride, const uint8_t *mask, int n, int minSamples, double cell,
+                              double *core2, int32_t *edgeA, int32_t *edgeB, double *edgeW2, int32_t *numEdges,
+                              int32_t *numLive, void *ws, size_t wsBytes, bool *wsTooSmall, hipStream_t s)
+{
+    Carve c;
+    hipError_t e = carve(n, ws, &c, s);
+    if (e != hipSuccess) return e;
+    *wsTooSmall = c.total > wsBytes;
+    if (*wsTooSmall) return hipSuccess;
+    const int blocks = (n + kBlock - 1) / kBlock;
+    const int waveBlocks = (n + kWaves - 1) / kWaves;
+    hdb_key_kernel<<<blocks, kBlock, 0, s>>>(pts, stride, mask, n, 1.0 / cell, c.keyIn, c.valIn);
+    e = rocprim::radix_sort_pairs(c.sortTmp, c.sortTmpBytes, c.keyIn, c.keyOut, c.valIn, c.valOut, (size_t)n, 0, 63,
+                                  s);
+    if (e != hipSuccess) return e;
+    hdb_gather_kernel<<<blocks, kBlock, 0, s>>>(pts, stride, c.keyOut, c.valOut, n, c.sorted, numLive, c.parent,
+                                                c.comp, c.numComp, numEdges, c.rounds);
+    Hdb h;
+    h.sorted = c.sorted;
+    h.nLive = numLive;
+    h.ch = Chunks{c.bmin, c.bmax, c.sufMinX, c.preMaxX};
+    h.core2 = c.core2;
+    h.comp = c.comp;
+    h.parent = c.parent;
+    h.chunkComp = c.chunkComp;
+    h.bestW2 = c.bestW2;
+    h.bestKey = c.bestKey;
+    h.bestQ = c.bestQ;
+    h.compW = c.compW;
+    h.compKey = c.compKey;
+    h.numComp = c.numComp;
+    h.edgeA = edgeA;
+    h.edgeB = edgeB;
+    h.edgeW2 = edgeW2;
+    h.numEdges = numEdges;
+    hdb_chunk_box_kernel<<<(c.numChunks + kWaves - 1) / kWaves, kBlock, 0, s>>>(c.sorted, numLive, c.numChunks, c.bmin,
+                                                                                c.bmax);
+    hdb_chunk_runs_kernel<<<1, 1024, 0, s>>>(c.bmin, c.bmax, c.numChunks, c.sufMinX, c.preMaxX);
+    hdb_core_kernel<<<waveBlocks, kBlock, 0, s>>>(h, c.numChunks, minSamples);
+    if (core2) hdb_core_out_kernel<<<blocks, kBlock, 0, s>>>(h, n, core2);
+    hdb_round_init_kernel<<<blocks, kBlock, 0, s>>>(h, n);
+    for (int r = 0; r < c.rounds; ++r) {
+        hdb_scan_kernel<<<waveBlocks, kBlock, 0, s>>>(h, c.numChunks, r);
+        hdb_reduce_weight_kernel<<<blocks, kBlock, 0, s>>>(h, r);
+        hdb_reduce_key_kernel<<<blocks, kBlock, 0, s>>>(h, r);
+        hdb_select_kernel<<<blocks, kBlock, 0, s>>>(h, r);
+        hdb_flatten_kernel<<<blocks, kBlock, 0, s>>>(h, r);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace icpflow

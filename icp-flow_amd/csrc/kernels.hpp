@@ -180,4 +180,10 @@ hipError_t launch_dbscan(const float *pts, int stride, const uint8_t *mask, int 
                          int32_t *labels, int32_t *counts, int32_t *numClusters, void *ws, size_t wsBytes,
                          bool *wsTooSmall, hipStream_t s);
 
+// hdbscan.hip: core distances + minimum spanning tree of the mutual-reachability graph
+hipError_t hdbscan_workspace_bytes(int n, size_t *bytes);
+hipError_t launch_hdbscan_mst(const float *pts, int stride, const uint8_t *mask, int n, int minSamples, double cell,
+                              double *core2, int32_t *edgeA, int32_t *edgeB, double *edgeW2, int32_t *numEdges,
+                              int32_t *numLive, void *ws, size_t wsBytes, bool *wsTooSmall, hipStream_t s);
+
 }  // namespace icpflow

@@ -8,8 +8,14 @@ a GPU tensor in -> GPU tensor out (labels stay resident for ClusterTable / match
 
 The neighbour search, core test, component labelling and sizes run in libicpflow_hip.so
 (`icpflow_dbscan`, csrc/cluster.hip); the choice of the clusters to keep is the reference's own numpy
-expression applied to the C cluster sizes (a few hundred numbers).  `cluster_hdbscan` is NOT built:
-the hdbscan package's approximate Boruvka spanning tree is not reproducible here.
+expression applied to the C cluster sizes (a few hundred numbers).
+
+`cluster_hdbscan(args, points)` (utils_cluster.py:10-29): the O(n^2) part -- core distances and the exact
+minimum spanning tree of the mutual-reachability graph -- runs in libicpflow_hip.so (`icpflow_hdbscan_mst`,
+csrc/hdbscan.hip); the sequential remainder on the n - 1 tree edges (sort, dendrogram, condensed tree,
+excess-of-mass selection) is delegated on the host to scikit-learn's compiled HDBSCAN routines, the same
+family of code the reference delegates to (`hdbscan` 0.8.29, whose approximate spanning tree is not
+reproducible).
 """
 import numpy as np
 import torch
@@ -86,8 +92,6 @@ def cluster_dbscan(args, points):
 def cluster_pcd(args, points, idxs_nonground):
     """utils_cluster.py:50-63: float64 labels, ground rows -1e8, the rest from cluster_dbscan of the
     non-ground rows (the mask is applied inside the kernels; no compacted copy is made)."""
-    if getattr(args, "if_hdbscan", False):
-        return cluster_hdbscan(args, points)
     _, resident = _device_points(points)
     if isinstance(idxs_nonground, torch.Tensor):
         mask = idxs_nonground
@@ -97,12 +101,111 @@ def cluster_pcd(args, points, idxs_nonground):
         full = np.zeros(len(points), dtype=bool)
         full[np.asarray(mask.cpu() if isinstance(mask, torch.Tensor) else mask)] = True
         mask = full
+    if getattr(args, "if_hdbscan", False):
+        lab_h = cluster_hdbscan(args, points, mask.cpu().numpy() if isinstance(mask, torch.Tensor) else mask)
+        out_h = np.where(lab_h == -2, -1e8, lab_h.astype(np.float64))
+        return torch.from_numpy(out_h).to(points.device) if resident else out_h
     lab = _cluster(args, points, mask)
     out = torch.where(lab == -2, torch.full((), -1e8, dtype=torch.float64, device=lab.device), lab.double())
     return out if resident else out.cpu().numpy()
 
 
-def cluster_hdbscan(args, points):
-    raise NotImplementedError(
-        "icp_flow_amd: cluster_hdbscan (utils_cluster.py:10-29) is not built -- pass labels computed upstream, "
-        "or use the DBSCAN branch (if_hdbscan=False); see DESIGN.md section 8")
+def hdbscan_mst(points, min_samples, mask=None, cell=0.25):
+    """Core distances and the minimum spanning tree of the mutual-reachability graph on the GPU.
+    -> dict of GPU tensors: a, b (int32 caller rows), w2 (float64 squared weights) of the n_live - 1 tree
+    edges, core2 (float64 [n] squared core distance, NaN for rows that took no part), n_live (int)."""
+    pts, _ = _device_points(points)
+    if pts.dim() != 2 or pts.shape[1] < 3:
+        raise RuntimeError(f"hdbscan_mst: expected points [n, >=3], got {tuple(pts.shape)}")
+    pts = pts.float().contiguous()
+    dev = pts.device
+    n = pts.shape[0]
+    if n == 0:
+        raise RuntimeError("hdbscan_mst: no points")
+    m = None
+    if mask is not None:
+        m = mask if isinstance(mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mask))
+        m = m.to(dev).to(torch.uint8).contiguous()
+        if m.shape != (n,):
+            raise RuntimeError(f"hdbscan_mst: mask must have shape ({n},), got {tuple(m.shape)}")
+    a = torch.empty(n, dtype=torch.int32, device=dev)
+    b = torch.empty(n, dtype=torch.int32, device=dev)
+    w2 = torch.empty(n, dtype=torch.float64, device=dev)
+    core2 = torch.empty(n, dtype=torch.float64, device=dev)
+    cnt = torch.empty(2, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(dev, int(_lib._L.icpflow_hdbscan_mst_workspace_bytes(n)))
+    _lib.call("icpflow_hdbscan_mst", _lib.ptr(pts), pts.shape[1], _lib.ptr(m), n, int(min_samples), float(cell),
+              _lib.ptr(core2), _lib.ptr(a), _lib.ptr(b), _lib.ptr(w2), _lib.ptr(cnt[0:1]), _lib.ptr(cnt[1:2]),
+              _lib.ptr(ws), ws.numel(), _lib.stream(dev))
+    ne, nl = (int(v) for v in cnt.cpu())
+    if nl < int(min_samples):
+        raise ValueError(f"hdbscan_mst: {nl} points have no {int(min_samples)}-th nearest neighbour (min_samples)")
+    if ne != max(nl - 1, 0):
+        raise RuntimeError(f"hdbscan_mst: {ne} tree edges for {nl} points (internal error)")
+    return dict(a=a[:ne], b=b[:ne], w2=w2[:ne], core2=core2, n_live=nl)
+
+
+def labels_from_mst(a, b, w, n, min_cluster_size):
+    """The sequential remainder of HDBSCAN on the n - 1 tree edges (host, numpy + scikit-learn's compiled
+    routines): edges directed away from point 0 (the order Prim's algorithm, which sklearn runs from point
+    0, emits them in: source already in the tree, then the new point), sorted by weight, single-linkage
+    dendrogram, condensed tree with min_cluster_size, excess-of-mass selection.  -> int labels [n], -1 noise."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import breadth_first_order
+    from sklearn.cluster._hdbscan._linkage import MST_edge_dtype, make_single_linkage
+    from sklearn.cluster._hdbscan._tree import tree_to_labels
+    a, b = np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)
+    if len(a) != n - 1:
+        raise ValueError(f"labels_from_mst: {len(a)} edges cannot span {n} points")
+    adj = coo_matrix((np.ones(2 * len(a), dtype=np.int8), (np.concatenate([a, b]), np.concatenate([b, a]))),
+                     shape=(n, n)).tocsr()
+    _, pred = breadth_first_order(adj, 0, directed=False)
+    child_is_a = pred[a] == b
+    mst = np.empty(len(a), dtype=MST_edge_dtype)
+    mst["current_node"] = np.where(child_is_a, b, a)
+    mst["next_node"] = np.where(child_is_a, a, b)
+    mst["distance"] = np.asarray(w, dtype=np.float64)
+    # hdbscan.py:_process_mst sorts by weight alone (numpy's unstable argsort: ties land in an order that
+    # depends on the input order); the tree arrives from the GPU in no particular order, so ties are put in a
+    # fixed order here and the labels are reproducible
+    mst = mst[np.lexsort((mst["next_node"], mst["current_node"], mst["distance"]))]
+    labels, _ = tree_to_labels(make_single_linkage(mst), int(min_cluster_size), "eom", False, 0.0, None)
+    return np.asarray(labels)
+
+
+def hdbscan(points, min_cluster_size, min_samples=None, mask=None, cell=0.25):
+    """hdbscan.HDBSCAN(min_cluster_size, min_samples).fit(points).labels_ for euclidean points, alpha 1, EOM
+    selection.  -> int64 numpy labels [n]: cluster id, -1 noise (and non-finite rows), -2 masked out."""
+    k = int(min_cluster_size if min_samples is None else min_samples)
+    t = hdbscan_mst(points, k, mask, cell)
+    n = int(t["core2"].numel())
+    live = torch.isfinite(t["core2"]) | torch.isinf(t["core2"])   # NaN marks rows that took no part
+    live_h = live.cpu().numpy()
+    nl = t["n_live"]
+    if nl < max(k, 2):
+        raise ValueError(f"hdbscan: {nl} points cannot be clustered with min_samples {k}")
+    sub = np.cumsum(live_h) - 1                                     # caller row -> row of the clustered subset
+    a, b = sub[t["a"].cpu().numpy()], sub[t["b"].cpu().numpy()]
+    lab = labels_from_mst(a, b, np.sqrt(t["w2"].cpu().numpy()), nl, min_cluster_size)
+    out = np.full(n, -1, dtype=np.int64)
+    out[live_h] = lab
+    if mask is not None:
+        mh = mask.cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
+        out[~mh.astype(bool)] = -2
+    return out
+
+
+def cluster_hdbscan(args, points, mask=None):
+    """utils_cluster.py:10-29: HDBSCAN(min_cluster_size=args.min_cluster_size, min_samples=None), then only the
+    args.num_clusters largest clusters survive (same numpy expression as the DBSCAN branch, :19-26)."""
+    _, resident = _device_points(points)
+    lab = hdbscan(points, args.min_cluster_size, None, mask)
+    keep = lab >= -1
+    lbls, counts = np.unique(lab[keep], return_counts=True)
+    cluster_info = np.array(list(zip(lbls[1:], counts[1:])))
+    cluster_info = cluster_info[cluster_info[:, 1].argsort()]
+    clusters_labels = cluster_info[::-1][:args.num_clusters, 0]
+    lab[keep & np.isin(lab, clusters_labels, invert=True)] = -1
+    if mask is None:
+        return torch.from_numpy(lab).to(points.device) if resident else lab
+    return lab

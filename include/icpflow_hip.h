@@ -259,6 +259,27 @@ int icpflow_dbscan(const float *d_points, int stride, const uint8_t *d_mask, int
                    icpflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * 8(f) row 4, HDBSCAN branch of cluster_pcd (utils_cluster.py:10-29: hdbscan.HDBSCAN(min_cluster_size,
+ * min_samples=None, metric='euclidean', alpha=1.0), third-party, environment.yml:57): the part that is
+ * O(n^2) on the CPU -- core distances and the minimum spanning tree of the mutual-reachability graph
+ *     d(a, b) = max(core(a), core(b), |a - b|),   core(a) = distance to a's min_samples-th nearest
+ *     neighbour, a itself counted (sklearn / hdbscan: tree.query(X, k=min_samples)[:, -1]).
+ * The dendrogram, condensed tree and cluster selection on the n - 1 edges are sequential host logic
+ * (icp-flow_amd/utils_cluster.py).
+ *
+ * d_points / stride / d_mask as icpflow_dbscan.  cell: edge of the uniform sort grid in metres (speed
+ * only; 0.25 suits LiDAR frames).  Outputs: d_edge_a / d_edge_b int32 [n], d_edge_w2 float64 [n]: the
+ * n_live - 1 tree edges (caller rows, SQUARED weight, unordered); d_num_edges, d_num_live int32 [1];
+ * d_core2 float64 [n] (optional): squared core distance per caller row, NaN for rows that took no part.
+ * Exact: ties between equal weights are broken by (smaller row, larger row), so the tree is unique.
+ * ------------------------------------------------------------------------- */
+size_t icpflow_hdbscan_mst_workspace_bytes(int n);
+int icpflow_hdbscan_mst(const float *d_points, int stride, const uint8_t *d_mask, int n, int min_samples, double cell,
+                        double *d_core2, int32_t *d_edge_a, int32_t *d_edge_b, double *d_edge_w2,
+                        int32_t *d_num_edges, int32_t *d_num_live, void *d_ws, size_t ws_bytes,
+                        icpflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Diagnostics: the vote kernels evaluate (v - min) / (max - min) with the loop-invariant part of
  * the IEEE division hoisted (hist.hip, AxisQuot).  For numerators d_a [n] this returns that
  * quotient (d_fast) next to the compiler's correctly rounded a / (max - min) (d_ieee); the two

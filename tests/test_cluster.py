@@ -168,8 +168,6 @@ def test_gpu_keep_largest_quirks_and_errors():
         oc.cluster_dbscan(a, lone)
     with pytest.raises(IndexError):
         hip.cluster_dbscan(a, lone)
-    with pytest.raises(NotImplementedError):
-        hip.cluster_pcd(SimpleNamespace(if_hdbscan=True), p, np.ones(len(p), bool))
     with pytest.raises(RuntimeError):
         hip.dbscan(torch.zeros(10, 3), 0.3, 5)             # CPU tensor: no CPU path
     with pytest.raises(RuntimeError):
@@ -214,3 +212,130 @@ def test_gpu_unlabelled_frame_pair_is_clustered_then_registered(tmp_path):
     assert len(got["pairs"]) > 40 and epe < 0.12, (len(got["pairs"]), epe)
     with pytest.raises(ValueError):
         frame_pairs.register_frame_pair(frame_pairs.default_args(max_points=2048), back, dev)
+
+
+# ============================================================================ HDBSCAN branch (utils_cluster.py:10-29)
+from oracle import hdbscan as oh  # noqa: E402
+
+
+def _partition_mismatch(a, b):
+    """points whose cluster differs after matching every cluster of `a` to the cluster of `b` it overlaps most
+    (noise is its own class on both sides)"""
+    a, b = np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64)
+    bad = int(((a < 0) != (b < 0)).sum())
+    both = (a >= 0) & (b >= 0)
+    for c in np.unique(a[both]):
+        inside = b[both & (a == c)]
+        bad += int(len(inside) - np.bincount(inside).max())
+    return bad
+
+
+def _lattice(n_side, step=0.25):
+    g = np.stack(np.meshgrid(np.arange(n_side), np.arange(n_side), np.arange(3), indexing="ij"), -1).reshape(-1, 3)
+    return (g * step).astype(np.float32)
+
+
+def test_oracle_tree_weights_equal_sklearn_prim():
+    """Every minimum spanning tree has the same multiset of weights: the oracle's exact tree against the
+    weights of sklearn's Prim tree recorded by the generator (G11), bit for bit."""
+    g = load_golden("g11_hdbscan")
+    for i in (0, 2):
+        p, (k, _) = g[f"crop_{i}_points"], g[f"crop_{i}_params"]
+        _, _, w2, c2 = oh.mst(p, int(k))
+        assert np.array_equal(np.sort(np.sqrt(w2)), g[f"crop_{i}_tree_weights"])
+        from scipy.spatial import cKDTree
+        d, _ = cKDTree(p.astype(np.float64)).query(p.astype(np.float64), k=int(k))
+        assert np.array_equal(np.sqrt(c2), d[:, -1])
+
+
+def _gpu_tree(p, k, mask=None):
+    t = _hip().hdbscan_mst(p, k, mask)
+    a, b = t["a"].cpu().numpy().astype(np.int64), t["b"].cpu().numpy().astype(np.int64)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    o = np.lexsort((hi, lo))
+    return lo[o], hi[o], t["w2"].cpu().numpy()[o], t["core2"].cpu().numpy(), t["n_live"]
+
+
+@gpu
+@pytest.mark.parametrize("case", ["crop_0", "crop_1", "crop_2", "synth", "lattice", "duplicates", "k1", "tiny"])
+def test_gpu_spanning_tree_equals_oracle_edge_for_edge(case):
+    g = load_golden("g11_hdbscan")
+    mask = None
+    if case.startswith("crop"):
+        p, k = g[f"{case}_points"], int(g[f"{case}_params"][0])
+    elif case == "synth":
+        p, k, mask = g["synth_points"], int(g["synth_params"][0]), g["synth_nonground"]
+    elif case == "lattice":           # every weight is tied many times over: the tie rule decides everything
+        p, k = _lattice(14), 7
+    elif case == "duplicates":
+        p, k = np.repeat(_cloud(41, 300), 4, axis=0), 6
+    elif case == "k1":
+        p, k = _cloud(42, 1200), 1
+    else:
+        p, k = _cloud(43, 9), 3
+    lo, hi, w2, c2, n_live = _gpu_tree(p, k, mask)
+    sub = p if mask is None else p[mask]
+    ra, rb, rw, rc = oh.mst(sub, k)
+    rows = np.arange(len(p)) if mask is None else np.flatnonzero(mask)
+    assert n_live == len(sub) and len(lo) == len(sub) - 1
+    assert np.array_equal(c2[rows], rc) and (mask is None or np.isnan(c2[~mask]).all())
+    assert np.array_equal(lo, rows[ra]) and np.array_equal(hi, rows[rb]) and np.array_equal(w2, rw)
+    if f"{case}_tree_weights" in g:
+        assert np.array_equal(np.sort(np.sqrt(w2)), g[f"{case}_tree_weights"])
+
+
+@gpu
+def test_gpu_spanning_tree_of_the_demo_frame_has_sklearn_prims_weights():
+    """126 598 points: the sorted weights of the GPU tree equal those of sklearn's exact Prim tree (G11; three
+    minutes on a CPU core), bit for bit; core distances against a KD-tree."""
+    g = load_golden("g11_hdbscan")
+    pts = _demo_points()
+    t = _hip().hdbscan_mst(pts, 20)
+    assert t["n_live"] == len(pts) and len(t["a"]) == len(pts) - 1
+    assert np.array_equal(np.sort(np.sqrt(t["w2"].cpu().numpy())), g["demo_tree_weights"])
+    from scipy.spatial import cKDTree
+    sample = np.random.default_rng(0).choice(len(pts), 4000, replace=False)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts[sample].astype(np.float64), k=20)
+    assert np.array_equal(np.sqrt(t["core2"].cpu().numpy()[sample]), d[:, -1])
+    # the edges form one tree
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    a, b = t["a"].cpu().numpy(), t["b"].cpu().numpy()
+    nc, _ = connected_components(coo_matrix((np.ones(len(a)), (a, b)), shape=(len(pts), len(pts))), directed=False)
+    assert nc == 1
+
+
+@gpu
+@pytest.mark.parametrize("case", ["crop_0", "crop_1", "crop_2", "synth"])
+def test_gpu_hdbscan_labels_against_reference_run(case):
+    """cluster_pcd with if_hdbscan against the reference's own cluster_pcd (sklearn standing in for the hdbscan
+    package): same partition up to points at tied merge heights (Prim's visiting order vs the total order)."""
+    g = load_golden("g11_hdbscan")
+    p, (k, ncl), want = g[f"{case}_points"], g[f"{case}_params"], g[f"{case}_labels"]
+    mask = g["synth_nonground"] if case == "synth" else np.ones(len(p), dtype=bool)
+    a = SimpleNamespace(min_cluster_size=int(k), num_clusters=int(ncl), if_hdbscan=True, epsilon=0.25)
+    got = _hip().cluster_pcd(a, p, mask)
+    assert got.dtype == np.float64 and np.array_equal(got == -1e8, want == -1e8)
+    bad = _partition_mismatch(got[mask], want[mask])
+    assert bad <= 0.01 * mask.sum(), (bad, int(mask.sum()))
+    # the host half on its own: the oracle's tree through the product's host logic gives the product's labels
+    ra, rb, rw, _ = oh.mst(p[mask], int(k))
+    lab = _hip().labels_from_mst(ra, rb, np.sqrt(rw), int(mask.sum()), int(k))
+    full = _hip().hdbscan(p, int(k), None, None if case != "synth" else mask)
+    assert np.array_equal(full[mask], lab)
+
+
+@gpu
+def test_gpu_hdbscan_demo_frame_against_reference_run():
+    from sklearn.metrics import adjusted_rand_score
+    L = load_golden("g8_demo_labels")
+    want = np.concatenate([L["label_dst"], L["label_src"]]).astype(np.int64)
+    pts = _demo_points()
+    a = SimpleNamespace(min_cluster_size=20, num_clusters=200, if_hdbscan=True, epsilon=0.25)
+    got = _hip().cluster_pcd(a, pts, np.ones(len(pts), dtype=bool)).astype(np.int64)
+    assert adjusted_rand_score(want, got) > 0.999
+    assert _partition_mismatch(got, want) < 0.005 * len(pts)
+    with pytest.raises(RuntimeError):
+        _hip().hdbscan_mst(pts, 65)                      # min_samples beyond the wave-wide selection
+    with pytest.raises(ValueError):
+        _hip().hdbscan(pts[:10], 20)

@@ -402,7 +402,61 @@ def g10_dbscan():
     save("g10_dbscan", **out)
 
 
-GENS = dict(g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
+def g11_hdbscan():
+    """SURVEY 8(f) row 4, HDBSCAN branch: the reference's cluster_pcd (utils_cluster.py:10-29, 50-63 with
+    if_hdbscan True) on crops of the demo frame pair and on a synthetic cloud with a ground mask, the
+    `hdbscan` package replaced by sklearn's HDBSCAN (tools/standins/hdbscan).  Besides the labels, the SORTED
+    WEIGHTS of sklearn's exact spanning tree (Prim, _single_linkage_tree_['value']) are recorded, for the
+    crops and for the whole stacked demo frame (~3 min): the multiset of tree weights is the same for every
+    minimum spanning tree, whatever the tie-breaking, so it pins an exact tree bit for bit."""
+    import utils_cluster  # noqa: E402  (reference)
+    from sklearn.cluster import HDBSCAN
+    data = np.load(os.path.join(REF, "demo.npz"))
+    src = data["pc1"][data["pc1_flows_valid_idx"]].astype(np.float32)
+    dst = data["pc2"][data["pc2_flows_valid_idx"]].astype(np.float32)
+    pts = np.concatenate([dst, src], axis=0)                                     # demo.py:210
+    out = {}
+
+    def tree_weights(p, k):
+        return np.asarray(HDBSCAN(min_cluster_size=k, leaf_size=100).fit(p[:, :3].astype(np.float64))
+                          ._single_linkage_tree_["value"], dtype=np.float64)
+
+    crops = [(0, 5, 1500, 20, 200), (20, -10, 3000, 20, 4), (-15, 20, 2500, 30, 200)]
+    for i, (cx, cy, n, k, ncl) in enumerate(crops):
+        sel = (np.abs(pts[:, 0] - cx) < 15) & (np.abs(pts[:, 1] - cy) < 12)
+        p = pts[sel][:n]
+        a = args_ns(min_cluster_size=k, num_clusters=ncl, if_hdbscan=True, epsilon=0.25)
+        lab = utils_cluster.cluster_pcd(a, p, np.ones(len(p)).astype(bool))
+        out[f"crop_{i}_points"] = p
+        out[f"crop_{i}_params"] = np.array([k, ncl], dtype=np.int64)
+        out[f"crop_{i}_labels"] = lab.astype(np.int32)
+        out[f"crop_{i}_tree_weights"] = tree_weights(p, k)
+        print(f"  crop {i}: n {len(p)} k {k}: {len(np.unique(lab[lab >= 0]))} clusters kept, {int((lab == -1).sum())} unclustered")
+    rng = np.random.default_rng(11)
+    centers = rng.uniform(-8, 8, size=(9, 3)) * np.array([1, 1, 0.2])
+    p = centers[rng.integers(0, 9, 4000)] + rng.normal(0, 0.3, size=(4000, 3)) * np.array([1, 1, 0.5])
+    p[:700] = rng.uniform(-10, 10, size=(700, 3)) * np.array([1, 1, 0.2])
+    p = p.astype(np.float32)
+    nonground = p[:, 2] > -0.4
+    a = args_ns(min_cluster_size=15, num_clusters=5, if_hdbscan=True, epsilon=0.25)
+    lab = utils_cluster.cluster_pcd(a, p, nonground)
+    out["synth_points"], out["synth_nonground"], out["synth_labels"] = p, nonground, lab
+    out["synth_params"] = np.array([15, 5], dtype=np.int64)
+    out["synth_tree_weights"] = tree_weights(p[nonground], 15)
+    print(f"  synthetic: {int(nonground.sum())} non-ground of {len(p)}: {len(np.unique(lab[lab >= 0]))} clusters kept")
+    import time
+    t = time.time()
+    m = HDBSCAN(min_cluster_size=20, leaf_size=100).fit(pts.astype(np.float64))
+    print(f"  demo frame: sklearn HDBSCAN of {len(pts)} points took {time.time() - t:.0f} s")
+    g8 = np.load(os.path.join(OUT, "g8_demo_labels.npz"))
+    lab8 = np.concatenate([g8["label_dst"], g8["label_src"]]).astype(np.int64)
+    print("  labels equal the G8 label fixture:", bool(np.array_equal(m.labels_, lab8)))
+    out["demo_tree_weights"] = np.asarray(m._single_linkage_tree_["value"], dtype=np.float64)
+    out["demo_cpu_seconds"] = np.array(time.time() - t)
+    save("g11_hdbscan", **out)
+
+
+GENS = dict(g11=g11_hdbscan, g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -410,7 +464,7 @@ if __name__ == "__main__":
     ns = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g9", "g10")]   # g8: ~3 min, on request
+    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g9", "g10", "g11")]   # g8: ~3 min, on request
     for k in want:
         print(f"== {k}")
         GENS[k]()
