@@ -52,6 +52,7 @@ SIGNATURES = {
     "icpflow_dbscan": (_i, [_p, _i, _p, _i, _d, _i, _p, _p, _p, _p, _sz, _p]),
     "icpflow_hdbscan_mst_workspace_bytes": (_sz, [_i]),
     "icpflow_hdbscan_mst": (_i, [_p, _i, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "icpflow_hdbscan_labels": (_i, [_p, _p, _p, _i, _i, _p]),
     "icpflow_selftest_vote_quotient": (_i, [_p, _i, _f, _f, _p, _p, _p]),
     "icpflow_set_icp_search": (_i, [_i]),
     "icpflow_profile_enable": (_i, [_i]),

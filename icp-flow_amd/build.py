@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libicpflow_hip.so")
-SOURCES = ["api.hip", "hist.hip", "nn.hip", "icp.hip", "pose.hip", "sort.hip", "cluster.hip", "hdbscan.hip"]
+SOURCES = ["api.hip", "hist.hip", "nn.hip", "icp.hip", "pose.hip", "sort.hip", "cluster.hip", "hdbscan.hip", "hdbscan_tree.cpp"]
 HEADERS = ["common.hpp", "scan.hpp", "kernels.hpp", "votekey.hpp", "cluster_util.hpp", os.path.join("..", "..", "include", "icpflow_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]

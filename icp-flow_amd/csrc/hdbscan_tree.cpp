@@ -1,0 +1,219 @@
+// hdbscan_tree.cpp -- the sequential remainder of HDBSCAN on the n - 1 edges of the spanning tree (HOST code).
+//
+// What hdbscan.HDBSCAN does after its spanning tree (the reference calls it at utils_cluster.py:12-17; third-party
+// `hdbscan` 0.8.29, environment.yml:57; scikit-learn's port of the same steps: sklearn/cluster/_hdbscan/hdbscan.py
+// _process_mst, _linkage.pyx make_single_linkage, _tree.pyx _condense_tree / _compute_stability / _get_clusters /
+// _do_labelling), restated from the published algorithm (Campello, Moulavi, Sander 2013; McInnes, Healy 2017)
+// with the defaults the reference uses: cluster_selection_method "eom", allow_single_cluster False,
+// cluster_selection_epsilon 0, no max_cluster_size:
+//   1. edges directed away from point 0 (Prim's emission order: endpoint already in the tree, new endpoint),
+//      sorted by (weight, first endpoint, second endpoint) -- a fixed order for ties;
+//   2. single-linkage dendrogram by union-find (merge i creates node n + i);
+//   3. condensed tree, breadth first from the root: a split counts when both sides hold >= min_cluster_size
+//      points, otherwise the small side's points fall out of the parent at lambda = 1 / distance;
+//   4. stability = sum over the rows of a cluster of (lambda - lambda_birth) * size, accumulated in row order;
+//   5. excess of mass, children before parents: a cluster survives unless its children's stabilities sum higher;
+//   6. a point takes the label of its nearest selected ancestor (labels = rank of the selected cluster ids),
+//      -1 if there is none.
+// All of it is O(n log n) pointer chasing on ~10^5 edges: a few milliseconds on one host core, not device work.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+#include "../../include/icpflow_hip.h"
+
+namespace {
+
+struct Row {   // condensed tree
+    int parent, child;
+    double lambda;
+    int size;
+};
+
+}  // namespace
+
+extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_edge_b, const double *h_edge_w,
+                                      int n_points, int min_cluster_size, int32_t *h_labels)
+{
+    const int n = n_points;
+    if (!h_labels || n <= 0 || min_cluster_size < 2) return ICPFLOW_E_ARG;
+    if (n == 1) {
+        h_labels[0] = -1;
+        return 0;
+    }
+    if (!h_edge_a || !h_edge_b || !h_edge_w) return ICPFLOW_E_ARG;
+    const int m = n - 1;
+    for (int e = 0; e < m; ++e)
+        if (h_edge_a[e] < 0 || h_edge_a[e] >= n || h_edge_b[e] < 0 || h_edge_b[e] >= n || h_edge_a[e] == h_edge_b[e])
+            return ICPFLOW_E_ARG;
+
+    // 1. orientation away from point 0
+    std::vector<int> start(n + 1, 0), adj(2 * (size_t)m);
+    for (int e = 0; e < m; ++e) {
+        ++start[h_edge_a[e] + 1];
+        ++start[h_edge_b[e] + 1];
+    }
+    for (int i = 0; i < n; ++i) start[i + 1] += start[i];
+    {
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int e = 0; e < m; ++e) {
+            adj[fill[h_edge_a[e]]++] = h_edge_b[e];
+            adj[fill[h_edge_b[e]]++] = h_edge_a[e];
+        }
+    }
+    std::vector<int> pred(n, -1), queue;
+    queue.reserve(n);
+    queue.push_back(0);
+    pred[0] = 0;
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const int u = queue[head];
+        for (int k = start[u]; k < start[u + 1]; ++k)
+            if (pred[adj[k]] < 0) {
+                pred[adj[k]] = u;
+                queue.push_back(adj[k]);
+            }
+    }
+    if ((int)queue.size() != n) return ICPFLOW_E_ARG;   // the edges do not span the points
+    std::vector<int> cur(m), nxt(m), order(m);
+    for (int e = 0; e < m; ++e) {
+        const bool aIsChild = pred[h_edge_a[e]] == h_edge_b[e];
+        cur[e] = aIsChild ? h_edge_b[e] : h_edge_a[e];
+        nxt[e] = aIsChild ? h_edge_a[e] : h_edge_b[e];
+    }
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int x, int y) {
+        if (h_edge_w[x] != h_edge_w[y]) return h_edge_w[x] < h_edge_w[y];
+        if (cur[x] != cur[y]) return cur[x] < cur[y];
+        return nxt[x] < nxt[y];
+    });
+
+    // 2. single linkage: node n + i = i-th merge
+    const int nodes = 2 * n - 1, root = 2 * n - 2;
+    std::vector<int> up(nodes), left(m), right(m), count(nodes, 1);
+    std::vector<double> dist(m);
+    std::iota(up.begin(), up.end(), 0);
+    auto find = [&](int x) {
+        int r = x;
+        while (up[r] != r) r = up[r];
+        while (up[x] != r) {
+            const int t = up[x];
+            up[x] = r;
+            x = t;
+        }
+        return r;
+    };
+    for (int i = 0; i < m; ++i) {
+        const int e = order[i];
+        const int l = find(cur[e]), r = find(nxt[e]);
+        left[i] = l;
+        right[i] = r;
+        dist[i] = h_edge_w[e];
+        count[n + i] = count[l] + count[r];
+        up[l] = up[r] = n + i;
+    }
+
+    // 3. condensed tree
+    std::vector<Row> rows;
+    rows.reserve((size_t)n + 64);
+    std::vector<int> relabel(nodes, -1), bfs, sub;
+    std::vector<uint8_t> ignore(nodes, 0);
+    bfs.reserve(nodes);
+    bfs.push_back(root);
+    for (size_t head = 0; head < bfs.size(); ++head) {
+        const int v = bfs[head];
+        if (v >= n) {
+            bfs.push_back(left[v - n]);
+            bfs.push_back(right[v - n]);
+        }
+    }
+    relabel[root] = n;
+    int nextLabel = n + 1;
+    auto fall_out = [&](int top, int parentLabel, double lambda) {   // every point below `top` leaves the parent
+        sub.clear();
+        sub.push_back(top);
+        for (size_t head = 0; head < sub.size(); ++head) {
+            const int v = sub[head];
+            ignore[v] = 1;
+            if (v >= n) {
+                sub.push_back(left[v - n]);
+                sub.push_back(right[v - n]);
+            } else {
+                rows.push_back(Row{parentLabel, v, lambda, 1});
+            }
+        }
+    };
+    for (const int v : bfs) {
+        if (v < n || ignore[v]) continue;
+        const int l = left[v - n], r = right[v - n];
+        const double d = dist[v - n];
+        const double lambda = d > 0.0 ? 1.0 / d : std::numeric_limits<double>::infinity();
+        const int lc = count[l], rc = count[r];
+        if (lc >= min_cluster_size && rc >= min_cluster_size) {
+            relabel[l] = nextLabel++;
+            rows.push_back(Row{relabel[v], relabel[l], lambda, lc});
+            relabel[r] = nextLabel++;
+            rows.push_back(Row{relabel[v], relabel[r], lambda, rc});
+        } else if (lc < min_cluster_size && rc < min_cluster_size) {
+            fall_out(l, relabel[v], lambda);
+            fall_out(r, relabel[v], lambda);
+        } else if (lc < min_cluster_size) {
+            relabel[r] = relabel[v];
+            fall_out(l, relabel[v], lambda);
+        } else {
+            relabel[l] = relabel[v];
+            fall_out(r, relabel[v], lambda);
+        }
+    }
+
+    // 4. stability per cluster id (ids n .. nextLabel - 1; n is the root)
+    const int clusters = nextLabel - n;
+    std::vector<double> birth(nextLabel, std::numeric_limits<double>::quiet_NaN()), stability(clusters, 0.0);
+    for (const Row &w : rows) birth[w.child] = w.lambda;
+    birth[n] = 0.0;
+    for (const Row &w : rows) stability[w.parent - n] += (w.lambda - birth[w.parent]) * (double)w.size;
+
+    // 5. excess of mass.  Cluster children of a cluster come in pairs and carry larger ids than their parent.
+    std::vector<int> childA(clusters, -1), childB(clusters, -1);
+    for (const Row &w : rows)
+        if (w.size > 1) (childA[w.parent - n] < 0 ? childA[w.parent - n] : childB[w.parent - n]) = w.child - n;
+    std::vector<uint8_t> selected(clusters, 1);
+    selected[0] = 0;   // the root is no candidate (allow_single_cluster False)
+    for (int c = clusters - 1; c >= 1; --c) {
+        double below = 0.0;
+        if (childA[c] >= 0) below = stability[childA[c]] + (childB[c] >= 0 ? stability[childB[c]] : 0.0);
+        if (below > stability[c]) {
+            selected[c] = 0;
+            stability[c] = below;
+        } else {   // the cluster stands: nothing beneath it does
+            sub.clear();
+            if (childA[c] >= 0) sub.push_back(childA[c]);
+            if (childB[c] >= 0) sub.push_back(childB[c]);
+            for (size_t head = 0; head < sub.size(); ++head) {
+                const int x = sub[head];
+                selected[x] = 0;
+                if (childA[x] >= 0) sub.push_back(childA[x]);
+                if (childB[x] >= 0) sub.push_back(childB[x]);
+            }
+        }
+    }
+
+    // 6. labels: rank of the selected ids; a point follows its nearest selected ancestor
+    std::vector<int> label(clusters, -1), owner(clusters, -1);
+    int next = 0;
+    for (int c = 1; c < clusters; ++c)
+        if (selected[c]) label[c] = next++;
+    for (const Row &w : rows) {   // rows are top-down: a cluster's parent row precedes its own rows
+        const int p = w.parent - n;
+        if (w.size > 1) {
+            const int c = w.child - n;
+            owner[c] = selected[c] ? c : owner[p];
+        } else {
+            const int o = (p == 0) ? -1 : (selected[p] ? p : owner[p]);
+            h_labels[w.child] = o < 0 ? -1 : label[o];
+        }
+    }
+    return 0;
+}

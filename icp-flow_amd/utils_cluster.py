@@ -13,9 +13,8 @@ expression applied to the C cluster sizes (a few hundred numbers).
 `cluster_hdbscan(args, points)` (utils_cluster.py:10-29): the O(n^2) part -- core distances and the exact
 minimum spanning tree of the mutual-reachability graph -- runs in libicpflow_hip.so (`icpflow_hdbscan_mst`,
 csrc/hdbscan.hip); the sequential remainder on the n - 1 tree edges (sort, dendrogram, condensed tree,
-excess-of-mass selection) is delegated on the host to scikit-learn's compiled HDBSCAN routines, the same
-family of code the reference delegates to (`hdbscan` 0.8.29, whose approximate spanning tree is not
-reproducible).
+excess-of-mass selection) is host C++ in the same library (`icpflow_hdbscan_labels`, csrc/hdbscan_tree.cpp),
+checked against scikit-learn's compiled routines for those steps.
 """
 import numpy as np
 import torch
@@ -146,31 +145,20 @@ def hdbscan_mst(points, min_samples, mask=None, cell=0.25):
 
 
 def labels_from_mst(a, b, w, n, min_cluster_size):
-    """The sequential remainder of HDBSCAN on the n - 1 tree edges (host, numpy + scikit-learn's compiled
-    routines): edges directed away from point 0 (the order Prim's algorithm, which sklearn runs from point
-    0, emits them in: source already in the tree, then the new point), sorted by weight, single-linkage
-    dendrogram, condensed tree with min_cluster_size, excess-of-mass selection.  -> int labels [n], -1 noise."""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import breadth_first_order
-    from sklearn.cluster._hdbscan._linkage import MST_edge_dtype, make_single_linkage
-    from sklearn.cluster._hdbscan._tree import tree_to_labels
-    a, b = np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)
-    if len(a) != n - 1:
+    """The sequential remainder of HDBSCAN on the n - 1 tree edges (host C++ in libicpflow_hip.so,
+    csrc/hdbscan_tree.cpp): edges directed away from point 0 and sorted by weight, single-linkage dendrogram,
+    condensed tree with min_cluster_size, excess-of-mass selection.  -> int64 labels [n], -1 noise."""
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    if len(a) != n - 1 or len(b) != n - 1 or len(w) != n - 1:
         raise ValueError(f"labels_from_mst: {len(a)} edges cannot span {n} points")
-    adj = coo_matrix((np.ones(2 * len(a), dtype=np.int8), (np.concatenate([a, b]), np.concatenate([b, a]))),
-                     shape=(n, n)).tocsr()
-    _, pred = breadth_first_order(adj, 0, directed=False)
-    child_is_a = pred[a] == b
-    mst = np.empty(len(a), dtype=MST_edge_dtype)
-    mst["current_node"] = np.where(child_is_a, b, a)
-    mst["next_node"] = np.where(child_is_a, a, b)
-    mst["distance"] = np.asarray(w, dtype=np.float64)
-    # hdbscan.py:_process_mst sorts by weight alone (numpy's unstable argsort: ties land in an order that
-    # depends on the input order); the tree arrives from the GPU in no particular order, so ties are put in a
-    # fixed order here and the labels are reproducible
-    mst = mst[np.lexsort((mst["next_node"], mst["current_node"], mst["distance"]))]
-    labels, _ = tree_to_labels(make_single_linkage(mst), int(min_cluster_size), "eom", False, 0.0, None)
-    return np.asarray(labels)
+    out = np.empty(n, dtype=np.int32)
+    rc = _lib._L.icpflow_hdbscan_labels(a.ctypes.data, b.ctypes.data, w.ctypes.data, int(n), int(min_cluster_size),
+                                        out.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"labels_from_mst: invalid tree or min_cluster_size (code {rc})")
+    return out.astype(np.int64)
 
 
 def hdbscan(points, min_cluster_size, min_samples=None, mask=None, cell=0.25):

@@ -279,6 +279,15 @@ int icpflow_hdbscan_mst(const float *d_points, int stride, const uint8_t *d_mask
                         int32_t *d_num_edges, int32_t *d_num_live, void *d_ws, size_t ws_bytes,
                         icpflow_stream_t stream);
 
+/* HOST function (host pointers, no device work, callable without a GPU): HDBSCAN's sequential remainder on
+ * the n_points - 1 spanning-tree edges -- what hdbscan.HDBSCAN / sklearn's HDBSCAN do after their spanning tree
+ * (sklearn/cluster/_hdbscan/_linkage.pyx make_single_linkage, _tree.pyx tree_to_labels with "eom", no single
+ * cluster, epsilon 0): edges (rows of the clustered subset, 0-based; weight = mutual-reachability DISTANCE,
+ * i.e. the square root of icpflow_hdbscan_mst's output) -> h_labels int32 [n_points], -1 = noise.
+ * Returns ICPFLOW_E_ARG when the edges do not span the points or min_cluster_size < 2. */
+int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_edge_b, const double *h_edge_w,
+                           int n_points, int min_cluster_size, int32_t *h_labels);
+
 /* ---------------------------------------------------------------------------
  * Diagnostics: the vote kernels evaluate (v - min) / (max - min) with the loop-invariant part of
  * the IEEE division hoisted (hist.hip, AxisQuot).  For numerators d_a [n] this returns that

@@ -339,3 +339,51 @@ def test_gpu_hdbscan_demo_frame_against_reference_run():
         _hip().hdbscan_mst(pts, 65)                      # min_samples beyond the wave-wide selection
     with pytest.raises(ValueError):
         _hip().hdbscan(pts[:10], 20)
+
+
+def test_host_tree_labels_equal_sklearns_routines_on_the_same_tree():
+    """icpflow_hdbscan_labels (host C++, runs without a GPU) against sklearn's make_single_linkage +
+    tree_to_labels fed the same edges in the same order, on the oracle's trees of fixture crops and on random
+    trees with heavy ties."""
+    import ctypes
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import breadth_first_order, minimum_spanning_tree
+    from sklearn.cluster._hdbscan._linkage import MST_edge_dtype, make_single_linkage
+    from sklearn.cluster._hdbscan._tree import tree_to_labels
+    from icp_flow_amd import _lib
+
+    def ours(a, b, w, n, mcs):
+        a, b = np.ascontiguousarray(a, np.int32), np.ascontiguousarray(b, np.int32)
+        w = np.ascontiguousarray(w, np.float64)
+        out = np.empty(n, np.int32)
+        rc = _lib._L.icpflow_hdbscan_labels(a.ctypes.data, b.ctypes.data, w.ctypes.data, n, mcs, out.ctypes.data)
+        assert rc == 0
+        return out
+
+    def theirs(a, b, w, n, mcs):
+        adj = coo_matrix((np.ones(2 * len(a)), (np.r_[a, b], np.r_[b, a])), shape=(n, n)).tocsr()
+        _, pred = breadth_first_order(adj, 0, directed=False)
+        child_is_a = pred[a] == b
+        mst = np.empty(len(a), dtype=MST_edge_dtype)
+        mst["current_node"], mst["next_node"], mst["distance"] = np.where(child_is_a, b, a), np.where(child_is_a, a, b), w
+        mst = mst[np.lexsort((mst["next_node"], mst["current_node"], mst["distance"]))]
+        return np.asarray(tree_to_labels(make_single_linkage(mst), mcs, "eom", False, 0.0, None)[0])
+
+    g = load_golden("g11_hdbscan")
+    cases = []
+    for i in (0, 1, 2):
+        p, k = g[f"crop_{i}_points"][:1200], int(g[f"crop_{i}_params"][0])
+        a, b, w2, _ = oh.mst(p, k)
+        cases.append((a, b, np.sqrt(w2), len(p), k))
+    rng = np.random.default_rng(3)
+    for n, mcs, levels in [(2, 2, 3), (5, 2, 2), (60, 3, 4), (400, 5, 6), (1500, 10, 50), (1500, 4, 1000000)]:
+        dense = np.triu(rng.integers(1, levels + 1, size=(n, n)).astype(np.float64), 1)   # few distinct weights
+        t = minimum_spanning_tree(dense).tocoo()
+        perm = rng.permutation(len(t.data))
+        cases.append((t.row[perm], t.col[perm], t.data[perm] / levels, n, mcs))
+    for a, b, w, n, mcs in cases:
+        assert np.array_equal(ours(a, b, w, n, mcs), theirs(a, b, w, n, mcs)), (n, mcs)
+    # not a spanning tree / bad arguments
+    bad = np.empty(4, np.int32)
+    e = np.array([0, 0, 1], np.int32), np.array([1, 1, 0], np.int32), np.ones(3)
+    assert _lib._L.icpflow_hdbscan_labels(e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, 4, 2, bad.ctypes.data) != 0
