@@ -248,7 +248,48 @@ def frame_pair_measurement(dev):
             entry["max_flow_difference_to_reference_m"] = float(np.abs(flow.cpu().numpy() - g["flow"]).max())
         res[f"max_points_{mp}"] = entry
     res["cluster_dbscan"] = cluster_measurement(dev, g, gdir)
+    res["cluster_hdbscan"] = hdbscan_measurement(dev, g, gdir)
     return res
+
+
+def hdbscan_measurement(dev, g, gdir):
+    """SURVEY 8(f) row 4, the branch the reference's scripts select (--if_hdbscan): cluster_pcd of the stacked demo
+    frame pair; spanning tree on the GPU checked against the weights of sklearn's exact Prim tree (G11), labels
+    against the reference run's (G8 label fixture: sklearn's HDBSCAN through the reference's cluster_pcd, whose
+    wall time in the build container is recorded in G11 as the CPU figure)."""
+    from types import SimpleNamespace
+    from icp_flow_amd import utils_cluster
+    try:
+        g11, lab8 = np.load(os.path.join(gdir, "g11_hdbscan.npz")), np.load(os.path.join(gdir, "g8_demo_labels.npz"))
+    except OSError:
+        return None
+    pts = torch.from_numpy(np.concatenate([g["point_dst"], g["point_src"]], axis=0)).to(dev)
+    a = SimpleNamespace(min_cluster_size=20, num_clusters=200, if_hdbscan=True, epsilon=0.25)
+    nonground = torch.ones(len(pts), dtype=torch.bool, device=dev)
+
+    def timeit(fn, reps=5):
+        fn()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / reps * 1e3, out
+
+    ms_tree, tree = timeit(lambda: utils_cluster.hdbscan_mst(pts, 20))
+    ms_all, lab = timeit(lambda: utils_cluster.cluster_pcd(a, pts, nonground))
+    want = np.concatenate([lab8["label_dst"], lab8["label_src"]]).astype(np.int64)
+    got = lab.cpu().numpy().astype(np.int64)
+    noise_both = int(((got < 0) & (want < 0)).sum())
+    moved = int(((got < 0) != (want < 0)).sum())
+    return {"points": int(len(pts)), "min_cluster_size": 20, "clusters": int(got.max() + 1),
+            "ms_per_frame_pair": round(ms_all, 2), "ms_spanning_tree_gpu": round(ms_tree, 2),
+            "tree_weights_equal_sklearn_prim_g11": bool(np.array_equal(np.sort(np.sqrt(tree["w2"].cpu().numpy())),
+                                                                       g11["demo_tree_weights"])),
+            "reference_run_clusters": int(want.max() + 1), "noise_points_both": noise_both,
+            "points_noise_in_one_only": moved,
+            "cpu_reference_run_s": round(float(g11["demo_cpu_seconds"]), 1),
+            "cpu_reference_run": "sklearn HDBSCAN (exact Prim) through the reference's cluster_hdbscan, build container, 1 core"}
 
 
 def cluster_measurement(dev, g, gdir):

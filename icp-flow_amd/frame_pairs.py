@@ -10,10 +10,11 @@ points.  On disk: one .npz per pair with keys
 
 or the reference's Argoverse/demo keys (dataset_argo.py:34-45: pc1, pc2, pc1_flows_valid_idx,
 pc2_flows_valid_idx, gt_flow_0_1) plus labels_src / labels_dst (clustering is precomputed in the BASELINE
-configs).  A pair WITHOUT labels is clustered on the GPU when the arguments say how (`cluster="dbscan"`
-with epsilon / min_cluster_size / num_clusters: both clouds stacked dst-first and clustered jointly as
-demo.py:210 / dataset_argo.py:119 do, utils_cluster.cluster_pcd's DBSCAN branch, SURVEY 8(f) rank 4;
-optional keys nonground_src / nonground_dst mark the rows to cluster).
+configs).  A pair WITHOUT labels is clustered on the GPU when the arguments say how (`cluster="hdbscan"`
+-- what the reference's scripts select, --if_hdbscan -- or `cluster="dbscan"`, with min_cluster_size /
+num_clusters (/ epsilon): both clouds stacked dst-first and clustered jointly as demo.py:210 /
+dataset_argo.py:119 do, utils_cluster.cluster_pcd; optional keys nonground_src /
+nonground_dst mark the rows to cluster).
 
 `run_stream` registers every pair of a directory (round-robin over ranks: frame pairs are
 independent, main.py:184), and reports ms / frame pair and the reference's accuracy metrics.
@@ -129,16 +130,16 @@ def frame_translation(args, pose, gap=1):
 def cluster_frame_pair(args, ps, pd, nonground_src=None, nonground_dst=None):
     """Joint clustering of a frame pair as demo.py:210 / dataset_argo.py:112-121 do it: both clouds stacked
     dst-first, one cluster_pcd call, labels split back.  -> (labels_src, labels_dst) float32 device tensors."""
-    if getattr(args, "cluster", None) != "dbscan":
+    if getattr(args, "cluster", None) not in ("dbscan", "hdbscan"):
         raise ValueError("frame pair without cluster labels: pass precomputed labels_src / labels_dst or set "
-                         "args.cluster = 'dbscan' (the HDBSCAN branch is not built)")
+                         "args.cluster = 'hdbscan' | 'dbscan'")
     from . import utils_cluster
     dev = ps.device
     ones = lambda n: torch.ones(n, dtype=torch.bool, device=dev)
     m_src = ones(len(ps)) if nonground_src is None else torch.as_tensor(nonground_src, device=dev).bool()
     m_dst = ones(len(pd)) if nonground_dst is None else torch.as_tensor(nonground_dst, device=dev).bool()
     a = SimpleNamespace(epsilon=float(args.epsilon), min_cluster_size=int(args.min_cluster_size),
-                        num_clusters=int(args.num_clusters), if_hdbscan=False)
+                        num_clusters=int(args.num_clusters), if_hdbscan=args.cluster == "hdbscan")
     labels = utils_cluster.cluster_pcd(a, torch.cat([pd, ps], dim=0), torch.cat([m_dst, m_src], dim=0)).float()
     return labels[len(pd):].contiguous(), labels[: len(pd)].contiguous()
 

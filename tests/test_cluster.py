@@ -387,3 +387,20 @@ def test_host_tree_labels_equal_sklearns_routines_on_the_same_tree():
     bad = np.empty(4, np.int32)
     e = np.array([0, 0, 1], np.int32), np.array([1, 1, 0], np.int32), np.ones(3)
     assert _lib._L.icpflow_hdbscan_labels(e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, 4, 2, bad.ctypes.data) != 0
+
+
+@gpu
+def test_gpu_unlabelled_frame_pair_hdbscan_then_registered():
+    """The reference's demo pipeline end to end on the GPU: joint HDBSCAN of the stacked frame pair (demo.py:210,
+    --if_hdbscan) + track + flow.  Against the reference's own run (G8: labels by sklearn's HDBSCAN, 81 matched
+    pairs, EPE 0.0585): the clustering agrees up to tie points, so the matched pairs and the error agree closely."""
+    from icp_flow_amd import frame_pairs
+    g = load_golden("g8_demo")
+    fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], None, None, None, g["gt_flow"])
+    a = frame_pairs.default_args(max_points=2048, cluster="hdbscan", min_cluster_size=20, num_clusters=200)
+    got = frame_pairs.register_frame_pair(a, fp, torch.device("cuda", 0))
+    flow = got["flow"].cpu().numpy()
+    epe = float(np.linalg.norm(flow - g["gt_flow"], axis=1).mean())
+    assert abs(len(got["pairs"]) - len(g["pairs"])) <= 3 and abs(epe - float(g["epe"])) < 5e-3, (len(got["pairs"]), epe)
+    same = np.abs(flow - g["flow"]).max(axis=1) < 1e-4
+    assert same.mean() > 0.97, same.mean()
