@@ -59,6 +59,8 @@ struct Hdb {
     unsigned long long *compW;    // per root: bits of the lightest weight / its (row, row) key
     unsigned long long *compKey;
     int *numComp;           // [rounds + 1]
+    int *compSize;          // per root: rows of the component
+    unsigned long long *giant;   // [rounds + 1]: (size << 32 | root) of the largest component
     int32_t *edgeA, *edgeB;
     double *edgeW2;
     int *numEdges;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void hdb_gather_kernel(const float *__restr
                                                             float4 *__restrict__ sorted, int *__restrict__ nLive,
                                                             int *__restrict__ parent, int *__restrict__ comp,
                                                             int *__restrict__ numComp, int *__restrict__ numEdges,
-                                                            int rounds)
+                                                            unsigned long long *__restrict__ giant, int rounds)
 {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= n) return;
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(kBlock) void hdb_gather_kernel(const float *__restr
         }
         *numEdges = 0;
         for (int r = 1; r <= rounds; ++r) numComp[r] = 0;
+        for (int r = 0; r <= rounds; ++r) giant[r] = 0ull;
     }
 }
 
@@ -212,20 +215,21 @@ __device__ inline double sq_dist(double px, double py, double pz, const float4 t
 // Walk the chunks outward from chunk `own` of a point at (px, py, pz).  `bound()` is the wave-uniform
 // squared radius that can still matter; `skip(t)` (per lane) drops chunk t unread; `visit(t)` processes
 // it.  A chunk is visited when its box is within the bound, nearest box first inside a group of 64 chunks.
-template <class Bound, class Skip, class Visit>
+template <class Bound, class Skip, class Visit, class Tick>
 __device__ inline void walk_chunks(const Chunks &ch, int numChunks, int own, double px, double py, double pz,
-                                   Bound bound, Skip skip, Visit visit)
+                                   Bound bound, Skip skip, Visit visit, Tick tick, int maxSteps)
 {
     const int lane = threadIdx.x & 63;
     const int groups = (numChunks + 63) >> 6, g0 = own >> 6;
     visit(own);
     bool rightDone = false, leftDone = false;
-    for (int step = 0; step < 2 * groups; ++step) {
+    for (int step = 0; step < min(maxSteps, 2 * groups); ++step) {
         const int off = (step + 1) >> 1;
         const int g = (step & 1) ? g0 - off : g0 + off;   // g0, g0 - 1, g0 + 1, g0 - 2, ...
         if (g < 0 || g >= groups) continue;
         if (g > g0 && rightDone) continue;
         if (g < g0 && leftDone) continue;
+        tick();
         const int t = g * 64 + lane;
         const bool valid = t < numChunks && t != own;
         double lb2 = kInfD;
@@ -306,14 +310,18 @@ __global__ __launch_bounds__(kBlock) void hdb_core_kernel(Hdb h, int numChunks, 
             if (__ballot(d2 < kth) == 0) return;
             best = wave_merge_smallest(best, d2);
             kth = shfl_f64(best, k - 1);
-        });
+        },
+        []() {}, 2 * ((numChunks + 63) >> 6));
     if (lane == 0) h.core2[j] = kth;
 }
 
-__global__ __launch_bounds__(kBlock) void hdb_scan_kernel(Hdb h, int numChunks, int round)
+// probe = true: own group of 64 chunks only, in rounds that start with few components (an upper bound per
+// component for the full pass); probe = false: the full walk
+__global__ __launch_bounds__(kBlock) void hdb_scan_kernel(Hdb h, int numChunks, int round, bool probe)
 {
     if (h.numComp[round] <= 1) return;
     const int nLive = *h.nLive;
+    if (probe && h.numComp[round] > (nLive >> 4)) return;   // many small components: the full pass is already local
     const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (threadIdx.x >> 6));
     if (j >= nLive) return;
     const int lane = threadIdx.x & 63;
@@ -321,11 +329,30 @@ __global__ __launch_bounds__(kBlock) void hdb_scan_kernel(Hdb h, int numChunks, 
     const double px = p.x, py = p.y, pz = p.z;
     const int me = __float_as_int(p.w);
     const int myComp = h.comp[j];
+    // The largest component sits this round out: every other component still finds its lightest outgoing edge
+    // (a tree edge by the cut property) and merges, so the rounds still halve the count -- and the rows with
+    // the widest searches, deep inside the big component, never search at all.
+    const unsigned long long big = h.giant[round];
+    if ((big >> 32) > 1 && (int)(big & 0xffffffffu) == myComp) {
+        if (lane == 0) {
+            h.bestW2[j] = kInfD;
+            h.bestKey[j] = kNoKey;
+            h.bestQ[j] = -1;
+        }
+        return;
+    }
     const double myCore2 = h.core2[j];
     double bw = kInfD;                 // lane-local lightest edge
     unsigned long long bk = kNoKey;
     int bq = -1;
-    double bnd = kInfD;                // wave-uniform min of bw
+    // wave-uniform: nothing heavier can be the component's lightest edge.  After the probe pass the component's
+    // record already holds the weight of a real outgoing edge found near the component's rim: rows deep inside
+    // start with that bound and find every remaining chunk beyond it.
+    double bnd = kInfD;
+    if (!probe) {
+        const unsigned long long cb = h.compW[myComp];
+        if (cb != ~0ull) bnd = __longlong_as_double((long long)cb);
+    }
     walk_chunks(
         h.ch, numChunks, j >> 6, px, py, pz, [&]() { return bnd; },
         [&](int t) { return h.chunkComp[t] == myComp; },
@@ -345,7 +372,8 @@ __global__ __launch_bounds__(kBlock) void hdb_scan_kernel(Hdb h, int numChunks, 
                 }
             }
             bnd = fmin(bnd, wave_min_f64(w2));
-        });
+        },
+        []() {}, probe ? 1 : 2 * ((numChunks + 63) >> 6));
     // lightest edge of the wave: (weight, key) lexicographic
     const double wmin = wave_min_f64(bw);
     unsigned long long kk = (bw == wmin) ? bk : kNoKey;
@@ -369,9 +397,31 @@ __global__ __launch_bounds__(kBlock) void hdb_reduce_weight_kernel(Hdb h, int ro
 {
     if (h.numComp[round] <= 1) return;
     const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= *h.nLive) return;
-    const double w = h.bestW2[j];
-    if (w < kInfD) atomicMin(h.compW + h.comp[j], (unsigned long long)__double_as_longlong(w));
+    const int lane = threadIdx.x & 63;
+    unsigned long long bits = ~0ull;
+    int c = -1;
+    if (j < *h.nLive) {
+        const double w = h.bestW2[j];
+        if (w < kInfD) {
+            bits = (unsigned long long)__double_as_longlong(w);
+            c = h.comp[j];
+        }
+    }
+    // one atomic per (wave, component): neighbouring rows mostly share their component
+    bool pending = c >= 0;
+    unsigned long long todo;
+    while ((todo = __ballot(pending)) != 0) {
+        const int lead = __builtin_ctzll(todo);
+        const int cv = __shfl(c, lead);
+        const bool same = pending && c == cv;
+        unsigned long long m = same ? bits : ~0ull;
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned long long o = shfl_xor_u64(m, d);
+            m = o < m ? o : m;
+        }
+        if (lane == lead) atomicMin(h.compW + cv, m);
+        if (same) pending = false;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void hdb_reduce_key_kernel(Hdb h, int round)
@@ -389,6 +439,7 @@ __global__ __launch_bounds__(kBlock) void hdb_select_kernel(Hdb h, int round)
     if (h.numComp[round] <= 1) return;
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= *h.nLive) return;
+    h.compSize[j] = 0;   // recounted by the flatten step
     const double w = h.bestW2[j];
     if (!(w < kInfD)) return;
     const unsigned long long bits = (unsigned long long)__double_as_longlong(w), key = h.bestKey[j];
@@ -429,6 +480,23 @@ __global__ __launch_bounds__(kBlock) void hdb_flatten_kernel(Hdb h, int round)
     }
     const unsigned long long roots = __ballot(j < nLive && root == j);
     if (lane == 0 && roots) atomicAdd(h.numComp + round + 1, (int)__popcll(roots));
+    bool pending = j < nLive;
+    unsigned long long todo;
+    while ((todo = __ballot(pending)) != 0) {
+        const int lead = __builtin_ctzll(todo);
+        const int rv = __shfl(root, lead);
+        const unsigned long long same = __ballot(pending && root == rv);
+        if (lane == lead) atomicAdd(h.compSize + rv, (int)__popcll(same));
+        if (root == rv) pending = false;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void hdb_giant_kernel(Hdb h, int round)
+{
+    if (h.numComp[round] <= 1) return;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= *h.nLive || h.comp[j] != j) return;
+    atomicMax(h.giant + round + 1, ((unsigned long long)(unsigned)h.compSize[j] << 32) | (unsigned)j);
 }
 
 __global__ __launch_bounds__(kBlock) void hdb_round_init_kernel(Hdb h, int n)
@@ -455,7 +523,8 @@ struct Carve {
     float4 *sorted;
     float *bmin, *bmax;
     double *sufMinX, *preMaxX;
-    int *nLive, *numComp, *comp, *parent, *chunkComp, *bestQ;
+    int *nLive, *numComp, *comp, *parent, *chunkComp, *bestQ, *compSize;
+    unsigned long long *giant;
     double *bestW2;
     unsigned long long *bestKey, *compW, *compKey;
     void *sortTmp;
@@ -501,6 +570,8 @@ hipError_t carve(int n, void *ws, Carve *c, hipStream_t s)
     c->nLive = (int *)take(4);
     c->numComp = (int *)take((size_t)(c->rounds + 2) * 4);
     c->comp = (int *)take(N * 4);
+    c->compSize = (int *)take(N * 4);
+    c->giant = (unsigned long long *)take((size_t)(c->rounds + 2) * 8);
     c->parent = (int *)take(N * 4);
     c->chunkComp = (int *)take(C * 4);
     c->bestQ = (int *)take(N * 4);
@@ -540,7 +611,7 @@ hipError_t launch_hdbscan_mst(const float *pts, int stride, const uint8_t *mask,
                                   s);
     if (e != hipSuccess) return e;
     hdb_gather_kernel<<<blocks, kBlock, 0, s>>>(pts, stride, c.keyOut, c.valOut, n, c.sorted, numLive, c.parent,
-                                                c.comp, c.numComp, numEdges, c.rounds);
+                                                c.comp, c.numComp, numEdges, c.giant, c.rounds);
     Hdb h;
     h.sorted = c.sorted;
     h.nLive = numLive;
@@ -555,6 +626,8 @@ hipError_t launch_hdbscan_mst(const float *pts, int stride, const uint8_t *mask,
     h.compW = c.compW;
     h.compKey = c.compKey;
     h.numComp = c.numComp;
+    h.compSize = c.compSize;
+    h.giant = c.giant;
     h.edgeA = edgeA;
     h.edgeB = edgeB;
     h.edgeW2 = edgeW2;
@@ -566,11 +639,16 @@ hipError_t launch_hdbscan_mst(const float *pts, int stride, const uint8_t *mask,
     if (core2) hdb_core_out_kernel<<<blocks, kBlock, 0, s>>>(h, n, core2);
     hdb_round_init_kernel<<<blocks, kBlock, 0, s>>>(h, n);
     for (int r = 0; r < c.rounds; ++r) {
-        hdb_scan_kernel<<<waveBlocks, kBlock, 0, s>>>(h, c.numChunks, r);
+        if (r >= 2) {   // two rounds of nearest-neighbour merges always leave plenty of components
+            hdb_scan_kernel<<<waveBlocks, kBlock, 0, s>>>(h, c.numChunks, r, true);
+            hdb_reduce_weight_kernel<<<blocks, kBlock, 0, s>>>(h, r);
+        }
+        hdb_scan_kernel<<<waveBlocks, kBlock, 0, s>>>(h, c.numChunks, r, false);
         hdb_reduce_weight_kernel<<<blocks, kBlock, 0, s>>>(h, r);
         hdb_reduce_key_kernel<<<blocks, kBlock, 0, s>>>(h, r);
         hdb_select_kernel<<<blocks, kBlock, 0, s>>>(h, r);
         hdb_flatten_kernel<<<blocks, kBlock, 0, s>>>(h, r);
+        hdb_giant_kernel<<<blocks, kBlock, 0, s>>>(h, r);
     }
     return hipGetLastError();
 }

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <numeric>
 #include <vector>
@@ -77,18 +78,52 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
             }
     }
     if ((int)queue.size() != n) return ICPFLOW_E_ARG;   // the edges do not span the points
-    std::vector<int> cur(m), nxt(m), order(m);
+    struct Edge {
+        double w;
+        int cur, nxt;
+    };
+    std::vector<Edge> edges(m);
     for (int e = 0; e < m; ++e) {
         const bool aIsChild = pred[h_edge_a[e]] == h_edge_b[e];
-        cur[e] = aIsChild ? h_edge_b[e] : h_edge_a[e];
-        nxt[e] = aIsChild ? h_edge_a[e] : h_edge_b[e];
+        edges[e] = Edge{h_edge_w[e], aIsChild ? h_edge_b[e] : h_edge_a[e], aIsChild ? h_edge_a[e] : h_edge_b[e]};
     }
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int x, int y) {
-        if (h_edge_w[x] != h_edge_w[y]) return h_edge_w[x] < h_edge_w[y];
-        if (cur[x] != cur[y]) return cur[x] < cur[y];
-        return nxt[x] < nxt[y];
-    });
+    const auto byEnds = [](const Edge &x, const Edge &y) { return x.cur != y.cur ? x.cur < y.cur : x.nxt < y.nxt; };
+    bool plain = true;   // non-negative weights order like their bit patterns: radix sort, then order the ties
+    for (int e = 0; e < m; ++e) {
+        if (std::isnan(edges[e].w)) return ICPFLOW_E_ARG;
+        plain = plain && !std::signbit(edges[e].w);
+    }
+    if (plain) {
+        std::vector<Edge> tmp(m);
+        std::vector<uint32_t> hist(1 << 16);
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 16 * pass;
+            auto digit = [&](const Edge &x) {
+                uint64_t bits;
+                std::memcpy(&bits, &x.w, 8);
+                return (uint32_t)((bits >> shift) & 0xffff);
+            };
+            std::fill(hist.begin(), hist.end(), 0u);
+            for (const Edge &x : edges) ++hist[digit(x)];
+            uint32_t run = 0;
+            for (uint32_t &hv : hist) {
+                const uint32_t c = hv;
+                hv = run;
+                run += c;
+            }
+            for (const Edge &x : edges) tmp[hist[digit(x)]++] = x;
+            edges.swap(tmp);
+        }
+        for (int i = 0; i < m;) {
+            int k = i + 1;
+            while (k < m && edges[k].w == edges[i].w) ++k;
+            if (k - i > 1) std::sort(edges.begin() + i, edges.begin() + k, byEnds);
+            i = k;
+        }
+    } else {
+        std::sort(edges.begin(), edges.end(),
+                  [&](const Edge &x, const Edge &y) { return x.w != y.w ? x.w < y.w : byEnds(x, y); });
+    }
 
     // 2. single linkage: node n + i = i-th merge
     const int nodes = 2 * n - 1, root = 2 * n - 2;
@@ -106,11 +141,10 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
         return r;
     };
     for (int i = 0; i < m; ++i) {
-        const int e = order[i];
-        const int l = find(cur[e]), r = find(nxt[e]);
+        const int l = find(edges[i].cur), r = find(edges[i].nxt);
         left[i] = l;
         right[i] = r;
-        dist[i] = h_edge_w[e];
+        dist[i] = edges[i].w;
         count[n + i] = count[l] + count[r];
         up[l] = up[r] = n + i;
     }
