@@ -72,3 +72,18 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "liboracle" not in txt, f
+
+
+def test_plain_c_program_consumes_the_header(tmp_path):
+    """include/icpflow_hip.h is C (no C++/torch types): a C99 program compiled with gcc links the library, gets
+    status codes for bad arguments and runs the host-side HDBSCAN tree function (no GPU needed)."""
+    import subprocess
+    import __graft_entry__ as entry
+    so = entry.build()
+    exe = str(tmp_path / "abi_consumer")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                           os.path.join(REPO, "tests", "abi_consumer.c"), "-o", exe, so,
+                           "-Wl,-rpath," + os.path.dirname(so)])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.startswith("ok ")
