@@ -41,6 +41,7 @@ int g_side_stream = 1;   // developer knob (ICPFLOW_SIDE_STREAM=0: everything on
 int g_eval_sweep = 1;    // developer knob (ICPFLOW_EVAL_SWEEP=0 selects the all-pairs match_eval scans)
 int g_check_sweep = 1;   // developer knob (ICPFLOW_CHECK_SWEEP=0 selects the all-pairs roll-back check)
 int g_score_sweep = 1;   // developer knob (ICPFLOW_SCORE_SWEEP=0 selects the all-pairs scoring scan)
+int g_score_prune = 1;   // developer knob (ICPFLOW_SCORE_PRUNE=0: every scoring scan runs to the end)
 int g_hist_sorted = 1;   // developer knob (ICPFLOW_HIST_SORTED=0 selects the all-pairs vote)
 
 // the scoring sweep prunes by the largest NN distance inside a wave: it pays on large clusters (real
@@ -58,6 +59,7 @@ struct Workspace {
     float *peakVotes = nullptr;
     int64_t *peakIdx = nullptr;
     float *cand = nullptr;
+    double *scoreAccum = nullptr;
     double *partial = nullptr;
     float *Tinit = nullptr, *M = nullptr;
     IcpState *state = nullptr;
@@ -90,8 +92,10 @@ struct Workspace {
         peakIdx = (int64_t *)take(b * kTopK * 8);
         cand = (float *)take(b * kCand * 3 * 4);
         {
-            const size_t qb = (size_t)(scan_qblocks(N, B) > sweep_qblocks(N) ? scan_qblocks(N, B) : sweep_qblocks(N));
+            size_t qb = (size_t)(scan_qblocks(N, B) > sweep_qblocks(N) ? scan_qblocks(N, B) : sweep_qblocks(N));
+            if ((size_t)score_qblocks(N) > qb) qb = (size_t)score_qblocks(N);
             partial = (double *)take(b * 12 * qb * kPartial * 8);
+            scoreAccum = (double *)take(b * 12 * 8);
         }
         Tinit = (float *)take(b * 16 * 4);
         M = (float *)take(b * 16 * 4);
@@ -240,6 +244,9 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
         }
         ICPFLOW_TRY(launch_sweep_score(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
         ICPFLOW_TRY(launch_score_pick(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
+    } else if (g_score_prune) {
+        ICPFLOW_TRY(launch_scan_score_pruned(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s));
+        ICPFLOW_TRY(launch_score_pick(w.partial, score_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
     } else {
         ICPFLOW_TRY(launch_scan_score(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
         ICPFLOW_TRY(launch_score_pick(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
@@ -266,6 +273,8 @@ int icpflow_version(void)
         if (e && e[0] == '0') g_check_sweep = 0;
         e = getenv("ICPFLOW_SCORE_SWEEP");
         if (e && e[0] == '0') g_score_sweep = 0;
+        e = getenv("ICPFLOW_SCORE_PRUNE");
+        if (e && e[0] == '0') g_score_prune = 0;
         e = getenv("ICPFLOW_ICP_TEAMS");
         if (e && e[0] == '0') icpflow::g_icp_teams = 0;
         e = getenv("ICPFLOW_ICP_SPECULATIVE");

@@ -105,6 +105,10 @@ hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, cons
 hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                              const uint8_t *swap, int B, int N, const float *cand, double *partial,
                              hipStream_t s);
+int score_qblocks(int maxRows);
+hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
+                                    const uint8_t *swap, int B, int N, const float *cand, double *partial,
+                                    double *accum, hipStream_t s);
 hipError_t launch_scan_check(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                              const uint8_t *swap, int B, int N, const float *poseInit,
                              const float *poseFinal, double *partial, hipStream_t s);

@@ -34,6 +34,12 @@ struct ScanParams {
     int qblocks;           // query blocks per job
     // MODE_SCORE: candidate translations [B,6,3]
     const float *cand;
+    // MODE_SCORE in two launches (launch_scan_score_pruned): this launch covers the scans subBegin ..
+    // subBegin + subCount - 1 of every pair (scan = 2 * candidate + direction); with `prune` a workgroup
+    // first looks at what the earlier workgroups of its scan have summed (`accum`, [B,12]) and leaves when
+    // that already exceeds the score of candidate 0
+    int subBegin, subCount, prune;
+    double *accum;
     // MODE_CHECK: poseA = init [B,4,4], poseB = final [B,4,4];  MODE_EVAL: poseA = T
     const float *poseA;
     const float *poseB;
@@ -54,13 +60,24 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
 
     // ---- XCD-aware decode of the linear workgroup id --------------------------------
     const int lin = blockIdx.x;
-    const int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);
-    const int qb = (lin >> 3) % p.qblocks;
+    int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);
+    int qb = (lin >> 3) % p.qblocks;
+    if (MODE == MODE_SCORE && p.prune) {
+        // query block major: the first blocks of ALL scans are dispatched before anybody's second block, so
+        // later blocks find the sums of earlier ones (njobs is padded to 8: a scan stays on one XCD)
+        const int padded = (p.njobs + 7) & ~7;
+        qb = lin / padded;
+        job = lin % padded;
+    }
     if (job >= p.njobs) return;
 
     // ---- job -> (query cloud, target cloud, maps) -------------------------------------
     int b, sub;
-    if (MODE == MODE_SCORE) { b = job / 12; sub = job % 12; }
+    if (MODE == MODE_SCORE) {
+        b = job / p.subCount;
+        sub = p.subBegin + job % p.subCount;
+        job = b * 12 + sub;   // the scan's place in the partial records
+    }
     else if (MODE == MODE_NN) { b = job; sub = 0; }
     else { b = job >> 1; sub = job & 1; }
 
@@ -96,6 +113,35 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
         const bool backward = (MODE == MODE_SCORE) ? (sub & 1) : (MODE == MODE_EVAL ? (sub == 1) : false);
         if (!backward) { qc = a; qxf = axf; tc = c; }
         else           { qc = c; tc = a; txf = axf; }
+    }
+
+    if (MODE == MODE_SCORE && p.prune) {
+        // score_k = min(mean forward, mean backward) and only the smallest score matters (utils_hist.py:103-105).
+        // Nearest-neighbour distances are non-negative, so the part of this scan's sum that is already known is
+        // a lower bound of its mean; once that exceeds candidate 0's score (complete: earlier launch) this
+        // direction cannot make candidate k the winner, and if the other direction still does, the score is
+        // that direction's mean alone.  The scan reports +inf instead of its sum; the pick is unchanged.
+        __shared__ int leave;
+        if (threadIdx.x == 0) {
+            const bool sw = p.swap != nullptr && p.swap[b] != 0;
+            const float na = (float)(sw ? p.lenC : p.lenA)[b], nc = (float)(sw ? p.lenA : p.lenC)[b];
+            double f0 = 0.0, b0 = 0.0;
+            for (int q = 0; q < p.qblocks; ++q) {
+                f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
+                b0 += p.partial[((size_t)(b * 12 + 1) * p.qblocks + q) * kPartial];
+            }
+            const float bound = fminf((float)f0 / na, (float)b0 / nc);
+            const double seen = __hip_atomic_load(p.accum + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float low = (float)(seen / (double)((sub & 1) ? nc : na));
+            leave = low > bound * 1.0001f ? 1 : 0;   // NaN / inf bounds never prune
+            if (leave) {
+                double *o = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
+                o[0] = __builtin_huge_val();
+                for (int k = 1; k < kPartial; ++k) o[k] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (leave) return;
     }
 
     const int q0 = qb * (kScanBlock * Q);
@@ -165,6 +211,7 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
         double *o = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
 #pragma unroll
         for (int k = 0; k < kPartial; ++k) o[k] = v[k];
+        if (MODE == MODE_SCORE && p.accum != nullptr) atomicAdd(p.accum + job, v[0]);
     }
 }
 
@@ -466,7 +513,32 @@ hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA
     ScanParams p{};
     p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.N = N;
     p.njobs = B * 12; p.cand = cand; p.partial = partial;
+    p.subBegin = 0; p.subCount = 12;
     return launch_scan<MODE_SCORE>(p, N, B, s);
+}
+
+// The same twelve scans per pair with branch and bound: candidate 0 (the highest peak of the vote) is
+// scored completely first; the other ten scans run in query blocks of 256 rows, each block leaving at once
+// when the blocks before it have already summed more than candidate 0's score allows (see nn_scan_kernel).
+int score_qblocks(int maxRows) { return (maxRows + kScanBlock - 1) / kScanBlock; }
+
+hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
+                                    const uint8_t *swap, int B, int N, const float *cand, double *partial,
+                                    double *accum, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(accum, 0, (size_t)B * 12 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    ScanParams p{};
+    p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.N = N;
+    p.cand = cand; p.partial = partial; p.accum = accum;
+    p.qblocks = score_qblocks(N);
+    p.njobs = B * 2; p.subBegin = 0; p.subCount = 2; p.prune = 0;
+    hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) / 8) * 8 * p.qblocks)),
+                       dim3(kScanBlock), 0, s, p);
+    p.njobs = B * 10; p.subBegin = 2; p.subCount = 10; p.prune = 1;
+    hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) & ~7) * p.qblocks)),
+                       dim3(kScanBlock), 0, s, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan_check(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
