@@ -642,7 +642,6 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             }
             const float *keyf = (GRID == 4) ? (axis == 0 ? lx : (axis == 1 ? ly : lz))
                                             : (axis == 0 ? gx : (axis == 1 ? gy : gz));
-            static_assert(Q == 1, "sorted sweep: one query per lane");
             constexpr int PER = BLOCK * Q;            // a wave owns 64 CONSECUTIVE sorted queries
             // team member `rank` owns the sorted queries [qBegin, qEnd)
             const int qShare = (TEAM && G > 1) ? ((xc.n + G - 1) / G + kWave - 1) / kWave * kWave : xc.n;
@@ -710,12 +709,14 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 // chunk).  If several targets tie -- in that chunk or, flagged by the scan, in another
                 // one -- the lowest ORIGINAL index wins: only then are the original indices fetched
                 // (w component of the sorted array).
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
                 double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0, wq = 0.0;
-                if (live[0] && acc.best[0] <= p.thr2) {  // :160-161
+                if (live[q] && acc.best[q] <= p.thr2) {  // :160-161
                     float ynx = 0.f, yny = 0.f, ynz = 0.f;
-                    int matches = tie[0] ? 2 : 0;
-                    if (!tie[0]) {
-                        const int c0 = acc.chunk[0];
+                    int matches = tie[q] ? 2 : 0;
+                    if (!tie[q]) {
+                        const int c0 = acc.chunk[q];
 #pragma unroll
                         for (int u = 0; u < kChunk / 4; ++u) {
                             const float4 tx = *reinterpret_cast<const float4 *>((GRID == 4 ? lx : gx) + c0 + 4 * u);
@@ -726,24 +727,24 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             const float tzs[4] = {tz.x, tz.y, tz.z, tz.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float d = sqdist(qx[0], qy[0], qz[0], txs[e], tys[e], tzs[e]);
-                                if (d == acc.best[0]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; }
+                                const float d = sqdist(qx[q], qy[q], qz[q], txs[e], tys[e], tzs[e]);
+                                if (d == acc.best[q]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; }
                             }
                         }
                     }
                     if (matches != 1) {
-                        const int r0 = tie[0] ? cb : acc.chunk[0];
-                        const int r1 = tie[0] ? ce : acc.chunk[0] + kChunk;
+                        const int r0 = tie[q] ? cb : acc.chunk[q];
+                        const int r1 = tie[q] ? ce : acc.chunk[q] + kChunk;
                         int bj = 0x7fffffff;
                         for (int k = r0; k < min(r1, yc.n); ++k) {
                             const float4 t = ys[k];
-                            const float d = sqdist(qx[0], qy[0], qz[0], t.x, t.y, t.z);
+                            const float d = sqdist(qx[q], qy[q], qz[q], t.x, t.y, t.z);
                             const int j = __float_as_int(t.w);
-                            if (d == acc.best[0] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
+                            if (d == acc.best[q] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
                         }
                     }
                     wq = 1.0;
-                    ax = (double)(x0x[0] - ox); ay = (double)(x0y[0] - oy); az = (double)(x0z[0] - oz);
+                    ax = (double)(x0x[q] - ox); ay = (double)(x0y[q] - oy); az = (double)(x0z[q] - oz);
                     bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
                 }
                 ICPFLOW_STAMP(10);
@@ -761,6 +762,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     const double a8 = swap32_sum(ax * ax + ay * ay + az * az, bx * bx + by * by + bz * bz);
                     fold[4] += swap16_sum(a8, a8);
                 }
+                            }
             }
             // rows of 16 lanes -> lane 15 of each row holds the wave total of "its" moment
 #pragma unroll
@@ -1327,7 +1329,8 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
     const bool timed = g_prof.used < (int)g_prof.start.size();
     if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
     if (p.sortY != nullptr) {    // sorted sweep
-        // one query per lane (Q = 1): a wave's 64 consecutive sorted queries span the narrowest window;
+        // one query per lane (Q = 1; two per lane on 8 waves measured 25 % slower at n = 1024): a wave's 64
+        // consecutive sorted queries span the narrowest window;
         // clouds longer than the workgroup take several passes.  GRID 4 keeps the sorted fixed cloud
         // in LDS (12 B/point, up to 144 KiB of the CU's 160 KiB at N = 12288); beyond that GRID 3
         // streams it through scalar loads (no LDS image, any N the sort can handle).
