@@ -147,8 +147,8 @@ def main():
     }
 
     extras = {}
-    if not a.no_extras:
-        extras = extra_measurements(args, src, dst, T if world == 1 else T[:B], dev, a)
+    if not a.no_extras and world == 1:   # single-GPU runs only: the N > 1 runs measure scaling, nothing else
+        extras = extra_measurements(args, src, dst, T, dev, a)
 
     cpu = cpu_baseline(S, D, a) if (a.cpu_pairs > 0 and world == 1) else None
 
