@@ -42,6 +42,15 @@ KERNEL1(k_fmac, "v_fmac_f32 %0, %1, %2")
 KERNEL1(k_min, "v_min_f32 %0, %0, %1")
 KERNEL1(k_min3, "v_min3_f32 %0, %0, %1, %2")
 KERNEL1(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+KERNEL1(k_cndmask64, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+KERNEL1(k_cmp, "v_cmp_lt_f32 vcc, %0, %1")
+KERNEL1(k_cmp_sgpr, "v_cmp_lt_f32_e64 s[22:23], %0, %1")
+KERNEL1(k_cmp_cnd, "v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc")
+KERNEL1(k_max, "v_max_f32 %0, %0, %1")
+KERNEL1(k_med3, "v_med3_f32 %0, %0, %1, %2")
+KERNEL1(k_sub_dpp, "v_sub_f32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf")
+KERNEL1(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf")
+KERNEL1(k_readlane, "v_readlane_b32 s20, %1, 3\n\tv_add_f32 %0, s20, %0")
 KERNEL2(k_pk_add, "v_pk_add_f32 %0, %0, %1")
 KERNEL2(k_pk_add_neg, "v_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]")
 KERNEL2(k_pk_mul, "v_pk_mul_f32 %0, %0, %1")
@@ -66,10 +75,10 @@ int main()
     typedef void (*K)(float *, float, float);
     struct { const char *n; K k; } ks[] = {
         {"v_add_f32", k_add}, {"v_sub_f32", k_sub}, {"v_mul_f32", k_mul}, {"v_fma_f32", k_fma}, {"v_fmac_f32", k_fmac},
-        {"v_min_f32", k_min}, {"v_min3_f32", k_min3}, {"v_cndmask_b32", k_cndmask},
+        {"v_sub_f32_dpp newbcast", k_sub_dpp}, {"v_mov_b32_dpp newbcast", k_mov_dpp}, {"v_readlane+v_add", k_readlane}, {"v_min_f32", k_min}, {"v_min3_f32", k_min3}, {"v_cndmask_b32 vcc", k_cndmask}, {"v_cndmask_b32 sgpr", k_cndmask64}, {"v_cmp_lt_f32 vcc", k_cmp}, {"v_cmp_lt_f32 sgpr", k_cmp_sgpr}, {"v_cmp+v_cndmask", k_cmp_cnd}, {"v_max_f32", k_max}, {"v_med3_f32", k_med3},
         {"v_pk_add_f32", k_pk_add}, {"v_pk_add_f32(neg)", k_pk_add_neg}, {"v_pk_mul_f32", k_pk_mul}, {"v_pk_fma_f32", k_pk_fma}};
     // effective clock: calibrate with v_fma at 32 waves/CU assuming 2 cycles/instr
-    for (int wpc : {4, 8, 16, 32}) {
+    for (int wpc : {16}) {
         printf("waves/CU %d\n", wpc);
         for (auto &e : ks) {
             const int blocks = 256 * wpc / 4;
