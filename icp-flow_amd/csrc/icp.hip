@@ -472,13 +472,22 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
         if (lane == 0) __hip_atomic_store(&ctrl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return true;
     }
+    // The records are read with agent-scope atomic loads, which the compiler keeps in program order with a full
+    // round trip each (~0.7 us): spread them over the lanes.  Lane 18 g + k (g < 3) adds moment k of the members
+    // g, g + 3, g + 6, ...; the three partial sums are then added in the order g = 0, 1, 2 -- the same on every
+    // member, so all members still get bit-identical totals.  Lane 63 fetches member 0's stop flag meanwhile.
     const double *base = t.mom + ((size_t)b * 2 + (it & 1)) * kMaxTeam * kTeamStride;
-    double sum = 0.0;
-    if (lane < kMoments)
-        for (int r = 0; r < G; ++r)
-            sum += __hip_atomic_load(&base[r * kTeamStride + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mine = sum;
-    return __hip_atomic_load(&base[kMoments], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
+    constexpr int kLanesPerGroup = kMoments, kGroups = 3;
+    const int g = lane / kLanesPerGroup, k = lane - g * kLanesPerGroup;
+    double part = 0.0;
+    if (g < kGroups)
+        for (int r = g; r < G; r += kGroups)
+            part += __hip_atomic_load(&base[r * kTeamStride + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double stop = 0.0;
+    if (lane == 63) stop = __hip_atomic_load(&base[kMoments], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double p1 = __shfl(part, (lane + kLanesPerGroup) & 63, kWave), p2 = __shfl(part, (lane + 2 * kLanesPerGroup) & 63, kWave);
+    mine = (part + p1) + p2;   // meaningful in lanes < 18
+    return __shfl(stop, 63, kWave) != 0.0;
 }
 
 // Work decomposition inside the workgroup (one pair): the NWAVE waves form NWAVE/TS query
