@@ -40,6 +40,9 @@ struct ScanParams {
     // that already exceeds the score of candidate 0
     int subBegin, subCount, prune;
     double *accum;
+    // MODE_SCORE, pruned launches: 2 = a workgroup takes 128 query rows and its two halves scan one half of
+    // every target tile each (finer blocks: a scan can leave after an eighth of a 1024-point cloud)
+    int split;
     // MODE_CHECK: poseA = init [B,4,4], poseB = final [B,4,4];  MODE_EVAL: poseA = T
     const float *poseA;
     const float *poseB;
@@ -144,7 +147,9 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
         if (leave) return;
     }
 
-    const int q0 = qb * (kScanBlock * Q);
+    const int split = (MODE == MODE_SCORE && Q == 1 && p.split > 1) ? p.split : 1;   // 1, 2 or 4
+    const int rowsPerBlock = kScanBlock * Q / split;
+    const int q0 = qb * rowsPerBlock;
     const int nq_rows = (MODE == MODE_NN) ? p.N : qc.n;  // rows that get an output / a sum
     if (q0 >= nq_rows) {                                 // whole block beyond the cloud
         // its partial record is still summed by the epilogue kernels: publish zeros
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
     bool live[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int i = q0 + q * kScanBlock + threadIdx.x;
+        const int i = q0 + q * kScanBlock + (threadIdx.x & (rowsPerBlock - 1));
         live[q] = i < qc.n;
         qx[q] = qy[q] = qz[q] = 0.f;
         ox[q] = oy[q] = oz[q] = 0.f;
@@ -169,7 +174,22 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
     }
 
     ScanAcc<Q> acc;
-    scan_cloud<Q>(tc, txf, tile, qx, qy, qz, acc);
+    if (split > 1) {
+        // the `split` parts of the workgroup hold the same queries; part h scans share h of every tile and the
+        // minima meet in LDS (the minimum of the partial minima is the minimum over all targets)
+        __shared__ float partMin[kScanBlock];
+        const int part = threadIdx.x / rowsPerBlock;
+        scan_cloud<Q>(tc, txf, tile, qx, qy, qz, acc, part, split);
+        partMin[threadIdx.x] = acc.best[0];
+        __syncthreads();
+        if (part == 0) {
+            for (int h = 1; h < split; ++h) acc.best[0] = fminf(acc.best[0], partMin[threadIdx.x + h * rowsPerBlock]);
+        } else {
+            live[0] = false;   // its rows are summed by part 0
+        }
+    } else {
+        scan_cloud<Q>(tc, txf, tile, qx, qy, qz, acc);
+    }
 
     if (MODE == MODE_NN) {
 #pragma unroll
@@ -518,9 +538,10 @@ hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA
 }
 
 // The same twelve scans per pair with branch and bound: candidate 0 (the highest peak of the vote) is
-// scored completely first; the other ten scans run in query blocks of 256 rows, each block leaving at once
+// scored completely first; the other ten scans run in query blocks of 128 rows, each block leaving at once
 // when the blocks before it have already summed more than candidate 0's score allows (see nn_scan_kernel).
-int score_qblocks(int maxRows) { return (maxRows + kScanBlock - 1) / kScanBlock; }
+constexpr int kScoreSplit = 2;   // 128-row blocks (64-row blocks measured slower: every block stages the whole target cloud)
+int score_qblocks(int maxRows) { return (maxRows + kScanBlock / kScoreSplit - 1) / (kScanBlock / kScoreSplit); }
 
 hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                                     const uint8_t *swap, int B, int N, const float *cand, double *partial,
@@ -532,6 +553,7 @@ hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_
     p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.N = N;
     p.cand = cand; p.partial = partial; p.accum = accum;
     p.qblocks = score_qblocks(N);
+    p.split = kScoreSplit;
     p.njobs = B * 2; p.subBegin = 0; p.subCount = 2; p.prune = 0;
     hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) / 8) * 8 * p.qblocks)),
                        dim3(kScanBlock), 0, s, p);
