@@ -121,19 +121,17 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
     if (MODE == MODE_SCORE && p.prune) {
         // score_k = min(mean forward, mean backward) and only the smallest score matters (utils_hist.py:103-105).
         // Nearest-neighbour distances are non-negative, so the part of this scan's sum that is already known is
-        // a lower bound of its mean; once that exceeds candidate 0's score (complete: earlier launch) this
+        // a lower bound of its mean; once that exceeds candidate 0's forward mean (>= its score) this
         // direction cannot make candidate k the winner, and if the other direction still does, the score is
         // that direction's mean alone.  The scan reports +inf instead of its sum; the pick is unchanged.
         __shared__ int leave;
         if (threadIdx.x == 0) {
             const bool sw = p.swap != nullptr && p.swap[b] != 0;
             const float na = (float)(sw ? p.lenC : p.lenA)[b], nc = (float)(sw ? p.lenA : p.lenC)[b];
-            double f0 = 0.0, b0 = 0.0;
-            for (int q = 0; q < p.qblocks; ++q) {
-                f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
-                b0 += p.partial[((size_t)(b * 12 + 1) * p.qblocks + q) * kPartial];
-            }
-            const float bound = fminf((float)f0 / na, (float)b0 / nc);
+            // the forward mean of candidate 0 (complete: earlier launch) is an upper bound of its score
+            double f0 = 0.0;
+            for (int q = 0; q < p.qblocks; ++q) f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
+            const float bound = (float)f0 / na;
             const double seen = __hip_atomic_load(p.accum + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float low = (float)(seen / (double)((sub & 1) ? nc : na));
             leave = low > bound * 1.0001f ? 1 : 0;   // NaN / inf bounds never prune
@@ -537,8 +535,8 @@ hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA
     return launch_scan<MODE_SCORE>(p, N, B, s);
 }
 
-// The same twelve scans per pair with branch and bound: candidate 0 (the highest peak of the vote) is
-// scored completely first; the other ten scans run in query blocks of 128 rows, each block leaving at once
+// The same twelve scans per pair with branch and bound: the forward scan of candidate 0 (the highest peak of
+// the vote) runs to the end first; the other eleven scans run in query blocks of 128 rows, each block leaving at once
 // when the blocks before it have already summed more than candidate 0's score allows (see nn_scan_kernel).
 constexpr int kScoreSplit = 2;   // 128-row blocks (64-row blocks measured slower: every block stages the whole target cloud)
 int score_qblocks(int maxRows) { return (maxRows + kScanBlock / kScoreSplit - 1) / (kScanBlock / kScoreSplit); }
@@ -554,10 +552,10 @@ hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_
     p.cand = cand; p.partial = partial; p.accum = accum;
     p.qblocks = score_qblocks(N);
     p.split = kScoreSplit;
-    p.njobs = B * 2; p.subBegin = 0; p.subCount = 2; p.prune = 0;
+    p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
     hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) / 8) * 8 * p.qblocks)),
                        dim3(kScanBlock), 0, s, p);
-    p.njobs = B * 10; p.subBegin = 2; p.subCount = 10; p.prune = 1;
+    p.njobs = B * 11; p.subBegin = 1; p.subCount = 11; p.prune = 1;
     hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) & ~7) * p.qblocks)),
                        dim3(kScanBlock), 0, s, p);
     return hipGetLastError();
