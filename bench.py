@@ -78,7 +78,7 @@ def main():
     def step():
         T, iters = utils_match.hist_icp(args, src, dst, return_iterations=True)
         if world > 1:
-            T = gather_results(T, world)                         # RCCL all_gather over xGMI
+            T = gather_results(T, world, counts=[B] * world)     # ONE RCCL all_gather over xGMI, no host sync
         return T, iters
 
     def sync():

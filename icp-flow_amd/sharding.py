@@ -25,16 +25,22 @@ def shard_range(rank, world, total):
     return first, base + (1 if rank < extra else 0)
 
 
-def gather_results(local, world, group=None):
+def gather_results(local, world, group=None, counts=None):
     """all_gather per-pair result rows ([B_local, ...]) in rank order -> [sum B_local, ...].
-    Handles uneven shards by padding to the largest one."""
+    `counts` (rows of every rank, known to all ranks -- e.g. from shard_range) makes this ONE collective with
+    no host synchronisation; without it the counts are exchanged first (one more collective and a device ->
+    host read per call).  Uneven shards are padded to the largest one."""
     if world == 1:
         return local
     local = local.contiguous()
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        got = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(got, n, group=group)
+        counts = [int(c.item()) for c in got]
+    counts = [int(c) for c in counts]
+    if len(counts) != world or counts[dist.get_rank(group)] != local.shape[0]:
+        raise ValueError(f"gather_results: counts {counts} do not describe this rank's {local.shape[0]} rows")
     nmax = max(counts)
     if all(c == nmax for c in counts):
         out = local.new_empty((world * nmax,) + tuple(local.shape[1:]))
@@ -52,4 +58,5 @@ def register_sharded(args, src, dst, rank, world, register_fn, group=None):
     with `register_fn(args, src_block, dst_block) -> [B_local,4,4]` and gather all transforms."""
     first, count = shard_range(rank, world, src.shape[0])
     T = register_fn(args, src[first:first + count], dst[first:first + count])
-    return gather_results(T, world, group=group)
+    counts = [shard_range(r, world, src.shape[0])[1] for r in range(world)]   # every rank can compute them
+    return gather_results(T, world, group=group, counts=counts)
