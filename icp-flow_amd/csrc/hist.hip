@@ -161,8 +161,14 @@ __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int 
                 const int py = (int)(axis_quot<FAST>(vy - box.min_y, dqy) * fly);
                 const int pz = (int)(axis_quot<FAST>(vz - box.min_z, dqz) * flz);
                 // FAST also promises len_x * len_y and len_z below 2^23: 24-bit multiplies (full rate) are exact
-                const int bin = FAST ? __mul24(__mul24(px, box.len_y) + py, box.len_z) + pz
-                                     : (px * box.len_y + py) * box.len_z + pz;
+                int bin;
+                if (FAST) {   // v_mad_i32_i24 is full rate (the compiler picks the quarter-rate v_mad_u64_u32 here)
+                    int row;
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(px), "s"(box.len_y), "v"(py));
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(bin) : "v"(row), "s"(box.len_z), "v"(pz));
+                } else {
+                    bin = (px * box.len_y + py) * box.len_z + pz;
+                }
                 atomicAdd(&counters[bin], 1u);
             }
         }
