@@ -208,6 +208,26 @@ def extra_measurements(args, src, dst, T, dev, a):
     out["hist_all_pairs_vote_ms_per_batch"] = round(ms, 4)
     ms = timeit(lambda: utils_helper.nearest_neighbor_batch(src, dst))
     out["nearest_neighbor_batch_ms_per_batch"] = round(ms, 4)
+    # capacity with several INDEPENDENT batches in flight: consecutive batches alternate between HIP streams (each
+    # batch is still one 256-pair registration with its own batch-global stop rule and identical results); the tail
+    # of one batch's ICP launch -- few pairs still iterating, most CUs idle -- overlaps the next batch's vote and
+    # scoring.  Not the headline: `value` times one batch after the other on one stream.
+    streams = [torch.cuda.Stream(dev) for _ in range(4)]
+
+    def in_flight(steps):
+        outs = []
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                outs.append(utils_match.hist_icp(args, src, dst))
+        return outs
+
+    in_flight(8)
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    outs = in_flight(40)
+    torch.cuda.synchronize(dev)
+    out["four_batches_in_flight_registrations_per_s"] = round(B * 40 / (time.perf_counter() - t), 1)
+    out["four_batches_in_flight_identical_results"] = bool(all(torch.equal(outs[0], o) for o in outs))
     fp = frame_pair_measurement(dev)
     if fp is not None:
         out["frame_pair"] = fp
