@@ -157,7 +157,10 @@ def register_frame_pair(args, fp, device, gap=1):
         ls = torch.from_numpy(fp.labels_src).to(device)
         ld = torch.from_numpy(fp.labels_dst).to(device)
     pose = torch.from_numpy(fp.pose).to(device)
-    torch.manual_seed(0)                                    # main.py:139 (random subsampling of over-long clusters)
+    # main.py:139 seeds torch's global generator once; a private generator with the same seed gives the same
+    # draws (random subsampling of over-long clusters) without touching the caller's global RNG state
+    a.generator = torch.Generator()
+    a.generator.manual_seed(0)
     pairs, T = utils_track.track(a, ps, pd, ls, ld)
     flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, T, pose)
     return dict(pairs=pairs, transformations=T, flow=flow)

@@ -59,7 +59,9 @@ def match_eval(args, pcd1, pcd2, transformations):
 def _gather_pair_batches(args, st, dt, si, di):
     """pad_segment (utils_helper.py:185-196) of the candidate clusters (rows si / di of the tables), one
     kernel per cloud: -> two [B, max_points, 4] device tensors.  Over-long clusters are subsampled with
-    torch.randperm on the host generator, src then dst, pair by pair -- the reference's stream of draws
+    torch.randperm on the host generator (or `args.generator`, a torch.Generator private to the caller, so that
+    frame pairs registered concurrently do not share a stream of draws), src then dst, pair by pair -- the
+    reference's stream of draws
     (utils_match.py:84-89, utils_helper.py:198-201)."""
     N = int(args.max_points)
     dev = st.points.device
@@ -73,7 +75,7 @@ def _gather_pair_batches(args, st, dt, si, di):
         for which, c in ((0, cs), (1, cd)):
             if c[k] > N:
                 seg[which, 2, k] = len(perms) * N
-                perms.append(torch.randperm(int(c[k]))[0:N].to(torch.int32))
+                perms.append(torch.randperm(int(c[k]), generator=getattr(args, "generator", None))[0:N].to(torch.int32))
     d_seg = torch.from_numpy(seg).to(dev)
     d_perm = torch.cat(perms).to(dev) if perms else None
     segs = torch.empty((2, B, N, 4), dtype=torch.float32, device=dev)
