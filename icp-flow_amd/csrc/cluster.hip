@@ -163,29 +163,52 @@ __global__ __launch_bounds__(kBlock) void dbscan_hook_kernel(const float4 *__res
     if (lane == 0) parent[j] = first;
 }
 
-__global__ __launch_bounds__(kBlock) void dbscan_flatten_kernel(int n, int *__restrict__ parent)
+// every point points at the root of its tree; per chunk of 64 sorted rows: the root shared by all its core
+// points (-1: none at all, -2: several) -- the union step skips such chunks without reading them
+__global__ __launch_bounds__(kBlock) void dbscan_flatten_kernel(int n, const uint8_t *__restrict__ core,
+                                                                int *__restrict__ parent,
+                                                                int *__restrict__ chunkRoot)
 {
     const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= n) return;
-    parent[j] = uf_find(parent, j);
+    const int lane = threadIdx.x & 63;
+    int root = -1;
+    bool isCore = false;
+    if (j < n) {
+        root = uf_find(parent, j);
+        parent[j] = root;
+        isCore = core[j] != 0;
+    }
+    const unsigned long long cores = __ballot(isCore);
+    if (blockIdx.x * kBlock + (threadIdx.x & ~63) < n) {
+        int shared = -1;
+        if (cores) {
+            const int first = __shfl(root, __builtin_ctzll(cores));
+            shared = __ballot(isCore && root != first) == 0 ? first : -2;
+        }
+        if (lane == 0) chunkRoot[j >> 6] = shared;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void dbscan_union_kernel(const float4 *__restrict__ sorted,
                                                               const int2 *__restrict__ runs,
                                                               const uint8_t *__restrict__ core, int n, double eps2,
-                                                              int *parent)
+                                                              const int *__restrict__ chunkRoot, int *parent)
 {
     const int j = wave_point(n);
     if (j < 0 || !core[j]) return;
     const int lane = threadIdx.x & 63;
     const float4 p = sorted[j];
     int mine = parent[j];   // root after the flatten step; refreshed when this wave merges trees
+    const int mine0 = mine;
     for (int r = 0; r < kRuns; ++r) {
         const int2 run = runs[(size_t)r * n + j];
         const int hi = min(run.y, j);   // every core-core edge once, from its later endpoint
-        for (int q0 = run.x; q0 < hi; q0 += 64) {
+        for (int q0 = run.x & ~63; q0 < hi; q0 += 64) {   // chunk-aligned steps
+            // after hook + flatten nearly every chunk around a point holds only its own tree (or no core point)
+            const int shared = chunkRoot[q0 >> 6];
+            if (shared == -1 || shared == mine0) continue;
             const int q = q0 + lane;
-            const bool cross = q < hi && core[q] && parent[q] != mine && closer(p, sorted[q], eps2);
+            const bool cross = q >= run.x && q < hi && core[q] && parent[q] != mine && closer(p, sorted[q], eps2);
             if (__ballot(cross) == 0) continue;
             if (cross) uf_union(parent, q, j);
             mine = __shfl(uf_find(parent, j), 0);
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void dbscan_label_kernel(const float4 *__re
 
 struct Carve {
     unsigned long long *keyIn, *keyOut;
-    int *valIn, *valOut, *parent, *firstRow, *rootOf, *rank;
+    int *valIn, *valOut, *parent, *firstRow, *rootOf, *rank, *chunkRoot;
     float4 *sorted;
     int2 *runs;
     uint8_t *core;
@@ -353,6 +376,7 @@ hipError_t carve(int n, void *ws, Carve *c, hipStream_t s)
     c->valOut = (int *)take(N * 4);
     c->parent = (int *)take(N * 4);
     c->firstRow = (int *)take(N * 4);
+    c->chunkRoot = (int *)take(((N + 63) / 64) * 4);
     c->rootOf = (int *)take(N * 4);
     c->rank = (int *)take(N * 4);
     c->sorted = (float4 *)take(N * 16);
@@ -395,8 +419,8 @@ hipError_t launch_dbscan(const float *pts, int stride, const uint8_t *mask, int 
     const int waveBlocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     dbscan_core_kernel<<<waveBlocks, kBlock, 0, s>>>(c.sorted, c.keyOut, n, eps2, minPoints, c.runs, c.core);
     dbscan_hook_kernel<<<waveBlocks, kBlock, 0, s>>>(c.sorted, c.runs, c.core, n, eps2, c.parent);
-    dbscan_flatten_kernel<<<blocks, kBlock, 0, s>>>(n, c.parent);
-    dbscan_union_kernel<<<waveBlocks, kBlock, 0, s>>>(c.sorted, c.runs, c.core, n, eps2, c.parent);
+    dbscan_flatten_kernel<<<blocks, kBlock, 0, s>>>(n, c.core, c.parent, c.chunkRoot);
+    dbscan_union_kernel<<<waveBlocks, kBlock, 0, s>>>(c.sorted, c.runs, c.core, n, eps2, c.chunkRoot, c.parent);
     dbscan_first_row_kernel<<<blocks, kBlock, 0, s>>>(c.sorted, c.core, n, c.parent, c.firstRow);
     dbscan_assign_kernel<<<waveBlocks, kBlock, 0, s>>>(c.sorted, c.keyOut, c.runs, c.core, n, eps2, c.parent,
                                                        c.firstRow, c.rootOf);
