@@ -153,16 +153,10 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
     std::vector<Row> rows;
     rows.reserve((size_t)n + 64);
     std::vector<int> relabel(nodes, -1), bfs, sub;
-    std::vector<uint8_t> ignore(nodes, 0);
+    // breadth first over the dendrogram, but only through nodes that are still part of a cluster: a side that
+    // falls out is walked once, by fall_out (the order of the surviving nodes is that of the full walk)
     bfs.reserve(nodes);
     bfs.push_back(root);
-    for (size_t head = 0; head < bfs.size(); ++head) {
-        const int v = bfs[head];
-        if (v >= n) {
-            bfs.push_back(left[v - n]);
-            bfs.push_back(right[v - n]);
-        }
-    }
     relabel[root] = n;
     int nextLabel = n + 1;
     auto fall_out = [&](int top, int parentLabel, double lambda) {   // every point below `top` leaves the parent
@@ -170,7 +164,6 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
         sub.push_back(top);
         for (size_t head = 0; head < sub.size(); ++head) {
             const int v = sub[head];
-            ignore[v] = 1;
             if (v >= n) {
                 sub.push_back(left[v - n]);
                 sub.push_back(right[v - n]);
@@ -179,8 +172,9 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
             }
         }
     };
-    for (const int v : bfs) {
-        if (v < n || ignore[v]) continue;
+    for (size_t head = 0; head < bfs.size(); ++head) {
+        const int v = bfs[head];
+        if (v < n) continue;
         const int l = left[v - n], r = right[v - n];
         const double d = dist[v - n];
         const double lambda = d > 0.0 ? 1.0 / d : std::numeric_limits<double>::infinity();
@@ -190,15 +184,19 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
             rows.push_back(Row{relabel[v], relabel[l], lambda, lc});
             relabel[r] = nextLabel++;
             rows.push_back(Row{relabel[v], relabel[r], lambda, rc});
+            bfs.push_back(l);
+            bfs.push_back(r);
         } else if (lc < min_cluster_size && rc < min_cluster_size) {
             fall_out(l, relabel[v], lambda);
             fall_out(r, relabel[v], lambda);
         } else if (lc < min_cluster_size) {
             relabel[r] = relabel[v];
             fall_out(l, relabel[v], lambda);
+            bfs.push_back(r);
         } else {
             relabel[l] = relabel[v];
             fall_out(r, relabel[v], lambda);
+            bfs.push_back(l);
         }
     }
 
