@@ -172,8 +172,10 @@ def hdbscan(points, min_cluster_size, min_samples=None, mask=None, cell=0.25):
     nl = t["n_live"]
     if nl < max(k, 2):
         raise ValueError(f"hdbscan: {nl} points cannot be clustered with min_samples {k}")
-    sub = np.cumsum(live_h) - 1                                     # caller row -> row of the clustered subset
-    a, b = sub[t["a"].cpu().numpy()], sub[t["b"].cpu().numpy()]
+    a, b = t["a"].cpu().numpy(), t["b"].cpu().numpy()
+    if nl != n:                                                     # caller row -> row of the clustered subset
+        sub = np.cumsum(live_h) - 1
+        a, b = sub[a], sub[b]
     lab = labels_from_mst(a, b, np.sqrt(t["w2"].cpu().numpy()), nl, min_cluster_size)
     out = np.full(n, -1, dtype=np.int64)
     out[live_h] = lab
@@ -193,7 +195,9 @@ def cluster_hdbscan(args, points, mask=None):
     cluster_info = np.array(list(zip(lbls[1:], counts[1:])))
     cluster_info = cluster_info[cluster_info[:, 1].argsort()]
     clusters_labels = cluster_info[::-1][:args.num_clusters, 0]
-    lab[keep & np.isin(lab, clusters_labels, invert=True)] = -1
+    kept = np.zeros(int(lab.max()) + 2, dtype=bool)                 # label + 1 -> survives (table instead of isin)
+    kept[np.asarray(clusters_labels, dtype=np.int64) + 1] = True
+    lab[keep & ~kept[np.maximum(lab, -1) + 1]] = -1
     if mask is None:
         return torch.from_numpy(lab).to(points.device) if resident else lab
     return lab
