@@ -404,3 +404,49 @@ def test_gpu_unlabelled_frame_pair_hdbscan_then_registered():
     assert abs(len(got["pairs"]) - len(g["pairs"])) <= 3 and abs(epe - float(g["epe"])) < 5e-3, (len(got["pairs"]), epe)
     same = np.abs(flow - g["flow"]).max(axis=1) < 1e-4
     assert same.mean() > 0.97, same.mean()
+
+
+@gpu
+def test_gpu_clustering_input_variants():
+    """Rows of four floats (x, y, z, flag) on the GPU, an index list instead of a mask, min_samples different from
+    min_cluster_size: same answers as the plain calls / the oracle."""
+    hip = _hip()
+    p = _cloud(51, 3000)
+    wide = torch.from_numpy(np.concatenate([p, np.ones((len(p), 1), np.float32)], 1)).cuda()
+    lab3, _ = hip.dbscan(p, 0.3, 6)
+    lab4, _ = hip.dbscan(wide, 0.3, 6)
+    assert torch.equal(lab3, lab4)
+    a = SimpleNamespace(epsilon=0.3, min_cluster_size=6, num_clusters=8, if_hdbscan=False)
+    mask = np.random.default_rng(1).random(len(p)) < 0.8
+    by_mask = hip.cluster_pcd(a, p, mask)
+    by_index = hip.cluster_pcd(a, p, np.flatnonzero(mask))
+    assert np.array_equal(by_mask, by_index) and np.array_equal(by_mask, oc.cluster_pcd(a, p, mask))
+    # min_samples given explicitly: the tree is the oracle's tree for that k, labels through the host routine
+    sub = p[:1500]
+    t = hip.hdbscan_mst(torch.from_numpy(sub).cuda(), 7)
+    ra, rb, rw, rc = oh.mst(sub, 7)
+    lo = np.minimum(t["a"].cpu().numpy(), t["b"].cpu().numpy()).astype(np.int64)
+    hi = np.maximum(t["a"].cpu().numpy(), t["b"].cpu().numpy()).astype(np.int64)
+    o = np.lexsort((hi, lo))
+    assert np.array_equal(lo[o], ra) and np.array_equal(hi[o], rb) and np.array_equal(t["w2"].cpu().numpy()[o], rw)
+    got = hip.hdbscan(sub, 25, min_samples=7)
+    assert np.array_equal(got, hip.labels_from_mst(ra, rb, np.sqrt(rw), len(sub), 25))
+    from sklearn.cluster import HDBSCAN
+    ref = HDBSCAN(min_cluster_size=25, min_samples=7, leaf_size=100).fit(sub.astype(np.float64)).labels_
+    assert _partition_mismatch(got, ref) <= 0.01 * len(sub)
+
+
+@gpu
+def test_gpu_frame_pairs_cli_clusters_and_registers(tmp_path, capsys):
+    """python -m icp_flow_amd.frame_pairs DIR --cluster hdbscan on two unlabelled copies of the demo frame pair."""
+    import json
+    from icp_flow_amd import frame_pairs
+    g = load_golden("g8_demo")
+    fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], None, None, None, g["gt_flow"])
+    for k in range(2):
+        frame_pairs.save_frame_pair(str(tmp_path / f"f{k}.npz"), fp)
+    frame_pairs.main([str(tmp_path), "--max-points", "2048", "--cluster", "hdbscan", "--min-cluster-size", "20",
+                      "--num-clusters", "200"])
+    s = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert s["frame_pairs"] == 2 and s["evaluated_points"] == 2 * len(g["gt_flow"])
+    assert abs(s["epe"] - float(g["epe"])) < 5e-3 and s["ms_per_frame_pair"] > 0
