@@ -692,3 +692,37 @@ def test_full_size_registration_recovers_motion(config2):
     want = rp.hist_icp(a, C(S[:4]), C(D[:4]), max_iterations=50).numpy()
     got = utils_match.hist_icp(a, G(S[:4]), G(D[:4])).cpu().numpy()
     assert_pose_close(got, want, S[:4])
+
+
+def test_full_size_init_pose_pick_is_the_argmin_of_all_six_scores(config2):
+    """BASELINE config 2 size: the branch-and-bound scoring picks the candidate a plain evaluation of ALL twelve
+    means picks (torch ops on the device: exact fp32 differences, every scan to the end), for every pair whose
+    two best scores are not within rounding of each other."""
+    S, D, _ = config2
+    a = rp.default_args()
+    ex, ey, ez = utils_hist.bin_edges(a)
+    nb = 64
+    s, d = G(S[:nb]), G(D[:nb])
+    T = utils_hist.estimate_init_pose(a, s, d)
+    h = hip_hist.hist(d, s, ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), len(ex), len(ey), len(ez))
+    _, idx = utils_hist.topk_nms(h)
+    H, W, Dz = len(ex), len(ey), len(ez)
+    exd, eyd, ezd = ex.to(DEV), ey.to(DEV), ez.to(DEV)
+    t = torch.stack([exd[idx // Dz // W % H], eyd[idx // Dz % W], ezd[idx % Dz]], dim=-1)      # utils_hist.py:78
+    t = torch.cat([t, t.new_zeros(nb, 1, 3)], dim=1)                                            # + zero translation
+    scores = torch.empty(nb, 6, device=DEV)
+    for k in range(6):
+        moved = s[:, :, 0:3] + t[:, k, None, :]
+        diff = moved[:, :, None, :] - d[:, None, :, 0:3]
+        d2 = diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1] + diff[..., 2] * diff[..., 2]
+        fwd = d2.min(dim=2).values.sqrt().mean(dim=1)
+        bwd = d2.min(dim=1).values.sqrt().mean(dim=1)
+        scores[:, k] = torch.minimum(fwd, bwd)
+    best2 = scores.topk(2, dim=1, largest=False).values
+    clear = (best2[:, 1] - best2[:, 0]) > 1e-5 * best2[:, 1]
+    pick = scores.argmin(dim=1)
+    want = t[torch.arange(nb, device=DEV), pick]
+    assert int(clear.sum()) >= nb * 3 // 4
+    assert torch.equal(T[clear][:, 0:3, 3], want[clear])
+    eye = torch.eye(3, device=DEV).expand(nb, 3, 3)
+    assert torch.equal(T[:, 0:3, 0:3], eye)
