@@ -132,9 +132,26 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
             double f0 = 0.0;
             for (int q = 0; q < p.qblocks; ++q) f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
             const float bound = (float)f0 / na;
+            if (p.prune == 2) {
+                // third launch: the backward scan of candidate 0.  score_0 = min(forward, backward) <= bound, and
+                // candidate 0 wins ties (first arg-min): when every other candidate's score -- known by now, exact
+                // wherever it is not +inf -- exceeds the bound, candidate 0 is the pick whatever this scan finds
+                bool othersOut = true;
+                for (int k = 1; k < 6; ++k) {
+                    double fk = 0.0, bk = 0.0;
+                    for (int q = 0; q < p.qblocks; ++q) {
+                        fk += p.partial[((size_t)(b * 12 + 2 * k) * p.qblocks + q) * kPartial];
+                        bk += p.partial[((size_t)(b * 12 + 2 * k + 1) * p.qblocks + q) * kPartial];
+                    }
+                    const float sk = fminf((float)fk / na, (float)bk / nc);
+                    othersOut = othersOut && (sk > bound * 1.0001f);   // NaN keeps the candidate in
+                }
+                leave = othersOut ? 1 : 0;
+            } else {
             const double seen = __hip_atomic_load(p.accum + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float low = (float)(seen / (double)((sub & 1) ? nc : na));
             leave = low > bound * 1.0001f ? 1 : 0;   // NaN / inf bounds never prune
+            }
             if (leave) {
                 double *o = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
                 o[0] = __builtin_huge_val();
@@ -536,7 +553,7 @@ hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA
 }
 
 // The same twelve scans per pair with branch and bound: the forward scan of candidate 0 (the highest peak of
-// the vote) runs to the end first; the other eleven scans run in query blocks of 128 rows, each block leaving at once
+// the vote) runs to the end first; the scans of the other five candidates run in query blocks of 128 rows, each block leaving at once
 // when the blocks before it have already summed more than candidate 0's score allows (see nn_scan_kernel).
 constexpr int kScoreSplit = 2;   // 128-row blocks (64-row blocks measured slower: every block stages the whole target cloud)
 int score_qblocks(int maxRows) { return (maxRows + kScanBlock / kScoreSplit - 1) / (kScanBlock / kScoreSplit); }
@@ -555,7 +572,11 @@ hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_
     p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
     hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) / 8) * 8 * p.qblocks)),
                        dim3(kScanBlock), 0, s, p);
-    p.njobs = B * 11; p.subBegin = 1; p.subCount = 11; p.prune = 1;
+    p.njobs = B * 10; p.subBegin = 2; p.subCount = 10; p.prune = 1;
+    hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) & ~7) * p.qblocks)),
+                       dim3(kScanBlock), 0, s, p);
+    // candidate 0's backward scan last: it only matters when some other candidate survived the bound
+    p.njobs = B; p.subBegin = 1; p.subCount = 1; p.prune = 2;
     hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) & ~7) * p.qblocks)),
                        dim3(kScanBlock), 0, s, p);
     return hipGetLastError();
