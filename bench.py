@@ -148,9 +148,17 @@ def main():
 
     extras = {}
     if not a.no_extras and world == 1:   # single-GPU runs only: the N > 1 runs measure scaling, nothing else
-        extras = extra_measurements(args, src, dst, T, dev, a)
+        try:
+            extras = extra_measurements(args, src, dst, T, dev, a)
+        except Exception as e:               # the headline line must survive a failing side measurement
+            extras = {"error": repr(e)}
 
-    cpu = cpu_baseline(S, D, a) if (a.cpu_pairs > 0 and world == 1) else None
+    cpu = None
+    if a.cpu_pairs > 0 and world == 1:
+        try:
+            cpu = cpu_baseline(S, D, a)
+        except Exception as e:                   # e.g. no C compiler for the oracle on this box
+            cpu = {"value": None, "unit": "registrations/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
 
     out = {
         "metric": "cluster-pair ICP registrations/sec", "value": round(value, 2), "unit": "registrations/s",
