@@ -44,3 +44,9 @@ print("sweep vs oracle fp32   :", np.round(disp(hR, hT, o32.R.numpy(), o32.T.num
 print("sweep vs oracle kabsch64:", np.round(disp(hR, hT, o64.R.numpy(), o64.T.numpy()), 5).tolist())
 print("oracle fp32 vs kabsch64 :", np.round(disp(o32.R.numpy(), o32.T.numpy(), o64.R.numpy(), o64.T.numpy()), 5).tolist())
 print("sweep vs scan          :", np.round(disp(hR, hT, res["scan"].RTs.R.cpu().numpy(), res["scan"].RTs.T.cpu().numpy()), 7).tolist())
+# inliers of the oracle's final state (gate d^2 <= thres^2): fewer than three leave the rotation undetermined
+Xt = o64.Xt
+for b in range(B):
+    v = moved[b, :, 3] > 0; w = C[b, :, 3] > 0
+    d2 = ((Xt[b, v, None, :3] - C[b, None, w, :3]) ** 2).sum(-1).min(1).values
+    print("pair", b, "inliers at the end", int((d2 <= np.float32(0.1 * 0.1)).sum()), "of", int(v.sum()))

@@ -1,7 +1,7 @@
 """Developer check: the fused registration against the oracle on many random ragged batches.  Initial poses must be
 identical; the ICP from the common initial pose is compared on the pairs on which the oracle itself is stable (its
-fp32 evaluation and the evaluation with an fp64 Kabsch step agree to 1e-5 m: pairs with fewer than three inliers or
-a flipping gate decision are not a meaningful expectation); then the whole hist_icp on those pairs.
+fp32 evaluation and the evaluation with an fp64 Kabsch step agree to 1e-5 m and at least three neighbours pass the
+gate at the end: a flipping gate decision or an undetermined rotation is not a meaningful expectation); then the whole hist_icp on those pairs.
 A pair may still differ by a millimetre: clusters sit tens of metres from the origin, so rotations that agree to 1e-7
 move a point by micrometres, and a neighbour within that of the 0.1 m gate changes sides (all three HIP search modes
 then agree with each other bit for bit: tools/dbg/registration_case.py).  Seen on about 1 pair in 200."""
@@ -47,6 +47,10 @@ for trial in range(trials):
         p = moved[b, v, :3].double().numpy()
         all_pairs += 1
         if o32.iterations != o64.iterations or disp(p, o32.R[b].numpy(), o32.T[b].numpy(), o64.R[b].numpy(), o64.T[b].numpy()) > 1e-5:
+            continue
+        w = C[b, :, 3] > 0   # fewer than three gated neighbours at the end: the rotation is not determined (DESIGN 4.6 ii)
+        d2 = ((o64.Xt[b, v, None, :3] - C[b, None, w, :3]) ** 2).sum(-1).min(1).values
+        if int((d2 <= np.float32(0.1 * 0.1)).sum()) < 3:
             continue
         stable_pairs += 1
         e = disp(p, hR[b], hT[b], o64.R[b].numpy(), o64.T[b].numpy())
