@@ -89,15 +89,16 @@ def main():
     for _ in range(a.warmup):
         step()
     # ---- timed region: exactly K steps, HIP-event timing of the dominant kernel inside ------
-    _lib.profile_enable(a.steps * a.iters)
+    prof = _lib.Profile(a.steps * a.iters)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        T, iters = step()
+    with _lib.options(profile=prof):
+        for _ in range(a.steps):
+            T, iters = step()
     sync()
     dt = time.perf_counter() - t0
-    icp_ms, icp_launches = _lib.profile_collect()
-    _lib.profile_enable(0)
+    icp_ms, icp_launches = prof.collect()
+    prof.close()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -198,10 +199,9 @@ def extra_measurements(args, src, dst, T, dev, a):
     out = {"match_eval_ms_per_batch": round(timeit(lambda: utils_match.match_eval(args, src, dst, T)), 4)}
     # the same registration with the ICP loop's correspondence search forced to the all-pairs LDS scan
     # (the north star's brute-force formulation; identical results)
-    _lib.set_icp_search("scan")
-    ms = timeit(lambda: utils_match.hist_icp(args, src, dst), reps=5)
+    with _lib.options(search="scan"):
+        ms = timeit(lambda: utils_match.hist_icp(args, src, dst), reps=5)
     out["all_pairs_scan_search_registrations_per_s"] = round(B / ms * 1e3, 1)
-    _lib.set_icp_search("auto")
     fast = SimpleNamespace(**{**vars(args), "icp_stop_mode": "per_pair"})
     ms = timeit(lambda: utils_match.hist_icp(fast, src, dst))
     out["per_pair_stop_registrations_per_s"] = round(B / ms * 1e3, 1)

@@ -1,14 +1,10 @@
-"""Importable alias of the `icp-flow_amd/` package directory.
+"""icp_flow_amd -- MI355X-native drop-in for ICP-Flow's cluster-pair registration
+hot path (utils_hist / utils_icp / utils_match of yanconglin/ICP-Flow).
 
-The product lives in `icp-flow_amd/` (a name Python cannot import because of the
-dash); this shim makes it importable as `icp_flow_amd` by pointing the package
-search path at that directory and executing its __init__.
+Device work is done by hand-written HIP kernels for gfx950 behind a C ABI
+(`include/icpflow_hip.h`, built into `icp_flow_amd/libicpflow_hip.so`); this
+package is the thin Python host side that mirrors the reference's function
+names.  There is NO CPU fallback: importing the operator modules without the
+HIP library raises.
 """
-import os as _os
-
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
-                      "icp-flow_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+__version__ = "0.1.0"

@@ -1,0 +1,215 @@
+"""ctypes binding of libicpflow_hip.so (C ABI: include/icpflow_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing this module raises at
+import, and every wrapper refuses non-GPU tensors.  torch is used only as the
+owner of device memory and of the current HIP stream.
+"""
+import contextlib
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# ICPFLOW_HIP_LIB: developer override to load an instrumented build of the same ABI
+LIB_PATH = os.environ.get("ICPFLOW_HIP_LIB") or os.path.join(_HERE, "libicpflow_hip.so")
+
+STOP_REFERENCE = 0
+STOP_PER_PAIR = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python icp_flow_amd/build.py` "
+        "(hipcc --offload-arch=gfx950).  icp_flow_amd has no CPU fallback.")
+
+_L = ctypes.CDLL(LIB_PATH)
+
+_f = ctypes.c_float
+_d = ctypes.c_double
+_i = ctypes.c_int
+_p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/icpflow_hip.h declares
+SIGNATURES = {
+    "icpflow_version": (_i, []),
+    "icpflow_last_error": (ctypes.c_char_p, []),
+    "icpflow_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "icpflow_hist_vote": (_i, [_p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _p, _p]),
+    "icpflow_hist_peaks": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "icpflow_nn_batch": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
+    "icpflow_transform_points": (_i, [_p, _p, _i, _i, _p, _p]),
+    "icpflow_count_valid": (_i, [_p, _i, _i, _p, _p]),
+    "icpflow_build_info": (ctypes.c_char_p, []),
+    "icpflow_estimate_init_pose": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _p, _p, _sz, _p, _p]),
+    "icpflow_icp": (_i, [_p, _p, _p, _i, _i, _d, _i, _d, _i, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_apply_icp": (_i, [_p, _p, _p, _i, _i, _d, _i, _d, _i, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_hist_icp": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_match_eval": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_gather_pad": (_i, [_p, _p, _i, _i, _p, _p]),
+    "icpflow_gather_segments": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
+    "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "icpflow_flow_rigid": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
+    "icpflow_dbscan_workspace_bytes": (_sz, [_i]),
+    "icpflow_dbscan": (_i, [_p, _i, _p, _i, _d, _i, _p, _p, _p, _p, _sz, _p]),
+    "icpflow_hdbscan_mst_workspace_bytes": (_sz, [_i]),
+    "icpflow_hdbscan_mst": (_i, [_p, _i, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "icpflow_hdbscan_labels": (_i, [_p, _p, _p, _i, _i, _p]),
+    "icpflow_selftest_vote_quotient": (_i, [_p, _i, _f, _f, _p, _p, _p]),
+    "icpflow_profile_create": (_i, [_i, ctypes.POINTER(_p)]),
+    "icpflow_profile_collect": (_i, [_p, ctypes.POINTER(_d), ctypes.POINTER(_i)]),
+    "icpflow_profile_destroy": (_i, [_p]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_L, _name)          # AttributeError here = header/library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+VERSION = int(_L.icpflow_version())
+BUILD_INFO = _L.icpflow_build_info().decode()
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise RuntimeError with the library's message."""
+    rc = getattr(_L, name)(*args)
+    if rc != 0:
+        msg = _L.icpflow_last_error()
+        raise RuntimeError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+SEARCH_AUTO, SEARCH_SCAN, SEARCH_GRID, SEARCH_SWEEP = 0, 1, 2, 3
+ARITH_FP64, ARITH_FP32_REFERENCE = 0, 1
+# developer switches (include/icpflow_hip.h ICPFLOW_OPT_*): each turns one optimisation off, results identical
+OPT_FLAGS = {"no_sorted_vote": 1 << 0, "no_side_stream": 1 << 1, "no_eval_sweep": 1 << 2, "no_check_sweep": 1 << 3,
+             "no_score_sweep": 1 << 4, "no_score_prune": 1 << 5, "no_teams": 1 << 6, "no_speculative": 1 << 7}
+
+
+class Options(ctypes.Structure):
+    """icpflow_options_t: the per-call options of the fused entry points."""
+    _fields_ = [("struct_size", _sz), ("icp_search", _i), ("icp_arith", _i), ("flags", ctypes.c_uint),
+                ("profile", _p), ("d_vote_bins_u32", _p)]
+
+
+class Profile:
+    """icpflow_profile_t: HIP-event recorder of the ICP-iteration kernel's launches (owned by the caller)."""
+
+    def __init__(self, capacity):
+        self._h = _p()
+        call("icpflow_profile_create", int(capacity), ctypes.byref(self._h))
+
+    def collect(self):
+        """-> (summed duration in ms, number of launches); re-arms the recorder."""
+        ms, n = _d(0.0), _i(0)
+        call("icpflow_profile_collect", self._h, ctypes.byref(ms), ctypes.byref(n))
+        return float(ms.value), int(n.value)
+
+    def close(self):
+        if self._h:
+            _L.icpflow_profile_destroy(self._h)
+            self._h = _p()
+
+    __del__ = close
+
+
+_tls = threading.local()   # the options in force on THIS host thread (nothing process-global)
+
+
+def _env_default_flags():
+    """Developer convenience: ICPFLOW_<SWITCH>=1 in the environment turns that optimisation off for every call
+    that does not say otherwise (parsed here, on the Python side; the library itself reads no environment)."""
+    f = 0
+    for name, bit in OPT_FLAGS.items():
+        if os.environ.get("ICPFLOW_" + name.upper(), "0") not in ("0", ""):
+            f |= bit
+    return f
+
+
+_DEFAULT_FLAGS = _env_default_flags()
+
+
+def _current():
+    return getattr(_tls, "stack", None) or [dict(search=0, arith=0, flags=_DEFAULT_FLAGS, profile=None, vote_bins=None)]
+
+
+@contextlib.contextmanager
+def options(search=None, arith=None, profile=None, vote_bins=None, **switches):
+    """Per-call options for every wrapper invoked inside the `with` block on this thread.
+    search: 'auto' | 'scan' | 'grid' | 'sweep';  arith: 'fp64' | 'fp32_reference';  profile: a Profile;
+    vote_bins: uint32 device tensor [B, Lx*Ly*Lz] receiving the fused vote's bins;  switches: no_teams=True ..."""
+    cur = dict(_current()[-1])
+    if search is not None:
+        cur["search"] = {"auto": 0, "scan": 1, "grid": 2, "sweep": 3}.get(search, search)
+    if arith is not None:
+        cur["arith"] = {"fp64": 0, "fp32_reference": 1}.get(arith, arith)
+    if profile is not None:
+        cur["profile"] = profile
+    if vote_bins is not None:
+        cur["vote_bins"] = vote_bins
+    for k, v in switches.items():
+        cur["flags"] = (cur["flags"] | OPT_FLAGS[k]) if v else (cur["flags"] & ~OPT_FLAGS[k])
+    stack = getattr(_tls, "stack", None)
+    if stack is None:
+        stack = _tls.stack = []
+    stack.append(cur)
+    try:
+        yield
+    finally:
+        stack.pop()
+
+
+def opt():
+    """ctypes pointer to the icpflow_options_t in force on this thread (NULL = library defaults)."""
+    cur = _current()[-1]
+    if cur["search"] == 0 and cur["arith"] == 0 and cur["flags"] == 0 and cur["profile"] is None and cur["vote_bins"] is None:
+        return None
+    o = Options(ctypes.sizeof(Options), int(cur["search"]), int(cur["arith"]), int(cur["flags"]),
+                cur["profile"]._h if cur["profile"] is not None else None,
+                ctypes.c_void_p(cur["vote_bins"].data_ptr()) if cur["vote_bins"] is not None else None)
+    _tls.last = o          # keep the struct alive until this thread builds the next one
+    return ctypes.cast(ctypes.pointer(o), _p)
+
+
+def workspace_bytes(B, N, lens=(0, 0, 0)):
+    return int(_L.icpflow_workspace_bytes(int(B), int(N), int(lens[0]), int(lens[1]), int(lens[2])))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError("icp_flow_amd: input must be a GPU (HIP) tensor -- there is no CPU path "
+                               "(the reference refuses CPU tensors too, hist_cuda/cpp/hist.cpp:22)")
+
+
+def cloud(t, name="cloud"):
+    """Validate a [B,N,4] float32 cloud; returns it contiguous."""
+    require_gpu(t)
+    if t.dim() != 3 or t.shape[2] != 4:
+        raise RuntimeError(f"{name}: expected shape [B,N,4] (x,y,z,flag), got {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(device, nbytes):
+    """A cached, grow-only scratch buffer per (device, current stream): calls issued on different streams
+    may overlap on the GPU and must not share scratch (torch caching-allocator owned)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -34,15 +34,24 @@ int hipfail(hipError_t e, const char *what)
         if (e__ != hipSuccess) return hipfail(e__, #expr); \
     } while (0)
 
-// ICP correspondence search: 0 = auto, 1 = all-pairs LDS scan, 2 = exact hashed grid,
-// 3 = sorted sweep (icp.hip)
-int g_icp_search = 0;
-int g_side_stream = 1;   // developer knob (ICPFLOW_SIDE_STREAM=0: everything on the caller's stream)
-int g_eval_sweep = 1;    // developer knob (ICPFLOW_EVAL_SWEEP=0 selects the all-pairs match_eval scans)
-int g_check_sweep = 1;   // developer knob (ICPFLOW_CHECK_SWEEP=0 selects the all-pairs roll-back check)
-int g_score_sweep = 1;   // developer knob (ICPFLOW_SCORE_SWEEP=0 selects the all-pairs scoring scan)
-int g_score_prune = 1;   // developer knob (ICPFLOW_SCORE_PRUNE=0: every scoring scan runs to the end)
-int g_hist_sorted = 1;   // developer knob (ICPFLOW_HIST_SORTED=0 selects the all-pairs vote)
+// The options of one call (icpflow_options_t, validated): nothing here outlives the call.
+struct Opts {
+    int search = ICPFLOW_SEARCH_AUTO;
+    int arith = ICPFLOW_ARITH_FP64;
+    unsigned flags = 0u;
+    LaunchProfile *profile = nullptr;
+    uint32_t *voteBins = nullptr;
+    bool on(unsigned offFlag) const { return (flags & offFlag) == 0u; }
+    IcpOpts icp() const
+    {
+        IcpOpts o;
+        o.arith = arith;
+        o.teams = on(ICPFLOW_OPT_NO_TEAMS);
+        o.speculative = on(ICPFLOW_OPT_NO_SPECULATIVE);
+        o.profile = profile;
+        return o;
+    }
+};
 
 // the scoring sweep prunes by the largest NN distance inside a wave: it pays on large clusters (real
 // data, hundreds of queries per metre along the sort axis), not on ~1000-point vehicles
@@ -131,14 +140,35 @@ struct Workspace {
     }
 };
 
-const GridScratch *search_scratch(Workspace &w, int N)
+const GridScratch *search_scratch(Workspace &w, int N, const Opts &o)
 {
-    int mode = g_icp_search;
+    int mode = o.search;
+    if (o.arith == ICPFLOW_ARITH_FP32_REFERENCE) mode = 1;   // the study mode is written for the all-pairs search
     if (mode == 0) mode = (N >= 64 && N <= kMaxSortN) ? 3 : 1;
     if (mode == 3 && N > kMaxSortN) mode = 1;   // the bitonic sort holds (key, index) pairs in LDS
     if (mode == 1) return nullptr;
     w.grid.mode = mode;
     return &w.grid;
+}
+
+// -> 0 and `o` filled, or an argument error
+int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
+{
+    if (opt == nullptr) return 0;
+    if (opt->struct_size != sizeof(icpflow_options_t))
+        return fail(ICPFLOW_E_ARG, "%s: options struct_size %zu, this library expects %zu", fn, opt->struct_size,
+                    sizeof(icpflow_options_t));
+    if (opt->icp_search < 0 || opt->icp_search > 3)
+        return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
+    if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
+        return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
+    if (opt->flags >> 8) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    o.search = opt->icp_search;
+    o.arith = opt->icp_arith;
+    o.flags = opt->flags;
+    o.profile = reinterpret_cast<LaunchProfile *>(opt->profile);
+    o.voteBins = opt->d_vote_bins_u32;
+    return 0;
 }
 
 int check_ws(void *ws, size_t have, size_t need)
@@ -174,6 +204,13 @@ struct SideStream {
     hipEvent_t fork = nullptr, join = nullptr;
     int device = -1;
     bool ok = false;
+    void destroy()   // (on the device the objects were created on; errors are moot at this point)
+    {
+        if (stream) (void)hipStreamDestroy(stream);
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        stream = nullptr; fork = join = nullptr; ok = false;
+    }
     void create()
     {
         ok = hipGetDevice(&device) == hipSuccess &&
@@ -189,23 +226,34 @@ SideStream &side_stream()
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { s.ok = false; return s; }
     if (s.device != dev) {   // first use on this thread, or the thread moved to another GPU
+        s.destroy();
         s = SideStream{};
         s.create();
     }
     return s;
 }
 
+// Joins the side stream back into the caller's stream when a fused entry point leaves early through an
+// error path: without it the side work would still be writing into the caller's workspace after the
+// call has returned, and a capturing caller would be left with a dangling fork.
+struct JoinGuard {
+    hipStream_t s = nullptr;
+    hipEvent_t join = nullptr;
+    ~JoinGuard() { if (join != nullptr) (void)hipStreamWaitEvent(s, join, 0); }
+    void joined() { join = nullptr; }
+};
+
 // shared tail of apply_icp / hist_icp: ICP from Tinit, compose, check, select
 int run_icp_and_select(const float *src, const float *dst, Workspace &w, const uint8_t *swap,
                        const float *init, int B, int N, double thres, int maxIter, double relThr,
-                       int stopMode, int invertSwapped, float *Tout, int32_t *iters, hipStream_t s)
+                       int stopMode, int invertSwapped, float *Tout, int32_t *iters, const Opts &o, hipStream_t s)
 {
-    const GridScratch *search = search_scratch(w, N);
+    const GridScratch *search = search_scratch(w, N, o);
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, search, w.history, &w.team, s));
+                           w.state, w.ctrl, search, w.history, &w.team, o.icp(), s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s, w.ctrl, iters));   // also reports the iteration count
     // roll-back check: sweeps over the sorted clouds the ICP left behind, or the all-pairs scan
-    if (search != nullptr && search->mode == 3 && g_check_sweep) {
+    if (search != nullptr && search->mode == 3 && o.on(ICPFLOW_OPT_NO_CHECK_SWEEP)) {
         ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
         ICPFLOW_TRY(launch_select(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, init, w.M, B, invertSwapped,
                                   Tout, s));
@@ -220,22 +268,25 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
 // joinBefore (hist_icp): event after which the side stream has both clouds sorted (w.grid.presorted)
 int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_t *swap, int B,
                   int N, const float *ex, int lx, const float *ey, int ly, const float *ez, int lz,
-                  float shift, float *Tout, hipStream_t s, hipEvent_t joinBefore = nullptr)
+                  float shift, float *Tout, const Opts &o, hipStream_t s, hipEvent_t joinBefore = nullptr)
 {
     const int lens[3] = {lx, ly, lz};
     // vote with X = dst role, Y = src role (utils_hist.py:69); z-sorted sweep while the sort fits LDS
     // (N <= 16384), all-pairs otherwise -- identical bins either way
-    if (N <= kMaxSortN && g_hist_sorted)
+    if (N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE))
         ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.zsortC,
                                             w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s));
     else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
+    if (o.voteBins != nullptr)   // debug export of the bins the peak search is about to read
+        ICPFLOW_TRY(hipMemcpyAsync(o.voteBins, w.bins, (size_t)B * lx * ly * lz * sizeof(uint32_t),
+                                   hipMemcpyDeviceToDevice, s));
     PeakDecode dec;
     dec.ex = ex; dec.ey = ey; dec.ez = ez; dec.shift = shift; dec.cand = w.cand;   // peaks -> 6 candidate translations
     ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,
                                       w.peakVotes, w.peakIdx, s, dec));
     // candidate scoring: sorted sweep while the sort fits LDS, all-pairs scan otherwise (same sums)
-    if (N > kScoreSweepMinN && N <= kMaxSortN && g_score_sweep) {
+    if (N > kScoreSweepMinN && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SCORE_SWEEP)) {
         if (joinBefore != nullptr) {
             ICPFLOW_TRY(hipStreamWaitEvent(s, joinBefore, 0));
         } else if (!w.grid.presorted) {
@@ -244,7 +295,7 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
         }
         ICPFLOW_TRY(launch_sweep_score(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
         ICPFLOW_TRY(launch_score_pick(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
-    } else if (g_score_prune) {
+    } else if (o.on(ICPFLOW_OPT_NO_SCORE_PRUNE)) {
         ICPFLOW_TRY(launch_scan_score_pruned(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s));
         ICPFLOW_TRY(launch_score_pick(w.partial, score_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
     } else {
@@ -258,30 +309,12 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
 
 extern "C" {
 
-int icpflow_version(void)
-{
-    static bool once = false;
-    if (!once) {
-        once = true;
-        const char *e = getenv("ICPFLOW_HIST_SORTED");
-        if (e && e[0] == '0') g_hist_sorted = 0;
-        e = getenv("ICPFLOW_SIDE_STREAM");
-        if (e && e[0] == '0') g_side_stream = 0;
-        e = getenv("ICPFLOW_EVAL_SWEEP");
-        if (e && e[0] == '0') g_eval_sweep = 0;
-        e = getenv("ICPFLOW_CHECK_SWEEP");
-        if (e && e[0] == '0') g_check_sweep = 0;
-        e = getenv("ICPFLOW_SCORE_SWEEP");
-        if (e && e[0] == '0') g_score_sweep = 0;
-        e = getenv("ICPFLOW_SCORE_PRUNE");
-        if (e && e[0] == '0') g_score_prune = 0;
-        e = getenv("ICPFLOW_ICP_TEAMS");
-        if (e && e[0] == '0') icpflow::g_icp_teams = 0;
-        e = getenv("ICPFLOW_ICP_SPECULATIVE");
-        if (e && e[0] == '0') icpflow::g_icp_speculative = 0;
-    }
-    return ICPFLOW_VERSION;
-}
+int icpflow_version(void) { return ICPFLOW_VERSION; }
+
+#ifndef ICPFLOW_SOURCE_HASH
+#define ICPFLOW_SOURCE_HASH "unknown"
+#endif
+const char *icpflow_build_info(void) { return ICPFLOW_SOURCE_HASH; }
 
 const char *icpflow_last_error(void) { return g_err; }
 
@@ -292,23 +325,27 @@ size_t icpflow_workspace_bytes(int B, int N, int Lx, int Ly, int Lz)
     return Workspace(nullptr, B, N, L).bytes;
 }
 
-int icpflow_set_icp_search(int mode)
+int icpflow_profile_create(int capacity, icpflow_profile_t **out)
 {
-    if (mode < 0 || mode > 3) return fail(ICPFLOW_E_ARG, "icpflow_set_icp_search: mode must be 0..3 (got %d)", mode);
-    g_icp_search = mode;
+    if (out == nullptr) return fail(ICPFLOW_E_ARG, "icpflow_profile_create: null pointer");
+    if (capacity < 0 || capacity > (1 << 20)) return fail(ICPFLOW_E_ARG, "icpflow_profile_create: bad capacity %d", capacity);
+    hipError_t e = hipSuccess;
+    LaunchProfile *p = profile_create(capacity, &e);
+    if (p == nullptr) return hipfail(e, "icpflow_profile_create");
+    *out = reinterpret_cast<icpflow_profile_t *>(p);
     return 0;
 }
 
-int icpflow_profile_enable(int capacity)
+int icpflow_profile_collect(icpflow_profile_t *profile, double *total_ms, int *launches)
 {
-    if (capacity < 0 || capacity > (1 << 20)) return fail(ICPFLOW_E_ARG, "icpflow_profile_enable: bad capacity %d", capacity);
-    ICPFLOW_TRY(profile_enable(capacity));
+    if (profile == nullptr) return fail(ICPFLOW_E_ARG, "icpflow_profile_collect: null recorder");
+    ICPFLOW_TRY(profile_collect(reinterpret_cast<LaunchProfile *>(profile), total_ms, launches));
     return 0;
 }
 
-int icpflow_profile_collect(double *total_ms, int *launches)
+int icpflow_profile_destroy(icpflow_profile_t *profile)
 {
-    ICPFLOW_TRY(profile_collect(total_ms, launches));
+    profile_destroy(reinterpret_cast<LaunchProfile *>(profile));
     return 0;
 }
 
@@ -501,8 +538,10 @@ int icpflow_count_valid(const float *d_pts, int B, int N, int32_t *d_len, icpflo
 int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, int N,
                                const float *d_edges_x, int len_x, const float *d_edges_y, int len_y,
                                const float *d_edges_z, int len_z, float decode_shift, float *d_T_out,
-                               void *d_ws, size_t ws_bytes, icpflow_stream_t stream)
+                               void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt)
 {
+    Opts o;
+    if (int r = parse_options("icpflow_estimate_init_pose", opt, o)) return r;
     if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
         return fail(ICPFLOW_E_ARG, "icpflow_estimate_init_pose: null pointer");
     if (int r = check_batch("icpflow_estimate_init_pose", B, N)) return r;
@@ -514,14 +553,16 @@ int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, in
     hipStream_t s = (hipStream_t)stream;
     launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s);
     return run_init_pose(d_src, d_dst, w, nullptr, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
-                         len_z, decode_shift, d_T_out, s);
+                         len_z, decode_shift, d_T_out, o, s);
 }
 
 int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int B, int N, double thres,
                 int max_iterations, double relative_rmse_thr, int stop_mode, float *d_R, float *d_T,
                 float *d_rmse, int32_t *d_iters, int32_t *d_converged, void *d_ws, size_t ws_bytes,
-                icpflow_stream_t stream)
+                icpflow_stream_t stream, const icpflow_options_t *opt)
 {
+    Opts o;
+    if (int r = parse_options("icpflow_icp", opt, o)) return r;
     if (!d_X || !d_Y) return fail(ICPFLOW_E_ARG, "icpflow_icp: null pointer");
     if (int r = check_batch("icpflow_icp", B, N)) return r;
     if (max_iterations <= 0 || max_iterations > kMaxIterCap)
@@ -533,7 +574,8 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     hipStream_t s = (hipStream_t)stream;
     launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
-                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N), w.history, &w.team, s));
+                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N, o), w.history, &w.team,
+                           o.icp(), s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
     return 0;
 }
@@ -541,8 +583,10 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
 int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_init, int B, int N,
                       double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
                       float *d_T_out, int32_t *d_iters, void *d_ws, size_t ws_bytes,
-                      icpflow_stream_t stream)
+                      icpflow_stream_t stream, const icpflow_options_t *opt)
 {
+    Opts o;
+    if (int r = parse_options("icpflow_apply_icp", opt, o)) return r;
     if (!d_src || !d_dst || !d_init || !d_T_out) return fail(ICPFLOW_E_ARG, "icpflow_apply_icp: null pointer");
     if (int r = check_batch("icpflow_apply_icp", B, N)) return r;
     if (max_iterations <= 0 || max_iterations > kMaxIterCap)
@@ -556,15 +600,17 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
     // d_T_out may alias d_init: keep a private copy of the init poses
     ICPFLOW_TRY(hipMemcpyAsync(w.Tinit, d_init, (size_t)B * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return run_icp_and_select(d_src, d_dst, w, nullptr, w.Tinit, B, N, thres_dist, max_iterations,
-                              relative_rmse_thr, stop_mode, 0, d_T_out, d_iters, s);
+                              relative_rmse_thr, stop_mode, 0, d_T_out, d_iters, o, s);
 }
 
 int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x,
                      int len_x, const float *d_edges_y, int len_y, const float *d_edges_z, int len_z,
                      float decode_shift, double thres_dist, int max_iterations, double relative_rmse_thr,
                      int stop_mode, float *d_T_out, int32_t *d_iters, void *d_ws, size_t ws_bytes,
-                     icpflow_stream_t stream)
+                     icpflow_stream_t stream, const icpflow_options_t *opt)
 {
+    Opts o;
+    if (int r = parse_options("icpflow_hist_icp", opt, o)) return r;
     if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
         return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: null pointer");
     if (int r = check_batch("icpflow_hist_icp", B, N)) return r;
@@ -581,32 +627,41 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s);   // lengths + swap, utils_match.py:139-146
     // the axis sort of both clouds (scoring sweep, ICP) runs on the side stream next to the vote
     hipEvent_t join = nullptr;
-    const GridScratch *search = search_scratch(w, N);
-    if (search != nullptr && search->mode == 3 && N >= 64 && g_side_stream) {
+    JoinGuard guard;   // every return below leaves the side stream joined into s
+    const GridScratch *search = search_scratch(w, N, o);
+    if (search != nullptr && search->mode == 3 && N >= 64 && o.on(ICPFLOW_OPT_NO_SIDE_STREAM)) {
         SideStream &side = side_stream();
         if (side.ok) {
             ICPFLOW_TRY(hipEventRecord(side.fork, s));
             ICPFLOW_TRY(hipStreamWaitEvent(side.stream, side.fork, 0));
-            ICPFLOW_TRY(launch_sort_clouds_soa(d_src, d_dst, w.lenA, w.lenC, w.swap, B, N, &w.grid, side.stream));
-            ICPFLOW_TRY(hipEventRecord(side.join, side.stream));
+            // from here on the side stream belongs to the caller's stream order (and capture): a failed
+            // launch still records the join so that the fork never dangles
+            const hipError_t se = launch_sort_clouds_soa(d_src, d_dst, w.lenA, w.lenC, w.swap, B, N, &w.grid, side.stream);
+            const hipError_t je = hipEventRecord(side.join, side.stream);
+            if (je == hipSuccess) { guard.s = s; guard.join = side.join; }
+            ICPFLOW_TRY(se);
+            ICPFLOW_TRY(je);
             w.grid.presorted = 1;
             join = side.join;
         }
     }
-    const bool sweepScore = N > kScoreSweepMinN && N <= kMaxSortN && g_score_sweep;
+    const bool sweepScore = N > kScoreSweepMinN && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SCORE_SWEEP);
     if (int r = run_init_pose(d_src, d_dst, w, w.swap, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
-                              len_z, decode_shift, w.Tinit, s, sweepScore ? join : nullptr))
+                              len_z, decode_shift, w.Tinit, o, s, sweepScore ? join : nullptr))
         return r;
     if (join != nullptr && !sweepScore) ICPFLOW_TRY(hipStreamWaitEvent(s, join, 0));
+    guard.joined();
     return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
-                              relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, s);
+                              relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s);
 }
 
 int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_T, int B, int N,
                        double thres_dist, float *d_errors, float *d_inliers, float *d_ratios,
                        float *d_ious, float *d_translations, float *d_rotations, void *d_ws,
-                       size_t ws_bytes, icpflow_stream_t stream)
+                       size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt)
 {
+    Opts o;
+    if (int r = parse_options("icpflow_match_eval", opt, o)) return r;
     if (!d_pcd1 || !d_pcd2 || !d_T || !d_errors || !d_inliers || !d_ratios || !d_ious || !d_translations ||
         !d_rotations)
         return fail(ICPFLOW_E_ARG, "icpflow_match_eval: null pointer");
@@ -616,7 +671,7 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
     hipStream_t s = (hipStream_t)stream;
     launch_count_pair(d_pcd1, d_pcd2, B, N, w.lenA, w.lenC, nullptr, s);
     // long clouds: both directions as sorted sweeps (the sort pays for itself above ~2000 points)
-    if (N > kScoreSweepMinN && N <= kMaxSortN && g_eval_sweep) {
+    if (N > kScoreSweepMinN && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_EVAL_SWEEP)) {
         ICPFLOW_TRY(launch_sort_clouds_soa(d_pcd1, d_pcd2, w.lenA, w.lenC, nullptr, B, N, &w.grid, s));
         ICPFLOW_TRY(launch_sweep_eval(&w.grid, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.zsortA, w.partial, s));
         ICPFLOW_TRY(launch_eval_epilogue(w.partial, sweep_qblocks(N), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,

@@ -6,7 +6,7 @@
 // neighbour (itself included) = core distance, then a minimum spanning tree of the complete graph under
 //     d_mreach(a, b) = max(core(a), core(b), |a - b|),
 // and only then the (cheap, sequential) dendrogram / condensed tree / cluster selection, which stays host
-// logic (icp-flow_amd/utils_cluster.py).  The pinned library builds the tree with an approximate dual-tree
+// logic (icp_flow_amd/utils_cluster.py).  The pinned library builds the tree with an approximate dual-tree
 // Boruvka; sklearn's port uses exact Prim, O(n^2) distance evaluations on one core.  Here: EXACT Boruvka.
 //
 //   * points are sorted by a uniform-grid cell key (x-major), so 64 consecutive rows ("chunk") are a compact

@@ -427,12 +427,8 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
     int NP2 = 64;
     while (NP2 < N) NP2 <<= 1;
     if ((size_t)NP2 * 8 > 64 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&zsort_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr = true;
-        }
+        static std::atomic<unsigned long long> attr{0ull};   // per device
+        ensure_dynamic_lds(reinterpret_cast<const void *>(&zsort_kernel), 128 * 1024, &attr);
     }
     if (N > kChunkSortMinN && ckey != nullptr) {   // long clouds: several workgroups per sort (sort.hip)
         hipError_t e = launch_zsort_chunked(X, Y, nX, nY, B, N, sortX, sortY, bins_u32, (int)L, ckey, cidx, ez, lens[2],
@@ -597,12 +593,8 @@ static hipError_t launch_peaks_t(const BinT *bins, int B, int Lx, int Ly, int Lz
 {
     const size_t lds = 3 * sizeof(uint32_t) * (size_t)Lx * Ly * Lz;
     if (lds <= 150 * 1024) {
-        static bool attr = false;   // dynamic LDS above 64 KiB needs the attribute once per kernel
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_peaks_kernel<BinT, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr = true;
-        }
+        static std::atomic<unsigned long long> attr{0ull};   // dynamic LDS above 64 KiB needs the attribute once per kernel and device
+        ensure_dynamic_lds(reinterpret_cast<const void *>(&hist_peaks_kernel<BinT, 1>), 150 * 1024, &attr);
         hipLaunchKernelGGL((hist_peaks_kernel<BinT, 1>), dim3(B), dim3(kPeakBlock), lds, s, bins, Lx, Ly, Lz, k,
                            (kernel_size - 1) / 2, wsA, wsB, votes, idx, dec);
     } else {

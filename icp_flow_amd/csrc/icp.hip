@@ -13,6 +13,7 @@
 // front; each pair that is not converged bumps ctrl->notconv[it]; the launch of iteration
 // it+1 returns immediately when notconv[it] == 0.  ICPFLOW_STOP_PER_PAIR loops inside one
 // launch and lets every pair stop on its own.
+#include <atomic>
 #include <vector>
 
 #include "scan.hpp"
@@ -330,8 +331,7 @@ __global__ __launch_bounds__(kGridBlock) void grid_build_kernel(
 // ones of the all-pairs search; equal-distance ties are resolved to the lowest ORIGINAL index.
 // ---------------------------------------------------------------------------------
 constexpr int kSortBlock = 1024;
-int g_icp_teams = 1;         // developer knob (ICPFLOW_ICP_TEAMS=0: always one workgroup per pair)
-int g_icp_speculative = 1;   // developer knob (api.hip: ICPFLOW_ICP_SPECULATIVE=0 forces one launch per iteration)
+static std::atomic<unsigned long long> g_sortAttr{0ull};   // devices on which sort_clouds_kernel has its dynamic-LDS opt-in
 
 // grid (B, 2): blockIdx.y == 0 sorts the fixed cloud, 1 the moving cloud (pre-pose applied)
 __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
@@ -1188,7 +1188,7 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
     }
     if (b == 0) {
         const int n = ctrl->iters;
-        if (iters) *iters = n;
+        if (iters) *iters = ctrl->error ? -1 : n;
         if (converged) {
             if (stopMode == ICPFLOW_STOP_REFERENCE_) *converged = (n > 0 && ctrl->notconv[n - 1] == 0) ? 1 : 0;
             else *converged = (ctrl->notconv[0] == 0) ? 1 : 0;
@@ -1267,13 +1267,9 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
 {
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
                        : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 : 0;
-    if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-            raised = true;
-        }
+    if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation and device
+        static std::atomic<unsigned long long> raised{0ull};
+        ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM>), 156 * 1024, &raised);
     }
     const int wgs = TEAM ? p.team.maxWG : B;
     hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID, TEAM>), dim3(wgs), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
@@ -1282,12 +1278,11 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
 // ---- optional per-launch timing of this (dominant) kernel with HIP events ---------------------
 // bench.py needs the average launch duration of the dominant kernel measured on the stream it
 // runs on; the events are recorded by the library because only it sees the individual launches.
-namespace {
+// The recorder is an object the caller owns (icpflow_profile_t) and passes with the call's options.
 struct LaunchProfile {
     std::vector<hipEvent_t> start, stop;
     int used = 0;
-} g_prof;
-}  // namespace
+};
 
 #ifdef ICPFLOW_PHASE_TIMING
 extern "C" int icpflow_debug_phase_stamps(long long *out16)
@@ -1300,43 +1295,75 @@ extern "C" int icpflow_debug_wave_stamps(long long *out256)
 }
 #endif
 
-hipError_t profile_enable(int capacity)
+LaunchProfile *profile_create(int capacity, hipError_t *err)
 {
-    for (hipEvent_t e : g_prof.start) (void)hipEventDestroy(e);
-    for (hipEvent_t e : g_prof.stop) (void)hipEventDestroy(e);
-    g_prof.start.clear(); g_prof.stop.clear(); g_prof.used = 0;
+    LaunchProfile *p = new LaunchProfile;
+    *err = hipSuccess;
     for (int i = 0; i < capacity; ++i) {
         hipEvent_t a, b;
         hipError_t e = hipEventCreate(&a);
-        if (e != hipSuccess) return e;
-        e = hipEventCreate(&b);
-        if (e != hipSuccess) return e;
-        g_prof.start.push_back(a); g_prof.stop.push_back(b);
+        if (e == hipSuccess) {
+            e = hipEventCreate(&b);
+            if (e != hipSuccess) (void)hipEventDestroy(a);
+        }
+        if (e != hipSuccess) { *err = e; profile_destroy(p); return nullptr; }
+        p->start.push_back(a); p->stop.push_back(b);
     }
-    return hipSuccess;
+    return p;
 }
 
-hipError_t profile_collect(double *total_ms, int *launches)
+void profile_destroy(LaunchProfile *p)
+{
+    if (p == nullptr) return;
+    for (hipEvent_t e : p->start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->stop) (void)hipEventDestroy(e);
+    delete p;
+}
+
+hipError_t profile_collect(LaunchProfile *p, double *total_ms, int *launches)
 {
     double sum = 0.0;
-    for (int i = 0; i < g_prof.used; ++i) {
-        hipError_t e = hipEventSynchronize(g_prof.stop[i]);
+    for (int i = 0; i < p->used; ++i) {
+        hipError_t e = hipEventSynchronize(p->stop[i]);
         if (e != hipSuccess) return e;
         float ms = 0.f;
-        e = hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]);
+        e = hipEventElapsedTime(&ms, p->start[i], p->stop[i]);
         if (e != hipSuccess) return e;
         sum += ms;
     }
     if (total_ms) *total_ms = sum;
-    if (launches) *launches = g_prof.used;
-    g_prof.used = 0;
+    if (launches) *launches = p->used;
+    p->used = 0;
     return hipSuccess;
 }
 
-static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
+int device_cus()
 {
-    const bool timed = g_prof.used < (int)g_prof.start.size();
-    if (timed) (void)hipEventRecord(g_prof.start[g_prof.used], s);
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    int c = cache[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 1;
+        cache[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
+void ensure_dynamic_lds(const void *func, int bytes, std::atomic<unsigned long long> *mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (mask->load(std::memory_order_acquire) & bit)) return;
+    (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev < 64) mask->fetch_or(bit, std::memory_order_release);
+}
+
+static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, LaunchProfile *prof, hipStream_t s)
+{
+    const bool timed = prof != nullptr && prof->used < (int)prof->start.size();
+    if (timed) (void)hipEventRecord(prof->start[prof->used], s);
     if (p.sortY != nullptr) {    // sorted sweep
         // one query per lane (Q = 1; two per lane on 8 waves measured 25 % slower at n = 1024): a wave's 64
         // consecutive sorted queries span the narrowest window;
@@ -1364,13 +1391,14 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
         else if (p.N <= 1024) launch_icp_variant<1024, 4, 4, 0>(p, B, itBegin, itEnd, s);  // 1024
         else launch_icp_variant<1024, 4, 2, 0>(p, B, itBegin, itEnd, s);                   // 2048 per pass
     }
-    if (timed) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
+    if (timed) (void)hipEventRecord(prof->stop[prof->used++], s);
 }
 
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      const GridScratch *grid, float *history, const IcpTeam *team, hipStream_t s)
+                      const GridScratch *grid, float *history, const IcpTeam *team, const IcpOpts &opts,
+                      hipStream_t s)
 {
     IcpParams p{};
     p.B = B;
@@ -1390,14 +1418,8 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     } else if (grid != nullptr && grid->mode == 3) {
         int NP2 = 64;
         while (NP2 < N) NP2 <<= 1;
-        if ((size_t)NP2 * 8 > 64 * 1024) {   // dynamic LDS above 64 KiB needs the attribute (N > 8192)
-            static bool attr = false;
-            if (!attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_clouds_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                attr = true;
-            }
-        }
+        if ((size_t)NP2 * 8 > 64 * 1024)   // dynamic LDS above 64 KiB needs the attribute (N > 8192)
+            ensure_dynamic_lds(reinterpret_cast<const void *>(&sort_clouds_kernel), 128 * 1024, &g_sortAttr);
         if (N > kChunkSortMinN && grid->ckey != nullptr) {   // long clouds: several workgroups per sort
             e = launch_sort_clouds_chunked(X, Y, lenX, lenY, swap, prePose, B, N, grid->axis, grid->sortX, grid->pts,
                                            grid->sortYsoa, nullptr, grid->ckey, grid->cidx, s);
@@ -1417,19 +1439,13 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.gridPts = (const float4 *)grid->pts; p.gridStart = grid->start; p.gridOrigin = grid->origin;
         p.gridH = grid->H; p.gridInvH = invh;
     }
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 1;
-    }
-    const bool speculative = stopMode == ICPFLOW_STOP_REFERENCE_ && history != nullptr && g_icp_speculative &&
+    const int cus = device_cus();
+    const bool speculative = stopMode == ICPFLOW_STOP_REFERENCE_ && history != nullptr && opts.speculative &&
                              maxIter > 1 && maxIter <= kHistIters;
     // Teams: with at most half of the CUs taken by one workgroup per pair, the spare CUs join the pairs
     // whose moving cloud needs several passes (real clusters, N > 1024).  Needs every workgroup of the
     // launch resident at once (members wait for each other): single-launch modes only.
-    if (team != nullptr && g_icp_teams && grid != nullptr && grid->mode == 3 && N > 1024 && 2 * B <= cus &&
+    if (team != nullptr && opts.teams && grid != nullptr && grid->mode == 3 && N > 1024 && 2 * B <= cus &&
         B <= 256 && (speculative || stopMode == ICPFLOW_STOP_PER_PAIR_)) {
         p.team = *team;
         p.team.maxWG = min(cus, team->maxWG);
@@ -1445,14 +1461,14 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         // Beyond kHistIters iterations: one launch per iteration.
         if (speculative) {
             p.history = history;
-            launch_icp_iters(p, B, 0, maxIter, s);
+            launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
             e = launch_icp_resolve_history(state, ctrl, history, B, maxIter, s);
             if (e != hipSuccess) return e;
         } else {
-            for (int it = 0; it < maxIter; ++it) launch_icp_iters(p, B, it, it + 1, s);
+            for (int it = 0; it < maxIter; ++it) launch_icp_iters(p, B, it, it + 1, opts.profile, s);
         }
     } else {
-        launch_icp_iters(p, B, 0, maxIter, s);
+        launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
     }
     return hipGetLastError();
 }
@@ -1464,14 +1480,8 @@ hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t 
 {
     int NP2 = 64;
     while (NP2 < N) NP2 <<= 1;
-    if ((size_t)NP2 * 8 > 64 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_clouds_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr = true;
-        }
-    }
+    if ((size_t)NP2 * 8 > 64 * 1024)
+        ensure_dynamic_lds(reinterpret_cast<const void *>(&sort_clouds_kernel), 128 * 1024, &g_sortAttr);
     if (N > kChunkSortMinN && grid->ckey != nullptr)   // long clouds: several workgroups per sort (sort.hip)
         return launch_sort_clouds_chunked(X, Y, lenX, lenY, swap, nullptr, B, N, grid->axis, grid->sortX, grid->pts,
                                           grid->sortYsoa, grid->sortXsoa, grid->ckey, grid->cidx, s);

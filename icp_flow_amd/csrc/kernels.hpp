@@ -2,6 +2,7 @@
 // libicpflow_hip.so (each .hip file owns its kernels; api.hip sequences them).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -136,16 +137,28 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
                        // (scoring sweep ran on this batch): the ICP applies the pre-pose when it loads
 };
 int grid_buckets(int N);
-extern int g_icp_speculative;
-extern int g_icp_teams;
+// per-call switches of the ICP launch (icpflow_options_t, include/icpflow_hip.h); nothing process-global
+struct LaunchProfile;   // icp.hip: HIP-event recorder behind icpflow_profile_t
+struct IcpOpts {
+    int arith = 0;                 // ICPFLOW_ARITH_*
+    bool teams = true;             // several workgroups per large pair when the batch leaves CUs idle
+    bool speculative = true;       // batch-global stop in ONE launch (false: one launch per iteration)
+    LaunchProfile *profile = nullptr;
+};
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
-                      const GridScratch *grid, float *history, const IcpTeam *team, hipStream_t s);
+                      const GridScratch *grid, float *history, const IcpTeam *team, const IcpOpts &opts,
+                      hipStream_t s);
 hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                                   const uint8_t *swap, int B, int N, const GridScratch *grid, hipStream_t s);
-hipError_t profile_enable(int capacity);
-hipError_t profile_collect(double *total_ms, int *launches);
+LaunchProfile *profile_create(int capacity, hipError_t *err);
+void profile_destroy(LaunchProfile *p);
+hipError_t profile_collect(LaunchProfile *p, double *total_ms, int *launches);
+// per-device caches (a process may drive several GPUs): CU count, and the opt-in of a kernel to more
+// than the default dynamic LDS, which HIP keeps per device
+int device_cus();
+void ensure_dynamic_lds(const void *func, int bytes, std::atomic<unsigned long long> *doneMask);
 hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,
                              float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s);
 hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const float *history, int B, int maxIter,

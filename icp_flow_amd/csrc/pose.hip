@@ -61,7 +61,8 @@ __global__ void compose_kernel(const IcpState *__restrict__ st, const float *__r
                                float *__restrict__ M, const IcpCtrl *__restrict__ ctrl, int32_t *__restrict__ iters)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0 && iters != nullptr) *iters = ctrl->iters;   // iterations of the batch (what icp_export reports)
+    // iterations of the batch (what icp_export reports); -1 = a team gave up waiting, transforms are NaN
+    if (b == 0 && iters != nullptr) *iters = ctrl->error ? -1 : ctrl->iters;
     if (b >= B) return;
     float A[16];
     for (int i = 0; i < 3; ++i) {
@@ -69,6 +70,7 @@ __global__ void compose_kernel(const IcpState *__restrict__ st, const float *__r
         A[i * 4 + 3] = st[b].T[i];
     }
     A[12] = A[13] = A[14] = 0.f; A[15] = 1.f;
+    if (ctrl != nullptr && ctrl->error) A[0] = __int_as_float(0x7fc00000);   // abandoned launch: poison every pose
     const float *I = init + (size_t)b * 16;
     float *o = M + (size_t)b * 16;
     for (int i = 0; i < 4; ++i)

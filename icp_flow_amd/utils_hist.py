@@ -54,7 +54,7 @@ def estimate_init_pose_batch(args, src, dst):
     shift = float(args.thres_dist // 2)                                  # utils_hist.py:78
     _lib.call("icpflow_estimate_init_pose", _lib.ptr(s), _lib.ptr(d), B, N, _lib.ptr(ex), lens[0],
               _lib.ptr(ey), lens[1], _lib.ptr(ez), lens[2], shift, _lib.ptr(T), _lib.ptr(ws),
-              ws.numel(), _lib.stream(s.device))
+              ws.numel(), _lib.stream(s.device), _lib.opt())
     return T
 
 

@@ -45,5 +45,5 @@ def apply_icp(args, src, dst, init_poses, return_iterations=False):
     ws = _lib.workspace(s.device, _lib.workspace_bytes(B, N))
     _lib.call("icpflow_apply_icp", _lib.ptr(s), _lib.ptr(d), _lib.ptr(init), B, N, float(args.thres_dist),
               max_it, rel, stop, _lib.ptr(out), _lib.ptr(iters), _lib.ptr(ws), ws.numel(),
-              _lib.stream(s.device))
+              _lib.stream(s.device), _lib.opt())
     return (out, iters) if return_iterations else out

@@ -57,7 +57,7 @@ def iterative_closest_point(X, Y, init_transform=None, thres=0.1, max_iterations
     ws = _lib.workspace(dev, _lib.workspace_bytes(B, N))
     _lib.call("icpflow_icp", _lib.ptr(x), _lib.ptr(y), None, B, N, float(thres), int(max_iterations),
               float(relative_rmse_thr), stop_mode_of(stop_mode), _lib.ptr(R), _lib.ptr(T), _lib.ptr(rmse),
-              _lib.ptr(flags[0:1]), _lib.ptr(flags[1:2]), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
+              _lib.ptr(flags[0:1]), _lib.ptr(flags[1:2]), _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())
     # Xt = s X R + T (utils_icp_pytorch3d.py:177, :395) -- returned for API parity
     Xt = torch.baddbmm(T[:, None, :], x[:, :, 0:3], R)
     sol = ICPSolution(_LazyFlag(flags, 1), rmse, Xt,

@@ -24,7 +24,7 @@ def hist_icp(args, src, dst, return_iterations=False):
     ws = _lib.workspace(s.device, _lib.workspace_bytes(B, N, lens))
     _lib.call("icpflow_hist_icp", _lib.ptr(s), _lib.ptr(d), B, N, _lib.ptr(ex), lens[0], _lib.ptr(ey),
               lens[1], _lib.ptr(ez), lens[2], float(args.thres_dist // 2), float(args.thres_dist), max_it,
-              rel, stop, _lib.ptr(out), _lib.ptr(iters), _lib.ptr(ws), ws.numel(), _lib.stream(s.device))
+              rel, stop, _lib.ptr(out), _lib.ptr(iters), _lib.ptr(ws), ws.numel(), _lib.stream(s.device), _lib.opt())
     return (out, iters) if return_iterations else out
 
 
@@ -43,7 +43,7 @@ def match_eval(args, pcd1, pcd2, transformations):
     ws = _lib.workspace(dev, _lib.workspace_bytes(B, N))
     _lib.call("icpflow_match_eval", _lib.ptr(a), _lib.ptr(b), _lib.ptr(T), B, N, float(args.thres_dist),
               _lib.ptr(o2[0]), _lib.ptr(o2[1]), _lib.ptr(o2[2]), _lib.ptr(o2[3]), _lib.ptr(o3[0]),
-              _lib.ptr(o3[1]), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
+              _lib.ptr(o3[1]), _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())
     return o2[0], o2[1], o2[2], o2[3], o3[0], o3[1]
 
 
@@ -90,10 +90,16 @@ def _match_pairs_host(args, st, dt, pairs):
     si, di = st.find_host(pairs[:, 0]), dt.find_host(pairs[:, 1])
     assert (si >= 0).all() and (di >= 0).all()
     segs_src, segs_dst = _gather_pair_batches(args, st, dt, si, di)
-    T = hist_icp(args, segs_src, segs_dst)
+    T, iters = hist_icp(args, segs_src, segs_dst, return_iterations=True)
     ev = match_eval(args, segs_src, segs_dst, T)
     B = len(pairs)
-    r = torch.cat([T.reshape(B, 16)] + [e.reshape(B, -1) for e in ev], dim=1).cpu().numpy()      # the one sync
+    r = torch.cat([T.reshape(B, 16)] + [e.reshape(B, -1) for e in ev] + [iters.float().expand(B, 1)],
+                  dim=1).cpu().numpy()                                                             # the one sync
+    if r[0, -1] < 0:
+        # a team of workgroups sharing one large pair gave up waiting for a member (include/icpflow_hip.h, a-5):
+        # the transforms are NaN.  Never let that pass as "no match" -- the points would silently get ego flow only.
+        raise RuntimeError("icpflow_hist_icp abandoned the batch: a workgroup team timed out (GPU shared with another "
+                           "process?); retry, or register with _lib.options(no_teams=True)")
     T_h, errors, inliers, ratios, ious = r[:, 0:16].reshape(B, 4, 4), r[:, 16:18], r[:, 18:20], r[:, 20:22], r[:, 22:24]
     keep = check_transformation(args, r[:, 24:27], r[:, 27:30], np.minimum(ious[:, 0], ious[:, 1]))
     S, D = len(st.h_labels), len(dt.h_labels)

@@ -4,8 +4,10 @@
  *
  * Every pointer named d_* is a DEVICE pointer owned by the caller (e.g. the
  * data_ptr() of a torch-ROCm tensor); the library never allocates or frees
- * caller memory and keeps no global state besides a thread-local error string
- * (and the optional launch-timing recorder at the end of this header).
+ * caller memory and keeps NO mutable process-global state: the only state outside
+ * the arguments is a thread-local error string, a thread-local helper stream and
+ * per-device caches of immutable device properties.  Tuning switches and the
+ * launch-timing recorder travel with each call in an icpflow_options_t.
  * Scratch comes from a caller-provided workspace (icpflow_workspace_bytes()).
  * All work is enqueued asynchronously on `stream` (a hipStream_t passed as
  * void*; NULL = the default stream); no entry point synchronises the device.
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 100 /* 0.1.0 */
+#define ICPFLOW_VERSION 200 /* 0.2.0: per-call options replace the process-global switches of 0.1 */
 
 #define ICPFLOW_OK 0
 #define ICPFLOW_E_ARG (-1)       /* bad pointer / size / enum                      */
@@ -53,6 +55,62 @@ typedef void *icpflow_stream_t; /* hipStream_t */
 
 int icpflow_version(void);
 const char *icpflow_last_error(void);
+/* Hash (16 hex digits) of the sources, headers and compiler flags this library was built from
+ * (icp_flow_amd/build.py); lets a deployment tell which tree a prebuilt .so belongs to. */
+const char *icpflow_build_info(void);
+
+/* ---------------------------------------------------------------------------
+ * Per-call options of the fused entry points (last argument; NULL = defaults).
+ * Nothing here changes results except icp_arith: every search mode and every
+ * ICPFLOW_OPT_* switch selects between implementations that are bit-identical in
+ * their outputs (the parity tests run all of them).
+ *
+ * icp_search -- correspondence search inside the ICP loop:
+ *   ICPFLOW_SEARCH_AUTO (0)   sorted sweep when 64 <= N <= 16384, else the all-pairs scan
+ *   ICPFLOW_SEARCH_SCAN (1)   all-pairs LDS-tiled scan of the fixed cloud every iteration
+ *   ICPFLOW_SEARCH_GRID (2)   exact hashed uniform grid of the fixed cloud, built once per
+ *                             registration: only the 27 cells within the gate radius are evaluated
+ *   ICPFLOW_SEARCH_SWEEP (3)  both clouds sorted once along the fixed cloud's longest axis; each
+ *                             wave scans (LDS broadcast) only the window its queries can gate
+ * icp_arith -- arithmetic of the Kabsch step (utils_icp_pytorch3d.py:303-382):
+ *   ICPFLOW_ARITH_FP64 (0)    one pass of 18 raw moments in fp64, closed-form rotation in fp64
+ *                             (the default: at least as accurate as the reference)
+ *   ICPFLOW_ARITH_FP32_REFERENCE (1)  the reference's own operation order in fp32: weighted
+ *                             means (:314-315), centring (:318-325), 3x3 product and division
+ *                             (:335-336), T = mu_y - mu_x R (:376), rmse from the moved points
+ *                             (:191-192) -- reproduces the rounding NOISE LEVEL of the reference's
+ *                             tensors (not its bits: the summation order of a GPU reduction differs
+ *                             from any other backend's).  All-pairs search, slower; a study mode.
+ * profile -- optional recorder of the dominant kernel's launches (see the end of this header).
+ * d_vote_bins_u32 -- optional debug output of icpflow_estimate_init_pose / icpflow_hist_icp: the
+ *   uint32 bins [B, Lx*Ly*Lz] of the fused (sorted) vote exactly as the peak search reads them.
+ * ------------------------------------------------------------------------- */
+#define ICPFLOW_SEARCH_AUTO 0
+#define ICPFLOW_SEARCH_SCAN 1
+#define ICPFLOW_SEARCH_GRID 2
+#define ICPFLOW_SEARCH_SWEEP 3
+#define ICPFLOW_ARITH_FP64 0
+#define ICPFLOW_ARITH_FP32_REFERENCE 1
+/* developer switches (flags): each turns one optimisation off; results are identical */
+#define ICPFLOW_OPT_NO_SORTED_VOTE (1u << 0)  /* all-pairs vote instead of the z-sorted one        */
+#define ICPFLOW_OPT_NO_SIDE_STREAM (1u << 1)  /* everything on the caller's stream                 */
+#define ICPFLOW_OPT_NO_EVAL_SWEEP (1u << 2)   /* all-pairs match_eval scans                        */
+#define ICPFLOW_OPT_NO_CHECK_SWEEP (1u << 3)  /* all-pairs roll-back check                         */
+#define ICPFLOW_OPT_NO_SCORE_SWEEP (1u << 4)  /* all-pairs candidate scoring                       */
+#define ICPFLOW_OPT_NO_SCORE_PRUNE (1u << 5)  /* every scoring scan runs to the end                */
+#define ICPFLOW_OPT_NO_TEAMS (1u << 6)        /* always one workgroup per pair                     */
+#define ICPFLOW_OPT_NO_SPECULATIVE (1u << 7)  /* batch-global stop: one launch per iteration       */
+
+typedef struct icpflow_profile icpflow_profile_t; /* opaque */
+
+typedef struct icpflow_options {
+    size_t struct_size; /* sizeof(icpflow_options_t) of the caller's header */
+    int icp_search;
+    int icp_arith;
+    unsigned flags;
+    icpflow_profile_t *profile;
+    uint32_t *d_vote_bins_u32;
+} icpflow_options_t;
 
 /* Bytes of device scratch the fused entry points below need for a batch of B
  * pairs padded to N points with a translation histogram of Lx*Ly*Lz bins.
@@ -133,7 +191,8 @@ int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, in
                                const float *d_edges_y, int len_y,
                                const float *d_edges_z, int len_z,
                                float decode_shift, float *d_T_out,
-                               void *d_ws, size_t ws_bytes, icpflow_stream_t stream);
+                               void *d_ws, size_t ws_bytes, icpflow_stream_t stream,
+                               const icpflow_options_t *opt);
 
 /* ---------------------------------------------------------------------------
  * a-5..a-7  masked batched point-to-point ICP.
@@ -153,12 +212,17 @@ int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, in
  * Outputs (any may be NULL): d_R [B,3,3], d_T [B,3], d_rmse [B],
  * d_iters int32 [1] (loop bodies executed; per-pair mode: max over pairs),
  * d_converged int32 [1].
+ * Failure inside the launch: when several workgroups share one large pair (N > 1024, batch smaller
+ * than half the GPU) and a member is not scheduled for 2 s -- another process saturating the GPU --
+ * the registration is abandoned instead of hanging the queue: every R of the batch is NaN and
+ * *d_iters = -1 (also for icpflow_apply_icp / icpflow_hist_icp, whose transforms are then NaN).
+ * Callers must treat iters < 0 as an error (the Python mirrors raise).
  * ------------------------------------------------------------------------- */
 int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int B, int N,
                 double thres, int max_iterations, double relative_rmse_thr, int stop_mode,
                 float *d_R, float *d_T, float *d_rmse, int32_t *d_iters,
                 int32_t *d_converged, void *d_ws, size_t ws_bytes,
-                icpflow_stream_t stream);
+                icpflow_stream_t stream, const icpflow_options_t *opt);
 
 /* ---------------------------------------------------------------------------
  * a-8, a-9  ICP from an initial pose with roll-back.
@@ -172,7 +236,7 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
                       int B, int N, double thres_dist, int max_iterations,
                       double relative_rmse_thr, int stop_mode, float *d_T_out,
                       int32_t *d_iters, void *d_ws, size_t ws_bytes,
-                      icpflow_stream_t stream);
+                      icpflow_stream_t stream, const icpflow_options_t *opt);
 
 /* ---------------------------------------------------------------------------
  * a-11  one full registration per cluster pair.
@@ -190,7 +254,7 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N,
                      float decode_shift, double thres_dist, int max_iterations,
                      double relative_rmse_thr, int stop_mode, float *d_T_out,
                      int32_t *d_iters, void *d_ws, size_t ws_bytes,
-                     icpflow_stream_t stream);
+                     icpflow_stream_t stream, const icpflow_options_t *opt);
 
 /* ---------------------------------------------------------------------------
  * a-12  registration quality metrics.
@@ -202,7 +266,7 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
                        int B, int N, double thres_dist, float *d_errors,
                        float *d_inliers, float *d_ratios, float *d_ious,
                        float *d_translations, float *d_rotations, void *d_ws,
-                       size_t ws_bytes, icpflow_stream_t stream);
+                       size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt);
 
 /* ---------------------------------------------------------------------------
  * a-15 / 8(f)  helpers of the host association around the path.
@@ -251,7 +315,7 @@ int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, cons
  * Outputs: d_labels int32 [n]: cluster id 0..C-1 in order of each cluster's smallest core-point row
  * (Open3D's numbering), -1 noise, -2 masked out;  d_counts int32 [n]: the first C entries are the
  * cluster sizes;  d_num_clusters int32 [1] = C.  Keeping only the num_clusters largest clusters
- * (utils_cluster.py:38-45) is host logic on d_counts (icp-flow_amd/utils_cluster.py).
+ * (utils_cluster.py:38-45) is host logic on d_counts (icp_flow_amd/utils_cluster.py).
  * ------------------------------------------------------------------------- */
 size_t icpflow_dbscan_workspace_bytes(int n);
 int icpflow_dbscan(const float *d_points, int stride, const uint8_t *d_mask, int n, double eps, int min_points,
@@ -265,7 +329,7 @@ int icpflow_dbscan(const float *d_points, int stride, const uint8_t *d_mask, int
  *     d(a, b) = max(core(a), core(b), |a - b|),   core(a) = distance to a's min_samples-th nearest
  *     neighbour, a itself counted (sklearn / hdbscan: tree.query(X, k=min_samples)[:, -1]).
  * The dendrogram, condensed tree and cluster selection on the n - 1 edges are sequential host logic
- * (icp-flow_amd/utils_cluster.py).
+ * (icp_flow_amd/utils_cluster.py).
  *
  * d_points / stride / d_mask as icpflow_dbscan.  cell: edge of the uniform sort grid in metres (speed
  * only; 0.25 suits LiDAR frames).  Outputs: d_edge_a / d_edge_b int32 [n], d_edge_w2 float64 [n]: the
@@ -298,31 +362,16 @@ int icpflow_selftest_vote_quotient(const float *d_a, int n, float min_v, float m
                                    float *d_ieee, icpflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------
- * Correspondence search used inside the ICP loop (process-global tuning knob, results are
- * bit-identical in every mode):
- *   ICPFLOW_SEARCH_AUTO (0)   sorted sweep when 64 <= N <= 16384, else the all-pairs scan
- *   ICPFLOW_SEARCH_SCAN (1)   all-pairs LDS-tiled scan of the fixed cloud every iteration
- *   ICPFLOW_SEARCH_GRID (2)   exact hashed uniform grid of the fixed cloud, built once per
- *                             registration: only the 27 cells within the gate radius are evaluated
- *   ICPFLOW_SEARCH_SWEEP (3)  both clouds sorted once along the fixed cloud's longest axis; each
- *                             wave scans (LDS broadcast) only the window its queries can gate
+ * Measurement aid (no reference counterpart): per-launch timing of the dominant kernel, the ICP
+ * iteration.  A recorder is an object the caller owns: every launch of that kernel made by a call
+ * that carries it in its options (up to `capacity` launches) is bracketed by HIP events recorded on
+ * the caller's stream; icpflow_profile_collect() waits for the recorded events, returns the summed
+ * duration in milliseconds and the number of launches, and re-arms the recorder.  One recorder must
+ * not be used by two host threads at once; distinct recorders are independent.
  * ------------------------------------------------------------------------- */
-#define ICPFLOW_SEARCH_AUTO 0
-#define ICPFLOW_SEARCH_SCAN 1
-#define ICPFLOW_SEARCH_GRID 2
-#define ICPFLOW_SEARCH_SWEEP 3
-int icpflow_set_icp_search(int mode);
-
-/* ---------------------------------------------------------------------------
- * Measurement aid (no reference counterpart): per-launch timing of the dominant kernel,
- * the ICP iteration.  After icpflow_profile_enable(capacity) every launch of that kernel
- * (up to `capacity` of them) is bracketed by HIP events recorded on the caller's stream;
- * icpflow_profile_collect() waits for the recorded events, returns the summed duration in
- * milliseconds and the number of launches, and re-arms the recorder.  capacity 0 disables
- * and frees the events.  This recorder is process-global and not thread-safe.
- * ------------------------------------------------------------------------- */
-int icpflow_profile_enable(int capacity);
-int icpflow_profile_collect(double *total_ms, int *launches);
+int icpflow_profile_create(int capacity, icpflow_profile_t **out);
+int icpflow_profile_collect(icpflow_profile_t *profile, double *total_ms, int *launches);
+int icpflow_profile_destroy(icpflow_profile_t *profile);
 
 #ifdef __cplusplus
 }

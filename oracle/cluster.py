@@ -1,7 +1,7 @@
 """CPU restatement of the reference's `cluster_dbscan` branch -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
-anything under oracle/.  The product package (icp-flow_amd/) must never do so.
+anything under oracle/.  The product package (icp_flow_amd/) must never do so.
 
 What is restated
   * `dbscan_index_order`  -- open3d 0.17.0 `PointCloud::ClusterDBSCAN(eps, min_points)`

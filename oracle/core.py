@@ -1,7 +1,7 @@
 """ctypes binding of oracle_core.c -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
-anything under oracle/.  The product package (icp-flow_amd/) must never do so.
+anything under oracle/.  The product package (icp_flow_amd/) must never do so.
 """
 import ctypes
 import os

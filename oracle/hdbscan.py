@@ -1,7 +1,7 @@
 """CPU restatement of the spanning-tree part of HDBSCAN -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
-anything under oracle/.  The product package (icp-flow_amd/) must never do so.
+anything under oracle/.  The product package (icp_flow_amd/) must never do so.
 
 The reference's `cluster_hdbscan` (utils_cluster.py:10-29) calls the third-party `hdbscan` 0.8.29
 (environment.yml:57; not in /root/reference, not installable here).  Its published algorithm (Campello et

@@ -3,7 +3,7 @@
  * cluster-pair registration hot path.  TEST INFRASTRUCTURE ONLY.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
- * load this library; the product path (icp-flow_amd/) never does.
+ * load this library; the product path (icp_flow_amd/) never does.
  *
  * What is restated here and from where:
  *

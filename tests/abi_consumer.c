@@ -8,7 +8,20 @@
 
 int main(void)
 {
-    if (icpflow_version() != 100) return 1;
+    if (icpflow_version() != ICPFLOW_VERSION) return 1;
+    if (strlen(icpflow_build_info()) == 0) return 1;
+    /* per-call options are validated before anything else: a struct from another header version is refused */
+    icpflow_options_t opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt) - 4;
+    int rco = icpflow_icp(NULL, NULL, NULL, 1, 1, 0.1, 10, 1e-6, ICPFLOW_STOP_REFERENCE, NULL, NULL, NULL, NULL, NULL,
+                          NULL, 0, NULL, &opt);
+    if (rco != ICPFLOW_E_ARG || strstr(icpflow_last_error(), "struct_size") == NULL) return 10;
+    opt.struct_size = sizeof(opt);
+    opt.icp_search = 9;
+    rco = icpflow_icp(NULL, NULL, NULL, 1, 1, 0.1, 10, 1e-6, ICPFLOW_STOP_REFERENCE, NULL, NULL, NULL, NULL, NULL, NULL,
+                      0, NULL, &opt);
+    if (rco != ICPFLOW_E_ARG || strstr(icpflow_last_error(), "icp_search") == NULL) return 11;
     if (icpflow_workspace_bytes(0, 10, 0, 0, 0) != 0) return 2;
     int rc = icpflow_dbscan(NULL, 3, NULL, 10, 0.25, 20, NULL, NULL, NULL, NULL, 0, NULL);
     if (rc != ICPFLOW_E_ARG || strstr(icpflow_last_error(), "null pointer") == NULL) return 3;

@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_the_header():
     from icp_flow_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.VERSION == 100
+    assert _lib.VERSION == 200
+    assert re.fullmatch(r"[0-9a-f]{16}", _lib.BUILD_INFO), _lib.BUILD_INFO
 
 
 def test_argument_errors_are_status_codes_with_messages():
@@ -40,14 +41,38 @@ def test_argument_errors_are_status_codes_with_messages():
     rc = L.icpflow_hist_vote(None, None, 1, 1, 1, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1, 1, 1, None, None)
     assert rc == -1 and b"null pointer" in L.icpflow_last_error()
     one = ctypes.c_void_p(16)
-    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 5000, 1e-6, 0, None, None, None, None, None, one, 1 << 30, None)
+    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 5000, 1e-6, 0, None, None, None, None, None, one, 1 << 30, None, None)
     assert rc == -1 and b"max_iterations" in L.icpflow_last_error()
-    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 10, 1e-6, 7, None, None, None, None, None, one, 1 << 30, None)
+    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 10, 1e-6, 7, None, None, None, None, None, one, 1 << 30, None, None)
     assert rc == -1 and b"stop_mode" in L.icpflow_last_error()
-    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 10, 1e-6, 0, None, None, None, None, None, one, 16, None)
+    rc = L.icpflow_icp(one, one, None, 4, 8, 0.1, 10, 1e-6, 0, None, None, None, None, None, one, 16, None, None)
     assert rc == -2 and b"workspace" in L.icpflow_last_error()
     rc = L.icpflow_nn_batch(one, one, 1, 4, 4, 2, 4, None, None, 1, one, one, None)
     assert rc == -1 and b"stride" in L.icpflow_last_error()
+
+
+def test_options_are_per_call_and_per_thread():
+    """Tuning switches travel with each call (icpflow_options_t); the Python side keeps the options in force in a
+    thread-local stack, so two host threads never see each other's settings."""
+    import threading
+    from icp_flow_amd import _lib
+    assert _lib.opt() is None or _lib._DEFAULT_FLAGS                     # defaults -> NULL pointer
+    seen = {}
+
+    def other():
+        seen["other"] = _lib._current()[-1]["search"]
+
+    with _lib.options(search="grid", no_teams=True):
+        o = ctypes.cast(_lib.opt(), ctypes.POINTER(_lib.Options)).contents
+        assert (o.struct_size, o.icp_search, o.flags & _lib.OPT_FLAGS["no_teams"]) == (ctypes.sizeof(_lib.Options), 2, 64)
+        with _lib.options(search="scan"):
+            assert _lib._current()[-1]["search"] == 1 and _lib._current()[-1]["flags"] & 64
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+    assert seen["other"] == 0
+    assert _lib._current()[-1]["search"] == 0
+    assert ctypes.sizeof(_lib.Options) == 40   # size_t, int, int, unsigned, pad, ptr, ptr on LP64
 
 
 def test_product_refuses_cpu_tensors_no_fallback():
@@ -64,8 +89,8 @@ def test_product_refuses_cpu_tensors_no_fallback():
 
 
 def test_product_never_imports_the_oracle():
-    """The oracle is the checker: nothing under icp-flow_amd/ may reference it."""
-    pkg = os.path.join(REPO, "icp-flow_amd")
+    """The oracle is the checker: nothing under icp_flow_amd/ may reference it."""
+    pkg = os.path.join(REPO, "icp_flow_amd")
     for root, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h")):

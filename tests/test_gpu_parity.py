@@ -25,14 +25,17 @@ from icp_flow_amd import _lib  # noqa: E402
 DEV = torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True, params=["scan", "grid", "sweep"])
+@pytest.fixture(params=["scan", "grid", "sweep"])
 def icp_search_mode(request):
-    """Every test runs with all correspondence searches of the ICP loop: the all-pairs LDS scan,
-    the exact hashed grid and the sorted sweep must be indistinguishable (same tolerances, same
-    iteration counts)."""
-    _lib.set_icp_search(request.param)
-    yield request.param
-    _lib.set_icp_search("auto")
+    """Every test that runs the ICP loop (marked `all_icp_searches`) runs with all correspondence searches
+    of the loop: the all-pairs LDS scan, the exact hashed grid and the sorted sweep must be
+    indistinguishable (same tolerances, same iteration counts).  The search is a per-call option
+    (icpflow_options_t), in force for the calls of this thread inside the block."""
+    with _lib.options(search=request.param):
+        yield request.param
+
+
+all_icp_searches = pytest.mark.usefixtures("icp_search_mode")
 
 TOL_M = 1e-4      # metres, on translations and moved points
 
@@ -109,12 +112,10 @@ def test_hist_vs_oracle_random_flags_and_big_histograms(tf, N):
     assert want.sum() > 0
 
 
-def test_vote_quotient_is_the_ieee_quotient(icp_search_mode):
+def test_vote_quotient_is_the_ieee_quotient():
     """The vote's (v - min) / (max - min) with the hoisted reciprocal equals the IEEE quotient bit for
     bit: 2^24 numerators per box (dense sweep of [0, r) plus the float neighbours of every bin
     boundary k * r / len), for the boxes of SURVEY A.1 and hist_cuda/test.py."""
-    if icp_search_mode != "scan":
-        pytest.skip("independent of the ICP search")
     boxes = [(-2.0, 2.0, 41), (-0.1, 0.1, 3), (-3.34, 3.36, 68), (-6.68, 6.72, 135), (-13.36, 13.44, 269),
              (-16.667, 16.733, 335), (-10.0, 10.0, 201), (-0.5, 0.5, 11), (-1.667, 1.733, 35)]
     rng = np.random.default_rng(5)
@@ -243,6 +244,7 @@ TOL_R_HP = 5e-7      # rotation entries vs the fp64 evaluation of the oracle
 TOL_M_HP = 1e-5      # moved points vs the fp64 evaluation (fp32 coordinates at ~50 m: ulp 4e-6)
 
 
+@all_icp_searches
 @pytest.mark.parametrize("case", list("abcde"))
 def test_icp_vs_golden(case):
     g = load_golden("g5_icp")
@@ -268,6 +270,7 @@ def test_icp_vs_golden(case):
     np.testing.assert_allclose(np.linalg.det(R.astype(np.float64)), 1.0, atol=1e-5)   # proper rotations
 
 
+@all_icp_searches
 @pytest.mark.parametrize("case", list("bce"))
 def test_icp_vs_fp64_evaluation_of_the_oracle(case):
     g = load_golden("g5_icp")
@@ -295,8 +298,8 @@ def test_search_modes_agree():
     dst[3, 40] = dst[3, 4]
     out = {}
     for mode in ("scan", "grid", "sweep"):
-        _lib.set_icp_search(mode)
-        sol = utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV))
+        with _lib.options(search=mode):
+            sol = utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV))
         out[mode] = (sol.RTs.R.cpu().numpy(), sol.RTs.T.cpu().numpy(), sol.rmse.cpu().numpy(), sol.converged.iterations)
     assert out["scan"][3] == out["grid"][3] == out["sweep"][3]
     for a, b in zip(out["scan"][:3], out["grid"][:3]):
@@ -306,6 +309,7 @@ def test_search_modes_agree():
     np.testing.assert_allclose(out["sweep"][2], out["scan"][2], atol=1e-7, rtol=0)
 
 
+@all_icp_searches
 def test_icp_per_pair_stop_stays_within_tolerance():
     """Per-pair stopping is NOT the reference's rule: each pair leaves the loop at
     its own convergence instead of iterating until the whole batch satisfies the test.  On
@@ -318,6 +322,7 @@ def test_icp_per_pair_stop_stays_within_tolerance():
     assert fast.converged.iterations <= int(g["c_iterations"]) and bool(fast.converged)
 
 
+@all_icp_searches
 def test_icp_multi_group_path_vs_oracle():
     """n_src > 2048 exercises the several-query-groups (scratch) path of the ICP kernel."""
     S, D, Tt = synthetic.make_batch(2, 2600, seed=77)
@@ -338,6 +343,7 @@ def test_icp_multi_group_path_vs_oracle():
     np.testing.assert_allclose(got.Xt.cpu().numpy(), ref.Xt.numpy(), atol=TOL_M, rtol=0)
 
 
+@all_icp_searches
 def test_icp_batch_larger_than_the_gpu_vs_oracle():
     """More pairs than compute units: the single-launch form of the batch-global stop rule has to work
     while late workgroups only start when early pairs have left (periodic pairs publish the rest of their
@@ -362,6 +368,7 @@ def test_icp_batch_larger_than_the_gpu_vs_oracle():
     assert np.where(valid, diff, 0).max() <= TOL_M
 
 
+@all_icp_searches
 def test_degenerate_pairs_do_not_disturb_their_neighbours():
     """A pair whose src role is empty (all pads) and a pair of two single points share a batch with normal
     pairs: the call returns, the normal pairs come out exactly as without the degenerate ones, the
@@ -387,6 +394,7 @@ def test_degenerate_pairs_do_not_disturb_their_neighbours():
 
 
 # ------------------------------------------------------------------ a-9 / a-11 / a-12
+@all_icp_searches
 def test_apply_icp_from_reference_init_poses():
     g = load_golden("g6_hist_icp")
     a = rp.default_args(translation_frame=float(g["translation_frame"]))
@@ -397,6 +405,7 @@ def test_apply_icp_from_reference_init_poses():
     assert np.array_equal(got.cpu().numpy()[rb], g["T_init_noswap"][rb])
 
 
+@all_icp_searches
 def test_rollback_on_identical_clouds():
     g = load_golden("g6_rollback")
     a = rp.default_args(translation_frame=float(g["translation_frame"]))
@@ -404,6 +413,7 @@ def test_rollback_on_identical_clouds():
     assert np.array_equal(got, g["T_hist_icp"])
 
 
+@all_icp_searches
 def test_hist_icp_ragged_vs_oracle_and_golden():
     g = load_golden("g6_hist_icp")
     a = rp.default_args(translation_frame=float(g["translation_frame"]))
@@ -418,6 +428,7 @@ def test_hist_icp_ragged_vs_oracle_and_golden():
     np.testing.assert_array_equal(got[:, 3], np.tile(np.array([0, 0, 0, 1], np.float32), (len(got), 1)))
 
 
+@all_icp_searches
 @pytest.mark.parametrize("tf", [3.34, 6.68])
 def test_hist_icp_larger_translation_frames_vs_oracle(tf):
     """Waymo gap 1 / gap 2 histogram geometry (68 and 135 bins per axis, 55 and 219 KB per pair):
@@ -433,6 +444,7 @@ def test_hist_icp_larger_translation_frames_vs_oracle(tf):
     assert_pose_close(got, want, S)
 
 
+@all_icp_searches
 def test_hist_icp_dense_vs_golden_and_match_eval():
     g = load_golden("g6_hist_icp_dense")
     S, D, _ = synthetic.make_batch(int(g["num_pairs"]), int(g["max_points"]), seed=int(g["seed"]))
@@ -454,6 +466,7 @@ def test_match_eval_ragged_vs_golden():
         np.testing.assert_allclose(got.cpu().numpy(), g["ev_" + key], atol=tol, rtol=1e-5)
 
 
+@all_icp_searches
 def test_hist_icp_real_data_shape_large_padding():
     """max_points = 10000 like demo.sh / main.sh: mostly tiny clusters plus a few thousand-point
     ones in the same padded batch (three-level window search, scalar-load sweep, sorts in 128 KiB
@@ -488,6 +501,7 @@ def test_hist_icp_real_data_shape_large_padding():
     np.testing.assert_array_equal(ev2[1].cpu().numpy(), wv2[1].numpy())
 
 
+@all_icp_searches
 def test_hist_icp_beyond_the_lds_image_and_beyond_the_sorts():
     """Padded lengths above 12288 (the sorted fixed cloud no longer fits LDS: scalar-load sweep) and above
     16384 (no sorts at all: all-pairs vote, scans and ICP search) must give the registration of the same
@@ -513,6 +527,7 @@ def test_hist_icp_beyond_the_lds_image_and_beyond_the_sorts():
         np.testing.assert_allclose(ev[0], base[2][0], atol=1e-6)               # mean errors
 
 
+@all_icp_searches
 def test_hist_icp_under_stream_capture_and_on_two_streams():
     """The fused registration can be captured into a HIP graph (the private side stream of the axis sort
     forks from and joins the capturing stream) and replayed with identical results; two streams running
@@ -553,6 +568,7 @@ def test_hist_icp_under_stream_capture_and_on_two_streams():
 
 
 # ------------------------------------------------------------------ 8(f): association + flow on the demo frame
+@all_icp_searches
 def test_demo_frame_pair_track_and_flow_vs_reference():
     """BASELINE config 1 (G8): demo.npz frame pair through the HIP path -- match_pcds (both stages:
     sanity_check, gather/pad, hist_icp, match_eval, reject, arg-min) and the flow kernel -- against
@@ -608,6 +624,7 @@ def test_cluster_stats_kernel_vs_torch():
         assert np.array_equal(t.extent[k].cpu().numpy(), want)
 
 
+@all_icp_searches
 def test_synthetic_frame_pair_vs_oracle():
     """A labelled synthetic frame pair (ragged clusters, relabelled objects -> both association
     stages) through track() + flow kernel against the oracle's match_pcds / flow."""
@@ -679,6 +696,7 @@ def test_full_size_nn_self_match_and_gather_property(config2):
     assert bool((dist <= other + 1e-6).all())
 
 
+@all_icp_searches
 def test_full_size_registration_recovers_motion(config2):
     S, D, Tt = config2
     a = rp.default_args(max_points=1024, icp_max_iterations=50)

@@ -12,7 +12,7 @@ src = torch.from_numpy(S); dst = torch.from_numpy(D)
 for i in range(B):   # pre-align so that there are inliers (like after the histogram init)
     Ti = torch.from_numpy(Tt[i]); src[i, :, :3] = src[i, :, :3] @ Ti[:3, :3].T + Ti[:3, 3] + torch.tensor([0.03, -0.02, 0.01])
 src, dst = src.cuda(), dst.cuda()
-_lib.set_icp_search(os.environ.get("SEARCH", "auto"))
+_opts = _lib.options(search=os.environ.get("SEARCH", "auto")); _opts.__enter__()
 names = ["entry->scan", "scan (stage+tiles)", "resolve+gate+acc", "block_sum7", "pass2+block_sum9", "kabsch", "pass3+block_sum1", "exit"]
 for k in (1, 2, 3):
     icp.iterative_closest_point(src, dst, max_iterations=k)

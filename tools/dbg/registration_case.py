@@ -25,11 +25,10 @@ o64 = rp.iterative_closest_point(moved, C, kabsch_dtype=torch.float64)
 print("B", B, "N", N, "oracle iterations fp32 / fp64-kabsch:", o32.iterations, o64.iterations)
 res = {}
 for mode in ("scan", "grid", "sweep"):
-    _lib.set_icp_search(mode)
-    sol = hip_icp.iterative_closest_point(moved.to(dev), C.to(dev))
+    with _lib.options(search=mode):
+        sol = hip_icp.iterative_closest_point(moved.to(dev), C.to(dev))
     res[mode] = sol
     print(mode, "iterations", sol.converged.iterations)
-_lib.set_icp_search("auto")
 def disp(R1, T1, R2, T2):
     out = []
     for b in range(B):
