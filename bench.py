@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- cluster-pair ICP registrations / second on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -7,11 +6,15 @@
 
 One "step" = one full registration (`hist_icp`: translation-histogram vote, NMS + top-5,
 6-candidate scoring, <= 50 ICP iterations with the reference's batch-global stop, roll-back
-check) of every pair of one synthetic batch.  Workload = BASELINE config 2: 256 cluster pairs
-x 1024 points, 50 ICP iterations, thres_dist 0.1, translation_frame 2.0, inputs resident in
-HBM before the timed region.  With N > 1 every rank registers its own 256 pairs (weak
-scaling; pair k of rank r is synthetic pair r*256+k) and the [B,4,4] transforms are
-all-gathered over RCCL inside the timed region -- the path has no other exchange step.
+check) of every pair of the workload, inputs resident in HBM before the timed region.
+
+  --gpus 1  (headline) BASELINE config 2: 256 cluster pairs x 1024 points.
+  --gpus N  (N > 1)    BASELINE config 4: 8192 cluster pairs x 2048 points in total, contiguous blocks of
+            8192/N pairs per rank (sharding.shard_range; pair k is synthetic pair k on every N), STRONG scaling;
+            the [B,4,4] transforms are all-gathered over RCCL inside the timed region -- the path has no other
+            exchange step.  The single-GPU line carries the same workload on one GPU (`config4_on_one_gpu`) so
+            that the scaling curve has its N = 1 point.
+  --workload config2|config4 overrides the choice.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -29,6 +32,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_LANE_OPS = 78.6e12    # 256 CU x 128 fp32 lanes x 2.4 GHz; 157.3 TFLOP/s counting fma = 2
+LANE_OPS_PER_EVAL = 8           # one 3-D squared distance + compare = 8 lane-ops
+COUNTERS_FILE = os.path.join(REPO, "profiles", "r02_icp_kernel_counters.json")
 
 
 def parse():
@@ -36,13 +42,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=256, help="cluster pairs per GPU per step")
-    ap.add_argument("--points", type=int, default=1024, help="points per cluster (= padded length)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4"])
+    ap.add_argument("--pairs", type=int, default=None, help="cluster pairs per step IN TOTAL (config2: 256 per GPU)")
+    ap.add_argument("--points", type=int, default=None, help="points per cluster (= padded length)")
     ap.add_argument("--iters", type=int, default=50, help="ICP iteration cap (BASELINE: 50)")
     ap.add_argument("--stop-mode", default="reference", choices=["reference", "per_pair"])
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements")
     return ap.parse_args()
+
+
+def timed_steps(step, sync, steps, warmup, iters_cap):
+    """W untimed steps, then exactly K steps between two (barrier + device synchronize); the launches of the
+    dominant kernel are bracketed by HIP events on the stream they run on (icpflow_profile_t)."""
+    from icp_flow_amd import _lib
+    for _ in range(warmup):
+        step()
+    prof = _lib.Profile(steps * iters_cap)
+    sync()
+    t0 = time.perf_counter()
+    with _lib.options(profile=prof):
+        for _ in range(steps):
+            T, iters = step()
+    sync()
+    dt = time.perf_counter() - t0
+    icp_ms, icp_launches = prof.collect()
+    prof.close()
+    return dt, icp_ms, icp_launches, T, iters
 
 
 def main():
@@ -65,10 +91,18 @@ def main():
     from icp_flow_amd import _lib, synthetic, utils_match
     from icp_flow_amd.sharding import gather_results, shard_range
 
-    B, N = a.pairs, a.points
-    first, count = shard_range(rank, world, B * world)          # contiguous block of B pairs
-    assert count == B
-    S, D, _ = synthetic.make_batch(B, N, seed=0, first=first)
+    workload = a.workload if a.workload != "auto" else ("config2" if world == 1 else "config4")
+    if workload == "config2":        # weak: every rank its own 256 pairs (only ever run with --gpus 1 by default)
+        N = a.points or 1024
+        total = (a.pairs or 256) * world
+        scaling = "weak"
+    else:                            # strong: the same 8192 pairs whatever N
+        N = a.points or 2048
+        total = a.pairs or 8192
+        scaling = "strong"
+    counts = [shard_range(r, world, total)[1] for r in range(world)]
+    first, B = shard_range(rank, world, total)                  # contiguous block of pairs
+    S, D, _ = synthetic.make_batch(B, N, seed=0, first=first)   # pair k = default_rng(k): the same pairs on every N
     src = torch.from_numpy(S).to(dev)
     dst = torch.from_numpy(D).to(dev)
     from types import SimpleNamespace
@@ -78,7 +112,7 @@ def main():
     def step():
         T, iters = utils_match.hist_icp(args, src, dst, return_iterations=True)
         if world > 1:
-            T = gather_results(T, world, counts=[B] * world)     # ONE RCCL all_gather over xGMI, no host sync
+            T = gather_results(T, world, counts=counts)          # ONE RCCL all_gather over xGMI, no host sync
         return T, iters
 
     def sync():
@@ -86,98 +120,142 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
-    # ---- timed region: exactly K steps, HIP-event timing of the dominant kernel inside ------
-    prof = _lib.Profile(a.steps * a.iters)
-    sync()
-    t0 = time.perf_counter()
-    with _lib.options(profile=prof):
-        for _ in range(a.steps):
-            T, iters = step()
-    sync()
-    dt = time.perf_counter() - t0
-    icp_ms, icp_launches = prof.collect()
-    prof.close()
+    dt, icp_ms, icp_launches, T, iters = timed_steps(step, sync, a.steps, a.warmup, a.iters)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     iters_done = int(iters.item())
+    if iters_done < 0:
+        raise SystemExit("hist_icp abandoned a batch (team timeout): the measurement is void")
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    regs = B * world * a.steps
-    value = regs / dt
-    # ---- roofline of the dominant kernel: icp_kernel.  With B <= #CUs one launch runs ALL ICP
-    # iterations of the batch (speculative execution of the batch-global stop rule);
-    # otherwise one launch per iteration.  Either way the algorithmic traffic is one pass over both
-    # clouds per executed iteration: P = (n_s + n_d) * 16 B per pair and iteration.
-    P = (N + N) * 16
-    alg_bytes_per_iter = B * P
-    executed = iters_done * a.steps                     # iterations that did work (same every step)
-    alg_bytes_per_launch = alg_bytes_per_iter * executed / max(icp_launches, 1)
-    avg_launch_ms = icp_ms / max(icp_launches, 1)
-    achieved_gbs = (alg_bytes_per_iter * executed) / (icp_ms * 1e-3) / 1e9 if icp_ms > 0 else 0.0
-    traffic = None
-    tfile = os.path.join(REPO, "profiles", "r01_icp_kernel_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            shape = "all_iterations" if icp_launches == a.steps else "one_iteration"
-            if tj.get("launch_shape") == shape:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {
-        "bound": "hbm", "kernel": "icp_kernel (all ICP iterations of the batch per launch)" if icp_launches == a.steps
-        else "icp_kernel (one ICP iteration of the batch per launch)",
-        "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-        "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-        "algorithmic_bytes_per_iteration": alg_bytes_per_iter,
-        "avg_launch_ms": round(avg_launch_ms, 5), "launches_timed": icp_launches,
-        "icp_iterations_executed_per_step": iters_done,
-        "icp_share_of_step": round(icp_ms / (dt * 1e3), 4),
-        "note": "the correspondence search is LDS-broadcast / FP32-VALU / latency bound, not HBM bound: the exact "
-                "sorted sweep evaluates ~12 % of the n^2 point pairs of a brute-force scan and both clouds stay "
-                "on chip for all iterations; see DESIGN.md 6",
-    }
+    value = total * a.steps / dt
+    roofline = roofline_block(B, N, a.steps, iters_done, icp_ms, icp_launches, dt, _lib.BUILD_INFO)
 
     extras = {}
-    if not a.no_extras and world == 1:   # single-GPU runs only: the N > 1 runs measure scaling, nothing else
+    if not a.no_extras and world == 1 and workload == "config2":   # N > 1 runs measure scaling, nothing else
         try:
             extras = extra_measurements(args, src, dst, T, dev, a)
         except Exception as e:               # the headline line must survive a failing side measurement
             extras = {"error": repr(e)}
 
     cpu = None
-    if a.cpu_pairs > 0 and world == 1:
+    if a.cpu_pairs > 0 and world == 1 and workload == "config2":
         try:
             cpu = cpu_baseline(S, D, a)
         except Exception as e:                   # e.g. no C compiler for the oracle on this box
             cpu = {"value": None, "unit": "registrations/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
 
+    name = ("BASELINE config 2: synthetic %d cluster pairs x %d pts per GPU" % (B, N) if workload == "config2" else
+            "BASELINE config 4: synthetic %d cluster pairs x %d pts in total, %s per GPU" % (total, N, "/".join(map(str, sorted(set(counts))))))
     out = {
         "metric": "cluster-pair ICP registrations/sec", "value": round(value, 2), "unit": "registrations/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE config 2: synthetic {B} cluster pairs x {N} pts per GPU, "
-                               f"<= {a.iters} ICP iters ({a.stop_mode} stop), thres_dist 0.1, "
+        "config": {"workload": f"{name}, <= {a.iters} ICP iters ({a.stop_mode} stop), thres_dist 0.1, "
                                f"translation_frame 2.0 (41x41x3 bins)",
-                   "pairs_per_gpu": B, "points": N, "icp_iteration_cap": a.iters,
-                   "stop_mode": a.stop_mode, "sharding": f"pairs/{world} contiguous, all_gather of [B,4,4]"},
+                   "pairs_total": total, "pairs_per_gpu": counts, "points": N, "icp_iteration_cap": a.iters,
+                   "stop_mode": a.stop_mode, "sharding": f"contiguous blocks of pairs over {world} rank(s), "
+                                                         f"all_gather of [B,4,4] inside the timed region"},
+        "library_build": _lib.BUILD_INFO,
         "roofline": roofline,
         "cpu_baseline": cpu,
         "extras": extras,
     }
+    if world == 1 and workload == "config2" and not a.no_extras:
+        try:
+            out["config4_on_one_gpu"] = config4_single_gpu(dev, a)
+        except Exception as e:
+            out["config4_on_one_gpu"] = {"error": repr(e)}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def roofline_block(B, N, steps, iters_done, icp_ms, icp_launches, dt, build):
+    """Roofline of the dominant kernel, icp_kernel.  One launch runs ALL ICP iterations of the batch (speculative
+    execution of the batch-global stop), or one launch per iteration beyond 128 iterations.
+    Algorithmic work per executed iteration: P = (n_s + n_d) * 16 B and E = n_s * n_d pair-evaluations
+    (8 lane-ops each) per pair.  Top-level achieved/peak/frac follow the bench contract (algorithmic HBM bytes /
+    launch duration); `bound` names what actually binds the kernel and `valu` carries that roofline."""
+    P, E = (N + N) * 16, N * N
+    executed = iters_done * steps                       # iterations of the batch rule (same every step)
+    alg_bytes = B * P * executed
+    alg_evals = B * E * executed
+    launches = max(icp_launches, 1)
+    sec = icp_ms * 1e-3
+    gbs = alg_bytes / sec / 1e9 if sec > 0 else 0.0
+    lane_alg = alg_evals * LANE_OPS_PER_EVAL / sec if sec > 0 else 0.0
+    counters, note = None, "no counters file"
+    if os.path.exists(COUNTERS_FILE):
+        try:
+            cj = json.load(open(COUNTERS_FILE))
+            shape = "all_iterations" if icp_launches == steps else "one_iteration"
+            if cj.get("library_build") != build:
+                note = f"{os.path.basename(COUNTERS_FILE)} was collected with library build {cj.get('library_build')}, this is {build}: refused"
+            elif (cj.get("launch_shape"), cj.get("pairs"), cj.get("points")) != (shape, B, N):
+                note = "counters file describes another launch shape: refused"
+            else:
+                counters, note = cj, "PMC passes of the same library build (profiles/, rocprofv3 --pmc, separate passes)"
+        except Exception as e:
+            note = "unreadable counters file: " + repr(e)
+    valu = {"peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+            "algorithmic_pair_evaluations_per_s": round(alg_evals / sec, 1) if sec > 0 else 0.0,
+            "algorithmic_lane_ops_per_s": round(lane_alg, 1),
+            "algorithmic_frac": round(lane_alg / VALU_PEAK_LANE_OPS, 4),
+            "algorithmic_note": "the brute-force formulation's n_s*n_d evaluations per iteration; the exact sorted sweep "
+                                "executes ~12 % of them and the periodic fast-forward skips repeated iterations, so this "
+                                "may exceed 1",
+            "SQ_INSTS_VALU_per_launch": None, "executed_lane_ops_per_s": None, "executed_frac": None}
+    if counters is not None and counters.get("SQ_INSTS_VALU_per_launch"):
+        insts = float(counters["SQ_INSTS_VALU_per_launch"])
+        lane_exec = insts * 64.0 / (sec / launches)
+        valu.update({"SQ_INSTS_VALU_per_launch": insts, "executed_lane_ops_per_s": round(lane_exec, 1),
+                     "executed_frac": round(lane_exec / VALU_PEAK_LANE_OPS, 4)})
+    return {
+        "bound": "valu",
+        "bound_note": "what binds: fp32 VALU issue + LDS broadcast latency of the correspondence search and the serial "
+                      "rotation solve of one wave per pair -- not HBM (both clouds stay in LDS for all iterations; "
+                      "arithmetic intensity ~256 lane-op/B against a ridge of ~10).  achieved/peak/frac below are the "
+                      "contract's HBM figures (algorithmic bytes / launch duration); see `valu` for the binding roofline",
+        "kernel": "icp_kernel (all ICP iterations of the batch per launch)" if icp_launches == steps
+        else "icp_kernel (one ICP iteration of the batch per launch)",
+        "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
+        "traffic": counters.get("hbm_bytes_per_launch") if counters else None,
+        "traffic_source": note,
+        "algorithmic_bytes_per_launch": int(alg_bytes / launches),
+        "algorithmic_bytes_per_iteration": B * P,
+        "avg_launch_ms": round(icp_ms / launches, 5), "launches_timed": icp_launches,
+        "icp_iterations_executed_per_step": iters_done,
+        "icp_share_of_step": round(icp_ms / (dt * 1e3), 4),
+        "valu": valu,
+    }
+
+
+def config4_single_gpu(dev, a):
+    """The N = 1 point of the config-4 scaling curve (what `--gpus N` runs, on one GPU), and the per-GPU shard shape
+    of the 8-GPU run (1024 pairs x 2048 points) on its own."""
+    from types import SimpleNamespace
+    from icp_flow_amd import synthetic, utils_match
+    N = 2048
+    args = SimpleNamespace(thres_dist=0.1, translation_frame=2.0, chunk_size=50, max_points=N,
+                           icp_max_iterations=a.iters, icp_stop_mode=a.stop_mode)
+    S, D, _ = synthetic.make_batch(8192, N, seed=0)
+    src, dst = torch.from_numpy(S).to(dev), torch.from_numpy(D).to(dev)
+    out = {"workload": "BASELINE config 4 (8192 cluster pairs x 2048 pts, <= %d iters), same timing protocol" % a.iters}
+    for tag, nb, steps in (("all_8192_pairs", 8192, 5), ("shard_of_8_gpus_1024_pairs", 1024, 10)):
+        s, d = src[:nb].contiguous(), dst[:nb].contiguous()
+        dt, icp_ms, launches, _, iters = timed_steps(lambda: utils_match.hist_icp(args, s, d, return_iterations=True),
+                                                     lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
+        out[tag] = {"registrations_per_s": round(nb * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                    "icp_iterations": int(iters.item()), "icp_kernel_ms_per_step": round(icp_ms / steps, 3)}
+    return out
 
 
 def extra_measurements(args, src, dst, T, dev, a):
@@ -360,29 +438,38 @@ def cluster_measurement(dev, g, gdir):
 
 
 def cpu_baseline(S, D, a):
-    """The oracle (CPU port of the reference's algorithm: padded [B,N,4] clouds, 1 vote + 12
-    scoring scans + I ICP iterations + 2 roll-back scans) on a bounded sample of the SAME batch,
-    all host cores (OpenMP over pairs inside oracle_core.c + torch-CPU threads)."""
+    """The oracle (CPU port of the reference's algorithm: padded [B,N,4] clouds, 1 vote + 12 scoring scans + I ICP
+    iterations + 2 roll-back scans) on a bounded sample of the SAME batch.  The port's inner loops (vote, K=1 NN) are
+    C with OpenMP over pairs (oracle_core.c), the rest torch-CPU ops -- a FASTER baseline than the reference's own
+    Python on CPU tensors (0.115 registrations/s on 8 cores at max_points 10000).  Timed at 32 threads
+    (where the many small torch ops stop scaling) and with os.cpu_count() threads in the C loops; `value` is the
+    better of the two."""
     from oracle import core as ocore
     from oracle import reference_path as rp
-    # threads actually used: all host cores up to 32 (on a 256-core box more threads only add fork/join
-    # overhead to the many small torch ops); sample = the whole batch by default (a few seconds of wall)
-    ncpu = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(ncpu)
-    ocore.set_num_threads(ncpu)
     n = min(a.cpu_pairs, S.shape[0])
     s, d = torch.from_numpy(S[:n]), torch.from_numpy(D[:n])
     args = rp.default_args(max_points=S.shape[1])
-    rp.hist_icp(args, s[:2], d[:2], max_iterations=a.iters)              # warm-up (page-in, threads)
-    t = time.perf_counter()
-    _, aux = rp.hist_icp(args, s, d, max_iterations=a.iters, return_aux=True)
-    dt = time.perf_counter() - t
-    return {"value": round(n / dt, 3), "unit": "registrations/s", "cores": ncpu,
+    runs = []
+    # (OpenMP threads of the C loops, torch intra-op threads).  All 256 cores for BOTH was measured: 0.98
+    # registrations/s -- the oracle's many small torch ops drown in fork/join -- so the second run gives every core
+    # to the C loops (they parallelise over pairs) and keeps torch at 32.
+    ncore = os.cpu_count() or 1
+    for omp, tth in sorted({(min(ncore, 32), min(ncore, 32)), (ncore, min(ncore, 32))}):
+        torch.set_num_threads(tth)
+        ocore.set_num_threads(omp)
+        rp.hist_icp(args, s[:2], d[:2], max_iterations=a.iters)              # warm-up (page-in, threads)
+        t = time.perf_counter()
+        _, aux = rp.hist_icp(args, s, d, max_iterations=a.iters, return_aux=True)
+        dt = time.perf_counter() - t
+        runs.append({"threads": omp, "torch_threads": tth, "registrations_per_s": round(n / dt, 3), "wall_s": round(dt, 2),
+                     "omp_threads": ocore.num_threads(), "icp_iterations": aux["iterations"]})
+    best = max(runs, key=lambda r: r["registrations_per_s"])
+    return {"value": best["registrations_per_s"], "unit": "registrations/s", "cores": best["threads"],
             "host_cores_available": os.cpu_count(), "kind": "port",
             "sample": f"first {n} of the {S.shape[0]} pairs of the same batch, same {a.iters}-iteration cap "
-                      f"(batch-global stop inside the sample after {aux['iterations']} iterations), "
-                      f"{dt:.2f} s wall",
-            "threads": ocore.num_threads()}
+                      f"(batch-global stop inside the sample after {best['icp_iterations']} iterations), "
+                      f"{best['wall_s']:.2f} s wall at {best['threads']} threads",
+            "runs": runs}
 
 
 if __name__ == "__main__":

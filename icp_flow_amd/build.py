@@ -12,7 +12,6 @@ The library carries the hash of the sources it was built from (icpflow_build_inf
 hash differs from the tree's is stale and rebuilt, whatever the file times say.
 """
 import concurrent.futures
-import ctypes
 import hashlib
 import os
 import subprocess
@@ -22,9 +21,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(HERE, "libicpflow_hip.so")
-SOURCES = ["api.hip", "hist.hip", "nn.hip", "icp.hip", "pose.hip", "sort.hip", "cluster.hip", "hdbscan.hip",
+SOURCES = ["api.hip", "hist.hip", "nn.hip", "icp.hip", "icp_fp32.hip", "pose.hip", "sort.hip", "cluster.hip", "hdbscan.hip",
            "hdbscan_tree.cpp"]
-HEADERS = ["common.hpp", "scan.hpp", "kernels.hpp", "votekey.hpp", "cluster_util.hpp",
+HEADERS = ["common.hpp", "scan.hpp", "kernels.hpp", "kabsch.hpp", "votekey.hpp", "cluster_util.hpp",
            os.path.join("..", "..", "include", "icpflow_hip.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
@@ -53,17 +52,23 @@ def source_hash():
     return _digest([os.path.join(CSRC, f) for f in SOURCES + HEADERS], CFLAGS)[:16]
 
 
+_MARK = b"ICPFLOW_SOURCE_HASH="
+
+
 def built_hash(path=OUT):
-    """The source hash baked into an existing library, or None."""
-    if not os.path.exists(path):
-        return None
+    """The source hash baked into an existing library, or None.  Read from the file's bytes: loading the library
+    here would pull the system HIP runtime into the process before torch brings its own (two runtimes in one
+    process do not share devices)."""
     try:
-        lib = ctypes.CDLL(path)
-        fn = lib.icpflow_build_info
-        fn.restype = ctypes.c_char_p
-        return fn().decode()
-    except (OSError, AttributeError):
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
         return None
+    k = blob.find(_MARK)
+    if k < 0:
+        return None
+    tag = blob[k + len(_MARK): k + len(_MARK) + 16]
+    return tag.decode() if len(tag) == 16 and all(c in b"0123456789abcdef" for c in tag) else None
 
 
 def stale():

@@ -42,9 +42,10 @@ struct Opts {
     LaunchProfile *profile = nullptr;
     uint32_t *voteBins = nullptr;
     bool on(unsigned offFlag) const { return (flags & offFlag) == 0u; }
-    IcpOpts icp() const
+    IcpOpts icp(float *scratch) const
     {
         IcpOpts o;
+        o.fp32Scratch = scratch;
         o.arith = arith;
         o.teams = on(ICPFLOW_OPT_NO_TEAMS);
         o.speculative = on(ICPFLOW_OPT_NO_SPECULATIVE);
@@ -171,6 +172,17 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
     return 0;
 }
 
+int check_arith(const char *fn, const Opts &o, int maxIter, int stopMode)
+{
+    if (o.arith != ICPFLOW_ARITH_FP32_REFERENCE) return 0;
+    if (stopMode != ICPFLOW_STOP_REFERENCE)
+        return fail(ICPFLOW_E_ARG, "%s: ICPFLOW_ARITH_FP32_REFERENCE implements the reference's batch-global stop only", fn);
+    if (maxIter > kHistIters)
+        return fail(ICPFLOW_E_LIMIT, "%s: ICPFLOW_ARITH_FP32_REFERENCE keeps a per-iteration history: max_iterations <= %d",
+                    fn, kHistIters);
+    return 0;
+}
+
 int check_ws(void *ws, size_t have, size_t need)
 {
     if (ws == nullptr || have < need)
@@ -250,7 +262,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
 {
     const GridScratch *search = search_scratch(w, N, o);
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, search, w.history, &w.team, o.icp(), s));
+                           w.state, w.ctrl, search, w.history, &w.team, o.icp(w.grid.sortX), s));
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s, w.ctrl, iters));   // also reports the iteration count
     // roll-back check: sweeps over the sorted clouds the ICP left behind, or the all-pairs scan
     if (search != nullptr && search->mode == 3 && o.on(ICPFLOW_OPT_NO_CHECK_SWEEP)) {
@@ -314,7 +326,9 @@ int icpflow_version(void) { return ICPFLOW_VERSION; }
 #ifndef ICPFLOW_SOURCE_HASH
 #define ICPFLOW_SOURCE_HASH "unknown"
 #endif
-const char *icpflow_build_info(void) { return ICPFLOW_SOURCE_HASH; }
+// the marker in front of the hash lets icp_flow_amd/build.py find it in the file without loading the library
+static const char g_build_info[] = "ICPFLOW_SOURCE_HASH=" ICPFLOW_SOURCE_HASH;
+const char *icpflow_build_info(void) { return g_build_info + sizeof("ICPFLOW_SOURCE_HASH=") - 1; }
 
 const char *icpflow_last_error(void) { return g_err; }
 
@@ -563,6 +577,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
 {
     Opts o;
     if (int r = parse_options("icpflow_icp", opt, o)) return r;
+    if (int r = check_arith("icpflow_icp", o, max_iterations, stop_mode)) return r;
     if (!d_X || !d_Y) return fail(ICPFLOW_E_ARG, "icpflow_icp: null pointer");
     if (int r = check_batch("icpflow_icp", B, N)) return r;
     if (max_iterations <= 0 || max_iterations > kMaxIterCap)
@@ -575,7 +590,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
                            relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N, o), w.history, &w.team,
-                           o.icp(), s));
+                           o.icp(w.grid.sortX), s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
     return 0;
 }
@@ -587,6 +602,7 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
 {
     Opts o;
     if (int r = parse_options("icpflow_apply_icp", opt, o)) return r;
+    if (int r = check_arith("icpflow_apply_icp", o, max_iterations, stop_mode)) return r;
     if (!d_src || !d_dst || !d_init || !d_T_out) return fail(ICPFLOW_E_ARG, "icpflow_apply_icp: null pointer");
     if (int r = check_batch("icpflow_apply_icp", B, N)) return r;
     if (max_iterations <= 0 || max_iterations > kMaxIterCap)
@@ -611,6 +627,7 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
 {
     Opts o;
     if (int r = parse_options("icpflow_hist_icp", opt, o)) return r;
+    if (int r = check_arith("icpflow_hist_icp", o, max_iterations, stop_mode)) return r;
     if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
         return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: null pointer");
     if (int r = check_batch("icpflow_hist_icp", B, N)) return r;

@@ -31,169 +31,9 @@ __device__ long long g_wave_stamps[16 * 16];   // [wave][k] of workgroup 0
 #define ICPFLOW_STAMP(k) do { } while (0)
 #endif
 
-// ---------------------------------------------------------------------------------
-// 3x3 Kabsch rotation, row-vector convention y = x R:  R = U diag(1,1,det(U V^T)) V^T for
-// H = U S V^T (utils_icp_pytorch3d.py:339-362), computed WITHOUT an SVD.  That R is the proper
-// rotation maximising sum_ij R_ij H_ij, i.e. Horn's closed-form absolute orientation: the unit
-// quaternion q that is the eigenvector of the largest eigenvalue of the symmetric 4x4 matrix N(H)
-// below (reflection case included).  lambda_max comes from Newton's method on the characteristic
-// quartic started at the upper bound (|Xc|^2 + |Yc|^2) / 2W (monotone from above: every root is
-// real), the eigenvector from the adjugate of N - lambda I, whose sixteen 3x3 minors are evaluated
-// side by side on sixteen lanes.  A dozen dependent fp64 operations per Newton step replace the
-// div / sqrt / rsqrt chains of a Jacobi SVD (three rotations per sweep) in the serial tail of an
-// ICP iteration.  horn_rotation returns false when the maximiser is numerically not unique
-// (rank(H) <= 1: fewer than three non-collinear correspondences; the reference's answer is then an
-// accident of its SVD backend) -- the caller then takes rank1_rotation.
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ double det3(double a, double b, double c, double d, double e, double f, double g,
-                                       double h, double i)
-{
-    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// Lane l < 16 returns cofactor (l / 4, l % 4) of the 4x4 matrix M (row-major, LDS): the sixteen 3x3
-// minors are evaluated side by side on sixteen lanes instead of one after the other, which also
-// keeps the register footprint of the solve at nine doubles.
-__device__ __forceinline__ double cofactor16(const double *M, int lane)
-{
-    // the nine element addresses depend on the lane only; recompute them here every time (an opaque copy
-    // of the lane index keeps the compiler from hoisting them out of the ICP loop, where they would be
-    // spilled and come back through nine dependent scratch loads per iteration)
-    asm volatile("" : "+v"(lane));
-    const int i = (lane >> 2) & 3, j = lane & 3;
-    const int r0 = (0 >= i) ? 1 : 0, r1 = (1 >= i) ? 2 : 1, r2 = (2 >= i) ? 3 : 2;
-    const int c0 = (0 >= j) ? 1 : 0, c1 = (1 >= j) ? 2 : 1, c2 = (2 >= j) ? 3 : 2;
-    const double d = det3(M[r0 * 4 + c0], M[r0 * 4 + c1], M[r0 * 4 + c2], M[r1 * 4 + c0], M[r1 * 4 + c1],
-                          M[r1 * 4 + c2], M[r2 * 4 + c0], M[r2 * 4 + c1], M[r2 * 4 + c2]);
-    return ((i + j) & 1) ? -d : d;
-}
-
-// Called by all 64 lanes of ONE wave with wave-uniform arguments; Nsh: 16 doubles of LDS scratch.
-__device__ bool horn_rotation(const double *S, double gsum, double *Nsh, int lane, double (&R)[9])
-{
-    double frob2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) frob2 += S[k] * S[k];
-    if (!(frob2 > 0.0)) return false;
-    // characteristic polynomial  l^4 + c2 l^2 + c1 l + c0  (N is traceless)
-    const double c2 = -2.0 * frob2;
-    const double c1 = -8.0 * det3(S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8]);
-    {
-        // every lane stores the same values (and later reads what it stored itself)
-        const double n01 = S[5] - S[7], n02 = S[6] - S[2], n03 = S[1] - S[3];
-        const double n12 = S[1] + S[3], n13 = S[6] + S[2], n23 = S[5] + S[7];
-        Nsh[0] = S[0] + S[4] + S[8]; Nsh[1] = n01; Nsh[2] = n02; Nsh[3] = n03;
-        Nsh[4] = n01; Nsh[5] = S[0] - S[4] - S[8]; Nsh[6] = n12; Nsh[7] = n13;
-        Nsh[8] = n02; Nsh[9] = n12; Nsh[10] = -S[0] + S[4] - S[8]; Nsh[11] = n23;
-        Nsh[12] = n03; Nsh[13] = n13; Nsh[14] = n23; Nsh[15] = -S[0] - S[4] + S[8];
-    }
-    const double n00 = Nsh[0], n11 = Nsh[5], n22 = Nsh[10], n33 = Nsh[15];
-    // c0 = det N: expansion along row 0, the four cofactors on lanes 0..3
-    const double term = Nsh[lane & 3] * cofactor16(Nsh, lane & 3);
-    const double c0 = (readlane_f64(term, 0) + readlane_f64(term, 1)) + (readlane_f64(term, 2) + readlane_f64(term, 3));
-    ICPFLOW_STAMP(13);
-    double lam = 0.5 * gsum, prevStep = 1e300;
-    for (int it = 0; it < 40; ++it) {
-        const double x2 = lam * lam;
-        const double b = (x2 + c2) * lam;
-        const double a = b + c1;
-        const double den = 2.0 * x2 * lam + b + a;
-        if (den == 0.0) break;
-        const double step = (a * lam + c0) / den;
-        lam -= step;
-        const double as = fabs(step);
-        // steps shrink monotonically above the largest root (real-rooted quartic): the first one
-        // that does not is rounding noise
-        if (as <= 1e-16 * fabs(lam) || as >= prevStep) break;
-        prevStep = as;
-    }
-    ICPFLOW_STAMP(14);
-    // adjugate of A = N - lam I (symmetric, rank 3): adj = c q q^T, entry (i, j) on lane 4 i + j
-    Nsh[0] = n00 - lam; Nsh[5] = n11 - lam; Nsh[10] = n22 - lam; Nsh[15] = n33 - lam;
-    const double C = cofactor16(Nsh, lane);
-    // column of the largest diagonal entry (c q_k^2): the best conditioned one
-    int k = 0;
-    double big = fabs(readlane_f64(C, 0));
-#pragma unroll
-    for (int d = 1; d < 4; ++d) {
-        const double v = fabs(readlane_f64(C, 5 * d));
-        if (v > big) { big = v; k = d; }
-    }
-    if (!(big * big > 1e-18 * frob2 * frob2 * frob2)) return false;   // (nearly) double top eigenvalue
-    k = __builtin_amdgcn_readfirstlane(k);
-    double q0 = readlane_f64(C, 4 * k + 0), q1 = readlane_f64(C, 4 * k + 1), q2 = readlane_f64(C, 4 * k + 2),
-           q3 = readlane_f64(C, 4 * k + 3);
-    const double inv = rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-    q0 *= inv; q1 *= inv; q2 *= inv; q3 *= inv;
-    // column-convention rotation Rc (y = Rc x) of the quaternion; the row convention wants Rc^T
-    const double ww = q0 * q0, xx = q1 * q1, yy = q2 * q2, zz = q3 * q3;
-    const double xy = q1 * q2, xz = q1 * q3, yz = q2 * q3, wx = q0 * q1, wy = q0 * q2, wz = q0 * q3;
-    R[0] = ww + xx - yy - zz; R[3] = 2.0 * (xy - wz);     R[6] = 2.0 * (xz + wy);
-    R[1] = 2.0 * (xy + wz);     R[4] = ww - xx + yy - zz; R[7] = 2.0 * (yz - wx);
-    R[2] = 2.0 * (xz - wy);     R[5] = 2.0 * (yz + wx);     R[8] = ww - xx - yy + zz;
-    return true;
-}
-
-// rank(H) <= 1:  H = sigma u v^T (or 0).  Every rotation with u R = v maximises sum R_ij H_ij; take the
-// smallest one (Rodrigues from u to v).  H = 0 (no gated correspondence): R = I, like torch.svd(0).
-__device__ void rank1_rotation(const double *S, double (&R)[9])
-{
-#pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    // v = direction of the largest row of H;  u = H v / |H v|  (signs consistent by construction)
-    int r = 0;
-    double best = -1.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double n2 = S[i * 3] * S[i * 3] + S[i * 3 + 1] * S[i * 3 + 1] + S[i * 3 + 2] * S[i * 3 + 2];
-        if (n2 > best) { best = n2; r = i; }
-    }
-    if (!(best > 0.0)) return;
-    const double iv = rsqrt(best);
-    const double v[3] = {S[r * 3] * iv, S[r * 3 + 1] * iv, S[r * 3 + 2] * iv};
-    double u[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) u[i] = S[i * 3] * v[0] + S[i * 3 + 1] * v[1] + S[i * 3 + 2] * v[2];
-    const double un2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-    if (!(un2 > 0.0)) return;
-    const double iu = rsqrt(un2);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) u[i] *= iu;
-    // column-convention Rc with Rc u = v:  Rc = c I + [w]x + w w^T / (1 + c),  w = u x v, c = u . v
-    const double c = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
-    double w[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
-    double Rc[9];
-    if (c > -1.0 + 1e-12) {
-        const double k = 1.0 / (1.0 + c);
-        Rc[0] = c + k * w[0] * w[0];    Rc[1] = k * w[0] * w[1] - w[2]; Rc[2] = k * w[0] * w[2] + w[1];
-        Rc[3] = k * w[1] * w[0] + w[2]; Rc[4] = c + k * w[1] * w[1];    Rc[5] = k * w[1] * w[2] - w[0];
-        Rc[6] = k * w[2] * w[0] - w[1]; Rc[7] = k * w[2] * w[1] + w[0]; Rc[8] = c + k * w[2] * w[2];
-    } else {
-        // v = -u: half turn about any axis a perpendicular to u,  Rc = 2 a a^T - I
-        const int m = (fabs(u[0]) <= fabs(u[1]) && fabs(u[0]) <= fabs(u[2])) ? 0 : (fabs(u[1]) <= fabs(u[2]) ? 1 : 2);
-        double e[3] = {0.0, 0.0, 0.0};
-        e[m] = 1.0;
-        double a[3] = {u[1] * e[2] - u[2] * e[1], u[2] * e[0] - u[0] * e[2], u[0] * e[1] - u[1] * e[0]};
-        const double ia = rsqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) a[i] *= ia;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) Rc[i * 3 + j] = 2.0 * a[i] * a[j] - (i == j ? 1.0 : 0.0);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rc[j * 3 + i];   // row convention
-}
+}  // namespace icpflow
+#include "kabsch.hpp"   // after ICPFLOW_STAMP: the solver carries the phase stamps of debug builds
+namespace icpflow {
 
 // ---------------------------------------------------------------------------------
 struct IcpParams {
@@ -1400,6 +1240,13 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
                       const GridScratch *grid, float *history, const IcpTeam *team, const IcpOpts &opts,
                       hipStream_t s)
 {
+    if (opts.arith == ICPFLOW_ARITH_FP32_REFERENCE) {   // study mode (icp_fp32.hip); api.hip validated the arguments
+        if (history == nullptr || opts.fp32Scratch == nullptr || maxIter > kHistIters ||
+            stopMode != ICPFLOW_STOP_REFERENCE_)
+            return hipErrorInvalidValue;
+        return launch_icp_fp32ref(X, Y, lenX, lenY, swap, prePose, B, N, thres, maxIter, relThr, state, ctrl, history,
+                                  opts.fp32Scratch, s);
+    }
     IcpParams p{};
     p.B = B;
     p.X = X; p.Y = Y; p.lenX = lenX; p.lenY = lenY; p.swap = swap; p.prePose = prePose; p.N = N;

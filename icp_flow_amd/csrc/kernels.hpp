@@ -144,7 +144,13 @@ struct IcpOpts {
     bool teams = true;             // several workgroups per large pair when the batch leaves CUs idle
     bool speculative = true;       // batch-global stop in ONE launch (false: one launch per iteration)
     LaunchProfile *profile = nullptr;
+    float *fp32Scratch = nullptr;  // ICPFLOW_ARITH_FP32_REFERENCE: [B,N,4] floats (neighbour and weight per point)
 };
+// icp_fp32.hip: the reference's fp32 operation order (study mode), batch-global stop via the history epilogue
+hipError_t launch_icp_fp32ref(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
+                              const uint8_t *swap, const float *prePose, int B, int N, double thres, int maxIter,
+                              double relThr, IcpState *state, IcpCtrl *ctrl, float *history, float *nnScratch,
+                              hipStream_t s);
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,

@@ -83,9 +83,29 @@ def transform_points_batch(xyz, pose):
     return torch.cat([moved[:, :, 0:3], xyz[:, :, 3:4]], dim=-1)
 
 
-def wmean(x, weight, eps=1e-9):
+def tree_sum(x, dim):
+    """Sum over `dim` in balanced pairwise order (halves added elementwise, zero padded to a power of two), in
+    x's dtype.  NOT torch's order: torch-CPU accumulates long runs sequentially per output element (error grows
+    like sqrt(n) ulps of the running total), GPU reductions -- the reference runs on CUDA -- are trees (log n).
+    Tests use this to show which of the reference's observables depend on the summation ORDER of its backend."""
+    x = x.movedim(dim, 0)
+    n = x.shape[0]
+    m = 1
+    while m < n:
+        m <<= 1
+    if m != n:
+        x = torch.cat([x, x.new_zeros((m - n,) + tuple(x.shape[1:]))], dim=0)
+    while x.shape[0] > 1:
+        h = x.shape[0] // 2
+        x = x[:h] + x[h:]
+    return x[0]
+
+
+def wmean(x, weight, eps=1e-9, sum_order=None):
     """pytorch3d.ops.utils.wmean(dim=-2, keepdim=True); weight may be bool."""
     w = weight[..., None]
+    if sum_order == "tree":
+        return tree_sum(x * w, -2).unsqueeze(-2) / w.sum(dim=-2, keepdim=True).clamp(eps)
     return (x * w).sum(dim=-2, keepdim=True) / w.sum(dim=-2, keepdim=True).clamp(eps)
 
 
@@ -174,7 +194,7 @@ def estimate_init_pose(args, src, dst):
 # --------------------------------------------------------------------------
 # ICP, utils_icp_pytorch3d.py
 # --------------------------------------------------------------------------
-def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None):
+def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_order=None):
     """utils_icp_pytorch3d.py:303-382 (estimate_scale=False, allow_reflection=False).
     X, Y [B,N,3] already mask-multiplied, weights bool [B,N].  y = x R + T.
 
@@ -186,13 +206,16 @@ def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None):
     if dtype is not None:
         X, Y = X.to(dtype), Y.to(dtype)
     b = X.shape[0]
-    mu_x = wmean(X, weights, eps)                                             # :314
-    mu_y = wmean(Y, weights, eps)                                             # :315
+    mu_x = wmean(X, weights, eps, sum_order)                                  # :314
+    mu_y = wmean(Y, weights, eps, sum_order)                                  # :315
     w = weights[:, :, None]
     Xc = (X - mu_x) * w                                                       # :318,324
     Yc = (Y - mu_y) * w                                                       # :319,325
     total = torch.clamp(weights.sum(1), eps)                                  # :326
-    H = torch.bmm(Xc.transpose(2, 1), Yc) / total[:, None, None]              # :335-336
+    if sum_order == "tree":   # the same 3x3 product, its sum over the points in pairwise order (see tree_sum)
+        H = tree_sum(Xc[:, :, :, None] * Yc[:, :, None, :], 1) / total[:, None, None]
+    else:
+        H = torch.bmm(Xc.transpose(2, 1), Yc) / total[:, None, None]          # :335-336
     U, S, V = torch.svd(H)                                                    # :339
     E = torch.eye(3, dtype=H.dtype)[None].repeat(b, 1, 1)
     E[:, -1, -1] = torch.det(torch.bmm(U, V.transpose(2, 1)))                 # :358-359
@@ -202,11 +225,12 @@ def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None):
 
 
 def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
-                            relative_rmse_thr=ICP_REL_RMSE, trace=False, kabsch_dtype=None):
+                            relative_rmse_thr=ICP_REL_RMSE, trace=False, kabsch_dtype=None, sum_order=None):
     """utils_icp_pytorch3d.py:100-225.  Returns a namespace with
     converged, rmse, Xt, R, T, iterations (number of loop bodies executed) and,
     with trace=True, the per-iteration (R, T, rmse, inlier count) history.
-    kabsch_dtype: see corresponding_points_alignment (None = the reference's fp32)."""
+    kabsch_dtype: see corresponding_points_alignment (None = the reference's fp32); sum_order: see tree_sum
+    (None = torch's own order)."""
     X0 = X[:, :, 0:3].clone()                                                 # :100,115
     Yt = Y[:, :, 0:3]
     b = X0.shape[0]
@@ -226,12 +250,12 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
         d2, _, nn = knn_points(Xt, Yt, n_x, n_y, return_nn=True)              # :154-157
         w = torch.logical_and(m0, d2 <= thr2)                                 # :160-161
         R, T = corresponding_points_alignment(X0 * w[:, :, None], nn * w[:, :, None], w,
-                                              dtype=kabsch_dtype)
+                                              dtype=kabsch_dtype, sum_order=sum_order)
         Xt = torch.bmm(X0, R) + T[:, None, :]                                 # :177,395
         sq = ((Xt - nn) ** 2).sum(2)                                          # :191
         if kabsch_dtype is not None:
             sq = sq.to(kabsch_dtype)
-        rmse = wmean(sq[:, :, None], w).sqrt()[:, 0, 0].to(X0.dtype)          # :192
+        rmse = wmean(sq[:, :, None], w, sum_order=sum_order).sqrt()[:, 0, 0].to(X0.dtype)   # :192
         rel = rmse.new_ones(b) if prev is None else (prev - rmse) / prev      # :195-198
         if trace:
             history.append((R.clone(), T.clone(), rmse.clone(), w.sum(-1).clone()))
@@ -243,11 +267,11 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
                            iterations=it + 1, history=history)
 
 
-def pytorch3d_icp(args, src, dst, max_iterations=ICP_MAX_ITER):
+def pytorch3d_icp(args, src, dst, max_iterations=ICP_MAX_ITER, kabsch_dtype=None, sum_order=None):
     """utils_icp.py:50-73: column-vector 4x4 from the row-vector (R, T)."""
     sol = iterative_closest_point(src, dst, thres=args.thres_dist,
                                   max_iterations=max_iterations,
-                                  relative_rmse_thr=ICP_REL_RMSE)
+                                  relative_rmse_thr=ICP_REL_RMSE, kabsch_dtype=kabsch_dtype, sum_order=sum_order)
     b = len(sol.T)
     M = torch.zeros(b, 4, 4)
     M[:, 0:3, 0:3] = sol.R.transpose(1, 2)                                    # :63-64
@@ -256,10 +280,12 @@ def pytorch3d_icp(args, src, dst, max_iterations=ICP_MAX_ITER):
     return M, sol
 
 
-def apply_icp(args, src, dst, init_poses, max_iterations=ICP_MAX_ITER, return_aux=False):
-    """utils_icp.py:20-48: ICP from the init pose, roll back where it did not help."""
+def apply_icp(args, src, dst, init_poses, max_iterations=ICP_MAX_ITER, return_aux=False, kabsch_dtype=None,
+              sum_order=None):
+    """utils_icp.py:20-48: ICP from the init pose, roll back where it did not help.
+    kabsch_dtype: see corresponding_points_alignment (None = the reference's fp32)."""
     moved = transform_points_batch(src, init_poses)                           # :21
-    M, sol = pytorch3d_icp(args, moved, dst, max_iterations)                  # :23
+    M, sol = pytorch3d_icp(args, moved, dst, max_iterations, kabsch_dtype, sum_order)   # :23
     M = torch.bmm(M, init_poses)                                              # :24
     valid = src[:, :, -1] > 0.0                                               # :27
     _, e0 = nearest_neighbor_batch(moved, dst)                                # :28
@@ -277,19 +303,23 @@ def apply_icp(args, src, dst, init_poses, max_iterations=ICP_MAX_ITER, return_au
 # --------------------------------------------------------------------------
 # orchestration + metrics, utils_match.py
 # --------------------------------------------------------------------------
-def hist_icp(args, src, dst, max_iterations=ICP_MAX_ITER, return_aux=False):
-    """utils_match.py:138-157."""
+def hist_icp(args, src, dst, max_iterations=ICP_MAX_ITER, return_aux=False, kabsch_dtype=None, init=None,
+             sum_order=None):
+    """utils_match.py:138-157.  kabsch_dtype: see corresponding_points_alignment (None = the reference's fp32);
+    init: initial poses of a previous call on the same batch (skips the vote and the scoring scans)."""
     n1 = (src[:, :, -1] > 0.0).sum(1)
     n2 = (dst[:, :, -1] > 0.0).sum(1)
     swap = n1 > n2                                                            # :142 (strict)
     a, b = src.clone(), dst.clone()
     a[swap] = dst[swap]
     b[swap] = src[swap]
-    init = estimate_init_pose(args, a, b)                                     # :149
+    if init is None:
+        init = estimate_init_pose(args, a, b)                                 # :149
     if return_aux:
-        M, aux = apply_icp(args, a, b, init, max_iterations, return_aux=True)
+        M, aux = apply_icp(args, a, b, init, max_iterations, return_aux=True, kabsch_dtype=kabsch_dtype,
+                           sum_order=sum_order)
     else:
-        M, aux = apply_icp(args, a, b, init, max_iterations), None            # :150
+        M, aux = apply_icp(args, a, b, init, max_iterations, kabsch_dtype=kabsch_dtype, sum_order=sum_order), None   # :150
     if int(swap.sum()) > 0:                                                   # :152
         M = M.clone()
         M[swap] = torch.linalg.inv(M[swap])                                   # :154

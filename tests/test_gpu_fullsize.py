@@ -1,0 +1,256 @@
+"""BASELINE's headline shapes through the C ABI against the oracle on the WHOLE batch.
+
+  * config 2 (256 cluster pairs x 1024 points, <= 50 ICP iterations, the reference's batch-global stop):
+    every pair of the batch against `rp.hist_icp` on the same batch -- initial poses, iteration count,
+    where the points end up (north_star: < 1e-4 m).
+  * the bins of the FUSED vote (the z-sorted kernel the bench times), bit for bit against the oracle.
+  * config 4's per-GPU shape (1024 pairs x 2048 points): size-independent properties on the whole shard,
+    the oracle on a 64-pair batch of it.
+
+Which pairs can the oracle pin?  The reference's tensors are fp32 and its answer for a pair that is still
+moving when the batch rule stops -- and the iteration at which the batch rule stops -- depend on the rounding of
+its own reductions, i.e. on the SUMMATION ORDER of the backend it runs on.  Measured: the fp32
+oracle on this very batch stops after 47 iterations with 8 torch threads and runs into the cap of 50 with 32
+(torch-CPU splits its sums by thread count); with its sums in pairwise order (`sum_order="tree"`, what a GPU
+reduction does -- and the reference runs on CUDA) it stops after 47, like its exact evaluation
+(`kabsch_dtype=torch.float64`: same formulas, same fp32 inputs) and like the HIP path.  So the test takes THREE
+evaluations of the oracle -- fp32 in torch's order, fp32 in pairwise order, Kabsch step in fp64 -- and calls a pair
+DETERMINED when all three agree to DETERMINED_TOL.  On every determined pair the HIP path must meet the north-star
+tolerance against the fp32 oracle in torch's order -- the reference's arithmetic as restated.  The mask is computed
+here, from the oracle alone, and its size is bounded, so a regression cannot hide in it.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from icp_flow_amd import _lib, synthetic, utils_hist, utils_match  # noqa: E402
+from oracle import core as ocore  # noqa: E402
+from oracle import reference_path as rp  # noqa: E402
+
+DEV = torch.device("cuda:0")
+TOL_M = 1e-4             # north_star: flow error vs reference < 1e-4 m
+DETERMINED_TOL = 2e-5    # the oracle's fp32 and fp64-Kabsch evaluations agree to this => the oracle pins the pair
+
+
+def G(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def C(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def displacement(Ta, Tb, clouds):
+    """Per pair: the largest distance (max over valid points and axes) between where Ta and Tb put a point."""
+    Ta, Tb = np.asarray(Ta, np.float64), np.asarray(Tb, np.float64)
+    p = clouds[:, :, :3].astype(np.float64)
+    ma = np.einsum("bij,bnj->bni", Ta[:, :3, :3], p) + Ta[:, None, :3, 3]
+    mb = np.einsum("bij,bnj->bni", Tb[:, :3, :3], p) + Tb[:, None, :3, 3]
+    d = np.abs(ma - mb).max(-1)
+    return np.where(clouds[:, :, 3] > 0, d, 0.0).max(1)
+
+
+def _all_host_threads():
+    # 32 threads: the many small torch ops of the oracle stop scaling there (256 threads: 80x SLOWER, measured)
+    n = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(n)
+    ocore.set_num_threads(n)
+
+
+def _oracle_three(args, S, D, cap):
+    """The oracle in the reference's fp32 (torch's summation order), in fp32 with pairwise sums, and with its
+    Kabsch step in fp64 -- all from the same initial poses.  -> dict of (T [B,4,4] numpy, aux) + the mask of
+    pairs on which the three agree to DETERMINED_TOL."""
+    _all_host_threads()
+    T32, aux32 = rp.hist_icp(args, C(S), C(D), max_iterations=cap, return_aux=True)
+    Ttr, auxtr = rp.hist_icp(args, C(S), C(D), max_iterations=cap, return_aux=True, sum_order="tree", init=aux32["init"])
+    T64, aux64 = rp.hist_icp(args, C(S), C(D), max_iterations=cap, return_aux=True, kabsch_dtype=torch.float64,
+                             init=aux32["init"])
+    T32, Ttr, T64 = T32.numpy(), Ttr.numpy(), T64.numpy()
+    self_dis = np.maximum.reduce([displacement(T32, T64, S), displacement(Ttr, T64, S), displacement(T32, Ttr, S)])
+    return dict(T32=T32, aux32=aux32, Ttr=Ttr, auxtr=auxtr, T64=T64, aux64=aux64, determined=self_dis < DETERMINED_TOL,
+                iters=f"fp32 oracle (torch order, {torch.get_num_threads()} threads) {aux32['iterations']}, fp32 oracle "
+                      f"(pairwise order) {auxtr['iterations']}, fp64-Kabsch oracle {aux64['iterations']}")
+
+
+# ------------------------------------------------------------------------------------------ config 2
+@pytest.fixture(scope="module")
+def config2():
+    S, D, _ = synthetic.make_batch(256, 1024, seed=0)
+    args = rp.default_args(max_points=1024, icp_max_iterations=50)
+    return dict(S=S, D=D, args=args, **_oracle_three(args, S, D, 50))
+
+
+def _report(name, err, ok):
+    return (f"{name}: {int((err < TOL_M).sum())}/{len(err)} pairs within {TOL_M:g} m, determined {int(ok.sum())}, "
+            f"max on determined {err[ok].max():.2e}, max overall {err.max():.2e}, worst {np.argsort(-err)[:6].tolist()}")
+
+
+def test_config2_full_batch_initial_poses_equal_the_oracle(config2):
+    c = config2
+    init = utils_hist.estimate_init_pose(c["args"], G(c["S"]), G(c["D"])).cpu().numpy()
+    assert np.array_equal(init, c["aux32"]["init"].numpy())
+
+
+def test_config2_full_batch_vs_oracle(config2):
+    """Default arithmetic (fp64 moments).  Iteration count = the oracle's when its sums are exact or pairwise;
+    every determined pair within 1e-4 m of the fp32 oracle; the undetermined pairs are few and are exactly the
+    ones on which the oracle disagrees with itself."""
+    c = config2
+    T, iters = utils_match.hist_icp(c["args"], G(c["S"]), G(c["D"]), return_iterations=True)
+    T = T.cpu().numpy()
+    assert np.isfinite(T).all()
+    determined = c["determined"]
+    err32 = displacement(T, c["T32"], c["S"])
+    errtr = displacement(T, c["Ttr"], c["S"])
+    err64 = displacement(T, c["T64"], c["S"])
+    msg = "\n".join([_report("HIP vs fp32 oracle (torch order)", err32, determined),
+                     _report("HIP vs fp32 oracle (pairwise order)", errtr, determined),
+                     _report("HIP vs fp64-Kabsch oracle", err64, determined),
+                     f"iterations HIP {int(iters)}, " + c["iters"],
+                     f"oracle self-disagreement > {DETERMINED_TOL:g} m on pairs {np.nonzero(~determined)[0].tolist()}"])
+    print(msg)
+    assert int(iters) == c["aux64"]["iterations"] == c["auxtr"]["iterations"], msg
+    assert determined.sum() >= 256 - 16, msg                 # the mask cannot swallow a regression
+    assert err32[determined].max() < TOL_M, msg              # the north-star bound, on every pair the oracle pins
+    assert errtr[determined].max() < TOL_M and err64[determined].max() < TOL_M, msg
+    assert (err64 < TOL_M).sum() >= 256 - 2, msg             # and against the exact evaluation nearly everywhere
+    # a pair outside the bound must be one of the oracle's own undetermined pairs
+    assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(np.nonzero(~determined)[0]), msg
+
+
+def test_config2_full_batch_fp32_reference_arithmetic(config2):
+    """ICPFLOW_ARITH_FP32_REFERENCE (a study mode): the Kabsch step in the reference's own fp32 operation order, its
+    sums as GPU tree reductions.  Same iteration count as the pairwise-order fp32 oracle and the exact evaluations
+    (it is the ORDER of long fp32 accumulations, not fp32 itself, that keeps torch-CPU from converging); fp32
+    rounding moves individual slowly-converging pairs by a few 1e-4 m, which is the scatter the reference's own
+    CUDA run has against any other evaluation of itself."""
+    c = config2
+    with _lib.options(arith="fp32_reference"):
+        T, iters = utils_match.hist_icp(c["args"], G(c["S"]), G(c["D"]), return_iterations=True)
+    T = T.cpu().numpy()
+    assert np.isfinite(T).all()
+    err32 = displacement(T, c["T32"], c["S"])
+    msg = (_report("HIP fp32-reference arithmetic vs fp32 oracle", err32, c["determined"])
+           + f"\niterations HIP {int(iters)}, " + c["iters"])
+    print(msg)
+    assert int(iters) == c["auxtr"]["iterations"], msg
+    assert (err32 < TOL_M).sum() >= 256 - 10 and err32[c["determined"]].max() < 1e-3, msg
+
+
+# ------------------------------------------------------------------------------------------ fused vote bins
+def _wide_pair(n, seed):
+    """A wall: 24 m x 0.4 m x 2.6 m, n points -- wider than the 8 m above which the vote sorts by the composite
+    key (votekey.hpp) -- and the same wall 0.7 m further along, re-sampled."""
+    r = np.random.default_rng(seed)
+    def wall(m):
+        p = np.stack([r.uniform(0, 24.0, m), r.uniform(0, 0.4, m), r.uniform(0, 2.6, m)], 1)
+        return p + np.array([12.0, -30.0, 0.2])
+    def pad(p):
+        out = np.zeros((n, 4), np.float32)
+        out[:, :3] = p
+        out[:, 3] = 1.0
+        return out
+    return pad(wall(n)), pad(wall(n) + np.array([0.7, 0.05, 0.0]))
+
+
+def _fused_cases():
+    S2, D2, _ = synthetic.make_batch(256, 1024, seed=0)
+    Sr, Dr, _ = synthetic.make_batch(24, 700, seed=11, ragged=True)
+    w = [_wide_pair(3000, s) for s in (1, 2)]
+    Sw, Dw = np.stack([a for a, _ in w]), np.stack([b for _, b in w])
+    Sc, Dc, _ = synthetic.make_batch(3, 6000, seed=5)
+    Sc[1, 4000:] = (1e8, 1e8, 1e8, 0.0)                      # one shorter cloud in the chunk-sorted batch
+    Sg, Dg, _ = synthetic.make_batch(6, 900, seed=21, ragged=True)
+    return {"config2_256x1024_tf2": (S2, D2, 2.0), "ragged_24x700_tf2": (Sr, Dr, 2.0),
+            "wide_cluster_composite_key_tf3p34": (Sw, Dw, 3.34), "chunked_sort_N6000_tf2": (Sc, Dc, 2.0),
+            "global_atomics_269_bins_tf13p36": (Sg, Dg, 13.36)}
+
+
+@pytest.mark.parametrize("case", ["config2_256x1024_tf2", "ragged_24x700_tf2", "wide_cluster_composite_key_tf3p34",
+                                  "chunked_sort_N6000_tf2", "global_atomics_269_bins_tf13p36"])
+@pytest.mark.parametrize("entry", ["estimate_init_pose", "hist_icp"])
+def test_fused_vote_bins_bit_exact(case, entry):
+    """The vote that the registration path actually runs (zsort_kernel + hist_vote_sorted_kernel, composite key for
+    wide clusters, chunked sort above 4096 points, global atomics for histograms beyond the LDS): its uint32 bins,
+    exported through icpflow_options_t.d_vote_bins_u32, equal the oracle's vote (hist_cuda_core.cuh:40-60) bin for
+    bin.  Through hist_icp the clouds of swapped pairs vote in exchanged roles (utils_match.py:139-146)."""
+    S, D, tf = _fused_cases()[case]
+    _all_host_threads()
+    a = rp.default_args(max_points=S.shape[1], translation_frame=tf, icp_max_iterations=2)
+    ex, ey, ez = rp.bin_edges(a)
+    L = len(ex) * len(ey) * len(ez)
+    bins = torch.full((len(S), L), -1, dtype=torch.int32, device=DEV)      # uint32 on the device, every bin overwritten
+    with _lib.options(vote_bins=bins):
+        if entry == "estimate_init_pose":
+            utils_hist.estimate_init_pose(a, G(S), G(D))
+            src, dst = C(S), C(D)
+        else:
+            utils_match.hist_icp(a, G(S), G(D))
+            n1, n2 = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
+            sw = n1 > n2                                                            # utils_match.py:142
+            src, dst = C(S).clone(), C(D).clone()
+            src[sw], dst[sw] = C(D)[sw], C(S)[sw]
+    want = rp.hist(dst, src, ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), len(ex), len(ey), len(ez))
+    got = bins.cpu().numpy().view(np.uint32).astype(np.int64)
+    want = want.numpy().reshape(len(S), L).astype(np.int64)
+    assert want.sum() > 0
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} bins differ"
+
+
+# ------------------------------------------------------------------------------------------ config 4 (per-GPU shape)
+@pytest.fixture(scope="module")
+def config4_shard():
+    """Rank 0's shard of BASELINE config 4 (8192 x 2048 over 8 GPUs): pairs 0..1023, 2048 points each."""
+    S, D, Tt = synthetic.make_batch(1024, 2048, seed=0)
+    return S, D, Tt
+
+
+def test_config4_shard_properties(config4_shard):
+    """1024 pairs x 2048 points in one call: finite, motion recovered on the shared-sample pairs, running the
+    shard in two halves changes nothing but what the batch-global stop couples (iteration counts), and the result
+    is reproducible bit for bit."""
+    S, D, Tt = config4_shard
+    a = rp.default_args(max_points=2048, icp_max_iterations=50)
+    s, d = G(S), G(D)
+    T, iters = utils_match.hist_icp(a, s, d, return_iterations=True)
+    T2 = utils_match.hist_icp(a, s, d)
+    assert torch.equal(T, T2)                                           # run-to-run bit-reproducible
+    T = T.cpu().numpy()
+    assert np.isfinite(T).all() and 1 <= int(iters) <= 50
+    err = displacement(T, Tt, S)
+    assert np.median(err[0::2]) < 0.005 and err[0::2].max() < 0.03     # shared-sample pairs: the true motion
+    # the initial poses do not depend on the batch: the first 64 pairs alone give the same ones
+    i_full = utils_hist.estimate_init_pose(a, s, d)
+    i_part = utils_hist.estimate_init_pose(a, s[:64].contiguous(), d[:64].contiguous())
+    assert torch.equal(i_full[:64], i_part)
+    # per-pair stop: every pair on its own; same poses wherever the batch rule had converged pairs waiting
+    ap = rp.default_args(max_points=2048, icp_max_iterations=50, icp_stop_mode="per_pair")
+    Tp = utils_match.hist_icp(ap, s, d).cpu().numpy()
+    assert np.percentile(displacement(T, Tp, S), 90) < TOL_M
+
+
+def test_config4_shape_64_pair_batch_vs_oracle(config4_shard):
+    S, D, _ = config4_shard
+    S, D = S[:64], D[:64]
+    a = rp.default_args(max_points=2048, icp_max_iterations=50)
+    o = _oracle_three(a, S, D, 50)
+    init = utils_hist.estimate_init_pose(a, G(S), G(D)).cpu().numpy()
+    assert np.array_equal(init, o["aux32"]["init"].numpy())
+    T, iters = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+    T = T.cpu().numpy()
+    determined = o["determined"]
+    err32 = displacement(T, o["T32"], S)
+    msg = _report("HIP vs fp32 oracle (64 x 2048)", err32, determined) + f"\niterations HIP {int(iters)}, " + o["iters"]
+    print(msg)
+    assert int(iters) == o["aux64"]["iterations"] == o["auxtr"]["iterations"], msg
+    assert determined.sum() >= 64 - 8, msg
+    assert err32[determined].max() < TOL_M, msg
+    assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(np.nonzero(~determined)[0]), msg
