@@ -37,10 +37,16 @@
 #include <omp.h>
 #endif
 
+/* Threads of THIS library's loops only (a num_threads clause on its own parallel regions).  The OpenMP runtime is
+ * shared with torch-CPU in the same process: omp_set_num_threads() here would also change the thread count of
+ * every torch op of the oracle (measured on a 256-core host: 256 threads for the oracle's many small torch ops
+ * make it 80x slower). */
+static int g_threads = 0;   /* 0 = the runtime's default */
+
 int oracle_num_threads(void)
 {
 #if defined(_OPENMP)
-    return omp_get_max_threads();
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
 #else
     return 1;
 #endif
@@ -48,11 +54,7 @@ int oracle_num_threads(void)
 
 void oracle_set_num_threads(int n)
 {
-#if defined(_OPENMP)
-    if (n > 0) omp_set_num_threads(n);
-#else
-    (void)n;
-#endif
+    if (n > 0) g_threads = n;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -70,7 +72,7 @@ void oracle_hist_vote(const float *X, const float *Y, int B, int NX, int NY,
     const float flx = (float)len_x, fly = (float)len_y, flz = (float)len_z;
     const float rx = max_x - min_x, ry = max_y - min_y, rz = max_z - min_z;
 
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_num_threads())
     for (int b = 0; b < B; ++b) {
         const float *xb = X + (size_t)b * NX * 4;
         const float *yb = Y + (size_t)b * NY * 4;
@@ -143,7 +145,7 @@ void oracle_knn1(const float *P1, const float *P2, int B, int N1, int N2,
                  int s1, int s2, const int64_t *len1, const int64_t *len2,
                  int64_t *idx, float *d2, float *nn)
 {
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_num_threads())
     for (int b = 0; b < B; ++b) {
         int l1 = len1 ? (int)len1[b] : N1;
         int l2 = len2 ? (int)len2[b] : N2;

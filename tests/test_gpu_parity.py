@@ -482,7 +482,11 @@ def test_hist_icp_real_data_shape_large_padding():
     got, iters = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
     want, aux = rp.hist_icp(a, C(S), C(D), max_iterations=12, return_aux=True)
     assert int(iters) == aux["iterations"]
-    assert_pose_close(got.cpu().numpy(), want.numpy(), S, tol=2e-4)   # 10^4-point fp32 reductions in the oracle
+    assert_pose_close(got.cpu().numpy(), want.numpy(), S, tol=2e-4)   # torch-CPU's long sequential fp32 accumulations
+    # the same fp32 oracle with its sums in pairwise order (what a GPU reduction -- the reference's CUDA run -- does):
+    # the north-star tolerance holds
+    want_tree = rp.hist_icp(a, C(S), C(D), max_iterations=12, sum_order="tree", init=aux["init"])
+    assert_pose_close(got.cpu().numpy(), want_tree.numpy(), S, tol=TOL_M)
     ev = utils_match.match_eval(a, G(S), G(D), got)
     wv = rp.match_eval(a, C(S), C(D), got.cpu())
     np.testing.assert_allclose(ev[0].cpu().numpy(), wv[0].numpy(), atol=1e-5, rtol=1e-4)
@@ -569,17 +573,22 @@ def test_hist_icp_under_stream_capture_and_on_two_streams():
 
 # ------------------------------------------------------------------ 8(f): association + flow on the demo frame
 @all_icp_searches
-def test_demo_frame_pair_track_and_flow_vs_reference():
+@pytest.mark.parametrize("fixture", ["g8_demo", "g8_demo_mp10000"])
+def test_demo_frame_pair_track_and_flow_vs_reference(fixture):
     """BASELINE config 1 (G8): demo.npz frame pair through the HIP path -- match_pcds (both stages:
     sanity_check, gather/pad, hist_icp, match_eval, reject, arg-min) and the flow kernel -- against
-    the reference's own pairs / transforms / per-point flow (63 276 points)."""
+    the reference's own pairs / transforms / per-point flow (63 276 points), at max_points 2048 and at the
+    reference's real setting, max_points 10000 (demo.sh:9-13; the 30 000-point wall is subsampled with the
+    reference's own torch.randperm stream, the ICP of the large clusters runs as a team of workgroups)."""
     from icp_flow_amd import utils_flow, utils_track
-    g = load_golden("g8_demo")
+    g0 = load_golden("g8_demo")
+    g = load_golden(fixture)
     lab = load_golden("g8_demo_labels")
     a = rp.default_args(max_points=int(g["max_points"]), min_cluster_size=20, translation_frame=2.0,
                         thres_box=0.1, thres_rot=0.1, thres_error=0.2, thres_iou=0.2)
+    assert a.max_points == (2048 if fixture == "g8_demo" else 10000)
     torch.manual_seed(0)
-    ps, pd = G(g["point_src"]), G(g["point_dst"])
+    ps, pd = G(g0["point_src"]), G(g0["point_dst"])
     ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
     pairs, Tm = utils_track.track(a, ps, pd, ls, ld)
     flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, torch.eye(4, device=DEV))
@@ -593,14 +602,17 @@ def test_demo_frame_pair_track_and_flow_vs_reference():
     np.testing.assert_allclose(pairs[order][:, 2:4], ref_pairs[:, 2:4], atol=2e-4)        # errors
     np.testing.assert_allclose(pairs[order][:, 4:6], ref_pairs[:, 4:6], atol=2)            # inlier counts
     err = np.linalg.norm(flow - ref_flow, axis=1)
-    frac = float(np.mean(err < TOL_M))
-    assert frac >= 0.97, f"per-point flow within 1e-4 m of the reference on {frac:.4f} of the points, max {err.max():.3e}"
+    lsrc = lab["label_src"]
+    worst = sorted(((float(err[lsrc == p[0]].max()), int(p[0]), int((lsrc == p[0]).sum())) for p in ref_pairs), reverse=True)[:4]
+    print(f"{fixture}: flow vs reference max {err.max():.3e} m, within 1e-4 m on {np.mean(err < TOL_M):.5f} of the points; "
+          f"worst clusters (max err, label, points) {worst}")
+    assert err.max() < TOL_M, f"per-point flow differs from the reference's by up to {err.max():.3e} m; worst clusters {worst}"
     # the flow kernel alone, fed with the reference's pairs / transforms
     flow2 = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, G(ref_pairs), G(ref_T), torch.eye(4, device=DEV))
     np.testing.assert_allclose(flow2.cpu().numpy(), ref_flow, atol=2e-5)
     # EPE against ground truth equals the reference's (utils_eval.py:137-182 epe3d)
-    epe = float(np.linalg.norm(flow - g["gt_flow"], axis=1).mean())
-    assert abs(epe - float(g["epe"])) < 2e-4
+    epe = float(np.linalg.norm(flow - g0["gt_flow"], axis=1).mean())
+    assert abs(epe - float(g["epe"])) < 1e-4
 
 
 def test_cluster_stats_kernel_vs_torch():

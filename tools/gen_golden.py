@@ -280,18 +280,21 @@ def g6_hist_icp():
          ev_ious=ev[3].numpy(), ev_translations=ev[4].numpy(), ev_rotations=ev[5].numpy())
 
 
-def g8_demo():
+def g8_demo(max_points=2048, name="g8_demo"):
     """BASELINE config 1: the reference's demo frame pair (demo.npz) through the reference's own
     match_pcds (both association stages) and flow_estimation_torch, on CPU.  Cluster labels come
     from sklearn's HDBSCAN through the reference's cluster_pcd (the pinned `hdbscan` package is
     not installable), so the labels are part of the fixture.  max_points = 2048 keeps the
-    reference's padded N^2 scans tractable on CPU (SURVEY A.8 probe 3)."""
+    reference's padded N^2 scans tractable on CPU (SURVEY A.8 probe 3); `g8mp10000` is the same run at the
+    reference's real setting, max_points = 10000 (demo.sh:9-13): 16 padded 10^4 x 10^4 scans per pair through
+    oracle_core.c -- the over-long clusters are subsampled with the reference's own torch.randperm stream
+    (seed 0, main.py:139)."""
     import utils_flow  # noqa: E402  (reference)
     data = np.load(os.path.join(REF, "demo.npz"))
     src = data["pc1"][data["pc1_flows_valid_idx"]].astype(np.float32)      # demo.py:37-51
     dst = data["pc2"][data["pc2_flows_valid_idx"]].astype(np.float32)
     gt = data["gt_flow_0_1"][data["pc1_flows_valid_idx"]].astype(np.float32)
-    a = args_ns(max_points=2048, min_cluster_size=20, num_clusters=200, epsilon=0.25, if_hdbscan=True,
+    a = args_ns(max_points=max_points, min_cluster_size=20, num_clusters=200, epsilon=0.25, if_hdbscan=True,
                 translation_frame=2.0, thres_dist=0.1, thres_box=0.1, thres_rot=0.1, thres_error=0.2,
                 thres_iou=0.2, chunk_size=50)
     lab_path = os.path.join(OUT, "g8_demo_labels.npz")
@@ -313,7 +316,8 @@ def g8_demo():
                                             pairs=pairs, transformations=T, pose=torch.eye(4))
     epe = float(np.linalg.norm(flow.numpy() - gt, axis=1).mean())
     print(f"  demo: {len(pairs)} matched pairs, EPE vs gt {epe:.4f} m (zero flow {np.linalg.norm(gt, axis=1).mean():.4f})")
-    save("g8_demo", point_src=src, point_dst=dst, gt_flow=gt, pairs=pairs.numpy(), transformations=T.numpy(),
+    inputs = dict(point_src=src, point_dst=dst, gt_flow=gt) if name == "g8_demo" else {}    # the inputs live in g8_demo.npz
+    save(name, **inputs, pairs=pairs.numpy(), transformations=T.numpy(),
          flow=flow.numpy(), max_points=np.array(a.max_points), epe=np.array(epe))
 
 
@@ -456,7 +460,11 @@ def g11_hdbscan():
     save("g11_hdbscan", **out)
 
 
-GENS = dict(g11=g11_hdbscan, g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
+def g8_demo_mp10000():
+    g8_demo(max_points=10000, name="g8_demo_mp10000")
+
+
+GENS = dict(g8mp10000=g8_demo_mp10000, g11=g11_hdbscan, g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -464,7 +472,7 @@ if __name__ == "__main__":
     ns = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g9", "g10", "g11")]   # g8: ~3 min, on request
+    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g8mp10000", "g9", "g10", "g11")]   # g8: ~3 min, on request
     for k in want:
         print(f"== {k}")
         GENS[k]()
