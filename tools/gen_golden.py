@@ -74,7 +74,7 @@ def ragged_batch(B, N, seed, first=0, n_min=20):
 
 
 
-def cut_is_tied(a, src, dst, swap_smaller_first=False):
+def cut_is_tied(a, src, dst, swap_smaller_first=False, any_votes=False):
     """True where the 5th and 6th surviving peak share a POSITIVE vote count: which peaks make
     the top-5 then depends on torch.topk's implementation-defined tie order, so
     the chosen initial pose of that pair is not a portable expectation."""
@@ -94,6 +94,8 @@ def cut_is_tied(a, src, dst, swap_smaller_first=False):
     xp = torch.nn.functional.max_pool3d(h[:, None], kernel_size=11, stride=1, padding=5)
     surv = (h[:, None] * (h[:, None] == xp).float()).reshape(len(h), -1)
     top = torch.sort(surv, dim=1, descending=True)[0][:, :6]
+    if any_votes:   # fewer than five positive peaks: zero-vote bins complete the top-5 in implementation-defined order
+        return (top[:, 4] == top[:, 5]).numpy()
     return ((top[:, 4] == top[:, 5]) & (top[:, 4] > 0)).numpy()
 
 
@@ -311,13 +313,57 @@ def g8_demo(max_points=2048, name="g8_demo"):
     torch.manual_seed(0)                                                         # main.py:139
     ps, pd = torch.from_numpy(src), torch.from_numpy(dst)
     ls, ld = torch.from_numpy(label_src).float(), torch.from_numpy(label_dst).float()
-    pairs, T = utils_match.match_pcds(a, ps, pd, ls, ld)
+    # Per association stage, what the reference's own functions return on the way (observers around its unmodified
+    # code): the candidate pairs, the initial poses of estimate_init_pose (smaller cloud first), whether the cut
+    # between the 5th and 6th surviving peak is tied (torch.topk's order among equal votes is implementation-defined:
+    # the pose of such a pair -- and, through the batch-global stop, the iteration count of its whole batch -- is not
+    # a portable expectation), the ICP iteration count and hist_icp's transforms.
+    stages = []
+    orig = dict(pairs=utils_match.match_pairs, init=utils_match.estimate_init_pose, icp=utils_icp.iterative_closest_point,
+                hist_icp=utils_match.hist_icp)
+
+    def match_pairs_obs(args, sp, dp, sl, dl, prs):
+        stages.append(dict(pairs=prs.numpy().astype(np.float32)))
+        return orig["pairs"](args, sp, dp, sl, dl, prs)
+
+    def init_obs(args, s_, d_):
+        out = orig["init"](args, s_, d_)
+        stages[-1]["init"] = out.numpy().copy()
+        stages[-1]["tied"] = cut_is_tied(args, s_, d_, any_votes=True)
+        return out
+
+    def icp_obs(*x, **kw):
+        sol = orig["icp"](*x, **kw)
+        stages[-1]["iterations"] = len(sol.t_history)
+        stages[-1]["converged"] = bool(sol.converged)
+        return sol
+
+    def hist_icp_obs(args, s_, d_):
+        out = orig["hist_icp"](args, s_, d_)
+        stages[-1]["T"] = out.numpy().copy()
+        return out
+
+    utils_match.match_pairs, utils_match.estimate_init_pose = match_pairs_obs, init_obs
+    utils_icp.iterative_closest_point, utils_match.hist_icp = icp_obs, hist_icp_obs
+    try:
+        pairs, T = utils_match.match_pcds(a, ps, pd, ls, ld)
+    finally:
+        utils_match.match_pairs, utils_match.estimate_init_pose = orig["pairs"], orig["init"]
+        utils_icp.iterative_closest_point, utils_match.hist_icp = orig["icp"], orig["hist_icp"]
+    stage_arrays = dict(stage_sizes=np.array([len(st["pairs"]) for st in stages]),
+                        stage_pairs=np.concatenate([st["pairs"] for st in stages]),
+                        stage_init=np.concatenate([st["init"] for st in stages]),
+                        stage_tied=np.concatenate([st["tied"] for st in stages]),
+                        stage_T=np.concatenate([st["T"] for st in stages]),
+                        stage_iterations=np.array([st["iterations"] for st in stages]),
+                        stage_converged=np.array([st["converged"] for st in stages]))
+    print("  stages:", [(len(st["pairs"]), st["iterations"], st["converged"], int(st["tied"].sum())) for st in stages])
     flow = utils_flow.flow_estimation_torch(a, src_points=ps, dst_points=pd, src_labels=ls, dst_labels=ld,
                                             pairs=pairs, transformations=T, pose=torch.eye(4))
     epe = float(np.linalg.norm(flow.numpy() - gt, axis=1).mean())
     print(f"  demo: {len(pairs)} matched pairs, EPE vs gt {epe:.4f} m (zero flow {np.linalg.norm(gt, axis=1).mean():.4f})")
     inputs = dict(point_src=src, point_dst=dst, gt_flow=gt) if name == "g8_demo" else {}    # the inputs live in g8_demo.npz
-    save(name, **inputs, pairs=pairs.numpy(), transformations=T.numpy(),
+    save(name, **inputs, **(stage_arrays if name != "g8_demo" else {}), pairs=pairs.numpy(), transformations=T.numpy(),
          flow=flow.numpy(), max_points=np.array(a.max_points), epe=np.array(epe))
 
 
