@@ -16,6 +16,15 @@ num_clusters (/ epsilon): both clouds stacked dst-first and clustered jointly as
 dataset_argo.py:119 do, utils_cluster.cluster_pcd; optional keys nonground_src /
 nonground_dst mark the rows to cluster).
 
+A Waymo / nuScenes sample of the reference (dataset_pca.py:41-45: one npz per SEQUENCE with raw_points,
+time_indice, ..., and the ego poses under `ego_motion` -- the reference's <split>_pose files -- or
+`ego_motion_gt`) is a multi-gap sample: `load_sequence` turns it into the num_frames - 1 frame pairs
+(frame j -> frame 0, j = 1 .. num_frames - 1) the reference's loop registers (dataset_pca.py:164-198,
+main.py:189-200): source = frame j moved by its ego pose, destination = frame 0, translation_frame =
+2 * max(speed * j, |ego translation of frame j|), flow on the RAW source points with the ego pose composed
+in (main.py:230-234, utils_flow.py:23-50).  Ground segmentation is upstream (BASELINE: "precomputed"): a
+`nonground` key [m] marks the rows to cluster; without it every point is clustered.
+
 `run_stream` registers every pair of a directory (round-robin over ranks: frame pairs are
 independent, main.py:184), and reports ms / frame pair and the reference's accuracy metrics.
 
@@ -36,7 +45,7 @@ from . import utils_eval, utils_flow, utils_track
 # demo.sh:9-13 / main.sh flags of the registration stage
 DEFAULT_ARGS = dict(max_points=10000, min_cluster_size=20, translation_frame=2.0, thres_dist=0.1, thres_box=0.1,
                     thres_rot=0.1, thres_error=0.2, thres_iou=0.2, chunk_size=50, speed=None,
-                    cluster=None, epsilon=0.25, num_clusters=200)
+                    cluster=None, epsilon=0.25, num_clusters=200, range_x=None, range_y=None)
 
 
 def default_args(**over):
@@ -47,7 +56,7 @@ def default_args(**over):
 
 class FramePair:
     def __init__(self, points_src, points_dst, labels_src=None, labels_dst=None, pose=None, gt_flow=None, mask=None,
-                 name="", nonground_src=None, nonground_dst=None):
+                 name="", nonground_src=None, nonground_dst=None, gap=1, points_src_raw=None):
         self.points_src = np.ascontiguousarray(points_src, dtype=np.float32)[:, 0:3]
         self.points_dst = np.ascontiguousarray(points_dst, dtype=np.float32)[:, 0:3]
         if (labels_src is None) != (labels_dst is None):
@@ -65,11 +74,19 @@ class FramePair:
                              f"({len(self.labels_src)}/{len(self.points_src)} src, "
                              f"{len(self.labels_dst)}/{len(self.points_dst)} dst)")
         self.pose = np.eye(4, dtype=np.float32) if pose is None else np.asarray(pose, dtype=np.float32).reshape(4, 4)
+        # the pose as given (the reference's ego poses are float64 and main.py:200 takes their norm as such)
+        self.pose_exact = np.eye(4) if pose is None else np.asarray(pose, dtype=np.float64).reshape(4, 4)
         self.gt_flow = None if gt_flow is None else np.asarray(gt_flow, dtype=np.float32)
         if self.gt_flow is not None and self.gt_flow.shape != self.points_src.shape:
             raise ValueError(f"frame pair {name!r}: gt_flow must be [Ns,3]")
         self.mask = None if mask is None else np.asarray(mask)
         self.name = name
+        # multi-gap samples (Waymo / nuScenes): frame `gap` against frame 0; the flow is reported on the source
+        # points BEFORE ego-motion compensation (main.py:230-234), registration runs on the compensated ones
+        self.gap = int(gap)
+        self.points_src_raw = None if points_src_raw is None else np.ascontiguousarray(points_src_raw, dtype=np.float32)[:, 0:3]
+        if self.points_src_raw is not None and self.points_src_raw.shape != self.points_src.shape:
+            raise ValueError(f"frame pair {name!r}: points_src_raw must match points_src")
 
 
 def save_frame_pair(path, fp):
@@ -105,6 +122,69 @@ def load_frame_pair(path):
             return FramePair(z["pc1"][v0], z["pc2"][v1], labels_src, labels_dst, first("pose"), gt, first("mask"),
                              name=os.path.basename(path), **ng)
         raise ValueError(f"{path}: neither points_src/points_dst nor pc1/pc2 present")
+
+
+def is_sequence(path):
+    with np.load(path) as z:
+        return "raw_points" in z.files and "time_indice" in z.files
+
+
+def _pose_file(path):
+    """The reference keeps estimated ego poses next to the split: .../val/x.npz -> .../val_pose/x.npz, key
+    `ego_motion` (dataset_pca.py:118-125)."""
+    for folder in ("train", "val", "test"):
+        if folder in path:
+            cand = path.replace(folder, folder + "_pose")
+            return cand if os.path.isfile(cand) else None
+    return None
+
+
+def load_sequence(path, args=None):
+    """A multi-frame sample in the reference's Waymo / nuScenes format (dataset_pca.py:41-45) -> the list of
+    frame pairs of the reference's loop, gap j = 1 .. num_frames - 1 (dataset_pca.py:164-198).
+    Keys: raw_points [m,>=3], time_indice [m] (0 .. F-1), ego poses [F,4,4] under `ego_motion` (the reference's
+    <split>_pose files, dataset_pca.py:122-125) or `ego_motion_gt`; optional nonground [m] (ground segmentation is
+    upstream), scene_flow [m,3] (ground truth, dataset_pca.py:67-69), labels [m] (precomputed per-frame cluster
+    labels are NOT possible in this format: frames are clustered jointly per gap).  args.range_x / range_y crop
+    the scene like dataset_pca.py:61-64."""
+    with np.load(path) as z:
+        keys = set(z.files)
+        raw = np.asarray(z["raw_points"])[:, 0:3].astype(np.float64)
+        t = np.asarray(z["time_indice"]).astype(np.int64)
+        side = _pose_file(path)
+        if side is not None:
+            with np.load(side) as zp:
+                poses = np.asarray(zp["ego_motion"]).astype(np.float64)
+        else:
+            poses = np.asarray(z["ego_motion"] if "ego_motion" in keys else z["ego_motion_gt"]).astype(np.float64)
+        nonground = np.asarray(z["nonground"]).astype(bool) if "nonground" in keys else None
+        gt = np.asarray(z["scene_flow"])[:, 0:3].astype(np.float32) if "scene_flow" in keys else None
+    if raw.shape[0] != t.shape[0] or poses.shape[1:] != (4, 4) or poses.shape[0] != t.max() + 1:
+        raise ValueError(f"{path}: raw_points / time_indice / ego poses do not describe one sequence")
+    rx, ry = (getattr(args, "range_x", None), getattr(args, "range_y", None)) if args is not None else (None, None)
+    if rx is not None and ry is not None:
+        keep = (np.abs(raw[:, 0]) < rx) & (np.abs(raw[:, 1]) < ry)                  # dataset_pca.py:61-64
+        raw, t = raw[keep], t[keep]
+        nonground = None if nonground is None else nonground[keep]
+        gt = None if gt is None else gt[keep]
+    out = []
+    dst = raw[t == 0]
+    for j in range(1, poses.shape[0]):
+        m = t == j
+        src_raw = raw[m]
+        hom = np.concatenate([src_raw, np.ones((len(src_raw), 1))], axis=1)
+        src_ego = (hom @ poses[j].T)[:, 0:3]                                          # utils_helper.py:89-93
+        out.append(FramePair(src_ego, dst, None, None, poses[j], None if gt is None else gt[m], None,
+                             name=f"{os.path.basename(path)}#gap{j}",
+                             nonground_src=None if nonground is None else nonground[m],
+                             nonground_dst=None if nonground is None else nonground[t == 0],
+                             gap=j, points_src_raw=src_raw))
+    return out
+
+
+def load_any(path, args=None):
+    """-> list of FramePair: one for a frame-pair file, num_frames - 1 for a sequence file."""
+    return load_sequence(path, args) if is_sequence(path) else [load_frame_pair(path)]
 
 
 def list_frame_pairs(directory):
@@ -144,11 +224,11 @@ def cluster_frame_pair(args, ps, pd, nonground_src=None, nonground_dst=None):
     return labels[len(pd):].contiguous(), labels[: len(pd)].contiguous()
 
 
-def register_frame_pair(args, fp, device, gap=1):
+def register_frame_pair(args, fp, device, gap=None):
     """One frame pair through (cluster_pcd when it carries no labels +) track() + flow_estimation_torch() on
     `device`.  -> dict(pairs [P,10], transformations [P,4,4], flow [Ns,3]) of device tensors."""
     a = SimpleNamespace(**vars(args))
-    a.translation_frame = frame_translation(args, fp.pose, gap)
+    a.translation_frame = frame_translation(args, fp.pose_exact, fp.gap if gap is None else gap)
     ps = torch.from_numpy(fp.points_src).to(device)
     pd = torch.from_numpy(fp.points_dst).to(device)
     if fp.labels_src is None:
@@ -162,8 +242,14 @@ def register_frame_pair(args, fp, device, gap=1):
     a.generator = torch.Generator()
     a.generator.manual_seed(0)
     pairs, T = utils_track.track(a, ps, pd, ls, ld)
-    flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, T, pose)
-    return dict(pairs=pairs, transformations=T, flow=flow)
+    if fp.points_src_raw is not None:
+        # multi-gap sample: flow of the RAW source points, the ego pose composed in (main.py:230-234; T registers the
+        # ego-compensated cloud, so a point moves by T * pose)
+        flow = utils_flow.flow_estimation_torch(a, torch.from_numpy(fp.points_src_raw).to(device), pd, ls, ld, pairs, T, pose)
+    else:
+        # frame-pair files hand over ego-compensated clouds; their `pose` (identity in demo.py:221) is composed as given
+        flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, T, pose)
+    return dict(pairs=pairs, transformations=T, flow=flow, translation_frame=a.translation_frame)
 
 
 def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, register_fn=None):
@@ -183,8 +269,7 @@ def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, regis
     mine = shard_round_robin(paths, rank, world)
     meter = utils_eval.AverageMeter()
     times, matched = [], 0
-    for path in mine:
-        fp = load_frame_pair(path)
+    for fp in (fp for path in mine for fp in load_any(path, args)):   # a sequence file yields one pair per gap
         if repeat > 1:
             register_fn(args, fp, device)                   # untimed pass: page-in, allocator
         sync()

@@ -126,3 +126,54 @@ def make_frame_pair(seed=0, n_objects=24, n_min=30, n_max=1500, relabel=0.25, n_
     return dict(points_src=f32(ps, perm_s), points_dst=f32(pd, perm_d), labels_src=f32(ls, perm_s),
                 labels_dst=f32(ld, perm_d), pose=np.eye(4, dtype=np.float32), gt_flow=f32(gt, perm_s),
                 T_true=np.stack(Ts).astype(np.float32))
+
+
+def make_sequence(seed=0, num_frames=3, n_objects=10, n_min=60, n_max=600, speed=1.2, n_background=1500, noise=0.01):
+    """A synthetic multi-frame sample in the reference's Waymo / nuScenes format (dataset_pca.py:41-45): the ego
+    vehicle drives along x, `n_objects` vehicle-like shells move with constant velocity (up to `speed` m per frame)
+    and yaw rate, static background points are labelled ground.  Frame j is given in ITS OWN ego coordinates
+    (raw_points), ego_motion_gt[j] maps them into frame 0's, scene_flow is the reference's ground truth
+    (dataset_pca.py:67-69: where the point is at time 0, in frame-0 coordinates, minus the raw point).
+    -> dict(raw_points [m,3], time_indice [m], ego_motion_gt [F,4,4], nonground [m], scene_flow [m,3])."""
+    rng = np.random.default_rng(55_000_007 + seed)
+    side = int(np.ceil(np.sqrt(n_objects)))
+
+    def rz(a):
+        c, s_ = np.cos(a), np.sin(a)
+        return np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+
+    objs = []
+    for k in range(n_objects):
+        n = int(round(np.exp(rng.uniform(np.log(n_min), np.log(n_max)))))
+        ext = np.array([rng.uniform(1.5, 5.0), rng.uniform(1.0, 2.2), rng.uniform(1.0, 2.0)])
+        centre = np.array([(k % side - side / 2) * 12.0 + rng.uniform(-2, 2), (k // side - side / 2) * 12.0 + rng.uniform(-2, 2),
+                           rng.uniform(0.5, 1.2)])
+        heading = rng.uniform(-np.pi, np.pi)
+        vel = rng.uniform(0.3, 1.0) * speed * np.array([np.cos(heading), np.sin(heading), 0.0]) * (rng.uniform() < 0.7)
+        yaw_rate = np.deg2rad(rng.uniform(-1.5, 1.5))
+        objs.append((_shell_points(rng, ext, n) @ rz(heading).T, centre, vel, yaw_rate))
+    span = side * 6.0 + 10.0
+    bg = np.stack([rng.uniform(-span, span, n_background), rng.uniform(-span, span, n_background),
+                   rng.uniform(-0.2, 0.1, n_background)], axis=1)
+    ego_v = np.array([rng.uniform(0.5, 1.5), rng.uniform(-0.1, 0.1), 0.0])
+    ego_yaw = np.deg2rad(rng.uniform(-0.8, 0.8))
+    raw, tim, ng, sf, poses = [], [], [], [], []
+    for j in range(num_frames):
+        P = np.eye(4)                                        # frame-j ego coordinates -> frame-0 coordinates
+        P[:3, :3], P[:3, 3] = rz(ego_yaw * j), ego_v * j
+        Pinv = np.linalg.inv(P)
+        poses.append(P)
+        w0s, wjs, flags = [], [], []
+        for local, centre, vel, yaw_rate in objs:
+            keep = rng.random(len(local)) < 0.9              # every frame sees most of the same surface samples
+            w0 = local[keep] + centre                         # world (= frame 0) position at time 0
+            wj = (local[keep] @ rz(yaw_rate * j).T) + centre + vel * j + rng.normal(0.0, noise, size=(int(keep.sum()), 3))
+            w0s.append(w0); wjs.append(wj); flags.append(np.ones(len(w0), bool))
+        w0s.append(bg); wjs.append(bg + rng.normal(0.0, noise, size=bg.shape)); flags.append(np.zeros(len(bg), bool))
+        w0, wj = np.concatenate(w0s), np.concatenate(wjs)
+        r = wj @ Pinv[:3, :3].T + Pinv[:3, 3]                 # what the sensor of frame j sees
+        perm = rng.permutation(len(r))
+        raw.append(r[perm]); tim.append(np.full(len(r), j)); ng.append(np.concatenate(flags)[perm]); sf.append((w0 - r)[perm])
+    return dict(raw_points=np.concatenate(raw).astype(np.float32), time_indice=np.concatenate(tim).astype(np.int64),
+                ego_motion_gt=np.stack(poses).astype(np.float64), nonground=np.concatenate(ng),
+                scene_flow=np.concatenate(sf).astype(np.float32))

@@ -135,3 +135,38 @@ def test_stream_two_ranks_equals_single_process(tmp_path):
     want = np.array([one[k] for k in ("frame_pairs", "matched_cluster_pairs", "evaluated_points", "epe", "accs", "accr",
                                       "outlier", "Routlier")], dtype=np.float64)
     assert np.allclose(two, want, rtol=1e-12, atol=0)
+
+
+def test_sequence_files_in_the_reference_waymo_format(tmp_path):
+    """dataset_pca.py:41-45 keys -> num_frames - 1 frame pairs (frame j -> frame 0): ego compensation
+    (utils_helper.py:89-93), range crop (dataset_pca.py:61-64), per-gap translation frame (main.py:200), the estimated
+    poses of the reference's <split>_pose side file (dataset_pca.py:118-125) taking precedence, ground truth per gap."""
+    d = synthetic.make_sequence(seed=5, num_frames=3, n_objects=4, n_max=120, n_background=150)
+    os.makedirs(os.path.join(tmp_path, "val"))
+    path = os.path.join(tmp_path, "val", "s0.npz")
+    np.savez(path, **d, sd_labels=np.zeros(len(d["raw_points"])), fb_labels=np.zeros(len(d["raw_points"])))
+    assert frame_pairs.is_sequence(path)
+    a = frame_pairs.default_args(speed=0.8333, range_x=30.0, range_y=30.0)
+    fps = frame_pairs.load_any(path, a)
+    assert [fp.gap for fp in fps] == [1, 2] and all(fp.labels_src is None for fp in fps)
+    raw, t, P = d["raw_points"].astype(np.float64), d["time_indice"], d["ego_motion_gt"]
+    keep = (np.abs(raw[:, 0]) < 30.0) & (np.abs(raw[:, 1]) < 30.0)
+    for fp in fps:
+        m = keep & (t == fp.gap)
+        hom = np.concatenate([raw[m], np.ones((int(m.sum()), 1))], axis=1)
+        assert np.array_equal(fp.points_src, (hom @ P[fp.gap].T)[:, 0:3].astype(np.float32))
+        assert np.array_equal(fp.points_src_raw, d["raw_points"][m]) and np.array_equal(fp.points_dst, d["raw_points"][keep & (t == 0)])
+        assert np.array_equal(fp.gt_flow, d["scene_flow"][m]) and np.array_equal(fp.nonground_src, d["nonground"][m])
+        tf = frame_pairs.frame_translation(a, fp.pose_exact, fp.gap)
+        assert tf == max(0.8333 * fp.gap, np.linalg.norm(P[fp.gap][0:3, -1])) * 2                  # main.py:200, verbatim
+    # side file with estimated poses
+    os.makedirs(os.path.join(tmp_path, "val_pose"))
+    est = P.copy()
+    est[:, 0, 3] += 0.25
+    np.savez(os.path.join(tmp_path, "val_pose", "s0.npz"), ego_motion=est)
+    fps2 = frame_pairs.load_any(path, a)
+    assert np.allclose(fps2[0].pose, est[1].astype(np.float32)) and not np.allclose(fps2[0].points_src, fps[0].points_src)
+    # a frame-pair file is still one pair
+    one = os.path.join(tmp_path, "pair.npz")
+    frame_pairs.save_frame_pair(one, frame_pairs.FramePair(fps[0].points_src, fps[0].points_dst))
+    assert not frame_pairs.is_sequence(one) and len(frame_pairs.load_any(one)) == 1

@@ -431,19 +431,22 @@ def test_hist_icp_ragged_vs_oracle_and_golden():
 
 
 @all_icp_searches
-@pytest.mark.parametrize("tf", [3.34, 6.68])
+@pytest.mark.parametrize("tf", [3.34, 6.68, 10.02, 13.36])
 def test_hist_icp_larger_translation_frames_vs_oracle(tf):
-    """Waymo gap 1 / gap 2 histogram geometry (68 and 135 bins per axis, 55 and 219 KB per pair):
-    the vote's bins no longer fit LDS next to the tile (global atomics) and, at 135 bins, the peaks kernel
-    works through global scratch volumes.  Initial pose and full registration against the oracle."""
+    """Waymo gap 1 .. gap 4 histogram geometry (main.py:200 at speed 1.67; SURVEY A.1: 68 / 135 / 202 / 269 bins per
+    axis, 55 KB .. 868 KB per pair): the vote's bins no longer fit LDS next to the tile (global atomics) and, from
+    135 bins on, the peaks kernel works through global scratch volumes.  Initial pose and full registration
+    against the oracle."""
     S, D, _ = synthetic.make_batch(6, 256, seed=41, ragged=True, n_min=80)
     a = rp.default_args(max_points=256, translation_frame=tf)
     got0 = utils_hist.estimate_init_pose(a, G(S), G(D)).cpu().numpy()
-    want0 = rp.estimate_init_pose(a, C(S), C(D)).numpy()
-    assert np.array_equal(got0, want0)           # (seed chosen without a tie at the 5th / 6th peak)
+    want0, aux0 = rp.estimate_init_pose_batch(a, C(S), C(D), return_aux=True)
+    tied = (aux0["peak_votes"][:, 4] == 0).numpy()    # fewer than five positive peaks: zero-vote bins complete the
+    assert not tied.all()                              # top-5 in an order that is the implementation's, not the data's
+    assert np.array_equal(got0[~tied], want0.numpy()[~tied])
     got = utils_match.hist_icp(a, G(S), G(D)).cpu().numpy()
     want = rp.hist_icp(a, C(S), C(D)).numpy()
-    assert_pose_close(got, want, S)
+    assert_pose_close(got, want, S, mask=~tied)
 
 
 @all_icp_searches
@@ -719,6 +722,49 @@ def test_synthetic_frame_pair_vs_oracle():
     err = np.linalg.norm(out["flow"].cpu().numpy() - want_flow, axis=1)
     assert err.max() < TOL_M, f"per-point flow differs from the oracle by up to {err.max():.3e} m"
     assert np.linalg.norm(out["flow"].cpu().numpy() - fp.gt_flow, axis=1).mean() < 0.02
+
+
+@pytest.mark.parametrize("clusterer", ["dbscan", "hdbscan"])
+def test_multi_gap_sequence_vs_oracle(tmp_path, clusterer):
+    """BASELINE config 3's shape without the dataset: a 4-frame sample in the reference's Waymo / nuScenes format
+    (dataset_pca.py:41-45 keys) through the stream -- per gap j: ego compensation, joint clustering of frame j and
+    frame 0 on the GPU, translation_frame = 2 max(speed j, |ego t|) (main.py:200: 68 / 135 / 202 histogram bins per
+    axis), both association stages, flow on the raw points with the ego pose composed in (main.py:230-234) --
+    against the oracle registering the same clusters with the same per-gap translation frame."""
+    from icp_flow_amd import frame_pairs
+    d = synthetic.make_sequence(seed=3, num_frames=4, n_objects=9, n_max=500)
+    path = os.path.join(tmp_path, "val_seq.npz")
+    np.savez(path, **d)
+    a = frame_pairs.default_args(max_points=1024, speed=1.67, cluster=clusterer, min_cluster_size=20, range_x=80.0,
+                                 range_y=80.0, epsilon=0.8)      # (sparse synthetic shells: ~30 points / m^2)
+    fps = frame_pairs.load_any(path, a)
+    assert [fp.gap for fp in fps] == [1, 2, 3]
+    epes = []
+    for fp in fps:
+        tf = frame_pairs.frame_translation(a, fp.pose_exact, fp.gap)
+        assert tf == max(1.67 * fp.gap, np.linalg.norm(d["ego_motion_gt"][fp.gap][0:3, -1])) * 2            # main.py:200
+        out = frame_pairs.register_frame_pair(a, fp, DEV)
+        assert out["translation_frame"] == tf
+        ps, pd = G(fp.points_src), G(fp.points_dst)
+        ls, ld = frame_pairs.cluster_frame_pair(a, ps, pd, fp.nonground_src, fp.nonground_dst)
+        oa = rp.default_args(max_points=1024, translation_frame=tf, min_cluster_size=20)
+        torch.manual_seed(0)
+        want_pairs, want_T = rp.match_pcds(oa, C(fp.points_src), C(fp.points_dst), ls.cpu(), ld.cpu())
+        want_flow = rp.flow_estimation_torch(C(fp.points_src_raw), ls.cpu(), want_pairs, want_T, C(fp.pose)).numpy()
+        pairs = out["pairs"].cpu().numpy()
+        assert np.array_equal(pairs[:, 0:2], want_pairs.numpy()[:, 0:2]) and len(pairs) >= 6
+        err = np.linalg.norm(out["flow"].cpu().numpy() - want_flow, axis=1)
+        assert err.max() < TOL_M, f"gap {fp.gap}: per-point flow differs from the oracle by up to {err.max():.3e} m"
+        # accuracy against the ground truth, on the points of matched clusters and on the static rest (an object the
+        # joint clustering split into per-frame fragments stays unmatched: that is the method, not the registration)
+        gt_err = np.linalg.norm(out["flow"].cpu().numpy() - fp.gt_flow, axis=1)
+        lsn = ls.cpu().numpy()
+        settled = np.isin(lsn, pairs[:, 0]) | ~fp.nonground_src
+        epes.append(float(gt_err[settled].mean()))
+    assert max(epes) < 0.03, epes
+    # the same file through the stream harness: three frame pairs, metrics of the reference's evaluation
+    s = frame_pairs.run_stream(a, [path], DEV)
+    assert s["frame_pairs"] == 3 and s["evaluated_points"] == int((d["time_indice"] > 0).sum()) and s["EPE3D"] < 0.5
 
 
 def test_frame_pair_stream_on_demo_frame_matches_reference_metrics(tmp_path):
