@@ -764,7 +764,7 @@ def test_multi_gap_sequence_vs_oracle(tmp_path, clusterer):
     assert max(epes) < 0.03, epes
     # the same file through the stream harness: three frame pairs, metrics of the reference's evaluation
     s = frame_pairs.run_stream(a, [path], DEV)
-    assert s["frame_pairs"] == 3 and s["evaluated_points"] == int((d["time_indice"] > 0).sum()) and s["EPE3D"] < 0.5
+    assert s["frame_pairs"] == 3 and s["evaluated_points"] == int((d["time_indice"] > 0).sum()) and s["epe"] < 0.5
 
 
 def test_frame_pair_stream_on_demo_frame_matches_reference_metrics(tmp_path):
