@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "kernels.hpp"
+#include "posefuse.hpp"
 
 using namespace icpflow;
 
@@ -46,6 +47,7 @@ struct Opts {
     {
         IcpOpts o;
         o.fp32Scratch = scratch;
+        o.ctrlCleared = true;   // every fused entry point clears the control block in its count_pair launch
         o.arith = arith;
         o.teams = on(ICPFLOW_OPT_NO_TEAMS);
         o.speculative = on(ICPFLOW_OPT_NO_SPECULATIVE);
@@ -261,15 +263,23 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, const Opts &o, hipStream_t s)
 {
     const GridScratch *search = search_scratch(w, N, o);
+    const bool sweepCheck = search != nullptr && search->mode == 3 && o.on(ICPFLOW_OPT_NO_CHECK_SWEEP);
+    // fused finish: the roll-back check and the select kernel take the final pose of every pair straight from the
+    // ICP's per-iteration history (or its state): no icp_resolve_history / compose launches in between
+    bool historyPending = false;
+    IcpOpts io = o.icp(w.grid.sortX);
+    if (sweepCheck && o.arith == ICPFLOW_ARITH_FP64) io.historyPending = &historyPending;
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, search, w.history, &w.team, o.icp(w.grid.sortX), s));
+                           w.state, w.ctrl, search, w.history, &w.team, io, s));
+    if (sweepCheck) {
+        PoseSource ps{w.state, w.ctrl, historyPending ? w.history : nullptr, init, B, maxIter};
+        ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, nullptr, w.partial, s, &ps));
+        ICPFLOW_TRY(launch_select(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, init, nullptr, B, invertSwapped,
+                                  Tout, s, &ps, iters));
+        return 0;
+    }
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s, w.ctrl, iters));   // also reports the iteration count
-    // roll-back check: sweeps over the sorted clouds the ICP left behind, or the all-pairs scan
-    if (search != nullptr && search->mode == 3 && o.on(ICPFLOW_OPT_NO_CHECK_SWEEP)) {
-        ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
-        ICPFLOW_TRY(launch_select(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, init, w.M, B, invertSwapped,
-                                  Tout, s));
-    } else {
+    {   // roll-back check: the all-pairs scan
         ICPFLOW_TRY(launch_scan_check(src, dst, w.lenA, w.lenC, swap, B, N, init, w.M, w.partial, s));
         ICPFLOW_TRY(launch_select(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, swap, init, w.M, B,
                                   invertSwapped, Tout, s));
@@ -308,7 +318,7 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
         ICPFLOW_TRY(launch_sweep_score(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
         ICPFLOW_TRY(launch_score_pick(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
     } else if (o.on(ICPFLOW_OPT_NO_SCORE_PRUNE)) {
-        ICPFLOW_TRY(launch_scan_score_pruned(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s));
+        ICPFLOW_TRY(launch_scan_score_pruned(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s, true));
         ICPFLOW_TRY(launch_score_pick(w.partial, score_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
     } else {
         ICPFLOW_TRY(launch_scan_score(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
@@ -565,7 +575,7 @@ int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, in
     Workspace w(d_ws, B, N, L);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s);
+    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s, w.scoreAccum, (size_t)B * 12 * sizeof(double));
     return run_init_pose(d_src, d_dst, w, nullptr, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
                          len_z, decode_shift, d_T_out, o, s);
 }
@@ -587,7 +597,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     Workspace w(d_ws, B, N, 0);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s);
+    launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, sizeof(IcpCtrl));
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
                            relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N, o), w.history, &w.team,
                            o.icp(w.grid.sortX), s));
@@ -612,7 +622,7 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
     Workspace w(d_ws, B, N, 0);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s);
+    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, sizeof(IcpCtrl));
     // d_T_out may alias d_init: keep a private copy of the init poses
     ICPFLOW_TRY(hipMemcpyAsync(w.Tinit, d_init, (size_t)B * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return run_icp_and_select(d_src, d_dst, w, nullptr, w.Tinit, B, N, thres_dist, max_iterations,
@@ -641,7 +651,8 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     Workspace w(d_ws, B, N, L);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s);   // lengths + swap, utils_match.py:139-146
+    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s, w.ctrl, sizeof(IcpCtrl), w.scoreAccum,
+                      (size_t)B * 12 * sizeof(double));   // lengths + swap (utils_match.py:139-146) + cleared scratch
     // the axis sort of both clouds (scoring sweep, ICP) runs on the side stream next to the vote
     hipEvent_t join = nullptr;
     JoinGuard guard;   // every return below leaves the side stream joined into s

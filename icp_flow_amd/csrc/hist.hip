@@ -31,10 +31,15 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const float4 *__restri
 // (swap[b] = n_src > n_dst, strict: utils_match.py:139-146); swap may be NULL
 __global__ __launch_bounds__(256) void count_pair_kernel(const float4 *__restrict__ A, const float4 *__restrict__ C,
                                                          int N, int32_t *__restrict__ lenA,
-                                                         int32_t *__restrict__ lenC, uint8_t *__restrict__ swap)
+                                                         int32_t *__restrict__ lenC, uint8_t *__restrict__ swap,
+                                                         uint32_t *__restrict__ zero0, unsigned words0,
+                                                         uint32_t *__restrict__ zero1, unsigned words1)
 {
     __shared__ int scratch[2 * 4];
     const int b = blockIdx.x;
+    // scratch the later kernels of this call expect zeroed (ICP control block, scoring accumulators)
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < words0; k += gridDim.x * blockDim.x) zero0[k] = 0u;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < words1; k += gridDim.x * blockDim.x) zero1[k] = 0u;
     const float4 *pa = A + (size_t)b * N, *pc = C + (size_t)b * N;
     int c[2] = {0, 0};
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
@@ -50,10 +55,10 @@ __global__ __launch_bounds__(256) void count_pair_kernel(const float4 *__restric
 }
 
 void launch_count_pair(const float *A, const float *C, int B, int N, int32_t *lenA, int32_t *lenC, uint8_t *swap,
-                       hipStream_t s)
+                       hipStream_t s, void *zero0, size_t bytes0, void *zero1, size_t bytes1)
 {
     hipLaunchKernelGGL(count_pair_kernel, dim3(B), dim3(256), 0, s, (const float4 *)A, (const float4 *)C, N, lenA,
-                       lenC, swap);
+                       lenC, swap, (uint32_t *)zero0, (unsigned)(bytes0 / 4), (uint32_t *)zero1, (unsigned)(bytes1 / 4));
 }
 
 void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s)

@@ -1253,8 +1253,12 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     p.thr2 = (float)(thres * thres);
     p.relThr = (float)relThr;
     p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
-    hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(IcpCtrl), s);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (opts.historyPending != nullptr) *opts.historyPending = false;
+    if (!opts.ctrlCleared) {
+        e = hipMemsetAsync(ctrl, 0, sizeof(IcpCtrl), s);
+        if (e != hipSuccess) return e;
+    }
     if (grid != nullptr && grid->mode == 3 && grid->presorted) {
         // the scoring sweep of this batch left both clouds sorted along the fixed cloud's longest axis;
         // a translation-only pre-pose (hist_icp) keeps that order
@@ -1309,8 +1313,12 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         if (speculative) {
             p.history = history;
             launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
-            e = launch_icp_resolve_history(state, ctrl, history, B, maxIter, s);
-            if (e != hipSuccess) return e;
+            if (opts.historyPending != nullptr) {
+                *opts.historyPending = true;   // the consumers read the history themselves (posefuse.hpp)
+            } else {
+                e = launch_icp_resolve_history(state, ctrl, history, B, maxIter, s);
+                if (e != hipSuccess) return e;
+            }
         } else {
             for (int it = 0; it < maxIter; ++it) launch_icp_iters(p, B, it, it + 1, opts.profile, s);
         }

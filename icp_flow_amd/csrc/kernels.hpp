@@ -58,8 +58,9 @@ constexpr int kHistStride = 16;   // floats per (iteration, pair): R (9), T (3),
 
 // hist.hip
 void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s);
+// (also zeroes up to two scratch buffers the later kernels of the call want cleared: saves their memsets)
 void launch_count_pair(const float *A, const float *C, int B, int N, int32_t *lenA, int32_t *lenC, uint8_t *swap,
-                       hipStream_t s);
+                       hipStream_t s, void *zero0 = nullptr, size_t bytes0 = 0, void *zero1 = nullptr, size_t bytes1 = 0);
 hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int NY,
                             const float mins[3], const float maxs[3], const int lens[3],
                             const float *ex, const float *ey, const float *ez,
@@ -98,9 +99,11 @@ int scan_qblocks(int maxRows, int batch);
 int sweep_qblocks(int maxRows);
 hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const int32_t *len2, int B, int N,
                              const float *pose, float thres, float *srcT, double *partial, hipStream_t s);
+struct PoseSource;   // posefuse.hpp
+// poseFinal == NULL: the final pose of every pair is composed inside the kernel from `fused`
 hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
                               const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
-                              const float *poseFinal, double *partial, hipStream_t s);
+                              const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused = nullptr);
 hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
                               int B, int N, const float *cand, double *partial, hipStream_t s);
 hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
@@ -109,7 +112,7 @@ hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA
 int score_qblocks(int maxRows);
 hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                                     const uint8_t *swap, int B, int N, const float *cand, double *partial,
-                                    double *accum, hipStream_t s);
+                                    double *accum, hipStream_t s, bool accumCleared = false);
 hipError_t launch_scan_check(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                              const uint8_t *swap, int B, int N, const float *poseInit,
                              const float *poseFinal, double *partial, hipStream_t s);
@@ -144,6 +147,9 @@ struct IcpOpts {
     bool teams = true;             // several workgroups per large pair when the batch leaves CUs idle
     bool speculative = true;       // batch-global stop in ONE launch (false: one launch per iteration)
     LaunchProfile *profile = nullptr;
+    bool ctrlCleared = false;      // the caller's count_pair launch already zeroed *ctrl
+    bool *historyPending = nullptr;   // non-NULL: do not launch the history epilogue; *historyPending = "the final
+                                   // states are still in the per-iteration history" (the consumers resolve it)
     float *fp32Scratch = nullptr;  // ICPFLOW_ARITH_FP32_REFERENCE: [B,N,4] floats (neighbour and weight per point)
 };
 // icp_fp32.hip: the reference's fp32 operation order (study mode), batch-global stop via the history epilogue
@@ -176,9 +182,10 @@ hipError_t launch_score_pick(const double *partial, int qblocks, const int32_t *
                              float *Tinit, hipStream_t s);
 hipError_t launch_compose(const IcpState *state, const float *init, int B, float *M, hipStream_t s,
                           const IcpCtrl *ctrl = nullptr, int32_t *iters = nullptr);
+// M == NULL: the composed pose comes from `fused` (and the iteration count is written to *iters)
 hipError_t launch_select(const double *partial, int qblocks, const int32_t *lenA, const int32_t *lenC,
                          const uint8_t *swap, const float *init, const float *M, int B, int invertSwapped,
-                         float *out, hipStream_t s);
+                         float *out, hipStream_t s, const PoseSource *fused = nullptr, int32_t *iters = nullptr);
 hipError_t launch_eval_epilogue(const double *partial, int qblocks, const int32_t *len1,
                                 const int32_t *len2, const float *T, int B, float *errors,
                                 float *inliers, float *ratios, float *ious, float *translations,

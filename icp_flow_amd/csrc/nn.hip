@@ -15,6 +15,7 @@
 // an XCD and therefore the L2 copy of that job's target cloud.
 #include "scan.hpp"
 #include "kernels.hpp"
+#include "posefuse.hpp"
 
 namespace icpflow {
 
@@ -305,6 +306,7 @@ struct SweepParams {
     const float4 *sortX;
     const float *X, *Y;     // [B,N,4] as passed to the registration (src, dst)
     const float *poseA, *poseB;   // [B,4,4] init pose and composed final pose
+    PoseSource fused;             // poseB == NULL: the final pose is composed in the kernel (posefuse.hpp)
     int rawSorted;
     // SWEEP_EVAL (match_eval): Asoa = pcd1 sorted (raw), Csoa = pcd2 sorted, srcT = pcd1 * T in pcd1's sorted
     // order (transform_soa_kernel), poseA = T, thres = inlier threshold on the Euclidean distance
@@ -348,6 +350,23 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         if (threadIdx.x < kPartial) out[threadIdx.x] = 0.0;
         return;
     }
+    __shared__ float poseSh[16];
+    if (MODE == SWEEP_CHECK) {   // the pose of this job: init (sub 0) or final (sub 1; composed here when fused)
+        if (sub == 1 && p.poseB == nullptr) {
+            if (wave == 0) {
+                const int n = pose_stop_iteration_wave(p.fused, lane);
+                if (lane == 0) {
+                    float M[16];
+                    final_pose(p.fused, b, n, M);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) poseSh[k] = M[k];
+                }
+            }
+        } else if (threadIdx.x < 16) {
+            poseSh[threadIdx.x] = ((sub == 0 ? p.poseA : p.poseB) + (size_t)b * 16)[threadIdx.x];
+        }
+        __syncthreads();
+    }
     float tx = 0.f, ty = 0.f, tz = 0.f;
     if (MODE == SWEEP_SCORE) {
         const float *t3 = p.cand + ((size_t)b * 6 + (sub >> 1)) * 3;
@@ -377,7 +396,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
                 const float4 r4 = reinterpret_cast<const float4 *>(sw ? p.Y : p.X)[(size_t)b * p.N + __float_as_int(s4.w)];
                 rx = r4.x; ry = r4.y; rz = r4.z;
             }
-            const Affine pose = affine_from_pose((sub == 0 ? p.poseA : p.poseB) + (size_t)b * 16);
+            const Affine pose = affine_from_pose(poseSh);
             affine_apply(pose, rx, ry, rz, qx, qy, qz);
         }
         cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
@@ -531,9 +550,13 @@ hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const
 // the composed final pose, as sweeps over the sorted clouds the ICP left in `grid`
 hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
                               const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
-                              const float *poseFinal, double *partial, hipStream_t s)
+                              const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused)
 {
     SweepParams p{};
+    if (poseFinal == nullptr) {
+        if (fused == nullptr) return hipErrorInvalidValue;
+        p.fused = *fused;
+    }
     p.Asoa = grid->sortYsoa;   // unused in this mode (valid pointer for the address arithmetic)
     p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.axis = grid->axis;
     p.sortX = (const float4 *)grid->sortX; p.X = X; p.Y = Y; p.poseA = poseInit; p.poseB = poseFinal;
@@ -560,10 +583,12 @@ int score_qblocks(int maxRows) { return (maxRows + kScanBlock / kScoreSplit - 1)
 
 hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                                     const uint8_t *swap, int B, int N, const float *cand, double *partial,
-                                    double *accum, hipStream_t s)
+                                    double *accum, hipStream_t s, bool accumCleared)
 {
-    hipError_t e = hipMemsetAsync(accum, 0, (size_t)B * 12 * sizeof(double), s);
-    if (e != hipSuccess) return e;
+    if (!accumCleared) {
+        hipError_t e = hipMemsetAsync(accum, 0, (size_t)B * 12 * sizeof(double), s);
+        if (e != hipSuccess) return e;
+    }
     ScanParams p{};
     p.A = A; p.C = C; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.N = N;
     p.cand = cand; p.partial = partial; p.accum = accum;

@@ -5,6 +5,7 @@
 // One lane per pair: these are latency-trivial next to the O(n^2) scans.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "posefuse.hpp"
 
 namespace icpflow {
 
@@ -95,15 +96,25 @@ hipError_t launch_compose(const IcpState *state, const float *init, int B, float
 __global__ void select_kernel(const double *__restrict__ partial, int qblocks,
                               const int32_t *__restrict__ lenA, const int32_t *__restrict__ lenC,
                               const uint8_t *__restrict__ swap, const float *__restrict__ init,
-                              const float *__restrict__ M, int B, int invertSwapped, float *__restrict__ out)
+                              const float *__restrict__ M, int B, int invertSwapped, float *__restrict__ out,
+                              PoseSource fused, int32_t *__restrict__ iters)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // fused finish (M == NULL): the composed pose comes straight from the ICP's history / state
+    int n = 0;
+    if (M == nullptr) {
+        n = pose_stop_iteration(fused);
+        // iterations of the batch; -1 = a team gave up waiting, transforms are NaN
+        if (b == 0 && iters != nullptr) *iters = fused.ctrl->error ? -1 : n;
+    }
     if (b >= B) return;
+    float Mf[16];
+    if (M == nullptr) final_pose(fused, b, n, Mf);
     const bool sw = swap != nullptr && swap[b] != 0;
     const float na = (float)(sw ? lenC[b] : lenA[b]);
     const float e0 = (float)partial_total(partial, b * 2 + 0, qblocks, 0) / na;
     const float e1 = (float)partial_total(partial, b * 2 + 1, qblocks, 0) / na;
-    const float *src = (e1 >= e0) ? init + (size_t)b * 16 : M + (size_t)b * 16;  // NaN keeps ICP
+    const float *src = (e1 >= e0) ? init + (size_t)b * 16 : (M != nullptr ? M + (size_t)b * 16 : Mf);  // NaN keeps ICP
     float P[16];
     for (int k = 0; k < 16; ++k) P[k] = src[k];
     if (sw && invertSwapped) {
@@ -132,10 +143,11 @@ __global__ void select_kernel(const double *__restrict__ partial, int qblocks,
 
 hipError_t launch_select(const double *partial, int qblocks, const int32_t *lenA, const int32_t *lenC,
                          const uint8_t *swap, const float *init, const float *M, int B, int invertSwapped,
-                         float *out, hipStream_t s)
+                         float *out, hipStream_t s, const PoseSource *fused, int32_t *iters)
 {
+    if (M == nullptr && fused == nullptr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, qblocks, lenA, lenC,
-                       swap, init, M, B, invertSwapped, out);
+                       swap, init, M, B, invertSwapped, out, fused ? *fused : PoseSource{}, iters);
     return hipGetLastError();
 }
 

@@ -161,10 +161,15 @@ def labels_from_mst(a, b, w, n, min_cluster_size):
     return out.astype(np.int64)
 
 
-def hdbscan(points, min_cluster_size, min_samples=None, mask=None, cell=0.25):
+def hdbscan(points, min_cluster_size, min_samples=None, mask=None, cell=0.25, counts_self=False):
     """hdbscan.HDBSCAN(min_cluster_size, min_samples).fit(points).labels_ for euclidean points, alpha 1, EOM
-    selection.  -> int64 numpy labels [n]: cluster id, -1 noise (and non-finite rows), -2 masked out."""
-    k = int(min_cluster_size if min_samples is None else min_samples)
+    selection.  -> int64 numpy labels [n]: cluster id, -1 noise (and non-finite rows), -2 masked out.
+
+    Core distance = distance to the min_samples-th nearest neighbour NOT counting the point itself: the convention
+    of the `hdbscan` package on the reference's path (0.8.29, algorithm 'best' -> boruvka_kdtree on 3-D euclidean
+    data: _hdbscan_boruvka.pyx queries k = min_samples + 1 and takes column [min_samples]).  counts_self=True
+    gives scikit-learn's convention ("includes the point itself"): one neighbour fewer."""
+    k = int(min_cluster_size if min_samples is None else min_samples) + (0 if counts_self else 1)
     t = hdbscan_mst(points, k, mask, cell)
     n = int(t["core2"].numel())
     live = torch.isfinite(t["core2"]) | torch.isinf(t["core2"])   # NaN marks rows that took no part

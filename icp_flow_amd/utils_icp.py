@@ -41,7 +41,7 @@ def apply_icp(args, src, dst, init_poses, return_iterations=False):
     assert init.shape == (B, 4, 4)
     max_it, rel, stop = _icp_options(args)
     out = torch.empty((B, 4, 4), dtype=torch.float32, device=s.device)
-    iters = torch.zeros((1,), dtype=torch.int32, device=s.device)
+    iters = torch.empty((1,), dtype=torch.int32, device=s.device)   # always written by the call
     ws = _lib.workspace(s.device, _lib.workspace_bytes(B, N))
     _lib.call("icpflow_apply_icp", _lib.ptr(s), _lib.ptr(d), _lib.ptr(init), B, N, float(args.thres_dist),
               max_it, rel, stop, _lib.ptr(out), _lib.ptr(iters), _lib.ptr(ws), ws.numel(),

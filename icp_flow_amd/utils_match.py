@@ -20,7 +20,7 @@ def hist_icp(args, src, dst, return_iterations=False):
     lens = (len(ex), len(ey), len(ez))
     max_it, rel, stop = _icp_options(args)
     out = torch.empty((B, 4, 4), dtype=torch.float32, device=s.device)
-    iters = torch.zeros((1,), dtype=torch.int32, device=s.device)
+    iters = torch.empty((1,), dtype=torch.int32, device=s.device)   # always written by the call
     ws = _lib.workspace(s.device, _lib.workspace_bytes(B, N, lens))
     _lib.call("icpflow_hist_icp", _lib.ptr(s), _lib.ptr(d), B, N, _lib.ptr(ex), lens[0], _lib.ptr(ey),
               lens[1], _lib.ptr(ez), lens[2], float(args.thres_dist // 2), float(args.thres_dist), max_it,

@@ -327,7 +327,10 @@ int icpflow_dbscan(const float *d_points, int stride, const uint8_t *d_mask, int
  * min_samples=None, metric='euclidean', alpha=1.0), third-party, environment.yml:57): the part that is
  * O(n^2) on the CPU -- core distances and the minimum spanning tree of the mutual-reachability graph
  *     d(a, b) = max(core(a), core(b), |a - b|),   core(a) = distance to a's min_samples-th nearest
- *     neighbour, a itself counted (sklearn / hdbscan: tree.query(X, k=min_samples)[:, -1]).
+ *     neighbour, a ITSELF COUNTED (tree.query(X, k)[:, -1]: scikit-learn's convention).  The hdbscan package
+ *     does not count the point (its boruvka_kdtree path queries k = min_samples + 1, _hdbscan_boruvka.pyx):
+ *     pass its min_samples + 1 here -- icp_flow_amd/utils_cluster.py does, for the reference's
+ *     HDBSCAN(min_cluster_size, min_samples=None) that is min_cluster_size + 1.
  * The dendrogram, condensed tree and cluster selection on the n - 1 edges are sequential host logic
  * (icp_flow_amd/utils_cluster.py).
  *

@@ -7,8 +7,9 @@ The reference's `cluster_hdbscan` (utils_cluster.py:10-29) calls the third-party
 (environment.yml:57; not in /root/reference, not installable here).  Its published algorithm (Campello et
 al. 2013; McInnes & Healy 2017), as also implemented by scikit-learn's port
 (sklearn/cluster/_hdbscan/hdbscan.py:_hdbscan_prims, _linkage.pyx:mst_from_data_matrix):
-  core(a)      = distance from a to its min_samples-th nearest neighbour, a itself counted
-                 (tree.query(X, k=min_samples)[0][:, -1]),
+  core(a)      = distance from a to its k-th nearest neighbour, a itself counted (tree.query(X, k)[0][:, -1]);
+                 scikit-learn takes k = min_samples, the hdbscan package k = min_samples + 1 (it does not count
+                 the point: _hdbscan_boruvka.pyx).  `min_samples` below is that k, the point counted,
   d_mreach(a,b) = max(core(a), core(b), |a - b| / alpha),  alpha = 1,
   a minimum spanning tree of the complete graph under d_mreach, then the single-linkage dendrogram,
   the condensed tree (min_cluster_size) and the excess-of-mass selection.

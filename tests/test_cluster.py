@@ -241,10 +241,11 @@ def test_oracle_tree_weights_equal_sklearn_prim():
     g = load_golden("g11_hdbscan")
     for i in (0, 2):
         p, (k, _) = g[f"crop_{i}_points"], g[f"crop_{i}_params"]
-        _, _, w2, c2 = oh.mst(p, int(k))
+        k = int(k) + 1           # min_cluster_size = min_samples of the hdbscan package: the point itself not counted
+        _, _, w2, c2 = oh.mst(p, k)
         assert np.array_equal(np.sort(np.sqrt(w2)), g[f"crop_{i}_tree_weights"])
         from scipy.spatial import cKDTree
-        d, _ = cKDTree(p.astype(np.float64)).query(p.astype(np.float64), k=int(k))
+        d, _ = cKDTree(p.astype(np.float64)).query(p.astype(np.float64), k=k)
         assert np.array_equal(np.sqrt(c2), d[:, -1])
 
 
@@ -261,10 +262,10 @@ def _gpu_tree(p, k, mask=None):
 def test_gpu_spanning_tree_equals_oracle_edge_for_edge(case):
     g = load_golden("g11_hdbscan")
     mask = None
-    if case.startswith("crop"):
-        p, k = g[f"{case}_points"], int(g[f"{case}_params"][0])
+    if case.startswith("crop"):       # k = the package's min_samples + 1 (the kernels count the point itself)
+        p, k = g[f"{case}_points"], int(g[f"{case}_params"][0]) + 1
     elif case == "synth":
-        p, k, mask = g["synth_points"], int(g["synth_params"][0]), g["synth_nonground"]
+        p, k, mask = g["synth_points"], int(g["synth_params"][0]) + 1, g["synth_nonground"]
     elif case == "lattice":           # every weight is tied many times over: the tie rule decides everything
         p, k = _lattice(14), 7
     elif case == "duplicates":
@@ -290,12 +291,12 @@ def test_gpu_spanning_tree_of_the_demo_frame_has_sklearn_prims_weights():
     minutes on a CPU core), bit for bit; core distances against a KD-tree."""
     g = load_golden("g11_hdbscan")
     pts = _demo_points()
-    t = _hip().hdbscan_mst(pts, 20)
+    t = _hip().hdbscan_mst(pts, 21)      # HDBSCAN(min_cluster_size=20, min_samples=None) of the hdbscan package
     assert t["n_live"] == len(pts) and len(t["a"]) == len(pts) - 1
     assert np.array_equal(np.sort(np.sqrt(t["w2"].cpu().numpy())), g["demo_tree_weights"])
     from scipy.spatial import cKDTree
     sample = np.random.default_rng(0).choice(len(pts), 4000, replace=False)
-    d, _ = cKDTree(pts.astype(np.float64)).query(pts[sample].astype(np.float64), k=20)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts[sample].astype(np.float64), k=21)
     assert np.array_equal(np.sqrt(t["core2"].cpu().numpy()[sample]), d[:, -1])
     # the edges form one tree
     from scipy.sparse import coo_matrix
@@ -319,7 +320,7 @@ def test_gpu_hdbscan_labels_against_reference_run(case):
     bad = _partition_mismatch(got[mask], want[mask])
     assert bad <= 0.01 * mask.sum(), (bad, int(mask.sum()))
     # the host half on its own: the oracle's tree through the product's host logic gives the product's labels
-    ra, rb, rw, _ = oh.mst(p[mask], int(k))
+    ra, rb, rw, _ = oh.mst(p[mask], int(k) + 1)
     lab = _hip().labels_from_mst(ra, rb, np.sqrt(rw), int(mask.sum()), int(k))
     full = _hip().hdbscan(p, int(k), None, None if case != "synth" else mask)
     assert np.array_equal(full[mask], lab)
@@ -392,7 +393,7 @@ def test_host_tree_labels_equal_sklearns_routines_on_the_same_tree():
 @gpu
 def test_gpu_unlabelled_frame_pair_hdbscan_then_registered():
     """The reference's demo pipeline end to end on the GPU: joint HDBSCAN of the stacked frame pair (demo.py:210,
-    --if_hdbscan) + track + flow.  Against the reference's own run (G8: labels by sklearn's HDBSCAN, 81 matched
+    --if_hdbscan) + track + flow.  Against the reference's own run (G8: labels by sklearn's HDBSCAN, 83 matched
     pairs, EPE 0.0585): the clustering agrees up to tie points, so the matched pairs and the error agree closely."""
     from icp_flow_amd import frame_pairs
     g = load_golden("g8_demo")
@@ -429,7 +430,7 @@ def test_gpu_clustering_input_variants():
     hi = np.maximum(t["a"].cpu().numpy(), t["b"].cpu().numpy()).astype(np.int64)
     o = np.lexsort((hi, lo))
     assert np.array_equal(lo[o], ra) and np.array_equal(hi[o], rb) and np.array_equal(t["w2"].cpu().numpy()[o], rw)
-    got = hip.hdbscan(sub, 25, min_samples=7)
+    got = hip.hdbscan(sub, 25, min_samples=7, counts_self=True)          # scikit-learn's convention
     assert np.array_equal(got, hip.labels_from_mst(ra, rb, np.sqrt(rw), len(sub), 25))
     from sklearn.cluster import HDBSCAN
     ref = HDBSCAN(min_cluster_size=25, min_samples=7, leaf_size=100).fit(sub.astype(np.float64)).labels_

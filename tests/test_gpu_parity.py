@@ -591,7 +591,7 @@ def test_demo_frame_pair_track_and_flow_vs_reference(fixture):
     lab = load_golden("g8_demo_labels")
     a = rp.default_args(max_points=int(g["max_points"]), min_cluster_size=20, translation_frame=2.0,
                         thres_box=0.1, thres_rot=0.1, thres_error=0.2, thres_iou=0.2)
-    assert a.max_points == (2048 if fixture == "g8_demo" else 10000)
+    assert a.max_points == (2048 if fixture == "g8_demo" else 10000) and len(g["pairs"]) == 83
     torch.manual_seed(0)
     ps, pd = G(g0["point_src"]), G(g0["point_dst"])
     ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
@@ -611,19 +611,18 @@ def test_demo_frame_pair_track_and_flow_vs_reference(fixture):
     worst = sorted(((float(err[lsrc == p[0]].max()), int(p[0]), int((lsrc == p[0]).sum())) for p in ref_pairs), reverse=True)[:4]
     print(f"{fixture}: flow vs reference max {err.max():.3e} m, within 1e-4 m on {np.mean(err < TOL_M):.5f} of the points; "
           f"worst clusters (max err, label, points) {worst}")
+    # In the reference's run stage 1 stopped after 41 (max_points 2048) / 55 (10000) iterations; here it runs 100: one
+    # candidate pair (a few dozen points) has fewer than five positive vote peaks, torch.topk completes its top-5
+    # with zero-vote bins in implementation-defined order, the reference's pick registers, the deterministic rule's
+    # pick (vote desc, index asc) has no inlier at all -- rel = NaN, the batch-global stop can never fire
+    # (utils_icp_pytorch3d.py:209).  The pair itself is rejected either way; the iteration count of the batch moves
+    # the clusters that are still moving at that iteration (test_demo_frame_stages_from_the_reference_initial_poses
+    # pins those by starting from the reference's own initial poses).  Here: every cluster that has settled by then.
     pinned = np.ones(len(err), bool)
-    if fixture == "g8_demo_mp10000":
-        # In the reference's run stage 1 stopped after 44 iterations; here it runs 100: one candidate pair (21 vs 47
-        # points) has fewer than five positive vote peaks, torch.topk completes its top-5 with zero-vote bins in
-        # implementation-defined order, the reference's pick registers, the deterministic rule's pick (vote desc,
-        # index asc) has no inlier at all -- rel = NaN, the batch-global stop can never fire (utils_icp_pytorch3d.py:
-        # 209).  The pair itself is rejected either way; the iteration count of the batch moves the clusters that
-        # are still moving at iteration 44 (test_demo_frame_stages_from_the_reference_initial_poses pins them by
-        # starting from the reference's own initial poses).  Here: every cluster that has settled by then.
-        moving = [int(p[0]) for p in ref_pairs if err[lsrc == p[0]].max() >= TOL_M]
-        assert len(moving) <= 2 and all((lsrc == l).sum() > 4000 for l in moving), worst
-        for l in moving:
-            pinned &= lsrc != l
+    moving = [int(p[0]) for p in ref_pairs if err[lsrc == p[0]].max() >= TOL_M]
+    assert len(moving) <= 3 and all((lsrc == l).sum() > 900 for l in moving), worst
+    for l in moving:
+        pinned &= lsrc != l
     assert err[pinned].max() < TOL_M, f"per-point flow differs from the reference's by up to {err[pinned].max():.3e} m; worst clusters {worst}"
     # the flow kernel alone, fed with the reference's pairs / transforms
     flow2 = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, G(ref_pairs), G(ref_T), torch.eye(4, device=DEV))
@@ -638,17 +637,18 @@ def test_demo_frame_pair_track_and_flow_vs_reference(fixture):
     assert abs(epe - float(g["epe"])) < 6e-3
 
 
-def test_demo_frame_stages_from_the_reference_initial_poses():
-    """BASELINE config 1 at the reference's real setting (max_points 10000): both association stages of the
-    reference's own run, stage by stage.  The padded batches are rebuilt by the product's gather (same randperm
+@pytest.mark.parametrize("fixture", ["g8_demo", "g8_demo_mp10000"])
+def test_demo_frame_stages_from_the_reference_initial_poses(fixture):
+    """BASELINE config 1 at max_points 2048 and at the reference's real setting (max_points 10000): both association
+    stages of the reference's own run, stage by stage.  The padded batches are rebuilt by the product's gather (same randperm
     stream as the reference: seed 0, source then destination, stage 1 then stage 2), the initial poses of the HIP
     path are compared with the reference's (equal unless the top-5 cut of that pair is tied), and the ICP + roll-back
-    (icpflow_apply_icp) runs from the REFERENCE's initial poses: same batch-global iteration count (44, converged;
-    100, not converged), and every cluster -- the 10 000-point sample of the 30 000-point wall included -- ends up
+    (icpflow_apply_icp) runs from the REFERENCE's initial poses: same batch-global iteration count (stage 1: 41 at 2048,
+    55 at 10000, converged; stage 2: 100, not converged), and every cluster -- the 10 000-point sample of the 30 000-point wall included -- ends up
     where the reference put it."""
     from icp_flow_amd.utils_check import ClusterTable
-    g0, g, lab = load_golden("g8_demo"), load_golden("g8_demo_mp10000"), load_golden("g8_demo_labels")
-    a = rp.default_args(max_points=10000, min_cluster_size=20, translation_frame=2.0,
+    g0, g, lab = load_golden("g8_demo"), load_golden(fixture), load_golden("g8_demo_labels")
+    a = rp.default_args(max_points=int(g["max_points"]), min_cluster_size=20, translation_frame=2.0,
                         thres_box=0.1, thres_rot=0.1, thres_error=0.2, thres_iou=0.2)
     ps, pd = G(g0["point_src"]), G(g0["point_dst"])
     ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()

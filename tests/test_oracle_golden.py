@@ -174,25 +174,67 @@ def test_hist_icp_dense_config2_shape():
     assert np.abs(ref - tru).max(axis=(1, 2))[0::2].max() < 0.01
 
 
+def _stage_batch(a, ps, pd, ls, ld, pairs):
+    """The padded batch the reference's match_pairs registers (utils_match.py:81-91) and its smaller-cloud-first
+    arrangement (utils_match.py:139-146)."""
+    S, D = [], []
+    for p in pairs:          # source then destination, pair by pair: the reference's stream of randperm draws
+        S.append(rp.pad_segment(ps[ls == p[0], 0:3], a.max_points))
+        D.append(rp.pad_segment(pd[ld == p[1], 0:3], a.max_points))
+    S, D = torch.stack(S), torch.stack(D)
+    sw = (S[:, :, -1] > 0).sum(1) > (D[:, :, -1] > 0).sum(1)
+    A, B = S.clone(), D.clone()
+    A[sw], B[sw] = D[sw], S[sw]
+    return S, A, B, sw
+
+
 def test_demo_frame_pair_match_pcds_and_flow():
-    """G8 (BASELINE config 1): the oracle's restatement of match_pcds (both association stages,
-    sanity_check, reject + row arg-min) and of flow_estimation_torch on the reference's demo frame,
-    against the reference's own output (81 matched clusters, per-point flow of 63 276 points)."""
+    """G8 (BASELINE config 1): the oracle's restatement of match_pcds (both association stages, sanity_check,
+    reject + row arg-min) and of flow_estimation_torch on the reference's demo frame, against the reference's own
+    run (83 matched clusters, per-point flow of 63 276 points).
+
+    One thing in that run is not a portable expectation: a candidate pair with fewer than five positive
+    vote peaks gets its top-5 completed with zero-vote bins in torch.topk's implementation-defined order, and the
+    batch-global ICP stop (utils_icp_pytorch3d.py:209) couples every pair of the batch to that pick: in the
+    reference's run stage 1 stops after 41 iterations, with the deterministic tie rule of the restatement (vote
+    desc, index asc) the picked pose has no inlier, rel = NaN, and the batch runs all 100 -- which moves the (few,
+    large) clusters that are still moving at iteration 41.  So: (1) per stage, from the reference's OWN initial
+    poses the restatement reproduces the reference bit for bit -- iteration count and every transform; (2) end to
+    end, the same pairs are matched and every cluster that has settled by then agrees exactly."""
     g = load_golden("g8_demo")
     lab = load_golden("g8_demo_labels")
     a = rp.default_args(max_points=int(g["max_points"]), min_cluster_size=20, translation_frame=2.0,
                         thres_box=0.1, thres_rot=0.1, thres_error=0.2, thres_iou=0.2)
-    torch.manual_seed(0)
     ps, pd = T(g["point_src"]), T(g["point_dst"])
     ls, ld = T(lab["label_src"]).float(), T(lab["label_dst"]).float()
+    # (1) stage by stage from the reference's initial poses
+    torch.manual_seed(0)
+    off = 0
+    for k, n in enumerate(g["stage_sizes"]):
+        pr, ref_init, ref_T = g["stage_pairs"][off:off + n], T(g["stage_init"][off:off + n]), g["stage_T"][off:off + n]
+        tied = g["stage_tied"][off:off + n]
+        off += n
+        S, A, B, sw = _stage_batch(a, ps, pd, ls, ld, pr)
+        init = rp.estimate_init_pose(a, A, B)
+        same = (init == ref_init).all(-1).all(-1).numpy()
+        assert (~same).sum() <= 1 and not (~same & ~tied).any(), (k, np.nonzero(~same)[0])
+        M, aux = rp.apply_icp(a, A, B, ref_init, return_aux=True)
+        assert aux["iterations"] == int(g["stage_iterations"][k]) and aux["converged"] == bool(g["stage_converged"][k])
+        M[sw] = torch.linalg.inv(M[sw])                                       # utils_match.py:152-154
+        np.testing.assert_array_equal(M.numpy(), ref_T)
+    # (2) end to end
+    torch.manual_seed(0)
     pairs, Tm = rp.match_pcds(a, ps, pd, ls, ld)
     ref_pairs, ref_T = g["pairs"], g["transformations"]
-    # the restatement reproduces the reference's run exactly: same pairs, bit-equal transforms / flow
     assert np.array_equal(pairs[:, 0:2].numpy(), ref_pairs[:, 0:2])
-    np.testing.assert_allclose(pairs.numpy(), ref_pairs, atol=1e-6, rtol=1e-6)
-    np.testing.assert_allclose(Tm.numpy(), ref_T, atol=1e-6)
-    flow = rp.flow_estimation_torch(ps, ls, pairs, Tm, torch.eye(4))
-    np.testing.assert_allclose(flow.numpy(), g["flow"], atol=1e-6)
+    settled = np.abs(Tm.numpy() - ref_T).max((1, 2)) <= 1e-6
+    assert (~settled).sum() <= 3, np.nonzero(~settled)[0]
+    np.testing.assert_allclose(pairs.numpy()[settled], ref_pairs[settled], atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(pairs.numpy()[:, 2:4], ref_pairs[:, 2:4], atol=5e-3)        # errors of the moving ones
+    flow = rp.flow_estimation_torch(ps, ls, pairs, Tm, torch.eye(4)).numpy()
+    on_settled = np.isin(lab["label_src"], ref_pairs[settled, 0]) | ~np.isin(lab["label_src"], ref_pairs[:, 0])
+    np.testing.assert_allclose(flow[on_settled], g["flow"][on_settled], atol=1e-6)
+    assert np.abs(flow - g["flow"]).max() < 0.05
     # flow kernel restatement alone, from the reference's pairs / transforms: exact
     flow2 = rp.flow_estimation_torch(ps, ls, T(ref_pairs), T(ref_T), torch.eye(4))
     np.testing.assert_allclose(flow2.numpy(), g["flow"], atol=1e-6)

@@ -363,7 +363,7 @@ def g8_demo(max_points=2048, name="g8_demo"):
     epe = float(np.linalg.norm(flow.numpy() - gt, axis=1).mean())
     print(f"  demo: {len(pairs)} matched pairs, EPE vs gt {epe:.4f} m (zero flow {np.linalg.norm(gt, axis=1).mean():.4f})")
     inputs = dict(point_src=src, point_dst=dst, gt_flow=gt) if name == "g8_demo" else {}    # the inputs live in g8_demo.npz
-    save(name, **inputs, **(stage_arrays if name != "g8_demo" else {}), pairs=pairs.numpy(), transformations=T.numpy(),
+    save(name, **inputs, **stage_arrays, pairs=pairs.numpy(), transformations=T.numpy(),
          flow=flow.numpy(), max_points=np.array(a.max_points), epe=np.array(epe))
 
 
@@ -468,7 +468,8 @@ def g11_hdbscan():
     out = {}
 
     def tree_weights(p, k):
-        return np.asarray(HDBSCAN(min_cluster_size=k, leaf_size=100).fit(p[:, :3].astype(np.float64))
+        # min_samples + 1: the hdbscan library does not count the point itself, sklearn does (tools/standins/hdbscan)
+        return np.asarray(HDBSCAN(min_cluster_size=k, min_samples=k + 1, leaf_size=100).fit(p[:, :3].astype(np.float64))
                           ._single_linkage_tree_["value"], dtype=np.float64)
 
     crops = [(0, 5, 1500, 20, 200), (20, -10, 3000, 20, 4), (-15, 20, 2500, 30, 200)]
@@ -496,7 +497,7 @@ def g11_hdbscan():
     print(f"  synthetic: {int(nonground.sum())} non-ground of {len(p)}: {len(np.unique(lab[lab >= 0]))} clusters kept")
     import time
     t = time.time()
-    m = HDBSCAN(min_cluster_size=20, leaf_size=100).fit(pts.astype(np.float64))
+    m = HDBSCAN(min_cluster_size=20, min_samples=21, leaf_size=100).fit(pts.astype(np.float64))
     print(f"  demo frame: sklearn HDBSCAN of {len(pts)} points took {time.time() - t:.0f} s")
     g8 = np.load(os.path.join(OUT, "g8_demo_labels.npz"))
     lab8 = np.concatenate([g8["label_dst"], g8["label_src"]]).astype(np.int64)
