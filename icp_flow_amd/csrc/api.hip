@@ -542,7 +542,7 @@ int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, cons
 {
     if (!d_points || !d_labels || !d_pose || !d_flow) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: null pointer");
     if (N <= 0) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: N must be positive");
-    if (P < 0 || P > 2048) return fail(ICPFLOW_E_LIMIT, "icpflow_flow_rigid: 0 <= P <= 2048 pairs (got %d)", P);
+    if (P < 0 || P > (1 << 24)) return fail(ICPFLOW_E_LIMIT, "icpflow_flow_rigid: 0 <= P <= 2^24 pairs (got %d)", P);
     if (P > 0 && (!d_pair_labels || !d_T)) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: null pair arrays");
     if (int r = check_ws(d_ws, ws_bytes, (size_t)(P + 1) * 16 * sizeof(float))) return r;
     ICPFLOW_TRY(launch_flow_rigid(d_points, d_labels, N, d_pair_labels, d_T, P, d_pose, (float *)d_ws, d_flow,

@@ -372,21 +372,25 @@ __global__ void flow_compose_kernel(const float *__restrict__ T, const float *__
 }
 
 constexpr int kFlowBlock = 256;
-constexpr int kFlowMaxPairs = 2048;   // pair labels cached in LDS
+constexpr int kFlowTile = 2048;   // pair labels cached in LDS, one tile at a time (any number of pairs)
 
 __global__ __launch_bounds__(kFlowBlock) void flow_rigid_kernel(
     const float *__restrict__ points, const float *__restrict__ labels, int N,
     const float *__restrict__ pairLabels, int P, const float *__restrict__ M, float *__restrict__ flow)
 {
-    __shared__ float lab[kFlowMaxPairs];
-    for (int k = threadIdx.x; k < P; k += kFlowBlock) lab[k] = pairLabels[k];
-    __syncthreads();
+    __shared__ float lab[kFlowTile];
     const int i = blockIdx.x * kFlowBlock + threadIdx.x;
-    if (i >= N) return;
-    const float l = labels[i];
+    const float l = i < N ? labels[i] : 0.f;
     int p = P;                                   // not matched: pose only
-    for (int k = 0; k < P; ++k)
-        if (lab[k] == l) p = k;                  // pairs[:,0] holds each source label at most once
+    for (int k0 = 0; k0 < P; k0 += kFlowTile) {
+        const int kn = min(kFlowTile, P - k0);
+        if (k0 > 0) __syncthreads();
+        for (int k = threadIdx.x; k < kn; k += kFlowBlock) lab[k] = pairLabels[k0 + k];
+        __syncthreads();
+        for (int k = 0; k < kn; ++k)
+            if (lab[k] == l) p = k0 + k;         // pairs[:,0] holds each source label at most once
+    }
+    if (i >= N) return;
     const float *m = M + (size_t)p * 16;
     const float x = points[(size_t)i * 3 + 0], y = points[(size_t)i * 3 + 1], z = points[(size_t)i * 3 + 2];
     // (T pose [x y z 1]^T)[0:3] - p, utils_flow.py:67-68

@@ -696,6 +696,29 @@ def test_demo_frame_stages_from_the_reference_initial_poses(fixture):
         assert d[finite].max() < TOL_M
 
 
+def test_flow_rigid_with_more_pairs_than_one_label_tile():
+    """flow_estimation_torch (utils_flow.py:57-69) with 5000 matched pairs -- the kernel caches the pair labels in
+    LDS 2048 at a time; the reference has no such limit -- against the oracle's restatement."""
+    from icp_flow_amd import utils_flow
+    rng = np.random.default_rng(3)
+    P, N = 5000, 60000
+    labels = rng.integers(-1, P + 200, N).astype(np.float32)
+    labels[rng.random(N) < 0.1] = -1e8
+    pts = rng.uniform(-50, 50, (N, 3)).astype(np.float32)
+    pair_labels = rng.permutation(P + 200)[:P].astype(np.float32)
+    pairs = np.zeros((P, 10), np.float32)
+    pairs[:, 0] = pair_labels
+    T = np.tile(np.eye(4, dtype=np.float32), (P, 1, 1))
+    T[:, :3, 3] = rng.uniform(-1, 1, (P, 3))
+    ang = rng.uniform(-0.05, 0.05, P)
+    T[:, 0, 0], T[:, 0, 1], T[:, 1, 0], T[:, 1, 1] = np.cos(ang), -np.sin(ang), np.sin(ang), np.cos(ang)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, 3] = (0.3, -0.2, 0.01)
+    got = utils_flow.flow_estimation_torch(None, G(pts), None, G(labels), None, G(pairs), G(T), G(pose)).cpu().numpy()
+    want = rp.flow_estimation_torch(C(pts), C(labels), C(pairs), C(T), C(pose)).numpy()
+    np.testing.assert_allclose(got, want, atol=2e-5)
+
+
 def test_cluster_stats_kernel_vs_torch():
     """icpflow_cluster_stats (centroid, sorted bbox extents per label) against plain torch per cluster."""
     from icp_flow_amd.utils_check import ClusterTable
