@@ -3,7 +3,7 @@
 # run, --kernel-trace only: the pool refuses --pmc together with other trace domains).
 # Usage (on the GPU box, via gpurun):  bash tools/profile_pmc.sh <tag>
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"

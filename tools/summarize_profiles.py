@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output under gpurun_out/ into small, tracked summaries under profiles/.
 
-    python tools/summarize_profiles.py <round-tag> <kernel-stats-dir> <pmc-dir>
+    python tools/summarize_profiles.py <round-tag> <kernel-stats-dir> <pmc-dir> [pairs points]
 
 Writes profiles/<tag>_kernel_stats.csv (verbatim rocprofv3 --stats table),
 profiles/<tag>_pmc_summary.json (per-kernel per-dispatch counter averages) and
@@ -17,6 +17,7 @@ import shutil
 import sys
 
 tag, stats_dir, pmc_dir = sys.argv[1:4]
+pairs, points = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (256, 1024)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(REPO, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -61,4 +62,20 @@ if dom:
                 "batch-global stop that return immediately",
     }
     json.dump(traffic, open(os.path.join(out, f"{tag}_icp_kernel_traffic.json"), "w"), indent=1)
+    # what bench.py reads for roofline.traffic / roofline.valu: stamped with the hash of the library that was
+    # profiled (icpflow_build_info()); bench.py refuses the file when its own library differs
+    sys.path.insert(0, REPO)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("icpflow_build", os.path.join(REPO, "icp_flow_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    counters = dict(traffic)
+    counters.update({"library_build": b.built_hash(), "pairs": pairs, "points": points,
+                     "SQ_INSTS_VALU_per_launch": e.get("SQ_INSTS_VALU_per_dispatch"),
+                     "SQ_INSTS_LDS_per_launch": e.get("SQ_INSTS_LDS_per_dispatch"),
+                     "SQ_LDS_BANK_CONFLICT_per_launch": e.get("SQ_LDS_BANK_CONFLICT_per_dispatch"),
+                     "SQ_ACTIVE_INST_LDS_per_launch": e.get("SQ_ACTIVE_INST_LDS_per_dispatch"),
+                     "SQ_WAVE_CYCLES_per_launch": e.get("SQ_WAVE_CYCLES_per_dispatch"),
+                     "SQ_BUSY_CYCLES_per_launch": e.get("SQ_BUSY_CYCLES_per_dispatch")})
+    json.dump(counters, open(os.path.join(out, f"{tag}_icp_kernel_counters.json"), "w"), indent=1)
 print(open(os.path.join(out, f"{tag}_icp_kernel_traffic.json")).read() if dom else "no dominant kernel found")
