@@ -68,6 +68,8 @@ struct IcpParams {
     float *history;          // [kHistIters, B, kHistStride] or NULL
     int B;
     IcpTeam team;            // wgPair == NULL: one workgroup per pair (blockIdx.x = pair)
+    int recOn;               // sorted sweep in LDS, one workgroup per pair: per-query records behind the LDS image
+                             // (adaptive windows, see the search phase)
 };
 
 
@@ -272,6 +274,11 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
 // sum w |x R + T - y|^2 = (Sxx - W|mx'|^2) + (Syy - W|my'|^2) - 2 W sum_ij R_ij H_ij  (== :191,
 // evaluated without rounding X R + T to fp32 first), so one pass over the points suffices.
 constexpr int kMoments = 18;
+// adaptive windows: LDS image (12 B / point) + query records (16 B / point) <= 112 KiB.  Used when the batch is larger
+// than the GPU (B > #CUs: the launch is bound by the total search work, measured -8.5 % at 1024 x 2048); a batch that
+// fits (BASELINE config 2) is bound by the latency of its slowest pair, where the bookkeeping of the records costs as
+// much as the shorter windows save (+1.3 %).  Results are identical either way.
+constexpr int kRecMaxN = 4096;
 constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
 // ---------------------------------------------------------------------------------
@@ -485,6 +492,19 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             // GRID == 4: the sorted fixed cloud is staged into LDS once per launch and every
             // per-iteration access (window search, scan, resolve) stays on chip
             float *lx = reinterpret_cast<float *>(dynLds), *ly = lx + NP16, *lz = ly + NP16;
+            // Adaptive windows.  The gate only asks for neighbours within thres, but after the first iterations almost
+            // every query already HAS one much closer: the target found in the previous iteration, at distance d, is
+            // still there, and the query has moved by |dq| since -- so its nearest neighbour is now at most d + |dq|
+            // away, and nothing farther than that along the sort axis can be it (or tie with it): half-window
+            // d + |dq| instead of 1.01 thres.  A query WITHOUT a neighbour inside the gate is the opposite case: once a
+            // window of half-width Mc = 1.25 thres has shown that its nearest target is at least lb > thres away, it
+            // stays outside the gate until it has moved by lb - thres, and until then it needs no window at all.
+            // Each query keeps (where it was; +d or -lb) in LDS behind the image.  The minimum over the window, the
+            // gate decision and the neighbour of every gated query are those of the full window: results are
+            // bit-identical, the windows shorter.
+            constexpr bool REC = (GRID == 4) && !TEAM;
+            float4 *rec = reinterpret_cast<float4 *>(dynLds + (size_t)NP16 * 12);
+            const bool recOn = REC && p.recOn != 0;
             if (GRID == 4 && it == itBegin) {
                 for (int k = tid; k < np16; k += BLOCK) { lx[k] = gx[k]; ly[k] = gy[k]; lz[k] = gz[k]; }
                 __syncthreads();
@@ -501,6 +521,11 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
                 bool live[Q];
                 float lo = kInf, hi = -kInf;
+                float recM[Q], recW[Q];   // adaptive windows: this query's half-window (< 0: none) and carried bound
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { recM[q] = 0.f; recW[q] = 0.f; }
+                const float certMargin = 1.25f * p.sweepMargin;       // Mc
+                const float gateOut = p.sweepMargin;                  // > thres with 1 % to spare (1.01 thres)
                 ICPFLOW_STAMP(1);
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
@@ -520,11 +545,28 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                         qy[q] = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1])) + Tf[1];
                         qz[q] = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2])) + Tf[2];
                         const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
-                        lo = fminf(lo, qa); hi = fmaxf(hi, qa);
+                        float m = p.sweepMargin;
+                        if (recOn) {
+                            m = certMargin;   // first iteration, lost bounds: the certifying window
+                            if (it > itBegin) {
+                                const float4 o = rec[i];
+                                const float ex = qx[q] - o.x, ey = qy[q] - o.y, ez = qz[q] - o.z;
+                                const float dq = fabsf(ex) + fabsf(ey) + fabsf(ez);   // >= the distance moved (no sqrt)
+                                if (o.w < 0.f) {   // certified outside the gate: nearest target at least -o.w away
+                                    const float lb = -o.w - dq * 1.001f - 1e-6f;
+                                    if (lb > gateOut) { m = -1.f; recW[q] = -lb; }   // still outside: no window, no search
+                                } else {
+                                    const float ub = (o.w + dq) * 1.001f + 1e-5f;
+                                    if (ub <= p.sweepMargin) m = ub;   // (inf / NaN bounds take the certifying window)
+                                }
+                            }
+                            recM[q] = m;
+                        }
+                        if (m >= 0.f) { lo = fminf(lo, qa - m); hi = fmaxf(hi, qa + m); }
                     }
                 }
                 ICPFLOW_STAMP(11);
-                // span of this wave's live queries along the sort axis
+                // the part of the sort axis in which this wave's live queries can find their neighbours
                 lo = wave_min_uniform(lo);
                 hi = wave_max_uniform(hi);
                 ScanAcc<Q> acc;
@@ -537,9 +579,9 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     // single pass: this wave's window of the previous iteration is the hint
                     int jlo = winLo, jhi = winHi;
                     if (ngr == 1 && winHi >= 0)
-                        sorted_window_hint(keyf, yc.n, lo - p.sweepMargin, hi + p.sweepMargin, lane, jlo, jhi);
+                        sorted_window_hint(keyf, yc.n, lo, hi, lane, jlo, jhi);
                     else
-                        sorted_window(keyf, yc.n, lo - p.sweepMargin, hi + p.sweepMargin, lane, jlo, jhi);
+                        sorted_window(keyf, yc.n, lo, hi, lane, jlo, jhi);
                     winLo = jlo; winHi = jhi;
                     cb = (jlo / kChunk) * kChunk;
                     ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
@@ -554,6 +596,26 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                         scan_range_tie_uniform<Q>(gx, gy, gz, cb, ce, qx, qy, qz, acc, tie);
                 }
                 ICPFLOW_STAMP(2);
+                if (recOn) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const int i = qBegin + g * PER + (wave * Q + q) * kWave + lane;
+                        if (!live[q]) continue;
+                        float w = recW[q];                       // no window: the carried lower bound
+                        if (recM[q] >= 0.f) {
+                            // nearest target of a window that covers qa +- recM (raw v_sqrt_f32, 1 ulp: the bounds
+                            // built from it carry margins of 1e-6 and more)
+                            const float d = __builtin_amdgcn_sqrtf(acc.best[q]);
+                            w = d;
+                            // nothing inside the gate and the window was the certifying one: every target is at least
+                            // min(d, Mc) away (targets outside the window differ by more than Mc along the sort axis)
+                            if (recM[q] == certMargin && d > gateOut) w = -fminf(d, certMargin) * 0.999999f;
+                        } else {
+                            acc.best[q] = kInf;                  // (not searched: certainly not gated)
+                        }
+                        rec[i] = make_float4(qx[q], qy[q], qz[q], w);
+                    }
+                }
                 // neighbour = the target at distance `best` (bit-equal re-evaluation of the winning
                 // chunk).  If several targets tie -- in that chunk or, flagged by the scan, in another
                 // one -- the lowest ORIGINAL index wins: only then are the original indices fetched
@@ -1106,7 +1168,7 @@ template <int BLOCK, int Q, int TS, int GRID, bool TEAM = false>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
-                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 : 0;
+                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + ((!TEAM && p.recOn) ? (size_t)p.N * 16 : 0) : 0;
     if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation and device
         static std::atomic<unsigned long long> raised{0ull};
         ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM>), 156 * 1024, &raised);
@@ -1266,6 +1328,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
         p.sortedRaw = 1;
+        p.recOn = opts.adaptiveWindows && N <= kRecMaxN && B > device_cus();
     } else if (grid != nullptr && grid->mode == 3) {
         int NP2 = 64;
         while (NP2 < N) NP2 <<= 1;
@@ -1282,6 +1345,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
+        p.recOn = opts.adaptiveWindows && N <= kRecMaxN && B > device_cus();
     } else if (grid != nullptr) {
         // bin the fixed cloud once: cell edge 1 % above the gate radius (rounding head-room)
         const float invh = (float)(1.0 / (1.01 * thres));

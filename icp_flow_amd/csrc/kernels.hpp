@@ -146,6 +146,7 @@ struct IcpOpts {
     int arith = 0;                 // ICPFLOW_ARITH_*
     bool teams = true;             // several workgroups per large pair when the batch leaves CUs idle
     bool speculative = true;       // batch-global stop in ONE launch (false: one launch per iteration)
+    bool adaptiveWindows = true;   // sorted sweep: per-query windows from the previous iteration's neighbours
     LaunchProfile *profile = nullptr;
     bool ctrlCleared = false;      // the caller's count_pair launch already zeroed *ctrl
     bool *historyPending = nullptr;   // non-NULL: do not launch the history epilogue; *historyPending = "the final

@@ -145,6 +145,31 @@ def test_config2_full_batch_fp32_reference_arithmetic(config2):
     assert (err32 < TOL_M).sum() >= 256 - 10 and err32[c["determined"]].max() < 1e-3, msg
 
 
+@pytest.mark.parametrize("shape", ["config4_shard_1024x2048", "ragged_600x1024", "ragged_400x3000"])
+def test_adaptive_windows_change_nothing(shape):
+    """Batches larger than the GPU: every query's search window comes from where its neighbour was in the previous
+    iteration, and queries certified to be outside the gate are not searched at all (icp.hip, "Adaptive windows").
+    Gate decisions and neighbours are those of the full window: transforms and iteration count are bit-identical
+    to ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS."""
+    if shape == "config4_shard_1024x2048":
+        S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
+    elif shape == "ragged_600x1024":
+        S, D, _ = synthetic.make_batch(600, 1024, seed=31, ragged=True, n_min=60)
+    else:
+        S, D, _ = synthetic.make_batch(400, 3000, seed=47, ragged=True, n_min=300)
+    a = rp.default_args(max_points=S.shape[1], icp_max_iterations=50)
+    s, d = G(S), G(D)
+    with _lib.options(no_adaptive_windows=True):
+        T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    assert int(it0) == int(it1) and int(it1) > 0
+    assert torch.equal(T0, T1)
+    ap = rp.default_args(max_points=S.shape[1], icp_max_iterations=50, icp_stop_mode="per_pair")
+    with _lib.options(no_adaptive_windows=True):
+        P0 = utils_match.hist_icp(ap, s, d)
+    assert torch.equal(P0, utils_match.hist_icp(ap, s, d))
+
+
 # ------------------------------------------------------------------------------------------ fused vote bins
 def _wide_pair(n, seed):
     """A wall: 24 m x 0.4 m x 2.6 m, n points -- wider than the 8 m above which the vote sorts by the composite

@@ -14,7 +14,7 @@ for i in range(B):   # pre-align so that there are inliers (like after the histo
 src, dst = src.cuda(), dst.cuda()
 _opts = _lib.options(search=os.environ.get("SEARCH", "auto")); _opts.__enter__()
 names = ["entry->scan", "scan (stage+tiles)", "resolve+gate+acc", "block_sum7", "pass2+block_sum9", "kabsch", "pass3+block_sum1", "exit"]
-for k in (1, 2, 3):
+for k in (1, 2, 3, 8, 20):
     icp.iterative_closest_point(src, dst, max_iterations=k)
     torch.cuda.synchronize()
     st = (ctypes.c_longlong * 16)()
@@ -30,7 +30,7 @@ for k in (1, 2, 3):
         print(f"   +{v[idx]-prev:8d}  {name}")
         prev = v[idx]
 
-    if k == 3:
+    if k >= 3:
         ws = (ctypes.c_longlong * 256)()
         _lib._L.icpflow_debug_wave_stamps(ws)
         w = np.array(ws[:], dtype=np.int64).reshape(16, 16)
