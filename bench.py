@@ -394,7 +394,7 @@ def hdbscan_measurement(dev, g, gdir):
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t) / reps * 1e3, out
 
-    ms_tree, tree = timeit(lambda: utils_cluster.hdbscan_mst(pts, 20))
+    ms_tree, tree = timeit(lambda: utils_cluster.hdbscan_mst(pts, 21))   # min_samples 20 of the hdbscan package: the point itself not counted
     ms_all, lab = timeit(lambda: utils_cluster.cluster_pcd(a, pts, nonground))
     want = np.concatenate([lab8["label_dst"], lab8["label_src"]]).astype(np.int64)
     got = lab.cpu().numpy().astype(np.int64)

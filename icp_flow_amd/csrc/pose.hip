@@ -103,7 +103,7 @@ __global__ void select_kernel(const double *__restrict__ partial, int qblocks,
     // fused finish (M == NULL): the composed pose comes straight from the ICP's history / state
     int n = 0;
     if (M == nullptr) {
-        n = pose_stop_iteration(fused);
+        n = pose_stop_iteration_wave(fused, threadIdx.x & (kWave - 1));   // 64 tallies per round, every wave for itself
         // iterations of the batch; -1 = a team gave up waiting, transforms are NaN
         if (b == 0 && iters != nullptr) *iters = fused.ctrl->error ? -1 : n;
     }
