@@ -230,6 +230,43 @@ def _partition_mismatch(a, b):
     return bad
 
 
+def _mismatch_mask(a, b):
+    """the points _partition_mismatch counts"""
+    a, b = np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64)
+    bad = (a < 0) != (b < 0)
+    both = (a >= 0) & (b >= 0)
+    for c in np.unique(a[both]):
+        sel = both & (a == c)
+        bad |= sel & (b != np.bincount(b[sel]).argmax())
+    return bad
+
+
+def _assert_mismatches_sit_at_tied_merge_heights(ea, eb, w, got, want):
+    """Two correct HDBSCAN runs can only differ where the hierarchy is not unique: at TIED merge heights (equal
+    mutual-reachability weights, which Prim orders by visiting order, numpy's argsort arbitrarily and this build by
+    row numbers).  Checked explicitly: the points labelled differently form connected pieces of the spanning tree,
+    and the lightest tree edge leaving each piece -- the height at which it merges with the rest -- has a weight
+    that occurs more than once in the tree.  -> number of differing points."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    bad = _mismatch_mask(got, want)
+    if not bad.any():
+        return 0
+    n = len(got)
+    vals, counts = np.unique(w, return_counts=True)
+    tied = dict(zip(vals.tolist(), (counts > 1).tolist()))
+    inside = bad[ea] & bad[eb]
+    _, comp = connected_components(coo_matrix((np.ones(int(inside.sum())), (ea[inside], eb[inside])), shape=(n, n)),
+                                   directed=False)
+    leaving = bad[ea] != bad[eb]                         # edges with exactly one end in the differing set
+    piece = np.where(bad[ea], comp[ea], comp[eb])[leaving]
+    wl = w[leaving]
+    for c in np.unique(comp[bad]):
+        lightest = wl[piece == c].min()
+        assert tied[float(lightest)], (int((comp == c).sum()), float(lightest))
+    return int(bad.sum())
+
+
 def _lattice(n_side, step=0.25):
     g = np.stack(np.meshgrid(np.arange(n_side), np.arange(n_side), np.arange(3), indexing="ij"), -1).reshape(-1, 3)
     return (g * step).astype(np.float32)
@@ -247,6 +284,22 @@ def test_oracle_tree_weights_equal_sklearn_prim():
         from scipy.spatial import cKDTree
         d, _ = cKDTree(p.astype(np.float64)).query(p.astype(np.float64), k=k)
         assert np.array_equal(np.sqrt(c2), d[:, -1])
+
+
+@pytest.mark.parametrize("case", ["crop_0", "crop_1", "crop_2", "synth"])
+def test_host_labels_on_the_oracle_tree_equal_the_reference_run_up_to_tied_heights(case):
+    """No GPU: the oracle's exact tree (core distances in the hdbscan package's convention) through the product's
+    host routine (icpflow_hdbscan_labels) against the reference's own cluster_pcd run (G11); whatever differs sits
+    at a tied merge height."""
+    g = load_golden("g11_hdbscan")
+    p, (k, ncl), want = g[f"{case}_points"], g[f"{case}_params"], g[f"{case}_labels"]
+    mask = g["synth_nonground"] if case == "synth" else np.ones(len(p), dtype=bool)
+    ra, rb, rw, _ = oh.mst(p[mask], int(k) + 1)
+    lab = _hip().labels_from_mst(ra, rb, np.sqrt(rw), int(mask.sum()), int(k))
+    # the fixture went through the reference's keep-the-largest step: compare on the points it kept clustered
+    kept = want[mask] >= 0
+    n_bad = _assert_mismatches_sit_at_tied_merge_heights(ra, rb, np.sqrt(rw), np.where(kept | (lab < 0), lab, -1), want[mask])
+    assert n_bad <= 0.01 * mask.sum()
 
 
 def _gpu_tree(p, k, mask=None):
@@ -322,6 +375,11 @@ def test_gpu_hdbscan_labels_against_reference_run(case):
     # the host half on its own: the oracle's tree through the product's host logic gives the product's labels
     ra, rb, rw, _ = oh.mst(p[mask], int(k) + 1)
     lab = _hip().labels_from_mst(ra, rb, np.sqrt(rw), int(mask.sum()), int(k))
+    # ... and every point labelled differently from the reference run sits at a tied merge height
+    # (the fixture went through the reference's keep-the-largest step: compare on the points it kept clustered)
+    kept = want[mask] >= 0
+    assert _assert_mismatches_sit_at_tied_merge_heights(ra, rb, np.sqrt(rw), np.where(kept | (lab < 0), lab, -1),
+                                                        want[mask]) <= 0.01 * mask.sum()
     full = _hip().hdbscan(p, int(k), None, None if case != "synth" else mask)
     assert np.array_equal(full[mask], lab)
 
@@ -336,6 +394,12 @@ def test_gpu_hdbscan_demo_frame_against_reference_run():
     got = _hip().cluster_pcd(a, pts, np.ones(len(pts), dtype=bool)).astype(np.int64)
     assert adjusted_rand_score(want, got) > 0.999
     assert _partition_mismatch(got, want) < 0.005 * len(pts)
+    # the differing points, explicitly: pieces of the spanning tree that merge with the rest at tied heights
+    t = _hip().hdbscan_mst(pts, 21)
+    raw = _hip().hdbscan(pts, 20)                              # before the keep-largest step (all clusters survive here)
+    n_bad = _assert_mismatches_sit_at_tied_merge_heights(t["a"].cpu().numpy().astype(np.int64), t["b"].cpu().numpy().astype(np.int64),
+                                                         np.sqrt(t["w2"].cpu().numpy()), raw, want)
+    assert n_bad < 0.001 * len(pts), n_bad
     with pytest.raises(RuntimeError):
         _hip().hdbscan_mst(pts, 65)                      # min_samples beyond the wave-wide selection
     with pytest.raises(ValueError):
