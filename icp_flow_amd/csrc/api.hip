@@ -42,6 +42,8 @@ struct Opts {
     unsigned flags = 0u;
     LaunchProfile *profile = nullptr;
     uint32_t *voteBins = nullptr;
+    const float *initR = nullptr, *initT = nullptr;
+    float *history = nullptr;
     bool on(unsigned offFlag) const { return (flags & offFlag) == 0u; }
     IcpOpts icp(float *scratch) const
     {
@@ -172,6 +174,11 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
     o.flags = opt->flags;
     o.profile = reinterpret_cast<LaunchProfile *>(opt->profile);
     o.voteBins = opt->d_vote_bins_u32;
+    if ((opt->d_icp_init_R == nullptr) != (opt->d_icp_init_T == nullptr))
+        return fail(ICPFLOW_E_ARG, "%s: options.d_icp_init_R and d_icp_init_T come together", fn);
+    o.initR = opt->d_icp_init_R;
+    o.initT = opt->d_icp_init_T;
+    o.history = opt->d_icp_history;
     return 0;
 }
 
@@ -599,9 +606,22 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
     launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, sizeof(IcpCtrl));
+    IcpOpts io = o.icp(w.grid.sortX);
+    io.initR = o.initR;
+    io.initT = o.initT;
+    if (o.history != nullptr &&
+        !(stop_mode == ICPFLOW_STOP_REFERENCE && max_iterations > 1 && max_iterations <= kHistIters &&
+          o.arith == ICPFLOW_ARITH_FP64 && io.speculative))
+        return fail(ICPFLOW_E_ARG, "icpflow_icp: options.d_icp_history needs the single-launch reference stop mode "
+                                   "(2 <= max_iterations <= %d, fp64 arithmetic)", kHistIters);
+    if (o.initR != nullptr && o.arith != ICPFLOW_ARITH_FP64)
+        return fail(ICPFLOW_E_ARG, "icpflow_icp: an initial transform is not built for ICPFLOW_ARITH_FP32_REFERENCE");
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
                            relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N, o), w.history, &w.team,
-                           o.icp(w.grid.sortX), s));
+                           io, s));
+    if (o.history != nullptr)   // t_history: the per-iteration records of the speculative launch
+        ICPFLOW_TRY(hipMemcpyAsync(o.history, w.history, (size_t)max_iterations * B * kHistStride * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
     ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
     return 0;
 }

@@ -68,6 +68,8 @@ struct IcpParams {
     float *history;          // [kHistIters, B, kHistStride] or NULL
     int B;
     IcpTeam team;            // wgPair == NULL: one workgroup per pair (blockIdx.x = pair)
+    const float *initR;      // [B,3,3] / [B,3]: the state before the first iteration (init_transform), NULL = identity
+    const float *initT;
     int recOn;               // sorted sweep in LDS, one workgroup per pair: per-query records behind the LDS image
                              // (adaptive windows, see the search phase)
 };
@@ -411,12 +413,17 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     // at a time in the serial tail of every iteration).
     int active = 1;
     if (itBegin == 0) {
-        if (tid < 12) bcast[tid] = (tid < 9 && tid % 4 == 0) ? 1.f : 0.f;  // :140
+        // state 0: identity (:140) or the caller's init_transform (:118-138)
+        float s0 = (tid < 9 && tid % 4 == 0) ? 1.f : 0.f;
+        if (p.initR != nullptr && tid < 12) s0 = tid < 9 ? p.initR[(size_t)b * 9 + tid] : p.initT[(size_t)b * 3 + tid - 9];
+        if (tid < 12) bcast[tid] = s0;
         if (tid == 0) { bcast[12] = 1.f; bcast[13] = 0.f; bcast[14] = 0.f; }
-        if (tid < 16) ring[tid] = (tid < 9) ? ((tid % 4 == 0) ? 1.f : 0.f) : 0.f;   // state 0 = identity
-        if (tid == 13) {   // and its hash (same formula as in the loop)
-            const int one = __float_as_int(1.0f);
-            ring[13] = __int_as_float((one * 3) ^ (one * 11) ^ (one * 19));
+        if (tid < 16) ring[tid] = tid < 12 ? s0 : 0.f;
+        if (tid < kWave) {   // and its hash (same formula as in the loop), every lane of wave 0 the same value
+            int hash = 0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) hash ^= __float_as_int(__shfl(s0, k, kWave)) * (k < 9 ? 2 * k + 3 : 2 * (k - 9) + 23);
+            if (tid == 13) ring[13] = __int_as_float(hash);
         }
     } else {
         if (tid < 9) bcast[tid] = st->R[tid];
@@ -1315,6 +1322,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     p.thr2 = (float)(thres * thres);
     p.relThr = (float)relThr;
     p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
+    p.initR = opts.initR; p.initT = opts.initT;
     hipError_t e = hipSuccess;
     if (opts.historyPending != nullptr) *opts.historyPending = false;
     if (!opts.ctrlCleared) {

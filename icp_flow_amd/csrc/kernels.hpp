@@ -147,6 +147,8 @@ struct IcpOpts {
     bool teams = true;             // several workgroups per large pair when the batch leaves CUs idle
     bool speculative = true;       // batch-global stop in ONE launch (false: one launch per iteration)
     bool adaptiveWindows = true;   // sorted sweep: per-query windows from the previous iteration's neighbours
+    const float *initR = nullptr;  // [B,3,3] / [B,3]: state before the first iteration (init_transform), or identity
+    const float *initT = nullptr;
     LaunchProfile *profile = nullptr;
     bool ctrlCleared = false;      // the caller's count_pair launch already zeroed *ctrl
     bool *historyPending = nullptr;   // non-NULL: do not launch the history epilogue; *historyPending = "the final

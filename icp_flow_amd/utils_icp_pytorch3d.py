@@ -36,33 +36,82 @@ def iterative_closest_point(X, Y, init_transform=None, thres=0.1, max_iterations
                             verbose=False, stop_mode="reference"):
     """utils_icp_pytorch3d.py:37-225 on [B,N,4] clouds (x,y,z,flag).
 
-    Differences from the reference object, all outside what its callers read
-    (utils_icp.py:60-61 reads RTs.R / RTs.T only): `t_history` is empty (the per-iteration
-    transforms never leave the device) and `converged` is materialised lazily from a device
-    flag.  estimate_scale / allow_reflection / init_transform are fixed to the values the
-    reference passes (utils_icp.py:51-58) and anything else raises.
+    `init_transform` (SimilarityTransform with unit scale, :118-138): the first correspondence search runs on
+    X R0 + T0.  `t_history` (:187) is materialised lazily from the per-iteration records on the device (reference
+    stop rule, max_iterations <= 128, at most 64 MiB of records; empty otherwise) and `converged` is a lazy device
+    flag.  estimate_scale / allow_reflection are fixed to the values ICP-Flow passes (utils_icp.py:51-58) and raise
+    otherwise (the rotation is the closed form of the proper-rotation problem, without singular values).
     """
-    if estimate_scale or allow_reflection or init_transform is not None:
-        raise NotImplementedError("only the configuration used by ICP-Flow (utils_icp.py:51-58) is built")
+    if estimate_scale or allow_reflection:
+        raise NotImplementedError("only estimate_scale=False, allow_reflection=False (what ICP-Flow uses, "
+                                  "utils_icp.py:51-58) is built")
     x = _lib.cloud(X, "X")
     y = _lib.cloud(Y, "Y")
     if x.shape != y.shape:
         raise ValueError("Point sets X and Y have to have the same number of batches, points and dimensions.")
     B, N, _ = x.shape
     dev = x.device
+    init = None
+    if init_transform is not None:
+        try:                                                                        # :121-133
+            R0, T0, s0 = init_transform
+            assert R0.shape == (B, 3, 3) and T0.shape == (B, 3) and s0.shape == (B,)
+        except Exception:
+            raise ValueError("The initial transformation init_transform has to be a named tuple SimilarityTransform "
+                             "with elements (R, T, s). R are dim x dim orthonormal matrices of shape (minibatch, dim, "
+                             "dim), T is a batch of dim-dimensional translations of shape (minibatch, dim) and s is a "
+                             "batch of scalars of shape (minibatch,).") from None
+        if not bool((s0 == 1).all()):
+            raise NotImplementedError("init_transform with a scale other than 1 (estimate_scale is not built)")
+        init = (R0.to(device=dev, dtype=torch.float32).contiguous(), T0.to(device=dev, dtype=torch.float32).contiguous())
     R = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
     T = torch.empty((B, 3), dtype=torch.float32, device=dev)
     rmse = torch.empty((B,), dtype=torch.float32, device=dev)
     flags = torch.zeros((2,), dtype=torch.int32, device=dev)        # [iterations, converged]
+    hist = None
+    if stop_mode_of(stop_mode) == _lib.STOP_REFERENCE and 2 <= int(max_iterations) <= 128 and \
+            int(max_iterations) * B * 64 <= (64 << 20) and not (_lib._current()[-1]["flags"] & _lib.OPT_FLAGS["no_speculative"]) \
+            and _lib._current()[-1]["arith"] == 0:
+        hist = torch.empty((int(max_iterations), B, 16), dtype=torch.float32, device=dev)
     ws = _lib.workspace(dev, _lib.workspace_bytes(B, N))
-    _lib.call("icpflow_icp", _lib.ptr(x), _lib.ptr(y), None, B, N, float(thres), int(max_iterations),
-              float(relative_rmse_thr), stop_mode_of(stop_mode), _lib.ptr(R), _lib.ptr(T), _lib.ptr(rmse),
-              _lib.ptr(flags[0:1]), _lib.ptr(flags[1:2]), _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())
+    with _lib.options(icp_init=init, icp_history=hist):
+        _lib.call("icpflow_icp", _lib.ptr(x), _lib.ptr(y), None, B, N, float(thres), int(max_iterations),
+                  float(relative_rmse_thr), stop_mode_of(stop_mode), _lib.ptr(R), _lib.ptr(T), _lib.ptr(rmse),
+                  _lib.ptr(flags[0:1]), _lib.ptr(flags[1:2]), _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())
     # Xt = s X R + T (utils_icp_pytorch3d.py:177, :395) -- returned for API parity
     Xt = torch.baddbmm(T[:, None, :], x[:, :, 0:3], R)
     sol = ICPSolution(_LazyFlag(flags, 1), rmse, Xt,
-                      SimilarityTransform(R, T, torch.ones(B, dtype=torch.float32, device=dev)), [])
+                      SimilarityTransform(R, T, torch.ones(B, dtype=torch.float32, device=dev)),
+                      _LazyHistory(hist, flags))
     return sol
+
+
+class _LazyHistory(list):
+    """t_history: one SimilarityTransform per executed iteration, built from the device records on first use."""
+
+    def __init__(self, hist, flags):
+        super().__init__()
+        self._hist, self._flags, self._done = hist, flags, hist is None
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            n = int(self._flags[0].item())
+            h = self._hist[:max(n, 0)]
+            B = h.shape[1]
+            ones = torch.ones(B, dtype=torch.float32, device=h.device)
+            for k in range(h.shape[0]):
+                super().append(SimilarityTransform(h[k, :, 0:9].reshape(B, 3, 3), h[k, :, 9:12], ones))
+        return self
+
+    def __len__(self):
+        return list.__len__(self._fill())
+
+    def __iter__(self):
+        return list.__iter__(self._fill())
+
+    def __getitem__(self, i):
+        return list.__getitem__(self._fill(), i)
 
 
 class _LazyFlag:

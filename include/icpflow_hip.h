@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 200 /* 0.2.0: per-call options replace the process-global switches of 0.1 */
+#define ICPFLOW_VERSION 201 /* 0.2.1: per-call options replace the process-global switches of 0.1;
+                               icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
 #define ICPFLOW_E_ARG (-1)       /* bad pointer / size / enum                      */
@@ -84,6 +85,13 @@ const char *icpflow_build_info(void);
  * profile -- optional recorder of the dominant kernel's launches (see the end of this header).
  * d_vote_bins_u32 -- optional debug output of icpflow_estimate_init_pose / icpflow_hist_icp: the
  *   uint32 bins [B, Lx*Ly*Lz] of the fused (sorted) vote exactly as the peak search reads them.
+ * d_icp_init_R [B,3,3], d_icp_init_T [B,3] -- icpflow_icp only, both or neither: `init_transform` of
+ *   iterative_closest_point (utils_icp_pytorch3d.py:118-138, scale 1): the first correspondence search runs
+ *   on X R0 + T0 instead of X (every iteration still solves for the absolute transform of X).
+ * d_icp_history [max_iterations, B, 16] -- icpflow_icp only: `t_history` of the reference's ICPSolution
+ *   (:187), i.e. (R row-major 9, T 3, rmse, 3 unused) after every iteration; rows of iterations the batch rule
+ *   did not reach are unspecified.  Available in the single-launch reference stop mode (max_iterations <= 128,
+ *   fp64 arithmetic); otherwise ICPFLOW_E_ARG.
  * ------------------------------------------------------------------------- */
 #define ICPFLOW_SEARCH_AUTO 0
 #define ICPFLOW_SEARCH_SCAN 1
@@ -111,6 +119,9 @@ typedef struct icpflow_options {
     unsigned flags;
     icpflow_profile_t *profile;
     uint32_t *d_vote_bins_u32;
+    const float *d_icp_init_R;
+    const float *d_icp_init_T;
+    float *d_icp_history;
 } icpflow_options_t;
 
 /* Bytes of device scratch the fused entry points below need for a batch of B

@@ -225,7 +225,8 @@ def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_orde
 
 
 def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
-                            relative_rmse_thr=ICP_REL_RMSE, trace=False, kabsch_dtype=None, sum_order=None):
+                            relative_rmse_thr=ICP_REL_RMSE, trace=False, kabsch_dtype=None, sum_order=None,
+                            init_transform=None):
     """utils_icp_pytorch3d.py:100-225.  Returns a namespace with
     converged, rmse, Xt, R, T, iterations (number of loop bodies executed) and,
     with trace=True, the per-iteration (R, T, rmse, inlier count) history.
@@ -240,6 +241,9 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
     Xt = X0
     R = torch.eye(3)[None].repeat(b, 1, 1)                                    # :140
     T = X0.new_zeros((b, 3))
+    if init_transform is not None:                                            # :118-138 (unit scale)
+        R, T = init_transform[0], init_transform[1]
+        Xt = torch.bmm(X0, R) + T[:, None, :]                                 # _apply_similarity_transform, :395
     prev = None
     rmse = None
     converged = False

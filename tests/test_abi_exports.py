@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_the_header():
     from icp_flow_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.VERSION == 200
+    assert _lib.VERSION == 201
     assert re.fullmatch(r"[0-9a-f]{16}", _lib.BUILD_INFO), _lib.BUILD_INFO
 
 
@@ -73,7 +73,7 @@ def test_options_are_per_call_and_per_thread():
     assert seen["other"] == 0
     assert _lib._current()[-1]["search"] == 0
     assert set(_lib.OPT_FLAGS.values()) == {1 << k for k in range(9)}
-    assert ctypes.sizeof(_lib.Options) == 40   # size_t, int, int, unsigned, pad, ptr, ptr on LP64
+    assert ctypes.sizeof(_lib.Options) == 64   # size_t, int, int, unsigned, pad, five pointers on LP64
 
 
 def test_product_refuses_cpu_tensors_no_fallback():

@@ -312,6 +312,47 @@ def test_search_modes_agree():
 
 
 @all_icp_searches
+def test_icp_init_transform_and_t_history_vs_oracle():
+    """iterative_closest_point(init_transform=...) (utils_icp_pytorch3d.py:118-138) and ICPSolution.t_history (:187):
+    the first search runs on X R0 + T0, every iteration's (R, T) comes back.  Against the oracle's trace; a wrong-shaped
+    init_transform raises the reference's ValueError, a non-unit scale is refused."""
+    S, D, Tt = synthetic.make_batch(10, 400, seed=321, ragged=True, n_min=120)
+    src, dst = C(S), C(D)
+    # initial transform = the true motion, perturbed by up to 2 degrees about the moved cloud's centre and 6 cm
+    M0 = np.empty((10, 4, 4), np.float64)
+    for i, deg in enumerate(np.linspace(-2.0, 2.0, 10)):
+        c, sn = np.cos(np.deg2rad(deg)), np.sin(np.deg2rad(deg))
+        P = np.eye(4)
+        P[:3, :3] = [[c, -sn, 0], [sn, c, 0], [0, 0, 1]]
+        ctr = (Tt[i].astype(np.float64) @ np.append(S[i, :20, :3].mean(0), 1.0))[:3]
+        P[:3, 3] = ctr - P[:3, :3] @ ctr + np.array([0.05, -0.04, 0.01])
+        M0[i] = P @ Tt[i].astype(np.float64)
+    R0 = C(np.ascontiguousarray(M0[:, :3, :3].transpose(0, 2, 1)).astype(np.float32))   # row convention: y = x R + T
+    T0 = C(M0[:, :3, 3].astype(np.float32))
+    init = utils_icp_pytorch3d.SimilarityTransform(R0, T0, torch.ones(10))
+    want = rp.iterative_closest_point(src, dst, init_transform=(R0, T0), trace=True, kabsch_dtype=torch.float64)
+    plain = rp.iterative_closest_point(src, dst, kabsch_dtype=torch.float64)
+    got = utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), init_transform=init)
+    assert got.converged.iterations == want.iterations
+    assert not torch.equal(want.R, plain.R)          # (the initial transform matters on this batch)
+    v = S[:, :, 3] > 0
+    np.testing.assert_allclose(got.Xt.cpu().numpy()[v], want.Xt.numpy()[v], atol=2e-5, rtol=0)
+    hist = got.t_history
+    assert len(hist) == want.iterations and len(want.history) == want.iterations
+    for k in (0, 1, len(hist) - 1):
+        np.testing.assert_allclose(hist[k].R.cpu().numpy(), want.history[k][0].numpy(), atol=2e-6, rtol=0)
+        np.testing.assert_allclose(hist[k].T.cpu().numpy(), want.history[k][1].numpy(), atol=2e-4, rtol=0)
+    assert torch.equal(hist[-1].R, got.RTs.R) and torch.equal(hist[-1].T, got.RTs.T)
+    with pytest.raises(ValueError, match="init_transform"):
+        utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), init_transform=(R0[:3], T0, torch.ones(10)))
+    with pytest.raises(NotImplementedError):
+        utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV),
+                                                    init_transform=(R0, T0, torch.full((10,), 1.1)))
+    # per-pair stop: no per-iteration records -> empty history, like round 1
+    assert len(utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), stop_mode="per_pair").t_history) == 0
+
+
+@all_icp_searches
 def test_icp_per_pair_stop_stays_within_tolerance():
     """Per-pair stopping is NOT the reference's rule: each pair leaves the loop at
     its own convergence instead of iterating until the whole batch satisfies the test.  On
