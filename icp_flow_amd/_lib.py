@@ -90,7 +90,7 @@ class Options(ctypes.Structure):
     """icpflow_options_t: the per-call options of the fused entry points."""
     _fields_ = [("struct_size", _sz), ("icp_search", _i), ("icp_arith", _i), ("flags", ctypes.c_uint),
                 ("profile", _p), ("d_vote_bins_u32", _p), ("d_icp_init_R", _p), ("d_icp_init_T", _p),
-                ("d_icp_history", _p)]
+                ("d_icp_history", _p), ("icp_allow_reflection", _i)]
 
 
 class Profile:
@@ -132,11 +132,12 @@ _DEFAULT_FLAGS = _env_default_flags()
 
 def _current():
     return getattr(_tls, "stack", None) or [dict(search=0, arith=0, flags=_DEFAULT_FLAGS, profile=None, vote_bins=None,
-                                                 icp_init=None, icp_history=None)]
+                                                 icp_init=None, icp_history=None, icp_allow_reflection=False)]
 
 
 @contextlib.contextmanager
-def options(search=None, arith=None, profile=None, vote_bins=None, icp_init=None, icp_history=None, **switches):
+def options(search=None, arith=None, profile=None, vote_bins=None, icp_init=None, icp_history=None,
+            icp_allow_reflection=None, **switches):
     """Per-call options for every wrapper invoked inside the `with` block on this thread.
     search: 'auto' | 'scan' | 'grid' | 'sweep';  arith: 'fp64' | 'fp32_reference';  profile: a Profile;
     vote_bins: uint32 device tensor [B, Lx*Ly*Lz] receiving the fused vote's bins;  switches: no_teams=True ..."""
@@ -153,6 +154,8 @@ def options(search=None, arith=None, profile=None, vote_bins=None, icp_init=None
         cur["icp_init"] = icp_init
     if icp_history is not None:     # float32 [max_iterations, B, 16] device tensor: t_history of icpflow_icp
         cur["icp_history"] = icp_history
+    if icp_allow_reflection is not None:
+        cur["icp_allow_reflection"] = bool(icp_allow_reflection)
     for k, v in switches.items():
         cur["flags"] = (cur["flags"] | OPT_FLAGS[k]) if v else (cur["flags"] & ~OPT_FLAGS[k])
     stack = getattr(_tls, "stack", None)
@@ -169,13 +172,15 @@ def opt():
     """ctypes pointer to the icpflow_options_t in force on this thread (NULL = library defaults)."""
     cur = _current()[-1]
     if (cur["search"] == 0 and cur["arith"] == 0 and cur["flags"] == 0 and cur["profile"] is None
-            and cur["vote_bins"] is None and cur["icp_init"] is None and cur["icp_history"] is None):
+            and cur["vote_bins"] is None and cur["icp_init"] is None and cur["icp_history"] is None
+            and not cur["icp_allow_reflection"]):
         return None
     dp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
     o = Options(ctypes.sizeof(Options), int(cur["search"]), int(cur["arith"]), int(cur["flags"]),
                 cur["profile"]._h if cur["profile"] is not None else None, dp(cur["vote_bins"]),
                 dp(cur["icp_init"][0] if cur["icp_init"] is not None else None),
-                dp(cur["icp_init"][1] if cur["icp_init"] is not None else None), dp(cur["icp_history"]))
+                dp(cur["icp_init"][1] if cur["icp_init"] is not None else None), dp(cur["icp_history"]),
+                1 if cur["icp_allow_reflection"] else 0)
     _tls.last = o          # keep the struct alive until this thread builds the next one
     return ctypes.cast(ctypes.pointer(o), _p)
 

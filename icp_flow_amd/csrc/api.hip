@@ -44,6 +44,7 @@ struct Opts {
     uint32_t *voteBins = nullptr;
     const float *initR = nullptr, *initT = nullptr;
     float *history = nullptr;
+    bool allowReflection = false;
     bool on(unsigned offFlag) const { return (flags & offFlag) == 0u; }
     IcpOpts icp(float *scratch) const
     {
@@ -179,6 +180,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
     o.initR = opt->d_icp_init_R;
     o.initT = opt->d_icp_init_T;
     o.history = opt->d_icp_history;
+    o.allowReflection = opt->icp_allow_reflection != 0;
     return 0;
 }
 
@@ -609,6 +611,9 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     IcpOpts io = o.icp(w.grid.sortX);
     io.initR = o.initR;
     io.initT = o.initT;
+    io.allowReflection = o.allowReflection;
+    if (o.allowReflection && o.arith != ICPFLOW_ARITH_FP64)
+        return fail(ICPFLOW_E_ARG, "icpflow_icp: allow_reflection is not built for ICPFLOW_ARITH_FP32_REFERENCE");
     if (o.history != nullptr &&
         !(stop_mode == ICPFLOW_STOP_REFERENCE && max_iterations > 1 && max_iterations <= kHistIters &&
           o.arith == ICPFLOW_ARITH_FP64 && io.speculative))

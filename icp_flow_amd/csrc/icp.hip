@@ -70,6 +70,7 @@ struct IcpParams {
     IcpTeam team;            // wgPair == NULL: one workgroup per pair (blockIdx.x = pair)
     const float *initR;      // [B,3,3] / [B,3]: the state before the first iteration (init_transform), NULL = identity
     const float *initT;
+    int allowReflection;     // R = U V^T whatever its determinant (:354-362 with E = I)
     int recOn;               // sorted sweep in LDS, one workgroup per pair: per-query records behind the LDS image
                              // (adaptive windows, see the search phase)
 };
@@ -889,7 +890,22 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             }
             ICPFLOW_STAMP(5);
             double Rd[9];
+            // allow_reflection (:354-362 with E = I): R = U V^T is the best ORTHOGONAL matrix; for det H < 0 that is the
+            // reflection -R', R' the best proper rotation of -H (sum_ij (-R')_ij H_ij = sum_ij R'_ij (-H)_ij)
+            bool mirror = false;
+            if (p.allowReflection) {
+                const double *h = ksh + 8;
+                mirror = det3(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]) < 0.0;
+                if (mirror) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) ksh[8 + k] = -ksh[8 + k];   // (every lane writes the same values)
+                }
+            }
             if (!horn_rotation(ksh + 8, ksh[6] + ksh[7], Nsh, lane, Rd)) rank1_rotation(ksh + 8, Rd);
+            if (mirror) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { Rd[k] = -Rd[k]; ksh[8 + k] = -ksh[8 + k]; }
+            }
             ICPFLOW_STAMP(6);
             // T = mu_y - mu_x R with mu = o + m', :376
             const double o0 = (double)bcast[16], o1 = (double)bcast[17], o2 = (double)bcast[18];
@@ -1322,7 +1338,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     p.thr2 = (float)(thres * thres);
     p.relThr = (float)relThr;
     p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
-    p.initR = opts.initR; p.initT = opts.initT;
+    p.initR = opts.initR; p.initT = opts.initT; p.allowReflection = opts.allowReflection ? 1 : 0;
     hipError_t e = hipSuccess;
     if (opts.historyPending != nullptr) *opts.historyPending = false;
     if (!opts.ctrlCleared) {

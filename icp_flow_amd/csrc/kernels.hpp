@@ -149,6 +149,7 @@ struct IcpOpts {
     bool adaptiveWindows = true;   // sorted sweep: per-query windows from the previous iteration's neighbours
     const float *initR = nullptr;  // [B,3,3] / [B,3]: state before the first iteration (init_transform), or identity
     const float *initT = nullptr;
+    bool allowReflection = false;  // R = U V^T whatever its determinant (utils_icp_pytorch3d.py:354-362)
     LaunchProfile *profile = nullptr;
     bool ctrlCleared = false;      // the caller's count_pair launch already zeroed *ctrl
     bool *historyPending = nullptr;   // non-NULL: do not launch the history epilogue; *historyPending = "the final

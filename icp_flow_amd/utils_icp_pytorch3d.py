@@ -39,12 +39,12 @@ def iterative_closest_point(X, Y, init_transform=None, thres=0.1, max_iterations
     `init_transform` (SimilarityTransform with unit scale, :118-138): the first correspondence search runs on
     X R0 + T0.  `t_history` (:187) is materialised lazily from the per-iteration records on the device (reference
     stop rule, max_iterations <= 128, at most 64 MiB of records; empty otherwise) and `converged` is a lazy device
-    flag.  estimate_scale / allow_reflection are fixed to the values ICP-Flow passes (utils_icp.py:51-58) and raise
-    otherwise (the rotation is the closed form of the proper-rotation problem, without singular values).
+    flag.  `allow_reflection=True` (:354-362) returns the best orthogonal matrix instead of the best rotation.
+    `estimate_scale=True` raises (ICP-Flow passes False, utils_icp.py:51-58; the closed-form rotation carries no
+    singular values).
     """
-    if estimate_scale or allow_reflection:
-        raise NotImplementedError("only estimate_scale=False, allow_reflection=False (what ICP-Flow uses, "
-                                  "utils_icp.py:51-58) is built")
+    if estimate_scale:
+        raise NotImplementedError("estimate_scale=True is not built (ICP-Flow passes False, utils_icp.py:51-58)")
     x = _lib.cloud(X, "X")
     y = _lib.cloud(Y, "Y")
     if x.shape != y.shape:
@@ -74,7 +74,7 @@ def iterative_closest_point(X, Y, init_transform=None, thres=0.1, max_iterations
             and _lib._current()[-1]["arith"] == 0:
         hist = torch.empty((int(max_iterations), B, 16), dtype=torch.float32, device=dev)
     ws = _lib.workspace(dev, _lib.workspace_bytes(B, N))
-    with _lib.options(icp_init=init, icp_history=hist):
+    with _lib.options(icp_init=init, icp_history=hist, icp_allow_reflection=bool(allow_reflection)):
         _lib.call("icpflow_icp", _lib.ptr(x), _lib.ptr(y), None, B, N, float(thres), int(max_iterations),
                   float(relative_rmse_thr), stop_mode_of(stop_mode), _lib.ptr(R), _lib.ptr(T), _lib.ptr(rmse),
                   _lib.ptr(flags[0:1]), _lib.ptr(flags[1:2]), _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())

@@ -88,6 +88,8 @@ const char *icpflow_build_info(void);
  * d_icp_init_R [B,3,3], d_icp_init_T [B,3] -- icpflow_icp only, both or neither: `init_transform` of
  *   iterative_closest_point (utils_icp_pytorch3d.py:118-138, scale 1): the first correspondence search runs
  *   on X R0 + T0 instead of X (every iteration still solves for the absolute transform of X).
+ * icp_allow_reflection -- icpflow_icp only: `allow_reflection` of corresponding_points_alignment (:354-362): R = U V^T
+ *   whatever its determinant (the best ORTHOGONAL matrix; a reflection when det H < 0) instead of the best rotation.
  * d_icp_history [max_iterations, B, 16] -- icpflow_icp only: `t_history` of the reference's ICPSolution
  *   (:187), i.e. (R row-major 9, T 3, rmse, 3 unused) after every iteration; rows of iterations the batch rule
  *   did not reach are unspecified.  Available in the single-launch reference stop mode (max_iterations <= 128,
@@ -122,6 +124,7 @@ typedef struct icpflow_options {
     const float *d_icp_init_R;
     const float *d_icp_init_T;
     float *d_icp_history;
+    int icp_allow_reflection;
 } icpflow_options_t;
 
 /* Bytes of device scratch the fused entry points below need for a batch of B

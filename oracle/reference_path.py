@@ -194,7 +194,7 @@ def estimate_init_pose(args, src, dst):
 # --------------------------------------------------------------------------
 # ICP, utils_icp_pytorch3d.py
 # --------------------------------------------------------------------------
-def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_order=None):
+def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_order=None, allow_reflection=False):
     """utils_icp_pytorch3d.py:303-382 (estimate_scale=False, allow_reflection=False).
     X, Y [B,N,3] already mask-multiplied, weights bool [B,N].  y = x R + T.
 
@@ -218,7 +218,8 @@ def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_orde
         H = torch.bmm(Xc.transpose(2, 1), Yc) / total[:, None, None]          # :335-336
     U, S, V = torch.svd(H)                                                    # :339
     E = torch.eye(3, dtype=H.dtype)[None].repeat(b, 1, 1)
-    E[:, -1, -1] = torch.det(torch.bmm(U, V.transpose(2, 1)))                 # :358-359
+    if not allow_reflection:                                                  # :354
+        E[:, -1, -1] = torch.det(torch.bmm(U, V.transpose(2, 1)))             # :358-359
     R = torch.bmm(torch.bmm(U, E), V.transpose(2, 1))                         # :362
     T = mu_y[:, 0, :] - torch.bmm(mu_x, R)[:, 0, :]                           # :376
     return R.to(out_dtype), T.to(out_dtype)
@@ -226,7 +227,7 @@ def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_orde
 
 def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
                             relative_rmse_thr=ICP_REL_RMSE, trace=False, kabsch_dtype=None, sum_order=None,
-                            init_transform=None):
+                            init_transform=None, allow_reflection=False):
     """utils_icp_pytorch3d.py:100-225.  Returns a namespace with
     converged, rmse, Xt, R, T, iterations (number of loop bodies executed) and,
     with trace=True, the per-iteration (R, T, rmse, inlier count) history.
@@ -254,7 +255,8 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
         d2, _, nn = knn_points(Xt, Yt, n_x, n_y, return_nn=True)              # :154-157
         w = torch.logical_and(m0, d2 <= thr2)                                 # :160-161
         R, T = corresponding_points_alignment(X0 * w[:, :, None], nn * w[:, :, None], w,
-                                              dtype=kabsch_dtype, sum_order=sum_order)
+                                              dtype=kabsch_dtype, sum_order=sum_order,
+                                              allow_reflection=allow_reflection)
         Xt = torch.bmm(X0, R) + T[:, None, :]                                 # :177,395
         sq = ((Xt - nn) ** 2).sum(2)                                          # :191
         if kabsch_dtype is not None:

@@ -353,6 +353,37 @@ def test_icp_init_transform_and_t_history_vs_oracle():
 
 
 @all_icp_searches
+def test_icp_allow_reflection_vs_oracle():
+    """allow_reflection=True (utils_icp_pytorch3d.py:354-362): R = U V^T whatever its determinant.  Targets that are the
+    MIRROR image of the source (plus a small rigid motion): the best orthogonal fit is a reflection (det R = -1) with a
+    small rmse; without the flag the best rotation is found instead."""
+    rng = np.random.default_rng(12)
+    B, N = 6, 300
+    S = np.zeros((B, N, 4), np.float32)
+    D = np.zeros((B, N, 4), np.float32)
+    for i in range(B):
+        p = rng.normal(size=(N, 3)) * np.array([1.5, 0.8, 0.4]) + np.array([10.0 + i, -5.0, 1.0])
+        q = p.copy()
+        q[:, 1] = -10.0 - q[:, 1]                                  # mirrored in the plane y = -5
+        S[i, :, :3], D[i, :, :3] = p, q + np.array([0.03, -0.02, 0.01]) + rng.normal(0, 0.003, size=(N, 3))
+        S[i, :, 3] = D[i, :, 3] = 1.0
+    # start from the mirror itself (init_transform): the gate sees neighbours from the first iteration on
+    R0 = C(np.tile(np.diag([1.0, -1.0, 1.0]).astype(np.float32), (B, 1, 1)))
+    T0 = C(np.tile(np.array([0.0, -10.0, 0.0], np.float32), (B, 1)))
+    want = rp.iterative_closest_point(C(S), C(D), init_transform=(R0, T0), allow_reflection=True, kabsch_dtype=torch.float64)
+    got = utils_icp_pytorch3d.iterative_closest_point(G(S), G(D), init_transform=(R0, T0, torch.ones(B)), allow_reflection=True)
+    R = got.RTs.R.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(np.linalg.det(R), -1.0, atol=1e-5)
+    assert got.converged.iterations == want.iterations
+    np.testing.assert_allclose(R, want.R.numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(got.Xt.cpu().numpy(), want.Xt.numpy(), atol=2e-5, rtol=0)
+    assert float(got.rmse.max()) < 0.01
+    # without the flag: a proper rotation, and a much worse fit
+    plain = utils_icp_pytorch3d.iterative_closest_point(G(S), G(D), init_transform=(R0, T0, torch.ones(B)))
+    np.testing.assert_allclose(np.linalg.det(plain.RTs.R.cpu().numpy().astype(np.float64)), 1.0, atol=1e-5)
+
+
+@all_icp_searches
 def test_icp_per_pair_stop_stays_within_tolerance():
     """Per-pair stopping is NOT the reference's rule: each pair leaves the loop at
     its own convergence instead of iterating until the whole batch satisfies the test.  On
