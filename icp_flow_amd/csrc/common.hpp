@@ -169,6 +169,23 @@ __device__ __forceinline__ float wave_max_uniform(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// minimum over each group of 8 consecutive lanes, in every lane of the group (quad swaps + half-row mirror)
+__device__ __forceinline__ float row8_min(float v)
+{
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));   // quad_perm:[1,0,3,2]
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));   // quad_perm:[2,3,0,1]
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+    return v;
+}
+
+__device__ __forceinline__ int row8_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+    return v;
+}
+
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
 // outstanding global stores / atomics (vmcnt), which would put an L2 round trip on the path.
 __device__ __forceinline__ void barrier_lds_only()

@@ -25,10 +25,18 @@ namespace icpflow {
 // debug builds only (tools/dbg/phase_timing.py): shader-clock stamps of workgroup 0
 __device__ long long g_phase_stamps[16];
 __device__ long long g_wave_stamps[16 * 16];   // [wave][k] of workgroup 0
-#define ICPFLOW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamps[k] = clock64(); \
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_wave_stamps[(threadIdx.x >> 6) * 16 + (k)] = clock64(); } while (0)
+__device__ int g_stamp_block;                  // the workgroup that stamps (icpflow_debug_set_stamp_block)
+#define ICPFLOW_STAMP(k) do { if ((int)blockIdx.x == g_stamp_block && threadIdx.x == 0) g_phase_stamps[k] = clock64(); \
+    if ((int)blockIdx.x == g_stamp_block && (threadIdx.x & 63) == 0) g_wave_stamps[(threadIdx.x >> 6) * 16 + (k)] = clock64(); } while (0)
 #else
 #define ICPFLOW_STAMP(k) do { } while (0)
+#endif
+
+#ifdef ICPFLOW_CERT_STATS
+// debug builds only (tools/dbg/cert_stats.py): per iteration, over the whole batch: waves that ran, waves that searched,
+// queries that searched, targets scanned (per wave)
+__device__ unsigned long long g_cert_stats[128 * 4];
+__device__ unsigned long long g_probe_stats[128 * 2];   // probes, conclusive probes
 #endif
 
 }  // namespace icpflow
@@ -282,6 +290,8 @@ constexpr int kMoments = 18;
 // fits (BASELINE config 2) is bound by the latency of its slowest pair, where the bookkeeping of the records costs as
 // much as the shorter windows save (+1.3 %).  Results are identical either way.
 constexpr int kRecMaxN = 4096;
+constexpr int kProbeMax = 24;   // uncertified queries a wave settles by probes; more take the window scan
+constexpr int kProbeSteps = 4;  // blocks of 64 targets a probe may evaluate
 constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
 // ---------------------------------------------------------------------------------
@@ -500,18 +510,23 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             // GRID == 4: the sorted fixed cloud is staged into LDS once per launch and every
             // per-iteration access (window search, scan, resolve) stays on chip
             float *lx = reinterpret_cast<float *>(dynLds), *ly = lx + NP16, *lz = ly + NP16;
-            // Adaptive windows.  The gate only asks for neighbours within thres, but after the first iterations almost
-            // every query already HAS one much closer: the target found in the previous iteration, at distance d, is
-            // still there, and the query has moved by |dq| since -- so its nearest neighbour is now at most d + |dq|
-            // away, and nothing farther than that along the sort axis can be it (or tie with it): half-window
-            // d + |dq| instead of 1.01 thres.  A query WITHOUT a neighbour inside the gate is the opposite case: once a
-            // window of half-width Mc = 1.25 thres has shown that its nearest target is at least lb > thres away, it
-            // stays outside the gate until it has moved by lb - thres, and until then it needs no window at all.
-            // Each query keeps (where it was; +d or -lb) in LDS behind the image.  The minimum over the window, the
-            // gate decision and the neighbour of every gated query are those of the full window: results are
-            // bit-identical, the windows shorter.
+            // Neighbour certificates.  The search answers one question per query: which target is nearest, and is it
+            // inside the gate.  After the first iterations the answer hardly ever changes, and that can be PROVEN
+            // without searching: a search at position q0 that found the neighbour j1 also knows a lower bound L on the
+            // distance of every OTHER target (the runner-up of the scan; targets outside the scanned window differ by
+            // more than the window's half-width along the sort axis).  After the query has moved to q, every other
+            // target is still at least L - |q - q0| away (triangle inequality on the fp32 points themselves), so
+            //   (A)  |q - t_j1| < L - |q - q0|             => j1 is still the unique nearest neighbour: its distance is
+            //        evaluated with the instruction sequence of the scan (same bits), gate decision as usual;
+            //   (B)  |q - t_j1| > thres and L - |q - q0| > 1.01 thres   => nothing is inside the gate.
+            // A query that holds neither certificate searches: its window is its own +-m, and a wave scans the union of
+            // the windows of its uncertified lanes only -- nothing at all once every lane is certified.  Each query keeps
+            // (q0, L; j1) in LDS behind the image.  Minimum, gate decision and neighbour are those of the full search in
+            // every case: results are bit-identical (test_adaptive_windows_change_nothing), the iterations after the
+            // first few cost a distance evaluation per query instead of a window scan.
             constexpr bool REC = (GRID == 4) && !TEAM;
             float4 *rec = reinterpret_cast<float4 *>(dynLds + (size_t)NP16 * 12);
+            int *recJ = reinterpret_cast<int *>(dynLds + (size_t)NP16 * 12 + (size_t)p.N * 16);
             const bool recOn = REC && p.recOn != 0;
             if (GRID == 4 && it == itBegin) {
                 for (int k = tid; k < np16; k += BLOCK) { lx[k] = gx[k]; ly[k] = gy[k]; lz[k] = gz[k]; }
@@ -529,10 +544,13 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
                 bool live[Q];
                 float lo = kInf, hi = -kInf;
-                float recM[Q], recW[Q];   // adaptive windows: this query's half-window (< 0: none) and carried bound
+                float recM[Q];   // this query's half-window; < 0: certified, takes no part in the search
+                int certJ[Q];    // certificate (A): the neighbour (slot of the sorted image)
+                float certD[Q];  // certified squared distance (inf: outside the gate)
+                float newL[Q];   // >= 0: this query's record is rewritten (bound on every target but the neighbour)
 #pragma unroll
-                for (int q = 0; q < Q; ++q) { recM[q] = 0.f; recW[q] = 0.f; }
-                const float certMargin = 1.25f * p.sweepMargin;       // Mc
+                for (int q = 0; q < Q; ++q) { recM[q] = p.sweepMargin; certJ[q] = -1; certD[q] = kInf; newL[q] = -1.f; }
+                const float certMargin = 1.25f * p.sweepMargin;       // window of queries that may be outside the gate
                 const float gateOut = p.sweepMargin;                  // > thres with 1 % to spare (1.01 thres)
                 ICPFLOW_STAMP(1);
 #pragma unroll
@@ -552,38 +570,144 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                         qx[q] = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0])) + Tf[0];  // :177, :395
                         qy[q] = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1])) + Tf[1];
                         qz[q] = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2])) + Tf[2];
-                        const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
                         float m = p.sweepMargin;
                         if (recOn) {
-                            m = certMargin;   // first iteration, lost bounds: the certifying window
+                            m = certMargin;   // first iteration: nothing known
                             if (it > itBegin) {
                                 const float4 o = rec[i];
+                                const int j1 = recJ[i];
                                 const float ex = qx[q] - o.x, ey = qy[q] - o.y, ez = qz[q] - o.z;
-                                const float dq = fabsf(ex) + fabsf(ey) + fabsf(ez);   // >= the distance moved (no sqrt)
-                                if (o.w < 0.f) {   // certified outside the gate: nearest target at least -o.w away
-                                    const float lb = -o.w - dq * 1.001f - 1e-6f;
-                                    if (lb > gateOut) { m = -1.f; recW[q] = -lb; }   // still outside: no window, no search
-                                } else {
-                                    const float ub = (o.w + dq) * 1.001f + 1e-5f;
-                                    if (ub <= p.sweepMargin) m = ub;   // (inf / NaN bounds take the certifying window)
-                                }
+                                // (raw v_sqrt_f32, 1 ulp: every bound below carries a relative margin of 1e-6, 8 ulp)
+                                const float dq = __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+                                const float others = o.w * 0.999999f - dq * 1.000001f - 1e-6f;
+                                float e2 = kInf;
+                                if (j1 >= 0) e2 = sqdist(qx[q], qy[q], qz[q], lx[j1], ly[j1], lz[j1]);
+                                const float e1 = __builtin_amdgcn_sqrtf(e2);
+                                certJ[q] = j1;   // (also the hint of the probe below)
+#ifdef ICPFLOW_CERT_STATS
+                                if (it == 40 && !(e1 * 1.000001f + 1e-6f < others) && !(others > gateOut && !(e2 <= p.thr2)))
+                                    printf("b %d i %d j1 %d e1 %.6f L %.6f dq %.3e others %.6f\n", b, i, j1, e1, o.w, dq, others);
+#endif
+                                if (e1 * 1.000001f + 1e-6f < others) { m = -1.f; certD[q] = e2; }   // (A)
+                                else if (others > gateOut && !(e2 <= p.thr2)) m = -1.f;             // (B)
+                                else if (e2 <= p.thr2) m = p.sweepMargin;   // certainly gated: the gate's own window
                             }
-                            recM[q] = m;
                         }
-                        if (m >= 0.f) { lo = fminf(lo, qa - m); hi = fmaxf(hi, qa + m); }
+                        recM[q] = m;
                     }
                 }
+                // Probes.  The few queries of a wave that hold no certificate are settled eight at a time, each by a row
+                // of 8 lanes that evaluates the 64 sorted targets around the query's previous neighbour (8 per lane, one
+                // 16-byte LDS read per coordinate and four targets).  The targets NOT evaluated lie beyond the ends of the
+                // evaluated range along the sort axis, at least rho away: the probe is conclusive when rho exceeds the
+                // minimum found (then that is the nearest neighbour) or, for a minimum outside the gate, when rho exceeds
+                // 1.01 thres; otherwise the range grows by 64 targets on its short side, up to kProbeSteps times.
+                // Inconclusive probes, equal minima (the first-index rule is the scan's business), queries without a
+                // previous neighbour and waves with many uncertified lanes take the window scan.
+                if (REC && recOn && it > itBegin) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        unsigned long long need = __ballot(live[q] && recM[q] >= 0.f && certJ[q] >= 0);
+                        if (__popcll(need) > kProbeMax) continue;
+                        while (need != 0ull) {
+                            // this round's queries: the (up to) eight lowest uncertified lanes, row r takes the r-th
+                            unsigned srcLo = 0xffffffffu, srcHi = 0xffffffffu;   // 4 x 8-bit lane numbers each, 0xff = none
+                            unsigned long long roundMask = 0ull;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                if (need != 0ull) {
+                                    const unsigned l = (unsigned)(__ffsll((long long)need) - 1);
+                                    need &= need - 1ull;
+                                    roundMask |= 1ull << l;
+                                    if (r < 4) srcLo = (srcLo & ~(0xffu << (8 * r))) | (l << (8 * r));
+                                    else srcHi = (srcHi & ~(0xffu << (8 * (r - 4)))) | (l << (8 * (r - 4)));
+                                }
+                            }
+                            const int row = lane >> 3, li = lane & 7;
+                            const int src = (int)(((row < 4 ? srcLo : srcHi) >> (8 * (row & 3))) & 0xffu);
+                            const bool rowOn = src != 0xff;
+                            const int srcl = rowOn ? src : lane;
+                            const float sx = __shfl(qx[q], srcl, kWave), sy = __shfl(qy[q], srcl, kWave),
+                                        sz = __shfl(qz[q], srcl, kWave);
+                            const int j1 = __shfl(certJ[q], srcl, kWave);
+                            const float qa = axis == 0 ? sx : (axis == 1 ? sy : sz);
+                            int a = min(max((j1 & ~7) - 32, 0), max(np16 - 64, 0));   // evaluated so far: [a, bEnd)
+                            int bEnd = a + 64;
+                            int bs = a, be = bEnd;                                    // this step's block
+                            float lb = kInf, lsec = kInf;                             // this lane's minimum and runner-up
+                            int lslot = 0;
+                            bool done = !rowOn, ok = false, isNN = false;
+                            float rowbest = kInf, rho = 0.f;
+                            for (int step = 0; step < kProbeSteps; ++step) {
+                                const int t0 = bs + 8 * li;
+                                if (!done && t0 < be && t0 < np16) {
+                                    const float4 xa = *reinterpret_cast<const float4 *>(lx + t0), xb = *reinterpret_cast<const float4 *>(lx + t0 + 4);
+                                    const float4 ya = *reinterpret_cast<const float4 *>(ly + t0), yb = *reinterpret_cast<const float4 *>(ly + t0 + 4);
+                                    const float4 za = *reinterpret_cast<const float4 *>(lz + t0), zb = *reinterpret_cast<const float4 *>(lz + t0 + 4);
+                                    const float txs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                                    const float tys[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+                                    const float tzs[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) {
+                                        const float d = sqdist(sx, sy, sz, txs[e], tys[e], tzs[e]);
+                                        const bool lt = d < lb;
+                                        lsec = lt ? lb : fminf(lsec, d);
+                                        lslot = lt ? t0 + e : lslot;
+                                        lb = lt ? d : lb;
+                                    }
+                                }
+                                rowbest = row8_min(lb);
+                                const float kLo = a > 0 ? keyf[a] : -kInf;
+                                const float kHi = bEnd < np16 ? keyf[bEnd - 1] : kInf;   // (+inf padding past the last target)
+                                const float rL = qa - kLo, rR = kHi - qa;
+                                rho = fminf(rL, rR) * 0.9999f - 1e-6f;
+                                const bool nn = rho > 0.f && rho * rho > rowbest * 1.000003f;
+                                const bool out = !(rowbest <= p.thr2) && rho > gateOut;
+                                if (!done) {
+                                    if (nn || out) { done = true; ok = true; isNN = nn; }
+                                    else if (step + 1 == kProbeSteps) done = true;
+                                    else if (rL < rR) { be = a; bs = max(a - 64, 0); a = bs; }   // (a > 0: rL is finite)
+                                    else { bs = bEnd; be = bEnd + 64; bEnd = be; }               // (bEnd < np16: rR is finite)
+                                }
+                                if (__ballot(!done) == 0ull) break;
+                            }
+                            // the row's winner: exactly one lane may hold the minimum, and only once
+                            const bool isW = rowOn && lb == rowbest;
+                            const unsigned long long wm = __ballot(isW);
+                            const int cnt = __popc((unsigned)(wm >> (lane & ~7)) & 0xffu);
+                            const float secv = row8_min(isW ? lsec : lb);
+                            const int slot = row8_min(isW ? lslot : 0x7fffffff);
+                            ok = ok && cnt == 1 && secv > rowbest;
+#ifdef ICPFLOW_CERT_STATS
+                            if (li == 0 && rowOn && it < 128) { atomicAdd(&g_probe_stats[it * 2], 1ull); atomicAdd(&g_probe_stats[it * 2 + 1], ok ? 1ull : 0ull); }
+#endif
+                            // hand the result to the lane that owns the query
+                            const bool mine = ((roundMask >> lane) & 1ull) != 0ull;
+                            const int from = __popcll(roundMask & ((1ull << lane) - 1ull)) * 8;
+                            const float rD = __shfl(isNN ? rowbest : kInf, from, kWave);
+                            const float rNewL = __shfl(fminf(__builtin_amdgcn_sqrtf(secv), rho), from, kWave);
+                            const int rSlot = __shfl(ok ? slot : -1, from, kWave);
+                            if (mine && rSlot >= 0) { recM[q] = -1.f; certD[q] = rD; certJ[q] = rSlot; newL[q] = rNewL; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
+                    if (live[q] && recM[q] >= 0.f) { lo = fminf(lo, qa - recM[q]); hi = fmaxf(hi, qa + recM[q]); }
+                }
                 ICPFLOW_STAMP(11);
-                // the part of the sort axis in which this wave's live queries can find their neighbours
+                // the part of the sort axis in which this wave's searching queries can find their neighbours
                 lo = wave_min_uniform(lo);
                 hi = wave_max_uniform(hi);
                 ScanAcc<Q> acc;
                 bool tie[Q];
+                float second[Q];
 #pragma unroll
-                for (int q = 0; q < Q; ++q) tie[q] = false;
+                for (int q = 0; q < Q; ++q) { tie[q] = false; second[q] = kInf; }
                 scan_init(acc);
                 int cb = 0, ce = 0;
-                if (lo <= hi) {  // wave has live queries (wave-uniform)
+                if (lo <= hi) {  // wave has searching queries (wave-uniform)
                     // single pass: this wave's window of the previous iteration is the hint
                     int jlo = winLo, jhi = winHi;
                     if (ngr == 1 && winHi >= 0)
@@ -595,35 +719,35 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
                     ICPFLOW_STAMP(12);
 #ifdef ICPFLOW_PHASE_TIMING
-                    if (blockIdx.x == 0 && lane == 0) g_wave_stamps[wave * 16 + 15] = ce - cb;
+                    if ((int)blockIdx.x == g_stamp_block && lane == 0) g_wave_stamps[wave * 16 + 15] = ce - cb;
 #endif
-                    if (GRID == 4)
-                        scan_range_tie<Q>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
-                                          reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie);
-                    else
+                    if (GRID == 4) {
+                        if (REC && recOn)
+                            scan_range_tie<Q, true>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
+                                                    reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie, second);
+                        else
+                            scan_range_tie<Q>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
+                                              reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie);
+                    } else
                         scan_range_tie_uniform<Q>(gx, gy, gz, cb, ce, qx, qy, qz, acc, tie);
                 }
-                ICPFLOW_STAMP(2);
-                if (recOn) {
+#ifdef ICPFLOW_PHASE_TIMING
+                else if ((int)blockIdx.x == g_stamp_block && lane == 0) g_wave_stamps[wave * 16 + 15] = 0;
+#endif
+#ifdef ICPFLOW_CERT_STATS
+                if (it < 128) {
+                    int nsearch = 0;
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        const int i = qBegin + g * PER + (wave * Q + q) * kWave + lane;
-                        if (!live[q]) continue;
-                        float w = recW[q];                       // no window: the carried lower bound
-                        if (recM[q] >= 0.f) {
-                            // nearest target of a window that covers qa +- recM (raw v_sqrt_f32, 1 ulp: the bounds
-                            // built from it carry margins of 1e-6 and more)
-                            const float d = __builtin_amdgcn_sqrtf(acc.best[q]);
-                            w = d;
-                            // nothing inside the gate and the window was the certifying one: every target is at least
-                            // min(d, Mc) away (targets outside the window differ by more than Mc along the sort axis)
-                            if (recM[q] == certMargin && d > gateOut) w = -fminf(d, certMargin) * 0.999999f;
-                        } else {
-                            acc.best[q] = kInf;                  // (not searched: certainly not gated)
-                        }
-                        rec[i] = make_float4(qx[q], qy[q], qz[q], w);
+                    for (int q = 0; q < Q; ++q) nsearch += __popcll(__ballot(live[q] && recM[q] >= 0.f));
+                    if (lane == 0) {
+                        atomicAdd(&g_cert_stats[it * 4 + 0], 1ull);
+                        atomicAdd(&g_cert_stats[it * 4 + 1], lo <= hi ? 1ull : 0ull);
+                        atomicAdd(&g_cert_stats[it * 4 + 2], (unsigned long long)nsearch);
+                        atomicAdd(&g_cert_stats[it * 4 + 3], (unsigned long long)(ce - cb));
                     }
                 }
+#endif
+                ICPFLOW_STAMP(2);
                 // neighbour = the target at distance `best` (bit-equal re-evaluation of the winning
                 // chunk).  If several targets tie -- in that chunk or, flagged by the scan, in another
                 // one -- the lowest ORIGINAL index wins: only then are the original indices fetched
@@ -631,9 +755,18 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                 double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0, wq = 0.0;
-                if (live[q] && acc.best[q] <= p.thr2) {  // :160-161
+                const bool searched = live[q] && recM[q] >= 0.f;
+                if (!searched) { acc.best[q] = certD[q]; tie[q] = false; }
+                // with certificates every searched query with a target in its window is resolved (the record wants the
+                // neighbour and the runner-up), otherwise only the gated ones
+                if (live[q] && (acc.best[q] <= p.thr2 || (recOn && searched && acc.best[q] < kInf))) {  // :160-161
                     float ynx = 0.f, yny = 0.f, ynz = 0.f;
+                    int slot = certJ[q];
+                    if (!searched) {   // certified or probed
+                        ynx = lx[slot]; yny = ly[slot]; ynz = lz[slot];
+                    } else {
                     int matches = tie[q] ? 2 : 0;
+                    float sec = second[q];
                     if (!tie[q]) {
                         const int c0 = acc.chunk[q];
 #pragma unroll
@@ -647,7 +780,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float d = sqdist(qx[q], qy[q], qz[q], txs[e], tys[e], tzs[e]);
-                                if (d == acc.best[q]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; }
+                                if (d == acc.best[q]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; slot = c0 + 4 * u + e; }
+                                else if (REC) sec = fminf(sec, d);
                             }
                         }
                     }
@@ -659,12 +793,32 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             const float4 t = ys[k];
                             const float d = sqdist(qx[q], qy[q], qz[q], t.x, t.y, t.z);
                             const int j = __float_as_int(t.w);
-                            if (d == acc.best[q] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; }
+                            if (d == acc.best[q] && j < bj) { bj = j; ynx = t.x; yny = t.y; ynz = t.z; slot = k; }
                         }
+                        sec = acc.best[q];   // a second target at the same distance
                     }
-                    wq = 1.0;
-                    ax = (double)(x0x[q] - ox); ay = (double)(x0y[q] - oy); az = (double)(x0z[q] - oz);
-                    bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
+                    second[q] = sec;
+                    certJ[q] = slot;
+                    }
+                    if (acc.best[q] <= p.thr2) {
+                        wq = 1.0;
+                        ax = (double)(x0x[q] - ox); ay = (double)(x0y[q] - oy); az = (double)(x0z[q] - oz);
+                        bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
+                    }
+                }
+                if (recOn && searched) {
+                    // every target other than the neighbour: at least the runner-up of the window away, and targets
+                    // outside the window differ by more than this query's half-window along the sort axis (the window
+                    // bounds qa -+ m are rounded: 4 ulp of head-room, and 0.1 % on the half-width)
+                    const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
+                    const float cap = recM[q] * 0.999f - fabsf(qa) * 2.4e-7f;
+                    newL[q] = fmaxf(fminf(__builtin_amdgcn_sqrtf(second[q]), cap), 0.f);
+                    if (!(acc.best[q] < kInf)) certJ[q] = -1;
+                }
+                if (recOn && newL[q] >= 0.f) {
+                    const int i = qBegin + g * PER + (wave * Q + q) * kWave + lane;
+                    rec[i] = make_float4(qx[q], qy[q], qz[q], newL[q]);
+                    recJ[i] = certJ[q];
                 }
                 ICPFLOW_STAMP(10);
                 // 18 moments -> 5 registers by two folding levels (see common.hpp): fold[j] holds, per
@@ -1191,7 +1345,7 @@ template <int BLOCK, int Q, int TS, int GRID, bool TEAM = false>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
-                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + ((!TEAM && p.recOn) ? (size_t)p.N * 16 : 0) : 0;
+                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + ((!TEAM && p.recOn) ? (size_t)p.N * 20 : 0) : 0;
     if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation and device
         static std::atomic<unsigned long long> raised{0ull};
         ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM>), 156 * 1024, &raised);
@@ -1209,7 +1363,24 @@ struct LaunchProfile {
     int used = 0;
 };
 
+#ifdef ICPFLOW_CERT_STATS
+extern "C" int icpflow_debug_cert_stats(unsigned long long *out512, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_cert_stats), sizeof(unsigned long long) * 512);
+    rc |= (int)hipMemcpyFromSymbol(out512 + 512, HIP_SYMBOL(g_probe_stats), sizeof(unsigned long long) * 256);
+    if (reset) {
+        static unsigned long long zeros[512];
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cert_stats), zeros, sizeof(zeros));
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_stats), zeros, sizeof(unsigned long long) * 256);
+    }
+    return rc;
+}
+#endif
 #ifdef ICPFLOW_PHASE_TIMING
+extern "C" int icpflow_debug_set_stamp_block(int b)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_block), &b, sizeof(int));
+}
 extern "C" int icpflow_debug_phase_stamps(long long *out16)
 {
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_stamps), sizeof(long long) * 16);
@@ -1352,7 +1523,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
         p.sortedRaw = 1;
-        p.recOn = opts.adaptiveWindows && N <= kRecMaxN && B > device_cus();
+        p.recOn = opts.adaptiveWindows && N <= kRecMaxN;
     } else if (grid != nullptr && grid->mode == 3) {
         int NP2 = 64;
         while (NP2 < N) NP2 <<= 1;
@@ -1369,7 +1540,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
-        p.recOn = opts.adaptiveWindows && N <= kRecMaxN && B > device_cus();
+        p.recOn = opts.adaptiveWindows && N <= kRecMaxN;
     } else if (grid != nullptr) {
         // bin the fixed cloud once: cell edge 1 % above the gate radius (rounding head-room)
         const float invh = (float)(1.0 / (1.01 * thres));

@@ -175,11 +175,15 @@ __device__ __forceinline__ int scan_resolve(const CloudView &tg, const PointXf &
 // whether the running minimum was attained (bit-equal) by more than one chunk: used by the
 // sorted sweep of the ICP loop, where scan order is not index order and the first-index rule
 // has to be restored explicitly in the (rare) tie case.
-template <int Q>
+// SECOND: also keep the smallest chunk minimum among the chunks OTHER than the winning one (equal to the minimum
+// itself when two chunks tie): with the runner-up inside the winning chunk, found when that chunk is re-evaluated,
+// it bounds the distance of every target but the nearest (the neighbour certificates of the ICP loop, icp.hip).
+template <int Q, bool SECOND = false>
 __device__ __forceinline__ void scan_range_tie(const float4 *__restrict__ sx, const float4 *__restrict__ sy,
                                                const float4 *__restrict__ sz, int cBegin, int cEnd,
                                                const float (&qx)[Q], const float (&qy)[Q],
-                                               const float (&qz)[Q], ScanAcc<Q> &acc, bool (&tie)[Q])
+                                               const float (&qz)[Q], ScanAcc<Q> &acc, bool (&tie)[Q],
+                                               float *second = nullptr)
 {
     for (int c = cBegin; c < cEnd; c += kChunk) {
         float m[Q];
@@ -203,6 +207,7 @@ __device__ __forceinline__ void scan_range_tie(const float4 *__restrict__ sx, co
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
+            if (SECOND) second[q] = fminf(second[q], fmaxf(m[q], acc.best[q]));   // the larger of (old best, this chunk)
             if (m[q] < acc.best[q]) { acc.best[q] = m[q]; acc.chunk[q] = c; tie[q] = false; }
             else if (m[q] == acc.best[q]) tie[q] = true;
         }

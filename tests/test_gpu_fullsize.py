@@ -145,13 +145,15 @@ def test_config2_full_batch_fp32_reference_arithmetic(config2):
     assert (err32 < TOL_M).sum() >= 256 - 10 and err32[c["determined"]].max() < 1e-3, msg
 
 
-@pytest.mark.parametrize("shape", ["config4_shard_1024x2048", "ragged_600x1024", "ragged_400x3000"])
+@pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_400x3000"])
 def test_adaptive_windows_change_nothing(shape):
     """Batches larger than the GPU: every query's search window comes from where its neighbour was in the previous
     iteration, and queries certified to be outside the gate are not searched at all (icp.hip, "Adaptive windows").
     Gate decisions and neighbours are those of the full window: transforms and iteration count are bit-identical
     to ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS."""
-    if shape == "config4_shard_1024x2048":
+    if shape == "config2_256x1024":
+        S, D, _ = synthetic.make_batch(256, 1024, seed=0)
+    elif shape == "config4_shard_1024x2048":
         S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
     elif shape == "ragged_600x1024":
         S, D, _ = synthetic.make_batch(600, 1024, seed=31, ragged=True, n_min=60)
