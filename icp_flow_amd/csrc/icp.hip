@@ -290,7 +290,7 @@ constexpr int kMoments = 18;
 // fits (BASELINE config 2) is bound by the latency of its slowest pair, where the bookkeeping of the records costs as
 // much as the shorter windows save (+1.3 %).  Results are identical either way.
 constexpr int kRecMaxN = 4096;
-constexpr int kProbeMax = 24;   // uncertified queries a wave settles by probes; more take the window scan
+constexpr int kProbeMax = 16;   // uncertified queries a wave settles by probes; more take the window scan
 constexpr int kProbeSteps = 4;  // blocks of 64 targets a probe may evaluate
 constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
@@ -465,6 +465,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 
     int specChk = 0;  // speculative mode: first iteration not yet known to be complete-and-unconverged
     int winLo = -1, winHi = -1;   // sorted sweep: this wave's target window of the previous iteration
+    int prevNN = -2;              // certificates, single pass: this lane's gated neighbour of the previous iteration
     unsigned long long ownConvLo = 0ull, ownConvHi = 0ull;   // iterations at which this pair was converged
     for (int it = itBegin; it < itEnd; ++it) {
         if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
@@ -540,6 +541,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             const int qBegin = min(rank * qShare, xc.n), qEnd = min(qBegin + qShare, xc.n);
             const int ngr = (qEnd - qBegin + PER - 1) / PER;
             double fold[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            bool reuseMoments = false;   // this wave's 18 sums are those of the previous iteration (still in `red`)
             for (int g = 0; g < ngr; ++g) {
                 float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
                 bool live[Q];
@@ -755,6 +757,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                 double ax = 0.0, ay = 0.0, az = 0.0, bx = 0.0, by = 0.0, bz = 0.0, wq = 0.0;
+                int nnSlot = -1;   // the gated neighbour (slot of the sorted image)
                 const bool searched = live[q] && recM[q] >= 0.f;
                 if (!searched) { acc.best[q] = certD[q]; tie[q] = false; }
                 // with certificates every searched query with a target in its window is resolved (the record wants the
@@ -802,6 +805,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     }
                     if (acc.best[q] <= p.thr2) {
                         wq = 1.0;
+                        nnSlot = slot;
                         ax = (double)(x0x[q] - ox); ay = (double)(x0y[q] - oy); az = (double)(x0z[q] - oz);
                         bx = (double)(ynx - ox); by = (double)(yny - oy); bz = (double)(ynz - oz);
                     }
@@ -821,9 +825,18 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     recJ[i] = certJ[q];
                 }
                 ICPFLOW_STAMP(10);
+                // The moments are sums over (x0, gated neighbour) only -- the pose enters through WHICH neighbour is
+                // gated.  A wave none of whose queries changed its gated neighbour since the previous iteration would
+                // add up the same numbers in the same order: its 18 sums are still in `red` (single-pass clouds).
+                if constexpr (REC && Q == 1) {
+                    if (recOn && ngr == 1) {
+                        reuseMoments = it > itBegin && __ballot(nnSlot != prevNN) == 0ull;
+                        prevNN = nnSlot;
+                    }
+                }
                 // 18 moments -> 5 registers by two folding levels (see common.hpp): fold[j] holds, per
                 // row of 16 lanes, partial sums of moments (4j, 4j+2, 4j+1, 4j+3); fold[4]: 16,16,17,17
-                {
+                if (!reuseMoments) {
                     const double a0 = swap32_sum(wq, ax), a1 = swap32_sum(ay, az);
                     fold[0] += swap16_sum(a0, a1);
                     const double a2 = swap32_sum(bx, by), a3 = swap32_sum(bz, ax * bx);
@@ -838,6 +851,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             }
             }
             // rows of 16 lanes -> lane 15 of each row holds the wave total of "its" moment
+            if (!reuseMoments)
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 const double r = row_sum_f64(fold[j]);
