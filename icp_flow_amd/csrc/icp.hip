@@ -32,11 +32,17 @@ __device__ int g_stamp_block;                  // the workgroup that stamps (icp
 #define ICPFLOW_STAMP(k) do { } while (0)
 #endif
 
+#ifdef ICPFLOW_TAIL_CLOCK
+// debug builds only (tools/dbg/tail_clock.py): per pair, shader clocks wave 0 spent between the block barrier and the
+// publication of (R, T) (the serial tail), in the rest of the loop, and the iterations it executed
+__device__ long long g_tail_clock[1024 * 3];
+#endif
 #ifdef ICPFLOW_CERT_STATS
 // debug builds only (tools/dbg/cert_stats.py): per iteration, over the whole batch: waves that ran, waves that searched,
 // queries that searched, targets scanned (per wave)
 __device__ unsigned long long g_cert_stats[128 * 4];
 __device__ unsigned long long g_probe_stats[128 * 2];   // probes, conclusive probes
+__device__ int g_stats_block = -1;                       // >= 0: only this workgroup counts
 #endif
 
 }  // namespace icpflow
@@ -285,12 +291,13 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
 // sum w |x R + T - y|^2 = (Sxx - W|mx'|^2) + (Syy - W|my'|^2) - 2 W sum_ij R_ij H_ij  (== :191,
 // evaluated without rounding X R + T to fp32 first), so one pass over the points suffices.
 constexpr int kMoments = 18;
-// adaptive windows: LDS image (12 B / point) + query records (16 B / point) <= 112 KiB.  Used when the batch is larger
-// than the GPU (B > #CUs: the launch is bound by the total search work, measured -8.5 % at 1024 x 2048); a batch that
-// fits (BASELINE config 2) is bound by the latency of its slowest pair, where the bookkeeping of the records costs as
-// much as the shorter windows save (+1.3 %).  Results are identical either way.
+// neighbour certificates: LDS image (12 B / point) + per query the record (q0, L: 16 B) and the neighbour's slot (4 B)
+// <= 128 KiB.  Results are identical with and without (ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS).
 constexpr int kRecMaxN = 4096;
-constexpr int kProbeMax = 16;   // uncertified queries a wave settles by probes; more take the window scan
+#ifndef ICPFLOW_PROBE_MAX
+#define ICPFLOW_PROBE_MAX 16
+#endif
+constexpr int kProbeMax = ICPFLOW_PROBE_MAX;   // uncertified queries a wave settles by probes; more take the window scan
 constexpr int kProbeSteps = 4;  // blocks of 64 targets a probe may evaluate
 constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
@@ -467,6 +474,9 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     int winLo = -1, winHi = -1;   // sorted sweep: this wave's target window of the previous iteration
     int prevNN = -2;              // certificates, single pass: this lane's gated neighbour of the previous iteration
     unsigned long long ownConvLo = 0ull, ownConvHi = 0ull;   // iterations at which this pair was converged
+#ifdef ICPFLOW_TAIL_CLOCK
+    long long tcTail = 0, tcSearch = 0, tcLoop0 = clock64();
+#endif
     for (int it = itBegin; it < itEnd; ++it) {
         if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
             // speculative mode: only member 0 watches the batch tally; it tells its team to stop
@@ -474,6 +484,20 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             if (TEAM && G > 1 && rank == 0 && p.stopMode == ICPFLOW_STOP_REFERENCE_ && wave == 0)
                 team_publish(p.team, b, it, 0, 0.0, 1.0, lane);
             break;
+        }
+        // Speculative mode, wave 0: the batch rule cannot hold at an iteration at which THIS pair was not converged, so
+        // those are skipped without looking at the tally (pairs that do converge leave through the periodic
+        // fast-forward; the shared tally line is read only in the in-between cases).  The tally of the first candidate
+        // is fetched HERE, a whole search phase before it is looked at: an agent-scope load crosses the fabric
+        // (the XCDs' L2s are not coherent), which is not something to wait for in the serial tail.
+        unsigned long long specTally = 0ull;
+        bool specLoaded = false;
+        if (wave == 0 && p.history != nullptr && rank == 0) {
+            while (specChk < it && !((specChk < 64 ? ownConvLo >> specChk : ownConvHi >> (specChk - 64)) & 1ull)) ++specChk;
+            if (specChk < it) {
+                specTally = __hip_atomic_load(&ctrl->tally[specChk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                specLoaded = true;
+            }
         }
         // this iteration's (R, T) and the origin of the moments, from LDS (dead after the search phase)
         float Rf[9], Tf[3];
@@ -587,7 +611,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                                 const float e1 = __builtin_amdgcn_sqrtf(e2);
                                 certJ[q] = j1;   // (also the hint of the probe below)
 #ifdef ICPFLOW_CERT_STATS
-                                if (it == 40 && !(e1 * 1.000001f + 1e-6f < others) && !(others > gateOut && !(e2 <= p.thr2)))
+                                if (false && it == 40 && !(e1 * 1.000001f + 1e-6f < others) && !(others > gateOut && !(e2 <= p.thr2)))
                                     printf("b %d i %d j1 %d e1 %.6f L %.6f dq %.3e others %.6f\n", b, i, j1, e1, o.w, dq, others);
 #endif
                                 if (e1 * 1.000001f + 1e-6f < others) { m = -1.f; certD[q] = e2; }   // (A)
@@ -681,7 +705,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             const int slot = row8_min(isW ? lslot : 0x7fffffff);
                             ok = ok && cnt == 1 && secv > rowbest;
 #ifdef ICPFLOW_CERT_STATS
-                            if (li == 0 && rowOn && it < 128) { atomicAdd(&g_probe_stats[it * 2], 1ull); atomicAdd(&g_probe_stats[it * 2 + 1], ok ? 1ull : 0ull); }
+                            if (li == 0 && rowOn && it < 128 && (g_stats_block < 0 || g_stats_block == (int)blockIdx.x)) { atomicAdd(&g_probe_stats[it * 2], 1ull); atomicAdd(&g_probe_stats[it * 2 + 1], ok ? 1ull : 0ull); }
 #endif
                             // hand the result to the lane that owns the query
                             const bool mine = ((roundMask >> lane) & 1ull) != 0ull;
@@ -700,8 +724,13 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 }
                 ICPFLOW_STAMP(11);
                 // the part of the sort axis in which this wave's searching queries can find their neighbours
-                lo = wave_min_uniform(lo);
-                hi = wave_max_uniform(hi);
+                bool anyScan = false;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) anyScan = anyScan || __ballot(live[q] && recM[q] >= 0.f) != 0ull;
+                if (anyScan) {
+                    lo = wave_min_uniform(lo);
+                    hi = wave_max_uniform(hi);
+                }
                 ScanAcc<Q> acc;
                 bool tie[Q];
                 float second[Q];
@@ -737,7 +766,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 else if ((int)blockIdx.x == g_stamp_block && lane == 0) g_wave_stamps[wave * 16 + 15] = 0;
 #endif
 #ifdef ICPFLOW_CERT_STATS
-                if (it < 128) {
+                if (it < 128 && (g_stats_block < 0 || g_stats_block == (int)blockIdx.x)) {
                     int nsearch = 0;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) nsearch += __popcll(__ballot(live[q] && recM[q] >= 0.f));
@@ -1006,20 +1035,27 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         ICPFLOW_STAMP(3);
         __syncthreads();  // every wave's row is complete
         ICPFLOW_STAMP(4);
+#ifdef ICPFLOW_TAIL_CLOCK
+        const long long tcTail0 = clock64();
+        tcSearch += tcTail0 - tcLoop0;
+#endif
         // ------------- wave 0 solves for (R, T, rmse) ---------------------------------------
         if (wave == 0) {
-            // the batch rule cannot hold at an iteration at which THIS pair was not converged: skip those
-            // without looking at the tally (pairs that do converge leave through the periodic
-            // fast-forward, so the shared tally line is read only in the rare in-between cases)
-            while (specChk < it && !((specChk < 64 ? ownConvLo >> specChk : ownConvHi >> (specChk - 64)) & 1ull)) ++specChk;
-            unsigned long long specTally = 0ull;
-            if (p.history != nullptr && specChk < it && rank == 0)
-                specTally = __hip_atomic_load(&ctrl->tally[specChk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // lane k < 18 sums moment k over the waves; totals are then wave-uniform via readlane
             double mine = 0.0;
             if (lane < kMoments) {
-                mine = red[lane];
-                for (int w = 1; w < NWAVE; ++w) mine += red[w * kMoments + lane];
+                // all NWAVE loads in flight at once (left to itself the compiler alternates load, wait, add: NWAVE / 2
+                // dependent LDS round trips in the serial tail); the sum itself stays in wave order
+                double r[NWAVE];
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) r[w] = red[w * kMoments + lane];
+#pragma unroll
+                for (int w = 0; w < NWAVE; w += 4) {
+                    if (w + 3 < NWAVE) asm volatile("" : "+v"(r[w]), "+v"(r[w + 1]), "+v"(r[w + 2]), "+v"(r[w + 3]));
+                }
+                mine = r[0];
+#pragma unroll
+                for (int w = 1; w < NWAVE; ++w) mine += r[w];
             }
             bool teamStop = false;
             if (TEAM && G > 1) {
@@ -1110,9 +1146,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     __hip_atomic_fetch_add(&ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // specTally was loaded before the solve (its latency hides behind the rotation solve):
-                // it describes iteration specChk <= it - 1
-                if (specChk < it && rank == 0) {
+                // specTally (fetched at the top of this iteration) describes iteration specChk <= it - 1
+                if (specLoaded) {
                     if ((int)(specTally & 0xffffffffull) >= p.B) {   // everybody has been there
                         if ((specTally >> 32) == 0ull) active = 0;   // the batch stops at specChk
                         else ++specChk;
@@ -1208,6 +1243,10 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         }
         itersDone = it + 1;
         ICPFLOW_STAMP(7);
+#ifdef ICPFLOW_TAIL_CLOCK
+        tcLoop0 = clock64();
+        tcTail += tcLoop0 - tcTail0;
+#endif
         if (it + 1 < itEnd) {  // more iterations inside this launch: publish (R, T) to the block
             barrier_lds_only();   // the history stores / tally atomic of wave 0 stay in flight
             if (wave != 0) active = bcast[12] != 0.f;   // (R, T) are read back at the top of the loop
@@ -1215,6 +1254,9 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     }
     ICPFLOW_STAMP(8);
     __syncthreads();
+#ifdef ICPFLOW_TAIL_CLOCK
+    if (tid == 0 && b < 1024) { g_tail_clock[b * 3] = tcTail; g_tail_clock[b * 3 + 1] = tcSearch; g_tail_clock[b * 3 + 2] = itersDone; }
+#endif
     if (tid == 0 && rank == 0) {  // wave 0 (of member 0) holds the final state
 #pragma unroll
         for (int k = 0; k < 9; ++k) st->R[k] = bcast[k];
@@ -1377,7 +1419,17 @@ struct LaunchProfile {
     int used = 0;
 };
 
+#ifdef ICPFLOW_TAIL_CLOCK
+extern "C" int icpflow_debug_tail_clock(long long *out3072)
+{
+    return (int)hipMemcpyFromSymbol(out3072, HIP_SYMBOL(g_tail_clock), sizeof(long long) * 3072);
+}
+#endif
 #ifdef ICPFLOW_CERT_STATS
+extern "C" int icpflow_debug_set_stats_block(int b)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stats_block), &b, sizeof(int));
+}
 extern "C" int icpflow_debug_cert_stats(unsigned long long *out512, int reset)
 {
     int rc = (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_cert_stats), sizeof(unsigned long long) * 512);

@@ -11,6 +11,7 @@ a = rp.default_args(max_points=N, icp_max_iterations=50)
 s, d = torch.from_numpy(S).cuda(), torch.from_numpy(D).cuda()
 st = (ctypes.c_ulonglong * 768)()
 torch.cuda.synchronize()
+_lib._L.icpflow_debug_set_stats_block(int(os.environ.get('PAIR', -1)))
 _lib._L.icpflow_debug_cert_stats(st, 1)
 T, it = utils_match.hist_icp(a, s, d, return_iterations=True)
 torch.cuda.synchronize()
