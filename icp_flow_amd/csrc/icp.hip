@@ -291,6 +291,14 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
 // sum w |x R + T - y|^2 = (Sxx - W|mx'|^2) + (Syy - W|my'|^2) - 2 W sum_ij R_ij H_ij  (== :191,
 // evaluated without rounding X R + T to fp32 first), so one pass over the points suffices.
 constexpr int kMoments = 18;
+
+// word k of a state (R row-major, T) as it enters the 32-bit hash of the state: rotated by a per-word amount, all
+// twelve xor-ed (full-rate v_alignbit_b32 / v_xor3_b32; a filter only -- a hit is confirmed word by word)
+__device__ __forceinline__ int state_hash_word(float w, int k)
+{
+    const unsigned u = (unsigned)__float_as_int(w);
+    return (int)__builtin_amdgcn_alignbit(u, u, (unsigned)((5 * k + 3) & 31));
+}
 // neighbour certificates: LDS image (12 B / point) + per query the record (q0, L: 16 B) and the neighbour's slot (4 B)
 // <= 128 KiB.  Results are identical with and without (ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS).
 constexpr int kRecMaxN = 4096;
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         if (tid < kWave) {   // and its hash (same formula as in the loop), every lane of wave 0 the same value
             int hash = 0;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) hash ^= __float_as_int(__shfl(s0, k, kWave)) * (k < 9 ? 2 * k + 3 : 2 * (k - 9) + 23);
+            for (int k = 0; k < 12; ++k) hash ^= state_hash_word(__shfl(s0, k, kWave), k);
             if (tid == 13) ring[13] = __int_as_float(hash);
         }
     } else {
@@ -1076,19 +1084,23 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             const double W = mom[0] > 1e-9 ? mom[0] : 1e-9;  // clamp(eps), :314-315, :326
             double h9[9];
             {
-                const double iW = 1.0 / W;
+                // (reciprocal refined to the last bit or two instead of an IEEE division; explicit fused multiply-adds
+                // below: the serial tail is a chain of dependent fp64 operations, each one left out counts)
+                double iW = __builtin_amdgcn_rcp(W);
+                iW = fma(fma(-W, iW, 1.0), iW, iW);
+                iW = fma(fma(-W, iW, 1.0), iW, iW);
                 const double mx0 = mom[1] * iW, mx1 = mom[2] * iW, mx2 = mom[3] * iW;
                 const double my0 = mom[4] * iW, my1 = mom[5] * iW, my2 = mom[6] * iW;
                 const double mxv[3] = {mx0, mx1, mx2}, myv[3] = {my0, my1, my2};
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) h9[i * 3 + j] = mom[7 + i * 3 + j] * iW - mxv[i] * myv[j];  // :318-336
+                    for (int j = 0; j < 3; ++j) h9[i * 3 + j] = fma(-mxv[i], myv[j], mom[7 + i * 3 + j] * iW);  // :318-336
                 // park what is needed after the solve in LDS: the Jacobi sweeps want the registers
                 // (every lane writes the same value to the same address and reads its own write)
                 ksh[0] = mx0; ksh[1] = mx1; ksh[2] = mx2; ksh[3] = my0; ksh[4] = my1; ksh[5] = my2;
-                ksh[6] = mom[16] * iW - (mx0 * mx0 + mx1 * mx1 + mx2 * mx2);   // sum w |x_c|^2 / W
-                ksh[7] = mom[17] * iW - (my0 * my0 + my1 * my1 + my2 * my2);   // sum w |y_c|^2 / W
+                ksh[6] = mom[16] * iW - fma(mx2, mx2, fma(mx1, mx1, mx0 * mx0));   // sum w |x_c|^2 / W
+                ksh[7] = mom[17] * iW - fma(my2, my2, fma(my1, my1, my0 * my0));   // sum w |y_c|^2 / W
 #pragma unroll
                 for (int k = 0; k < 9; ++k) ksh[8 + k] = h9[k];
             }
@@ -1115,13 +1127,13 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             const double o0 = (double)bcast[16], o1 = (double)bcast[17], o2 = (double)bcast[18];
             const double mux[3] = {o0 + ksh[0], o1 + ksh[1], o2 + ksh[2]};
             const double muy[3] = {o0 + ksh[3], o1 + ksh[4], o2 + ksh[5]};
-            const double Td0 = muy[0] - (mux[0] * Rd[0] + mux[1] * Rd[3] + mux[2] * Rd[6]);
-            const double Td1 = muy[1] - (mux[0] * Rd[1] + mux[1] * Rd[4] + mux[2] * Rd[7]);
-            const double Td2 = muy[2] - (mux[0] * Rd[2] + mux[1] * Rd[5] + mux[2] * Rd[8]);
+            const double Td0 = muy[0] - fma(mux[2], Rd[6], fma(mux[1], Rd[3], mux[0] * Rd[0]));
+            const double Td1 = muy[1] - fma(mux[2], Rd[7], fma(mux[1], Rd[4], mux[0] * Rd[1]));
+            const double Td2 = muy[2] - fma(mux[2], Rd[8], fma(mux[1], Rd[5], mux[0] * Rd[2]));
             // rmse^2 = (Sxx_c + Syy_c)/W - 2 sum_ij R_ij H_ij, :191-192
             double rh = 0.0;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) rh += Rd[k] * ksh[8 + k];
+            for (int k = 0; k < 9; ++k) rh = fma(Rd[k], ksh[8 + k], rh);
             const double ms = ksh[6] + ksh[7] - 2.0 * rh;
             float Rn[9], Tn[3];   // the new state
 #pragma unroll
@@ -1174,14 +1186,15 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     // the remembered states, all eight at once; the word-by-word comparison only runs on a hit
                     int hash = 0;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) hash ^= __float_as_int(Rn[k]) * (2 * k + 3);
+                    for (int k = 0; k < 9; ++k) hash ^= state_hash_word(Rn[k], k);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) hash ^= __float_as_int(Tn[k]) * (2 * k + 23);
+                    for (int k = 0; k < 3; ++k) hash ^= state_hash_word(Tn[k], 9 + k);
                     const int kk = lane + 1;   // lane l < kRing looks at state newest - (l + 1)
                     const bool cand = lane < kRing && kk <= newest - itBegin &&
                                       __float_as_int(ring[((newest - kk) % kRing) * 16 + 13]) == hash;
                     const bool anyCand = __ballot(cand) != 0ull;
-                    const float cur16 = __shfl(cur, lane & 15, kWave);
+                    float cur16 = 0.f;
+                    if (anyCand) cur16 = __shfl(cur, lane & 15, kWave);
                     for (int k0 = 1; anyCand && k0 <= kRing && period == 0; k0 += 4) {
                         const int k = k0 + (lane >> 4);
                         const bool valid = k <= kRing && k <= newest - itBegin;

@@ -25,7 +25,9 @@ namespace icpflow {
 static __device__ __forceinline__ double det3(double a, double b, double c, double d, double e, double f, double g,
                                        double h, double i)
 {
-    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    // (explicit fused multiply-adds: half the dependent operations of the mul / sub form in the serial tail)
+    const double m0 = fma(e, i, -(f * h)), m1 = fma(d, i, -(f * g)), m2 = fma(d, h, -(e * g));
+    return fma(c, m2, fma(a, m0, -(b * m1)));
 }
 
 static __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -38,18 +40,32 @@ static __device__ __forceinline__ double readlane_f64(double v, int lane)
 // Lane l < 16 returns cofactor (l / 4, l % 4) of the 4x4 matrix M (row-major, LDS): the sixteen 3x3
 // minors are evaluated side by side on sixteen lanes instead of one after the other, which also
 // keeps the register footprint of the solve at nine doubles.
-static __device__ __forceinline__ double cofactor16(const double *M, int lane)
+// The nine element indices of the minor depend on the lane only: computed once per solve (an opaque copy of the
+// lane index keeps the compiler from hoisting them out of the ICP loop, where they would be spilled and come back
+// through dependent scratch loads in every iteration) and shared by the two cofactor evaluations of a solve.
+struct MinorIdx {
+    int e[9];
+    bool neg;
+};
+
+static __device__ __forceinline__ MinorIdx minor_indices(int lane)
 {
-    // the nine element addresses depend on the lane only; recompute them here every time (an opaque copy
-    // of the lane index keeps the compiler from hoisting them out of the ICP loop, where they would be
-    // spilled and come back through nine dependent scratch loads per iteration)
     asm volatile("" : "+v"(lane));
     const int i = (lane >> 2) & 3, j = lane & 3;
-    const int r0 = (0 >= i) ? 1 : 0, r1 = (1 >= i) ? 2 : 1, r2 = (2 >= i) ? 3 : 2;
+    const int r0 = (0 >= i) ? 4 : 0, r1 = (1 >= i) ? 8 : 4, r2 = (2 >= i) ? 12 : 8;
     const int c0 = (0 >= j) ? 1 : 0, c1 = (1 >= j) ? 2 : 1, c2 = (2 >= j) ? 3 : 2;
-    const double d = det3(M[r0 * 4 + c0], M[r0 * 4 + c1], M[r0 * 4 + c2], M[r1 * 4 + c0], M[r1 * 4 + c1],
-                          M[r1 * 4 + c2], M[r2 * 4 + c0], M[r2 * 4 + c1], M[r2 * 4 + c2]);
-    return ((i + j) & 1) ? -d : d;
+    MinorIdx m;
+    m.e[0] = r0 + c0; m.e[1] = r0 + c1; m.e[2] = r0 + c2;
+    m.e[3] = r1 + c0; m.e[4] = r1 + c1; m.e[5] = r1 + c2;
+    m.e[6] = r2 + c0; m.e[7] = r2 + c1; m.e[8] = r2 + c2;
+    m.neg = ((i + j) & 1) != 0;
+    return m;
+}
+
+static __device__ __forceinline__ double cofactor16(const double *M, const MinorIdx &m)
+{
+    const double d = det3(M[m.e[0]], M[m.e[1]], M[m.e[2]], M[m.e[3]], M[m.e[4]], M[m.e[5]], M[m.e[6]], M[m.e[7]], M[m.e[8]]);
+    return m.neg ? -d : d;
 }
 
 // Called by all 64 lanes of ONE wave with wave-uniform arguments; Nsh: 16 doubles of LDS scratch.
@@ -57,7 +73,7 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
 {
     double frob2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) frob2 += S[k] * S[k];
+    for (int k = 0; k < 9; ++k) frob2 = fma(S[k], S[k], frob2);
     if (!(frob2 > 0.0)) return false;
     // characteristic polynomial  l^4 + c2 l^2 + c1 l + c0  (N is traceless)
     const double c2 = -2.0 * frob2;
@@ -73,7 +89,8 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
     }
     const double n00 = Nsh[0], n11 = Nsh[5], n22 = Nsh[10], n33 = Nsh[15];
     // c0 = det N: expansion along row 0, the four cofactors on lanes 0..3
-    const double term = Nsh[lane & 3] * cofactor16(Nsh, lane & 3);
+    const MinorIdx mi = minor_indices(lane);   // lanes 0..3: row 0, whose cofactors give det N
+    const double term = Nsh[lane & 3] * cofactor16(Nsh, mi);
     const double c0 = (readlane_f64(term, 0) + readlane_f64(term, 1)) + (readlane_f64(term, 2) + readlane_f64(term, 3));
     ICPFLOW_STAMP(13);
     double lam = 0.5 * gsum, prevStep = 1e300;
@@ -81,9 +98,14 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
         const double x2 = lam * lam;
         const double b = (x2 + c2) * lam;
         const double a = b + c1;
-        const double den = 2.0 * x2 * lam + b + a;
+        const double den = fma(2.0 * x2, lam, b + a);
         if (den == 0.0) break;
-        const double step = (a * lam + c0) / den;
+        // quotient by a refined reciprocal (the step need not be correctly rounded: the iteration corrects itself
+        // and stops on the size of the step), a third of the dependent operations of an IEEE division
+        double rc = __builtin_amdgcn_rcp(den);
+        rc = fma(fma(-den, rc, 1.0), rc, rc);
+        rc = fma(fma(-den, rc, 1.0), rc, rc);
+        const double step = fma(a, lam, c0) * rc;
         lam -= step;
         const double as = fabs(step);
         // steps shrink monotonically above the largest root (real-rooted quartic): the first one
@@ -94,7 +116,7 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
     ICPFLOW_STAMP(14);
     // adjugate of A = N - lam I (symmetric, rank 3): adj = c q q^T, entry (i, j) on lane 4 i + j
     Nsh[0] = n00 - lam; Nsh[5] = n11 - lam; Nsh[10] = n22 - lam; Nsh[15] = n33 - lam;
-    const double C = cofactor16(Nsh, lane);
+    const double C = cofactor16(Nsh, mi);
     // column of the largest diagonal entry (c q_k^2): the best conditioned one
     int k = 0;
     double big = fabs(readlane_f64(C, 0));
@@ -107,7 +129,7 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
     k = __builtin_amdgcn_readfirstlane(k);
     double q0 = readlane_f64(C, 4 * k + 0), q1 = readlane_f64(C, 4 * k + 1), q2 = readlane_f64(C, 4 * k + 2),
            q3 = readlane_f64(C, 4 * k + 3);
-    const double inv = rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    const double inv = rsqrt(fma(q3, q3, fma(q2, q2, fma(q1, q1, q0 * q0))));
     q0 *= inv; q1 *= inv; q2 *= inv; q3 *= inv;
     // column-convention rotation Rc (y = Rc x) of the quaternion; the row convention wants Rc^T
     const double ww = q0 * q0, xx = q1 * q1, yy = q2 * q2, zz = q3 * q3;
