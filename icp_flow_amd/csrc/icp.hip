@@ -685,12 +685,12 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                                     for (int e = 0; e < 8; ++e) {
                                         const float d = sqdist(sx, sy, sz, txs[e], tys[e], tzs[e]);
                                         const bool lt = d < lb;
-                                        lsec = lt ? lb : fminf(lsec, d);
+                                        lsec = lt ? lb : min_nonneg(lsec, d);
                                         lslot = lt ? t0 + e : lslot;
                                         lb = lt ? d : lb;
                                     }
                                 }
-                                rowbest = row8_min(lb);
+                                rowbest = row8_min_nonneg(lb);
                                 const float kLo = a > 0 ? keyf[a] : -kInf;
                                 const float kHi = bEnd < np16 ? keyf[bEnd - 1] : kInf;   // (+inf padding past the last target)
                                 const float rL = qa - kLo, rR = kHi - qa;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             const bool isW = rowOn && lb == rowbest;
                             const unsigned long long wm = __ballot(isW);
                             const int cnt = __popc((unsigned)(wm >> (lane & ~7)) & 0xffu);
-                            const float secv = row8_min(isW ? lsec : lb);
+                            const float secv = row8_min_nonneg(isW ? lsec : lb);
                             const int slot = row8_min(isW ? lslot : 0x7fffffff);
                             ok = ok && cnt == 1 && secv > rowbest;
 #ifdef ICPFLOW_CERT_STATS
