@@ -187,6 +187,11 @@ __device__ __forceinline__ float min_nonneg(float a, float b)
     return __int_as_float(min(__float_as_int(a), __float_as_int(b)));
 }
 
+__device__ __forceinline__ float max_nonneg(float a, float b)
+{
+    return __int_as_float(max(__float_as_int(a), __float_as_int(b)));
+}
+
 __device__ __forceinline__ float row8_min_nonneg(float v)
 {
     return __int_as_float(row8_min(__float_as_int(v)));

@@ -821,7 +821,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             for (int e = 0; e < 4; ++e) {
                                 const float d = sqdist(qx[q], qy[q], qz[q], txs[e], tys[e], tzs[e]);
                                 if (d == acc.best[q]) { ++matches; ynx = txs[e]; yny = tys[e]; ynz = tzs[e]; slot = c0 + 4 * u + e; }
-                                else if (REC) sec = fminf(sec, d);
+                                else if (REC) sec = min_nonneg(sec, d);
                             }
                         }
                     }

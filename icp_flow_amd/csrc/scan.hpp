@@ -207,7 +207,7 @@ __device__ __forceinline__ void scan_range_tie(const float4 *__restrict__ sx, co
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            if (SECOND) second[q] = fminf(second[q], fmaxf(m[q], acc.best[q]));   // the larger of (old best, this chunk)
+            if (SECOND) second[q] = min_nonneg(second[q], max_nonneg(m[q], acc.best[q]));   // the larger of (old best, this chunk)
             if (m[q] < acc.best[q]) { acc.best[q] = m[q]; acc.chunk[q] = c; tie[q] = false; }
             else if (m[q] == acc.best[q]) tie[q] = true;
         }
