@@ -172,6 +172,70 @@ def test_adaptive_windows_change_nothing(shape):
     assert torch.equal(P0, utils_match.hist_icp(ap, s, d))
 
 
+def _adversarial_batch():
+    """Cluster pairs built to stress the certificates' bounds: exact distance ties (lattice points, duplicated targets),
+    coordinates of a few km (fp32 ulp 2.4e-4 m .. 4.9e-4 m: the rounding of the window bounds and of the moved points is
+    of the size of the margins), tiny clouds, clouds without a single neighbour inside the gate, and plain pairs."""
+    rng = np.random.default_rng(2024)
+    B, N = 96, 700
+    S = np.full((B, N, 4), 1e8, np.float32)
+    D = np.full((B, N, 4), 1e8, np.float32)
+    S[:, :, 3] = D[:, :, 3] = 0.0
+    for b in range(B):
+        kind = b % 6
+        ns = int(rng.integers(3, N + 1)) if kind == 4 else int(rng.integers(200, N + 1))
+        nd = int(rng.integers(3, N + 1)) if kind == 4 else int(rng.integers(200, N + 1))
+        ext = np.array([rng.uniform(1.0, 5.0), rng.uniform(0.8, 2.0), rng.uniform(0.5, 1.8)])
+        centre = rng.uniform(-40, 40, 3)
+        if kind == 1:                                         # lattice: many exactly equal distances
+            g = 0.0625
+            src = np.floor(rng.uniform(-0.5, 0.5, (ns, 3)) * ext / g) * g
+            dst = np.floor(rng.uniform(-0.5, 0.5, (nd, 3)) * ext / g) * g + np.array([g / 2, 0.0, 0.0])
+            centre = np.round(centre / g) * g
+        else:
+            src = rng.uniform(-0.5, 0.5, (ns, 3)) * ext
+            dst = rng.uniform(-0.5, 0.5, (nd, 3)) * ext
+            if kind in (0, 2, 3, 4):                          # overlapping surfaces, small motion
+                m = min(ns, nd)
+                dst[:m] = src[:m] + rng.normal(0, 0.01, (m, 3))
+            dst = dst + np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 0.02])
+        if kind == 2:                                         # duplicated targets: the first-index rule decides
+            dup = rng.integers(0, nd, nd // 3)
+            dst[rng.integers(0, nd, nd // 3)] = dst[dup]
+        if kind == 3:                                         # kilometres from the origin
+            centre = centre + np.array([4000.0, -7000.0, 0.0])
+        if kind == 5:                                         # nothing inside the gate
+            dst = dst + np.array([3.0, 0.0, 0.0])
+        S[b, :ns, :3] = src + centre; S[b, :ns, 3] = 1.0
+        D[b, :nd, :3] = dst + centre; D[b, :nd, 3] = 1.0
+    return S, D
+
+
+def test_certificates_on_adversarial_clouds_change_nothing():
+    """The neighbour certificates and probes (icp.hip) against the plain window scan on clouds built to hit their
+    bounds: ties, duplicates, km-sized coordinates, tiny clouds, empty gates.  Bit-identical transforms, iteration
+    counts and per-pair results, straight ICP (no vote in front: large first steps) and hist_icp."""
+    from icp_flow_amd import utils_icp_pytorch3d
+    S, D = _adversarial_batch()
+    s, d = G(S), G(D)
+    for cap, stop in ((60, "reference"), (25, "per_pair")):
+        kw = dict(max_iterations=cap, stop_mode=stop)
+        with _lib.options(no_adaptive_windows=True):
+            a0 = utils_icp_pytorch3d.iterative_closest_point(s, d, **kw)
+            R0, T0, e0, x0 = a0.RTs.R.clone(), a0.RTs.T.clone(), a0.rmse.clone(), a0.Xt.clone()
+            n0 = a0.converged.iterations
+        a1 = utils_icp_pytorch3d.iterative_closest_point(s, d, **kw)
+        assert a1.converged.iterations == n0
+        assert torch.equal(a1.RTs.R, R0) and torch.equal(a1.RTs.T, T0)
+        assert torch.equal(torch.nan_to_num(a1.rmse, nan=-1.0), torch.nan_to_num(e0, nan=-1.0))
+        assert torch.equal(torch.nan_to_num(a1.Xt, nan=-1.0), torch.nan_to_num(x0, nan=-1.0))
+    for stop in ("reference", "per_pair"):
+        a = rp.default_args(max_points=S.shape[1], icp_max_iterations=40, icp_stop_mode=stop)
+        with _lib.options(no_adaptive_windows=True):
+            T0 = utils_match.hist_icp(a, s, d)
+        assert torch.equal(T0, utils_match.hist_icp(a, s, d))
+
+
 # ------------------------------------------------------------------------------------------ fused vote bins
 def _wide_pair(n, seed):
     """A wall: 24 m x 0.4 m x 2.6 m, n points -- wider than the 8 m above which the vote sorts by the composite
