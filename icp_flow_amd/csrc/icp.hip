@@ -85,8 +85,8 @@ struct IcpParams {
     const float *initR;      // [B,3,3] / [B,3]: the state before the first iteration (init_transform), NULL = identity
     const float *initT;
     int allowReflection;     // R = U V^T whatever its determinant (:354-362 with E = I)
-    int recOn;               // sorted sweep in LDS, one workgroup per pair: per-query records behind the LDS image
-                             // (adaptive windows, see the search phase)
+    int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
+                             // certificates, see the search phase); a workgroup whose share of the queries fits uses them
 };
 
 
@@ -557,10 +557,14 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             // (q0, L; j1) in LDS behind the image.  Minimum, gate decision and neighbour are those of the full search in
             // every case: results are bit-identical (test_adaptive_windows_change_nothing), the iterations after the
             // first few cost a distance evaluation per query instead of a window scan.
-            constexpr bool REC = (GRID == 4) && !TEAM;
-            float4 *rec = reinterpret_cast<float4 *>(dynLds + (size_t)NP16 * 12);
-            int *recJ = reinterpret_cast<int *>(dynLds + (size_t)NP16 * 12 + (size_t)p.N * 16);
-            const bool recOn = REC && p.recOn != 0;
+            constexpr bool REC = (GRID == 4);
+            // team member `rank` owns the sorted queries [qBegin, qEnd)
+            const int qShare = (TEAM && G > 1) ? ((xc.n + G - 1) / G + kWave - 1) / kWave * kWave : xc.n;
+            const int qBegin = min(rank * qShare, xc.n), qEnd = min(qBegin + qShare, xc.n);
+            // records of this workgroup's queries (indexed from qBegin), if its share fits the room behind the image
+            float4 *rec = reinterpret_cast<float4 *>(dynLds + (size_t)NP16 * 12) - qBegin;
+            int *recJ = reinterpret_cast<int *>(dynLds + (size_t)NP16 * 12 + (size_t)p.recCap * 16) - qBegin;
+            const bool recOn = REC && p.recCap > 0 && qEnd - qBegin <= p.recCap;
             if (GRID == 4 && it == itBegin) {
                 for (int k = tid; k < np16; k += BLOCK) { lx[k] = gx[k]; ly[k] = gy[k]; lz[k] = gz[k]; }
                 __syncthreads();
@@ -568,9 +572,6 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             const float *keyf = (GRID == 4) ? (axis == 0 ? lx : (axis == 1 ? ly : lz))
                                             : (axis == 0 ? gx : (axis == 1 ? gy : gz));
             constexpr int PER = BLOCK * Q;            // a wave owns 64 CONSECUTIVE sorted queries
-            // team member `rank` owns the sorted queries [qBegin, qEnd)
-            const int qShare = (TEAM && G > 1) ? ((xc.n + G - 1) / G + kWave - 1) / kWave * kWave : xc.n;
-            const int qBegin = min(rank * qShare, xc.n), qEnd = min(qBegin + qShare, xc.n);
             const int ngr = (qEnd - qBegin + PER - 1) / PER;
             double fold[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
             bool reuseMoments = false;   // this wave's 18 sums are those of the previous iteration (still in `red`)
@@ -1414,7 +1415,7 @@ template <int BLOCK, int Q, int TS, int GRID, bool TEAM = false>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
-                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + ((!TEAM && p.recOn) ? (size_t)p.N * 20 : 0) : 0;
+                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + (size_t)p.recCap * 20 : 0;
     if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation and device
         static std::atomic<unsigned long long> raised{0ull};
         ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM>), 156 * 1024, &raised);
@@ -1590,6 +1591,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
     p.initR = opts.initR; p.initT = opts.initT; p.allowReflection = opts.allowReflection ? 1 : 0;
     hipError_t e = hipSuccess;
+    bool recWanted = false;   // neighbour certificates (sorted sweep with the LDS image)
     if (opts.historyPending != nullptr) *opts.historyPending = false;
     if (!opts.ctrlCleared) {
         e = hipMemsetAsync(ctrl, 0, sizeof(IcpCtrl), s);
@@ -1602,7 +1604,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
         p.sortedRaw = 1;
-        p.recOn = opts.adaptiveWindows && N <= kRecMaxN;
+        recWanted = opts.adaptiveWindows;
     } else if (grid != nullptr && grid->mode == 3) {
         int NP2 = 64;
         while (NP2 < N) NP2 <<= 1;
@@ -1619,7 +1621,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
-        p.recOn = opts.adaptiveWindows && N <= kRecMaxN;
+        recWanted = opts.adaptiveWindows;
     } else if (grid != nullptr) {
         // bin the fixed cloud once: cell edge 1 % above the gate radius (rounding head-room)
         const float invh = (float)(1.0 / (1.01 * thres));
@@ -1639,6 +1641,17 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.team = *team;
         p.team.maxWG = min(cus, team->maxWG);
         hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, p.team);
+    }
+    if (recWanted && p.sortY != nullptr) {
+        // room for the per-query records behind the LDS image: every query of a pair when one workgroup serves it,
+        // the member's own share of the queries in a team (the image of a 10^4-point cloud leaves room for ~1800)
+        const size_t img = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
+        const size_t room = 152 * 1024;   // dynamic LDS next to the kernel's ~3 KiB of static LDS
+        if (p.team.wgPair != nullptr) {
+            if (N <= 12288 && img + 64 * 20 <= room) p.recCap = (int)((room - img) / 20 / 64 * 64);
+        } else if (N <= kRecMaxN) {
+            p.recCap = N;
+        }
     }
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {
         // Batch-global stop rule.  ONE launch runs every pair through all iterations speculatively,

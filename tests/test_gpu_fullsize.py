@@ -145,7 +145,8 @@ def test_config2_full_batch_fp32_reference_arithmetic(config2):
     assert (err32 < TOL_M).sum() >= 256 - 10 and err32[c["determined"]].max() < 1e-3, msg
 
 
-@pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_400x3000"])
+@pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_400x3000",
+                                   "teams_ragged_20x10000", "teams_12x6000"])
 def test_adaptive_windows_change_nothing(shape):
     """Batches larger than the GPU: every query's search window comes from where its neighbour was in the previous
     iteration, and queries certified to be outside the gate are not searched at all (icp.hip, "Adaptive windows").
@@ -155,6 +156,10 @@ def test_adaptive_windows_change_nothing(shape):
         S, D, _ = synthetic.make_batch(256, 1024, seed=0)
     elif shape == "config4_shard_1024x2048":
         S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
+    elif shape == "teams_ragged_20x10000":   # few large pairs: several workgroups per pair, records of each member's share
+        S, D, _ = synthetic.make_batch(20, 10000, seed=7, ragged=True, n_min=500)
+    elif shape == "teams_12x6000":
+        S, D, _ = synthetic.make_batch(12, 6000, seed=9)
     elif shape == "ragged_600x1024":
         S, D, _ = synthetic.make_batch(600, 1024, seed=31, ragged=True, n_min=60)
     else:
