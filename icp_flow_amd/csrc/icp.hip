@@ -34,8 +34,13 @@ __device__ int g_stamp_block;                  // the workgroup that stamps (icp
 
 #ifdef ICPFLOW_TAIL_CLOCK
 // debug builds only (tools/dbg/tail_clock.py): per pair, shader clocks wave 0 spent between the block barrier and the
-// publication of (R, T) (the serial tail), in the rest of the loop, and the iterations it executed
+// publication of (R, T) (the serial tail), in the rest of the loop, and the iterations it executed; and the tail split
+// at the phase stamps (accumulated in LDS by thread 0)
 __device__ long long g_tail_clock[1024 * 3];
+__device__ long long g_tail_split[1024 * 16];
+__shared__ long long g_tcSh[17];
+#undef ICPFLOW_STAMP
+#define ICPFLOW_STAMP(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); g_tcSh[k] += t_ - g_tcSh[16]; g_tcSh[16] = t_; } } while (0)
 #endif
 #ifdef ICPFLOW_CERT_STATS
 // debug builds only (tools/dbg/cert_stats.py): per iteration, over the whole batch: waves that ran, waves that searched,
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     __shared__ double ksh[17];                // centroids, second moments and H parked across the solve
     __shared__ float bcast[20];               // R (9), T (3), active flag, prev rmse, rmse, -, origin (3)
     __shared__ float preL[12];                // pre-pose (R row-major 9, t 3), read back where it is applied
-    __shared__ float ring[kRing * 16];        // the last kRing states (R, T) and their rmse (cycle detection)
+    __shared__ __attribute__((aligned(16))) float ring[kRing * 16];        // the last kRing states (R, T) and their rmse (cycle detection)
     __shared__ float combD[TS > 1 ? NWAVE * Q * kWave : 1];   // [wave][q][lane]
     __shared__ int combC[TS > 1 ? NWAVE * Q * kWave : 1];
 
@@ -484,6 +489,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     unsigned long long ownConvLo = 0ull, ownConvHi = 0ull;   // iterations at which this pair was converged
 #ifdef ICPFLOW_TAIL_CLOCK
     long long tcTail = 0, tcSearch = 0, tcLoop0 = clock64();
+    if (threadIdx.x < 17) g_tcSh[threadIdx.x] = threadIdx.x == 16 ? clock64() : 0;
+    __syncthreads();
 #endif
     for (int it = itBegin; it < itEnd; ++it) {
         if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
@@ -1176,10 +1183,6 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 // the batch rule is unchanged, the iterations are not executed.
                 int period = 0;
                 {
-                    float cur = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) cur = (lane == k) ? Rn[k] : cur;
-                    cur = (lane == 9) ? Tn[0] : (lane == 10) ? Tn[1] : (lane == 11) ? Tn[2] : cur;
                     const int newest = it + 1;   // number of the new state
                     // four candidate periods per round: quarter q of the wave compares the new state
                     // (replicated into every quarter) with state newest - (k0 + q)
@@ -1194,8 +1197,13 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     const bool cand = lane < kRing && kk <= newest - itBegin &&
                                       __float_as_int(ring[((newest - kk) % kRing) * 16 + 13]) == hash;
                     const bool anyCand = __ballot(cand) != 0ull;
-                    float cur16 = 0.f;
-                    if (anyCand) cur16 = __shfl(cur, lane & 15, kWave);
+                    float cur16 = 0.f;   // word (lane & 15) of the new state: only a hash hit needs it
+                    if (anyCand) {
+                        const int wd = lane & 15;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) cur16 = (wd == k) ? Rn[k] : cur16;
+                        cur16 = (wd == 9) ? Tn[0] : (wd == 10) ? Tn[1] : (wd == 11) ? Tn[2] : cur16;
+                    }
                     for (int k0 = 1; anyCand && k0 <= kRing && period == 0; k0 += 4) {
                         const int k = k0 + (lane >> 4);
                         const bool valid = k <= kRing && k <= newest - itBegin;
@@ -1209,9 +1217,12 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             if (okq && kq <= kRing && kq <= newest - itBegin) period = kq;   // smallest period wins
                         }
                     }
-                    if (lane < 12) ring[(newest % kRing) * 16 + lane] = cur;
-                    if (lane == 12) ring[(newest % kRing) * 16 + 12] = rmse;
-                    if (lane == 13) ring[(newest % kRing) * 16 + 13] = __int_as_float(hash);
+                    if (lane == 0) {   // (the values are wave-uniform: one lane stores the row)
+                        float *rw = ring + (newest % kRing) * 16;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) rw[k] = Rn[k];
+                        rw[9] = Tn[0]; rw[10] = Tn[1]; rw[11] = Tn[2]; rw[12] = rmse; rw[13] = __int_as_float(hash);
+                    }
                 }
                 if (period > 0 && active) {
                     if (rank == 0) {
@@ -1270,6 +1281,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     __syncthreads();
 #ifdef ICPFLOW_TAIL_CLOCK
     if (tid == 0 && b < 1024) { g_tail_clock[b * 3] = tcTail; g_tail_clock[b * 3 + 1] = tcSearch; g_tail_clock[b * 3 + 2] = itersDone; }
+    if (tid < 16 && b < 1024) g_tail_split[b * 16 + tid] = g_tcSh[tid];
 #endif
     if (tid == 0 && rank == 0) {  // wave 0 (of member 0) holds the final state
 #pragma unroll
@@ -1437,6 +1449,10 @@ struct LaunchProfile {
 extern "C" int icpflow_debug_tail_clock(long long *out3072)
 {
     return (int)hipMemcpyFromSymbol(out3072, HIP_SYMBOL(g_tail_clock), sizeof(long long) * 3072);
+}
+extern "C" int icpflow_debug_tail_split(long long *out16384)
+{
+    return (int)hipMemcpyFromSymbol(out16384, HIP_SYMBOL(g_tail_split), sizeof(long long) * 16384);
 }
 #endif
 #ifdef ICPFLOW_CERT_STATS

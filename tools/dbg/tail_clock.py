@@ -22,3 +22,12 @@ for b in order[:12]:
     n = max(v[b, 2], 1)
     print(f"  {b:4d} {v[b,2]:4d}   {v[b,0]:9d} ({v[b,0]/n:7.0f})   {v[b,1]:9d} ({v[b,1]/n:7.0f})   {v[b,0]+v[b,1]:9d}")
 print("all pairs: tail %.3g clocks, rest %.3g clocks" % (v[:, 0].sum(), v[:, 1].sum()))
+sp = (ctypes.c_longlong * 16384)()
+_lib._L.icpflow_debug_tail_split(sp)
+w = np.array(sp[:], dtype=np.int64).reshape(1024, 16)[:B]
+names = {1: "top of loop -> queries loaded", 11: "certificates + probes", 12: "window", 2: "scan", 10: "resolve + records", 3: "moments", 4: "block barrier", 5: "totals + H", 13: "quartic coefficients",
+         14: "newton", 6: "adjugate + rotation", 15: "T, rmse", 9: "history + tally + stop check", 7: "cycle detection + publish", 8: "loop exit"}
+b = int(order[2])
+print(f"pair {b}: clocks per iteration between the stamps of thread 0 (each stamp costs a clock read + an LDS update)")
+for k in (1, 11, 12, 2, 10, 3, 4, 5, 13, 14, 6, 15, 9, 7):
+    print(f"   {names[k]:34s} {w[b, k] / max(v[b, 2], 1):8.0f}")
