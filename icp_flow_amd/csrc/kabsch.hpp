@@ -75,23 +75,30 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) frob2 = fma(S[k], S[k], frob2);
     if (!(frob2 > 0.0)) return false;
-    // characteristic polynomial  l^4 + c2 l^2 + c1 l + c0  (N is traceless)
+    // characteristic polynomial  l^4 + c2 l^2 + c1 l + c0  (N is traceless).  With the singular values s1, s2, s3 of H
+    // (s3 carrying the sign of det H) the eigenvalues of N are s1+s2+s3, s1-s2-s3, -s1+s2-s3, -s1-s2+s3, hence
+    //   c2 = -2 |H|_F^2,   c1 = -8 det H,   c0 = det N = |H|_F^4 - 4 |cof H|_F^2
+    // (the squared singular values of the cofactor matrix are the pairwise products): nine 2x2 minors in registers
+    // instead of a 4x4 determinant through LDS, and det H comes out of three of them.
+    const double m00 = fma(S[4], S[8], -(S[5] * S[7])), m01 = fma(S[3], S[8], -(S[5] * S[6])), m02 = fma(S[3], S[7], -(S[4] * S[6]));
+    const double m10 = fma(S[1], S[8], -(S[2] * S[7])), m11 = fma(S[0], S[8], -(S[2] * S[6])), m12 = fma(S[0], S[7], -(S[1] * S[6]));
+    const double m20 = fma(S[1], S[5], -(S[2] * S[4])), m21 = fma(S[0], S[5], -(S[2] * S[3])), m22 = fma(S[0], S[4], -(S[1] * S[3]));
+    const double cof2 = fma(m22, m22, fma(m21, m21, fma(m20, m20, fma(m12, m12, fma(m11, m11,
+                        fma(m10, m10, fma(m02, m02, fma(m01, m01, m00 * m00))))))));
+    const double detH = fma(S[2], m02, fma(S[0], m00, -(S[1] * m01)));
     const double c2 = -2.0 * frob2;
-    const double c1 = -8.0 * det3(S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8]);
+    const double c1 = -8.0 * detH;
+    const double c0 = fma(frob2, frob2, -4.0 * cof2);
     {
-        // every lane stores the same values (and later reads what it stored itself)
+        // N (symmetric 4x4) goes to LDS for the adjugate below; every lane stores the same values
         const double n01 = S[5] - S[7], n02 = S[6] - S[2], n03 = S[1] - S[3];
         const double n12 = S[1] + S[3], n13 = S[6] + S[2], n23 = S[5] + S[7];
-        Nsh[0] = S[0] + S[4] + S[8]; Nsh[1] = n01; Nsh[2] = n02; Nsh[3] = n03;
-        Nsh[4] = n01; Nsh[5] = S[0] - S[4] - S[8]; Nsh[6] = n12; Nsh[7] = n13;
-        Nsh[8] = n02; Nsh[9] = n12; Nsh[10] = -S[0] + S[4] - S[8]; Nsh[11] = n23;
-        Nsh[12] = n03; Nsh[13] = n13; Nsh[14] = n23; Nsh[15] = -S[0] - S[4] + S[8];
+        Nsh[1] = n01; Nsh[2] = n02; Nsh[3] = n03;
+        Nsh[4] = n01; Nsh[6] = n12; Nsh[7] = n13;
+        Nsh[8] = n02; Nsh[9] = n12; Nsh[11] = n23;
+        Nsh[12] = n03; Nsh[13] = n13; Nsh[14] = n23;
     }
-    const double n00 = Nsh[0], n11 = Nsh[5], n22 = Nsh[10], n33 = Nsh[15];
-    // c0 = det N: expansion along row 0, the four cofactors on lanes 0..3
-    const MinorIdx mi = minor_indices(lane);   // lanes 0..3: row 0, whose cofactors give det N
-    const double term = Nsh[lane & 3] * cofactor16(Nsh, mi);
-    const double c0 = (readlane_f64(term, 0) + readlane_f64(term, 1)) + (readlane_f64(term, 2) + readlane_f64(term, 3));
+    const double n00 = S[0] + S[4] + S[8], n11 = S[0] - S[4] - S[8], n22 = -S[0] + S[4] - S[8], n33 = -S[0] - S[4] + S[8];
     ICPFLOW_STAMP(13);
     double lam = 0.5 * gsum, prevStep = 1e300;
     for (int it = 0; it < 40; ++it) {
@@ -116,6 +123,7 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
     ICPFLOW_STAMP(14);
     // adjugate of A = N - lam I (symmetric, rank 3): adj = c q q^T, entry (i, j) on lane 4 i + j
     Nsh[0] = n00 - lam; Nsh[5] = n11 - lam; Nsh[10] = n22 - lam; Nsh[15] = n33 - lam;
+    const MinorIdx mi = minor_indices(lane);
     const double C = cofactor16(Nsh, mi);
     // column of the largest diagonal entry (c q_k^2): the best conditioned one
     int k = 0;
