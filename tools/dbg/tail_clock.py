@@ -1,5 +1,6 @@
 """Developer tool (library built with -DICPFLOW_TAIL_CLOCK): per pair of BASELINE config 2, the shader clocks wave 0 spent
-in the serial tail (block barrier -> (R, T) published) and in the rest of the iteration loop, two clock reads per iteration."""
+in the serial tail (block barrier -> (R, T) published) and in the rest of the iteration loop, two clock reads per iteration.
+SPLIT=1 with a library built with -DICPFLOW_TAIL_CLOCK -DICPFLOW_TAIL_SPLIT: the tail of one sliding pair phase by phase."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -22,6 +23,8 @@ for b in order[:12]:
     n = max(v[b, 2], 1)
     print(f"  {b:4d} {v[b,2]:4d}   {v[b,0]:9d} ({v[b,0]/n:7.0f})   {v[b,1]:9d} ({v[b,1]/n:7.0f})   {v[b,0]+v[b,1]:9d}")
 print("all pairs: tail %.3g clocks, rest %.3g clocks" % (v[:, 0].sum(), v[:, 1].sum()))
+if not os.environ.get("SPLIT"):
+    sys.exit(0)
 sp = (ctypes.c_longlong * 16384)()
 _lib._L.icpflow_debug_tail_split(sp)
 w = np.array(sp[:], dtype=np.int64).reshape(1024, 16)[:B]
