@@ -39,8 +39,10 @@ __device__ int g_stamp_block;                  // the workgroup that stamps (icp
 __device__ long long g_tail_clock[1024 * 3];
 __device__ long long g_tail_split[1024 * 16];
 __shared__ long long g_tcSh[17];
+#ifdef ICPFLOW_TAIL_SPLIT   // (each stamp costs ~200 clocks: the totals above are measured without)
 #undef ICPFLOW_STAMP
 #define ICPFLOW_STAMP(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); g_tcSh[k] += t_ - g_tcSh[16]; g_tcSh[16] = t_; } } while (0)
+#endif
 #endif
 #ifdef ICPFLOW_CERT_STATS
 // debug builds only (tools/dbg/cert_stats.py): per iteration, over the whole batch: waves that ran, waves that searched,
