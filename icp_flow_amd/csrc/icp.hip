@@ -92,6 +92,7 @@ struct IcpParams {
     const float *initR;      // [B,3,3] / [B,3]: the state before the first iteration (init_transform), NULL = identity
     const float *initT;
     int allowReflection;     // R = U V^T whatever its determinant (:354-362 with E = I)
+    int x0Cache;             // the records are followed by the queries' own points (12 B each): no L2 round trip per iteration
     int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
                              // certificates, see the search phase); a workgroup whose share of the queries fits uses them
 };
@@ -488,6 +489,9 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
     int specChk = 0;  // speculative mode: first iteration not yet known to be complete-and-unconverged
     int winLo = -1, winHi = -1;   // sorted sweep: this wave's target window of the previous iteration
     int prevNN = -2;              // certificates, single pass: this lane's gated neighbour of the previous iteration
+    int sweepAxis = 0;            // sorted sweep: the sort axis of this pair (read once: a load from L2 at the top of every
+                                  // iteration is a round trip that every wave of the workgroup sits out together)
+    if constexpr (GRID >= 3) sweepAxis = __builtin_amdgcn_readfirstlane(p.sortAxis[b]);
     unsigned long long ownConvLo = 0ull, ownConvHi = 0ull;   // iterations at which this pair was converged
 #ifdef ICPFLOW_TAIL_CLOCK
     long long tcTail = 0, tcSearch = 0, tcLoop0 = clock64();
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             const float *gz = gy + NP16;
             const float4 *ys = p.sortY + (size_t)b * p.N;
             const float4 *xs = p.sortX + (size_t)b * p.N;
-            const int axis = p.sortAxis[b];
+            const int axis = sweepAxis;
             // GRID == 4: the sorted fixed cloud is staged into LDS once per launch and every
             // per-iteration access (window search, scan, resolve) stays on chip
             float *lx = reinterpret_cast<float *>(dynLds), *ly = lx + NP16, *lz = ly + NP16;
@@ -574,6 +578,9 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
             float4 *rec = reinterpret_cast<float4 *>(dynLds + (size_t)NP16 * 12) - qBegin;
             int *recJ = reinterpret_cast<int *>(dynLds + (size_t)NP16 * 12 + (size_t)p.recCap * 16) - qBegin;
             const bool recOn = REC && p.recCap > 0 && qEnd - qBegin <= p.recCap;
+            // (and the query's own point, pre-pose applied, when there is room: read from L2 once, not once per iteration)
+            float *x0c = reinterpret_cast<float *>(dynLds + (size_t)NP16 * 12 + (size_t)p.recCap * 20) - qBegin;
+            const bool x0On = recOn && p.x0Cache != 0;
             if (GRID == 4 && it == itBegin) {
                 for (int k = tid; k < np16; k += BLOCK) { lx[k] = gx[k]; ly[k] = gy[k]; lz[k] = gz[k]; }
                 __syncthreads();
@@ -604,12 +611,17 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                     x0x[q] = x0y[q] = x0z[q] = 0.f;
                     qx[q] = qy[q] = qz[q] = 0.f;
                     if (live[q]) {
+                        if (x0On && it > itBegin) {
+                            x0x[q] = x0c[i]; x0y[q] = x0c[p.recCap + i]; x0z[q] = x0c[2 * p.recCap + i];
+                        } else {
                         const float4 s4 = xs[i];   // sorted; pre-pose (utils_icp.py:21) applied by the sort or here
                         x0x[q] = s4.x; x0y[q] = s4.y; x0z[q] = s4.z;
                         if (p.sortedRaw) {   // pre-pose (row-major rotation, translation) parked in LDS
                             x0x[q] = fmaf(s4.z, preL[2], fmaf(s4.y, preL[1], s4.x * preL[0])) + preL[9];
                             x0y[q] = fmaf(s4.z, preL[5], fmaf(s4.y, preL[4], s4.x * preL[3])) + preL[10];
                             x0z[q] = fmaf(s4.z, preL[8], fmaf(s4.y, preL[7], s4.x * preL[6])) + preL[11];
+                        }
+                        if (x0On) { x0c[i] = x0x[q]; x0c[p.recCap + i] = x0y[q]; x0c[2 * p.recCap + i] = x0z[q]; }
                         }
                         qx[q] = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0])) + Tf[0];  // :177, :395
                         qy[q] = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1])) + Tf[1];
@@ -1429,7 +1441,7 @@ template <int BLOCK, int Q, int TS, int GRID, bool TEAM = false>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
-                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + (size_t)p.recCap * 20 : 0;
+                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + (size_t)p.recCap * (p.x0Cache ? 32 : 20) : 0;
     if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation and device
         static std::atomic<unsigned long long> raised{0ull};
         ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM>), 156 * 1024, &raised);
@@ -1670,6 +1682,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         } else if (N <= kRecMaxN) {
             p.recCap = N;
         }
+        p.x0Cache = p.recCap > 0 && img + (size_t)p.recCap * 32 <= room;
     }
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {
         // Batch-global stop rule.  ONE launch runs every pair through all iterations speculatively,
