@@ -514,7 +514,23 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
         unsigned long long specTally = 0ull;
         bool specLoaded = false;
         if (wave == 0 && p.history != nullptr && rank == 0) {
-            while (specChk < it && !((specChk < 64 ? ownConvLo >> specChk : ownConvHi >> (specChk - 64)) & 1ull)) ++specChk;
+            // (wave-uniform values kept scalar: left to itself the compiler vectorises this search over the lanes)
+            specChk = __builtin_amdgcn_readfirstlane(specChk);
+            {
+                const unsigned long long lo = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(ownConvLo >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)ownConvLo);
+                const unsigned long long hi = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(ownConvHi >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)ownConvHi);
+                // first own-converged iteration >= specChk: count trailing zeros of the remaining bits
+                unsigned long long rest = specChk < 64 ? (lo >> specChk) : 0ull;
+                if (rest != 0ull) specChk += __builtin_ctzll(rest);
+                else {
+                    const int from = specChk < 64 ? 64 : specChk;
+                    rest = from < 128 ? (hi >> (from - 64)) : 0ull;
+                    specChk = rest != 0ull ? from + __builtin_ctzll(rest) : 128;
+                }
+                specChk = min(specChk, it);
+            }
             if (specChk < it) {
                 specTally = __hip_atomic_load(&ctrl->tally[specChk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 specLoaded = true;
