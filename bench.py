@@ -40,8 +40,8 @@ COUNTERS_FILE = os.path.join(REPO, "profiles", "r02_icp_kernel_counters.json")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4"])
     ap.add_argument("--pairs", type=int, default=None, help="cluster pairs per step IN TOTAL (config2: 256 per GPU)")
     ap.add_argument("--points", type=int, default=None, help="points per cluster (= padded length)")

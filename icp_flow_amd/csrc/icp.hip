@@ -679,26 +679,20 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                 if (REC && recOn && it > itBegin) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
-                        unsigned long long need = __ballot(live[q] && recM[q] >= 0.f && certJ[q] >= 0);
-                        if (__popcll(need) > kProbeMax) continue;
-                        while (need != 0ull) {
-                            // this round's queries: the (up to) eight lowest uncertified lanes, row r takes the r-th
-                            unsigned srcLo = 0xffffffffu, srcHi = 0xffffffffu;   // 4 x 8-bit lane numbers each, 0xff = none
-                            unsigned long long roundMask = 0ull;
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) {
-                                if (need != 0ull) {
-                                    const unsigned l = (unsigned)(__ffsll((long long)need) - 1);
-                                    need &= need - 1ull;
-                                    roundMask |= 1ull << l;
-                                    if (r < 4) srcLo = (srcLo & ~(0xffu << (8 * r))) | (l << (8 * r));
-                                    else srcHi = (srcHi & ~(0xffu << (8 * (r - 4)))) | (l << (8 * (r - 4)));
-                                }
-                            }
-                            const int row = lane >> 3, li = lane & 7;
-                            const int src = (int)(((row < 4 ? srcLo : srcHi) >> (8 * (row & 3))) & 0xffu);
-                            const bool rowOn = src != 0xff;
-                            const int srcl = rowOn ? src : lane;
+                        const bool wants = live[q] && recM[q] >= 0.f && certJ[q] >= 0;
+                        const unsigned long long need = __ballot(wants);
+                        const int nNeed = __popcll(need);
+                        if (nNeed > kProbeMax || nNeed == 0) continue;
+                        // the uncertified lanes in lane order: lane k of the wave learns who the k-th of them is (one
+                        // forward permute), row r of round t then serves the (8 t + r)-th
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+                        const int kth = __builtin_amdgcn_ds_permute((wants ? rank : nNeed + lane - rank) << 2, lane);   // (a permutation)
+                        const int row = lane >> 3, li = lane & 7;
+                        for (int t = 0; t * 8 < nNeed; ++t) {
+                            const int which = 8 * t + row;
+                            const bool rowOn = which < nNeed;
+                            const int kthOfRow = __shfl(kth, which & 63, kWave);   // (every lane takes part: the source lanes too)
+                            const int srcl = rowOn ? kthOfRow : lane;
                             const float sx = __shfl(qx[q], srcl, kWave), sy = __shfl(qy[q], srcl, kWave),
                                         sz = __shfl(qz[q], srcl, kWave);
                             const int j1 = __shfl(certJ[q], srcl, kWave);
@@ -754,8 +748,8 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, in
                             if (li == 0 && rowOn && it < 128 && (g_stats_block < 0 || g_stats_block == (int)blockIdx.x)) { atomicAdd(&g_probe_stats[it * 2], 1ull); atomicAdd(&g_probe_stats[it * 2 + 1], ok ? 1ull : 0ull); }
 #endif
                             // hand the result to the lane that owns the query
-                            const bool mine = ((roundMask >> lane) & 1ull) != 0ull;
-                            const int from = __popcll(roundMask & ((1ull << lane) - 1ull)) * 8;
+                            const bool mine = wants && (rank >> 3) == t;
+                            const int from = (rank & 7) * 8;
                             const float rD = __shfl(isNN ? rowbest : kInf, from, kWave);
                             const float rNewL = __shfl(fminf(__builtin_amdgcn_sqrtf(secv), rho), from, kWave);
                             const int rSlot = __shfl(ok ? slot : -1, from, kWave);
