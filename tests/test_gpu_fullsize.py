@@ -148,10 +148,11 @@ def test_config2_full_batch_fp32_reference_arithmetic(config2):
 @pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_400x3000",
                                    "teams_ragged_20x10000", "teams_12x6000"])
 def test_adaptive_windows_change_nothing(shape):
-    """Batches larger than the GPU: every query's search window comes from where its neighbour was in the previous
-    iteration, and queries certified to be outside the gate are not searched at all (icp.hip, "Adaptive windows").
-    Gate decisions and neighbours are those of the full window: transforms and iteration count are bit-identical
-    to ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS."""
+    """Neighbour certificates, probes and reused moment sums (icp.hip): a query whose previous neighbour is
+    provably still the nearest (or which provably has none inside the gate) is not searched, the few others of a wave
+    are probed by rows of eight lanes, and a wave whose gated neighbours did not change keeps its sums.  Gate decisions,
+    neighbours and sums are those of the plain window scan: transforms and iteration count are bit-identical to
+    ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS (the switch keeps its name from the first form of the per-query records)."""
     if shape == "config2_256x1024":
         S, D, _ = synthetic.make_batch(256, 1024, seed=0)
     elif shape == "config4_shard_1024x2048":
