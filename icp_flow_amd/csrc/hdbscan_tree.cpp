@@ -34,6 +34,20 @@ struct Row {   // condensed tree
     int size;
 };
 
+struct Edge {
+    double w;
+    int cur, nxt;
+};
+
+// The work arrays (~130 bytes per point) are kept per host thread between calls: allocating and first touching 15 MB
+// per frame pair costs about a millisecond of page faults, a quarter of what the rest of the function takes.
+struct Scratch {
+    std::vector<int> start, adj, fill, pred, queue, par, top, left, right, count, first, leafOrder, relabel, bfs, sub;
+    std::vector<Edge> edges, tmp;
+    std::vector<double> dist;
+    std::vector<Row> rows;
+};
+
 }  // namespace
 
 extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_edge_b, const double *h_edge_w,
@@ -52,20 +66,26 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
             return ICPFLOW_E_ARG;
 
     // 1. orientation away from point 0
-    std::vector<int> start(n + 1, 0), adj(2 * (size_t)m);
+    static thread_local Scratch S;
+    std::vector<int> &start = S.start, &adj = S.adj;
+    start.assign(n + 1, 0);
+    adj.resize(2 * (size_t)m);
     for (int e = 0; e < m; ++e) {
         ++start[h_edge_a[e] + 1];
         ++start[h_edge_b[e] + 1];
     }
     for (int i = 0; i < n; ++i) start[i + 1] += start[i];
     {
-        std::vector<int> fill(start.begin(), start.end() - 1);
+        std::vector<int> &fill = S.fill;
+        fill.assign(start.begin(), start.end() - 1);
         for (int e = 0; e < m; ++e) {
             adj[fill[h_edge_a[e]]++] = h_edge_b[e];
             adj[fill[h_edge_b[e]]++] = h_edge_a[e];
         }
     }
-    std::vector<int> pred(n, -1), queue;
+    std::vector<int> &pred = S.pred, &queue = S.queue;
+    pred.assign(n, -1);
+    queue.clear();
     queue.reserve(n);
     queue.push_back(0);
     pred[0] = 0;
@@ -78,23 +98,33 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
             }
     }
     if ((int)queue.size() != n) return ICPFLOW_E_ARG;   // the edges do not span the points
-    struct Edge {
-        double w;
-        int cur, nxt;
-    };
-    std::vector<Edge> edges(m);
+    std::vector<Edge> &edges = S.edges;
+    edges.resize(m);
     for (int e = 0; e < m; ++e) {
         const bool aIsChild = pred[h_edge_a[e]] == h_edge_b[e];
         edges[e] = Edge{h_edge_w[e], aIsChild ? h_edge_b[e] : h_edge_a[e], aIsChild ? h_edge_a[e] : h_edge_b[e]};
     }
     const auto byEnds = [](const Edge &x, const Edge &y) { return x.cur != y.cur ? x.cur < y.cur : x.nxt < y.nxt; };
     bool plain = true;   // non-negative weights order like their bit patterns: radix sort, then order the ties
+    bool ascending = true;   // the caller may have sorted by weight already (the GPU does it in passing)
     for (int e = 0; e < m; ++e) {
         if (std::isnan(edges[e].w)) return ICPFLOW_E_ARG;
         plain = plain && !std::signbit(edges[e].w);
+        ascending = ascending && (e == 0 || edges[e - 1].w <= edges[e].w);
     }
-    if (plain) {
-        std::vector<Edge> tmp(m);
+    const auto order_ties = [&]() {
+        for (int i = 0; i < m;) {
+            int k = i + 1;
+            while (k < m && edges[k].w == edges[i].w) ++k;
+            if (k - i > 1) std::sort(edges.begin() + i, edges.begin() + k, byEnds);
+            i = k;
+        }
+    };
+    if (ascending) {
+        order_ties();
+    } else if (plain) {
+        std::vector<Edge> &tmp = S.tmp;
+        tmp.resize(m);
         std::vector<uint32_t> hist(1 << 16);
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 16 * pass;
@@ -114,63 +144,70 @@ extern "C" int icpflow_hdbscan_labels(const int32_t *h_edge_a, const int32_t *h_
             for (const Edge &x : edges) tmp[hist[digit(x)]++] = x;
             edges.swap(tmp);
         }
-        for (int i = 0; i < m;) {
-            int k = i + 1;
-            while (k < m && edges[k].w == edges[i].w) ++k;
-            if (k - i > 1) std::sort(edges.begin() + i, edges.begin() + k, byEnds);
-            i = k;
-        }
+        order_ties();
     } else {
         std::sort(edges.begin(), edges.end(),
                   [&](const Edge &x, const Edge &y) { return x.w != y.w ? x.w < y.w : byEnds(x, y); });
     }
 
     // 2. single linkage: node n + i = i-th merge
+    // (union-find over the POINTS, by size, with path halving; top[root] = the dendrogram node of that component:
+    // the same merges as a union-find over the dendrogram nodes, along much shorter paths)
     const int nodes = 2 * n - 1, root = 2 * n - 2;
-    std::vector<int> up(nodes), left(m), right(m), count(nodes, 1);
-    std::vector<double> dist(m);
-    std::iota(up.begin(), up.end(), 0);
+    std::vector<int> &par = S.par, &top = S.top, &left = S.left, &right = S.right, &count = S.count;
+    std::vector<double> &dist = S.dist;
+    par.resize(n); top.resize(n); left.resize(m); right.resize(m); dist.resize(m);
+    count.assign(nodes, 1);
+    std::iota(par.begin(), par.end(), 0);
+    std::iota(top.begin(), top.end(), 0);
     auto find = [&](int x) {
-        int r = x;
-        while (up[r] != r) r = up[r];
-        while (up[x] != r) {
-            const int t = up[x];
-            up[x] = r;
-            x = t;
+        while (par[x] != x) {
+            par[x] = par[par[x]];
+            x = par[x];
         }
-        return r;
+        return x;
     };
     for (int i = 0; i < m; ++i) {
-        const int l = find(edges[i].cur), r = find(edges[i].nxt);
+        int ra = find(edges[i].cur), rb = find(edges[i].nxt);
+        const int l = top[ra], r = top[rb];
         left[i] = l;
         right[i] = r;
         dist[i] = edges[i].w;
         count[n + i] = count[l] + count[r];
-        up[l] = up[r] = n + i;
+        if (count[l] < count[r]) std::swap(ra, rb);
+        par[rb] = ra;
+        top[ra] = n + i;
     }
 
     // 3. condensed tree
-    std::vector<Row> rows;
+    std::vector<Row> &rows = S.rows;
+    rows.clear();
     rows.reserve((size_t)n + 64);
-    std::vector<int> relabel(nodes, -1), bfs, sub;
+    // the points below a dendrogram node, as a contiguous range of one depth-first leaf order (parents carry larger
+    // ids than their children: one pass from the root down hands every node its range)
+    std::vector<int> &first = S.first, &leafOrder = S.leafOrder;
+    first.resize(nodes); leafOrder.resize(n);
+    first[root] = 0;
+    for (int v = root; v >= n; --v) {
+        first[left[v - n]] = first[v];
+        first[right[v - n]] = first[v] + count[left[v - n]];
+    }
+    for (int v = 0; v < n; ++v) leafOrder[first[v]] = v;
+    std::vector<int> &relabel = S.relabel, &bfs = S.bfs, &sub = S.sub;
+    relabel.assign(nodes, -1);
+    bfs.clear();
+    sub.clear();
     // breadth first over the dendrogram, but only through nodes that are still part of a cluster: a side that
     // falls out is walked once, by fall_out (the order of the surviving nodes is that of the full walk)
     bfs.reserve(nodes);
     bfs.push_back(root);
     relabel[root] = n;
     int nextLabel = n + 1;
-    auto fall_out = [&](int top, int parentLabel, double lambda) {   // every point below `top` leaves the parent
-        sub.clear();
-        sub.push_back(top);
-        for (size_t head = 0; head < sub.size(); ++head) {
-            const int v = sub[head];
-            if (v >= n) {
-                sub.push_back(left[v - n]);
-                sub.push_back(right[v - n]);
-            } else {
-                rows.push_back(Row{parentLabel, v, lambda, 1});
-            }
-        }
+    // every point below `node` leaves the parent (all these rows carry the same lambda, so their order among
+    // themselves does not touch the stability sums)
+    auto fall_out = [&](int node, int parentLabel, double lambda) {
+        const int f = first[node], c = count[node];
+        for (int k = f; k < f + c; ++k) rows.push_back(Row{parentLabel, leafOrder[k], lambda, 1});
     };
     for (size_t head = 0; head < bfs.size(); ++head) {
         const int v = bfs[head];

@@ -177,11 +177,14 @@ def hdbscan(points, min_cluster_size, min_samples=None, mask=None, cell=0.25, co
     nl = t["n_live"]
     if nl < max(k, 2):
         raise ValueError(f"hdbscan: {nl} points cannot be clustered with min_samples {k}")
-    a, b = t["a"].cpu().numpy(), t["b"].cpu().numpy()
+    # the edges leave the GPU in ascending weight (a device sort costs microseconds, the host's radix passes were a
+    # fifth of its share); ties are put in their fixed order by the host code either way
+    order = torch.argsort(t["w2"])
+    a, b = t["a"][order].cpu().numpy(), t["b"][order].cpu().numpy()
     if nl != n:                                                     # caller row -> row of the clustered subset
         sub = np.cumsum(live_h) - 1
         a, b = sub[a], sub[b]
-    lab = labels_from_mst(a, b, np.sqrt(t["w2"].cpu().numpy()), nl, min_cluster_size)
+    lab = labels_from_mst(a, b, np.sqrt(t["w2"][order].cpu().numpy()), nl, min_cluster_size)
     out = np.full(n, -1, dtype=np.int64)
     out[live_h] = lab
     if mask is not None:
@@ -196,7 +199,9 @@ def cluster_hdbscan(args, points, mask=None):
     _, resident = _device_points(points)
     lab = hdbscan(points, args.min_cluster_size, None, mask)
     keep = lab >= -1
-    lbls, counts = np.unique(lab[keep], return_counts=True)
+    hist = np.bincount(lab[keep] + 1)                               # == np.unique(lab[keep], return_counts=True) without
+    lbls = np.flatnonzero(hist) - 1                                  # the sort of 10^5 labels: values, ascending, and
+    counts = hist[lbls + 1]                                          # their counts
     cluster_info = np.array(list(zip(lbls[1:], counts[1:])))
     cluster_info = cluster_info[cluster_info[:, 1].argsort()]
     clusters_labels = cluster_info[::-1][:args.num_clusters, 0]
