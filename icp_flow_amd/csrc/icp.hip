@@ -92,6 +92,7 @@ struct IcpParams {
     const float *initR;      // [B,3,3] / [B,3]: the state before the first iteration (init_transform), NULL = identity
     const float *initT;
     int allowReflection;     // R = U V^T whatever its determinant (:354-362 with E = I)
+    int halfCu;              // launch policy: 512-thread workgroups, two per CU (see launch_icp_iters)
     int x0Cache;             // the records are followed by the queries' own points (12 B each): no L2 round trip per iteration
     int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
                              // certificates, see the search phase); a workgroup whose share of the queries fits uses them
@@ -386,8 +387,10 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
 // GRID: 0 = all-pairs LDS scan, 1 = exact grid read from global memory (L2), 2 = exact grid staged
 // into LDS at kernel entry (dynamic shared memory: (H+1) ints + n float4), 3 = sorted sweep
 // (targets streamed through scalar loads, no LDS image)
+// (512-thread workgroups are compiled for four waves per SIMD, 128 VGPRs, so that two of them share a CU)
 template <int BLOCK, int Q, int TS, int GRID, bool TEAM>
-__global__ __launch_bounds__(BLOCK) void icp_kernel(IcpParams p, int itBegin, int itEnd)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 512 ? 4 : 1)))
+void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
     ICPFLOW_STAMP(0);
     static_assert(GRID == 0 || TS == 1, "grid / sweep searches do not split targets over waves");
@@ -1595,6 +1598,9 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
         // 1024 threads (4 waves per SIMD, 128 VGPRs: the kernel fits but for three pointers spilled once
         // outside the loop) take a 1024-point cloud in one pass; up to 768 points 12 waves (170 VGPRs) do
         else if (p.N <= 768) launch_icp_variant<768, 1, 1, 4>(p, B, itBegin, itEnd, s);
+        // batches larger than the GPU, clouds whose image and records fit half a CU's LDS: two 512-thread workgroups
+        // per CU, so that one pair's serial tail (one wave) runs under the other pair's search phase
+        else if (p.halfCu) launch_icp_variant<512, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.N <= 12288) launch_icp_variant<1024, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else launch_icp_variant<768, 1, 1, 3>(p, B, itBegin, itEnd, s);   // (the scalar-load sweep spills at 1024 threads)
     } else if (p.gridPts != nullptr) {  // exact grid search; grid in LDS while it fits 48 KiB (N <= 2048)
@@ -1693,6 +1699,21 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
             p.recCap = N;
         }
         p.x0Cache = p.recCap > 0 && img + (size_t)p.recCap * 32 <= room;
+        // two workgroups per CU when the batch does not fit the GPU anyway: 76 KiB of dynamic LDS each
+        const size_t half = 76 * 1024;
+#ifndef ICPFLOW_HALF_CU_MIN_N
+#define ICPFLOW_HALF_CU_MIN_N 768
+#endif
+        // (measured +7 to +14 % at 512 ... 2048 pairs x 1024 points and 1024 x 1500 / 2048; -4 % at 300 x 1024 and -5 % at
+        // 600 x 2048, where half-size workgroups run alone on their CUs or the last, partial round runs on a mostly empty
+        // GPU: at least two pairs per CU, and weigh the two ways of filling the GPU)
+        const double fillHalf = (double)B / ((double)((B + 2 * cus - 1) / (2 * cus)) * 2 * cus);
+        const double fillFull = (double)B / ((double)((B + cus - 1) / cus) * cus);
+        if (p.team.wgPair == nullptr && B >= 2 * cus && N > ICPFLOW_HALF_CU_MIN_N && img + (size_t)p.recCap * 20 <= half &&
+            1.1 * fillHalf > fillFull) {
+            p.halfCu = 1;
+            p.x0Cache = img + (size_t)p.recCap * 32 <= half;
+        }
     }
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {
         // Batch-global stop rule.  ONE launch runs every pair through all iterations speculatively,
