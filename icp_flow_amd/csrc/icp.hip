@@ -389,7 +389,7 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
 // (targets streamed through scalar loads, no LDS image)
 // (512-thread workgroups are compiled for four waves per SIMD, 128 VGPRs, so that two of them share a CU)
 template <int BLOCK, int Q, int TS, int GRID, bool TEAM>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 512 ? 4 : 1)))
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK == 512 && GRID == 4) ? 4 : 1)))
 void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
     ICPFLOW_STAMP(0);
@@ -1575,6 +1575,9 @@ void ensure_dynamic_lds(const void *func, int bytes, std::atomic<unsigned long l
     if (hipGetDevice(&dev) != hipSuccess) return;
     const unsigned long long bit = 1ull << (dev & 63);
     if (dev < 64 && (mask->load(std::memory_order_acquire) & bit)) return;
+    // never more than the CU's 160 KiB less the kernel's static LDS (the request fails as a whole otherwise)
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, func) == hipSuccess) bytes = min(bytes, 160 * 1024 - (int)fa.sharedSizeBytes);
     (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (dev < 64) mask->fetch_or(bit, std::memory_order_release);
 }
@@ -1688,32 +1691,36 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.team.maxWG = min(cus, team->maxWG);
         hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, p.team);
     }
-    if (recWanted && p.sortY != nullptr) {
+    if (p.sortY != nullptr) {
         // room for the per-query records behind the LDS image: every query of a pair when one workgroup serves it,
         // the member's own share of the queries in a team (the image of a 10^4-point cloud leaves room for ~1800)
         const size_t img = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
         const size_t room = 152 * 1024;   // dynamic LDS next to the kernel's ~3 KiB of static LDS
+        int recCap = 0;
         if (p.team.wgPair != nullptr) {
-            if (N <= 12288 && img + 64 * 20 <= room) p.recCap = (int)((room - img) / 20 / 64 * 64);
+            if (N <= 12288 && img + 64 * 20 <= room) recCap = (int)((room - img) / 20 / 64 * 64);
         } else if (N <= kRecMaxN) {
-            p.recCap = N;
+            recCap = N;
         }
-        p.x0Cache = p.recCap > 0 && img + (size_t)p.recCap * 32 <= room;
-        // two workgroups per CU when the batch does not fit the GPU anyway: 76 KiB of dynamic LDS each
-        const size_t half = 76 * 1024;
+        bool x0Cache = recCap > 0 && img + (size_t)recCap * 32 <= room;
+        // Batches of at least two pairs per CU: 512-thread workgroups (compiled for 128 VGPRs), two per CU, so that one
+        // pair's serial tail (one wave) runs under the other pair's search phase.  Measured +7 to +14 % at 512 ... 2048
+        // pairs x 1024 points and 1024 x 1500 / 2048; -4 % at 300 x 1024 and -5 % at 600 x 2048, where half-size
+        // workgroups run alone on their CUs or the last, partial round runs on a mostly empty GPU: hence two pairs per
+        // CU at least, and the two ways of filling the GPU weighed.  (Decided on the shape alone, not on whether the
+        // records are switched on: the moment sums follow the workgroup's shape.)
+        const size_t half = 76 * 1024;   // (+ 2.2 KiB of static LDS each)
 #ifndef ICPFLOW_HALF_CU_MIN_N
 #define ICPFLOW_HALF_CU_MIN_N 768
 #endif
-        // (measured +7 to +14 % at 512 ... 2048 pairs x 1024 points and 1024 x 1500 / 2048; -4 % at 300 x 1024 and -5 % at
-        // 600 x 2048, where half-size workgroups run alone on their CUs or the last, partial round runs on a mostly empty
-        // GPU: at least two pairs per CU, and weigh the two ways of filling the GPU)
         const double fillHalf = (double)B / ((double)((B + 2 * cus - 1) / (2 * cus)) * 2 * cus);
         const double fillFull = (double)B / ((double)((B + cus - 1) / cus) * cus);
-        if (p.team.wgPair == nullptr && B >= 2 * cus && N > ICPFLOW_HALF_CU_MIN_N && img + (size_t)p.recCap * 20 <= half &&
+        if (p.team.wgPair == nullptr && B >= 2 * cus && N > ICPFLOW_HALF_CU_MIN_N && img + (size_t)recCap * 20 <= half &&
             1.1 * fillHalf > fillFull) {
             p.halfCu = 1;
-            p.x0Cache = img + (size_t)p.recCap * 32 <= half;
+            x0Cache = img + (size_t)recCap * 32 <= half;
         }
+        if (recWanted) { p.recCap = recCap; p.x0Cache = x0Cache ? 1 : 0; }
     }
     if (stopMode == ICPFLOW_STOP_REFERENCE_) {
         // Batch-global stop rule.  ONE launch runs every pair through all iterations speculatively,
