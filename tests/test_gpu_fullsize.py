@@ -240,6 +240,12 @@ def test_certificates_on_adversarial_clouds_change_nothing():
         with _lib.options(no_adaptive_windows=True):
             T0 = utils_match.hist_icp(a, s, d)
         assert torch.equal(T0, utils_match.hist_icp(a, s, d))
+    # more than 128 iterations: one launch per iteration (the records do not outlive a launch: every launch scans)
+    with _lib.options(no_adaptive_windows=True):
+        a0 = utils_icp_pytorch3d.iterative_closest_point(s[:24], d[:24], max_iterations=140)
+        R0, n0 = a0.RTs.R.clone(), a0.converged.iterations
+    a1 = utils_icp_pytorch3d.iterative_closest_point(s[:24], d[:24], max_iterations=140)
+    assert a1.converged.iterations == n0 and torch.equal(a1.RTs.R, R0)
 
 
 # ------------------------------------------------------------------------------------------ fused vote bins
