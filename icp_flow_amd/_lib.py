@@ -90,7 +90,8 @@ class Options(ctypes.Structure):
     """icpflow_options_t: the per-call options of the fused entry points."""
     _fields_ = [("struct_size", _sz), ("icp_search", _i), ("icp_arith", _i), ("flags", ctypes.c_uint),
                 ("profile", _p), ("d_vote_bins_u32", _p), ("d_icp_init_R", _p), ("d_icp_init_T", _p),
-                ("d_icp_history", _p), ("icp_allow_reflection", _i)]
+                ("d_icp_history", _p), ("icp_allow_reflection", _i), ("icp_estimate_scale", _i),
+                ("d_icp_scale", _p), ("d_icp_init_s", _p)]
 
 
 class Profile:
@@ -132,12 +133,13 @@ _DEFAULT_FLAGS = _env_default_flags()
 
 def _current():
     return getattr(_tls, "stack", None) or [dict(search=0, arith=0, flags=_DEFAULT_FLAGS, profile=None, vote_bins=None,
-                                                 icp_init=None, icp_history=None, icp_allow_reflection=False)]
+                                                 icp_init=None, icp_history=None, icp_allow_reflection=False,
+                                                 icp_scale=None)]
 
 
 @contextlib.contextmanager
 def options(search=None, arith=None, profile=None, vote_bins=None, icp_init=None, icp_history=None,
-            icp_allow_reflection=None, **switches):
+            icp_allow_reflection=None, icp_scale=None, **switches):
     """Per-call options for every wrapper invoked inside the `with` block on this thread.
     search: 'auto' | 'scan' | 'grid' | 'sweep';  arith: 'fp64' | 'fp32_reference';  profile: a Profile;
     vote_bins: uint32 device tensor [B, Lx*Ly*Lz] receiving the fused vote's bins;  switches: no_teams=True ..."""
@@ -156,6 +158,8 @@ def options(search=None, arith=None, profile=None, vote_bins=None, icp_init=None
         cur["icp_history"] = icp_history
     if icp_allow_reflection is not None:
         cur["icp_allow_reflection"] = bool(icp_allow_reflection)
+    if icp_scale is not None:       # float32 [B] device tensor: estimate_scale of icpflow_icp, receives s
+        cur["icp_scale"] = icp_scale
     for k, v in switches.items():
         cur["flags"] = (cur["flags"] | OPT_FLAGS[k]) if v else (cur["flags"] & ~OPT_FLAGS[k])
     stack = getattr(_tls, "stack", None)
@@ -173,14 +177,15 @@ def opt():
     cur = _current()[-1]
     if (cur["search"] == 0 and cur["arith"] == 0 and cur["flags"] == 0 and cur["profile"] is None
             and cur["vote_bins"] is None and cur["icp_init"] is None and cur["icp_history"] is None
-            and not cur["icp_allow_reflection"]):
+            and not cur["icp_allow_reflection"] and cur["icp_scale"] is None):
         return None
     dp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
     o = Options(ctypes.sizeof(Options), int(cur["search"]), int(cur["arith"]), int(cur["flags"]),
                 cur["profile"]._h if cur["profile"] is not None else None, dp(cur["vote_bins"]),
                 dp(cur["icp_init"][0] if cur["icp_init"] is not None else None),
                 dp(cur["icp_init"][1] if cur["icp_init"] is not None else None), dp(cur["icp_history"]),
-                1 if cur["icp_allow_reflection"] else 0)
+                1 if cur["icp_allow_reflection"] else 0, 1 if cur["icp_scale"] is not None else 0, dp(cur["icp_scale"]),
+                dp(cur["icp_init"][2] if cur["icp_init"] is not None and len(cur["icp_init"]) > 2 else None))
     _tls.last = o          # keep the struct alive until this thread builds the next one
     return ctypes.cast(ctypes.pointer(o), _p)
 

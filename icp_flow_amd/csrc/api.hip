@@ -45,6 +45,9 @@ struct Opts {
     const float *initR = nullptr, *initT = nullptr;
     float *history = nullptr;
     bool allowReflection = false;
+    bool estimateScale = false;
+    float *scaleOut = nullptr;
+    const float *initS = nullptr;
     bool on(unsigned offFlag) const { return (flags & offFlag) == 0u; }
     IcpOpts icp(float *scratch) const
     {
@@ -181,6 +184,11 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
     o.initT = opt->d_icp_init_T;
     o.history = opt->d_icp_history;
     o.allowReflection = opt->icp_allow_reflection != 0;
+    o.estimateScale = opt->icp_estimate_scale != 0;
+    o.scaleOut = opt->d_icp_scale;
+    o.initS = opt->d_icp_init_s;
+    if (o.initS != nullptr && o.initR == nullptr)
+        return fail(ICPFLOW_E_ARG, "%s: options.d_icp_init_s comes with d_icp_init_R / d_icp_init_T", fn);
     return 0;
 }
 
@@ -612,8 +620,10 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     io.initR = o.initR;
     io.initT = o.initT;
     io.allowReflection = o.allowReflection;
-    if (o.allowReflection && o.arith != ICPFLOW_ARITH_FP64)
-        return fail(ICPFLOW_E_ARG, "icpflow_icp: allow_reflection is not built for ICPFLOW_ARITH_FP32_REFERENCE");
+    io.estimateScale = o.estimateScale;
+    io.initS = o.initS;
+    if ((o.allowReflection || o.estimateScale) && o.arith != ICPFLOW_ARITH_FP64)
+        return fail(ICPFLOW_E_ARG, "icpflow_icp: allow_reflection / estimate_scale are not built for ICPFLOW_ARITH_FP32_REFERENCE");
     if (o.history != nullptr &&
         !(stop_mode == ICPFLOW_STOP_REFERENCE && max_iterations > 1 && max_iterations <= kHistIters &&
           o.arith == ICPFLOW_ARITH_FP64 && io.speculative))
@@ -621,13 +631,17 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
                                    "(2 <= max_iterations <= %d, fp64 arithmetic)", kHistIters);
     if (o.initR != nullptr && o.arith != ICPFLOW_ARITH_FP64)
         return fail(ICPFLOW_E_ARG, "icpflow_icp: an initial transform is not built for ICPFLOW_ARITH_FP32_REFERENCE");
+    const GridScratch *search = search_scratch(w, N, o);
+    if ((o.estimateScale || o.initS != nullptr) && (search == nullptr || search->mode != 3))
+        return fail(ICPFLOW_E_ARG, "icpflow_icp: estimate_scale / an initial transform with a scale need the sorted-sweep "
+                                   "search (the default for 64 <= N <= %d)", kMaxSortN);
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
-                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search_scratch(w, N, o), w.history, &w.team,
+                           relative_rmse_thr, stop_mode, w.state, w.ctrl, search, w.history, &w.team,
                            io, s));
     if (o.history != nullptr)   // t_history: the per-iteration records of the speculative launch
         ICPFLOW_TRY(hipMemcpyAsync(o.history, w.history, (size_t)max_iterations * B * kHistStride * sizeof(float),
                                    hipMemcpyDeviceToDevice, s));
-    ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s));
+    ICPFLOW_TRY(launch_icp_export(w.state, w.ctrl, B, stop_mode, d_R, d_T, d_rmse, d_iters, d_converged, s, o.scaleOut));
     return 0;
 }
 

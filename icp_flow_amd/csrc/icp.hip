@@ -92,6 +92,8 @@ struct IcpParams {
     const float *initR;      // [B,3,3] / [B,3]: the state before the first iteration (init_transform), NULL = identity
     const float *initT;
     int allowReflection;     // R = U V^T whatever its determinant (:354-362 with E = I)
+    int estimateScale;       // s = trace(E S) / Xcov (:364-374), Xt = s X R + T
+    const float *initS;      // [B] scale of the initial transform, NULL = 1
     int halfCu;              // launch policy: 512-thread workgroups, two per CU (see launch_icp_iters)
     int x0Cache;             // the records are followed by the queries' own points (12 B each): no L2 round trip per iteration
     int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
@@ -388,7 +390,9 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
 // into LDS at kernel entry (dynamic shared memory: (H+1) ints + n float4), 3 = sorted sweep
 // (targets streamed through scalar loads, no LDS image)
 // (512-thread workgroups are compiled for four waves per SIMD, 128 VGPRs, so that two of them share a CU)
-template <int BLOCK, int Q, int TS, int GRID, bool TEAM>
+// SCALE: similarity transforms (estimate_scale, or an initial transform with a scale; sorted-sweep kernels only): the
+// plain kernels do not carry the extra multiplications.
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK == 512 && GRID == 4) ? 4 : 1)))
 void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
@@ -454,19 +458,21 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         float s0 = (tid < 9 && tid % 4 == 0) ? 1.f : 0.f;
         if (p.initR != nullptr && tid < 12) s0 = tid < 9 ? p.initR[(size_t)b * 9 + tid] : p.initT[(size_t)b * 3 + tid - 9];
         if (tid < 12) bcast[tid] = s0;
-        if (tid == 0) { bcast[12] = 1.f; bcast[13] = 0.f; bcast[14] = 0.f; }
-        if (tid < 16) ring[tid] = tid < 12 ? s0 : 0.f;
+        const float scale0 = p.initS != nullptr ? p.initS[b] : 1.f;
+        if (tid == 0) { bcast[12] = 1.f; bcast[13] = 0.f; bcast[14] = 0.f; bcast[15] = scale0; }
+        if (tid < 16) ring[tid] = tid < 12 ? s0 : (tid == 14 ? scale0 : 0.f);
         if (tid < kWave) {   // and its hash (same formula as in the loop), every lane of wave 0 the same value
             int hash = 0;
 #pragma unroll
             for (int k = 0; k < 12; ++k) hash ^= state_hash_word(__shfl(s0, k, kWave), k);
+            hash ^= state_hash_word(scale0, 12);
             if (tid == 13) ring[13] = __int_as_float(hash);
         }
     } else {
         if (tid < 9) bcast[tid] = st->R[tid];
         if (tid < 3) bcast[9 + tid] = st->T[tid];
         active = st->active;
-        if (tid == 0) { bcast[12] = active ? 1.f : 0.f; bcast[13] = st->rmse; bcast[14] = st->rmse; }
+        if (tid == 0) { bcast[12] = active ? 1.f : 0.f; bcast[13] = st->rmse; bcast[14] = st->rmse; bcast[15] = st->s; }
     }
     int itersDone = (itBegin == 0) ? 0 : st->iters;
 
@@ -545,6 +551,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         for (int k = 0; k < 9; ++k) Rf[k] = bcast[k];
         Tf[0] = bcast[9]; Tf[1] = bcast[10]; Tf[2] = bcast[11];
         const float ox = bcast[16], oy = bcast[17], oz = bcast[18];
+        const float sc = SCALE ? bcast[15] : 1.f;   // scale of this iteration's transform (SCALE: estimate_scale / a scaled init)
         double macc[kMoments];  // wave-uniform running totals of this wave's query slots
 #pragma unroll
         for (int k = 0; k < kMoments; ++k) macc[k] = 0.0;
@@ -642,9 +649,11 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                         }
                         if (x0On) { x0c[i] = x0x[q]; x0c[p.recCap + i] = x0y[q]; x0c[2 * p.recCap + i] = x0z[q]; }
                         }
-                        qx[q] = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0])) + Tf[0];  // :177, :395
-                        qy[q] = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1])) + Tf[1];
-                        qz[q] = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2])) + Tf[2];
+                        float rx = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0]));  // :177, :395
+                        float ry = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1]));
+                        float rz = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2]));
+                        if constexpr (SCALE) { rx *= sc; ry *= sc; rz *= sc; }   // (similarity transforms only)
+                        qx[q] = rx + Tf[0]; qy[q] = ry + Tf[1]; qz[q] = rz + Tf[2];
                         float m = p.sweepMargin;
                         if (recOn) {
                             m = certMargin;   // first iteration: nothing known
@@ -1152,7 +1161,14 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                     for (int k = 0; k < 9; ++k) ksh[8 + k] = -ksh[8 + k];   // (every lane writes the same values)
                 }
             }
-            if (!horn_rotation(ksh + 8, ksh[6] + ksh[7], Nsh, lane, Rd)) rank1_rotation(ksh + 8, Rd);
+            double lam = 0.0;   // trace(E S): the scale's numerator (:364-366)
+            if (!horn_rotation(ksh + 8, ksh[6] + ksh[7], Nsh, lane, Rd, &lam)) {
+                rank1_rotation(ksh + 8, Rd);
+                double f2 = 0.0;   // rank <= 1: the one singular value is the Frobenius norm
+#pragma unroll
+                for (int k = 0; k < 9; ++k) f2 = fma(ksh[8 + k], ksh[8 + k], f2);
+                lam = sqrt(f2);
+            }
             if (mirror) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) { Rd[k] = -Rd[k]; ksh[8 + k] = -ksh[8 + k]; }
@@ -1162,18 +1178,31 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
             const double o0 = (double)bcast[16], o1 = (double)bcast[17], o2 = (double)bcast[18];
             const double mux[3] = {o0 + ksh[0], o1 + ksh[1], o2 + ksh[2]};
             const double muy[3] = {o0 + ksh[3], o1 + ksh[4], o2 + ksh[5]};
-            const double Td0 = muy[0] - fma(mux[2], Rd[6], fma(mux[1], Rd[3], mux[0] * Rd[0]));
-            const double Td1 = muy[1] - fma(mux[2], Rd[7], fma(mux[1], Rd[4], mux[0] * Rd[1]));
-            const double Td2 = muy[2] - fma(mux[2], Rd[8], fma(mux[1], Rd[5], mux[0] * Rd[2]));
+            // s = trace(E S) / clamp(Xcov, eps), :364-374 (1 otherwise: every product below is then exact)
+            double sd = 1.0;
+            double mR0 = fma(mux[2], Rd[6], fma(mux[1], Rd[3], mux[0] * Rd[0]));
+            double mR1 = fma(mux[2], Rd[7], fma(mux[1], Rd[4], mux[0] * Rd[1]));
+            double mR2 = fma(mux[2], Rd[8], fma(mux[1], Rd[5], mux[0] * Rd[2]));
+            if constexpr (SCALE) {
+                if (p.estimateScale) {
+                    sd = lam / (ksh[6] > 1e-9 ? ksh[6] : 1e-9);
+                    mR0 *= sd; mR1 *= sd; mR2 *= sd;
+                }
+            }
+            const double Td0 = muy[0] - mR0, Td1 = muy[1] - mR1, Td2 = muy[2] - mR2;
             // rmse^2 = (Sxx_c + Syy_c)/W - 2 sum_ij R_ij H_ij, :191-192
             double rh = 0.0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) rh = fma(Rd[k], ksh[8 + k], rh);
-            const double ms = ksh[6] + ksh[7] - 2.0 * rh;
+            double ms = ksh[6] + ksh[7] - 2.0 * rh;                        // sum w |s x R + T - y|^2 / W
+            if constexpr (SCALE) {
+                if (p.estimateScale) ms = sd * sd * ksh[6] + ksh[7] - 2.0 * sd * rh;
+            }
             float Rn[9], Tn[3];   // the new state
 #pragma unroll
             for (int k = 0; k < 9; ++k) Rn[k] = (float)Rd[k];
             Tn[0] = (float)Td0; Tn[1] = (float)Td1; Tn[2] = (float)Td2;
+            const float sn = SCALE ? (float)sd : 1.f;
             const float rmse = (float)sqrt(ms > 0.0 ? ms : 0.0);
             ICPFLOW_STAMP(15);
             const float prev = bcast[14];
@@ -1189,7 +1218,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                     float *h = p.history + ((size_t)it * p.B + b) * kHistStride;
 #pragma unroll
                     for (int k = 0; k < 9; ++k) h[k] = Rn[k];
-                    h[9] = Tn[0]; h[10] = Tn[1]; h[11] = Tn[2]; h[12] = rmse;
+                    h[9] = Tn[0]; h[10] = Tn[1]; h[11] = Tn[2]; h[12] = rmse; h[13] = sn;
                     __hip_atomic_fetch_add(&ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1220,6 +1249,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                     for (int k = 0; k < 9; ++k) hash ^= state_hash_word(Rn[k], k);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) hash ^= state_hash_word(Tn[k], 9 + k);
+                    hash ^= state_hash_word(sn, 12);
                     const int kk = lane + 1;   // lane l < kRing looks at state newest - (l + 1)
                     const bool cand = lane < kRing && kk <= newest - itBegin &&
                                       __float_as_int(ring[((newest - kk) % kRing) * 16 + 13]) == hash;
@@ -1229,13 +1259,13 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                         const int wd = lane & 15;
 #pragma unroll
                         for (int k = 0; k < 9; ++k) cur16 = (wd == k) ? Rn[k] : cur16;
-                        cur16 = (wd == 9) ? Tn[0] : (wd == 10) ? Tn[1] : (wd == 11) ? Tn[2] : cur16;
+                        cur16 = (wd == 9) ? Tn[0] : (wd == 10) ? Tn[1] : (wd == 11) ? Tn[2] : (wd == 14) ? sn : cur16;
                     }
                     for (int k0 = 1; anyCand && k0 <= kRing && period == 0; k0 += 4) {
                         const int k = k0 + (lane >> 4);
                         const bool valid = k <= kRing && k <= newest - itBegin;
                         const float old = ring[(((newest - (valid ? k : 0)) % kRing + kRing) % kRing) * 16 + (lane & 15)];
-                        const bool same = (lane & 15) >= 12 || __float_as_int(old) == __float_as_int(cur16);
+                        const bool same = ((lane & 15) >= 12 && (lane & 15) != 14) || __float_as_int(old) == __float_as_int(cur16);
                         const unsigned long long m = __ballot(same);
 #pragma unroll
                         for (int q = 3; q >= 0; --q) {
@@ -1248,7 +1278,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                         float *rw = ring + (newest % kRing) * 16;
 #pragma unroll
                         for (int k = 0; k < 9; ++k) rw[k] = Rn[k];
-                        rw[9] = Tn[0]; rw[10] = Tn[1]; rw[11] = Tn[2]; rw[12] = rmse; rw[13] = __int_as_float(hash);
+                        rw[9] = Tn[0]; rw[10] = Tn[1]; rw[11] = Tn[2]; rw[12] = rmse; rw[13] = __int_as_float(hash); rw[14] = sn;
                     }
                 }
                 if (period > 0 && active) {
@@ -1266,6 +1296,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                                 float *h = p.history + ((size_t)k * p.B + b) * kHistStride;
                                 for (int c = 0; c < 12; ++c) h[c] = rj[c];
                                 h[12] = rm;
+                                h[13] = rj[14];
                                 const float relk = (rmPrev - rm) / rmPrev;
                                 const bool convk = relk <= p.relThr;
                                 __hip_atomic_fetch_add(&ctrl->tally[k], 1ull | (convk ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
@@ -1290,6 +1321,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                 bcast[9] = Tn[0]; bcast[10] = Tn[1]; bcast[11] = Tn[2];
                 bcast[12] = active ? 1.f : 0.f;
                 bcast[14] = rmse;  // :213 prev_rmse = rmse
+                bcast[15] = sn;
             }
             }  // !teamStop
         }
@@ -1316,6 +1348,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
 #pragma unroll
         for (int k = 0; k < 3; ++k) st->T[k] = bcast[9 + k];
         st->rmse = bcast[14];
+        st->s = bcast[15];
         st->active = active;
         st->iters = itersDone;
         if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
@@ -1343,6 +1376,7 @@ __global__ void icp_resolve_history_kernel(IcpState *__restrict__ st, IcpCtrl *_
     for (int k = 0; k < 9; ++k) st[b].R[k] = h[k];
     for (int k = 0; k < 3; ++k) st[b].T[k] = h[9 + k];
     st[b].rmse = h[12];
+    st[b].s = h[13];
 #ifdef ICPFLOW_DEBUG_EXECUTED
     st[b].rmse = (float)st[b].iters;   // developer builds: iterations this pair actually executed
 #endif
@@ -1366,13 +1400,14 @@ hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const floa
 __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl *__restrict__ ctrl,
                                   int B, int stopMode, float *__restrict__ R, float *__restrict__ T,
                                   float *__restrict__ rmse, int32_t *__restrict__ iters,
-                                  int32_t *__restrict__ converged)
+                                  int32_t *__restrict__ converged, float *__restrict__ scale)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
         if (R) for (int k = 0; k < 9; ++k) R[(size_t)b * 9 + k] = ctrl->error ? __int_as_float(0x7fc00000) : st[b].R[k];
         if (T) for (int k = 0; k < 3; ++k) T[(size_t)b * 3 + k] = st[b].T[k];
         if (rmse) rmse[b] = st[b].rmse;
+        if (scale) scale[b] = st[b].s;
     }
     if (b == 0) {
         const int n = ctrl->iters;
@@ -1450,17 +1485,23 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     }
 }
 
-template <int BLOCK, int Q, int TS, int GRID, bool TEAM = false>
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM = false, bool SCALE = false>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
+    if constexpr (GRID >= 3 && !SCALE) {   // similarity transforms: the sweep kernels' SCALE instantiation
+        if (p.estimateScale != 0 || p.initS != nullptr) {
+            launch_icp_variant<BLOCK, Q, TS, GRID, TEAM, true>(p, B, itBegin, itEnd, s);
+            return;
+        }
+    }
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
                        : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + (size_t)p.recCap * (p.x0Cache ? 32 : 20) : 0;
     if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation and device
         static std::atomic<unsigned long long> raised{0ull};
-        ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM>), 156 * 1024, &raised);
+        ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE>), 156 * 1024, &raised);
     }
     const int wgs = TEAM ? p.team.maxWG : B;
-    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID, TEAM>), dim3(wgs), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
+    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE>), dim3(wgs), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
 }
 
 // ---- optional per-launch timing of this (dominant) kernel with HIP events ---------------------
@@ -1639,6 +1680,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     p.relThr = (float)relThr;
     p.stopMode = stopMode; p.maxIter = maxIter; p.state = state; p.ctrl = ctrl;
     p.initR = opts.initR; p.initT = opts.initT; p.allowReflection = opts.allowReflection ? 1 : 0;
+    p.initS = opts.initS; p.estimateScale = opts.estimateScale ? 1 : 0;
     hipError_t e = hipSuccess;
     bool recWanted = false;   // neighbour certificates (sorted sweep with the LDS image)
     if (opts.historyPending != nullptr) *opts.historyPending = false;
@@ -1767,10 +1809,10 @@ hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t 
 }
 
 hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,
-                             float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s)
+                             float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s, float *scale)
 {
     hipLaunchKernelGGL(icp_export_kernel, dim3((B + 127) / 128), dim3(128), 0, s, state, ctrl, B,
-                       stopMode, R, T, rmse, iters, converged);
+                       stopMode, R, T, rmse, iters, converged, scale);
     return hipGetLastError();
 }
 

@@ -69,7 +69,9 @@ static __device__ __forceinline__ double cofactor16(const double *M, const Minor
 }
 
 // Called by all 64 lanes of ONE wave with wave-uniform arguments; Nsh: 16 doubles of LDS scratch.
-static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, int lane, double (&R)[9])
+// *lamOut: the largest eigenvalue = s1 + s2 + s3 (s3 signed by det H) = trace(E S) of the reference's SVD form.
+static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, int lane, double (&R)[9],
+                                     double *lamOut = nullptr)
 {
     double frob2 = 0.0;
 #pragma unroll
@@ -121,6 +123,7 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
         prevStep = as;
     }
     ICPFLOW_STAMP(14);
+    if (lamOut != nullptr) *lamOut = lam;
     // adjugate of A = N - lam I (symmetric, rank 3): adj = c q q^T, entry (i, j) on lane 4 i + j
     Nsh[0] = n00 - lam; Nsh[5] = n11 - lam; Nsh[10] = n22 - lam; Nsh[15] = n33 - lam;
     const MinorIdx mi = minor_indices(lane);

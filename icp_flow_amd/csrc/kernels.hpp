@@ -25,7 +25,7 @@ struct IcpState {
     float rmse;
     int active;
     int iters;
-    int pad;
+    float s;   // scale (1 unless estimate_scale, utils_icp_pytorch3d.py:364-374)
 };
 
 struct IcpCtrl {
@@ -150,6 +150,8 @@ struct IcpOpts {
     const float *initR = nullptr;  // [B,3,3] / [B,3]: state before the first iteration (init_transform), or identity
     const float *initT = nullptr;
     bool allowReflection = false;  // R = U V^T whatever its determinant (utils_icp_pytorch3d.py:354-362)
+    bool estimateScale = false;    // s = trace(E S) / Xcov (:364-374); Xt = s X R + T
+    const float *initS = nullptr;  // [B] scale of the initial transform (with initR / initT), NULL = 1
     LaunchProfile *profile = nullptr;
     bool ctrlCleared = false;      // the caller's count_pair launch already zeroed *ctrl
     bool *historyPending = nullptr;   // non-NULL: do not launch the history epilogue; *historyPending = "the final
@@ -176,7 +178,8 @@ hipError_t profile_collect(LaunchProfile *p, double *total_ms, int *launches);
 int device_cus();
 void ensure_dynamic_lds(const void *func, int bytes, std::atomic<unsigned long long> *doneMask);
 hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,
-                             float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s);
+                             float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s,
+                             float *scale = nullptr);
 hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const float *history, int B, int maxIter,
                                       hipStream_t s);
 

@@ -40,11 +40,9 @@ def iterative_closest_point(X, Y, init_transform=None, thres=0.1, max_iterations
     X R0 + T0.  `t_history` (:187) is materialised lazily from the per-iteration records on the device (reference
     stop rule, max_iterations <= 128, at most 64 MiB of records; empty otherwise) and `converged` is a lazy device
     flag.  `allow_reflection=True` (:354-362) returns the best orthogonal matrix instead of the best rotation.
-    `estimate_scale=True` raises (ICP-Flow passes False, utils_icp.py:51-58; the closed-form rotation carries no
-    singular values).
+    `estimate_scale=True` (:364-374): s = trace(E S) / Xcov -- trace(E S) is the largest eigenvalue of the closed-form
+    solve -- and Xt = s X R + T.
     """
-    if estimate_scale:
-        raise NotImplementedError("estimate_scale=True is not built (ICP-Flow passes False, utils_icp.py:51-58)")
     x = _lib.cloud(X, "X")
     y = _lib.cloud(Y, "Y")
     if x.shape != y.shape:
@@ -61,9 +59,9 @@ def iterative_closest_point(X, Y, init_transform=None, thres=0.1, max_iterations
                              "with elements (R, T, s). R are dim x dim orthonormal matrices of shape (minibatch, dim, "
                              "dim), T is a batch of dim-dimensional translations of shape (minibatch, dim) and s is a "
                              "batch of scalars of shape (minibatch,).") from None
-        if not bool((s0 == 1).all()):
-            raise NotImplementedError("init_transform with a scale other than 1 (estimate_scale is not built)")
         init = (R0.to(device=dev, dtype=torch.float32).contiguous(), T0.to(device=dev, dtype=torch.float32).contiguous())
+        if not bool((s0 == 1).all()):        # a scale other than 1 travels along (the similarity kernels)
+            init = init + (s0.to(device=dev, dtype=torch.float32).contiguous(),)
     R = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
     T = torch.empty((B, 3), dtype=torch.float32, device=dev)
     rmse = torch.empty((B,), dtype=torch.float32, device=dev)
@@ -74,15 +72,16 @@ def iterative_closest_point(X, Y, init_transform=None, thres=0.1, max_iterations
             and _lib._current()[-1]["arith"] == 0:
         hist = torch.empty((int(max_iterations), B, 16), dtype=torch.float32, device=dev)
     ws = _lib.workspace(dev, _lib.workspace_bytes(B, N))
-    with _lib.options(icp_init=init, icp_history=hist, icp_allow_reflection=bool(allow_reflection)):
+    # the scale: estimated (:364-374), else 1 -- the scale of an initial transform shapes the first search only (:376-379)
+    scale = torch.ones(B, dtype=torch.float32, device=dev)
+    with _lib.options(icp_init=init, icp_history=hist, icp_allow_reflection=bool(allow_reflection),
+                      icp_scale=scale if estimate_scale else None):
         _lib.call("icpflow_icp", _lib.ptr(x), _lib.ptr(y), None, B, N, float(thres), int(max_iterations),
                   float(relative_rmse_thr), stop_mode_of(stop_mode), _lib.ptr(R), _lib.ptr(T), _lib.ptr(rmse),
                   _lib.ptr(flags[0:1]), _lib.ptr(flags[1:2]), _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())
     # Xt = s X R + T (utils_icp_pytorch3d.py:177, :395) -- returned for API parity
-    Xt = torch.baddbmm(T[:, None, :], x[:, :, 0:3], R)
-    sol = ICPSolution(_LazyFlag(flags, 1), rmse, Xt,
-                      SimilarityTransform(R, T, torch.ones(B, dtype=torch.float32, device=dev)),
-                      _LazyHistory(hist, flags))
+    Xt = scale[:, None, None] * torch.bmm(x[:, :, 0:3], R) + T[:, None, :]
+    sol = ICPSolution(_LazyFlag(flags, 1), rmse, Xt, SimilarityTransform(R, T, scale), _LazyHistory(hist, flags))
     return sol
 
 
@@ -99,9 +98,8 @@ class _LazyHistory(list):
             n = int(self._flags[0].item())
             h = self._hist[:max(n, 0)]
             B = h.shape[1]
-            ones = torch.ones(B, dtype=torch.float32, device=h.device)
             for k in range(h.shape[0]):
-                super().append(SimilarityTransform(h[k, :, 0:9].reshape(B, 3, 3), h[k, :, 9:12], ones))
+                super().append(SimilarityTransform(h[k, :, 0:9].reshape(B, 3, 3), h[k, :, 9:12], h[k, :, 13]))
         return self
 
     def __len__(self):

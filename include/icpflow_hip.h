@@ -90,6 +90,9 @@ const char *icpflow_build_info(void);
  *   on X R0 + T0 instead of X (every iteration still solves for the absolute transform of X).
  * icp_allow_reflection -- icpflow_icp only: `allow_reflection` of corresponding_points_alignment (:354-362): R = U V^T
  *   whatever its determinant (the best ORTHOGONAL matrix; a reflection when det H < 0) instead of the best rotation.
+ * icp_estimate_scale, d_icp_scale [B] -- icpflow_icp only: `estimate_scale` of iterative_closest_point (:364-374): the
+ *   transform is a similarity, Xt = s X R + T with s = trace(E S) / Xcov; d_icp_scale receives s (may be NULL).
+ *   d_icp_init_s [B] (with d_icp_init_R / d_icp_init_T): the scale of the initial transform, NULL = 1.
  * d_icp_history [max_iterations, B, 16] -- icpflow_icp only: `t_history` of the reference's ICPSolution
  *   (:187), i.e. (R row-major 9, T 3, rmse, 3 unused) after every iteration; rows of iterations the batch rule
  *   did not reach are unspecified.  Available in the single-launch reference stop mode (max_iterations <= 128,
@@ -125,6 +128,9 @@ typedef struct icpflow_options {
     const float *d_icp_init_T;
     float *d_icp_history;
     int icp_allow_reflection;
+    int icp_estimate_scale;
+    float *d_icp_scale;
+    const float *d_icp_init_s;
 } icpflow_options_t;
 
 /* Bytes of device scratch the fused entry points below need for a batch of B

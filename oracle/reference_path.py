@@ -194,8 +194,10 @@ def estimate_init_pose(args, src, dst):
 # --------------------------------------------------------------------------
 # ICP, utils_icp_pytorch3d.py
 # --------------------------------------------------------------------------
-def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_order=None, allow_reflection=False):
-    """utils_icp_pytorch3d.py:303-382 (estimate_scale=False, allow_reflection=False).
+def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_order=None, allow_reflection=False,
+                                   estimate_scale=False):
+    """utils_icp_pytorch3d.py:303-382 (ICP-Flow: estimate_scale=False, allow_reflection=False; with estimate_scale
+    the return value is (R, T, s)).
     X, Y [B,N,3] already mask-multiplied, weights bool [B,N].  y = x R + T.
 
     dtype=torch.float64 is NOT the reference: it evaluates the same formulas on the same
@@ -221,13 +223,19 @@ def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_orde
     if not allow_reflection:                                                  # :354
         E[:, -1, -1] = torch.det(torch.bmm(U, V.transpose(2, 1)))             # :358-359
     R = torch.bmm(torch.bmm(U, E), V.transpose(2, 1))                         # :362
+    if estimate_scale:
+        trace_ES = (torch.diagonal(E, dim1=1, dim2=2) * S).sum(1)             # :366
+        Xcov = (Xc * Xc).sum((1, 2)) / total                                  # :367
+        s = trace_ES / torch.clamp(Xcov, eps)                                 # :370
+        T = mu_y[:, 0, :] - s[:, None] * torch.bmm(mu_x, R)[:, 0, :]          # :373
+        return R.to(out_dtype), T.to(out_dtype), s.to(out_dtype)
     T = mu_y[:, 0, :] - torch.bmm(mu_x, R)[:, 0, :]                           # :376
     return R.to(out_dtype), T.to(out_dtype)
 
 
 def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
                             relative_rmse_thr=ICP_REL_RMSE, trace=False, kabsch_dtype=None, sum_order=None,
-                            init_transform=None, allow_reflection=False):
+                            init_transform=None, allow_reflection=False, estimate_scale=False):
     """utils_icp_pytorch3d.py:100-225.  Returns a namespace with
     converged, rmse, Xt, R, T, iterations (number of loop bodies executed) and,
     with trace=True, the per-iteration (R, T, rmse, inlier count) history.
@@ -242,9 +250,12 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
     Xt = X0
     R = torch.eye(3)[None].repeat(b, 1, 1)                                    # :140
     T = X0.new_zeros((b, 3))
-    if init_transform is not None:                                            # :118-138 (unit scale)
+    s = X0.new_ones(b)
+    if init_transform is not None:                                            # :118-138
         R, T = init_transform[0], init_transform[1]
-        Xt = torch.bmm(X0, R) + T[:, None, :]                                 # _apply_similarity_transform, :395
+        if len(init_transform) > 2:
+            s = init_transform[2]
+        Xt = s[:, None, None] * torch.bmm(X0, R) + T[:, None, :]              # _apply_similarity_transform, :395
     prev = None
     rmse = None
     converged = False
@@ -254,10 +265,12 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
     for it in range(max_iterations):                                          # :153
         d2, _, nn = knn_points(Xt, Yt, n_x, n_y, return_nn=True)              # :154-157
         w = torch.logical_and(m0, d2 <= thr2)                                 # :160-161
-        R, T = corresponding_points_alignment(X0 * w[:, :, None], nn * w[:, :, None], w,
-                                              dtype=kabsch_dtype, sum_order=sum_order,
-                                              allow_reflection=allow_reflection)
-        Xt = torch.bmm(X0, R) + T[:, None, :]                                 # :177,395
+        sol = corresponding_points_alignment(X0 * w[:, :, None], nn * w[:, :, None], w,
+                                             dtype=kabsch_dtype, sum_order=sum_order,
+                                             allow_reflection=allow_reflection, estimate_scale=estimate_scale)
+        R, T = sol[0], sol[1]
+        s = sol[2] if estimate_scale else X0.new_ones(b)                      # (:376-379: unit scale when not estimated)
+        Xt = s[:, None, None] * torch.bmm(X0, R) + T[:, None, :]              # :177,395
         sq = ((Xt - nn) ** 2).sum(2)                                          # :191
         if kabsch_dtype is not None:
             sq = sq.to(kabsch_dtype)
@@ -269,7 +282,7 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
             converged = True
             break
         prev = rmse
-    return SimpleNamespace(converged=converged, rmse=rmse, Xt=Xt, R=R, T=T,
+    return SimpleNamespace(converged=converged, rmse=rmse, Xt=Xt, R=R, T=T, s=s,
                            iterations=it + 1, history=history)
 
 

@@ -345,11 +345,59 @@ def test_icp_init_transform_and_t_history_vs_oracle():
     assert torch.equal(hist[-1].R, got.RTs.R) and torch.equal(hist[-1].T, got.RTs.T)
     with pytest.raises(ValueError, match="init_transform"):
         utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), init_transform=(R0[:3], T0, torch.ones(10)))
-    with pytest.raises(NotImplementedError):
-        utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV),
-                                                    init_transform=(R0, T0, torch.full((10,), 1.1)))
+    # an initial transform with a scale: it shapes the first search only (the alignment returns unit scale unless
+    # estimate_scale, utils_icp_pytorch3d.py:376-379)
+    s1 = torch.full((10,), 1.002)
+    if _lib._current()[-1]["search"] in (0, 3):     # (similarity transforms: the sorted-sweep kernels)
+        want_s = rp.iterative_closest_point(src, dst, init_transform=(R0, T0, s1), kabsch_dtype=torch.float64)
+        got_s = utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), init_transform=(R0, T0, s1))
+        assert got_s.converged.iterations == want_s.iterations
+        np.testing.assert_allclose(got_s.Xt.cpu().numpy()[v], want_s.Xt.numpy()[v], atol=2e-5, rtol=0)
+        assert bool((got_s.RTs.s == 1).all())
+    else:
+        with pytest.raises(RuntimeError, match="sorted-sweep"):
+            utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), init_transform=(R0, T0, s1))
     # per-pair stop: no per-iteration records -> empty history, like round 1
     assert len(utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), stop_mode="per_pair").t_history) == 0
+
+
+def test_icp_estimate_scale_vs_oracle():
+    """estimate_scale=True (utils_icp_pytorch3d.py:364-374): the transform is a similarity, Xt = s X R + T with
+    s = trace(E S) / Xcov.  Targets = the source scaled by 0.9 .. 1.1 about its centre, turned by a few degrees and
+    shifted; started from the true scale (init_transform carries s) less a few per cent."""
+    rng = np.random.default_rng(21)
+    B, N = 8, 400
+    S = np.zeros((B, N, 4), np.float32)
+    D = np.zeros((B, N, 4), np.float32)
+    s_true = rng.uniform(0.9, 1.1, B)
+    for i in range(B):
+        p = rng.uniform(-0.5, 0.5, (N, 3)) * np.array([4.0, 1.8, 1.5])
+        c = np.array([12.0 + 3 * i, -7.0, 0.8])
+        yaw = np.deg2rad(rng.uniform(-2, 2))
+        Rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1.0]])
+        q = s_true[i] * (p @ Rz.T) + c + np.array([0.03, -0.02, 0.01]) + rng.normal(0, 0.003, (N, 3))
+        S[i, :, :3], D[i, :, :3] = p + c, q
+        S[i, :, 3] = D[i, :, 3] = 1.0
+    # initial transform: the true scale within 1 %, about the cluster centre (T0 = c - s0 c)
+    s0 = (s_true * rng.uniform(0.99, 1.01, B)).astype(np.float32)
+    cen = S[:, :, :3].mean(1)
+    R0 = C(np.tile(np.eye(3, dtype=np.float32), (B, 1, 1)))
+    T0 = C((cen - s0[:, None] * cen).astype(np.float32))
+    want = rp.iterative_closest_point(C(S), C(D), init_transform=(R0, T0, C(s0)), estimate_scale=True,
+                                      kabsch_dtype=torch.float64)
+    got = utils_icp_pytorch3d.iterative_closest_point(G(S), G(D), init_transform=(R0, T0, C(s0)), estimate_scale=True)
+    assert got.converged.iterations == want.iterations
+    np.testing.assert_allclose(got.RTs.s.cpu().numpy(), want.s.numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(got.RTs.s.cpu().numpy(), s_true, atol=5e-3)          # and it is the scale that was applied
+    np.testing.assert_allclose(got.RTs.R.cpu().numpy(), want.R.numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(got.Xt.cpu().numpy(), want.Xt.numpy(), atol=3e-5, rtol=0)
+    np.testing.assert_allclose(got.rmse.cpu().numpy(), want.rmse.numpy(), atol=2e-6)
+    assert len(got.t_history) == want.iterations
+    np.testing.assert_allclose(got.t_history[-1].s.cpu().numpy(), want.s.numpy(), atol=2e-6)
+    # the certificates do not care: identical with the plain scan
+    with _lib.options(no_adaptive_windows=True):
+        plain = utils_icp_pytorch3d.iterative_closest_point(G(S), G(D), init_transform=(R0, T0, C(s0)), estimate_scale=True)
+    assert torch.equal(plain.RTs.R, got.RTs.R) and torch.equal(plain.RTs.s, got.RTs.s) and torch.equal(plain.RTs.T, got.RTs.T)
 
 
 @all_icp_searches
