@@ -6,9 +6,11 @@ import numpy as np, torch
 from icp_flow_amd import _lib, synthetic, utils_match, utils_icp_pytorch3d as icp
 from oracle import reference_path as rp
 bad = 0
-for seed in range(int(os.environ.get("SEEDS", 40))):
+for seed in range(int(os.environ.get("FIRST", 0)), int(os.environ.get("FIRST", 0)) + int(os.environ.get("SEEDS", 40))):
     rng = np.random.default_rng(seed)
     B, N = int(rng.integers(8, 300)), int(rng.choice([96, 300, 700, 1024, 1500, 2048, 3000, 4096]))
+    if seed % 5 == 4:   # few large pairs (teams), or many pairs (two workgroups per CU)
+        B, N = (int(rng.integers(4, 40)), int(rng.choice([3000, 6000, 10000]))) if seed % 2 else (int(rng.integers(512, 1300)), int(rng.choice([1024, 1500, 2048])))
     S, D, _ = synthetic.make_batch(B, N, seed=1000 * seed, ragged=bool(seed % 2), n_min=10)
     if seed % 3 == 0:   # far from the origin
         off = np.array([rng.uniform(-3000, 3000), rng.uniform(-3000, 3000), 0.0], np.float32)
