@@ -180,7 +180,8 @@ def opt():
             and not cur["icp_allow_reflection"] and cur["icp_scale"] is None):
         return None
     dp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
-    o = Options(ctypes.sizeof(Options), int(cur["search"]), int(cur["arith"]), int(cur["flags"]),
+    # (ICPFLOW_OPTIONS_SIZE: developer override for loading an older build of the ABI, whose struct was a prefix of this one)
+    o = Options(int(os.environ.get("ICPFLOW_OPTIONS_SIZE", ctypes.sizeof(Options))), int(cur["search"]), int(cur["arith"]), int(cur["flags"]),
                 cur["profile"]._h if cur["profile"] is not None else None, dp(cur["vote_bins"]),
                 dp(cur["icp_init"][0] if cur["icp_init"] is not None else None),
                 dp(cur["icp_init"][1] if cur["icp_init"] is not None else None), dp(cur["icp_history"]),
