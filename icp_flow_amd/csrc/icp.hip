@@ -627,7 +627,10 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                 float newL[Q];   // >= 0: this query's record is rewritten (bound on every target but the neighbour)
 #pragma unroll
                 for (int q = 0; q < Q; ++q) { recM[q] = p.sweepMargin; certJ[q] = -1; certD[q] = kInf; newL[q] = -1.f; }
-                const float certMargin = 1.25f * p.sweepMargin;       // window of queries that may be outside the gate
+                // (window of the queries that may be outside the gate: 10 % beyond the gate's own, so that a scan which finds
+                // nothing closer certifies "outside" for the next centimetre of drift; measured 1.05 .. 2.0: 1.05 - 1.18 are
+                // within 0.5 % of each other, 1.25 and beyond lose 2.5 % to the longer scans of the first iterations)
+                const float certMargin = 1.1f * p.sweepMargin;
                 const float gateOut = p.sweepMargin;                  // > thres with 1 % to spare (1.01 thres)
                 ICPFLOW_STAMP(1);
 #pragma unroll
