@@ -317,7 +317,12 @@ constexpr int kRecMaxN = 4096;
 #define ICPFLOW_PROBE_MAX 16
 #endif
 constexpr int kProbeMax = ICPFLOW_PROBE_MAX;   // uncertified queries a wave settles by probes; more take the window scan
-constexpr int kProbeSteps = 4;  // blocks of 64 targets a probe may evaluate
+#ifndef ICPFLOW_PROBE_STEPS
+#define ICPFLOW_PROBE_STEPS 8
+#endif
+// blocks of 64 targets a probe may evaluate (measured at config 2: 2 / 3 / 4 / 6 / 8 / 12 / 16 blocks -> ICP launch
+// 0.487 / 0.512 / 0.441 / 0.401 / 0.396 / 0.396 / 0.400 ms: an inconclusive probe sends its whole wave to the scan)
+constexpr int kProbeSteps = ICPFLOW_PROBE_STEPS;
 constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
 // ---------------------------------------------------------------------------------
