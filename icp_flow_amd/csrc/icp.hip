@@ -314,7 +314,7 @@ __device__ __forceinline__ int state_hash_word(float w, int k)
 // <= 128 KiB.  Results are identical with and without (ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS).
 constexpr int kRecMaxN = 4096;
 #ifndef ICPFLOW_PROBE_MAX
-#define ICPFLOW_PROBE_MAX 16
+#define ICPFLOW_PROBE_MAX 20
 #endif
 constexpr int kProbeMax = ICPFLOW_PROBE_MAX;   // uncertified queries a wave settles by probes; more take the window scan
 #ifndef ICPFLOW_PROBE_STEPS
@@ -632,10 +632,13 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                 float newL[Q];   // >= 0: this query's record is rewritten (bound on every target but the neighbour)
 #pragma unroll
                 for (int q = 0; q < Q; ++q) { recM[q] = p.sweepMargin; certJ[q] = -1; certD[q] = kInf; newL[q] = -1.f; }
-                // (window of the queries that may be outside the gate: 10 % beyond the gate's own, so that a scan which finds
-                // nothing closer certifies "outside" for the next centimetre of drift; measured 1.05 .. 2.0: 1.05 - 1.18 are
-                // within 0.5 % of each other, 1.25 and beyond lose 2.5 % to the longer scans of the first iterations)
-                const float certMargin = 1.1f * p.sweepMargin;
+                // (window of the queries that may be outside the gate: 30 % beyond the gate's own, so that a scan which finds
+                // nothing closer certifies "outside" for the next three centimetres of drift.  With probes of up to eight
+                // blocks, 1.04 / 1.1 / 1.2 / 1.3 / 1.4 measure within 2 % of each other, 1.3 in front)
+#ifndef ICPFLOW_CERT_MARGIN
+#define ICPFLOW_CERT_MARGIN 1.3f
+#endif
+                const float certMargin = ICPFLOW_CERT_MARGIN * p.sweepMargin;
                 const float gateOut = p.sweepMargin;                  // > thres with 1 % to spare (1.01 thres)
                 ICPFLOW_STAMP(1);
 #pragma unroll
