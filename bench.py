@@ -220,8 +220,10 @@ def roofline_block(B, N, steps, iters_done, icp_ms, icp_launches, dt, build):
                      "executed_frac": round(lane_exec / VALU_PEAK_LANE_OPS, 4)})
     return {
         "bound": "valu",
-        "bound_note": "what binds: fp32 VALU issue + LDS broadcast latency of the correspondence search and the serial "
-                      "rotation solve of one wave per pair -- not HBM (both clouds stay in LDS for all iterations; "
+        "bound_note": "what binds: the launch is paced by its slowest pairs (one workgroup each, 36-50 iterations): VALU "
+                      "issue of the search phase (neighbour certificates, probe rounds, moment sums; four waves per SIMD; "
+                      "window scans in the first iterations) and the serial rotation solve of one wave per pair -- not HBM "
+                      "(both clouds stay in LDS for all iterations; "
                       "arithmetic intensity ~256 lane-op/B against a ridge of ~10).  achieved/peak/frac below are the "
                       "contract's HBM figures (algorithmic bytes / launch duration); see `valu` for the binding roofline",
         "kernel": "icp_kernel (all ICP iterations of the batch per launch)" if icp_launches == steps
