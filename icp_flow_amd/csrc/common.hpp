@@ -206,6 +206,29 @@ __device__ __forceinline__ void barrier_lds_only()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// the same maximum on the VALU (DPP row shifts / broadcasts instead of a dozen ds_bpermute round trips); wave-uniform
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o > v ? o : v;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64_dpp(unsigned long long v)
+{
+    v = dpp_max_u64<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_max_u64<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_max_u64<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_max_u64<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row's maximum
+    v = dpp_max_u64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_max_u64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
 #pragma unroll

@@ -526,68 +526,102 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
         for (int f = tid; f < L; f += kPeakBlock) H0[f] = (uint32_t)h[f];
         __syncthreads();
     }
+    // (x, y, z) of this thread's bins f = tid, tid + kPeakBlock, ...: two divisions once, increments afterwards (the
+    // three passes used to spend most of their instructions on % and / by run-time extents)
+    const int LyLz = Ly * Lz;
+    const int stepX = kPeakBlock / LyLz, stepY = (kPeakBlock % LyLz) / Lz, stepZ = kPeakBlock % Lz;
+    const int x0 = tid / LyLz, y0 = (tid % LyLz) / Lz, z0 = tid % Lz;
+#define ICPFLOW_PEAK_ADVANCE()                                   \
+    do {                                                         \
+        z += stepZ; y += stepY; x += stepX;                      \
+        if (z >= Lz) { z -= Lz; ++y; }                           \
+        if (y >= Ly) { y -= Ly; ++x; }                           \
+    } while (0)
     // pass z: A = max over |dz| <= r of h   (-inf padding == ignore out of range)
-    for (int f = tid; f < L; f += kPeakBlock) {
-        const int z = f % Lz, base = f - z;
-        const int lo = max(0, z - radius), hi = min(Lz - 1, z + radius);
-        uint32_t m = 0;
-        for (int q = lo; q <= hi; ++q) m = max(m, MEM ? H0[base + q] : (uint32_t)h[base + q]);
-        A[f] = m;
+    {
+        int x = x0, y = y0, z = z0;
+        for (int f = tid; f < L; f += kPeakBlock) {
+            (void)x;
+            const int lo = max(0, z - radius), hi = min(Lz - 1, z + radius);
+            uint32_t m = 0;
+            for (int q = lo; q <= hi; ++q) m = max(m, MEM ? H0[f + (q - z)] : (uint32_t)h[f + (q - z)]);
+            A[f] = m;
+            ICPFLOW_PEAK_ADVANCE();
+        }
     }
     __syncthreads();
     // pass y: B = max over |dy| <= r of A
-    for (int f = tid; f < L; f += kPeakBlock) {
-        const int z = f % Lz, y = (f / Lz) % Ly, x = f / (Lz * Ly);
-        const int lo = max(0, y - radius), hi = min(Ly - 1, y + radius);
-        uint32_t m = 0;
-        for (int q = lo; q <= hi; ++q) m = max(m, A[(x * Ly + q) * Lz + z]);
-        Bv[f] = m;
+    {
+        int x = x0, y = y0, z = z0;
+        for (int f = tid; f < L; f += kPeakBlock) {
+            (void)x;
+            const int lo = max(0, y - radius), hi = min(Ly - 1, y + radius);
+            uint32_t m = 0;
+            for (int q = lo; q <= hi; ++q) m = max(m, A[f + (q - y) * Lz]);
+            Bv[f] = m;
+            ICPFLOW_PEAK_ADVANCE();
+        }
     }
     __syncthreads();
     // pass x: A = max over |dx| <= r of B  -> full 3-D window maximum
-    for (int f = tid; f < L; f += kPeakBlock) {
-        const int z = f % Lz, y = (f / Lz) % Ly, x = f / (Lz * Ly);
-        const int lo = max(0, x - radius), hi = min(Lx - 1, x + radius);
-        uint32_t m = 0;
-        for (int q = lo; q <= hi; ++q) m = max(m, Bv[(q * Ly + y) * Lz + z]);
-        A[f] = m;
+    {
+        int x = x0, y = y0, z = z0;
+        for (int f = tid; f < L; f += kPeakBlock) {
+            const int lo = max(0, x - radius), hi = min(Lx - 1, x + radius);
+            uint32_t m = 0;
+            for (int q = lo; q <= hi; ++q) m = max(m, Bv[f + (q - x) * LyLz]);
+            A[f] = m;
+            ICPFLOW_PEAK_ADVANCE();
+        }
     }
+#undef ICPFLOW_PEAK_ADVANCE
     __syncthreads();
     // surviving vote = h where h == window max, else 0 (utils_hist.py:25-26);
-    // k selection rounds, order (vote desc, flat index asc)
+    // k selection rounds, order (vote desc, flat index asc).  A thread's best remaining key only changes when it was
+    // the one chosen: everybody else carries its key into the next round.
+    unsigned long long best = 0ull;
+    bool stale = true;
     for (int r = 0; r < k; ++r) {
-        unsigned long long best = 0ull;
-        bool have = false;
-        for (int f = tid; f < L; f += kPeakBlock) {
-            const uint32_t v = MEM ? H0[f] : (uint32_t)h[f];
-            const uint32_t s = (v == A[f]) ? v : 0u;
-            const unsigned long long key =
-                ((unsigned long long)s << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)f);
-            bool taken = false;
-            for (int q = 0; q < r; ++q) taken |= (chosen[q] == key);
-            if (!taken && (!have || key > best)) { best = key; have = true; }
+        if (stale) {
+            best = 0ull;
+            bool have = false;
+            for (int f = tid; f < L; f += kPeakBlock) {
+                const uint32_t v = MEM ? H0[f] : (uint32_t)h[f];
+                const uint32_t s = (v == A[f]) ? v : 0u;
+                const unsigned long long key =
+                    ((unsigned long long)s << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)f);
+                bool taken = false;
+                for (int q = 0; q < r; ++q) taken |= (chosen[q] == key);
+                if (!taken && (!have || key > best)) { best = key; have = true; }
+            }
+            stale = false;   // (keys are unique -- index bits --, 0 can only be "nothing left")
         }
-        // keys are unique (index bits), 0 can only be "nothing found"
-        unsigned long long w = wave_max_u64(have ? best : 0ull);
+        unsigned long long w = wave_max_u64_dpp(best);
         if ((tid & (kWave - 1)) == 0) red[tid >> 6] = w;
         __syncthreads();
-        if (tid == 0) {
+        {
             unsigned long long m = red[0];
             for (int q = 1; q < kPeakBlock / kWave; ++q) m = red[q] > m ? red[q] : m;
-            chosen[r] = m;
-            votes[(size_t)b * k + r] = (float)(uint32_t)(m >> 32);
-            const uint32_t f = 0xFFFFFFFFu - (uint32_t)(m & 0xFFFFFFFFull);
-            idx_out[(size_t)b * k + r] = (int64_t)f;
-            if (dec.cand != nullptr) {
-                // fused path: flat peak index -> candidate translation (left bin edges + shift,
-                // utils_hist.py:78); the zero translation goes LAST (:83)
-                float *o = dec.cand + ((size_t)b * (k + 1) + r) * 3;
-                const int ix = (int)(f / Lz / Ly % Lx), iy = (int)(f / Lz % Ly), iz = (int)(f % Lz);
-                o[0] = dec.ex[ix] + dec.shift; o[1] = dec.ey[iy] + dec.shift; o[2] = dec.ez[iz] + dec.shift;
-                if (r == k - 1) { o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; }
-            }
+            if (tid == 0) chosen[r] = m;
+            if (m == best && m != 0ull) stale = true;   // mine was taken: look for my next one
         }
         __syncthreads();
+    }
+    // outputs: thread r writes peak r (and its candidate translation on the fused path)
+    if (tid < k) {
+        const int r = tid;
+        const unsigned long long m = chosen[r];
+        votes[(size_t)b * k + r] = (float)(uint32_t)(m >> 32);
+        const uint32_t f = 0xFFFFFFFFu - (uint32_t)(m & 0xFFFFFFFFull);
+        idx_out[(size_t)b * k + r] = (int64_t)f;
+        if (dec.cand != nullptr) {
+            // fused path: flat peak index -> candidate translation (left bin edges + shift,
+            // utils_hist.py:78); the zero translation goes LAST (:83)
+            float *o = dec.cand + ((size_t)b * (k + 1) + r) * 3;
+            const int ix = (int)(f / Lz / Ly % Lx), iy = (int)(f / Lz % Ly), iz = (int)(f % Lz);
+            o[0] = dec.ex[ix] + dec.shift; o[1] = dec.ey[iy] + dec.shift; o[2] = dec.ez[iz] + dec.shift;
+            if (r == k - 1) { o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; }
+        }
     }
 }
 
