@@ -361,18 +361,19 @@ def test_icp_init_transform_and_t_history_vs_oracle():
     assert len(utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), stop_mode="per_pair").t_history) == 0
 
 
-def test_icp_estimate_scale_vs_oracle():
+@pytest.mark.parametrize("B,N", [(8, 400), (6, 1500), (300, 1400), (520, 800)],
+                         ids=["one-pass", "teams", "several-passes", "two-workgroups-per-cu"])
+def test_icp_estimate_scale_vs_oracle(B, N):
     """estimate_scale=True (utils_icp_pytorch3d.py:364-374): the transform is a similarity, Xt = s X R + T with
     s = trace(E S) / Xcov.  Targets = the source scaled by 0.9 .. 1.1 about its centre, turned by a few degrees and
     shifted; started from the true scale (init_transform carries s) less a few per cent."""
     rng = np.random.default_rng(21)
-    B, N = 8, 400
     S = np.zeros((B, N, 4), np.float32)
     D = np.zeros((B, N, 4), np.float32)
     s_true = rng.uniform(0.9, 1.1, B)
     for i in range(B):
         p = rng.uniform(-0.5, 0.5, (N, 3)) * np.array([4.0, 1.8, 1.5])
-        c = np.array([12.0 + 3 * i, -7.0, 0.8])
+        c = np.array([12.0 + 3 * (i % 16), -7.0 + (i // 16), 0.8])
         yaw = np.deg2rad(rng.uniform(-2, 2))
         Rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1.0]])
         q = s_true[i] * (p @ Rz.T) + c + np.array([0.03, -0.02, 0.01]) + rng.normal(0, 0.003, (N, 3))
