@@ -65,8 +65,22 @@ struct Opts {
 
 // the scoring sweep prunes by the largest NN distance inside a wave: it pays on large clusters (real
 // data, hundreds of queries per metre along the sort axis), not on ~1000-point vehicles
-constexpr int kScoreSweepMinN = 2048;
+#ifndef ICPFLOW_SCORE_SWEEP_MIN_N
+#define ICPFLOW_SCORE_SWEEP_MIN_N 2048
+#endif
+constexpr int kScoreSweepMinN = ICPFLOW_SCORE_SWEEP_MIN_N;
 constexpr int kMaxSortN = 16384;   // bitonic sort of (key, index) pairs in 128 KiB of LDS
+// ... with the branch and bound of the all-pairs scoring and the clouds sorted anyway (hist_icp sorts them for the
+// ICP on the side stream) the sweep wins from ~1000 points on (config 2: 171 -> 153 us, config 4's shard: 1.50 -> 0.94 ms)
+#ifndef ICPFLOW_SCORE_SWEEP_MIN_N_SORTED
+#define ICPFLOW_SCORE_SWEEP_MIN_N_SORTED 512
+#endif
+constexpr int kScoreSweepMinNSorted = ICPFLOW_SCORE_SWEEP_MIN_N_SORTED;
+inline bool score_by_sweep(int N, bool sortedAnyway, const Opts &o)
+{
+    const int minN = (sortedAnyway && o.on(ICPFLOW_OPT_NO_SCORE_PRUNE)) ? kScoreSweepMinNSorted : kScoreSweepMinN;
+    return N > minN && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SCORE_SWEEP);
+}
 constexpr size_t kAlign = 256;
 size_t up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
 
@@ -326,14 +340,17 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
     ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,
                                       w.peakVotes, w.peakIdx, s, dec));
     // candidate scoring: sorted sweep while the sort fits LDS, all-pairs scan otherwise (same sums)
-    if (N > kScoreSweepMinN && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SCORE_SWEEP)) {
+    if (score_by_sweep(N, joinBefore != nullptr || w.grid.presorted, o)) {
         if (joinBefore != nullptr) {
             ICPFLOW_TRY(hipStreamWaitEvent(s, joinBefore, 0));
         } else if (!w.grid.presorted) {
             ICPFLOW_TRY(launch_sort_clouds_soa(src, dst, w.lenA, w.lenC, swap, B, N, &w.grid, s));
             w.grid.presorted = 1;
         }
-        ICPFLOW_TRY(launch_sweep_score(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
+        if (o.on(ICPFLOW_OPT_NO_SCORE_PRUNE))
+            ICPFLOW_TRY(launch_sweep_score_pruned(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s));
+        else
+            ICPFLOW_TRY(launch_sweep_score(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
         ICPFLOW_TRY(launch_score_pick(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
     } else if (o.on(ICPFLOW_OPT_NO_SCORE_PRUNE)) {
         ICPFLOW_TRY(launch_scan_score_pruned(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s, true));
@@ -713,7 +730,7 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
             join = side.join;
         }
     }
-    const bool sweepScore = N > kScoreSweepMinN && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SCORE_SWEEP);
+    const bool sweepScore = score_by_sweep(N, join != nullptr, o);
     if (int r = run_init_pose(d_src, d_dst, w, w.swap, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
                               len_z, decode_shift, w.Tinit, o, s, sweepScore ? join : nullptr))
         return r;

@@ -106,6 +106,9 @@ hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const flo
                               const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused = nullptr);
 hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
                               int B, int N, const float *cand, double *partial, hipStream_t s);
+hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC,
+                                     const uint8_t *swap, int B, int N, const float *cand, double *partial,
+                                     double *accum, hipStream_t s);
 hipError_t launch_scan_score(const float *A, const float *C, const int32_t *lenA, const int32_t *lenC,
                              const uint8_t *swap, int B, int N, const float *cand, double *partial,
                              hipStream_t s);

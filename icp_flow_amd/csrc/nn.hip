@@ -315,6 +315,11 @@ struct SweepParams {
     int N, NP16, njobs, qblocks;
     float r0;
     double *partial;        // [njobs, qblocks, kPartial]
+    // SWEEP_SCORE with branch and bound (launch_sweep_score_pruned; same scheme as ScanParams above): this launch
+    // covers the scans subBegin .. subBegin + subCount - 1 of every pair; prune 1: leave when the blocks before
+    // this one have summed more than candidate 0's forward mean allows, prune 2: candidate 0's backward scan
+    int subBegin, subCount, prune;
+    double *accum;          // [B,12] running sums of the scans (cleared by the caller)
 };
 
 constexpr int kSweepBlock = 256;
@@ -327,11 +332,17 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     __shared__ double red[(kSweepBlock / kWave) * kPartial];
     extern __shared__ __attribute__((aligned(16))) float keyLds[];   // the targets' sort keys (window searches)
     const int lin = blockIdx.x;
-    const int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);   // XCD-aware: the 8 XCDs take 8 jobs
-    const int qb = (lin >> 3) % p.qblocks;
+    int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);   // XCD-aware: the 8 XCDs take 8 jobs
+    int qb = (lin >> 3) % p.qblocks;
+    if (MODE == SWEEP_SCORE && p.prune) {   // query block major (see nn_scan_kernel): later blocks find earlier sums
+        const int padded = (p.njobs + 7) & ~7;
+        qb = lin / padded;
+        job = lin % padded;
+    }
     if (job >= p.njobs) return;
-    const int b = (MODE == SWEEP_SCORE) ? job / 12 : job >> 1;
-    const int sub = (MODE == SWEEP_SCORE) ? job % 12 : (job & 1);
+    const int b = (MODE == SWEEP_SCORE) ? job / p.subCount : job >> 1;
+    const int sub = (MODE == SWEEP_SCORE) ? p.subBegin + job % p.subCount : (job & 1);
+    if (MODE == SWEEP_SCORE) job = b * 12 + sub;   // the scan's place in the partial records
     const bool backward = (MODE == SWEEP_SCORE) ? (sub & 1) : (MODE == SWEEP_EVAL ? sub == 1 : false);
     const bool sw = p.swap != nullptr && p.swap[b] != 0;
     const int na = (sw ? p.lenC : p.lenA)[b], nc = (sw ? p.lenA : p.lenC)[b];
@@ -346,6 +357,43 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     const int nq = backward ? nc : na, nt = backward ? na : nc;
     double *out = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    __shared__ float boundSh;   // pruned scoring: candidate 0's forward mean
+    __shared__ int prunedSh;    // ... a wave of this block has proven the scan out of the race
+    if (MODE == SWEEP_SCORE && threadIdx.x == 0) prunedSh = 0;
+    if (MODE == SWEEP_SCORE && p.prune) {
+        // branch and bound exactly as in nn_scan_kernel (the argument is written there): the sum of the blocks
+        // before this one bounds the scan's mean from below; beyond candidate 0's forward mean it reports +inf
+        __shared__ int leave;
+        if (threadIdx.x == 0) {
+            double f0 = 0.0;
+            for (int q = 0; q < p.qblocks; ++q) f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
+            const float bound = (float)f0 / (float)na;
+            boundSh = bound;
+            if (p.prune == 2) {
+                bool othersOut = true;
+                for (int k = 1; k < 6; ++k) {
+                    double fk = 0.0, bk = 0.0;
+                    for (int q = 0; q < p.qblocks; ++q) {
+                        fk += p.partial[((size_t)(b * 12 + 2 * k) * p.qblocks + q) * kPartial];
+                        bk += p.partial[((size_t)(b * 12 + 2 * k + 1) * p.qblocks + q) * kPartial];
+                    }
+                    const float sk = fminf((float)fk / (float)na, (float)bk / (float)nc);
+                    othersOut = othersOut && (sk > bound * 1.0001f);   // NaN keeps the candidate in
+                }
+                leave = othersOut ? 1 : 0;
+            } else {
+                const double seen = __hip_atomic_load(p.accum + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float low = (float)(seen / (double)(float)(backward ? nc : na));
+                leave = low > bound * 1.0001f ? 1 : 0;   // NaN / inf bounds never prune
+            }
+            if (leave) {
+                out[0] = __builtin_huge_val();
+                for (int k = 1; k < kPartial; ++k) out[k] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (leave) return;
+    }
     if (qb * kSweepBlock >= nq) {   // block beyond the cloud: its record is still summed
         if (threadIdx.x < kPartial) out[threadIdx.x] = 0.0;
         return;
@@ -447,6 +495,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         // r = R settles it -- unless some lane has not seen any target yet (r quadruples: a query beyond the
         // end of the other cloud must not cost a scan of the whole cloud).
         int cb = 0, ce = 0;          // chunk range scanned so far
+        float lbAdded = 0.f;         // pruned scoring: what this wave has added to the scan's running lower bound
         for (int round = 0; round < 24; ++round) {
             int j0, j1;
             sorted_window(key, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
@@ -462,6 +511,29 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             cb = min(cb, k0); ce = max(ce, k1);
             const float worst = wave_max_uniform(live ? best : 0.f);
             const float proven = r * shrink;
+            if (MODE == SWEEP_SCORE && p.prune == 1) {
+                // Every target not scanned yet is farther than `proven` from every query of the wave, so
+                // min(sqrt(best), proven) bounds each lane's distance from below whether its neighbour has been
+                // found or not.  The wave adds what its bound has GROWN by to the scan's running sum and leaves as
+                // soon as that sum -- a lower bound of the scan's total at any time -- rules the candidate out:
+                // a candidate half a metre off is gone after the first round of its waves, no neighbour found.
+                const float sb = sqrtf(best), pr = proven * 0.99999f;
+                const float lbLane = !live ? 0.f : (sb < pr ? sb : (sb != sb ? sb : pr));   // NaN stays NaN: never prunes
+                const float L = wave_sum(lbLane) * 0.99999f;
+                if (lane == 0 && L > lbAdded) atomicAdd(p.accum + job, (double)(L - lbAdded));
+                if (L > lbAdded) lbAdded = L;
+                const bool done = worst <= proven * proven || (cb == 0 && ce == np16);
+                if (!done) {   // before another (wider) round: is the scan still in the race?
+                    double seen = 0.0;
+                    if (lane == 0) seen = __hip_atomic_load(p.accum + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float low = __int_as_float(__builtin_amdgcn_readfirstlane(
+                        __float_as_int((float)(seen / (double)(float)(backward ? nc : na)))));
+                    if (low > boundSh * 1.0001f) {
+                        if (lane == 0) prunedSh = 1;
+                        break;
+                    }
+                }
+            }
             if (worst <= proven * proven || (cb == 0 && ce == np16)) break;   // proven, or everything scanned
             r = (worst < kInf) ? sqrtf(worst) * (MODE == SWEEP_EVAL ? 1.001f : 1.000002f) : r * 4.0f;
         }
@@ -489,6 +561,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         double ssum = 0.0;
         if (threadIdx.x < NV)
             for (int w = 0; w < kSweepBlock / kWave; ++w) ssum += red[w * kPartial + threadIdx.x];
+        if (MODE == SWEEP_SCORE && prunedSh != 0 && threadIdx.x == 0) ssum = __builtin_huge_val();
         out[threadIdx.x] = ssum;
     }
 }
@@ -529,6 +602,27 @@ hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, cons
     SweepParams p{};
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.njobs = B * 12; p.partial = partial;
+    p.subBegin = 0; p.subCount = 12;
+    return launch_sweep<SWEEP_SCORE>(p, s);
+}
+
+// The same sweeps with the branch and bound of launch_scan_score_pruned (three launches: candidate 0 forward,
+// the other ten scans pruned against it, candidate 0 backward unless every other candidate is out); accum: [B,12]
+// zeros.  A pruned scan reports +inf, the pick is unchanged.
+hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC,
+                                     const uint8_t *swap, int B, int N, const float *cand, double *partial,
+                                     double *accum, hipStream_t s)
+{
+    SweepParams p{};
+    p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
+    p.axis = grid->axis; p.cand = cand; p.N = N; p.partial = partial; p.accum = accum;
+    p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
+    hipError_t e = launch_sweep<SWEEP_SCORE>(p, s);
+    if (e != hipSuccess) return e;
+    p.njobs = B * 10; p.subBegin = 2; p.subCount = 10; p.prune = 1;
+    e = launch_sweep<SWEEP_SCORE>(p, s);
+    if (e != hipSuccess) return e;
+    p.njobs = B; p.subBegin = 1; p.subCount = 1; p.prune = 2;
     return launch_sweep<SWEEP_SCORE>(p, s);
 }
 

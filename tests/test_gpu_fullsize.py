@@ -178,6 +178,34 @@ def test_adaptive_windows_change_nothing(shape):
     assert torch.equal(P0, utils_match.hist_icp(ap, s, d))
 
 
+@pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_90x2048"])
+def test_scoring_variants_change_nothing(shape):
+    """The six candidate translations are scored by sorted sweeps with branch and bound when hist_icp has the clouds
+    sorted anyway (nn.hip launch_sweep_score_pruned: blocks and waves leave a scan once its running LOWER bound rules
+    the candidate out), by the pruned all-pairs scans otherwise.  Pruning never changes the pick, so the registrations
+    are bit-identical to the pruned all-pairs scoring (ICPFLOW_OPT_NO_SCORE_SWEEP) and to every scan run to its end
+    (ICPFLOW_OPT_NO_SCORE_PRUNE) -- and the same from run to run, although WHICH scans get pruned depends on timing."""
+    if shape == "config2_256x1024":
+        S, D, _ = synthetic.make_batch(256, 1024, seed=0)
+    elif shape == "config4_shard_1024x2048":
+        S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
+    elif shape == "ragged_600x1024":
+        S, D, _ = synthetic.make_batch(600, 1024, seed=31, ragged=True, n_min=60)
+    else:
+        S, D, _ = synthetic.make_batch(90, 2048, seed=5, ragged=True, n_min=40)
+    a = rp.default_args(max_points=S.shape[1], icp_max_iterations=50)
+    s, d = G(S), G(D)
+    T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    with _lib.options(no_score_sweep=True):
+        T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    with _lib.options(no_score_prune=True):
+        T2, it2 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    assert int(it0) == int(it1) == int(it2) and int(it1) > 0
+    assert torch.equal(T0, T1) and torch.equal(T2, T1)
+    for _ in range(3):
+        assert torch.equal(utils_match.hist_icp(a, s, d), T1)
+
+
 def _adversarial_batch():
     """Cluster pairs built to stress the certificates' bounds: exact distance ties (lattice points, duplicated targets),
     coordinates of a few km (fp32 ulp 2.4e-4 m .. 4.9e-4 m: the rounding of the window bounds and of the moved points is
