@@ -535,7 +535,12 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
                 }
             }
             if (worst <= proven * proven || (cb == 0 && ce == np16)) break;   // proven, or everything scanned
+            const float rPrev = r;
             r = (worst < kInf) ? sqrtf(worst) * (MODE == SWEEP_EVAL ? 1.001f : 1.000002f) : r * 4.0f;
+            // a scan that may still be pruned widens its window by doublings: the lower bound grows with the proven
+            // radius, and a wave whose worst lane is a metre from everything must not pay for a metre of targets
+            // before the scan's running sum has had the chance to end it (config 2: -5 % per step)
+            if (MODE == SWEEP_SCORE && p.prune == 1) r = fminf(r, rPrev * 2.0f);
         }
     }
     // masked sums over this block's queries: sum of Euclidean NN distances (utils_helper.py:30,
