@@ -322,14 +322,15 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
 // joinBefore (hist_icp): event after which the side stream has both clouds sorted (w.grid.presorted)
 int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_t *swap, int B,
                   int N, const float *ex, int lx, const float *ey, int ly, const float *ez, int lz,
-                  float shift, float *Tout, const Opts &o, hipStream_t s, hipEvent_t joinBefore = nullptr)
+                  float shift, float *Tout, const Opts &o, hipStream_t s, hipEvent_t joinBefore = nullptr,
+                  const PairCountFuse *countFuse = nullptr)
 {
     const int lens[3] = {lx, ly, lz};
     // vote with X = dst role, Y = src role (utils_hist.py:69); z-sorted sweep while the sort fits LDS
     // (N <= 16384), all-pairs otherwise -- identical bins either way
     if (N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE))
         ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.zsortC,
-                                            w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s));
+                                            w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s, countFuse));
     else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
     if (o.voteBins != nullptr)   // debug export of the bins the peak search is about to read
@@ -708,31 +709,46 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     Workspace w(d_ws, B, N, L);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s, w.ctrl, sizeof(IcpCtrl), w.scoreAccum,
-                      (size_t)B * 12 * sizeof(double));   // lengths + swap (utils_match.py:139-146) + cleared scratch
+    // lengths + swap (utils_match.py:139-146) + cleared scratch: by the vote's sort itself where one workgroup sorts a
+    // cloud (PairCountFuse), by count_pair otherwise
+    const bool countInSort = N <= kMaxSortN && N <= kChunkSortMinN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE);
+    if (!countInSort)
+        launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s, w.ctrl, sizeof(IcpCtrl), w.scoreAccum,
+                          (size_t)B * 12 * sizeof(double));
     // the axis sort of both clouds (scoring sweep, ICP) runs on the side stream next to the vote
     hipEvent_t join = nullptr;
     JoinGuard guard;   // every return below leaves the side stream joined into s
     const GridScratch *search = search_scratch(w, N, o);
+    SideStream *side = nullptr;
     if (search != nullptr && search->mode == 3 && N >= 64 && o.on(ICPFLOW_OPT_NO_SIDE_STREAM)) {
-        SideStream &side = side_stream();
-        if (side.ok) {
-            ICPFLOW_TRY(hipEventRecord(side.fork, s));
-            ICPFLOW_TRY(hipStreamWaitEvent(side.stream, side.fork, 0));
-            // from here on the side stream belongs to the caller's stream order (and capture): a failed
-            // launch still records the join so that the fork never dangles
-            const hipError_t se = launch_sort_clouds_soa(d_src, d_dst, w.lenA, w.lenC, w.swap, B, N, &w.grid, side.stream);
-            const hipError_t je = hipEventRecord(side.join, side.stream);
-            if (je == hipSuccess) { guard.s = s; guard.join = side.join; }
-            ICPFLOW_TRY(se);
-            ICPFLOW_TRY(je);
-            w.grid.presorted = 1;
-            join = side.join;
-        }
+        side = &side_stream();
+        if (!side->ok) side = nullptr;
+    }
+    if (side != nullptr) {
+        ICPFLOW_TRY(hipEventRecord(side->fork, s));
+        ICPFLOW_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        // from here on the side stream belongs to the caller's stream order (and capture): a failed
+        // launch still records the join so that the fork never dangles.  With the counting folded into the sorts
+        // nothing on the side stream waits for a kernel of this call: the axis sort counts for itself (selfCount).
+        const hipError_t se = launch_sort_clouds_soa(d_src, d_dst, w.lenA, w.lenC, w.swap, B, N, &w.grid, side->stream,
+                                                     countInSort ? 2 : 0);
+        const hipError_t je = hipEventRecord(side->join, side->stream);
+        if (je == hipSuccess) { guard.s = s; guard.join = side->join; }
+        ICPFLOW_TRY(se);
+        ICPFLOW_TRY(je);
+        w.grid.presorted = 1;
+        join = side->join;
+    }
+    PairCountFuse fuse{};
+    if (countInSort) {
+        fuse.swapOut = w.swap;
+        fuse.zero0 = w.ctrl; fuse.bytes0 = sizeof(IcpCtrl);
+        fuse.zero1 = w.scoreAccum; fuse.bytes1 = (size_t)B * 12 * sizeof(double);
     }
     const bool sweepScore = score_by_sweep(N, join != nullptr, o);
     if (int r = run_init_pose(d_src, d_dst, w, w.swap, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
-                              len_z, decode_shift, w.Tinit, o, s, sweepScore ? join : nullptr))
+                              len_z, decode_shift, w.Tinit, o, s, sweepScore ? join : nullptr,
+                              countInSort ? &fuse : nullptr))
         return r;
     if (join != nullptr && !sweepScore) ICPFLOW_TRY(hipStreamWaitEvent(s, join, 0));
     guard.joined();

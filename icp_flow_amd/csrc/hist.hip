@@ -258,6 +258,13 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
 // ---------------------------------------------------------------------------------
 constexpr int kZsortBlock = 1024;
 
+struct ZsortCount {   // lenP != NULL: the kernel counts the valid rows itself (PairCountFuse, kernels.hpp)
+    int32_t *lenP, *lenQ;
+    uint8_t *swap;
+    uint32_t *zero0; unsigned words0;
+    uint32_t *zero1; unsigned words1;
+};
+
 // grid (B, 2): y = 0 sorts cloud P, y = 1 cloud Q; valid rows (flag > 0) first, ascending z
 __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__restrict__ P,
                                                            const float4 *__restrict__ Qc,
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
                                                            float4 *__restrict__ Ps, float4 *__restrict__ Qs,
                                                            uint32_t *__restrict__ bins, int L,
                                                            const float *__restrict__ ez, int len_z,
-                                                           float *__restrict__ keyRec)
+                                                           float *__restrict__ keyRec, ZsortCount cnt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     float *key = reinterpret_cast<float *>(dynLds);
@@ -274,6 +281,30 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
     __shared__ float bbScratch[6 * (kZsortBlock / kWave)];
     __shared__ float keyShared[kVoteKeyStride];
     const int b = blockIdx.x;
+    int cntP, cntQ;
+    if (cnt.lenP != nullptr) {
+        // count_pair_kernel's work (lengths, swap flag, cleared scratch) done here: one launch less per registration
+        const unsigned stride = gridDim.x * gridDim.y * kZsortBlock;
+        const unsigned first = (blockIdx.y * gridDim.x + blockIdx.x) * kZsortBlock + threadIdx.x;
+        for (unsigned k = first; k < cnt.words0; k += stride) cnt.zero0[k] = 0u;
+        for (unsigned k = first; k < cnt.words1; k += stride) cnt.zero1[k] = 0u;
+        __shared__ int cntScratch[2 * (kZsortBlock / kWave)];
+        const float4 *pp = P + (size_t)b * N, *pq = Qc + (size_t)b * N;
+        int c[2] = {0, 0};
+        for (int i = threadIdx.x; i < N; i += kZsortBlock) {
+            c[0] += (pp[i].w > 0.0f) ? 1 : 0;
+            c[1] += (pq[i].w > 0.0f) ? 1 : 0;
+        }
+        block_sum<2, int>(c, cntScratch);
+        cntP = c[0]; cntQ = c[1];
+        if (blockIdx.y == 0 && threadIdx.x == 0) {
+            cnt.lenP[b] = cntP;
+            cnt.lenQ[b] = cntQ;
+            if (cnt.swap != nullptr) cnt.swap[b] = cntQ > cntP ? 1 : 0;   // Q is the src role (utils_match.py:139-146)
+        }
+    } else {
+        cntP = nP[b]; cntQ = nQ[b];
+    }
     const float4 *in = (blockIdx.y == 0 ? P : Qc) + (size_t)b * N;
     float4 *out = (blockIdx.y == 0 ? Ps : Qs) + (size_t)b * N;
     // the vote that follows wants zeroed counters: each of the pair's two blocks clears one half
@@ -286,9 +317,9 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
     }
     // pad_segment layout (valid rows first): only the first n rows can be valid, and the network
     // only has to hold them -- next power of two >= n instead of >= N
-    const int n = min((blockIdx.y == 0 ? nP : nQ)[b], N);
+    const int n = min(blockIdx.y == 0 ? cntP : cntQ, N);
     // sort key of this pair (votekey.hpp): z, or (z slab, long horizontal axis) for wide clusters
-    const VoteKey vk = vote_key_params(P + (size_t)b * N, min(nP[b], N), Qc + (size_t)b * N, min(nQ[b], N),
+    const VoteKey vk = vote_key_params(P + (size_t)b * N, min(cntP, N), Qc + (size_t)b * N, min(cntQ, N),
                                        ez[len_z - 1] - ez[0], bbScratch, keyShared);
     if (blockIdx.y == 0 && threadIdx.x < kVoteKeyStride) keyRec[(size_t)b * kVoteKeyStride + threadIdx.x] = keyShared[threadIdx.x];
     int NP2 = kWave;
@@ -423,11 +454,13 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     }
 }
 
-hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t *nX, const int32_t *nY,
+hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, int32_t *nY,
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
-                                   uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s)
+                                   uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
+                                   const PairCountFuse *fuse)
 {
+    if (fuse != nullptr && N > kChunkSortMinN) return hipErrorInvalidValue;   // only zsort_kernel counts
     const size_t L = (size_t)lens[0] * lens[1] * lens[2];
     int NP2 = 64;
     while (NP2 < N) NP2 <<= 1;
@@ -440,9 +473,15 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t
                                             keyRec, s);
         if (e != hipSuccess) return e;
     } else {
+        ZsortCount zc{};
+        if (fuse != nullptr) {
+            zc.lenP = nX; zc.lenQ = nY; zc.swap = fuse->swapOut;
+            zc.zero0 = (uint32_t *)fuse->zero0; zc.words0 = (unsigned)(fuse->bytes0 / 4);
+            zc.zero1 = (uint32_t *)fuse->zero1; zc.words1 = (unsigned)(fuse->bytes1 / 4);
+        }
         hipLaunchKernelGGL(zsort_kernel, dim3(B, 2), dim3(kZsortBlock), (size_t)NP2 * 8, s, (const float4 *)X,
                            (const float4 *)Y, nX, nY, N, NP2, (float4 *)sortX, (float4 *)sortY, bins_u32, (int)L, ez,
-                           lens[2], keyRec);
+                           lens[2], keyRec, zc);
     }
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
     const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;

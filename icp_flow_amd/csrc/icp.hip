@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const int32_t *__restrict__ lenX,
     const int32_t *__restrict__ lenY, const uint8_t *__restrict__ swap, const float *__restrict__ prePose,
     int N, int NP2, int32_t *__restrict__ axisOut, float4 *__restrict__ Xs, float4 *__restrict__ Ys,
-    float *__restrict__ Ysoa, float *__restrict__ Xsoa)
+    float *__restrict__ Ysoa, float *__restrict__ Xsoa, int selfCount)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     float *key = reinterpret_cast<float *>(dynLds);
@@ -217,10 +217,29 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     __shared__ int axisSh;
     const int b = blockIdx.x, tid = threadIdx.x;
     const bool moving = blockIdx.y == 1;
-    const bool sw = swap != nullptr && swap[b] != 0;
+    int cX, cY;
+    bool sw;
+    if (selfCount) {
+        // hist_icp on the side stream, forked before anything has counted: the lengths (rows with a positive flag) and
+        // the smaller-cloud-first flag exactly as count_pair_kernel / zsort_kernel form them; lenX / lenY / swap unread
+        __shared__ int cntScratch[2 * (kSortBlock / kWave)];
+        const float4 *px = reinterpret_cast<const float4 *>(X) + (size_t)b * N;
+        const float4 *py = reinterpret_cast<const float4 *>(Y) + (size_t)b * N;
+        int c[2] = {0, 0};
+        for (int i = tid; i < N; i += kSortBlock) {
+            c[0] += (px[i].w > 0.0f) ? 1 : 0;
+            c[1] += (py[i].w > 0.0f) ? 1 : 0;
+        }
+        block_sum<2, int>(c, cntScratch);
+        cX = c[0]; cY = c[1];
+        sw = selfCount == 2 && cX > cY;
+    } else {
+        cX = lenX[b]; cY = lenY[b];
+        sw = swap != nullptr && swap[b] != 0;
+    }
     const float4 *xb = reinterpret_cast<const float4 *>(sw ? Y : X) + (size_t)b * N;  // moving role
     const float4 *yb = reinterpret_cast<const float4 *>(sw ? X : Y) + (size_t)b * N;  // fixed role
-    const int nx = (sw ? lenY : lenX)[b], ny = (sw ? lenX : lenY)[b];
+    const int nx = sw ? cY : cX, ny = sw ? cX : cY;
     // axis of largest extent of the fixed cloud (both blocks compute it the same way)
     float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
     for (int j = tid; j < ny; j += kSortBlock) {
@@ -1719,7 +1738,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         } else
         hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY,
                            swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts, grid->sortYsoa,
-                           (float *)nullptr);
+                           (float *)nullptr, 0);
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
@@ -1803,9 +1822,12 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
 
 // both clouds of every pair sorted along the fixed cloud's longest axis, without a pre-pose, with
 // structure-of-arrays images of BOTH: input of the scoring sweep (nn.hip)
+// selfCount (single-workgroup sorts only, N <= kChunkSortMinN): 1 = the kernel counts the valid rows itself, 2 = and
+// forms the smaller-cloud-first flag itself (X = src); lenX / lenY / swap are then not read
 hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
-                                  const uint8_t *swap, int B, int N, const GridScratch *grid, hipStream_t s)
+                                  const uint8_t *swap, int B, int N, const GridScratch *grid, hipStream_t s, int selfCount)
 {
+    if (selfCount != 0 && N > kChunkSortMinN) return hipErrorInvalidValue;
     int NP2 = 64;
     while (NP2 < N) NP2 <<= 1;
     if ((size_t)NP2 * 8 > 64 * 1024)
@@ -1815,7 +1837,7 @@ hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t 
                                           grid->sortYsoa, grid->sortXsoa, grid->ckey, grid->cidx, s);
     hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY, swap,
                        (const float *)nullptr, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts,
-                       grid->sortYsoa, grid->sortXsoa);
+                       grid->sortYsoa, grid->sortXsoa, selfCount);
     return hipGetLastError();
 }
 

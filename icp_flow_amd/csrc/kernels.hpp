@@ -65,10 +65,18 @@ hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int N
                             const float mins[3], const float maxs[3], const int lens[3],
                             const float *ex, const float *ey, const float *ez,
                             const uint8_t *swap, uint32_t *bins_u32, hipStream_t s);
-hipError_t launch_hist_vote_sorted(const float *X, const float *Y, const int32_t *nX, const int32_t *nY,
+// count_pair folded into the vote's sort (zsort_kernel, N <= kChunkSortMinN): the sort counts the valid rows of both
+// clouds itself, writes nX / nY / swapOut (swapOut[b] = nY > nX: Y is the src role) and clears the two scratch buffers.
+struct PairCountFuse {
+    uint8_t *swapOut;
+    void *zero0; size_t bytes0;
+    void *zero1; size_t bytes1;
+};
+hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, int32_t *nY,
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
-                                   uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s);
+                                   uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
+                                   const PairCountFuse *fuse = nullptr);
 // sort.hip: several workgroups per long cloud; same outputs as zsort_kernel / sort_clouds_kernel
 constexpr int kChunkSortMinN = 4096;
 int chunk_sort_length(int N);
@@ -172,7 +180,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
                       const GridScratch *grid, float *history, const IcpTeam *team, const IcpOpts &opts,
                       hipStream_t s);
 hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
-                                  const uint8_t *swap, int B, int N, const GridScratch *grid, hipStream_t s);
+                                  const uint8_t *swap, int B, int N, const GridScratch *grid, hipStream_t s, int selfCount = 0);
 LaunchProfile *profile_create(int capacity, hipError_t *err);
 void profile_destroy(LaunchProfile *p);
 hipError_t profile_collect(LaunchProfile *p, double *total_ms, int *launches);

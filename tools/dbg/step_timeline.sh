@@ -10,7 +10,7 @@ python - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/step_timeline/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'count_pair' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'zsort_kernel' in r['Kernel_Name'] or 'chunk_sort' in r['Kernel_Name']]
 start = idx[-1]
 t0 = int(rows[start]['Start_Timestamp'])
 for r in rows[start:]:
