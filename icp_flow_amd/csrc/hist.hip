@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
     int64_t *__restrict__ idx_out, PeakDecode dec)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned long long red[kPeakBlock / kWave];
+    __shared__ unsigned long long red[(kPeakBlock / kWave) * kPeakMaxK];   // the waves' k largest keys
     __shared__ unsigned long long chosen[kPeakMaxK];
     const int b = blockIdx.x;
     const int L = Lx * Ly * Lz;
@@ -615,37 +615,51 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
     }
 #undef ICPFLOW_PEAK_ADVANCE
     __syncthreads();
-    // surviving vote = h where h == window max, else 0 (utils_hist.py:25-26);
-    // k selection rounds, order (vote desc, flat index asc).  A thread's best remaining key only changes when it was
-    // the one chosen: everybody else carries its key into the next round.
-    unsigned long long best = 0ull;
-    bool stale = true;
-    for (int r = 0; r < k; ++r) {
-        if (stale) {
-            best = 0ull;
-            bool have = false;
-            for (int f = tid; f < L; f += kPeakBlock) {
-                const uint32_t v = MEM ? H0[f] : (uint32_t)h[f];
-                const uint32_t s = (v == A[f]) ? v : 0u;
-                const unsigned long long key =
-                    ((unsigned long long)s << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)f);
-                bool taken = false;
-                for (int q = 0; q < r; ++q) taken |= (chosen[q] == key);
-                if (!taken && (!have || key > best)) { best = key; have = true; }
+    // surviving vote = h where h == window max, else 0 (utils_hist.py:25-26); selection order (vote desc, flat index
+    // asc) on the key (vote << 32 | ~index).  Every wave first finds ITS k largest keys with wave reductions only (the
+    // global top k is a subset of the union of the waves' top k); one barrier; wave 0 then picks the k largest of those
+    // 16 k keys -- one barrier instead of two per round.  A thread's keys are distinct, so when its best one was taken
+    // its next one is the largest below it.
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    unsigned long long *wtop = reinterpret_cast<unsigned long long *>(red);   // [waves][kPeakMaxK], see the declaration
+    {
+        unsigned long long below = ~0ull, best = 0ull;
+        bool stale = true;
+        for (int r = 0; r < k; ++r) {
+            if (stale) {
+                best = 0ull;
+                for (int f = tid; f < L; f += kPeakBlock) {
+                    const uint32_t v = MEM ? H0[f] : (uint32_t)h[f];
+                    const uint32_t sv = (v == A[f]) ? v : 0u;
+                    const unsigned long long key =
+                        ((unsigned long long)sv << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)f);
+                    if (key < below && key > best) best = key;
+                }
+                stale = false;   // (0 can only be "nothing left": the index bits of a real bin are never all zero)
             }
-            stale = false;   // (keys are unique -- index bits --, 0 can only be "nothing left")
+            const unsigned long long w = wave_max_u64_dpp(best);
+            if (lane == 0) wtop[wave * kPeakMaxK + r] = w;
+            if (w == best && w != 0ull) { below = best; stale = true; }   // mine was taken: look for my next one
         }
-        unsigned long long w = wave_max_u64_dpp(best);
-        if ((tid & (kWave - 1)) == 0) red[tid >> 6] = w;
-        __syncthreads();
-        {
-            unsigned long long m = red[0];
-            for (int q = 1; q < kPeakBlock / kWave; ++q) m = red[q] > m ? red[q] : m;
-            if (tid == 0) chosen[r] = m;
-            if (m == best && m != 0ull) stale = true;   // mine was taken: look for my next one
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    if (wave == 0) {
+        constexpr int kWaves = kPeakBlock / kWave;
+        // candidate c = lane, lane + 64, ... of the kWaves * k keys (at most two per lane)
+        unsigned long long c0 = 0ull, c1 = 0ull;
+        {
+            const int n = kWaves * k;
+            if (lane < n) c0 = wtop[(lane / k) * kPeakMaxK + lane % k];
+            if (lane + kWave < n) c1 = wtop[((lane + kWave) / k) * kPeakMaxK + (lane + kWave) % k];
+        }
+        for (int r = 0; r < k; ++r) {
+            const unsigned long long m = wave_max_u64_dpp(c0 > c1 ? c0 : c1);
+            if (lane == 0) chosen[r] = m;
+            if (c0 == m) c0 = 0ull;
+            if (c1 == m) c1 = 0ull;
+        }
+    }
+    __syncthreads();
     // outputs: thread r writes peak r (and its candidate translation on the fused path)
     if (tid < k) {
         const int r = tid;
