@@ -19,4 +19,4 @@ torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): run()
 torch.cuda.synchronize(); pr.disable()
-st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("ROWS", "28")))
