@@ -345,7 +345,12 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
     }
 }
 
-__global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
+// BLOCK: X rows (threads) per workgroup.  The counters in LDS (20 KiB for 41 x 41 x 3 bins) limit a CU to four
+// workgroups whatever their size: batches that leave workgroups waiting take 512 rows -- eight waves share the counters,
+// 32 waves per CU instead of 16 (config 4's shard: vote 1.66 -> 1.44 ms); batches that fit keep 256 (more, smaller
+// workgroups spread better over the CUs).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     const float4 *__restrict__ Xs, const float4 *__restrict__ Ys, const int32_t *__restrict__ nXv,
     const int32_t *__restrict__ nYv, int N, int len_x, int len_y, int len_z,
     const float *__restrict__ ex, const float *__restrict__ ey, const float *__restrict__ ez,
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     // blockIdx.x = row block * tsplit + share: on long clouds the Y tiles are dealt to `tsplit` workgroups
     // per row block (kVoteSpan tiles each), so that one huge pair does not pace the launch
     const int tsplit = (N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile);
-    const int row0 = (blockIdx.x / tsplit) * kVoteBlock;
+    const int row0 = (blockIdx.x / tsplit) * BLOCK;
     const int jBegin = (blockIdx.x % tsplit) * kVoteSpan * kVoteTile;
     if (row0 >= nx || jBegin >= ny) return;  // sorted: valid rows first
     const float min_x = ex[0], max_x = ex[len_x - 1];
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (xvalid) xi = xb[i];
     if (useLds) {
-        for (int k = threadIdx.x; k < L; k += kVoteBlock) lhist[k] = 0u;
+        for (int k = threadIdx.x; k < L; k += BLOCK) lhist[k] = 0u;
     }
     const AxisQuot dqx = axis_quot_make(min_x, max_x), dqy = axis_quot_make(min_y, max_y), dqz = axis_quot_make(min_z, max_z);
     const bool allFast = dqx.fast && dqy.fast && dqz.fast && (long long)len_x * len_y < (1 << 23) && len_z < (1 << 23);
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     for (int j0 = jBegin; j0 < jEnd; j0 += kVoteTile) {
         const int tn = min(kVoteTile, jEnd - j0);
         __syncthreads();  // previous tile fully consumed (and lhist zeroed)
-        for (int k = threadIdx.x; k < tn; k += kVoteBlock) tile[k] = yb[j0 + k];
+        for (int k = threadIdx.x; k < tn; k += BLOCK) tile[k] = yb[j0 + k];
         __syncthreads();
         if (!(zlo <= zhi)) continue;  // wave without valid rows (wave-uniform)
         const float *zkey = reinterpret_cast<const float *>(tile) + 3;   // the sort key rides in w
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_sorted_kernel(
     }
     if (useLds) {
         __syncthreads();
-        for (int k = threadIdx.x; k < L; k += kVoteBlock) {
+        for (int k = threadIdx.x; k < L; k += BLOCK) {
             const uint32_t v = lhist[k];
             if (v) atomicAdd(&gb[k], v);
         }
@@ -487,10 +492,18 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
     const int useLds = lds_hist <= 64 * 1024;
     const int tsplit = (N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile);
-    dim3 grid(((N + kVoteBlock - 1) / kVoteBlock) * tsplit, B);
-    hipLaunchKernelGGL(hist_vote_sorted_kernel, grid, dim3(kVoteBlock), useLds ? lds_hist : tile_bytes, s,
-                       (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                       ez, swap, useLds, bins_u32, keyRec);
+    const long long wgs256 = (long long)((N + kVoteBlock - 1) / kVoteBlock) * tsplit * B;
+    if (wgs256 > 4LL * device_cus()) {
+        dim3 grid(((N + 511) / 512) * tsplit, B);
+        hipLaunchKernelGGL(hist_vote_sorted_kernel<512>, grid, dim3(512), useLds ? lds_hist : tile_bytes, s,
+                           (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
+                           ez, swap, useLds, bins_u32, keyRec);
+    } else {
+        dim3 grid(((N + kVoteBlock - 1) / kVoteBlock) * tsplit, B);
+        hipLaunchKernelGGL(hist_vote_sorted_kernel<kVoteBlock>, grid, dim3(kVoteBlock), useLds ? lds_hist : tile_bytes, s,
+                           (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
+                           ez, swap, useLds, bins_u32, keyRec);
+    }
     return hipGetLastError();
 }
 
