@@ -129,7 +129,8 @@ hipError_t launch_vote_quotient_probe(const float *a, int n, float mn, float mx,
 
 constexpr int kVoteBlock = 256;  // threads; one X row per thread per slice
 constexpr int kVoteTile = 1024;  // Y points staged in LDS per step (16 KiB)
-constexpr int kVoteSpan = 2;     // sorted vote: Y tiles per workgroup
+constexpr int kVoteSpan = 2;     // sorted vote: Y tiles per workgroup (at most)
+
 
 // The votes of one X row (per lane) against the staged targets [r0, r1) (wave-uniform bounds): the exact
 // box test and bin arithmetic of hist_cuda_core.cuh:44-60.  FAST: all three quotients take the hoisted
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     const int32_t *__restrict__ nYv, int N, int len_x, int len_y, int len_z,
     const float *__restrict__ ex, const float *__restrict__ ey, const float *__restrict__ ez,
     const uint8_t *__restrict__ swap, int useLds, uint32_t *__restrict__ bins_u32,
-    const float *__restrict__ keyRec)
+    const float *__restrict__ keyRec, int span)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
@@ -367,10 +368,10 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     const float4 *yb = (sw ? Xs : Ys) + (size_t)b * N;
     const int nx = (sw ? nYv : nXv)[b], ny = (sw ? nXv : nYv)[b];
     // blockIdx.x = row block * tsplit + share: on long clouds the Y tiles are dealt to `tsplit` workgroups
-    // per row block (kVoteSpan tiles each), so that one huge pair does not pace the launch
-    const int tsplit = (N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile);
+    // per row block (`span` sorted Y rows each), so that one huge pair does not pace the launch
+    const int tsplit = (N + span - 1) / span;
     const int row0 = (blockIdx.x / tsplit) * BLOCK;
-    const int jBegin = (blockIdx.x % tsplit) * kVoteSpan * kVoteTile;
+    const int jBegin = (blockIdx.x % tsplit) * span;
     if (row0 >= nx || jBegin >= ny) return;  // sorted: valid rows first
     const float min_x = ex[0], max_x = ex[len_x - 1];
     const float min_y = ey[0], max_y = ey[len_y - 1];
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
         slabLo = (int)floorf((wlo - vk.z0) / vk.h);
         slabHi = (int)floorf((whi - vk.z0) / vk.h);
     }
-    const int jEnd = min(ny, jBegin + kVoteSpan * kVoteTile);
+    const int jEnd = min(ny, jBegin + span);
     for (int j0 = jBegin; j0 < jEnd; j0 += kVoteTile) {
         const int tn = min(kVoteTile, jEnd - j0);
         __syncthreads();  // previous tile fully consumed (and lhist zeroed)
@@ -491,18 +492,29 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
     const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
     const int useLds = lds_hist <= 64 * 1024;
-    const int tsplit = (N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile);
-    const long long wgs256 = (long long)((N + kVoteBlock - 1) / kVoteBlock) * tsplit * B;
-    if (wgs256 > 4LL * device_cus()) {
+    // Workgroup shape.  The counters in LDS limit a CU to four workgroups whatever their size: batches that leave
+    // workgroups waiting take 512 rows per workgroup -- eight waves share the counters, 32 waves per CU instead of 16
+    // (config 4's shard: vote 1.66 -> 1.44 ms); batches that fit keep 256 (config 2: the same either way).  Batches too
+    // small to give every SIMD two waves (a frame's candidate pairs) deal the sorted Y rows of a pair to several
+    // workgroups, `span` rows each (64 x 1024: -2 % per registration; on a batch that fills the GPU the extra window
+    // searches and counter flushes cost 13 %).
+    const int cus = device_cus();
+    const long long wgs256 = (long long)((N + kVoteBlock - 1) / kVoteBlock) * ((N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile)) * B;
+    const int block = wgs256 > 4LL * cus ? 512 : kVoteBlock;
+    int span = kVoteSpan * kVoteTile;
+    const long long waves = (long long)((N + kWave - 1) / kWave) * B;
+    while (span > 256 && waves * ((N + span - 1) / span) < 8LL * cus) span >>= 1;
+    const int tsplit = (N + span - 1) / span;
+    if (block == 512) {
         dim3 grid(((N + 511) / 512) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<512>, grid, dim3(512), useLds ? lds_hist : tile_bytes, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                           ez, swap, useLds, bins_u32, keyRec);
+                           ez, swap, useLds, bins_u32, keyRec, span);
     } else {
         dim3 grid(((N + kVoteBlock - 1) / kVoteBlock) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<kVoteBlock>, grid, dim3(kVoteBlock), useLds ? lds_hist : tile_bytes, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                           ez, swap, useLds, bins_u32, keyRec);
+                           ez, swap, useLds, bins_u32, keyRec, span);
     }
     return hipGetLastError();
 }
