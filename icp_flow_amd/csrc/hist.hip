@@ -370,16 +370,21 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     // blockIdx.x = row block * tsplit + share: on long clouds the Y tiles are dealt to `tsplit` workgroups
     // per row block (`span` sorted Y rows each), so that one huge pair does not pace the launch
     const int tsplit = (N + span - 1) / span;
-    const int row0 = (blockIdx.x / tsplit) * BLOCK;
+    // The rows are sorted by z and a wave's work grows with the number of targets inside its z window: the slabs in the
+    // middle of a cloud take twice as long as those at its ends.  So the waves of a pair are dealt to its workgroups
+    // round robin -- wave w of row block rb takes the 64 rows of global wave w * rowBlocks + rb -- and every workgroup
+    // gets slabs from everywhere (SQ counters before: 7.5 of a CU's 16 waves resident on average).
+    const int rowBlocks = (N + BLOCK - 1) / BLOCK;
+    const int rb = blockIdx.x / tsplit;
     const int jBegin = (blockIdx.x % tsplit) * span;
-    if (row0 >= nx || jBegin >= ny) return;  // sorted: valid rows first
+    if (rb * kWave >= nx || jBegin >= ny) return;  // sorted: valid rows first (rb * 64: the first row of wave 0)
     const float min_x = ex[0], max_x = ex[len_x - 1];
     const float min_y = ey[0], max_y = ey[len_y - 1];
     const float min_z = ez[0], max_z = ez[len_z - 1];
     const int L = len_x * len_y * len_z;
     uint32_t *gb = bins_u32 + (size_t)b * L;
     const int lane = threadIdx.x & (kWave - 1);
-    const int i = row0 + threadIdx.x;
+    const int i = ((int)(threadIdx.x >> 6) * rowBlocks + rb) * kWave + lane;
     const bool xvalid = i < nx;
     float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (xvalid) xi = xb[i];
