@@ -501,16 +501,24 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     // workgroups waiting take 512 rows per workgroup -- eight waves share the counters, 32 waves per CU instead of 16
     // (config 4's shard: vote 1.66 -> 1.44 ms); batches that fit keep 256 (config 2: the same either way).  Batches too
     // small to give every SIMD two waves (a frame's candidate pairs) deal the sorted Y rows of a pair to several
-    // workgroups, `span` rows each (64 x 1024: -2 % per registration; on a batch that fills the GPU the extra window
+    // workgroups of 1024 rows, `span` Y rows each (64 x 1024: -5 % per registration; on a batch that fills the GPU the extra window
     // searches and counter flushes cost 13 %).
     const int cus = device_cus();
     const long long wgs256 = (long long)((N + kVoteBlock - 1) / kVoteBlock) * ((N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile)) * B;
-    const int block = wgs256 > 4LL * cus ? 512 : kVoteBlock;
+    int block = wgs256 > 4LL * cus ? 512 : kVoteBlock;
     int span = kVoteSpan * kVoteTile;
     const long long waves = (long long)((N + kWave - 1) / kWave) * B;
-    while (span > 256 && waves * ((N + span - 1) / span) < 8LL * cus) span >>= 1;
+    if (waves < 8LL * cus) {   // (1024 rows share one set of counters: the split's zeroing and flushing cost the least)
+        block = 1024;
+        while (span > 256 && waves * ((N + span - 1) / span) < 32LL * cus) span >>= 1;
+    }
     const int tsplit = (N + span - 1) / span;
-    if (block == 512) {
+    if (block == 1024) {
+        dim3 grid(((N + 1023) / 1024) * tsplit, B);
+        hipLaunchKernelGGL(hist_vote_sorted_kernel<1024>, grid, dim3(1024), useLds ? lds_hist : tile_bytes, s,
+                           (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
+                           ez, swap, useLds, bins_u32, keyRec, span);
+    } else if (block == 512) {
         dim3 grid(((N + 511) / 512) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<512>, grid, dim3(512), useLds ? lds_hist : tile_bytes, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
