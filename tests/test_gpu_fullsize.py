@@ -206,6 +206,27 @@ def test_scoring_variants_change_nothing(shape):
         assert torch.equal(utils_match.hist_icp(a, s, d), T1)
 
 
+@pytest.mark.parametrize("shape", ["config2_256x1024", "ragged_90x2048", "long_clouds_6x6000"])
+def test_launch_plumbing_variants_change_nothing(shape):
+    """hist_icp's launch plumbing: where one workgroup sorts a cloud (N <= 4096) the vote's sort counts the valid rows,
+    writes lengths and swap flag and clears the scratch, and the axis sort on the side stream counts for itself;
+    count_pair_kernel does it otherwise.  Without the side stream (ICPFLOW_OPT_NO_SIDE_STREAM), with the all-pairs vote
+    (ICPFLOW_OPT_NO_SORTED_VOTE: count_pair, identical bins) and with both, the registrations are the same bit for bit."""
+    if shape == "config2_256x1024":
+        S, D, _ = synthetic.make_batch(256, 1024, seed=0)
+    elif shape == "ragged_90x2048":
+        S, D, _ = synthetic.make_batch(90, 2048, seed=5, ragged=True, n_min=40)
+    else:
+        S, D, _ = synthetic.make_batch(6, 6000, seed=9, ragged=True, n_min=3000)
+    a = rp.default_args(max_points=S.shape[1], icp_max_iterations=50)
+    s, d = G(S), G(D)
+    T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    for opts in ({"no_side_stream": True}, {"no_sorted_vote": True}, {"no_side_stream": True, "no_sorted_vote": True}):
+        with _lib.options(**opts):
+            T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert int(it0) == int(it1) and torch.equal(T0, T1), opts
+
+
 def _adversarial_batch():
     """Cluster pairs built to stress the certificates' bounds: exact distance ties (lattice points, duplicated targets),
     coordinates of a few km (fp32 ulp 2.4e-4 m .. 4.9e-4 m: the rounding of the window bounds and of the moved points is
