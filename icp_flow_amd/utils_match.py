@@ -85,16 +85,29 @@ def _gather_pair_batches(args, st, dt, si, di):
     return segs[0], segs[1]
 
 
-def _match_pairs_host(args, st, dt, pairs):
-    """utils_match.py:69-136 on numpy candidate `pairs` [K,2] -> (pairs [P,10], transforms [P,4,4]) numpy."""
+def _launch_pairs(args, st, dt, pairs):
+    """The device half of utils_match.py:69-136 for numpy candidate `pairs` [K,2]: gather, hist_icp, match_eval, all
+    asynchronous.  -> what _finish_pairs needs (host work placed between the two overlaps the kernels)."""
     si, di = st.find_host(pairs[:, 0]), dt.find_host(pairs[:, 1])
     assert (si >= 0).all() and (di >= 0).all()
     segs_src, segs_dst = _gather_pair_batches(args, st, dt, si, di)
     T, iters = hist_icp(args, segs_src, segs_dst, return_iterations=True)
     ev = match_eval(args, segs_src, segs_dst, T)
     B = len(pairs)
-    r = torch.cat([T.reshape(B, 16)] + [e.reshape(B, -1) for e in ev] + [iters.float().expand(B, 1)],
-                  dim=1).cpu().numpy()                                                             # the one sync
+    r = torch.cat([T.reshape(B, 16)] + [e.reshape(B, -1) for e in ev] + [iters.float().expand(B, 1)], dim=1)
+    return si, di, r
+
+
+def _match_pairs_host(args, st, dt, pairs):
+    """utils_match.py:69-136 on numpy candidate `pairs` [K,2] -> (pairs [P,10], transforms [P,4,4]) numpy."""
+    return _finish_pairs(args, st, dt, _launch_pairs(args, st, dt, pairs))
+
+
+def _finish_pairs(args, st, dt, launched):
+    """The host half: ONE device -> host transfer of the [B, 31] results, reject test, S x D matrices, row arg-min."""
+    si, di, r = launched
+    B = len(si)
+    r = r.cpu().numpy()                                                                            # the one sync
     if r[0, -1] < 0:
         # a team of workgroups sharing one large pair gave up waiting for a member (include/icpflow_hip.h, a-5):
         # the transforms are NaN.  Never let that pass as "no match" -- the points would silently get ego flow only.
@@ -156,7 +169,11 @@ def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
     pairs = np.stack([labels_unq, labels_unq], axis=1)
     pairs = pairs[np.minimum(pairs[:, 0], pairs[:, 1]) >= 0].astype(np.float32)                  # :30-31
     pairs_true = pairs[_sanity_mask(args, st, dt, pairs)] if len(pairs) else pairs
-    pairs_sta, T_sta = _match_pairs_host(args, st, dt, pairs_true) if len(pairs_true) > 0 else empty
+    launched = _launch_pairs(args, st, dt, pairs_true) if len(pairs_true) > 0 else None
+    # while stage 1 runs on the GPU: the sanity test of EVERY source cluster against every destination cluster (stage 2
+    # reads the rows and columns of the clusters stage 1 leaves unmatched)
+    grid = sanity_grid(args, st, dt, np.arange(len(src_unq)), np.arange(len(dst_unq))) if len(src_unq) and len(dst_unq) else None
+    pairs_sta, T_sta = _finish_pairs(args, st, dt, launched) if launched is not None else empty
 
     if len(pairs_sta) < len(labels_unq):                                                          # :42
         if len(pairs_sta) > 0:
@@ -165,7 +182,7 @@ def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
         # every remaining source against every remaining destination (:45-53), tested on the S x D grid;
         # surviving candidates in the reference's order (source-major)
         si, di = st.find_host(src_unq.astype(np.float32)), dt.find_host(dst_unq.astype(np.float32))
-        rs, rd = np.nonzero(sanity_grid(args, st, dt, si, di)) if len(si) and len(di) else (si[:0], di[:0])
+        rs, rd = np.nonzero(grid[np.ix_(si, di)]) if len(si) and len(di) else (si[:0], di[:0])
         pairs_true = np.stack([src_unq[rs], dst_unq[rd]], axis=1).astype(np.float32).reshape(-1, 2)
     else:
         pairs_true = pairs[:0]
