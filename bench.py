@@ -11,10 +11,13 @@ check) of every pair of the workload, inputs resident in HBM before the timed re
   --gpus 1  (headline) BASELINE config 2: 256 cluster pairs x 1024 points.
   --gpus N  (N > 1)    BASELINE config 4: 8192 cluster pairs x 2048 points in total, contiguous blocks of
             8192/N pairs per rank (sharding.shard_range; pair k is synthetic pair k on every N), STRONG scaling;
-            the [B,4,4] transforms are all-gathered over RCCL inside the timed region -- the path has no other
-            exchange step.  The single-GPU line carries the same workload on one GPU (`config4_on_one_gpu`) so
-            that the scaling curve has its N = 1 point.
+            every step ends with the exchange the sharded product issues: match_eval fills the 40-byte
+            pair row, and ONE RCCL all_gather of [B,26] rows (transform + pair row, sharding.pack_rows) runs inside the
+            timed region -- the path has no other exchange step.  The single-GPU line carries the same workload on
+            one GPU (`config4_on_one_gpu`) so that the scaling curve has its N = 1 point.
   --workload config2|config4 overrides the choice.
+  --force-collective   world of ONE rank: initialise RCCL anyway and run the all_gather (single-GPU boxes exercise the
+            N > 1 code path); --check-gather compares the gathered rows with the local ones.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -49,6 +52,8 @@ def parse():
     ap.add_argument("--stop-mode", default="reference", choices=["reference", "per_pair"])
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements")
+    ap.add_argument("--force-collective", action="store_true", help="one rank: init RCCL and all_gather anyway")
+    ap.add_argument("--check-gather", action="store_true", help="compare the gathered rows with the local ones")
     return ap.parse_args()
 
 
@@ -83,13 +88,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    collective = world > 1 or a.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from icp_flow_amd import _lib, synthetic, utils_match
-    from icp_flow_amd.sharding import gather_results, shard_range
+    from icp_flow_amd.sharding import gather_results, pack_rows, shard_range, unpack_rows
 
     workload = a.workload if a.workload != "auto" else ("config2" if world == 1 else "config4")
     if workload == "config2":        # weak: every rank its own 256 pairs (only ever run with --gpus 1 by default)
@@ -111,17 +118,32 @@ def main():
 
     def step():
         T, iters = utils_match.hist_icp(args, src, dst, return_iterations=True)
-        if world > 1:
-            T = gather_results(T, world, counts=counts)          # ONE RCCL all_gather over xGMI, no host sync
+        if collective:
+            # what the sharded product exchanges: transform + the 40-byte pair row, ONE RCCL all_gather
+            # over xGMI of [B,26] float32 rows, no host sync (every rank knows all counts from shard_range)
+            ev = utils_match.match_eval(args, src, dst, T)
+            rows = pack_rows(T, first, ev[0], ev[1], ev[2], ev[3])
+            T = gather_results(rows, world, counts=counts, force_collective=True)
         return T, iters
 
     def sync():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     dt, icp_ms, icp_launches, T, iters = timed_steps(step, sync, a.steps, a.warmup, a.iters)
-    if world > 1:
+    gather_check = None
+    if collective:
+        if a.check_gather:      # the rows this rank contributed, as every rank received them
+            Tl, _ = utils_match.hist_icp(args, src, dst, return_iterations=True)
+            ev = utils_match.match_eval(args, src, dst, Tl)
+            mine = pack_rows(Tl, first, ev[0], ev[1], ev[2], ev[3])
+            gather_check = {"rows": list(T.shape), "identical_to_local_rows": bool(torch.equal(T[first:first + B], mine)),
+                            "pair_index_column_ok": bool(torch.equal(T[:, 16], torch.arange(total, device=dev, dtype=torch.float32))),
+                            "backend": dist.get_backend(),
+                            "rccl_library": next((ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln or "libnccl" in ln), None)}
+        T = unpack_rows(T)[0]
+    if collective:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -130,7 +152,7 @@ def main():
         raise SystemExit("hist_icp abandoned a batch (team timeout): the measurement is void")
 
     if rank != 0:
-        if world > 1:
+        if collective:
             dist.destroy_process_group()
         return
 
@@ -161,8 +183,10 @@ def main():
         "config": {"workload": f"{name}, <= {a.iters} ICP iters ({a.stop_mode} stop), thres_dist 0.1, "
                                f"translation_frame 2.0 (41x41x3 bins)",
                    "pairs_total": total, "pairs_per_gpu": counts, "points": N, "icp_iteration_cap": a.iters,
-                   "stop_mode": a.stop_mode, "sharding": f"contiguous blocks of pairs over {world} rank(s), "
-                                                         f"all_gather of [B,4,4] inside the timed region"},
+                   "stop_mode": a.stop_mode,
+                   "sharding": (f"contiguous blocks of pairs over {world} rank(s); every step = hist_icp + match_eval + ONE "
+                                f"RCCL all_gather of the [B,26] rows (transform + 40-byte pair row) inside the timed region")
+                   if collective else "one rank, no exchange step"},
         "library_build": _lib.BUILD_INFO,
         "roofline": roofline,
         "cpu_baseline": cpu,
@@ -173,8 +197,10 @@ def main():
             out["config4_on_one_gpu"] = config4_single_gpu(dev, a)
         except Exception as e:
             out["config4_on_one_gpu"] = {"error": repr(e)}
+    if gather_check is not None:
+        out["gather_check"] = gather_check
     print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 
@@ -257,6 +283,13 @@ def config4_single_gpu(dev, a):
                                                      lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
         out[tag] = {"registrations_per_s": round(nb * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
                     "icp_iterations": int(iters.item()), "icp_kernel_ms_per_step": round(icp_ms / steps, 3)}
+
+        def step_eval():   # the step `--gpus N` times on every rank, less the all_gather: hist_icp + match_eval
+            T, it = utils_match.hist_icp(args, s, d, return_iterations=True)
+            utils_match.match_eval(args, s, d, T)
+            return T, it
+        dt, _, _, _, _ = timed_steps(step_eval, lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
+        out[tag]["registrations_per_s_with_match_eval"] = round(nb * steps / dt, 1)
     return out
 
 

@@ -137,10 +137,17 @@ constexpr int kVoteSpan = 2;     // sorted vote: Y tiles per workgroup (at most)
 // division and the bin index fits 24-bit multiplies (decided once per launch); LDS_HIST: counters in LDS.  Four targets per round, all four LDS
 // reads issued before the first test: with one workgroup per CU (a frame-level batch) nothing else hides
 // the LDS latency of a one-target loop.
+// The quotient (v - min) / (max - min) of a difference one float below max can round to 1.0, i.e. p = len (the
+// reference does not clamp, hist_cuda_core.cuh:52-58): with p_x = len_x the flat bin index runs past the pair's
+// L bins into the next pair's (bins are one [B, L] allocation, hist_cuda.cu:59) -- or, for the last pair, past the
+// allocation (undefined in the reference; dropped here).  LDS counters therefore hold vote_overflow_bins() extra slots
+// behind the L bins (flushed into the next pair's bins), the global path drops what falls beyond `limit`.
+__host__ __device__ inline int vote_overflow_bins(int len_y, int len_z) { return len_y * len_z + len_z + 1; }
+
 template <bool FAST, bool LDS_HIST>
 __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int r0, int r1, const float4 &xi,
                                            const VoteBox &box, const AxisQuot &dqx, const AxisQuot &dqy,
-                                           const AxisQuot &dqz, uint32_t *__restrict__ counters)
+                                           const AxisQuot &dqz, uint32_t *__restrict__ counters, int limit)
 {
     const float flx = (float)box.len_x, fly = (float)box.len_y, flz = (float)box.len_z;
     // largest floats below the (exclusive) upper ends of the box; an empty axis (max <= min) stays empty
@@ -175,6 +182,7 @@ __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int 
                 } else {
                     bin = (px * box.len_y + py) * box.len_z + pz;
                 }
+                if (!LDS_HIST && bin >= limit) continue;   // last pair: past the allocation
                 atomicAdd(&counters[bin], 1u);
             }
         }
@@ -206,6 +214,9 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
     }
     const int L = box.len_x * box.len_y * box.len_z;
     uint32_t *gb = bins_u32 + (size_t)b * L;
+    const bool lastPair = b + 1 == (int)gridDim.y;
+    const int Lx = L + vote_overflow_bins(box.len_y, box.len_z);   // LDS counters: the pair's bins + the overflow row
+    const int limit = lastPair ? L : 0x7fffffff;
 
     const int i = blockIdx.x * kVoteBlock + threadIdx.x;
     float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
     if (!__syncthreads_or(xvalid ? 1 : 0)) return;
 
     if (LDS_HIST) {
-        for (int k = threadIdx.x; k < L; k += kVoteBlock) lhist[k] = 0u;
+        for (int k = threadIdx.x; k < Lx; k += kVoteBlock) lhist[k] = 0u;
     }
     // hist_cuda_core.cuh:52-54: (v-min)/(max-min) * float(len); the denominators
     // and float(len) are loop invariants
@@ -237,12 +248,12 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
         }
         if (!__syncthreads_or(any)) continue;  // a tile of pads
         if (!xvalid) continue;
-        if (allFast) vote_range<true, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb);
-        else vote_range<false, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb);
+        if (allFast) vote_range<true, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb, limit);
+        else vote_range<false, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb, limit);
     }
     if (LDS_HIST) {
         __syncthreads();
-        for (int k = threadIdx.x; k < L; k += kVoteBlock) {
+        for (int k = threadIdx.x; k < (lastPair ? L : Lx); k += kVoteBlock) {   // k >= L: the next pair's bin k - L
             const uint32_t v = lhist[k];
             if (v) atomicAdd(&gb[k], v);
         }
@@ -383,13 +394,16 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     const float min_z = ez[0], max_z = ez[len_z - 1];
     const int L = len_x * len_y * len_z;
     uint32_t *gb = bins_u32 + (size_t)b * L;
+    const bool lastPair = b + 1 == (int)gridDim.y;
+    const int Lx = L + vote_overflow_bins(len_y, len_z);   // LDS counters: the pair's bins + the overflow row (vote_range)
+    const int limit = lastPair ? L : 0x7fffffff;
     const int lane = threadIdx.x & (kWave - 1);
     const int i = ((int)(threadIdx.x >> 6) * rowBlocks + rb) * kWave + lane;
     const bool xvalid = i < nx;
     float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (xvalid) xi = xb[i];
     if (useLds) {
-        for (int k = threadIdx.x; k < L; k += BLOCK) lhist[k] = 0u;
+        for (int k = threadIdx.x; k < Lx; k += BLOCK) lhist[k] = 0u;
     }
     const AxisQuot dqx = axis_quot_make(min_x, max_x), dqy = axis_quot_make(min_y, max_y), dqz = axis_quot_make(min_z, max_z);
     const bool allFast = dqx.fast && dqy.fast && dqz.fast && (long long)len_x * len_y < (1 << 23) && len_z < (1 << 23);
@@ -448,17 +462,17 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
         r0 = __builtin_amdgcn_readfirstlane(r0);
         r1 = __builtin_amdgcn_readfirstlane(r1);
         if (allFast) {
-            if (useLds) vote_range<true, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist);
-            else vote_range<true, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb);
+            if (useLds) vote_range<true, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist, limit);
+            else vote_range<true, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb, limit);
         } else {
-            if (useLds) vote_range<false, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist);
-            else vote_range<false, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb);
+            if (useLds) vote_range<false, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist, limit);
+            else vote_range<false, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb, limit);
         }
         }  // windows
     }
     if (useLds) {
         __syncthreads();
-        for (int k = threadIdx.x; k < L; k += BLOCK) {
+        for (int k = threadIdx.x; k < (lastPair ? L : Lx); k += BLOCK) {   // k >= L: the next pair's bin k - L
             const uint32_t v = lhist[k];
             if (v) atomicAdd(&gb[k], v);
         }
@@ -495,7 +509,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                            lens[2], keyRec, zc);
     }
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
-    const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
+    const size_t lds_hist = tile_bytes + sizeof(uint32_t) * (L + (size_t)vote_overflow_bins(lens[1], lens[2]));
     const int useLds = lds_hist <= 64 * 1024;
     // Workgroup shape.  The counters in LDS limit a CU to four workgroups whatever their size: batches that leave
     // workgroups waiting take 512 rows per workgroup -- eight waves share the counters, 32 waves per CU instead of 16
@@ -553,7 +567,7 @@ hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int N
     const int rows = swap ? (NX > NY ? NX : NY) : NX;
     dim3 grid((rows + kVoteBlock - 1) / kVoteBlock, B);
     const size_t tile_bytes = sizeof(float4) * kVoteTile;
-    const size_t lds_hist = tile_bytes + sizeof(uint32_t) * L;
+    const size_t lds_hist = tile_bytes + sizeof(uint32_t) * (L + (size_t)vote_overflow_bins(lens[1], lens[2]));
     if (lds_hist <= 64 * 1024) {
         hipLaunchKernelGGL(hist_vote_kernel<true>, grid, dim3(kVoteBlock), lds_hist, s,
                            (const float4 *)X, (const float4 *)Y, NX, NY, box, ex, ey, ez, swap,

@@ -1249,6 +1249,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
 #pragma unroll
                     for (int k = 0; k < 9; ++k) h[k] = Rn[k];
                     h[9] = Tn[0]; h[10] = Tn[1]; h[11] = Tn[2]; h[12] = rmse; h[13] = sn;
+                    h[14] = (float)tot[0];   // gated correspondences of this iteration (sum w, :161; exact below 2^24)
                     __hip_atomic_fetch_add(&ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1309,6 +1310,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
 #pragma unroll
                         for (int k = 0; k < 9; ++k) rw[k] = Rn[k];
                         rw[9] = Tn[0]; rw[10] = Tn[1]; rw[11] = Tn[2]; rw[12] = rmse; rw[13] = __int_as_float(hash); rw[14] = sn;
+                        rw[15] = (float)tot[0];
                     }
                 }
                 if (period > 0 && active) {
@@ -1327,6 +1329,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                                 for (int c = 0; c < 12; ++c) h[c] = rj[c];
                                 h[12] = rm;
                                 h[13] = rj[14];
+                                h[14] = rj[15];
                                 const float relk = (rmPrev - rm) / rmPrev;
                                 const bool convk = relk <= p.relThr;
                                 __hip_atomic_fetch_add(&ctrl->tally[k], 1ull | (convk ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,

@@ -207,6 +207,8 @@ __global__ __launch_bounds__(kBlock) void icp_fp32ref_kernel(Fp32Params p)
 #pragma unroll
             for (int k = 0; k < 12; ++k) h[k] = st[k];
             h[12] = rmse;
+            h[13] = 1.f;
+            h[14] = W < 0.5f ? 0.f : W;   // gated correspondences (the clamp only acts on an empty gate)
             __hip_atomic_fetch_add(&p.ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -54,7 +54,7 @@ struct IcpTeam {
 };
 
 constexpr int kHistIters = 128;   // iterations of per-pair history kept in the workspace
-constexpr int kHistStride = 16;   // floats per (iteration, pair): R (9), T (3), rmse
+constexpr int kHistStride = 16;   // floats per (iteration, pair): R (9), T (3), rmse, scale, gated correspondences
 
 // hist.hip
 void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s);

@@ -1,8 +1,10 @@
 """Multi-GPU sharding of the registration path.
 
 Cluster pairs (and frame pairs) are independent units: one process per GPU registers a
-contiguous block of pairs and the only exchange step is one all_gather of the [B,4,4]
-transforms (64 B per pair) at the end -- `torch.distributed` backend "nccl" is RCCL over xGMI
+contiguous block of pairs and the only exchange step is one all_gather of the per-pair result
+rows at the end -- the [4,4] transform (64 B) and the 10-column pair row of match_pairs
+(utils_match.py:120-131: labels, errors, inliers, ratios, ious; 40 B), packed by `pack_rows`
+into ONE [B,26] float32 tensor -- `torch.distributed` backend "nccl" is RCCL over xGMI
 on ROCm; "gloo" works on CPU tensors and is what the CPU tests use.  There is no reduction on
 the path, so no collective other than this gather exists.
 
@@ -25,12 +27,32 @@ def shard_range(rank, world, total):
     return first, base + (1 if rank < extra else 0)
 
 
-def gather_results(local, world, group=None, counts=None):
+ROW_FLOATS = 26   # 16 (transform, row-major) + 10 (pair row)
+
+
+def pack_rows(T, first, errors, inliers, ratios, ious, labels=None):
+    """One [B,26] float32 row per registered pair: the [4,4] transform and the pair row of match_pairs
+    (utils_match.py:120-131): (src label, dst label, errors 2, inliers 2, ratios 2, ious 2).  Synthetic batches have no
+    cluster labels: the global pair index `first + b` stands for both (exact in float32 below 2^24)."""
+    B = T.shape[0]
+    if labels is None:
+        k = torch.arange(first, first + B, device=T.device, dtype=torch.float32)[:, None]
+        labels = torch.cat([k, k], dim=1)
+    return torch.cat([T.reshape(B, 16), labels.to(T.dtype), errors, inliers, ratios, ious], dim=1).contiguous()
+
+
+def unpack_rows(rows):
+    """-> (transforms [B,4,4], pair rows [B,10])."""
+    return rows[:, :16].reshape(-1, 4, 4), rows[:, 16:]
+
+
+def gather_results(local, world, group=None, counts=None, force_collective=False):
     """all_gather per-pair result rows ([B_local, ...]) in rank order -> [sum B_local, ...].
     `counts` (rows of every rank, known to all ranks -- e.g. from shard_range) makes this ONE collective with
     no host synchronisation; without it the counts are exchanged first (one more collective and a device ->
-    host read per call).  Uneven shards are padded to the largest one."""
-    if world == 1:
+    host read per call).  Uneven shards are padded to the largest one.  A world of one returns `local` untouched
+    unless `force_collective` asks for the collective anyway (a single GPU box exercising the RCCL path)."""
+    if world == 1 and not force_collective:
         return local
     local = local.contiguous()
     if counts is None:

@@ -102,6 +102,13 @@ class _LazyHistory(list):
                 super().append(SimilarityTransform(h[k, :, 0:9].reshape(B, 3, 3), h[k, :, 9:12], h[k, :, 13]))
         return self
 
+    def records(self):
+        """The raw per-iteration records [iterations, B, 16] on the device: R (9, row-major), T (3), rmse, scale, the
+        number of gated correspondences (sum of the weights of :161) and one unused float; None when no history was kept."""
+        if self._hist is None:
+            return None
+        return self._hist[:max(int(self._flags[0].item()), 0)]
+
     def __len__(self):
         return list.__len__(self._fill())
 

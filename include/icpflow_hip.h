@@ -94,8 +94,8 @@ const char *icpflow_build_info(void);
  *   transform is a similarity, Xt = s X R + T with s = trace(E S) / Xcov; d_icp_scale receives s (may be NULL).
  *   d_icp_init_s [B] (with d_icp_init_R / d_icp_init_T): the scale of the initial transform, NULL = 1.
  * d_icp_history [max_iterations, B, 16] -- icpflow_icp only: `t_history` of the reference's ICPSolution
- *   (:187), i.e. (R row-major 9, T 3, rmse, 3 unused) after every iteration; rows of iterations the batch rule
- *   did not reach are unspecified.  Available in the single-launch reference stop mode (max_iterations <= 128,
+ *   (:187), i.e. (R row-major 9, T 3, rmse, scale, number of gated correspondences sum(w) of :161, 1 unused) after
+ *   every iteration; rows of iterations the batch rule did not reach are unspecified.  Available in the single-launch reference stop mode (max_iterations <= 128,
  *   fp64 arithmetic); otherwise ICPFLOW_E_ARG.
  * ------------------------------------------------------------------------- */
 #define ICPFLOW_SEARCH_AUTO 0

@@ -31,6 +31,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include <stddef.h>
 
 #if defined(_OPENMP)
@@ -71,6 +72,9 @@ void oracle_hist_vote(const float *X, const float *Y, int B, int NX, int NY,
     /* __int2float_rd(len): exact for every len < 2^24 */
     const float flx = (float)len_x, fly = (float)len_y, flz = (float)len_z;
     const float rx = max_x - min_x, ry = max_y - min_y, rz = max_z - min_z;
+    /* p_x <= len_x, p_y <= len_y, p_z <= len_z: a flat index exceeds the pair's bins by at most this much */
+    const size_t nspill = (size_t)len_y * len_z + (size_t)len_z + 1;
+    float *spill = (float *)calloc((size_t)B * nspill, sizeof(float));
 
 #pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_num_threads())
     for (int b = 0; b < B; ++b) {
@@ -94,11 +98,23 @@ void oracle_hist_vote(const float *X, const float *Y, int B, int NX, int NY,
                     const int px = (int)floorf(qx * flx);
                     const int py = (int)floorf(qy * fly);
                     const int pz = (int)floorf(qz * flz);
-                    /* :57-58 */
-                    hb[((size_t)px * len_y + py) * len_z + pz] += 1.0f;
+                    /* :57-58.  The quotient of a difference one float below max can round to 1.0, i.e. p = len:
+                     * the reference does not clamp, its flat index then runs into the NEXT pair's bins (one
+                     * [B, L] allocation, hist_cuda.cu:59) -- or, for the last pair, past the allocation
+                     * (undefined there; dropped here).  Such votes are counted per pair in `spill` and added
+                     * to the next pair's bins after the parallel loop. */
+                    const size_t flat = ((size_t)px * len_y + py) * len_z + pz;
+                    if (flat < per) hb[flat] += 1.0f;
+                    else if (spill && flat - per < nspill) spill[(size_t)b * nspill + (flat - per)] += 1.0f;
                 }
             }
         }
+    }
+    if (spill) {
+        for (int b = 0; b + 1 < B; ++b)
+            for (size_t e = 0; e < nspill && e < per; ++e)
+                bins[(size_t)(b + 1) * per + e] += spill[(size_t)b * nspill + e];
+        free(spill);
     }
 }
 

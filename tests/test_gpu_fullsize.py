@@ -406,3 +406,45 @@ def test_config4_shape_64_pair_batch_vs_oracle(config4_shard):
     assert determined.sum() >= 64 - 16, msg      # every pair runs into the cap of 50 here: more of them still moving
     assert err32[determined].max() < TOL_M, msg
     assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(np.nonzero(~determined)[0]), msg
+
+
+# ------------------------------------------------------------------------------------------ p = len (no clamp)
+@pytest.mark.parametrize("tf", [2.0, 13.36])
+def test_vote_whose_quotient_rounds_to_one_lands_in_the_next_pair(tf):
+    """hist_cuda_core.cuh:52-58 does not clamp: a difference one float below max gives (v - min) / (max - min) == 1.0,
+    p_x = len_x, and the flat bin index runs into the NEXT pair's bins (one [B, L] allocation, hist_cuda.cu:59); past
+    the last pair the reference writes out of bounds (undefined; dropped here, never written).  Both vote kernels --
+    the public hist() and the fused z-sorted vote, with LDS counters (tf 2.0: 41 x 41 x 3 bins) and with global atomics
+    (tf 13.36: 269 x 269 x 3) -- against the oracle, bit for bit, and the memory behind the bins stays untouched."""
+    from icp_flow_amd import hist as hip_hist
+    a = rp.default_args(max_points=300, translation_frame=tf, icp_max_iterations=2)
+    ex, ey, ez = rp.bin_edges(a)
+    lens = (len(ex), len(ey), len(ez))
+    L = lens[0] * lens[1] * lens[2]
+    S, D, _ = synthetic.make_batch(5, 300, seed=77)
+    hi = np.nextafter(np.float32(ex.max()), np.float32(0.0))
+    for b in (1, 2, 4):                       # v = dst_i - src_j = pred(max) on x (and on y for pair 2): p = len
+        D[b, :4, :3] = (10.0, -20.0, 0.5)
+        S[b, 0, :3] = (np.float32(10.0) - hi, np.float32(-20.0) - (hi if b == 2 else ex[7].item()), 0.5)
+    vx = np.float32(D[1, 0, 0]) - np.float32(S[1, 0, 0])
+    assert vx < ex.max() and (vx - np.float32(ex.min())) / (np.float32(ex.max()) - np.float32(ex.min())) == np.float32(1.0)
+    want = rp.hist(C(D), C(S), ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), *lens).numpy()
+    clean_D = D.copy()
+    clean_D[[1, 2, 4], :4, 3] = 0.0           # (flags off: only for the expectation below, through the all-flags vote)
+    base = rp.hist(C(clean_D), C(S), ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), *lens).numpy()
+    assert (want[2] - base[2]).reshape(-1)[:lens[1] * lens[2]].sum() >= 4      # pair 1's overflow sits in pair 2's first x row
+    # public entry point
+    got = hip_hist.hist(G(D), G(S), ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), *lens)
+    assert np.array_equal(got.cpu().numpy(), want)
+    # ... and through the C ABI into a buffer with canaries behind the [B, L] bins: the last pair's overflow is dropped
+    out = torch.full((5 * L + 4096,), -7.0, dtype=torch.float32, device=DEV)
+    d, s = G(D), G(S)
+    _lib.call("icpflow_hist_vote", _lib.ptr(d), _lib.ptr(s), 5, 300, 300, float(ex.min()), float(ey.min()), float(ez.min()),
+              float(ex.max()), float(ey.max()), float(ez.max()), lens[0], lens[1], lens[2], _lib.ptr(out), _lib.stream(DEV))
+    assert np.array_equal(out[:5 * L].cpu().numpy().reshape(want.shape), want)
+    assert bool((out[5 * L:] == -7.0).all())
+    # fused vote (z-sorted kernel) through the debug export; the workspace region behind the bins is the library's own
+    bins = torch.full((5, L), -1, dtype=torch.int32, device=DEV)
+    with _lib.options(vote_bins=bins):
+        utils_hist.estimate_init_pose(a, G(S), G(D))
+    assert np.array_equal(bins.cpu().numpy().view(np.uint32).astype(np.int64), want.reshape(5, L).astype(np.int64))

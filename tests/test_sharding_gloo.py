@@ -59,3 +59,36 @@ def test_two_rank_gather_equals_single_process(tmp_path):
         want = rp.estimate_init_pose(rp.default_args(max_points=128), torch.from_numpy(S), torch.from_numpy(D))
         assert got.shape == (total, 4, 4)
         assert np.array_equal(got, want.numpy())
+
+
+def _rows_worker(rank, world, port, total, out_path, force):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = sharding.shard_range(rank, world, total)
+    g = torch.Generator().manual_seed(1234)
+    T = torch.randn(total, 4, 4, generator=g)[first:first + count]
+    ev = [torch.randn(total, 2, generator=g)[first:first + count] for _ in range(4)]
+    rows = sharding.pack_rows(T, first, *ev)
+    counts = [sharding.shard_range(r, world, total)[1] for r in range(world)]
+    got = sharding.gather_results(rows, world, counts=counts, force_collective=force)
+    if rank == 0:
+        np.save(out_path, got.numpy())
+    dist.destroy_process_group()
+
+
+def test_packed_rows_gather_in_rank_order(tmp_path):
+    """[B,26] rows (transform + 40-byte pair row) through the one collective of the path: two ranks with
+    even and uneven shards, and a world of ONE rank with the collective forced (what the GPU test runs over RCCL)."""
+    for world, total, force in ((2, 6, False), (2, 5, False), (1, 4, True)):
+        out = str(tmp_path / f"rows_{world}_{total}.npy")
+        mp.spawn(_rows_worker, args=(world, _free_port(), total, out, force), nprocs=world, join=True)
+        got = np.load(out)
+        g = torch.Generator().manual_seed(1234)
+        T = torch.randn(total, 4, 4, generator=g)
+        ev = [torch.randn(total, 2, generator=g) for _ in range(4)]
+        want = sharding.pack_rows(T, 0, *ev)
+        assert got.shape == (total, sharding.ROW_FLOATS)
+        assert np.array_equal(got, want.numpy())
+        Tg, rows = sharding.unpack_rows(torch.from_numpy(got))
+        assert torch.equal(Tg, T) and torch.equal(rows[:, 0], torch.arange(total, dtype=torch.float32))
