@@ -424,8 +424,8 @@ def test_vote_whose_quotient_rounds_to_one_lands_in_the_next_pair(tf):
     S, D, _ = synthetic.make_batch(5, 300, seed=77)
     hi = np.nextafter(np.float32(ex.max()), np.float32(0.0))
     for b in (1, 2, 4):                       # v = dst_i - src_j = pred(max) on x (and on y for pair 2): p = len
-        D[b, :4, :3] = (10.0, -20.0, 0.5)
-        S[b, 0, :3] = (np.float32(10.0) - hi, np.float32(-20.0) - (hi if b == 2 else ex[7].item()), 0.5)
+        D[b, :4, :3] = (0.0, 0.0, 0.5)
+        S[b, 0, :3] = (-hi, -(hi if b == 2 else ex[7].item()), 0.5)
     vx = np.float32(D[1, 0, 0]) - np.float32(S[1, 0, 0])
     assert vx < ex.max() and (vx - np.float32(ex.min())) / (np.float32(ex.max()) - np.float32(ex.min())) == np.float32(1.0)
     want = rp.hist(C(D), C(S), ex.min(), ey.min(), ez.min(), ex.max(), ey.max(), ez.max(), *lens).numpy()

@@ -10,11 +10,20 @@ it produces (first row of its `t_history`) with the oracle's state k + 1:
   * gate decisions: the number of gated correspondences (sum of the weights of :160-161) is EQUAL,
   * rotation within 1e-5, where the points end up within 1e-4 m (the north-star tolerance), rmse within 1e-5 m,
 
-for ALL pairs -- no `determined` mask, no allowance by count.  The only (pair, step)s treated separately are the ones
-the test ENUMERATES from the oracle's own squared distances: a query whose nearest neighbour sits within GATE_MARGIN of
-the gate radius, or whose two nearest targets are within GATE_MARGIN of each other while gated (either may change with
-the last bit of the moved point); there the count may differ by at most the number of such queries.  The report says
-how many steps were checked and how many of them were enumerated.
+for ALL pairs -- no `determined` mask, no allowance by count.  Two kinds of (pair, step) are treated separately, both
+ENUMERATED by the test from the oracle alone:
+
+  * gate-critical: a query whose nearest neighbour sits within GATE_MARGIN of the gate radius, or whose two nearest
+    targets are within GATE_MARGIN of each other while gated (either may change with the last bit of the moved point);
+    there the count may differ by at most the number of such queries;
+  * fp32-limited: steps on which the oracle's own fp32 Kabsch step (torch's summation order, fp32 SVD) is more than
+    half the tolerance away from the SAME step evaluated in fp64 (`kabsch_dtype=torch.float64`: same state, same
+    gated correspondences, same formulas) -- an ill-conditioned covariance, where the reference's rounding, not its
+    algorithm, sets the answer.  There the fp32 comparison is not made.
+
+EVERY step, enumerated or not, is also compared with that fp64 evaluation of the oracle's step, tightly (rotation
+1e-6, moved points 1e-5 m): nothing is excused from it but the gate-critical steps whose counts really differ.  The
+report says how many steps were checked and how many fell into each class.
 """
 import os
 
@@ -36,6 +45,8 @@ DEV = torch.device("cuda:0")
 TOL_R = 1e-5
 TOL_M = 1e-4
 TOL_RMSE = 1e-5
+TIGHT_R = 1e-6           # against the fp64 evaluation of the oracle's step
+TIGHT_M = 1e-5
 GATE_MARGIN = 1e-6       # metres: "a neighbour within 1 um of the gate"
 
 
@@ -97,8 +108,9 @@ def _one_step_conformance(S, D, cap, chunk):
     n_y = (fixed[:, :, 3] > 0).sum(1)
     gm, gf = G(moved), G(fixed)
     steps = _steps(sol.iterations)
-    checked = enumerated = 0
-    worst = dict(R=0.0, m=0.0, rmse=0.0)
+    checked = enumerated = limited = 0
+    worst = dict(R=0.0, m=0.0, rmse=0.0, R64=0.0, m64=0.0)
+    ones = torch.ones(B)
     lines, failures = [], []
     p64 = X0.double()
     for k in steps:
@@ -114,34 +126,60 @@ def _one_step_conformance(S, D, cap, chunk):
         rec = got.t_history.records()[0].cpu()                                    # state after ONE iteration from state k
         Rg, Tg, rmseg, cntg = rec[:, 0:9].reshape(B, 3, 3), rec[:, 9:12], rec[:, 12], rec[:, 14].long()
         crit = _critical_queries(Xt, fixed, valid, n_y, args.thres_dist, chunk)
+        # the same step of the oracle with its Kabsch step in fp64 (teacher-forced from the same state)
+        o64 = rp.iterative_closest_point(moved, fixed, thres=args.thres_dist, max_iterations=1, trace=True,
+                                         init_transform=(Rk, Tk, ones), kabsch_dtype=torch.float64)
+        R64, T64, _, cnt64 = o64.history[0]
+        assert torch.equal(cnt64, cnt1)                                       # same state, same gate decisions
+
+        def moved_by(R, T):
+            return torch.bmm(p64, R.double()) + T.double()[:, None, :]
+
+        def far(Ra, Ta, Rb, Tb):
+            return (Ra - Rb).abs().amax((1, 2)), ((moved_by(Ra, Ta) - moved_by(Rb, Tb)).abs().amax(2) * valid).amax(1)
+
         dc = (cntg - cnt1.long()).abs()
-        dR = (Rg - R1).abs().amax((1, 2))
-        mg = torch.bmm(p64, Rg.double()) + Tg.double()[:, None, :]
-        m1 = torch.bmm(p64, R1.double()) + T1.double()[:, None, :]
-        dm = ((mg - m1).abs().amax(2) * valid).amax(1)
+        dR, dm = far(Rg, Tg, R1, T1)              # HIP vs the oracle's fp32 step
+        dR64, dm64 = far(Rg, Tg, R64, T64)        # HIP vs the oracle's step evaluated in fp64
+        oR, om = far(R1, T1, R64, T64)            # the oracle's fp32 step vs its own fp64 evaluation
         dr = (rmseg - rmse1).abs()
         plain = crit == 0
+        fp32_limited = plain & ((oR > TOL_R / 2) | (om > TOL_M / 2))
+        strict = plain & ~fp32_limited
+        same_count = dc == 0
         checked += B
         enumerated += int((~plain).sum())
-        for name, bad in (("gated count", plain & (dc != 0)), ("gated count beyond the enumerated queries", ~plain & (dc > crit)),
-                          ("rotation", plain & ~(dR <= TOL_R)), ("moved points", plain & ~(dm <= TOL_M)),
-                          ("rmse", plain & ~(dr <= TOL_RMSE))):
+        limited += int(fp32_limited.sum())
+        for name, bad in (("gated count", plain & ~same_count), ("gated count beyond the enumerated queries", ~plain & (dc > crit)),
+                          ("rotation vs fp32 oracle", strict & ~(dR <= TOL_R)), ("moved points vs fp32 oracle", strict & ~(dm <= TOL_M)),
+                          ("rmse", strict & ~(dr <= TOL_RMSE)),
+                          ("rotation vs fp64 evaluation", same_count & ~(dR64 <= TIGHT_R)),
+                          ("moved points vs fp64 evaluation", same_count & ~(dm64 <= TIGHT_M))):
             for b in torch.nonzero(bad)[:, 0].tolist():
                 failures.append(f"step {k} pair {b}: {name}: count {int(cntg[b])} vs {int(cnt1[b])} (enumerated {int(crit[b])}), "
-                                f"|dR| {float(dR[b]):.2e}, moved {float(dm[b]):.2e} m, |drmse| {float(dr[b]):.2e}")
-        if plain.any():
-            worst["R"] = max(worst["R"], float(dR[plain].max()))
-            worst["m"] = max(worst["m"], float(dm[plain].max()))
-            worst["rmse"] = max(worst["rmse"], float(dr[plain].max()))
-        lines.append(f"step {k:2d}: gated counts equal on {int((dc == 0).sum())}/{B}, enumerated pairs {int((~plain).sum())} "
-                     f"(of them with a different count {int((~plain & (dc != 0)).sum())}), max |dR| {float(dR[plain].max()):.2e}, "
-                     f"moved {float(dm[plain].max()):.2e} m, |drmse| {float(dr[plain].max()):.2e}")
+                                f"vs fp32 oracle |dR| {float(dR[b]):.2e} moved {float(dm[b]):.2e} m |drmse| {float(dr[b]):.2e}; vs "
+                                f"fp64 evaluation |dR| {float(dR64[b]):.2e} moved {float(dm64[b]):.2e} m; oracle fp32 vs fp64 "
+                                f"|dR| {float(oR[b]):.2e} moved {float(om[b]):.2e} m")
+        if strict.any():
+            worst["R"] = max(worst["R"], float(dR[strict].max()))
+            worst["m"] = max(worst["m"], float(dm[strict].max()))
+            worst["rmse"] = max(worst["rmse"], float(dr[strict].max()))
+        worst["R64"] = max(worst["R64"], float(dR64[same_count].max()))
+        worst["m64"] = max(worst["m64"], float(dm64[same_count].max()))
+        lines.append(f"step {k:2d}: gated counts equal on {int(same_count.sum())}/{B}, gate-critical pairs {int((~plain).sum())} "
+                     f"(different count: {int((~plain & ~same_count).sum())}), fp32-limited {int(fp32_limited.sum())} "
+                     f"(oracle fp32 vs fp64 up to {float(om.max()):.2e} m); vs fp32 oracle max |dR| {float(dR[strict].max()):.2e} "
+                     f"moved {float(dm[strict].max()):.2e} m |drmse| {float(dr[strict].max()):.2e}; vs fp64 evaluation |dR| "
+                     f"{float(dR64[same_count].max()):.2e} moved {float(dm64[same_count].max()):.2e} m")
     summary = (f"{checked} (pair, iteration) steps checked at iterations {steps} of the oracle's {sol.iterations}; {enumerated} "
-               f"enumerated as gate-critical (margin {GATE_MARGIN:g} m); on the other {checked - enumerated}: gated counts equal, "
-               f"max |dR| {worst['R']:.2e}, max moved-point difference {worst['m']:.2e} m, max |drmse| {worst['rmse']:.2e}")
+               f"enumerated as gate-critical (margin {GATE_MARGIN:g} m), {limited} as fp32-limited (the oracle's fp32 step more than "
+               f"half the tolerance from its fp64 evaluation); on the other {checked - enumerated - limited}: gated counts equal, "
+               f"vs the fp32 oracle max |dR| {worst['R']:.2e}, moved points {worst['m']:.2e} m, |drmse| {worst['rmse']:.2e}; every "
+               f"step with equal counts vs the fp64 evaluation: max |dR| {worst['R64']:.2e}, moved points {worst['m64']:.2e} m")
     print("\n".join(lines + [summary]))
     assert not failures, "\n".join(failures[:40] + [summary])
-    assert enumerated * 20 <= checked, summary      # the enumeration itself stays a small minority (else the margin is wrong)
+    # the enumerations stay a small minority (else a margin is wrong)
+    assert enumerated * 20 <= checked and limited * 50 <= checked, summary
 
 
 def test_config2_every_pair_one_step_from_the_oracle_state():

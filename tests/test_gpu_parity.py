@@ -698,67 +698,98 @@ def test_hist_icp_under_stream_capture_and_on_two_streams():
 
 
 # ------------------------------------------------------------------ 8(f): association + flow on the demo frame
-@all_icp_searches
-@pytest.mark.parametrize("fixture", ["g8_demo", "g8_demo_mp10000"])
-def test_demo_frame_pair_track_and_flow_vs_reference(fixture):
-    """BASELINE config 1 (G8): demo.npz frame pair through the HIP path -- match_pcds (both stages:
-    sanity_check, gather/pad, hist_icp, match_eval, reject, arg-min) and the flow kernel -- against
-    the reference's own pairs / transforms / per-point flow (63 276 points), at max_points 2048 and at the
-    reference's real setting, max_points 10000 (demo.sh:9-13; the 30 000-point wall is subsampled with the
-    reference's own torch.randperm stream, the ICP of the large clusters runs as a team of workgroups)."""
+def _demo_frame_run(fixture):
+    """demo.npz frame pair through the HIP path (match_pcds: both association stages; flow kernel), outputs lined up
+    with the pairs of the reference run recorded in `fixture`."""
     from icp_flow_amd import utils_flow, utils_track
     g0 = load_golden("g8_demo")
     g = load_golden(fixture)
     lab = load_golden("g8_demo_labels")
     a = rp.default_args(max_points=int(g["max_points"]), min_cluster_size=20, translation_frame=2.0,
                         thres_box=0.1, thres_rot=0.1, thres_error=0.2, thres_iou=0.2)
-    assert a.max_points == (2048 if fixture == "g8_demo" else 10000) and len(g["pairs"]) == 83
+    assert len(g["pairs"]) == 83
     torch.manual_seed(0)
     ps, pd = G(g0["point_src"]), G(g0["point_dst"])
     ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
     pairs, Tm = utils_track.track(a, ps, pd, ls, ld)
     flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, torch.eye(4, device=DEV))
     pairs, Tm, flow = pairs.cpu().numpy(), Tm.cpu().numpy(), flow.cpu().numpy()
-    ref_pairs, ref_T, ref_flow = g["pairs"], g["transformations"], g["flow"]
+    ref_pairs = g["pairs"]
     got = {int(p[0]): (int(p[1]), k) for k, p in enumerate(pairs)}
     ref = {int(p[0]): (int(p[1]), k) for k, p in enumerate(ref_pairs)}
     assert set(got) == set(ref), (sorted(set(got) ^ set(ref)))
     assert all(got[s][0] == ref[s][0] for s in ref)
     order = [got[int(p[0])][1] for p in ref_pairs]
-    err = np.linalg.norm(flow - ref_flow, axis=1)
-    lsrc = lab["label_src"]
-    worst = sorted(((float(err[lsrc == p[0]].max()), int(p[0]), int((lsrc == p[0]).sum())) for p in ref_pairs), reverse=True)[:4]
-    print(f"{fixture}: flow vs reference max {err.max():.3e} m, within 1e-4 m on {np.mean(err < TOL_M):.5f} of the points; "
-          f"worst clusters (max err, label, points) {worst}")
-    # In the reference's run stage 1 stopped after 41 (max_points 2048) / 55 (10000) iterations; here it runs 100: one
-    # candidate pair (a few dozen points) has fewer than five positive vote peaks, torch.topk completes its top-5
-    # with zero-vote bins in implementation-defined order, the reference's pick registers, the deterministic rule's
-    # pick (vote desc, index asc) has no inlier at all -- rel = NaN, the batch-global stop can never fire
-    # (utils_icp_pytorch3d.py:209).  The pair itself is rejected either way; the iteration count of the batch moves
-    # the clusters that are still moving at that iteration (test_demo_frame_stages_from_the_reference_initial_poses
-    # pins those by starting from the reference's own initial poses).  Here: every cluster that has settled by then.
-    pinned = np.ones(len(err), bool)
-    moving = [int(p[0]) for p in ref_pairs if err[lsrc == p[0]].max() >= TOL_M]
-    assert len(moving) <= 4 and all((lsrc == l).sum() > 900 for l in moving), worst
-    for l in moving:
-        pinned &= lsrc != l
-    settled = ~np.isin(ref_pairs[:, 0], moving)
-    np.testing.assert_allclose(pairs[order][settled, 2:4], ref_pairs[settled, 2:4], atol=2e-4)                 # errors
-    np.testing.assert_allclose(pairs[order][settled, 4:6], ref_pairs[settled, 4:6], atol=2)                    # inlier counts
-    np.testing.assert_allclose(pairs[order][:, 2:4], ref_pairs[:, 2:4], atol=5e-3)
-    np.testing.assert_allclose(pairs[order][:, 4:6], ref_pairs[:, 4:6], atol=2, rtol=0.05)
-    assert err[pinned].max() < TOL_M, f"per-point flow differs from the reference's by up to {err[pinned].max():.3e} m; worst clusters {worst}"
+    return dict(a=a, g0=g0, g=g, lab=lab, ps=ps, pd=pd, ls=ls, ld=ld, pairs=pairs[order], T=Tm[order], flow=flow)
+
+
+@all_icp_searches
+@pytest.mark.parametrize("fixture", ["g8_demo_cudatopk", "g8_demo_mp10000_cudatopk"])
+def test_demo_frame_pair_track_and_flow_vs_reference(fixture):
+    """BASELINE config 1 end to end, EVERY point of the frame: demo.npz through the HIP path -- match_pcds (both stages:
+    sanity_check, gather / pad, hist_icp, match_eval, reject, arg-min) and the flow kernel -- against the reference's own
+    match_pcds + flow_estimation_torch (63 276 points), at max_points 2048 and at the reference's real setting 10000
+    (demo.sh:9-13; the 30 000-point wall is subsampled with the reference's own torch.randperm stream, the ICP of the
+    large clusters runs as a team of workgroups).
+
+    Tie rule.  `torch.topk` (utils_hist.py:27) cuts the top-5 of the NMS survivors; which of several EQUAL votes make the
+    cut is implementation-defined.  The product's rule is (vote descending, flat index ascending), which is what ATen's
+    CUDA implementation -- the platform the reference runs on -- yields: its single-block radix select
+    (aten/src/ATen/native/cuda/TensorTopK.cu, gatherTopK) finds the k-th value, writes everything strictly greater and
+    completes the k outputs with elements equal to it in ascending index order.  These fixtures are the reference's own
+    code run with exactly that order in place of torch-CPU's (tools/gen_golden.py `topk_cuda_order`; everything else
+    unmodified): stage 1 then runs all 100 iterations (one 21-vs-47-point pair, tied on a vote count of 2 at the cut,
+    starts from the zero translation and never has an inlier: rel = NaN, utils_icp_pytorch3d.py:209 cannot fire), exactly
+    as here.  No cluster is excused: same 83 matched pairs, per-point flow within 1e-4 m on every point."""
+    r = _demo_frame_run(fixture)
+    g, flow, pairs = r["g"], r["flow"], r["pairs"]
+    assert list(g["stage_iterations"]) == [100, 100]
+    err = np.linalg.norm(flow - g["flow"], axis=1)
+    lsrc = r["lab"]["label_src"]
+    worst = sorted(((float(err[lsrc == p[0]].max()), int(p[0]), int((lsrc == p[0]).sum())) for p in g["pairs"]), reverse=True)[:4]
+    print(f"{fixture}: flow vs the reference run (CUDA tie order) max {err.max():.3e} m over {len(err)} points; worst clusters "
+          f"(max err, label, points) {worst}")
+    assert err.max() < TOL_M, worst
+    np.testing.assert_allclose(pairs[:, 2:4], g["pairs"][:, 2:4], atol=2e-4)                 # errors
+    np.testing.assert_allclose(pairs[:, 4:6], g["pairs"][:, 4:6], atol=2)                    # inlier counts
+    np.testing.assert_allclose(pairs[:, 6:10], g["pairs"][:, 6:10], atol=2e-3)               # ratios, ious
     # the flow kernel alone, fed with the reference's pairs / transforms
-    flow2 = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, G(ref_pairs), G(ref_T), torch.eye(4, device=DEV))
-    np.testing.assert_allclose(flow2.cpu().numpy(), ref_flow, atol=2e-5)
+    from icp_flow_amd import utils_flow
+    flow2 = utils_flow.flow_estimation_torch(r["a"], r["ps"], r["pd"], r["ls"], r["ld"], G(g["pairs"]), G(g["transformations"]),
+                                             torch.eye(4, device=DEV))
+    np.testing.assert_allclose(flow2.cpu().numpy(), g["flow"], atol=2e-5)
     # EPE against ground truth equals the reference's (utils_eval.py:137-182 epe3d)
-    epe = float(np.linalg.norm(flow - g0["gt_flow"], axis=1).mean())
-    if pinned.all():
-        assert abs(epe - float(g["epe"])) < 1e-4
-    # (with the two still-moving clusters -- half of all points -- a few millimetres off, the EPE differs by as much)
-    epe_pinned = np.linalg.norm(flow[pinned] - g0["gt_flow"][pinned], axis=1).mean()
-    assert abs(epe_pinned - np.linalg.norm(ref_flow[pinned] - g0["gt_flow"][pinned], axis=1).mean()) < 1e-5
-    assert abs(epe - float(g["epe"])) < 2e-2     # (the 30 000-point wall alone is half of the frame)
+    epe = float(np.linalg.norm(flow - r["g0"]["gt_flow"], axis=1).mean())
+    assert abs(epe - float(g["epe"])) < 1e-4
+
+
+@pytest.mark.parametrize("fixture", ["g8_demo", "g8_demo_mp10000"])
+def test_demo_frame_pair_vs_the_torch_cpu_tie_order_run(fixture):
+    """The same frame against the reference run made with torch-CPU's topk (std::partial_sort: another subset of the
+    equal votes): there the tied pair of stage 1 starts from a pose that registers, the batch-global stop fires after 41
+    (max_points 2048) / 55 (10000) iterations instead of 100, and the clusters still moving at that iteration end up
+    elsewhere -- in the REFERENCE's two runs as much as here: its CUDA-order and CPU-order fixtures differ by up to
+    4.5 cm on half of the frame's points.  What can be asserted end to end is therefore exactly that: same matched pairs,
+    every cluster on which the reference's two runs agree to 1e-5 m within 1e-4 m here too, and nowhere farther from this
+    fixture than the reference's own other run is (plus the tolerance).  Stage by stage, from this run's initial poses,
+    every cluster is pinned by test_demo_frame_stages_from_the_reference_initial_poses."""
+    r = _demo_frame_run(fixture)
+    g, flow = r["g"], r["flow"]
+    other = load_golden(fixture + "_cudatopk")["flow"]
+    err = np.linalg.norm(flow - g["flow"], axis=1)
+    ref_gap = np.linalg.norm(other - g["flow"], axis=1)
+    lsrc = r["lab"]["label_src"]
+    settled = np.ones(len(err), bool)
+    moving = []
+    for p in g["pairs"]:
+        m = lsrc == p[0]
+        if ref_gap[m].max() > 1e-5:
+            settled &= ~m
+            moving.append((int(p[0]), int(m.sum()), float(ref_gap[m].max()), float(err[m].max())))
+    print(f"{fixture}: {len(moving)} clusters on which the reference's own two runs differ (label, points, their gap, ours): {moving}; "
+          f"max difference on the other {int(settled.sum())} points {err[settled].max():.3e} m")
+    assert err[settled].max() < TOL_M
+    assert (err <= ref_gap + TOL_M).all()
 
 
 @pytest.mark.parametrize("fixture", ["g8_demo", "g8_demo_mp10000"])

@@ -282,8 +282,22 @@ def g6_hist_icp():
          ev_ious=ev[3].numpy(), ev_translations=ev[4].numpy(), ev_rotations=ev[5].numpy())
 
 
-def g8_demo(max_points=2048, name="g8_demo"):
-    """BASELINE config 1: the reference's demo frame pair (demo.npz) through the reference's own
+def topk_cuda_order(x, k, dim=1, **kw):
+    """torch.topk with the tie order of ATen's CUDA implementation (what the reference runs on): the single-block
+    radix select (aten/src/ATen/native/cuda/TensorTopK.cu, gatherTopK -- slices of 41*41*3 = 5043 elements stay far
+    below the multi-block thresholds) first finds the k-th value by radix selection, then writes every element
+    strictly greater than it and completes the k outputs with elements EQUAL to it in ascending index order (an
+    exclusive prefix scan over the slice in index order).  A stable descending sort returns exactly that set; torch-CPU
+    (std::partial_sort on (value, index) pairs) picks another subset of the tied elements."""
+    order = torch.argsort(x, dim=dim, descending=True, stable=True).narrow(dim, 0, k)
+    return torch.gather(x, dim, order), order
+
+
+def g8_demo(max_points=2048, name="g8_demo", topk_rule="torch_cpu"):
+    """topk_rule "cuda": torch.topk replaced by `topk_cuda_order` while the reference's code runs (everything else
+    unmodified) -- the run the reference would make on its own platform as far as the tie order goes.
+
+    BASELINE config 1: the reference's demo frame pair (demo.npz) through the reference's own
     match_pcds (both association stages) and flow_estimation_torch, on CPU.  Cluster labels come
     from sklearn's HDBSCAN through the reference's cluster_pcd (the pinned `hdbscan` package is
     not installable), so the labels are part of the fixture.  max_points = 2048 keeps the
@@ -345,9 +359,13 @@ def g8_demo(max_points=2048, name="g8_demo"):
 
     utils_match.match_pairs, utils_match.estimate_init_pose = match_pairs_obs, init_obs
     utils_icp.iterative_closest_point, utils_match.hist_icp = icp_obs, hist_icp_obs
+    torch_topk = torch.topk
+    if topk_rule == "cuda":
+        torch.topk = topk_cuda_order          # (utils_hist.py:27 is the path's only torch.topk call)
     try:
         pairs, T = utils_match.match_pcds(a, ps, pd, ls, ld)
     finally:
+        torch.topk = torch_topk
         utils_match.match_pairs, utils_match.estimate_init_pose = orig["pairs"], orig["init"]
         utils_icp.iterative_closest_point, utils_match.hist_icp = orig["icp"], orig["hist_icp"]
     stage_arrays = dict(stage_sizes=np.array([len(st["pairs"]) for st in stages]),
@@ -511,7 +529,13 @@ def g8_demo_mp10000():
     g8_demo(max_points=10000, name="g8_demo_mp10000")
 
 
-GENS = dict(g8mp10000=g8_demo_mp10000, g11=g11_hdbscan, g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
+def g8_cuda_rule():
+    """The two G8 runs again with torch.topk's CUDA tie order (inputs and labels live in g8_demo.npz / g8_demo_labels.npz)."""
+    g8_demo(max_points=2048, name="g8_demo_cudatopk", topk_rule="cuda")
+    g8_demo(max_points=10000, name="g8_demo_mp10000_cudatopk", topk_rule="cuda")
+
+
+GENS = dict(g8cuda=g8_cuda_rule, g8mp10000=g8_demo_mp10000, g11=g11_hdbscan, g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -519,7 +543,7 @@ if __name__ == "__main__":
     ns = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g8mp10000", "g9", "g10", "g11")]   # g8: ~3 min, on request
+    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g8mp10000", "g8cuda", "g9", "g10", "g11")]   # g8: ~3 min, on request
     for k in want:
         print(f"== {k}")
         GENS[k]()
