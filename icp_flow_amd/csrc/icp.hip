@@ -37,12 +37,19 @@ __device__ int g_stamp_block;                  // the workgroup that stamps (icp
 // publication of (R, T) (the serial tail), in the rest of the loop, and the iterations it executed; and the tail split
 // at the phase stamps (accumulated in LDS by thread 0)
 __device__ long long g_tail_clock[1024 * 3];
+__device__ long long g_wg_wall[8192 * 4];   // per pair: wall clock (100 MHz) at entry and exit of its workgroup, HW_ID, XCC_ID
 __device__ long long g_tail_split[1024 * 16];
 __shared__ long long g_tcSh[17];
 #ifdef ICPFLOW_TAIL_SPLIT   // (each stamp costs ~200 clocks: the totals above are measured without)
 #undef ICPFLOW_STAMP
 #define ICPFLOW_STAMP(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); g_tcSh[k] += t_ - g_tcSh[16]; g_tcSh[16] = t_; } } while (0)
 #endif
+#endif
+#ifdef ICPFLOW_DEBUG_SOLVE
+// debug builds only (tools/dbg/onestep_case.py): the 18 moments, H, lambda and R of one pair's FIRST iteration
+__device__ double g_dbg_solve[64];
+__device__ float g_dbg_xt[4096 * 3];   // the moved points of that iteration by ORIGINAL row
+__device__ int g_dbg_pair = 0;
 #endif
 #ifdef ICPFLOW_CERT_STATS
 // debug builds only (tools/dbg/cert_stats.py): per iteration, over the whole batch: waves that ran, waves that searched,
@@ -527,6 +534,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
     if constexpr (GRID >= 3) sweepAxis = __builtin_amdgcn_readfirstlane(p.sortAxis[b]);
     unsigned long long ownConvLo = 0ull, ownConvHi = 0ull;   // iterations at which this pair was converged
 #ifdef ICPFLOW_TAIL_CLOCK
+    const long long tcWall0 = wall_clock64();
     long long tcTail = 0, tcSearch = 0, tcLoop0 = clock64();
     if (threadIdx.x < 17) g_tcSh[threadIdx.x] = threadIdx.x == 16 ? clock64() : 0;
     __syncthreads();
@@ -684,6 +692,12 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                         float rz = fmaf(x0z[q], Rf[8], fmaf(x0y[q], Rf[5], x0x[q] * Rf[2]));
                         if constexpr (SCALE) { rx *= sc; ry *= sc; rz *= sc; }   // (similarity transforms only)
                         qx[q] = rx + Tf[0]; qy[q] = ry + Tf[1]; qz[q] = rz + Tf[2];
+#ifdef ICPFLOW_DEBUG_SOLVE
+                        if (b == g_dbg_pair && it == itBegin) {
+                            const int orig = __float_as_int(xs[i].w);
+                            if (orig >= 0 && orig < 4096) { g_dbg_xt[orig * 3] = qx[q]; g_dbg_xt[orig * 3 + 1] = qy[q]; g_dbg_xt[orig * 3 + 2] = qz[q]; }
+                        }
+#endif
                         float m = p.sweepMargin;
                         if (recOn) {
                             m = certMargin;   // first iteration: nothing known
@@ -1204,6 +1218,15 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                 for (int k = 0; k < 9; ++k) { Rd[k] = -Rd[k]; ksh[8 + k] = -ksh[8 + k]; }
             }
             ICPFLOW_STAMP(6);
+#ifdef ICPFLOW_DEBUG_SOLVE
+            if (b == g_dbg_pair && it == itBegin && lane == 0) {
+                for (int k = 0; k < kMoments; ++k) g_dbg_solve[k] = tot[k];
+                for (int k = 0; k < 17; ++k) g_dbg_solve[18 + k] = ksh[k];
+                g_dbg_solve[35] = lam;
+                for (int k = 0; k < 9; ++k) g_dbg_solve[36 + k] = Rd[k];
+                g_dbg_solve[45] = (double)bcast[16]; g_dbg_solve[46] = (double)bcast[17]; g_dbg_solve[47] = (double)bcast[18];
+            }
+#endif
             // T = mu_y - mu_x R with mu = o + m', :376
             const double o0 = (double)bcast[16], o1 = (double)bcast[17], o2 = (double)bcast[18];
             const double mux[3] = {o0 + ksh[0], o1 + ksh[1], o2 + ksh[2]};
@@ -1374,6 +1397,11 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
 #ifdef ICPFLOW_TAIL_CLOCK
     if (tid == 0 && b < 1024) { g_tail_clock[b * 3] = tcTail; g_tail_clock[b * 3 + 1] = tcSearch; g_tail_clock[b * 3 + 2] = itersDone; }
     if (tid < 16 && b < 1024) g_tail_split[b * 16 + tid] = g_tcSh[tid];
+    if (tid == 0 && b < 8192) {
+        g_wg_wall[b * 4] = tcWall0; g_wg_wall[b * 4 + 1] = wall_clock64();
+        g_wg_wall[b * 4 + 2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+        g_wg_wall[b * 4 + 3] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11));
+    }
 #endif
     if (tid == 0 && rank == 0) {  // wave 0 (of member 0) holds the final state
 #pragma unroll
@@ -1551,9 +1579,24 @@ extern "C" int icpflow_debug_tail_clock(long long *out3072)
 {
     return (int)hipMemcpyFromSymbol(out3072, HIP_SYMBOL(g_tail_clock), sizeof(long long) * 3072);
 }
+extern "C" int icpflow_debug_wg_wall(long long *out32768)
+{
+    return (int)hipMemcpyFromSymbol(out32768, HIP_SYMBOL(g_wg_wall), sizeof(long long) * 32768);
+}
 extern "C" int icpflow_debug_tail_split(long long *out16384)
 {
     return (int)hipMemcpyFromSymbol(out16384, HIP_SYMBOL(g_tail_split), sizeof(long long) * 16384);
+}
+#endif
+#ifdef ICPFLOW_DEBUG_SOLVE
+extern "C" int icpflow_debug_solve(int pair, double *out64)
+{
+    if (out64 == nullptr) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_pair), &pair, sizeof(int));
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg_solve), sizeof(double) * 64);
+}
+extern "C" int icpflow_debug_xt(float *out12288)
+{
+    return (int)hipMemcpyFromSymbol(out12288, HIP_SYMBOL(g_dbg_xt), sizeof(float) * 12288);
 }
 #endif
 #ifdef ICPFLOW_CERT_STATS

@@ -75,11 +75,46 @@ def nearest_neighbor_batch(src, dst):
     return idx, d2.sqrt()
 
 
+def _fma32(a, b, c):
+    """fp32 fused multiply-add: the product of two fp32 numbers is exact in fp64, the sum is rounded to fp64 and then
+    to fp32 (the double rounding can only matter on an exact fp32 tie of a 53-bit sum)."""
+    return (a.double() * b.double() + c.double()).to(a.dtype)
+
+
+def point_mm(P, M):
+    """`torch.bmm(P, M)` for rows of points P [B,N,K] times a small matrix M [B,K,K'] (K = 3 or 4), with the rounding
+    PINNED: out = fma(p_{K-1}, m_{K-1}, ... fma(p_1, m_1, p_0 * m_0)), k ascending.
+    A BLAS call does not define its rounding: torch-CPU runs this very product as that FMA chain on the AVX2 host the
+    golden fixtures were generated on (and for the padded sizes they use, N >= 48), and as separate multiplies and adds
+    on other hosts (measured on the Zen-5 host of the GPU boxes) or for tiny N -- 1 ulp of the moved point apart on
+    ~40 % of the rows, enough to hand a query with two nearly equidistant targets the other neighbour.  The restatement
+    must not depend on the machine it runs on: it takes the fixtures' arithmetic, which is also the kernels'
+    (icp.hip: fmaf chain; nvcc contracts the same way)."""
+    if P.dtype != torch.float32:
+        return torch.bmm(P, M)
+    acc = P[..., :, 0:1] * M[..., 0:1, :]
+    for k in range(1, P.shape[-1]):
+        acc = _fma32(P[..., :, k:k + 1], M[..., k:k + 1, :], acc)
+    return acc
+
+
+def tiny_mm(A, M):
+    """`torch.bmm` of two SMALL matrices ([.,3,3], [.,4,4], a [.,1,3] row): products and sums rounded one by one, k
+    ascending -- how torch-CPU evaluates them on the host the fixtures come from (its native small-matrix path).
+    Pinned for the same reason as point_mm."""
+    if A.dtype != torch.float32:
+        return torch.bmm(A, M)
+    acc = A[..., :, 0:1] * M[..., 0:1, :]
+    for k in range(1, A.shape[-1]):
+        acc = acc + A[..., :, k:k + 1] * M[..., k:k + 1, :]
+    return acc
+
+
 def transform_points_batch(xyz, pose):
     """utils_helper.py:76-87: [x y z 1] @ pose^T, flag column carried through."""
     b, n, _ = xyz.shape
     hom = torch.cat([xyz[:, :, 0:3], xyz.new_ones((b, n, 1))], dim=-1)
-    moved = torch.bmm(hom, pose.transpose(1, 2))
+    moved = point_mm(hom, pose.transpose(1, 2))
     return torch.cat([moved[:, :, 0:3], xyz[:, :, 3:4]], dim=-1)
 
 
@@ -221,15 +256,15 @@ def corresponding_points_alignment(X, Y, weights, eps=1e-9, dtype=None, sum_orde
     U, S, V = torch.svd(H)                                                    # :339
     E = torch.eye(3, dtype=H.dtype)[None].repeat(b, 1, 1)
     if not allow_reflection:                                                  # :354
-        E[:, -1, -1] = torch.det(torch.bmm(U, V.transpose(2, 1)))             # :358-359
-    R = torch.bmm(torch.bmm(U, E), V.transpose(2, 1))                         # :362
+        E[:, -1, -1] = torch.det(tiny_mm(U, V.transpose(2, 1)))               # :358-359
+    R = tiny_mm(tiny_mm(U, E), V.transpose(2, 1))                             # :362
     if estimate_scale:
         trace_ES = (torch.diagonal(E, dim1=1, dim2=2) * S).sum(1)             # :366
         Xcov = (Xc * Xc).sum((1, 2)) / total                                  # :367
         s = trace_ES / torch.clamp(Xcov, eps)                                 # :370
-        T = mu_y[:, 0, :] - s[:, None] * torch.bmm(mu_x, R)[:, 0, :]          # :373
+        T = mu_y[:, 0, :] - s[:, None] * tiny_mm(mu_x, R)[:, 0, :]            # :373
         return R.to(out_dtype), T.to(out_dtype), s.to(out_dtype)
-    T = mu_y[:, 0, :] - torch.bmm(mu_x, R)[:, 0, :]                           # :376
+    T = mu_y[:, 0, :] - tiny_mm(mu_x, R)[:, 0, :]                             # :376
     return R.to(out_dtype), T.to(out_dtype)
 
 
@@ -255,7 +290,7 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
         R, T = init_transform[0], init_transform[1]
         if len(init_transform) > 2:
             s = init_transform[2]
-        Xt = s[:, None, None] * torch.bmm(X0, R) + T[:, None, :]              # _apply_similarity_transform, :395
+        Xt = s[:, None, None] * point_mm(X0, R) + T[:, None, :]               # _apply_similarity_transform, :395
     prev = None
     rmse = None
     converged = False
@@ -270,7 +305,7 @@ def iterative_closest_point(X, Y, thres=0.1, max_iterations=ICP_MAX_ITER,
                                              allow_reflection=allow_reflection, estimate_scale=estimate_scale)
         R, T = sol[0], sol[1]
         s = sol[2] if estimate_scale else X0.new_ones(b)                      # (:376-379: unit scale when not estimated)
-        Xt = s[:, None, None] * torch.bmm(X0, R) + T[:, None, :]              # :177,395
+        Xt = s[:, None, None] * point_mm(X0, R) + T[:, None, :]               # :177,395
         sq = ((Xt - nn) ** 2).sum(2)                                          # :191
         if kabsch_dtype is not None:
             sq = sq.to(kabsch_dtype)
@@ -305,7 +340,7 @@ def apply_icp(args, src, dst, init_poses, max_iterations=ICP_MAX_ITER, return_au
     kabsch_dtype: see corresponding_points_alignment (None = the reference's fp32)."""
     moved = transform_points_batch(src, init_poses)                           # :21
     M, sol = pytorch3d_icp(args, moved, dst, max_iterations, kabsch_dtype, sum_order)   # :23
-    M = torch.bmm(M, init_poses)                                              # :24
+    M = tiny_mm(M, init_poses)                                                # :24
     valid = src[:, :, -1] > 0.0                                               # :27
     _, e0 = nearest_neighbor_batch(moved, dst)                                # :28
     e0 = (e0 * valid).sum(1) / valid.sum(1)                                   # :29
@@ -492,6 +527,6 @@ def flow_estimation_torch(src_points, src_labels, pairs, transformations, pose):
     T = torch.eye(4)[None].repeat(n, 1, 1)
     rows, cols = torch.nonzero((src_labels[:, None] - pairs[:, 0][None, :]) == 0, as_tuple=True)
     T[rows] = transformations[cols]
-    T = torch.bmm(T, pose[None].expand(n, 4, 4))
+    T = tiny_mm(T, pose[None].expand(n, 4, 4))
     hom = torch.cat([src_points, src_points.new_ones(n, 1)], dim=-1)
-    return torch.bmm(T, hom[:, :, None])[:, 0:3, 0] - src_points
+    return tiny_mm(T, hom[:, :, None])[:, 0:3, 0] - src_points

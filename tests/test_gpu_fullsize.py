@@ -118,11 +118,15 @@ def test_config2_full_batch_vs_oracle(config2):
                      f"oracle self-disagreement > {DETERMINED_TOL:g} m on pairs {np.nonzero(~determined)[0].tolist()}"])
     print(msg)
     assert int(iters) == c["aux64"]["iterations"] == c["auxtr"]["iterations"], msg
-    assert determined.sum() >= 256 - 16, msg                 # the mask cannot swallow a regression
-    assert err32[determined].max() < TOL_M, msg              # the north-star bound, on every pair the oracle pins
-    assert errtr[determined].max() < TOL_M and err64[determined].max() < TOL_M, msg
-    assert (err64 < TOL_M).sum() >= 256 - 2, msg             # and against the exact evaluation nearly everywhere
-    # a pair outside the bound must be one of the oracle's own undetermined pairs
+    # EVERY pair, no mask: the whole 47-iteration trajectory against the exact (fp64 Kabsch) evaluation of the oracle
+    # (measured 2.4e-7 m; with the oracle's small matrix products pinned -- reference_path.point_mm -- its moved points
+    # are the kernels' bit for bit, so nothing but the Kabsch arithmetic separates the two)
+    assert err64.max() < 1e-5, msg
+    # the reference's own fp32 arithmetic (torch's and pairwise summation order): the north-star bound on every pair it
+    # pins; a pair outside the bound must be one of the oracle's own undetermined pairs (a report on ITS rounding:
+    # every pair is pinned by the line above and, step by step against the fp32 oracle, by tests/test_gpu_onestep.py)
+    assert determined.sum() >= 256 - 16, msg
+    assert err32[determined].max() < TOL_M and errtr[determined].max() < TOL_M, msg
     assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(np.nonzero(~determined)[0]), msg
 
 
@@ -400,10 +404,14 @@ def test_config4_shape_64_pair_batch_vs_oracle(config4_shard):
     T = T.cpu().numpy()
     determined = o["determined"]
     err32 = displacement(T, o["T32"], S)
-    msg = _report("HIP vs fp32 oracle (64 x 2048)", err32, determined) + f"\niterations HIP {int(iters)}, " + o["iters"]
+    err64 = displacement(T, o["T64"], S)
+    msg = (_report("HIP vs fp32 oracle (64 x 2048)", err32, determined) + "\n" + _report("HIP vs fp64-Kabsch oracle", err64, determined)
+           + f"\niterations HIP {int(iters)}, " + o["iters"])
     print(msg)
     assert int(iters) == o["aux64"]["iterations"] == o["auxtr"]["iterations"], msg
-    assert determined.sum() >= 64 - 16, msg      # every pair runs into the cap of 50 here: more of them still moving
+    assert err64.max() < 1e-5, msg               # every pair, no mask, against the exact evaluation of the oracle
+    # the reference's fp32 arithmetic: every pair it pins (every pair runs into the cap of 50 here: more of them are still
+    # moving, and fp32 summation order decides where those end up -- a report on the oracle's rounding, see config 2)
     assert err32[determined].max() < TOL_M, msg
     assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(np.nonzero(~determined)[0]), msg
 
