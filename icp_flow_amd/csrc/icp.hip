@@ -102,6 +102,7 @@ struct IcpParams {
     int estimateScale;       // s = trace(E S) / Xcov (:364-374), Xt = s X R + T
     const float *initS;      // [B] scale of the initial transform, NULL = 1
     int halfCu;              // launch policy: 512-thread workgroups, two per CU (see launch_icp_iters)
+    int persistent;          // grid = the workgroups the GPU holds at once; further pairs by ticket (see icp_kernel)
     int x0Cache;             // the records are followed by the queries' own points (12 B each): no L2 round trip per iteration
     int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
                              // certificates, see the search phase); a workgroup whose share of the queries fits uses them
@@ -423,9 +424,12 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
 // (512-thread workgroups are compiled for four waves per SIMD, 128 VGPRs, so that two of them share a CU)
 // SCALE: similarity transforms (estimate_scale, or an initial transform with a scale; sorted-sweep kernels only): the
 // plain kernels do not carry the extra multiplications.
-template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK == 512 && GRID == 4) ? 4 : 1)))
-void icp_kernel(IcpParams p, int itBegin, int itEnd)
+// One pair (one member of its team): every iteration of the launch.  Inlined into icp_kernel below, which decides WHICH
+// pair(s) this workgroup serves.
+// (P: IcpParams in whatever address space the caller reads it from)
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE, typename P>
+__device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank, const int G, const int itBegin,
+                                         const int itEnd)
 {
     ICPFLOW_STAMP(0);
     static_assert(GRID == 0 || TS == 1, "grid / sweep searches do not split targets over waves");
@@ -446,13 +450,11 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
     __shared__ float combD[TS > 1 ? NWAVE * Q * kWave : 1];   // [wave][q][lane]
     __shared__ int combC[TS > 1 ? NWAVE * Q * kWave : 1];
 
-    int b = blockIdx.x, rank = 0, G = 1;     // pair, member and size of the team serving it
+    static_assert(!TEAM || GRID >= 3, "teams: sorted sweep only");
+    IcpTeam team{};   // (a copy in the generic address space: `p` may live in the kernel-argument segment)
     if constexpr (TEAM) {
-        static_assert(!TEAM || GRID >= 3, "teams: sorted sweep only");
-        b = p.team.wgPair[blockIdx.x];
-        if (b < 0) return;                   // spare workgroup
-        rank = p.team.wgRank[blockIdx.x];
-        G = p.team.teamSize[b];
+        team.wgPair = p.team.wgPair; team.wgRank = p.team.wgRank; team.teamSize = p.team.teamSize;
+        team.arrived = p.team.arrived; team.mom = p.team.mom; team.maxWG = p.team.maxWG;
     }
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -544,7 +546,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
             // speculative mode: only member 0 watches the batch tally; it tells its team to stop
             // through the record of the iteration the others are about to exchange
             if (TEAM && G > 1 && rank == 0 && p.stopMode == ICPFLOW_STOP_REFERENCE_ && wave == 0)
-                team_publish(p.team, b, it, 0, 0.0, 1.0, lane);
+                team_publish(team, b, it, 0, 0.0, 1.0, lane);
             break;
         }
         // Speculative mode, wave 0: the batch rule cannot hold at an iteration at which THIS pair was not converged, so
@@ -1158,8 +1160,8 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                 // every member publishes its 18 partial moments, waits for the whole team and adds
                 // the records in member order: all members get bit-identical totals and solve for
                 // the same (R, T) on their own
-                team_publish(p.team, b, it, rank, mine, 0.0, lane);
-                teamStop = team_collect(p.team, ctrl, b, it, itBegin, G, lane, mine);
+                team_publish(team, b, it, rank, mine, 0.0, lane);
+                teamStop = team_collect(team, ctrl, b, it, itBegin, G, lane, mine);
             }
             if (teamStop) {   // leave (R, T) as they are; every wave of this member stops
                 active = 0;
@@ -1421,6 +1423,49 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
     }
 }
 
+// Which pairs a workgroup serves.  Teams: the plan's (pair, rank).  Otherwise workgroup w starts with pair w; with
+// `p.persistent` (a single launch of more pairs than the GPU holds workgroups of this kernel at once) the grid is only
+// as large as the GPU and a workgroup that has finished a pair draws the next one from a ticket counter.  The hardware's
+// own dispatcher deals workgroups to the eight XCDs round robin and IN ORDER: while one XCD has no free slot, the
+// workgroups behind the one that waits for it do not start either, whatever is free elsewhere -- measured on 8192 pairs
+// x 2048 points (per-workgroup wall clocks, tools/dbg/tail_clock_big.py): after the first third of the launch ~230 of
+// the 512 slots are occupied.  A ticket has no such order.
+// (PERSIST is a template parameter: the loop keeps more scalar state alive than the one-pair kernel, whose register
+// allocation at 128 VGPRs must not move -- it is the kernel of batches that fit the GPU, config 2 among them.)
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE = false, bool PERSIST = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK == 512 && GRID == 4) ? 4 : 1)))
+void icp_kernel(IcpParams p, int itBegin, int itEnd)
+{
+    int b = blockIdx.x, rank = 0, G = 1;     // pair, member and size of the team serving it
+    if constexpr (TEAM) {
+        b = p.team.wgPair[blockIdx.x];
+        if (b < 0) return;                   // spare workgroup
+        rank = p.team.wgRank[blockIdx.x];
+        G = p.team.teamSize[b];
+    }
+    if constexpr (!PERSIST) {
+        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE>(p, b, rank, G, itBegin, itEnd);
+    } else {
+        static_assert(!PERSIST || !TEAM, "teams are planned per launch");
+        __shared__ int nextPair;
+        // The parameters are read from the kernel-argument segment afresh for every pair (the pointer is laundered per
+        // round): loads from that constant address space can be repeated where the register allocator would otherwise
+        // keep ~60 scalars alive around the whole loop and spill them.
+        typedef const __attribute__((address_space(4))) IcpParams KernargParams;
+        KernargParams *pp = (KernargParams *)__builtin_amdgcn_kernarg_segment_ptr();
+        for (;;) {
+            asm volatile("" : "+s"(pp));
+            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE>(*pp, b, rank, G, itBegin, itEnd);
+            __syncthreads();                     // the pair's last reads of the static LDS state are done
+            if (threadIdx.x == 0)
+                nextPair = (int)gridDim.x + __hip_atomic_fetch_add(&p.ctrl->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            b = __builtin_amdgcn_readfirstlane(nextPair);   // (workgroup-uniform: keeps the pair's addresses scalar)
+            if (b >= p.B) break;
+        }
+    }
+}
+
 // speculative mode epilogue: the reference's stopping iteration is the first one at which every
 // pair had arrived and none was unconverged; every pair's state is taken from its history there.
 __global__ void icp_resolve_history_kernel(IcpState *__restrict__ st, IcpCtrl *__restrict__ ctrl,
@@ -1557,12 +1602,48 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
     }
     const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
                        : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + (size_t)p.recCap * (p.x0Cache ? 32 : 20) : 0;
+    IcpParams q = p;
+    q.persistent = 0;
+    // Batches larger than the GPU (sorted-sweep kernels, one launch for all iterations): a grid as large as the GPU, the
+    // other pairs by ticket (icp_kernel<..., PERSIST>)
+    if constexpr (!TEAM && !SCALE && GRID >= 3) {
+        if (p.persistent) {
+            constexpr auto kern = &icp_kernel<BLOCK, Q, TS, GRID, false, false, true>;
+            if (dyn > 48 * 1024) {
+                static std::atomic<unsigned long long> raisedP{0ull};
+                ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 156 * 1024, &raisedP);
+            }
+            // workgroups of this kernel the GPU holds at once (per device and dynamic-LDS size: asked once)
+            struct Slot { int dev; size_t dyn; int perCu; };
+            static std::atomic<int> nSlots{0};
+            static Slot slots[16];
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            int perCu = 0;
+            const int have = nSlots.load(std::memory_order_acquire);
+            for (int k = 0; k < have && k < 16; ++k)
+                if (slots[k].dev == dev && slots[k].dyn == dyn) perCu = slots[k].perCu;
+            if (perCu == 0) {
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void *>(kern), BLOCK, dyn) != hipSuccess ||
+                    perCu <= 0)
+                    perCu = 1;
+                const int k = nSlots.load(std::memory_order_acquire);
+                if (k < 16) { slots[k] = Slot{dev, dyn, perCu}; nSlots.store(k + 1, std::memory_order_release); }   // (a lost race only asks again)
+            }
+            const long long cap = (long long)perCu * device_cus();
+            if ((long long)B > cap) {
+                q.persistent = 1;
+                hipLaunchKernelGGL(kern, dim3((int)cap), dim3(BLOCK), dyn, s, q, itBegin, itEnd);
+                return;
+            }
+        }
+    }
     if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in once per instantiation and device
         static std::atomic<unsigned long long> raised{0ull};
         ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE>), 156 * 1024, &raised);
     }
     const int wgs = TEAM ? p.team.maxWG : B;
-    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE>), dim3(wgs), dim3(BLOCK), dyn, s, p, itBegin, itEnd);
+    hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE>), dim3(wgs), dim3(BLOCK), dyn, s, q, itBegin, itEnd);
 }
 
 // ---- optional per-launch timing of this (dominant) kernel with HIP events ---------------------
@@ -1850,6 +1931,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         // Beyond kHistIters iterations: one launch per iteration.
         if (speculative) {
             p.history = history;
+            p.persistent = opts.persistent ? 1 : 0;   // (one launch for all iterations: the ticket counter starts at zero)
             launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
             if (opts.historyPending != nullptr) {
                 *opts.historyPending = true;   // the consumers read the history themselves (posefuse.hpp)
@@ -1861,6 +1943,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
             for (int it = 0; it < maxIter; ++it) launch_icp_iters(p, B, it, it + 1, opts.profile, s);
         }
     } else {
+        p.persistent = opts.persistent ? 1 : 0;
         launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
     }
     return hipGetLastError();

@@ -32,7 +32,7 @@ struct IcpCtrl {
     int done;
     int iters;
     int error;     // a team member waited too long for its peers (results are poisoned with NaN)
-    int pad;
+    int ticket;    // persistent launches: pairs handed out beyond the first gridDim.x (icp_kernel)
     int notconv[kMaxIterCap];
     // speculative single-launch mode: per iteration, pairs arrived (low 32 bits) and pairs not
     // converged (high 32 bits), updated by ONE 64-bit atomic per pair so both are read consistently
@@ -158,6 +158,7 @@ struct IcpOpts {
     bool teams = true;             // several workgroups per large pair when the batch leaves CUs idle
     bool speculative = true;       // batch-global stop in ONE launch (false: one launch per iteration)
     bool adaptiveWindows = true;   // sorted sweep: per-query windows from the previous iteration's neighbours
+    bool persistent = true;        // batches larger than the GPU: a grid as large as the GPU, further pairs by ticket
     const float *initR = nullptr;  // [B,3,3] / [B,3]: state before the first iteration (init_transform), or identity
     const float *initT = nullptr;
     bool allowReflection = false;  // R = U V^T whatever its determinant (utils_icp_pytorch3d.py:354-362)

@@ -182,6 +182,31 @@ def test_adaptive_windows_change_nothing(shape):
     assert torch.equal(P0, utils_match.hist_icp(ap, s, d))
 
 
+@pytest.mark.parametrize("shape", ["config4_shard_1024x2048", "ragged_2500x700", "ragged_700x3000", "dense_1500x1024"])
+def test_ticket_dispatch_changes_nothing(shape):
+    """Batches larger than the GPU: the ICP launch is a grid as large as the GPU whose workgroups draw their further
+    pairs from a ticket counter (icp.hip icp_kernel<..., PERSIST>) instead of one workgroup per pair dealt by the hardware
+    dispatcher (round robin over the XCDs, in order: head-of-line blocking).  Which workgroup serves a pair changes
+    nothing: transforms and iteration counts bit-identical to ICPFLOW_OPT_NO_PERSISTENT, under both stop rules."""
+    if shape == "config4_shard_1024x2048":
+        S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
+    elif shape == "ragged_2500x700":
+        S, D, _ = synthetic.make_batch(2500, 700, seed=13, ragged=True, n_min=30)
+    elif shape == "ragged_700x3000":
+        S, D, _ = synthetic.make_batch(700, 3000, seed=17, ragged=True, n_min=200)
+    else:
+        S, D, _ = synthetic.make_batch(1500, 1024, seed=19)
+    s, d = G(S), G(D)
+    for stop in ("reference", "per_pair"):
+        a = rp.default_args(max_points=S.shape[1], icp_max_iterations=50, icp_stop_mode=stop)
+        with _lib.options(no_persistent=True):
+            T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert int(it0) == int(it1) and int(it1) > 0
+        assert torch.equal(T0, T1)
+        assert torch.equal(utils_match.hist_icp(a, s, d), T1)           # and from run to run
+
+
 @pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_90x2048"])
 def test_scoring_variants_change_nothing(shape):
     """The six candidate translations are scored by sorted sweeps with branch and bound when hist_icp has the clouds
