@@ -329,30 +329,74 @@ def extra_measurements(args, src, dst, T, dev, a):
     out["hist_all_pairs_vote_ms_per_batch"] = round(ms, 4)
     ms = timeit(lambda: utils_helper.nearest_neighbor_batch(src, dst))
     out["nearest_neighbor_batch_ms_per_batch"] = round(ms, 4)
-    # capacity with several INDEPENDENT batches in flight: consecutive batches alternate between HIP streams (each
-    # batch is still one 256-pair registration with its own batch-global stop rule and identical results); the tail
-    # of one batch's ICP launch -- few pairs still iterating, most CUs idle -- overlaps the next batch's vote and
-    # scoring.  Not the headline: `value` times one batch after the other on one stream.
-    streams = [torch.cuda.Stream(dev) for _ in range(4)]
-
-    def in_flight(steps):
-        outs = []
-        for i in range(steps):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                outs.append(utils_match.hist_icp(args, src, dst))
-        return outs
-
-    in_flight(8)
-    torch.cuda.synchronize(dev)
-    t = time.perf_counter()
-    outs = in_flight(40)
-    torch.cuda.synchronize(dev)
-    out["four_batches_in_flight_registrations_per_s"] = round(B * 40 / (time.perf_counter() - t), 1)
-    out["four_batches_in_flight_identical_results"] = bool(all(torch.equal(outs[0], o) for o in outs))
+    # capacity with several INDEPENDENT batches in flight through ONE call (icpflow_hist_icp_many / hist_icp_many): four
+    # different 256-pair config-2 batches (pairs 0..1023 of the generator), each one registration with its own
+    # batch-global stop rule and results identical to a call of its own; the tail of one batch's ICP launch -- few pairs
+    # still iterating, most CUs idle -- overlaps the vote and scoring of the others.  Not the headline: `value` times
+    # one batch after the other on one stream.
+    from icp_flow_amd import synthetic
+    many = [synthetic.make_batch(B, src.shape[1], seed=0, first=k * B) for k in range(4)]
+    srcs = [torch.from_numpy(m[0]).to(dev) for m in many]
+    dsts = [torch.from_numpy(m[1]).to(dev) for m in many]
+    separate = [utils_match.hist_icp(args, a_, b_) for a_, b_ in zip(srcs, dsts)]
+    ms, outs = None, None
+    for reps in (2, 10):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(reps):
+            outs = utils_match.hist_icp_many(args, srcs, dsts)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t) / reps * 1e3
+    out["four_batches_in_one_call_registrations_per_s"] = round(4 * B / ms * 1e3, 1)
+    out["four_batches_in_one_call_identical_to_separate_calls"] = bool(all(torch.equal(a_, b_) for a_, b_ in zip(outs, separate)))
+    ms = timeit(lambda: [utils_match.hist_icp(args, a_, b_) for a_, b_ in zip(srcs, dsts)], reps=10)
+    out["the_same_four_batches_one_after_the_other_registrations_per_s"] = round(4 * B / ms * 1e3, 1)
+    try:
+        out["ragged_real_shape"] = ragged_real_shape(dev)
+    except Exception as e:
+        out["ragged_real_shape"] = {"error": repr(e)}
     fp = frame_pair_measurement(dev)
     if fp is not None:
         out["frame_pair"] = fp
     return out
+
+
+def ragged_real_shape(dev, B=128, N=10000, cap=100):
+    """SURVEY 8(d) "ragged variant": the shape the real sweeps (BASELINE configs 3 and 5) present -- clusters of
+    n ~ logUniform(20, 10^4) points padded to max_points = 10000 (main.sh:10) with (1e8, 1e8, 1e8, 0), a frame's worth of
+    candidate pairs per batch (B = 128), the reference's 100-iteration cap (utils_icp.py:54).  Registrations/s of
+    hist_icp and a coarse split by entry point (each timed on its own): estimate_init_pose (vote, peaks, 12 scoring
+    scans), apply_icp (ICP from those poses + roll-back check), match_eval; the ICP kernel's share by HIP events."""
+    from types import SimpleNamespace
+    from icp_flow_amd import _lib, synthetic, utils_hist, utils_icp, utils_match
+    S, D, _ = synthetic.make_batch(B, N, seed=0, ragged=True, n_min=20)
+    src, dst = torch.from_numpy(S).to(dev), torch.from_numpy(D).to(dev)
+    args = SimpleNamespace(thres_dist=0.1, translation_frame=2.0, chunk_size=50, max_points=N, icp_max_iterations=cap,
+                           icp_stop_mode="reference")
+
+    def timeit(fn, reps=5):
+        fn()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / reps * 1e3, r
+
+    prof = _lib.Profile(64)
+    with _lib.options(profile=prof):
+        ms, (T, iters) = timeit(lambda: utils_match.hist_icp(args, src, dst, return_iterations=True))
+    icp_ms, launches = prof.collect()
+    prof.close()
+    ms_init, init = timeit(lambda: utils_hist.estimate_init_pose(args, src, dst))
+    ms_icp, _ = timeit(lambda: utils_icp.apply_icp(args, src, dst, init))
+    ms_eval, _ = timeit(lambda: utils_match.match_eval(args, src, dst, T))
+    n = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
+    return {"workload": f"{B} cluster pairs, n ~ logUniform(20, {N}) padded to {N}, <= {cap} ICP iterations (reference stop)",
+            "points_per_cluster_median": int(np.median(np.concatenate(n))), "points_per_cluster_max": int(max(n[0].max(), n[1].max())),
+            "registrations_per_s": round(B / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "icp_iterations": int(iters.item()),
+            "icp_kernel_ms_per_batch": round(icp_ms / 6, 3),   # (6 calls: one warm-up + 5 timed)
+            "split_ms": {"estimate_init_pose": round(ms_init, 3), "apply_icp": round(ms_icp, 3), "match_eval": round(ms_eval, 3)}}
 
 
 def frame_pair_measurement(dev):

@@ -46,6 +46,7 @@ SIGNATURES = {
     "icpflow_icp": (_i, [_p, _p, _p, _i, _i, _d, _i, _d, _i, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "icpflow_apply_icp": (_i, [_p, _p, _p, _i, _i, _d, _i, _d, _i, _p, _p, _p, _sz, _p, _p]),
     "icpflow_hist_icp": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_hist_icp_many": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _p, _p, _p]),
     "icpflow_match_eval": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "icpflow_gather_pad": (_i, [_p, _p, _i, _i, _p, _p]),
     "icpflow_gather_segments": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
@@ -234,3 +235,16 @@ def workspace(device, nbytes):
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def workspaces(device, sizes):
+    """Distinct cached scratch buffers for the batches of one icpflow_hist_icp_many call (slot k of the current stream)."""
+    out = []
+    for k, nbytes in enumerate(sizes):
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, "many", k)
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            _ws_cache[key] = buf
+        out.append(buf)
+    return out

@@ -267,17 +267,30 @@ struct SideStream {
     }
 };
 
-SideStream &side_stream()
+// One side stream per (host thread, caller stream): registrations issued on different streams from one thread -- the
+// batches of icpflow_hist_icp_many -- must not queue their sorts behind each other.  A handful of slots, recycled
+// round robin (a recycled slot keeps its stream: only the association changes).
+SideStream &side_stream(hipStream_t caller)
 {
-    static thread_local SideStream s;
+    constexpr int kSlots = 6;
+    struct Slot { SideStream s; hipStream_t caller = nullptr; bool used = false; };
+    static thread_local Slot slots[kSlots];
+    static thread_local int next = 0;
+    static thread_local SideStream none;
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) { s.ok = false; return s; }
-    if (s.device != dev) {   // first use on this thread, or the thread moved to another GPU
-        s.destroy();
-        s = SideStream{};
-        s.create();
+    if (hipGetDevice(&dev) != hipSuccess) { none.ok = false; return none; }
+    for (int k = 0; k < kSlots; ++k)
+        if (slots[k].used && slots[k].caller == caller && slots[k].s.device == dev) return slots[k].s;
+    Slot &sl = slots[next];
+    next = (next + 1) % kSlots;
+    if (!sl.used || sl.s.device != dev) {   // first use of the slot on this thread, or the thread moved to another GPU
+        sl.s.destroy();
+        sl.s = SideStream{};
+        sl.s.create();
     }
-    return s;
+    sl.used = true;
+    sl.caller = caller;
+    return sl.s;
 }
 
 // Joins the side stream back into the caller's stream when a fused entry point leaves early through an
@@ -722,7 +735,7 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     const GridScratch *search = search_scratch(w, N, o);
     SideStream *side = nullptr;
     if (search != nullptr && search->mode == 3 && N >= 64 && o.on(ICPFLOW_OPT_NO_SIDE_STREAM)) {
-        side = &side_stream();
+        side = &side_stream(s);
         if (!side->ok) side = nullptr;
     }
     if (side != nullptr) {
@@ -755,6 +768,62 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     guard.joined();
     return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
                               relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s);
+}
+
+// K independent batches in flight: batch k runs on worker stream k % 4 of the calling thread, forked from and joined
+// back into the caller's stream (stream capture sees one connected graph).  Every batch is one icpflow_hist_icp with its
+// own workspace, its own batch-global stop and bit-identical results; what overlaps is the tail of one batch's ICP
+// launch (few pairs still iterating, most CUs idle) with the vote and scoring of the others.
+int icpflow_hist_icp_many(int K, const float *const *d_src, const float *const *d_dst, const int *B, int N,
+                          const float *d_edges_x, int len_x, const float *d_edges_y, int len_y,
+                          const float *d_edges_z, int len_z, float decode_shift, double thres_dist,
+                          int max_iterations, double relative_rmse_thr, int stop_mode, float *const *d_T_out,
+                          int32_t *const *d_iters, void *const *d_ws, const size_t *ws_bytes,
+                          icpflow_stream_t stream, const icpflow_options_t *opt)
+{
+    if (K <= 0 || K > 64) return fail(ICPFLOW_E_ARG, "icpflow_hist_icp_many: K must be in 1..64 (got %d)", K);
+    if (!d_src || !d_dst || !B || !d_T_out || !d_iters || !d_ws || !ws_bytes)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp_many: null pointer");
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < k; ++j)
+            if (d_ws[k] == d_ws[j]) return fail(ICPFLOW_E_WORKSPACE, "icpflow_hist_icp_many: batches %d and %d share a workspace", j, k);
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int kWorkers = 4;
+    struct Pool {
+        hipStream_t w[kWorkers] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t fork = nullptr, join[kWorkers] = {nullptr, nullptr, nullptr, nullptr};
+        int device = -1;
+        bool ok = false;
+    };
+    static thread_local Pool pool;
+    int dev = -1;
+    ICPFLOW_TRY(hipGetDevice(&dev));
+    if (!pool.ok || pool.device != dev) {
+        // (streams and events of another device, if any, are abandoned to that device's context)
+        pool = Pool{};
+        pool.device = dev;
+        ICPFLOW_TRY(hipEventCreateWithFlags(&pool.fork, hipEventDisableTiming));
+        for (int k = 0; k < kWorkers; ++k) {
+            ICPFLOW_TRY(hipStreamCreateWithFlags(&pool.w[k], hipStreamNonBlocking));
+            ICPFLOW_TRY(hipEventCreateWithFlags(&pool.join[k], hipEventDisableTiming));
+        }
+        pool.ok = true;
+    }
+    const int used = K < kWorkers ? K : kWorkers;
+    ICPFLOW_TRY(hipEventRecord(pool.fork, s));
+    for (int k = 0; k < used; ++k) ICPFLOW_TRY(hipStreamWaitEvent(pool.w[k], pool.fork, 0));
+    int rc = 0;
+    for (int k = 0; k < K && rc == 0; ++k)
+        rc = icpflow_hist_icp(d_src[k], d_dst[k], B[k], N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z, len_z, decode_shift,
+                              thres_dist, max_iterations, relative_rmse_thr, stop_mode, d_T_out[k], d_iters[k], d_ws[k],
+                              ws_bytes[k], pool.w[k % kWorkers], opt);
+    // join whatever was enqueued, also on an error path (the workers must not outlive the call)
+    for (int k = 0; k < used; ++k) {
+        const hipError_t e1 = hipEventRecord(pool.join[k], pool.w[k]);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, pool.join[k], 0) : e1;
+        if (rc == 0 && e2 != hipSuccess) rc = hipfail(e2, "icpflow_hist_icp_many: join");
+    }
+    return rc;
 }
 
 int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_T, int B, int N,

@@ -28,6 +28,34 @@ def hist_icp(args, src, dst, return_iterations=False):
     return (out, iters) if return_iterations else out
 
 
+def hist_icp_many(args, srcs, dsts, return_iterations=False):
+    """K independent hist_icp batches (same max_points) in flight in ONE call (icpflow_hist_icp_many): each batch keeps
+    its own batch-global ICP stop and returns exactly what `hist_icp` returns for it; the library overlaps the tail of
+    one batch's ICP launch with the vote and scoring of the others on internal streams forked from / joined into the
+    current stream.  srcs, dsts: sequences of float32 [B_k, max_points, 4] -> list of [B_k,4,4] (and of iteration counts)."""
+    import ctypes
+    K = len(srcs)
+    assert K == len(dsts) and K > 0
+    ss = [_lib.cloud(x, "src") for x in srcs]
+    dd = [_lib.cloud(x, "dst") for x in dsts]
+    N = ss[0].shape[1]
+    dev = ss[0].device
+    assert all(a.shape == b.shape and a.shape[1] == N and a.device == dev for a, b in zip(ss, dd))
+    ex, ey, ez = bin_edges(args, dev)
+    lens = (len(ex), len(ey), len(ez))
+    max_it, rel, stop = _icp_options(args)
+    outs = [torch.empty((a.shape[0], 4, 4), dtype=torch.float32, device=dev) for a in ss]
+    iters = [torch.empty((1,), dtype=torch.int32, device=dev) for _ in ss]
+    need = [_lib.workspace_bytes(a.shape[0], N, lens) for a in ss]
+    ws = _lib.workspaces(dev, need)
+    arr = lambda ts: (ctypes.c_void_p * K)(*[t.data_ptr() for t in ts])   # noqa: E731
+    _lib.call("icpflow_hist_icp_many", K, arr(ss), arr(dd), (ctypes.c_int * K)(*[a.shape[0] for a in ss]), N,
+              _lib.ptr(ex), lens[0], _lib.ptr(ey), lens[1], _lib.ptr(ez), lens[2], float(args.thres_dist // 2),
+              float(args.thres_dist), max_it, rel, stop, arr(outs), arr(iters), arr(ws),
+              (ctypes.c_size_t * K)(*[w.numel() for w in ws]), _lib.stream(dev), _lib.opt())
+    return (outs, iters) if return_iterations else outs
+
+
 def match_eval(args, pcd1, pcd2, transformations):
     """utils_match.py:159-213 -> (errors, inliers, ratios, ious) [B,2], translations [B,3],
     rotations [B,3] (Euler ZYX degrees)."""

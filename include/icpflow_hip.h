@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 201 /* 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 202 /* 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -277,6 +277,24 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N,
                      double relative_rmse_thr, int stop_mode, float *d_T_out,
                      int32_t *d_iters, void *d_ws, size_t ws_bytes,
                      icpflow_stream_t stream, const icpflow_options_t *opt);
+
+/* ---------------------------------------------------------------------------
+ * a-11, several batches in flight.  K independent calls of icpflow_hist_icp (same N, histogram and ICP parameters;
+ * batch k: d_src[k], d_dst[k] of B[k] pairs, outputs d_T_out[k], d_iters[k], its OWN workspace d_ws[k] of
+ * ws_bytes[k] >= icpflow_workspace_bytes(B[k], N, ...)), enqueued on internal worker streams that are forked from and
+ * joined back into `stream`: to the caller it is one asynchronous call on `stream`.  Every batch keeps its own
+ * batch-global ICP stop (utils_icp_pytorch3d.py:209 couples the pairs of ONE hist_icp call, utils_match.py:138-157) and
+ * its results are bit-identical to a call of its own; what the overlap buys is the tail of one batch's ICP launch
+ * -- few pairs still iterating, most CUs idle -- running under the vote and scoring of the others.  The reference
+ * has no counterpart (it registers one batch after the other, main.py:184-215); frame pairs and association stages
+ * of different frames are independent and can be registered this way.
+ * ------------------------------------------------------------------------- */
+int icpflow_hist_icp_many(int K, const float *const *d_src, const float *const *d_dst, const int *B, int N,
+                          const float *d_edges_x, int len_x, const float *d_edges_y, int len_y,
+                          const float *d_edges_z, int len_z, float decode_shift, double thres_dist,
+                          int max_iterations, double relative_rmse_thr, int stop_mode, float *const *d_T_out,
+                          int32_t *const *d_iters, void *const *d_ws, const size_t *ws_bytes,
+                          icpflow_stream_t stream, const icpflow_options_t *opt);
 
 /* ---------------------------------------------------------------------------
  * a-12  registration quality metrics.

@@ -481,3 +481,63 @@ def test_vote_whose_quotient_rounds_to_one_lands_in_the_next_pair(tf):
     with _lib.options(vote_bins=bins):
         utils_hist.estimate_init_pose(a, G(S), G(D))
     assert np.array_equal(bins.cpu().numpy().view(np.uint32).astype(np.int64), want.reshape(5, L).astype(np.int64))
+
+
+# ------------------------------------------------------------------------------------------ ragged real shape
+def test_ragged_real_shape_16_pairs_vs_oracle():
+    """The shape real sweeps present (SURVEY 8(d) ragged variant, bench.py extras.ragged_real_shape): clusters of
+    n ~ logUniform(20, 10^4) points padded to max_points = 10000, the reference's 100-iteration cap.  The first 16 pairs
+    of the bench's batch against the oracle: initial poses equal, iteration count that of the exact evaluation, every
+    pair against the exact (fp64-Kabsch) evaluation of the oracle, and against its fp32 evaluation wherever the two agree."""
+    S, D, _ = synthetic.make_batch(128, 10000, seed=0, ragged=True, n_min=20)
+    S, D = S[:16], D[:16]
+    a = rp.default_args(max_points=10000, icp_max_iterations=100)
+    _all_host_threads()
+    T32, aux32 = rp.hist_icp(a, C(S), C(D), max_iterations=100, return_aux=True)
+    T64, aux64 = rp.hist_icp(a, C(S), C(D), max_iterations=100, return_aux=True, kabsch_dtype=torch.float64, init=aux32["init"])
+    T, iters = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+    init = utils_hist.estimate_init_pose(a, *[G(x) for x in _smaller_first(S, D)]).cpu().numpy()
+    assert np.array_equal(init, aux32["init"].numpy())
+    T = T.cpu().numpy()
+    err32, err64 = displacement(T, T32.numpy(), S), displacement(T, T64.numpy(), S)
+    agree = displacement(T32.numpy(), T64.numpy(), S) < DETERMINED_TOL
+    n = [(int((S[b, :, 3] > 0).sum()), int((D[b, :, 3] > 0).sum())) for b in range(16)]
+    msg = (f"cluster sizes {n}\niterations HIP {int(iters)}, fp32 oracle {aux32['iterations']}, fp64-Kabsch oracle {aux64['iterations']}\n"
+           f"vs fp64-Kabsch oracle {np.round(err64, 7).tolist()}\nvs fp32 oracle {np.round(err32, 7).tolist()}\nfp32 and fp64 oracle agree on {agree.tolist()}")
+    print(msg)
+    assert int(iters) == aux64["iterations"], msg
+    assert err64.max() < 1e-5, msg
+    assert err32[agree].max() < TOL_M, msg
+
+
+def _smaller_first(S, D):
+    n1, n2 = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
+    sw = n1 > n2                                                                # utils_match.py:142
+    A, B = S.copy(), D.copy()
+    A[sw], B[sw] = D[sw], S[sw]
+    return A, B
+
+
+# ------------------------------------------------------------------------------------------ several batches in flight
+def test_hist_icp_many_equals_separate_calls():
+    """icpflow_hist_icp_many: K independent batches through one call, on internal worker streams forked from / joined
+    into the caller's stream.  Every batch keeps its own batch-global stop: transforms and iteration counts are those of
+    K separate hist_icp calls, bit for bit -- batches of different sizes, more batches than worker streams, called from
+    the default and from a side stream, results consumed on the caller's stream without a host synchronisation."""
+    N = 1024
+    a = rp.default_args(max_points=N, icp_max_iterations=50)
+    shapes = [(256, False, 0), (64, True, 300), (256, False, 256), (300, True, 600), (17, False, 900), (256, False, 512)]
+    batches = [synthetic.make_batch(B, N, seed=0, first=first, ragged=r, n_min=40) for B, r, first in shapes]
+    srcs, dsts = [G(b[0]) for b in batches], [G(b[1]) for b in batches]
+    want = [utils_match.hist_icp(a, s_, d_, return_iterations=True) for s_, d_ in zip(srcs, dsts)]
+    for stream in (None, torch.cuda.Stream(DEV)):
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream(DEV)):
+            outs, iters = utils_match.hist_icp_many(a, srcs, dsts, return_iterations=True)
+            total = torch.stack([o.sum() for o in outs]).sum()         # consumed on the same stream, no host sync
+        torch.cuda.synchronize()
+        for (T0, it0), T1, it1 in zip(want, outs, iters):
+            assert int(it0) == int(it1) and torch.equal(T0, T1)
+        assert torch.isfinite(total)
+    # a single batch is the plain call
+    one, = utils_match.hist_icp_many(a, srcs[:1], dsts[:1])
+    assert torch.equal(one, want[0][0])
