@@ -145,6 +145,9 @@ def options(search=None, arith=None, profile=None, vote_bins=None, icp_init=None
     search: 'auto' | 'scan' | 'grid' | 'sweep';  arith: 'fp64' | 'fp32_reference';  profile: a Profile;
     vote_bins: uint32 device tensor [B, Lx*Ly*Lz] receiving the fused vote's bins;  switches: no_teams=True ..."""
     cur = dict(_current()[-1])
+    # device buffers belong to ONE call (their sizes follow that call's B, max_iterations, histogram): a nested block never
+    # inherits them from the block around it -- it names them itself or runs without
+    cur.update(vote_bins=None, icp_init=None, icp_history=None, icp_scale=None)
     if search is not None:
         cur["search"] = {"auto": 0, "scan": 1, "grid": 2, "sweep": 3}.get(search, search)
     if arith is not None:
@@ -248,3 +251,15 @@ def workspaces(device, sizes):
             _ws_cache[key] = buf
         out.append(buf)
     return out
+
+
+def check_vote_bins(B, lens):
+    """The debug export of the fused vote (options(vote_bins=...)) is written without size information on the C side:
+    refuse a tensor that is not uint32-sized [B, Lx*Ly*Lz] on the device."""
+    t = _current()[-1]["vote_bins"]
+    if t is None:
+        return
+    need = int(B) * int(lens[0]) * int(lens[1]) * int(lens[2])
+    if not t.is_cuda or t.element_size() != 4 or t.numel() < need or not t.is_contiguous():
+        raise RuntimeError(f"options(vote_bins=...): need a contiguous 4-byte device tensor of at least {need} elements "
+                           f"([B, Lx*Ly*Lz] = [{B}, {need // max(int(B), 1)}]), got {tuple(t.shape)} {t.dtype}")

@@ -647,13 +647,13 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     Workspace w(d_ws, B, N, 0);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, sizeof(IcpCtrl));
     IcpOpts io = o.icp(w.grid.sortX);
     io.initR = o.initR;
     io.initT = o.initT;
     io.allowReflection = o.allowReflection;
     io.estimateScale = o.estimateScale;
     io.initS = o.initS;
+    // (every argument check sits in front of the first launch: a refused call leaves the stream untouched)
     if ((o.allowReflection || o.estimateScale) && o.arith != ICPFLOW_ARITH_FP64)
         return fail(ICPFLOW_E_ARG, "icpflow_icp: allow_reflection / estimate_scale are not built for ICPFLOW_ARITH_FP32_REFERENCE");
     if (o.history != nullptr &&
@@ -667,6 +667,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     if ((o.estimateScale || o.initS != nullptr) && (search == nullptr || search->mode != 3))
         return fail(ICPFLOW_E_ARG, "icpflow_icp: estimate_scale / an initial transform with a scale need the sorted-sweep "
                                    "search (the default for 64 <= N <= %d)", kMaxSortN);
+    launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, sizeof(IcpCtrl));
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
                            relative_rmse_thr, stop_mode, w.state, w.ctrl, search, w.history, &w.team,
                            io, s));

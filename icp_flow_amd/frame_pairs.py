@@ -56,7 +56,7 @@ def default_args(**over):
 
 class FramePair:
     def __init__(self, points_src, points_dst, labels_src=None, labels_dst=None, pose=None, gt_flow=None, mask=None,
-                 name="", nonground_src=None, nonground_dst=None, gap=1, points_src_raw=None):
+                 name="", nonground_src=None, nonground_dst=None, gap=1, points_src_raw=None, pose_source="given"):
         self.points_src = np.ascontiguousarray(points_src, dtype=np.float32)[:, 0:3]
         self.points_dst = np.ascontiguousarray(points_dst, dtype=np.float32)[:, 0:3]
         if (labels_src is None) != (labels_dst is None):
@@ -81,6 +81,7 @@ class FramePair:
             raise ValueError(f"frame pair {name!r}: gt_flow must be [Ns,3]")
         self.mask = None if mask is None else np.asarray(mask)
         self.name = name
+        self.pose_source = pose_source        # where the ego pose came from (load_sequence), reported by run_stream
         # multi-gap samples (Waymo / nuScenes): frame `gap` against frame 0; the flow is reported on the source
         # points BEFORE ego-motion compensation (main.py:230-234), registration runs on the compensated ones
         self.gap = int(gap)
@@ -131,32 +132,58 @@ def is_sequence(path):
 
 def _pose_file(path):
     """The reference keeps estimated ego poses next to the split: .../val/x.npz -> .../val_pose/x.npz, key
-    `ego_motion` (dataset_pca.py:118-125)."""
-    for folder in ("train", "val", "test"):
-        if folder in path:
-            cand = path.replace(folder, folder + "_pose")
+    `ego_motion` (dataset_pca.py:118-125).  Only a DIRECTORY COMPONENT named train / val / test is a split (the last one
+    wins): '/latest/val/x.npz' -> '/latest/val_pose/x.npz', never '/latest_pose/...'."""
+    parts = os.path.normpath(path).split(os.sep)
+    for k in range(len(parts) - 2, -1, -1):
+        if parts[k] in ("train", "val", "test"):
+            cand = os.sep.join(parts[:k] + [parts[k] + "_pose"] + parts[k + 1:])
             return cand if os.path.isfile(cand) else None
     return None
 
 
-def load_sequence(path, args=None):
+POSE_SOURCES = ("auto", "pose_file", "ego_motion", "ego_motion_gt")
+
+
+def load_sequence(path, args=None, pose_source=None):
     """A multi-frame sample in the reference's Waymo / nuScenes format (dataset_pca.py:41-45) -> the list of
     frame pairs of the reference's loop, gap j = 1 .. num_frames - 1 (dataset_pca.py:164-198).
-    Keys: raw_points [m,>=3], time_indice [m] (0 .. F-1), ego poses [F,4,4] under `ego_motion` (the reference's
-    <split>_pose files, dataset_pca.py:122-125) or `ego_motion_gt`; optional nonground [m] (ground segmentation is
-    upstream), scene_flow [m,3] (ground truth, dataset_pca.py:67-69), labels [m] (precomputed per-frame cluster
+    Keys: raw_points [m,>=3], time_indice [m] (0 .. F-1), ego poses [F,4,4]; optional nonground [m] (ground segmentation
+    is upstream), scene_flow [m,3] (ground truth, dataset_pca.py:67-69), labels [m] (precomputed per-frame cluster
     labels are NOT possible in this format: frames are clustered jointly per gap).  args.range_x / range_y crop
-    the scene like dataset_pca.py:61-64."""
+    the scene like dataset_pca.py:61-64.
+
+    Ego poses (`pose_source`, default args.pose_source or "auto"): the reference reads ESTIMATED poses from its
+    <split>_pose files (key `ego_motion`, dataset_pca.py:118-125) and estimates them itself (KISS-ICP, out of scope here)
+    when the file is missing.  "pose_file": that file, an error without it; "ego_motion": the key of that name in the
+    sample itself; "ego_motion_gt": the GROUND-TRUTH poses of the sample -- accuracy measured with them is not the
+    reference's protocol; "auto": pose file, else in-file `ego_motion`, else `ego_motion_gt` WITH a warning.  Every
+    frame pair records where its pose came from (`FramePair.pose_source`, carried into run_stream's results)."""
+    import warnings
+    source = pose_source or (getattr(args, "pose_source", None) if args is not None else None) or "auto"
+    if source not in POSE_SOURCES:
+        raise ValueError(f"pose_source must be one of {POSE_SOURCES} (got {source!r})")
     with np.load(path) as z:
         keys = set(z.files)
         raw = np.asarray(z["raw_points"])[:, 0:3].astype(np.float64)
         t = np.asarray(z["time_indice"]).astype(np.int64)
-        side = _pose_file(path)
+        side = _pose_file(path) if source in ("auto", "pose_file") else None
         if side is not None:
             with np.load(side) as zp:
                 poses = np.asarray(zp["ego_motion"]).astype(np.float64)
+            used = "pose_file"
+        elif source == "pose_file":
+            raise FileNotFoundError(f"{path}: no <split>_pose file next to the split directory (pose_source='pose_file')")
+        elif source in ("auto", "ego_motion") and "ego_motion" in keys:
+            poses, used = np.asarray(z["ego_motion"]).astype(np.float64), "ego_motion"
+        elif source in ("auto", "ego_motion_gt") and "ego_motion_gt" in keys:
+            poses, used = np.asarray(z["ego_motion_gt"]).astype(np.float64), "ego_motion_gt"
+            if source == "auto":
+                warnings.warn(f"{path}: no estimated ego poses (no <split>_pose file, no `ego_motion` key): falling back to "
+                              "GROUND-TRUTH poses `ego_motion_gt`; the reference would estimate them (dataset_pca.py:126-130). "
+                              "Pass pose_source='ego_motion_gt' to accept this silently.", stacklevel=2)
         else:
-            poses = np.asarray(z["ego_motion"] if "ego_motion" in keys else z["ego_motion_gt"]).astype(np.float64)
+            raise KeyError(f"{path}: no ego poses for pose_source={source!r} (keys: {sorted(keys)})")
         nonground = np.asarray(z["nonground"]).astype(bool) if "nonground" in keys else None
         gt = np.asarray(z["scene_flow"])[:, 0:3].astype(np.float32) if "scene_flow" in keys else None
     if raw.shape[0] != t.shape[0] or poses.shape[1:] != (4, 4) or poses.shape[0] != t.max() + 1:
@@ -178,13 +205,13 @@ def load_sequence(path, args=None):
                              name=f"{os.path.basename(path)}#gap{j}",
                              nonground_src=None if nonground is None else nonground[m],
                              nonground_dst=None if nonground is None else nonground[t == 0],
-                             gap=j, points_src_raw=src_raw))
+                             gap=j, points_src_raw=src_raw, pose_source=used))
     return out
 
 
-def load_any(path, args=None):
+def load_any(path, args=None, pose_source=None):
     """-> list of FramePair: one for a frame-pair file, num_frames - 1 for a sequence file."""
-    return load_sequence(path, args) if is_sequence(path) else [load_frame_pair(path)]
+    return load_sequence(path, args, pose_source) if is_sequence(path) else [load_frame_pair(path)]
 
 
 def list_frame_pairs(directory):
@@ -269,7 +296,9 @@ def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, regis
     mine = shard_round_robin(paths, rank, world)
     meter = utils_eval.AverageMeter()
     times, matched = [], 0
+    pose_sources = {}
     for fp in (fp for path in mine for fp in load_any(path, args)):   # a sequence file yields one pair per gap
+        pose_sources[fp.pose_source] = pose_sources.get(fp.pose_source, 0) + 1
         if repeat > 1:
             register_fn(args, fp, device)                   # untimed pass: page-in, allocator
         sync()
@@ -296,7 +325,8 @@ def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, regis
     out = {"frame_pairs": n_fp, "matched_cluster_pairs": int(tot[8]), "n_gpus": world,
            "ms_per_frame_pair": tot[6] / max(n_fp, 1),
            "frame_pairs_per_s": n_fp / (float(tmax.item()) * 1e-3) if n_fp else 0.0,
-           "evaluated_points": int(n_pts)}
+           "evaluated_points": int(n_pts),
+           "pose_sources": pose_sources}     # (this rank's frame pairs: "ego_motion_gt" = ground-truth ego poses were used)
     if n_pts > 0:
         out.update({m: tot[k] / n_pts for k, m in enumerate(utils_eval.METRIC_NAMES)})
     return out

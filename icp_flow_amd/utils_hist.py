@@ -50,6 +50,7 @@ def estimate_init_pose_batch(args, src, dst):
     ex, ey, ez = bin_edges(args, s.device)
     lens = (len(ex), len(ey), len(ez))
     T = torch.empty((B, 4, 4), dtype=torch.float32, device=s.device)
+    _lib.check_vote_bins(B, lens)
     ws = _lib.workspace(s.device, _lib.workspace_bytes(B, N, lens))
     shift = float(args.thres_dist // 2)                                  # utils_hist.py:78
     _lib.call("icpflow_estimate_init_pose", _lib.ptr(s), _lib.ptr(d), B, N, _lib.ptr(ex), lens[0],

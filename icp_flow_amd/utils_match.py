@@ -21,6 +21,7 @@ def hist_icp(args, src, dst, return_iterations=False):
     max_it, rel, stop = _icp_options(args)
     out = torch.empty((B, 4, 4), dtype=torch.float32, device=s.device)
     iters = torch.empty((1,), dtype=torch.int32, device=s.device)   # always written by the call
+    _lib.check_vote_bins(B, lens)
     ws = _lib.workspace(s.device, _lib.workspace_bytes(B, N, lens))
     _lib.call("icpflow_hist_icp", _lib.ptr(s), _lib.ptr(d), B, N, _lib.ptr(ex), lens[0], _lib.ptr(ey),
               lens[1], _lib.ptr(ez), lens[2], float(args.thres_dist // 2), float(args.thres_dist), max_it,
@@ -46,6 +47,8 @@ def hist_icp_many(args, srcs, dsts, return_iterations=False):
     max_it, rel, stop = _icp_options(args)
     outs = [torch.empty((a.shape[0], 4, 4), dtype=torch.float32, device=dev) for a in ss]
     iters = [torch.empty((1,), dtype=torch.int32, device=dev) for _ in ss]
+    if _lib._current()[-1]["vote_bins"] is not None:
+        raise RuntimeError("options(vote_bins=...) describes ONE batch: not available through hist_icp_many")
     need = [_lib.workspace_bytes(a.shape[0], N, lens) for a in ss]
     ws = _lib.workspaces(dev, need)
     arr = lambda ts: (ctypes.c_void_p * K)(*[t.data_ptr() for t in ts])   # noqa: E731

@@ -113,3 +113,18 @@ def test_plain_c_program_consumes_the_header(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert out.stdout.startswith("ok ")
+
+
+def test_per_call_buffers_are_not_inherited_by_nested_option_blocks():
+    """options(vote_bins=..., icp_history=..., icp_init=..., icp_scale=...) name device buffers whose sizes follow ONE call;
+    a nested block keeps the switches of the block around it but never its buffers."""
+    from icp_flow_amd import _lib
+    marker = object()
+    with _lib.options(search="grid", no_teams=True, vote_bins=marker, icp_history=marker, icp_scale=marker, icp_init=(marker, marker)):
+        cur = _lib._current()[-1]
+        assert cur["vote_bins"] is marker and cur["icp_history"] is marker
+        with _lib.options(no_score_prune=True):
+            inner = _lib._current()[-1]
+            assert inner["search"] == 2 and inner["flags"] & _lib.OPT_FLAGS["no_teams"] and inner["flags"] & _lib.OPT_FLAGS["no_score_prune"]
+            assert inner["vote_bins"] is None and inner["icp_history"] is None and inner["icp_scale"] is None and inner["icp_init"] is None
+        assert _lib._current()[-1]["vote_bins"] is marker

@@ -147,7 +147,19 @@ def test_sequence_files_in_the_reference_waymo_format(tmp_path):
     np.savez(path, **d, sd_labels=np.zeros(len(d["raw_points"])), fb_labels=np.zeros(len(d["raw_points"])))
     assert frame_pairs.is_sequence(path)
     a = frame_pairs.default_args(speed=0.8333, range_x=30.0, range_y=30.0)
-    fps = frame_pairs.load_any(path, a)
+    # the sample only carries GROUND-TRUTH ego poses: "auto" falls back to them with a warning and says so in the result;
+    # asked for explicitly there is no warning; a missing estimated-pose file is an error when it is asked for
+    with pytest.warns(UserWarning, match="GROUND-TRUTH"):
+        fps = frame_pairs.load_any(path, a)
+    assert all(fp.pose_source == "ego_motion_gt" for fp in fps)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert len(frame_pairs.load_any(path, a, pose_source="ego_motion_gt")) == 2
+    with pytest.raises(FileNotFoundError):
+        frame_pairs.load_any(path, a, pose_source="pose_file")
+    with pytest.raises(KeyError):
+        frame_pairs.load_any(path, a, pose_source="ego_motion")
     assert [fp.gap for fp in fps] == [1, 2] and all(fp.labels_src is None for fp in fps)
     raw, t, P = d["raw_points"].astype(np.float64), d["time_indice"], d["ego_motion_gt"]
     keep = (np.abs(raw[:, 0]) < 30.0) & (np.abs(raw[:, 1]) < 30.0)
@@ -166,6 +178,17 @@ def test_sequence_files_in_the_reference_waymo_format(tmp_path):
     np.savez(os.path.join(tmp_path, "val_pose", "s0.npz"), ego_motion=est)
     fps2 = frame_pairs.load_any(path, a)
     assert np.allclose(fps2[0].pose, est[1].astype(np.float32)) and not np.allclose(fps2[0].points_src, fps[0].points_src)
+    assert all(fp.pose_source == "pose_file" for fp in fps2)
+    # only a DIRECTORY named like a split is one: '<tmp>/latest/val/...' must look in '<tmp>/latest/val_pose', and a
+    # 'val' inside another name ('interval') or inside the file name is not a split
+    deep = os.path.join(tmp_path, "interval_test_data", "latest", "val")
+    os.makedirs(deep)
+    p2 = os.path.join(deep, "val_s0.npz")
+    np.savez(p2, **d)
+    assert frame_pairs._pose_file(p2) is None
+    os.makedirs(os.path.join(tmp_path, "interval_test_data", "latest", "val_pose"))
+    np.savez(os.path.join(tmp_path, "interval_test_data", "latest", "val_pose", "val_s0.npz"), ego_motion=est)
+    assert frame_pairs._pose_file(p2) == os.path.join(tmp_path, "interval_test_data", "latest", "val_pose", "val_s0.npz")
     # a frame-pair file is still one pair
     one = os.path.join(tmp_path, "pair.npz")
     frame_pairs.save_frame_pair(one, frame_pairs.FramePair(fps[0].points_src, fps[0].points_dst))
