@@ -446,6 +446,20 @@ def frame_pair_measurement(dev):
                 entry["reference_runs_differ_between_tie_orders_by_m"] = float(np.abs(cpu["flow"] - ref["flow"]).max())
             except OSError:
                 pass
+        # the same frame pair as a STREAM (BASELINE configs 3 / 5 are streams of independent frame pairs, main.py:184-215):
+        # 12 copies, 4 in flight (frame_pairs.register_in_flight: one stream each, asynchronous hand-overs, one host
+        # thread); wall time of the stream over its frame pairs -- throughput, not the latency above
+        fp_obj = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
+        copies = [fp_obj] * 12
+        for in_flight in (4,):
+            for _ in frame_pairs.register_in_flight(a, copies[:4], dev, in_flight):
+                pass
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            flows = {i: o["flow"] for i, _, o in frame_pairs.register_in_flight(a, copies, dev, in_flight)}
+            torch.cuda.synchronize(dev)
+            entry[f"stream_ms_per_frame_pair_{in_flight}_in_flight"] = round((time.perf_counter() - t) / len(copies) * 1e3, 3)
+            entry[f"stream_{in_flight}_in_flight_identical_flow"] = bool(all(torch.equal(f, flow) for f in flows.values()))
         res[f"max_points_{mp}"] = entry
     res["cluster_dbscan"] = cluster_measurement(dev, g, gdir)
     res["cluster_hdbscan"] = hdbscan_measurement(dev, g, gdir)

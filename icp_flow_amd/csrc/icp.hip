@@ -369,8 +369,12 @@ __device__ __forceinline__ void team_publish(const IcpTeam &t, int b, int it, in
     double *slot = t.mom + (((size_t)b * 2 + (it & 1)) * kMaxTeam + rank) * kTeamStride;
     if (lane <= kMoments)
         __hip_atomic_store(&slot[lane], lane < kMoments ? mine : stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) __hip_atomic_fetch_add(&t.arrived[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // The record is the ONLY data the peers read, and it was stored write-through (agent-scope atomic stores are `sc1`
+    // stores: they do not linger in this XCD's L2).  Draining this wave's stores before the arrival is therefore all the
+    // release the hand-off needs; an agent-scope release FENCE would also write back every other dirty line of the XCD's
+    // L2 (~1.7 us and more, once per iteration, in the serial part of it).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&t.arrived[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // -> true when the team has to stop (member 0 said so, or the wait timed out); otherwise `mine` of
@@ -381,11 +385,13 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
     const unsigned want = (unsigned)G * (unsigned)(it - itBegin + 1);
     const long long t0 = wall_clock64();
     bool timeout = false;
-    while (__hip_atomic_load(&t.arrived[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    // (relaxed poll; the records are then read with agent-scope atomic loads -- `sc1` loads, which bypass this CU's L1 --
+    // of data that was stored write-through: no acquire fence, i.e. no L1 invalidation, is needed for them)
+    while (__hip_atomic_load(&t.arrived[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t0 > kTeamTimeoutTicks) { timeout = true; break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("" ::: "memory");
     if (timeout) {
         if (lane == 0) __hip_atomic_store(&ctrl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return true;
@@ -1793,8 +1799,26 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
         if (p.N <= 256) launch_icp_variant<256, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.N <= 512) launch_icp_variant<512, 1, 1, 4>(p, B, itBegin, itEnd, s);
         else if (p.team.wgPair != nullptr) {   // several workgroups per large pair (N > 1024)
+            // The members of a team wait for each other inside the launch.  Two team launches in flight at once (the
+            // same host thread registering on several streams: hist_icp_many, frame pairs in flight) could each hold
+            // part of the GPU with members that spin for teammates the other launch keeps from starting; so the team
+            // launches of one host thread are chained by an event, whatever streams they are on.  (Not under stream
+            // capture, where an event from outside the graph cannot be waited for: a captured registration stands alone.)
+            struct TeamLane { hipEvent_t ev = nullptr; int device = -1; bool recorded = false; };
+            static thread_local TeamLane lane;
+            int dev = -1;
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            const bool chain = hipGetDevice(&dev) == hipSuccess && hipStreamIsCapturing(s, &cap) == hipSuccess &&
+                               cap == hipStreamCaptureStatusNone;
+            if (chain && (lane.ev == nullptr || lane.device != dev)) {
+                lane = TeamLane{};
+                lane.device = dev;
+                if (hipEventCreateWithFlags(&lane.ev, hipEventDisableTiming) != hipSuccess) lane.ev = nullptr;
+            }
+            if (chain && lane.ev != nullptr && lane.recorded) (void)hipStreamWaitEvent(s, lane.ev, 0);
             if (p.N <= 12288) launch_icp_variant<768, 1, 1, 4, true>(p, B, itBegin, itEnd, s);
             else launch_icp_variant<768, 1, 1, 3, true>(p, B, itBegin, itEnd, s);
+            if (chain && lane.ev != nullptr) lane.recorded = hipEventRecord(lane.ev, s) == hipSuccess;
         }
         // 1024 threads (4 waves per SIMD, 128 VGPRs: the kernel fits but for three pointers spilled once
         // outside the loop) take a 1024-point cloud in one pass; up to 768 points 12 waves (170 VGPRs) do

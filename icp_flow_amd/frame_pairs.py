@@ -251,9 +251,11 @@ def cluster_frame_pair(args, ps, pd, nonground_src=None, nonground_dst=None):
     return labels[len(pd):].contiguous(), labels[: len(pd)].contiguous()
 
 
-def register_frame_pair(args, fp, device, gap=None):
-    """One frame pair through (cluster_pcd when it carries no labels +) track() + flow_estimation_torch() on
-    `device`.  -> dict(pairs [P,10], transformations [P,4,4], flow [Ns,3]) of device tensors."""
+def register_frame_pair_steps(args, fp, device, gap=None, asynchronous=False):
+    """One frame pair through (cluster_pcd when it carries no labels +) track() + flow_estimation_torch() on `device`, as
+    a generator that yields at every device -> host hand-over of the association (utils_match.match_pcds_steps) and
+    returns dict(pairs [P,10], transformations [P,4,4], flow [Ns,3]) of device tensors."""
+    from . import utils_match
     a = SimpleNamespace(**vars(args))
     a.translation_frame = frame_translation(args, fp.pose_exact, fp.gap if gap is None else gap)
     ps = torch.from_numpy(fp.points_src).to(device)
@@ -268,7 +270,7 @@ def register_frame_pair(args, fp, device, gap=None):
     # draws (random subsampling of over-long clusters) without touching the caller's global RNG state
     a.generator = torch.Generator()
     a.generator.manual_seed(0)
-    pairs, T = utils_track.track(a, ps, pd, ls, ld)
+    pairs, T = yield from utils_match.match_pcds_steps(a, ps, pd, ls, ld, asynchronous)      # utils_track.py:31-35
     if fp.points_src_raw is not None:
         # multi-gap sample: flow of the RAW source points, the ego pose composed in (main.py:230-234; T registers the
         # ego-compensated cloud, so a point moves by T * pose)
@@ -279,14 +281,86 @@ def register_frame_pair(args, fp, device, gap=None):
     return dict(pairs=pairs, transformations=T, flow=flow, translation_frame=a.translation_frame)
 
 
-def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, register_fn=None):
+def register_frame_pair(args, fp, device, gap=None):
+    """`register_frame_pair_steps` driven to its end (every hand-over blocks)."""
+    from . import utils_match
+    return utils_match.drive(register_frame_pair_steps(args, fp, device, gap))
+
+
+def register_in_flight(args, fps, device, in_flight=4):
+    """Register the frame pairs `fps` (an iterable) with up to `in_flight` of them at once: each on its own HIP stream,
+    its device -> host hand-overs as asynchronous copies into pinned memory, and ONE host thread that resumes whichever
+    frame pair's transfer has landed -- the host half of one frame pair (candidate lists, reject test, assignment) and
+    the gaps between its small launches run under the kernels of the others.  Frame pairs are independent
+    (main.py:184-215), every one gets exactly the result of `register_frame_pair` (its own random stream included).
+    Yields (index, frame pair, result dict) in completion order; the results' tensors are ready on the device."""
+    device = torch.device(device)
+    streams = [torch.cuda.Stream(device) for _ in range(max(int(in_flight), 1))]
+    free = list(range(len(streams)))
+    running = {}                                   # slot -> [index, fp, generator, pending]
+    source = enumerate(fps)
+    exhausted = False
+
+    def advance(slot):
+        idx, fp, gen, _ = running[slot]
+        with torch.cuda.stream(streams[slot]):
+            try:
+                running[slot][3] = next(gen)
+                return None
+            except StopIteration as done:
+                ev = torch.cuda.Event()
+                ev.record()
+                del running[slot]
+                free.append(slot)
+                return idx, fp, done.value, ev
+
+    finished = []
+    while True:
+        while free and not exhausted:
+            try:
+                idx, fp = next(source)
+            except StopIteration:
+                exhausted = True
+                break
+            slot = free.pop()
+            running[slot] = [idx, fp, register_frame_pair_steps(args, fp, device, asynchronous=True), None]
+            out = advance(slot)
+            if out is not None:
+                finished.append(out)
+        progressed = False
+        for slot in list(running):
+            if running[slot][3].ready():
+                out = advance(slot)
+                progressed = True
+                if out is not None:
+                    finished.append(out)
+        for k in range(len(finished) - 1, -1, -1):
+            if finished[k][3].query():
+                idx, fp, res, _ = finished.pop(k)
+                yield idx, fp, res
+                progressed = True
+        if not running and not finished and exhausted:
+            return
+        if not progressed:
+            # nothing has landed yet: wait for the oldest hand-over instead of spinning on the queries
+            if running:
+                next(iter(running.values()))[3].get()
+            elif finished:
+                finished[0][3].synchronize()
+
+
+def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, register_fn=None, in_flight=1):
     """Register this rank's share of `paths`; -> summary dict (identical on every rank).
     ms / frame pair is the mean wall time per pair, host -> device upload of the clouds included
     (the stream hands over host buffers); frame_pairs_per_s uses the slowest rank's total.
     `register_fn(args, fp, device) -> dict(pairs, transformations, flow)` defaults to the HIP path
-    (`register_frame_pair`); the CPU tests of the sharding logic pass the oracle here."""
+    (`register_frame_pair`); the CPU tests of the sharding logic pass the oracle here.
+    in_flight > 1 (HIP path only): that many frame pairs at once (`register_in_flight`: one stream each, asynchronous
+    hand-overs, one host thread); ms / frame pair is then the wall time of the whole share over its frame pairs --
+    throughput of the stream, not the latency of one pair."""
     import torch.distributed as dist
     device = torch.device(device)
+    pipelined = int(in_flight) > 1 and register_fn is None
     register_fn = register_fn or register_frame_pair
 
     def sync():
@@ -297,21 +371,37 @@ def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, regis
     meter = utils_eval.AverageMeter()
     times, matched = [], 0
     pose_sources = {}
-    for fp in (fp for path in mine for fp in load_any(path, args)):   # a sequence file yields one pair per gap
+
+    def account(fp, out):
+        nonlocal matched
         pose_sources[fp.pose_source] = pose_sources.get(fp.pose_source, 0) + 1
-        if repeat > 1:
-            register_fn(args, fp, device)                   # untimed pass: page-in, allocator
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(repeat):
-            out = register_fn(args, fp, device)
-        sync()
-        times.append((time.perf_counter() - t0) / repeat * 1e3)
         matched += int(out["pairs"].shape[0])
         if fp.gt_flow is not None:
             m = utils_eval.compute_epe_test(out["flow"].cpu().numpy(), fp.gt_flow, fp.mask)
             n = int((np.asarray(fp.mask) > 0).sum()) if fp.mask is not None else len(fp.gt_flow)
             meter.update(*m, n)
+
+    every = (fp for path in mine for fp in load_any(path, args))   # a sequence file yields one pair per gap
+    if pipelined:
+        sync()
+        t0 = time.perf_counter()
+        n = 0
+        for _, fp, out in register_in_flight(args, every, device, in_flight):
+            account(fp, out)
+            n += 1
+        sync()
+        times = [(time.perf_counter() - t0) * 1e3 / max(n, 1)] * n
+    else:
+        for fp in every:
+            if repeat > 1:
+                register_fn(args, fp, device)                   # untimed pass: page-in, allocator
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(repeat):
+                out = register_fn(args, fp, device)
+            sync()
+            times.append((time.perf_counter() - t0) / repeat * 1e3)
+            account(fp, out)
     # five weighted sums + point count + time + frame pairs + matches: one small all_reduce
     local = [getattr(meter, m + "_sum") for m in utils_eval.METRIC_NAMES] + [meter.num, sum(times), len(times), matched]
     on_gpu = world > 1 and dist.get_backend(group) == "nccl"
@@ -336,6 +426,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("directory")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--in-flight", type=int, default=1, help="frame pairs registered at once (streams, one host thread)")
     for k, v in DEFAULT_ARGS.items():
         kind = str if k == "cluster" else float if isinstance(v, float) or v is None else type(v)
         ap.add_argument("--" + k.replace("_", "-"), type=kind, default=v)
@@ -351,7 +442,7 @@ def main(argv=None):
     args = SimpleNamespace(**{k: getattr(ns, k) for k in DEFAULT_ARGS})
     args.max_points, args.min_cluster_size, args.chunk_size = int(args.max_points), int(args.min_cluster_size), int(args.chunk_size)
     args.num_clusters = int(args.num_clusters)
-    summary = run_stream(args, list_frame_pairs(ns.directory), device, rank, world, ns.repeat)
+    summary = run_stream(args, list_frame_pairs(ns.directory), device, rank, world, ns.repeat, in_flight=ns.in_flight)
     if rank == 0:
         print(json.dumps(summary))
     if world > 1:

@@ -129,16 +129,46 @@ def _launch_pairs(args, st, dt, pairs):
     return si, di, r
 
 
+class Pending:
+    """A device tensor on its way to the host.  Synchronous form (the default): `.cpu()` right away.  Asynchronous form
+    (frame pairs in flight, frame_pairs.run_stream): a copy into pinned memory on the current stream + an event; the
+    caller's scheduler resumes the frame pair once `ready()`, `get()` then returns without blocking."""
+    _pinned = {}
+
+    def __init__(self, t, asynchronous=False, slot=0):
+        if not asynchronous:
+            self.host, self.ev = t.cpu(), None
+            return
+        key = (torch.cuda.current_stream(t.device).cuda_stream, slot, t.dtype)
+        buf = Pending._pinned.get(key)
+        if buf is None or buf.numel() < t.numel():
+            buf = torch.empty(max(t.numel(), 1 << 14), dtype=t.dtype, pin_memory=True)
+            Pending._pinned[key] = buf
+        self.host = buf[: t.numel()].view(t.shape)
+        self.host.copy_(t, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+
+    def ready(self):
+        return self.ev is None or self.ev.query()
+
+    def get(self):
+        if self.ev is not None:
+            self.ev.synchronize()
+        return self.host.numpy()
+
+
 def _match_pairs_host(args, st, dt, pairs):
     """utils_match.py:69-136 on numpy candidate `pairs` [K,2] -> (pairs [P,10], transforms [P,4,4]) numpy."""
-    return _finish_pairs(args, st, dt, _launch_pairs(args, st, dt, pairs))
+    si, di, r = _launch_pairs(args, st, dt, pairs)
+    return _finish_pairs(args, st, dt, (si, di, r.cpu().numpy()))
 
 
 def _finish_pairs(args, st, dt, launched):
-    """The host half: ONE device -> host transfer of the [B, 31] results, reject test, S x D matrices, row arg-min."""
+    """The host half, on the [B, 31] results of the stage brought to the host in ONE transfer: reject test, S x D
+    matrices, row arg-min."""
     si, di, r = launched
     B = len(si)
-    r = r.cpu().numpy()                                                                            # the one sync
     if r[0, -1] < 0:
         # a team of workgroups sharing one large pair gave up waiting for a member (include/icpflow_hip.h, a-5):
         # the transforms are NaN.  Never let that pass as "no match" -- the points would silently get ego flow only.
@@ -186,13 +216,19 @@ def setdiff1d(t1, t2):
     return t12[counts == 1]
 
 
-def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
-    """utils_match.py:24-66: stage 1 registers clusters that keep their label across the two
-    frames (static / slow objects), stage 2 every remaining source cluster against every remaining
-    destination cluster.  -> pairs [P,10] (labels, errors, inliers, ratios, ious), transforms [P,4,4]."""
+def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, asynchronous=False):
+    """utils_match.py:24-66 as a generator: yields a `Pending` at each of its three device -> host hand-overs (cluster
+    tables, results of stage 1, results of stage 2) and returns (pairs [P,10], transforms [P,4,4]) device tensors.
+    `match_pcds` drives it to the end; frame_pairs.run_stream keeps several frame pairs in flight and resumes each one
+    when its transfer has landed, so that the host half of one frame pair runs under the kernels of the others."""
     _lib.require_gpu(src_points, dst_points, src_labels, dst_labels)
     dev = src_points.device
-    st, dt = ClusterTable.pair(src_points, src_labels, dst_points, dst_labels)
+    st, dt = ClusterTable(src_points, src_labels, fetch=False), ClusterTable(dst_points, dst_labels, fetch=False)
+    pend = Pending(torch.cat([st._packed, dt._packed], dim=0), asynchronous, 0)
+    yield pend
+    both = pend.get()
+    st.fetch(both[: len(st._packed)])
+    dt.fetch(both[len(st._packed):])
     src_unq, dst_unq = st.h_labels.astype(np.int64), dt.h_labels.astype(np.int64)
     labels_unq = np.unique(np.concatenate([src_unq, dst_unq]))
     empty = (np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32))
@@ -201,10 +237,15 @@ def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
     pairs = pairs[np.minimum(pairs[:, 0], pairs[:, 1]) >= 0].astype(np.float32)                  # :30-31
     pairs_true = pairs[_sanity_mask(args, st, dt, pairs)] if len(pairs) else pairs
     launched = _launch_pairs(args, st, dt, pairs_true) if len(pairs_true) > 0 else None
+    pend = Pending(launched[2], asynchronous, 1) if launched is not None else None
     # while stage 1 runs on the GPU: the sanity test of EVERY source cluster against every destination cluster (stage 2
     # reads the rows and columns of the clusters stage 1 leaves unmatched)
     grid = sanity_grid(args, st, dt, np.arange(len(src_unq)), np.arange(len(dst_unq))) if len(src_unq) and len(dst_unq) else None
-    pairs_sta, T_sta = _finish_pairs(args, st, dt, launched) if launched is not None else empty
+    if pend is not None:
+        yield pend
+        pairs_sta, T_sta = _finish_pairs(args, st, dt, (launched[0], launched[1], pend.get()))
+    else:
+        pairs_sta, T_sta = empty
 
     if len(pairs_sta) < len(labels_unq):                                                          # :42
         if len(pairs_sta) > 0:
@@ -217,7 +258,29 @@ def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
         pairs_true = np.stack([src_unq[rs], dst_unq[rd]], axis=1).astype(np.float32).reshape(-1, 2)
     else:
         pairs_true = pairs[:0]
-    pairs_dyn, T_dyn = _match_pairs_host(args, st, dt, pairs_true) if len(pairs_true) > 0 else empty
+    if len(pairs_true) > 0:
+        launched = _launch_pairs(args, st, dt, pairs_true)
+        pend = Pending(launched[2], asynchronous, 2)
+        yield pend
+        pairs_dyn, T_dyn = _finish_pairs(args, st, dt, (launched[0], launched[1], pend.get()))
+    else:
+        pairs_dyn, T_dyn = empty
     out = np.concatenate([pairs_sta, pairs_dyn], axis=0)
     T = np.concatenate([T_sta, T_dyn], axis=0)
-    return torch.from_numpy(out).to(dev), torch.from_numpy(T).to(dev)
+    return torch.from_numpy(out).to(dev, non_blocking=asynchronous), torch.from_numpy(T).to(dev, non_blocking=asynchronous)
+
+
+def drive(gen):
+    """Run a generator of `Pending`s to its end, blocking at every hand-over; -> its return value."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as done:
+        return done.value
+
+
+def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
+    """utils_match.py:24-66: stage 1 registers clusters that keep their label across the two
+    frames (static / slow objects), stage 2 every remaining source cluster against every remaining
+    destination cluster.  -> pairs [P,10] (labels, errors, inliers, ratios, ious), transforms [P,4,4]."""
+    return drive(match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels))

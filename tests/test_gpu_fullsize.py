@@ -541,3 +541,24 @@ def test_hist_icp_many_equals_separate_calls():
     # a single batch is the plain call
     one, = utils_match.hist_icp_many(a, srcs[:1], dsts[:1])
     assert torch.equal(one, want[0][0])
+
+
+# ------------------------------------------------------------------------------------------ launch shape vs results
+def test_results_do_not_depend_on_what_else_is_in_the_batch():
+    """The ICP launch picks its workgroup shape from the batch (teams of workgroups for few large pairs, one 1024-thread
+    workgroup per pair, two 512-thread workgroups per CU above two pairs per CU, ticket dispatch beyond the GPU's
+    capacity), and the fp64 moment sums follow that shape in their last bits.  With the per-pair stop rule (no coupling
+    through the batch-global stop) the same 40 pairs must come out the same whatever surrounds them: bounded by the
+    rounding of one fp32 state, far below the north-star tolerance."""
+    S, D, _ = synthetic.make_batch(1400, 2048, seed=3, ragged=True, n_min=600)
+    a = rp.default_args(max_points=2048, icp_max_iterations=50, icp_stop_mode="per_pair")
+    ref = None
+    for B in (40, 300, 700, 1400):        # teams / one workgroup per pair / two per CU / ticket dispatch
+        T = utils_match.hist_icp(a, G(S[:B]), G(D[:B]))[:40].cpu().numpy()
+        assert np.isfinite(T).all()
+        if ref is None:
+            ref = T
+        else:
+            d = displacement(T, ref, S[:40])
+            print(f"B {B}: max displacement of the first 40 pairs vs B 40: {d.max():.2e} m")
+            assert d.max() < 2e-5

@@ -1062,3 +1062,48 @@ def test_full_size_init_pose_pick_is_the_argmin_of_all_six_scores(config2):
     assert torch.equal(T[clear][:, 0:3, 3], want[clear])
     eye = torch.eye(3, device=DEV).expand(nb, 3, 3)
     assert torch.equal(T[:, 0:3, 0:3], eye)
+
+
+def test_frame_pairs_in_flight_equal_one_after_the_other(tmp_path):
+    """frame_pairs.register_in_flight: several frame pairs at once (one HIP stream each, asynchronous device -> host
+    hand-overs into pinned memory, one host thread resuming whichever has landed; team launches chained by an event).
+    Frame pairs are independent (main.py:184-215): every one comes out exactly as from register_frame_pair -- pairs,
+    transforms and per-point flow bit for bit -- whatever runs next to it; labelled synthetic pairs of different sizes,
+    the demo frame pair (teams of workgroups on its large clusters, twice, so that two team launches are in flight), and a
+    multi-gap sequence whose pairs are clustered on the GPU.  Then the stream harness with in_flight = 3."""
+    from icp_flow_amd import frame_pairs
+    fps = []
+    for k, (nobj, nmax) in enumerate(((9, 400), (14, 900), (5, 2500), (11, 300), (7, 1500))):
+        d = synthetic.make_frame_pair(seed=20 + k, n_objects=nobj, n_max=nmax, n_background=1000)
+        fps.append(frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"], d["gt_flow"]))
+    g0, lab = load_golden("g8_demo"), load_golden("g8_demo_labels")
+    demo = frame_pairs.FramePair(g0["point_src"], g0["point_dst"], lab["label_src"], lab["label_dst"], None, g0["gt_flow"])
+    fps = fps[:2] + [demo] + fps[2:] + [demo]
+    a = frame_pairs.default_args(max_points=4096)
+    want = [frame_pairs.register_frame_pair(a, fp, DEV) for fp in fps]
+    for in_flight in (2, 4):
+        got = {}
+        for idx, fp, out in frame_pairs.register_in_flight(a, fps, DEV, in_flight=in_flight):
+            assert fp is fps[idx]
+            got[idx] = out
+        torch.cuda.synchronize()
+        assert sorted(got) == list(range(len(fps)))
+        for k, w in enumerate(want):
+            for key in ("pairs", "transformations", "flow"):
+                assert torch.equal(got[k][key], w[key]), (in_flight, k, key)
+    # the harness: same accuracy summary as one at a time, on files (a sequence file among them: GPU clustering per gap)
+    paths = []
+    for k, fp in enumerate(fps[:4]):
+        paths.append(os.path.join(tmp_path, f"pair{k}.npz"))
+        frame_pairs.save_frame_pair(paths[-1], fp)
+    seq = synthetic.make_sequence(seed=3, num_frames=3, n_objects=6, n_max=400)
+    paths.append(os.path.join(tmp_path, "val_seq.npz"))
+    np.savez(paths[-1], **seq)
+    a2 = frame_pairs.default_args(max_points=2048, speed=1.67, cluster="dbscan", min_cluster_size=20, epsilon=0.8)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")           # (the synthetic sequence only carries ground-truth ego poses)
+        one = frame_pairs.run_stream(a2, paths, DEV)
+        many = frame_pairs.run_stream(a2, paths, DEV, in_flight=3)
+    assert many["frame_pairs"] == one["frame_pairs"] == 6 and many["matched_cluster_pairs"] == one["matched_cluster_pairs"]
+    assert many["evaluated_points"] == one["evaluated_points"] and abs(many["epe"] - one["epe"]) < 1e-9
