@@ -586,6 +586,31 @@ int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const i
     return 0;
 }
 
+size_t icpflow_cluster_table_workspace_bytes(int M, int Lmax)
+{
+    if (M <= 0 || Lmax <= 0) return 0;
+    size_t bytes = 0;
+    if (cluster_table_workspace_bytes(M, Lmax, &bytes) != hipSuccess) return 0;
+    return bytes;
+}
+
+int icpflow_cluster_table(const float *d_points, const float *d_labels, int M, int64_t *d_order, double *d_table, int Lmax,
+                          int32_t *d_num, void *d_ws, size_t ws_bytes, icpflow_stream_t stream)
+{
+    if (!d_points || !d_labels || !d_order || !d_table || !d_num)
+        return fail(ICPFLOW_E_ARG, "icpflow_cluster_table: null pointer");
+    if (M <= 0) return fail(ICPFLOW_E_ARG, "icpflow_cluster_table: M must be positive (got %d)", M);
+    if (Lmax <= 0 || Lmax > 4096) return fail(ICPFLOW_E_LIMIT, "icpflow_cluster_table: 1 <= Lmax <= 4096 (got %d)", Lmax);
+    if (!d_ws) return fail(ICPFLOW_E_WORKSPACE, "icpflow_cluster_table: workspace is NULL");
+    bool tooSmall = false;
+    ICPFLOW_TRY(launch_cluster_table(d_points, d_labels, M, d_order, d_table, Lmax, d_num, d_ws, ws_bytes, &tooSmall,
+                                     (hipStream_t)stream));
+    if (tooSmall)
+        return fail(ICPFLOW_E_WORKSPACE, "icpflow_cluster_table: workspace too small (%zu bytes, need %zu)", ws_bytes,
+                    icpflow_cluster_table_workspace_bytes(M, Lmax));
+    return 0;
+}
+
 int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
                        const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws, size_t ws_bytes,
                        icpflow_stream_t stream)

@@ -223,6 +223,11 @@ hipError_t launch_transform_points(const float *xyz, const float *pose, int B, i
                                    hipStream_t s);
 
 
+// table.hip: the cluster table of a labelled cloud (rows sorted by label, distinct labels, per-cluster statistics)
+hipError_t cluster_table_workspace_bytes(int M, int Lmax, size_t *bytes);
+hipError_t launch_cluster_table(const float *points, const float *labels, int M, int64_t *order, double *table, int Lmax,
+                                int32_t *num, void *ws, size_t wsBytes, bool *wsTooSmall, hipStream_t s);
+
 // cluster.hip: DBSCAN of a frame pair's points (labels int32 [n]: cluster id, -1 noise, -2 masked out)
 hipError_t dbscan_workspace_bytes(int n, size_t *bytes);
 hipError_t launch_dbscan(const float *pts, int stride, const uint8_t *mask, int n, double eps, int minPoints,

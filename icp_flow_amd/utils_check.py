@@ -17,61 +17,97 @@ def _np(x, dtype=None):
     return a if dtype is None else a.astype(dtype, copy=False)
 
 
-class ClusterTable:
-    """Per-label statistics of one labelled cloud.
+TABLE_ROWS = 512       # distinct labels a device table holds (the reference keeps num_clusters = 200 + noise + ground)
 
-    device:  points [M,3] float32, order [M] (stable argsort of the labels: rows of a cluster in original
-             order), labels_unq / count / start [L], mean / extent [L,3]
+
+class ClusterTable:
+    """Per-label statistics of one labelled cloud (`icpflow_cluster_table`: one chain of launches).
+
+    device:  points [M,3] float32, order [M] int64 (stable sort of the rows by label: rows of a cluster in original
+             order); after `fetch`: labels_unq / count / start [L], mean / extent [L,3] (views of the table)
     host:    h_labels (float32), h_count, h_start (int64), h_mean, h_extent (float32) -- the same numbers
     mean     centroid (utils_check.py:34-35);  extent: sorted bbox extents (get_bbox_tensor,
-             utils_helper.py:166-170)
+             utils_helper.py:166-170); both zero for negative labels (ground, noise: never candidates, :32)
     """
 
-    def __init__(self, points, labels, fetch=True):
+    def __init__(self, points, labels, fetch=True, _buffer=None):
         _lib.require_gpu(points, labels)
         self.points = points[:, 0:3].contiguous().float()
         self.labels = labels
         dev = labels.device
-        self.order = torch.argsort(labels, stable=True)
-        self.labels_unq, self.count = torch.unique_consecutive(labels[self.order], return_counts=True)
-        self.start = torch.cumsum(self.count, 0) - self.count
-        L = len(self.labels_unq)
-        self.labels_unq = self.labels_unq.float().contiguous()
-        self.mean = torch.empty((L, 3), dtype=torch.float32, device=dev)
-        self.extent = torch.empty((L, 3), dtype=torch.float32, device=dev)
-        _lib.call("icpflow_cluster_stats", _lib.ptr(self.points), _lib.ptr(self.order), _lib.ptr(self.start),
-                  _lib.ptr(self.count), _lib.ptr(self.labels_unq), L, _lib.ptr(self.mean), _lib.ptr(self.extent),
-                  _lib.stream(dev))
-        self._packed = torch.cat([self.labels_unq.double()[:, None], self.count.double()[:, None],
-                                  self.start.double()[:, None], self.mean.double(), self.extent.double()], dim=1)
+        lab = labels.contiguous().float()
+        M = int(lab.shape[0])
+        self.order = torch.empty((M,), dtype=torch.int64, device=dev)
+        # one buffer: [0] holds the int32 number of clusters (first four bytes), [1:] the float64 table [TABLE_ROWS, 9]
+        self._packed = _buffer if _buffer is not None else torch.empty((1 + TABLE_ROWS * 9,), dtype=torch.float64, device=dev)
+        ws = _lib.workspace(dev, int(_lib._L.icpflow_cluster_table_workspace_bytes(M, TABLE_ROWS)))
+        _lib.call("icpflow_cluster_table", _lib.ptr(self.points), _lib.ptr(lab), M, _lib.ptr(self.order),
+                  self._packed.data_ptr() + 8, TABLE_ROWS, _lib.ptr(self._packed), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
+        self._lab = lab
         if fetch:
             self.fetch()
 
     def fetch(self, packed=None):
         """Bring the table to the host: one device -> host transfer (float64 holds the float32 values
-        and the counts exactly).  `packed`: this table's rows of a transfer shared with other tables."""
-        packed = self._packed.cpu().numpy() if packed is None else packed
-        self.h_labels = packed[:, 0].astype(np.float32)
-        self.h_count = packed[:, 1].astype(np.int64)
-        self.h_start = packed[:, 2].astype(np.int64)
-        self.h_mean = packed[:, 3:6].astype(np.float32)
-        self.h_extent = packed[:, 6:9].astype(np.float32)
+        and the counts exactly).  `packed`: this table's part of a transfer shared with other tables."""
+        packed = self._packed.cpu().numpy() if packed is None else np.asarray(packed).reshape(-1)
+        L = int(packed[0:1].view(np.int32)[0])
+        if L < 0:
+            self._from_torch()          # more distinct labels than the device table holds: the chain of torch ops
+            return
+        rows = packed[1: 1 + L * 9].reshape(L, 9)
+        self._set_host(rows)
+        self._table = self._packed[1: 1 + L * 9].view(L, 9)
+
+    def _set_host(self, rows):
+        self.h_labels = rows[:, 0].astype(np.float32)
+        self.h_count = rows[:, 1].astype(np.int64)
+        self.h_start = rows[:, 2].astype(np.int64)
+        self.h_mean = rows[:, 3:6].astype(np.float32)
+        self.h_extent = rows[:, 6:9].astype(np.float32)
+
+    def _from_torch(self):
+        labels, dev = self._lab, self._lab.device
+        self.order = torch.argsort(labels, stable=True)
+        labels_unq, count = torch.unique_consecutive(labels[self.order], return_counts=True)
+        start = torch.cumsum(count, 0) - count
+        L = len(labels_unq)
+        labels_unq = labels_unq.float().contiguous()
+        mean = torch.empty((L, 3), dtype=torch.float32, device=dev)
+        extent = torch.empty((L, 3), dtype=torch.float32, device=dev)
+        _lib.call("icpflow_cluster_stats", _lib.ptr(self.points), _lib.ptr(self.order), _lib.ptr(start), _lib.ptr(count),
+                  _lib.ptr(labels_unq), L, _lib.ptr(mean), _lib.ptr(extent), _lib.stream(dev))
+        self._table = torch.cat([labels_unq.double()[:, None], count.double()[:, None], start.double()[:, None],
+                                 mean.double(), extent.double()], dim=1)
+        self._set_host(self._table.cpu().numpy())
+
+    # device views of the table (after fetch)
+    labels_unq = property(lambda self: self._table[:, 0].float())
+    count = property(lambda self: self._table[:, 1].long())
+    start = property(lambda self: self._table[:, 2].long())
+    mean = property(lambda self: self._table[:, 3:6].float())
+    extent = property(lambda self: self._table[:, 6:9].float())
 
     @staticmethod
-    def pair(src_points, src_labels, dst_points, dst_labels):
-        """Both tables of a frame pair with ONE device -> host transfer."""
-        st, dt = ClusterTable(src_points, src_labels, fetch=False), ClusterTable(dst_points, dst_labels, fetch=False)
-        both = torch.cat([st._packed, dt._packed], dim=0).cpu().numpy()
-        st.fetch(both[: len(st._packed)])
-        dt.fetch(both[len(st._packed):])
+    def pair(src_points, src_labels, dst_points, dst_labels, fetch=True):
+        """Both tables of a frame pair in ONE buffer: one device -> host transfer for the two."""
+        both = torch.empty((2, 1 + TABLE_ROWS * 9), dtype=torch.float64, device=src_labels.device)
+        st = ClusterTable(src_points, src_labels, fetch=False, _buffer=both[0])
+        dt = ClusterTable(dst_points, dst_labels, fetch=False, _buffer=both[1])
+        st._both = both
+        if fetch:
+            host = both.cpu().numpy()
+            st.fetch(host[0])
+            dt.fetch(host[1])
         return st, dt
 
     def find(self, wanted):
         """Index of each wanted label in labels_unq, or -1 where the cloud has no such cluster
         (device tensors)."""
-        pos = torch.searchsorted(self.labels_unq, wanted.to(self.labels_unq.dtype))
-        pos = pos.clamp(max=len(self.labels_unq) - 1)
-        hit = self.labels_unq[pos] == wanted.to(self.labels_unq.dtype)
+        unq = self.labels_unq
+        pos = torch.searchsorted(unq, wanted.to(unq.dtype))
+        pos = pos.clamp(max=len(unq) - 1)
+        hit = unq[pos] == wanted.to(unq.dtype)
         return torch.where(hit, pos, torch.full_like(pos, -1))
 
     def find_host(self, wanted):

@@ -137,7 +137,7 @@ class Pending:
 
     def __init__(self, t, asynchronous=False, slot=0):
         if not asynchronous:
-            self.host, self.ev = t.cpu(), None
+            self.host, self.ev, self._dev = None, None, t      # (copied when asked for: host work in between overlaps the GPU)
             return
         key = (torch.cuda.current_stream(t.device).cuda_stream, slot, t.dtype)
         buf = Pending._pinned.get(key)
@@ -155,6 +155,8 @@ class Pending:
     def get(self):
         if self.ev is not None:
             self.ev.synchronize()
+        elif self.host is None:
+            self.host = self._dev.cpu()
         return self.host.numpy()
 
 
@@ -223,12 +225,12 @@ def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, async
     when its transfer has landed, so that the host half of one frame pair runs under the kernels of the others."""
     _lib.require_gpu(src_points, dst_points, src_labels, dst_labels)
     dev = src_points.device
-    st, dt = ClusterTable(src_points, src_labels, fetch=False), ClusterTable(dst_points, dst_labels, fetch=False)
-    pend = Pending(torch.cat([st._packed, dt._packed], dim=0), asynchronous, 0)
+    st, dt = ClusterTable.pair(src_points, src_labels, dst_points, dst_labels, fetch=False)
+    pend = Pending(st._both, asynchronous, 0)
     yield pend
     both = pend.get()
-    st.fetch(both[: len(st._packed)])
-    dt.fetch(both[len(st._packed):])
+    st.fetch(both[0])
+    dt.fetch(both[1])
     src_unq, dst_unq = st.h_labels.astype(np.int64), dt.h_labels.astype(np.int64)
     labels_unq = np.unique(np.concatenate([src_unq, dst_unq]))
     empty = (np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32))

@@ -339,6 +339,18 @@ int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
                           const int64_t *d_count, const float *d_labels, int L, float *d_mean,
                           float *d_extent, icpflow_stream_t stream);
+/* icpflow_cluster_table: everything match_pcds needs to know about the clusters of ONE labelled cloud, in one chain of
+ * launches: d_order int64 [M] = the rows sorted by label, STABLE (rows of a cluster in their original order: the
+ * reference's random subsample of over-long clusters, utils_helper.py:198-201, indexes into that order); d_table
+ * float64 [Lmax, 9], row c = (label, number of rows, first position in d_order, centroid x y z, bounding-box extents in
+ * ascending order) of the c-th distinct label in ascending order -- what torch.unique(labels) (utils_match.py:27-29),
+ * the per-pair masks (:81-86) and sanity_check (utils_check.py:34-43, get_bbox_tensor utils_helper.py:166-170) compute
+ * cluster by cluster; centroid and extents are zero for negative labels (ground, noise: never candidates,
+ * utils_check.py:32).  d_num int32 [1]: the number of distinct labels, or its negative when it exceeds Lmax (<= 4096;
+ * the table then holds nothing usable).  float64 carries the float32 statistics and the counts exactly. */
+size_t icpflow_cluster_table_workspace_bytes(int M, int Lmax);
+int icpflow_cluster_table(const float *d_points, const float *d_labels, int M, int64_t *d_order, double *d_table, int Lmax,
+                          int32_t *d_num, void *d_ws, size_t ws_bytes, icpflow_stream_t stream);
 int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
                        const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws,
                        size_t ws_bytes, icpflow_stream_t stream);

@@ -1107,3 +1107,30 @@ def test_frame_pairs_in_flight_equal_one_after_the_other(tmp_path):
         many = frame_pairs.run_stream(a2, paths, DEV, in_flight=3)
     assert many["frame_pairs"] == one["frame_pairs"] == 6 and many["matched_cluster_pairs"] == one["matched_cluster_pairs"]
     assert many["evaluated_points"] == one["evaluated_points"] and abs(many["epe"] - one["epe"]) < 1e-9
+
+
+def test_cluster_table_chain_equals_the_torch_ops():
+    """icpflow_cluster_table (key kernel, radix sort, boundaries, rows, statistics: one chain of launches) against the
+    chain of torch ops it replaces (stable argsort, unique_consecutive, cumsum + icpflow_cluster_stats): the same row
+    order, labels, counts, starts, centroids and extents, bit for bit; float labels of either sign, a cloud with more
+    distinct labels than the device table holds (falls back to the torch ops), a single-cluster cloud."""
+    from icp_flow_amd.utils_check import ClusterTable, TABLE_ROWS
+    rng = np.random.default_rng(5)
+    cases = {"frame": rng.choice(np.array([-1e8, -1.0, 0, 1, 2, 7, 19, 300, 2.5, -3.25], dtype=np.float32), size=70000,
+                                 p=[0.5, 0.1, 0.05, 0.05, 0.1, 0.05, 0.05, 0.04, 0.03, 0.03]),
+             "many": rng.integers(0, TABLE_ROWS - 3, 50000).astype(np.float32),
+             "overflow": rng.integers(0, TABLE_ROWS + 500, 60000).astype(np.float32),
+             "one": np.full(777, 4.0, np.float32)}
+    for name, lab in cases.items():
+        pts = rng.normal(0, 20, size=(len(lab), 3)).astype(np.float32)
+        t = ClusterTable(G(pts), G(lab))
+        ref = ClusterTable.__new__(ClusterTable)
+        ref.points, ref._lab = t.points, G(lab)
+        ref._from_torch()
+        assert torch.equal(t.order, ref.order), name
+        for attr in ("h_labels", "h_count", "h_start", "h_mean", "h_extent"):
+            assert np.array_equal(getattr(t, attr), getattr(ref, attr)), (name, attr)
+        assert torch.equal(t.labels_unq, ref.labels_unq) and torch.equal(t.mean, ref.mean) and torch.equal(t.extent, ref.extent)
+        assert np.array_equal(t.h_labels, np.unique(lab))
+    st, dt = ClusterTable.pair(G(pts), G(cases["one"]), G(pts[:500]), G(cases["one"][:500]))
+    assert list(st.h_count) == [777] and list(dt.h_count) == [500]
