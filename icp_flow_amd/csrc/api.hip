@@ -59,6 +59,7 @@ struct Opts {
         o.speculative = on(ICPFLOW_OPT_NO_SPECULATIVE);
         o.adaptiveWindows = on(ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS);
         o.persistent = on(ICPFLOW_OPT_NO_PERSISTENT);
+        o.helpers = on(ICPFLOW_OPT_NO_HELPERS);
         o.profile = profile;
         return o;
     }
@@ -98,6 +99,8 @@ struct Workspace {
     float *Tinit = nullptr, *M = nullptr;
     IcpState *state = nullptr;
     IcpCtrl *ctrl = nullptr;
+    float *helpState = nullptr;
+    double *helpOut = nullptr;
     GridScratch grid{};
     float *history = nullptr;
     float *zsortA = nullptr, *zsortC = nullptr;   // z-sorted copies of both clouds (vote)
@@ -134,7 +137,9 @@ struct Workspace {
         Tinit = (float *)take(b * 16 * 4);
         M = (float *)take(b * 16 * 4);
         state = (IcpState *)take(b * sizeof(IcpState));
-        ctrl = (IcpCtrl *)take(sizeof(IcpCtrl));
+        ctrl = (IcpCtrl *)take(icp_ctrl_bytes(B));   // + the helpers' per-pair words and tags, cleared with it
+        helpState = (float *)take(b * 32 * 4);
+        helpOut = (double *)take((size_t)kHelpMaxWG * kHelpOutStride * 8);
         grid.H = grid_buckets(N);
         grid.origin = (float *)take(b * 4 * 4);
         grid.start = (int32_t *)take(b * ((size_t)grid.H + 1) * 4);
@@ -187,7 +192,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
     if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
-    if (opt->flags >> 10) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    if (opt->flags >> 11) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
     o.search = opt->icp_search;
     o.arith = opt->icp_arith;
     o.flags = opt->flags;
@@ -314,6 +319,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     // ICP's per-iteration history (or its state): no icp_resolve_history / compose launches in between
     bool historyPending = false;
     IcpOpts io = o.icp(w.grid.sortX);
+    io.help = icp_help_carve(w.ctrl, B, w.helpState, w.helpOut);
     if (sweepCheck && o.arith == ICPFLOW_ARITH_FP64) io.historyPending = &historyPending;
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
                            w.state, w.ctrl, search, w.history, &w.team, io, s));
@@ -673,6 +679,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
     IcpOpts io = o.icp(w.grid.sortX);
+    io.help = icp_help_carve(w.ctrl, B, w.helpState, w.helpOut);
     io.initR = o.initR;
     io.initT = o.initT;
     io.allowReflection = o.allowReflection;
@@ -692,7 +699,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     if ((o.estimateScale || o.initS != nullptr) && (search == nullptr || search->mode != 3))
         return fail(ICPFLOW_E_ARG, "icpflow_icp: estimate_scale / an initial transform with a scale need the sorted-sweep "
                                    "search (the default for 64 <= N <= %d)", kMaxSortN);
-    launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, sizeof(IcpCtrl));
+    launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, icp_ctrl_bytes(B));
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
                            relative_rmse_thr, stop_mode, w.state, w.ctrl, search, w.history, &w.team,
                            io, s));
@@ -720,7 +727,7 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
     Workspace w(d_ws, B, N, 0);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, sizeof(IcpCtrl));
+    launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, icp_ctrl_bytes(B));
     // d_T_out may alias d_init: keep a private copy of the init poses
     ICPFLOW_TRY(hipMemcpyAsync(w.Tinit, d_init, (size_t)B * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return run_icp_and_select(d_src, d_dst, w, nullptr, w.Tinit, B, N, thres_dist, max_iterations,
@@ -753,7 +760,7 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     // cloud (PairCountFuse), by count_pair otherwise
     const bool countInSort = N <= kMaxSortN && N <= kChunkSortMinN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE);
     if (!countInSort)
-        launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s, w.ctrl, sizeof(IcpCtrl), w.scoreAccum,
+        launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s, w.ctrl, icp_ctrl_bytes(B), w.scoreAccum,
                           (size_t)B * 12 * sizeof(double));
     // the axis sort of both clouds (scoring sweep, ICP) runs on the side stream next to the vote
     hipEvent_t join = nullptr;
@@ -782,7 +789,7 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     PairCountFuse fuse{};
     if (countInSort) {
         fuse.swapOut = w.swap;
-        fuse.zero0 = w.ctrl; fuse.bytes0 = sizeof(IcpCtrl);
+        fuse.zero0 = w.ctrl; fuse.bytes0 = icp_ctrl_bytes(B);
         fuse.zero1 = w.scoreAccum; fuse.bytes1 = (size_t)B * 12 * sizeof(double);
     }
     const bool sweepScore = score_by_sweep(N, join != nullptr, o);

@@ -37,7 +37,8 @@ __device__ int g_stamp_block;                  // the workgroup that stamps (icp
 // publication of (R, T) (the serial tail), in the rest of the loop, and the iterations it executed; and the tail split
 // at the phase stamps (accumulated in LDS by thread 0)
 __device__ long long g_tail_clock[1024 * 3];
-__device__ long long g_wg_wall[8192 * 4];   // per pair: wall clock (100 MHz) at entry and exit of its workgroup, HW_ID, XCC_ID
+__device__ long long g_wg_wall[8192 * 4];
+__device__ unsigned long long g_help_stats[8];   // helpers that joined a pair, passes the owners took from helpers, owner clocks spent waiting   // per pair: wall clock (100 MHz) at entry and exit of its workgroup, HW_ID, XCC_ID
 __device__ long long g_tail_split[1024 * 16];
 __shared__ long long g_tcSh[17];
 #ifdef ICPFLOW_TAIL_SPLIT   // (each stamp costs ~200 clocks: the totals above are measured without)
@@ -103,6 +104,11 @@ struct IcpParams {
     const float *initS;      // [B] scale of the initial transform, NULL = 1
     int halfCu;              // launch policy: 512-thread workgroups, two per CU (see launch_icp_iters)
     int persistent;          // grid = the workgroups the GPU holds at once; further pairs by ticket (see icp_kernel)
+    IcpHelp help;            // helpers of persistent launches (pair == NULL: none)
+    int helpOn;
+    int redPasses;           // sorted sweep in LDS, one workgroup per pair, N <= kRecMaxN: the moment sums of every (pass, wave)
+                             // are kept apart in dynamic LDS (this many passes) and added in (pass, wave) order; 0: one
+                             // running sum per lane over all passes (static LDS)
     int x0Cache;             // the records are followed by the queries' own points (12 B each): no L2 round trip per iteration
     int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
                              // certificates, see the search phase); a workgroup whose share of the queries fits uses them
@@ -433,9 +439,12 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
 // One pair (one member of its team): every iteration of the launch.  Inlined into icp_kernel below, which decides WHICH
 // pair(s) this workgroup serves.
 // (P: IcpParams in whatever address space the caller reads it from)
-template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE, typename P>
+// HELP (persistent sorted-sweep kernels): role 0 = the pair's owner, role j + 1 = helper in slot j of pair b: it runs pass
+// `passes - 1 - j` of every iteration from the state the owner publishes and hands the pass's moment sums back (see
+// HelpPair in kernels.hpp and icp_kernel).
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE, bool HELP, typename P>
 __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank, const int G, const int itBegin,
-                                         const int itEnd)
+                                         const int itEnd, const int role = 0)
 {
     ICPFLOW_STAMP(0);
     static_assert(GRID == 0 || TS == 1, "grid / sweep searches do not split targets over waves");
@@ -457,6 +466,12 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     __shared__ int combC[TS > 1 ? NWAVE * Q * kWave : 1];
 
     static_assert(!TEAM || GRID >= 3, "teams: sorted sweep only");
+    static_assert(!HELP || (GRID == 4 && !TEAM && Q == 1), "helpers: sorted sweep with the LDS image, one workgroup per pair");
+    __shared__ int helpSh[8];                 // [0] passes done by helpers this iteration (bit g), [1..3] their workgroups,
+                                              // [4] helper: E(next iteration), [5] scratch
+    [[maybe_unused]] const bool helping = HELP && role != 0;
+    [[maybe_unused]] HelpPair *hp = nullptr;
+    if constexpr (HELP) hp = (p.helpOn && p.help.pair != nullptr) ? p.help.pair + b : nullptr;
     IcpTeam team{};   // (a copy in the generic address space: `p` may live in the kernel-argument segment)
     if constexpr (TEAM) {
         team.wgPair = p.team.wgPair; team.wgRank = p.team.wgRank; team.teamSize = p.team.teamSize;
@@ -534,6 +549,50 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     const int per = NQG * kWave * Q;         // queries per pass of the workgroup
     const int ngroups = (xc.n + per - 1) / per;
 
+    int itFirst = itBegin;   // first iteration of THIS workgroup on the pair (a helper joins later)
+    if constexpr (HELP) {
+        if (tid == 0) helpSh[0] = 0;          // (no pass of the first iteration comes from a helper; none ever without helpers)
+        if (hp == nullptr) __syncthreads();
+        if (hp != nullptr && !helping) {
+            // owner: how many passes the pair has, and that it is being iterated on by this workgroup
+            if (tid == 0) {
+                __hip_atomic_store(&hp->passes, (xc.n + BLOCK - 1) / BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&hp->iter, itBegin + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&p.help.owner[blockIdx.x], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        if (helping) {
+            // helper: announce "(this workgroup, from iteration cur + 1 on)", then wait for the owner's state of an
+            // iteration >= that.  Two iterations of lead: the owner reads the announcement at the END of an iteration.
+            if (tid == 0) {
+                int e = 0;
+                const int cur = __hip_atomic_load(&hp->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur > 0) {
+                    const int from = cur + 2;
+                    __hip_atomic_store(&hp->from[role - 1], ((int)blockIdx.x << 8) | from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const long long t0 = wall_clock64();
+                    for (;;) {
+                        e = __hip_atomic_load(&hp->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (e < 0 || e >= from) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (wall_clock64() - t0 > kTeamTimeoutTicks) { e = -1; break; }
+                    }
+                } else e = -1;
+                helpSh[4] = e;
+            }
+            __syncthreads();
+            const int e0 = __builtin_amdgcn_readfirstlane(helpSh[4]);   // (workgroup-uniform: keep the loop counter scalar)
+#ifdef ICPFLOW_TAIL_CLOCK
+            if (tid == 0) atomicAdd(&g_help_stats[e0 > 0 ? 0 : 3], 1ull);
+#endif
+            if (e0 <= 0) return;                       // the pair is finished (or was never started)
+            itFirst = e0 - 1;
+            if (tid < 12) bcast[tid] = __hip_atomic_load(&p.help.state[((size_t)b * 2 + (e0 & 1)) * 16 + tid], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
+    }
     int specChk = 0;  // speculative mode: first iteration not yet known to be complete-and-unconverged
     int winLo = -1, winHi = -1;   // sorted sweep: this wave's target window of the previous iteration
     int prevNN = -2;              // certificates, single pass: this lane's gated neighbour of the previous iteration
@@ -547,7 +606,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     if (threadIdx.x < 17) g_tcSh[threadIdx.x] = threadIdx.x == 16 ? clock64() : 0;
     __syncthreads();
 #endif
-    for (int it = itBegin; it < itEnd; ++it) {
+    for (int it = itFirst; it < itEnd; ++it) {
         if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
             // speculative mode: only member 0 watches the batch tally; it tells its team to stop
             // through the record of the iteration the others are about to exchange
@@ -562,7 +621,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
         // (the XCDs' L2s are not coherent), which is not something to wait for in the serial tail.
         unsigned long long specTally = 0ull;
         bool specLoaded = false;
-        if (wave == 0 && p.history != nullptr && rank == 0) {
+        if (wave == 0 && p.history != nullptr && rank == 0 && !helping) {
             // (wave-uniform values kept scalar: left to itself the compiler vectorises this search over the lanes)
             specChk = __builtin_amdgcn_readfirstlane(specChk);
             {
@@ -621,7 +680,11 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             const int axis = sweepAxis;
             // GRID == 4: the sorted fixed cloud is staged into LDS once per launch and every
             // per-iteration access (window search, scan, resolve) stays on chip
-            float *lx = reinterpret_cast<float *>(dynLds), *ly = lx + NP16, *lz = ly + NP16;
+            // dynamic LDS: [moment sums per (pass, wave): redPasses x NWAVE x 18 doubles][image][records][own points]
+            unsigned char *dyn = dynLds + (size_t)p.redPasses * (NWAVE * kMoments * sizeof(double));
+            float *lx = reinterpret_cast<float *>(dyn), *ly = lx + NP16, *lz = ly + NP16;
+            const bool perPass = !TEAM && p.redPasses != 0;
+            double *redDyn = reinterpret_cast<double *>(dynLds);
             // Neighbour certificates.  The search answers one question per query: which target is nearest, and is it
             // inside the gate.  After the first iterations the answer hardly ever changes, and that can be PROVEN
             // without searching: a search at position q0 that found the neighbour j1 also knows a lower bound L on the
@@ -641,13 +704,13 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             const int qShare = (TEAM && G > 1) ? ((xc.n + G - 1) / G + kWave - 1) / kWave * kWave : xc.n;
             const int qBegin = min(rank * qShare, xc.n), qEnd = min(qBegin + qShare, xc.n);
             // records of this workgroup's queries (indexed from qBegin), if its share fits the room behind the image
-            float4 *rec = reinterpret_cast<float4 *>(dynLds + (size_t)NP16 * 12) - qBegin;
-            int *recJ = reinterpret_cast<int *>(dynLds + (size_t)NP16 * 12 + (size_t)p.recCap * 16) - qBegin;
+            float4 *rec = reinterpret_cast<float4 *>(dyn + (size_t)NP16 * 12) - qBegin;
+            int *recJ = reinterpret_cast<int *>(dyn + (size_t)NP16 * 12 + (size_t)p.recCap * 16) - qBegin;
             const bool recOn = REC && p.recCap > 0 && qEnd - qBegin <= p.recCap;
             // (and the query's own point, pre-pose applied, when there is room: read from L2 once, not once per iteration)
-            float *x0c = reinterpret_cast<float *>(dynLds + (size_t)NP16 * 12 + (size_t)p.recCap * 20) - qBegin;
+            float *x0c = reinterpret_cast<float *>(dyn + (size_t)NP16 * 12 + (size_t)p.recCap * 20) - qBegin;
             const bool x0On = recOn && p.x0Cache != 0;
-            if (GRID == 4 && it == itBegin) {
+            if (GRID == 4 && it == itFirst) {
                 for (int k = tid; k < np16; k += BLOCK) { lx[k] = gx[k]; ly[k] = gy[k]; lz[k] = gz[k]; }
                 __syncthreads();
             }
@@ -657,7 +720,12 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             const int ngr = (qEnd - qBegin + PER - 1) / PER;
             double fold[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
             bool reuseMoments = false;   // this wave's 18 sums are those of the previous iteration (still in `red`)
+            [[maybe_unused]] int helpedPasses = 0;   // owner: passes of this iteration that helpers deliver (bit g)
+            if constexpr (HELP) helpedPasses = helping ? 0 : __builtin_amdgcn_readfirstlane(helpSh[0]);
             for (int g = 0; g < ngr; ++g) {
+                if constexpr (HELP) {
+                    if (helping ? g != ngr - role : ((helpedPasses >> g) & 1) != 0) continue;   // (workgroup-uniform)
+                }
                 float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
                 bool live[Q];
                 float lo = kInf, hi = -kInf;
@@ -683,7 +751,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     x0x[q] = x0y[q] = x0z[q] = 0.f;
                     qx[q] = qy[q] = qz[q] = 0.f;
                     if (live[q]) {
-                        if (x0On && it > itBegin) {
+                        if (x0On && it > itFirst) {
                             x0x[q] = x0c[i]; x0y[q] = x0c[p.recCap + i]; x0z[q] = x0c[2 * p.recCap + i];
                         } else {
                         const float4 s4 = xs[i];   // sorted; pre-pose (utils_icp.py:21) applied by the sort or here
@@ -709,7 +777,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         float m = p.sweepMargin;
                         if (recOn) {
                             m = certMargin;   // first iteration: nothing known
-                            if (it > itBegin) {
+                            if (it > itFirst) {
                                 const float4 o = rec[i];
                                 const int j1 = recJ[i];
                                 const float ex = qx[q] - o.x, ey = qy[q] - o.y, ez = qz[q] - o.z;
@@ -740,7 +808,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 // 1.01 thres; otherwise the range grows by 64 targets on its short side, up to kProbeSteps times.
                 // Inconclusive probes, equal minima (the first-index rule is the scan's business), queries without a
                 // previous neighbour and waves with many uncertified lanes take the window scan.
-                if (REC && recOn && it > itBegin) {
+                if (REC && recOn && it > itFirst) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const bool wants = live[q] && recM[q] >= 0.f && certJ[q] >= 0;
@@ -963,7 +1031,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 // add up the same numbers in the same order: its 18 sums are still in `red` (single-pass clouds).
                 if constexpr (REC && Q == 1) {
                     if (recOn && ngr == 1) {
-                        reuseMoments = it > itBegin && __ballot(nnSlot != prevNN) == 0ull;
+                        reuseMoments = it > itFirst && __ballot(nnSlot != prevNN) == 0ull;
                         prevNN = nnSlot;
                     }
                 }
@@ -982,9 +1050,51 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     fold[4] += swap16_sum(a8, a8);
                 }
                             }
+                // Sums per (pass, wave): the 18 moments of THIS pass go to their own slot and the lane sums start over.
+                // The pair's totals are then added in (pass, wave) order whoever computed a pass (icp_kernel's helpers
+                // take whole passes of a straggling pair): the order belongs to the pair, not to the launch.
+                if (perPass && !reuseMoments) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const double r = row_sum_f64(fold[j]);
+                        const int row = lane >> 4;
+                        const int m = (j < 4) ? 4 * j + ((row & 1) * 2 + (row >> 1)) : 16 + (row >> 1);
+                        if ((lane & 15) == 15) redDyn[(g * NWAVE + wave) * kMoments + m] = r;
+                        fold[j] = 0.0;
+                    }
+                }
+            }
+            if constexpr (HELP) {
+                // owner: wave 1 + j waits for helper j's pass of THIS iteration and copies its NWAVE x 18 sums into the
+                // pass's slot (the waves are through with their own passes; wave 0's serial part starts behind the
+                // barrier below either way)
+                if (!helping && helpedPasses != 0 && wave >= 1 && wave <= kHelpSlots && wave < NWAVE) {
+                    const int gj = ngr - wave;               // slot j = wave - 1 takes pass ngr - 1 - j
+                    if (gj >= 1 && ((helpedPasses >> gj) & 1) != 0) {
+                        const int wg = __builtin_amdgcn_readfirstlane(helpSh[wave]);
+                        const int want = (b << 8) | (it + 1);
+                        const long long t0 = wall_clock64();
+                        bool ok = true;
+                        while (__hip_atomic_load(&p.help.tag[wg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (wall_clock64() - t0 > kTeamTimeoutTicks) { ok = false; break; }
+                        }
+                        asm volatile("" ::: "memory");
+#ifdef ICPFLOW_TAIL_CLOCK
+                        if (lane == 0) { atomicAdd(&g_help_stats[1], 1ull); atomicAdd(&g_help_stats[2], (unsigned long long)(wall_clock64() - t0)); }
+#endif
+                        if (!ok) {
+                            if (lane == 0) __hip_atomic_store(&ctrl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            const double *out = p.help.out + (size_t)wg * kHelpOutStride;
+                            for (int k = lane; k < NWAVE * kMoments; k += kWave)
+                                redDyn[gj * NWAVE * kMoments + k] = __hip_atomic_load(&out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
             }
             // rows of 16 lanes -> lane 15 of each row holds the wave total of "its" moment
-            if (!reuseMoments)
+            if (!perPass && !reuseMoments)
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 const double r = row_sum_f64(fold[j]);
@@ -1143,23 +1253,76 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
         const long long tcTail0 = clock64();
         tcSearch += tcTail0 - tcLoop0;
 #endif
+        if constexpr (HELP) {
+            if (helping) {
+                // the pass's sums (one row of 18 per wave) go to this workgroup's outbox write-through, every wave drains
+                // its own stores, then ONE lane tags the outbox with (pair, iteration): what the owner polls for
+                {
+                    const int passes = (xc.n + BLOCK - 1) / BLOCK, gj = passes - role;
+                    double *out = p.help.out + (size_t)blockIdx.x * kHelpOutStride;
+                    const double *src = reinterpret_cast<const double *>(dynLds) + (size_t)(gj * NWAVE + wave) * kMoments;
+                    if (lane < kMoments)
+                        __hip_atomic_store(&out[wave * kMoments + lane], src[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_store(&p.help.tag[blockIdx.x], (b << 8) | (it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the state of a LATER iteration (the owner publishes one per iteration while a helper is signed up;
+                    // it cannot get further than one iteration past a pass it is waiting for)
+                    int e;
+                    const long long t0 = wall_clock64();
+                    for (;;) {
+                        e = __hip_atomic_load(&hp->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (e < 0 || e > it + 1) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (wall_clock64() - t0 > kTeamTimeoutTicks) { e = -1; break; }
+                    }
+                    helpSh[4] = e;
+                }
+                __syncthreads();
+                const int e = __builtin_amdgcn_readfirstlane(helpSh[4]);
+                if (e <= 0 || e > itEnd) break;          // the pair is finished
+                if (tid < 12) bcast[tid] = __hip_atomic_load(&p.help.state[((size_t)b * 2 + (e & 1)) * 16 + tid], __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                // (had the owner run two epochs ahead while this was being read -- it only does when it is not waiting
+                // for this helper -- the buffer may have been rewritten: the pass is then computed from garbage and
+                // nobody reads it; the next epoch is read afresh)
+                it = e - 2;                                // ++it -> iteration e - 1
+                continue;
+            }
+        }
         // ------------- wave 0 solves for (R, T, rmse) ---------------------------------------
         if (wave == 0) {
+            // helpers: who has signed up (lane 0: the count, lanes 1..3: the announcements), fetched HERE, a whole solve
+            // before it is looked at -- an agent-scope load is a round trip across the fabric
+            [[maybe_unused]] int helpWord = 0;
+            if constexpr (HELP) {
+                if (hp != nullptr && lane <= kHelpSlots)
+                    helpWord = __hip_atomic_load(lane == 0 ? &hp->nclaim : &hp->from[lane - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // lane k < 18 sums moment k over the waves; totals are then wave-uniform via readlane
             double mine = 0.0;
             if (lane < kMoments) {
                 // all NWAVE loads in flight at once (left to itself the compiler alternates load, wait, add: NWAVE / 2
                 // dependent LDS round trips in the serial tail); the sum itself stays in wave order
-                double r[NWAVE];
+                // (sums per (pass, wave) in dynamic LDS: pass after pass, the same way; a single pass is the static case)
+                const bool perPassT = GRID == 4 && !TEAM && p.redPasses != 0;
+                const int passes = perPassT ? (xc.n + BLOCK * Q - 1) / (BLOCK * Q) : 1;
+                const double *src = perPassT ? reinterpret_cast<const double *>(dynLds) : red;
+                for (int gp = 0; gp < passes; ++gp) {
+                    double r[NWAVE];
 #pragma unroll
-                for (int w = 0; w < NWAVE; ++w) r[w] = red[w * kMoments + lane];
+                    for (int w = 0; w < NWAVE; ++w) r[w] = src[(gp * NWAVE + w) * kMoments + lane];
 #pragma unroll
-                for (int w = 0; w < NWAVE; w += 4) {
-                    if (w + 3 < NWAVE) asm volatile("" : "+v"(r[w]), "+v"(r[w + 1]), "+v"(r[w + 2]), "+v"(r[w + 3]));
+                    for (int w = 0; w < NWAVE; w += 4) {
+                        if (w + 3 < NWAVE) asm volatile("" : "+v"(r[w]), "+v"(r[w + 1]), "+v"(r[w + 2]), "+v"(r[w + 3]));
+                    }
+                    mine = gp == 0 ? r[0] : mine + r[0];
+#pragma unroll
+                    for (int w = 1; w < NWAVE; ++w) mine += r[w];
                 }
-                mine = r[0];
-#pragma unroll
-                for (int w = 1; w < NWAVE; ++w) mine += r[w];
             }
             bool teamStop = false;
             if (TEAM && G > 1) {
@@ -1387,6 +1550,41 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 bcast[14] = rmse;  // :213 prev_rmse = rmse
                 bcast[15] = sn;
             }
+            if constexpr (HELP) {
+                if (hp != nullptr) {
+                    // progress for workgroups looking for a pair to help; with helpers signed up: the state of iteration
+                    // it + 1 (double-buffered by parity, write-through, drained, THEN the epoch), and which of its passes
+                    // the helpers that have announced themselves in time will deliver
+                    const bool goesOn = active && it + 1 < itEnd;
+                    int mask = 0;
+                    const int nclaim = __builtin_amdgcn_readfirstlane(helpWord);
+                    if (goesOn && nclaim > 0) {
+                        const int e = it + 2;                 // E(it + 1)
+                        if (lane < 12) {
+                            float v = Tn[0];
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) v = lane == k ? Rn[k] : v;
+                            v = lane == 10 ? Tn[1] : (lane == 11 ? Tn[2] : v);
+                            __hip_atomic_store(&p.help.state[((size_t)b * 2 + (e & 1)) * 16 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(&hp->epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int passes = (xc.n + BLOCK - 1) / BLOCK;
+                        const int f = __shfl(helpWord, (lane + 1) & 63, kWave);     // lane j < 3: slot j's announcement
+                        const bool on = lane < kHelpSlots && f != 0 && (f & 0xff) <= e && passes - 1 - lane >= 1;
+                        if (on) helpSh[1 + lane] = f >> 8;
+                        const unsigned long long m = __ballot(on);
+#pragma unroll
+                        for (int j = 0; j < kHelpSlots; ++j)
+                            if ((m >> j) & 1ull) mask |= 1 << (passes - 1 - j);
+                    }
+                    if (lane == 0) {
+                        helpSh[0] = mask;
+                        __hip_atomic_store(&hp->iter, goesOn ? it + 2 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!goesOn) __hip_atomic_store(&hp->epoch, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
             }  // !teamStop
         }
         itersDone = it + 1;
@@ -1411,6 +1609,14 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
         g_wg_wall[b * 4 + 3] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11));
     }
 #endif
+    if constexpr (HELP) {
+        if (helping) return;
+        if (hp != nullptr && tid == 0) {
+            __hip_atomic_store(&hp->iter, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&hp->epoch, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&p.help.owner[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (tid == 0 && rank == 0) {  // wave 0 (of member 0) holds the final state
 #pragma unroll
         for (int k = 0; k < 9; ++k) st->R[k] = bcast[k];
@@ -1438,7 +1644,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
 // the 512 slots are occupied.  A ticket has no such order.
 // (PERSIST is a template parameter: the loop keeps more scalar state alive than the one-pair kernel, whose register
 // allocation at 128 VGPRs must not move -- it is the kernel of batches that fit the GPU, config 2 among them.)
-template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE = false, bool PERSIST = false>
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE = false, bool PERSIST = false, bool HELPK = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((BLOCK == 512 && GRID == 4) ? 4 : 1)))
 void icp_kernel(IcpParams p, int itBegin, int itEnd)
 {
@@ -1450,24 +1656,75 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         G = p.team.teamSize[b];
     }
     if constexpr (!PERSIST) {
-        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE>(p, b, rank, G, itBegin, itEnd);
+        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false>(p, b, rank, G, itBegin, itEnd);
     } else {
         static_assert(!PERSIST || !TEAM, "teams are planned per launch");
-        __shared__ int nextPair;
+        constexpr bool HELP = HELPK && GRID == 4 && !SCALE && Q == 1;
+        __shared__ int nextPair, nextRole;
         // The parameters are read from the kernel-argument segment afresh for every pair (the pointer is laundered per
         // round): loads from that constant address space can be repeated where the register allocator would otherwise
         // keep ~60 scalars alive around the whole loop and spill them.
         typedef const __attribute__((address_space(4))) IcpParams KernargParams;
         KernargParams *pp = (KernargParams *)__builtin_amdgcn_kernarg_segment_ptr();
+        int role = 0;
         for (;;) {
             asm volatile("" : "+s"(pp));
-            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE>(*pp, b, rank, G, itBegin, itEnd);
+            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, HELP>(*pp, b, rank, G, itBegin, itEnd, role);
             __syncthreads();                     // the pair's last reads of the static LDS state are done
-            if (threadIdx.x == 0)
-                nextPair = (int)gridDim.x + __hip_atomic_fetch_add(&p.ctrl->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x < kWave) {
+                int nb = -1, nr = 0;
+                if (role == 0) {                 // still drawing tickets
+                    int t = 0;
+                    if (threadIdx.x == 0) t = (int)gridDim.x + __hip_atomic_fetch_add(&p.ctrl->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nb = __shfl(t, 0, kWave);
+                    if (nb >= p.B) nb = -1;
+                }
+                if constexpr (HELP) {
+                    // No pair left to start: look, among the pairs other workgroups are iterating on, for the one that has
+                    // come furthest and still has a pass to give away, and sign up for it (a few attempts: somebody else
+                    // may get the slot first).  Nothing found: this workgroup is done.
+                    if (nb < 0 && p.help.pair != nullptr && p.helpOn) {
+                        const int lane = threadIdx.x;
+                        for (int attempt = 0; attempt < 4 && nb < 0; ++attempt) {
+                            int best = -1, bestKey = 0;
+                            for (int w = lane; w < (int)gridDim.x; w += kWave) {
+                                const int ob = __hip_atomic_load(&p.help.owner[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+                                if (ob < 0) continue;
+                                const HelpPair *h = p.help.pair + ob;
+                                const int iter = __hip_atomic_load(&h->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const int nc = __hip_atomic_load(&h->nclaim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const int ps = __hip_atomic_load(&h->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const int slots = min(kHelpSlots, ps - 1);
+                                // The pair with the most iterations still ahead of it (nobody knows which pairs will
+                                // stop early; the cap bounds what is left), among those past their first iterations --
+                                // most pairs settle within a handful --, a pair that already has helpers first (the
+                                // third helper shortens an iteration as much as the first).  A pair in its last
+                                // iterations is not worth joining: two iterations pass before the first delivery.
+                                if (iter > 0 && iter + 3 < itEnd && nc < slots) {
+                                    const int key = (iter > 6 ? 1 << 20 : 0) + (itEnd - iter) * 8 + nc + 1;
+                                    if (key > bestKey) { bestKey = key; best = ob; }
+                                }
+                            }
+#pragma unroll
+                            for (int o = kWave / 2; o > 0; o >>= 1) {
+                                const int ok = __shfl_xor(bestKey, o, kWave), ob2 = __shfl_xor(best, o, kWave);
+                                if (ok > bestKey || (ok == bestKey && ob2 > best)) { bestKey = ok; best = ob2; }
+                            }
+                            if (best < 0) break;
+                            int j = 0;
+                            if (lane == 0) j = __hip_atomic_fetch_add(&p.help.pair[best].nclaim, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            j = __shfl(j, 0, kWave);
+                            const int ps = __hip_atomic_load(&p.help.pair[best].passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (j < min(kHelpSlots, ps - 1)) { nb = best; nr = j + 1; }
+                        }
+                    }
+                }
+                if (threadIdx.x == 0) { nextPair = nb; nextRole = nr; }
+            }
             __syncthreads();
             b = __builtin_amdgcn_readfirstlane(nextPair);   // (workgroup-uniform: keeps the pair's addresses scalar)
-            if (b >= p.B) break;
+            role = __builtin_amdgcn_readfirstlane(nextRole);
+            if (b < 0) break;
         }
     }
 }
@@ -1606,37 +1863,69 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
             return;
         }
     }
-    const size_t dyn = (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
-                       : (GRID == 4) ? (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + (size_t)p.recCap * (p.x0Cache ? 32 : 20) : 0;
     IcpParams q = p;
     q.persistent = 0;
-    // Batches larger than the GPU (sorted-sweep kernels, one launch for all iterations): a grid as large as the GPU, the
-    // other pairs by ticket (icp_kernel<..., PERSIST>)
+    q.helpOn = 0;
+    q.redPasses = 0;
+    // workgroups of a kernel the GPU holds at once (per device and dynamic-LDS size: asked once per instantiation)
+    auto capacity = [&](const void *kern, size_t dynBytes) -> long long {
+        struct Slot { const void *k; int dev; size_t dyn; int perCu; };
+        static std::atomic<int> nSlots{0};
+        static Slot slots[32];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int perCu = 0;
+        const int have = nSlots.load(std::memory_order_acquire);
+        for (int k = 0; k < have && k < 32; ++k)
+            if (slots[k].k == kern && slots[k].dev == dev && slots[k].dyn == dynBytes) perCu = slots[k].perCu;
+        if (perCu == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, BLOCK, dynBytes) != hipSuccess || perCu <= 0) perCu = 1;
+            const int k = nSlots.load(std::memory_order_acquire);
+            if (k < 32) { slots[k] = Slot{kern, dev, dynBytes, perCu}; nSlots.store(k + 1, std::memory_order_release); }   // (a lost race only asks again)
+        }
+        return (long long)perCu * device_cus();
+    };
+    auto dynBytes = [&](int redPasses) -> size_t {
+        return (GRID == 2) ? (((size_t)p.gridH + 1) * 4 + 15) / 16 * 16 + (size_t)p.N * 16
+               : (GRID == 4) ? (size_t)redPasses * (BLOCK / kWave) * kMoments * sizeof(double) +
+                               (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12 + (size_t)p.recCap * (p.x0Cache ? 32 : 20) : 0;
+    };
+    // Batches larger than the GPU (sorted-sweep kernels): a grid as large as the GPU, the other pairs by ticket
+    // (icp_kernel<..., PERSIST>).  Batches of up to four rounds whose pairs take three passes or more: the launch ends
+    // on a tail of stragglers, so the workgroups that run out of tickets HELP (icp_kernel<..., PERSIST, HELPK>), which
+    // wants the moment sums per (pass, wave) -- a few per cent of an iteration, which larger batches (no tail to speak
+    // of) and two-pass pairs (one pass to give away) do not get back.  The summation order is decided HERE, on the
+    // shape of the batch alone: every variant of the launch (hardware dispatch, no helpers, one launch per iteration)
+    // adds up the same way and gives the same bits.
+    if constexpr (!TEAM && !SCALE && GRID == 4 && Q == 1) {
+        constexpr auto kernH = &icp_kernel<BLOCK, Q, TS, GRID, false, false, true, true>;
+        const int passes = (p.N + BLOCK - 1) / BLOCK;
+        if (p.N <= kRecMaxN && passes >= 3 && dynBytes(passes) > 48 * 1024) {   // (before the occupancy is asked for)
+            static std::atomic<unsigned long long> raisedH{0ull};
+            ensure_dynamic_lds(reinterpret_cast<const void *>(kernH), 156 * 1024, &raisedH);
+        }
+        const long long capH = (p.N <= kRecMaxN && passes >= 3) ? capacity(reinterpret_cast<const void *>(kernH), dynBytes(passes)) : 0;
+        const bool eligible = capH > 0 && (long long)B > capH && (long long)B <= 4 * capH && capH <= kHelpMaxWG;
+        if (eligible) {
+            q.redPasses = passes;
+            if (p.persistent) {
+                const size_t dyn = dynBytes(passes);
+                q.persistent = 1;
+                q.helpOn = (p.helpOn && p.help.pair != nullptr) ? 1 : 0;
+                hipLaunchKernelGGL(kernH, dim3((int)capH), dim3(BLOCK), dyn, s, q, itBegin, itEnd);
+                return;
+            }
+        }
+    }
+    const size_t dyn = dynBytes(q.redPasses);
     if constexpr (!TEAM && !SCALE && GRID >= 3) {
-        if (p.persistent) {
-            constexpr auto kern = &icp_kernel<BLOCK, Q, TS, GRID, false, false, true>;
+        if (p.persistent && q.redPasses == 0) {
+            constexpr auto kern = &icp_kernel<BLOCK, Q, TS, GRID, false, false, true, false>;
             if (dyn > 48 * 1024) {
                 static std::atomic<unsigned long long> raisedP{0ull};
                 ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 156 * 1024, &raisedP);
             }
-            // workgroups of this kernel the GPU holds at once (per device and dynamic-LDS size: asked once)
-            struct Slot { int dev; size_t dyn; int perCu; };
-            static std::atomic<int> nSlots{0};
-            static Slot slots[16];
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            int perCu = 0;
-            const int have = nSlots.load(std::memory_order_acquire);
-            for (int k = 0; k < have && k < 16; ++k)
-                if (slots[k].dev == dev && slots[k].dyn == dyn) perCu = slots[k].perCu;
-            if (perCu == 0) {
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void *>(kern), BLOCK, dyn) != hipSuccess ||
-                    perCu <= 0)
-                    perCu = 1;
-                const int k = nSlots.load(std::memory_order_acquire);
-                if (k < 16) { slots[k] = Slot{dev, dyn, perCu}; nSlots.store(k + 1, std::memory_order_release); }   // (a lost race only asks again)
-            }
-            const long long cap = (long long)perCu * device_cus();
+            const long long cap = capacity(reinterpret_cast<const void *>(kern), dyn);
             if ((long long)B > cap) {
                 q.persistent = 1;
                 hipLaunchKernelGGL(kern, dim3((int)cap), dim3(BLOCK), dyn, s, q, itBegin, itEnd);
@@ -1669,6 +1958,12 @@ extern "C" int icpflow_debug_tail_clock(long long *out3072)
 extern "C" int icpflow_debug_wg_wall(long long *out32768)
 {
     return (int)hipMemcpyFromSymbol(out32768, HIP_SYMBOL(g_wg_wall), sizeof(long long) * 32768);
+}
+extern "C" int icpflow_debug_help_stats(unsigned long long *out8, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_help_stats), sizeof(unsigned long long) * 8);
+    if (reset) { static unsigned long long z[8]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_help_stats), z, sizeof(z)); }
+    return rc;
 }
 extern "C" int icpflow_debug_tail_split(long long *out16384)
 {
@@ -1866,7 +2161,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     bool recWanted = false;   // neighbour certificates (sorted sweep with the LDS image)
     if (opts.historyPending != nullptr) *opts.historyPending = false;
     if (!opts.ctrlCleared) {
-        e = hipMemsetAsync(ctrl, 0, sizeof(IcpCtrl), s);
+        e = hipMemsetAsync(ctrl, 0, icp_ctrl_bytes(B), s);
         if (e != hipSuccess) return e;
     }
     if (grid != nullptr && grid->mode == 3 && grid->presorted) {
@@ -1938,10 +2233,14 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
 #endif
         const double fillHalf = (double)B / ((double)((B + 2 * cus - 1) / (2 * cus)) * 2 * cus);
         const double fillFull = (double)B / ((double)((B + cus - 1) / cus) * cus);
-        if (p.team.wgPair == nullptr && B >= 2 * cus && N > ICPFLOW_HALF_CU_MIN_N && img + (size_t)recCap * 20 <= half &&
+        const size_t redHalf = N <= kRecMaxN ? (size_t)((N + 511) / 512) * 8 * kMoments * sizeof(double) : 0;   // (512 threads: 8 waves)
+        const size_t redFull = N <= kRecMaxN ? (size_t)((N + 1023) / 1024) * 16 * kMoments * sizeof(double) : 0;
+        if (p.team.wgPair == nullptr && B >= 2 * cus && N > ICPFLOW_HALF_CU_MIN_N && redHalf + img + (size_t)recCap * 20 <= half &&
             1.1 * fillHalf > fillFull) {
             p.halfCu = 1;
-            x0Cache = img + (size_t)recCap * 32 <= half;
+            x0Cache = redHalf + img + (size_t)recCap * 32 <= half;
+        } else if (p.team.wgPair == nullptr) {
+            x0Cache = x0Cache && redFull + img + (size_t)recCap * 32 <= room;
         }
         if (recWanted) { p.recCap = recCap; p.x0Cache = x0Cache ? 1 : 0; }
     }
@@ -1956,6 +2255,8 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         if (speculative) {
             p.history = history;
             p.persistent = opts.persistent ? 1 : 0;   // (one launch for all iterations: the ticket counter starts at zero)
+            p.help = opts.help;
+            p.helpOn = opts.helpers ? 1 : 0;
             launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
             if (opts.historyPending != nullptr) {
                 *opts.historyPending = true;   // the consumers read the history themselves (posefuse.hpp)
@@ -1968,6 +2269,8 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         }
     } else {
         p.persistent = opts.persistent ? 1 : 0;
+        p.help = opts.help;
+        p.helpOn = opts.helpers ? 1 : 0;
         launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
     }
     return hipGetLastError();

@@ -39,6 +39,31 @@ struct IcpCtrl {
     unsigned long long tally[kMaxIterCap];
 };
 
+// Helpers (icp.hip, persistent launches): a workgroup that finds no pair left to start takes whole PASSES (BLOCK
+// consecutive sorted queries) of a pair another workgroup is still iterating on.  One HelpPair per pair, one tag / owner
+// word / outbox per workgroup of the grid; every word is read and written with relaxed agent-scope atomics.
+// Encodings: E(n) = n + 1 for an iteration number n, so that 0 means "nothing yet"; -1 = the pair is finished.
+struct HelpPair {          // 64 bytes, cleared with the control block at the start of every call
+    int iter;              // E(iteration the owner is running or about to run); 0 = not started, -1 = finished
+    int nclaim;            // helper slots handed out (helpers: atomic add)
+    int epoch;             // E(n): state[(n + 1) & 1] holds (R, T) of iteration n; 0 = none published; -1 = finished
+    int passes;            // passes of this pair (slot j takes pass `passes - 1 - j`; the owner always keeps pass 0)
+    int from[4];           // helper j: (its workgroup << 8) | E(first iteration it takes part in); 0 = not announced
+    int pad[8];
+};
+constexpr int kHelpSlots = 3;
+constexpr int kHelpMaxWG = 1024;              // workgroups of a persistent grid, at most
+constexpr int kHelpOutStride = 16 * 18;       // doubles per outbox: the moment sums of one pass, <= 16 waves x 18
+struct IcpHelp {
+    HelpPair *pair = nullptr;   // [B]            (zeroed per call)
+    int *tag = nullptr;         // [kHelpMaxWG]   (zeroed per call) (pair << 8) | E(iteration) of the outbox's content
+    int *owner = nullptr;       // [kHelpMaxWG]   (zeroed per call) pair + 1 the workgroup is iterating on as its owner
+    float *state = nullptr;     // [B, 2, 16]     (R row-major 9, T 3) double-buffered by epoch parity
+    double *out = nullptr;      // [kHelpMaxWG, kHelpOutStride]
+};
+// bytes of the control block + everything cleared with it (IcpCtrl, HelpPair[B], tag, owner)
+inline size_t icp_ctrl_bytes(int B);
+
 // Teams (icp.hip): several workgroups share one LARGE pair.  Every member owns a contiguous range
 // of the sorted moving cloud, the 18 moments of an iteration are exchanged through `mom`, and each
 // member solves for the same (R, T) redundantly -- one exchange per iteration, nobody broadcasts.
@@ -52,6 +77,21 @@ struct IcpTeam {
     double *mom;            // [B, 2, kMaxTeam, kTeamStride]
     int maxWG;
 };
+
+inline size_t icp_ctrl_bytes(int B)
+{
+    return sizeof(IcpCtrl) + (size_t)B * sizeof(HelpPair) + 2 * (size_t)kHelpMaxWG * sizeof(int);
+}
+inline IcpHelp icp_help_carve(IcpCtrl *ctrl, int B, float *state, double *out)
+{
+    IcpHelp h;
+    h.pair = reinterpret_cast<HelpPair *>(ctrl + 1);
+    h.tag = reinterpret_cast<int *>(h.pair + B);
+    h.owner = h.tag + kHelpMaxWG;
+    h.state = state;
+    h.out = out;
+    return h;
+}
 
 constexpr int kHistIters = 128;   // iterations of per-pair history kept in the workspace
 constexpr int kHistStride = 16;   // floats per (iteration, pair): R (9), T (3), rmse, scale, gated correspondences
@@ -159,6 +199,8 @@ struct IcpOpts {
     bool speculative = true;       // batch-global stop in ONE launch (false: one launch per iteration)
     bool adaptiveWindows = true;   // sorted sweep: per-query windows from the previous iteration's neighbours
     bool persistent = true;        // batches larger than the GPU: a grid as large as the GPU, further pairs by ticket
+    bool helpers = true;           // ... whose workgroups, once the tickets are gone, take passes of pairs still iterating
+    IcpHelp help{};                // scratch of the helpers (NULL pointers: no helpers)
     const float *initR = nullptr;  // [B,3,3] / [B,3]: state before the first iteration (init_transform), or identity
     const float *initT = nullptr;
     bool allowReflection = false;  // R = U V^T whatever its determinant (utils_icp_pytorch3d.py:354-362)

@@ -115,6 +115,7 @@ const char *icpflow_build_info(void);
 #define ICPFLOW_OPT_NO_SPECULATIVE (1u << 7)  /* batch-global stop: one launch per iteration       */
 #define ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS (1u << 8) /* ICP sweep: no neighbour certificates / probes: every query scans */
 #define ICPFLOW_OPT_NO_PERSISTENT (1u << 9)   /* ICP: one workgroup per pair dealt by the hardware dispatcher, whatever B */
+#define ICPFLOW_OPT_NO_HELPERS (1u << 10)     /* ICP, persistent grid: workgroups without a pair left do not take passes of others */
 
 typedef struct icpflow_profile icpflow_profile_t; /* opaque */
 

@@ -182,7 +182,7 @@ def test_adaptive_windows_change_nothing(shape):
     assert torch.equal(P0, utils_match.hist_icp(ap, s, d))
 
 
-@pytest.mark.parametrize("shape", ["config4_shard_1024x2048", "ragged_2500x700", "ragged_700x3000", "dense_1500x1024"])
+@pytest.mark.parametrize("shape", ["config4_shard_1024x2048", "ragged_2500x700", "ragged_700x3000", "dense_1500x1024", "ragged_900x2048"])
 def test_ticket_dispatch_changes_nothing(shape):
     """Batches larger than the GPU: the ICP launch is a grid as large as the GPU whose workgroups draw their further
     pairs from a ticket counter (icp.hip icp_kernel<..., PERSIST>) instead of one workgroup per pair dealt by the hardware
@@ -194,6 +194,8 @@ def test_ticket_dispatch_changes_nothing(shape):
         S, D, _ = synthetic.make_batch(2500, 700, seed=13, ragged=True, n_min=30)
     elif shape == "ragged_700x3000":
         S, D, _ = synthetic.make_batch(700, 3000, seed=17, ragged=True, n_min=200)
+    elif shape == "ragged_900x2048":                      # (helpers on pairs of one to four passes, swapped roles)
+        S, D, _ = synthetic.make_batch(900, 2048, seed=23, ragged=True, n_min=100)
     else:
         S, D, _ = synthetic.make_batch(1500, 1024, seed=19)
     s, d = G(S), G(D)
@@ -204,7 +206,18 @@ def test_ticket_dispatch_changes_nothing(shape):
         T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
         assert int(it0) == int(it1) and int(it1) > 0
         assert torch.equal(T0, T1)
-        assert torch.equal(utils_match.hist_icp(a, s, d), T1)           # and from run to run
+        # Helpers (batches of up to four rounds of pairs with three passes or more, e.g. config 4's shard): a workgroup
+        # that finds no ticket left takes whole passes of a pair another workgroup is still iterating on.  WHICH passes
+        # come from helpers, and from which iteration on, depends on timing; the sums are kept per (pass, wave) and added
+        # in that order whoever computed them, so nothing else does: without helpers, and run after run, the same bits.
+        with _lib.options(no_helpers=True):
+            T2, it2 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert int(it2) == int(it1) and torch.equal(T2, T1)
+        for _ in range(3):
+            assert torch.equal(utils_match.hist_icp(a, s, d), T1)       # and from run to run
+    with _lib.options(no_speculative=True):                             # one launch per iteration: the same sums again
+        a = rp.default_args(max_points=S.shape[1], icp_max_iterations=50)
+        assert torch.equal(utils_match.hist_icp(a, s, d), utils_match.hist_icp(rp.default_args(max_points=S.shape[1], icp_max_iterations=50), s, d))
 
 
 @pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_90x2048"])

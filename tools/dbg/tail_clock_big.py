@@ -6,16 +6,20 @@ import numpy as np, torch
 from icp_flow_amd import _lib, synthetic, utils_match
 from oracle import reference_path as rp
 N = int(os.environ.get("N", 2048))
-for B in (1024, 2048, 8192):
+for B in [int(x) for x in os.environ.get("BS", "1024,2048,8192").split(",")]:
     S, D, _ = synthetic.make_batch(B, N, seed=0)
     a = rp.default_args(max_points=N, icp_max_iterations=50)
     s, d = torch.from_numpy(S).cuda(), torch.from_numpy(D).cuda()
     prof = _lib.Profile(8)
     utils_match.hist_icp(a, s, d)
+    hs = (ctypes.c_ulonglong * 8)()
+    _lib._L.icpflow_debug_help_stats(hs, 1)
     with _lib.options(profile=prof):
         T, it = utils_match.hist_icp(a, s, d, return_iterations=True)
     torch.cuda.synchronize()
     ms, n = prof.collect()
+    _lib._L.icpflow_debug_help_stats(hs, 0)
+    print(f"helpers: joined {hs[0]}, found the pair finished {hs[3]}, passes taken from helpers {hs[1]}, owner waves waited {hs[2] / 100.0 / max(hs[1], 1):.2f} us per pass on average")
     st = (ctypes.c_longlong * 3072)()
     _lib._L.icpflow_debug_tail_clock(st)
     v = np.array(st[:], dtype=np.int64).reshape(1024, 3)
