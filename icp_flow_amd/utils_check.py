@@ -135,12 +135,25 @@ def sanity_grid(args, st, dt, si, di):
     the tables): -> bool [len(si), len(di)].  Stage 2 of match_pcds tests all remaining sources against all
     remaining destinations (utils_match.py:45-53); on the grid the per-cluster numbers broadcast instead of
     being gathered for each of the S x D candidate rows."""
-    ok = (np.minimum(st.h_count[si][:, None], dt.h_count[di][None, :]) >= args.min_cluster_size)      # :31
-    ok &= (st.h_labels[si] >= 0)[:, None] & (dt.h_labels[di] >= 0)[None, :]                            # :32
-    dxy = dt.h_mean[di][None, :, 0:2] - st.h_mean[si][:, None, 0:2]
-    ok &= ~(np.sqrt(dxy[:, :, 0] * dxy[:, :, 0] + dxy[:, :, 1] * dxy[:, :, 1]) > np.float32(args.translation_frame))   # :36
-    es, ed = st.h_extent[si][:, None, :], dt.h_extent[di][None, :, :]
-    ok &= ~(np.minimum(es, ed) < np.float32(args.thres_box) * np.maximum(es, ed)).any(axis=2)           # :41-43
+    # (per-cluster tests first -- size and label are properties of ONE cluster, :31-32 --, the pairwise ones only on
+    # the rows and columns that survive them, axis by axis without [S, D, 3] temporaries: this runs on the host thread
+    # that also feeds the GPU)
+    s_ok = (st.h_count[si] >= args.min_cluster_size) & (st.h_labels[si] >= 0)
+    d_ok = (dt.h_count[di] >= args.min_cluster_size) & (dt.h_labels[di] >= 0)
+    ok = np.zeros((len(si), len(di)), dtype=bool)
+    rs, cs = np.nonzero(s_ok)[0], np.nonzero(d_ok)[0]
+    if len(rs) == 0 or len(cs) == 0:
+        return ok
+    ms, md = st.h_mean[si][rs], dt.h_mean[di][cs]
+    dx = md[None, :, 0] - ms[:, None, 0]
+    dy = md[None, :, 1] - ms[:, None, 1]
+    sub = ~(np.sqrt(dx * dx + dy * dy) > np.float32(args.translation_frame))                           # :36
+    es, ed = st.h_extent[si][rs], dt.h_extent[di][cs]
+    tb = np.float32(args.thres_box)
+    for k in range(3):                                                                                   # :41-43
+        a, b = es[:, None, k], ed[None, :, k]
+        sub &= ~(np.minimum(a, b) < tb * np.maximum(a, b))
+    ok[np.ix_(rs, cs)] = sub
     return ok
 
 
