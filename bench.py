@@ -37,7 +37,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_LANE_OPS = 78.6e12    # 256 CU x 128 fp32 lanes x 2.4 GHz; 157.3 TFLOP/s counting fma = 2
 LANE_OPS_PER_EVAL = 8           # one 3-D squared distance + compare = 8 lane-ops
-COUNTERS_FILE = os.path.join(REPO, "profiles", "r02_icp_kernel_counters.json")
+COUNTERS_FILE = os.path.join(REPO, "profiles", "r03_icp_kernel_counters.json")
 
 
 def parse():
@@ -63,7 +63,9 @@ def timed_steps(step, sync, steps, warmup, iters_cap):
     from icp_flow_amd import _lib
     for _ in range(warmup):
         step()
-    prof = _lib.Profile(steps * iters_cap)
+    # one event pair per ICP launch: one launch per step up to 128 iterations (speculative single launch), one per
+    # iteration beyond
+    prof = _lib.Profile(steps * (iters_cap if iters_cap > 128 else 1) + 8)
     sync()
     t0 = time.perf_counter()
     with _lib.options(profile=prof):
@@ -452,14 +454,17 @@ def frame_pair_measurement(dev):
         fp_obj = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
         copies = [fp_obj] * 12
         for in_flight in (4,):
-            for _ in frame_pairs.register_in_flight(a, copies[:4], dev, in_flight):
-                pass
+            # (the untimed pass keeps every result for the comparison; the timed one consumes them as a sweep would --
+            # holding twelve frames' outputs makes the caching allocator grow on every stream inside the timed region)
+            flows = {i: o["flow"] for i, _, o in frame_pairs.register_in_flight(a, copies, dev, in_flight)}
+            entry[f"stream_{in_flight}_in_flight_identical_flow"] = bool(all(torch.equal(f, flow) for f in flows.values()))
+            del flows
             torch.cuda.synchronize(dev)
             t = time.perf_counter()
-            flows = {i: o["flow"] for i, _, o in frame_pairs.register_in_flight(a, copies, dev, in_flight)}
+            for _ in frame_pairs.register_in_flight(a, copies, dev, in_flight):
+                pass
             torch.cuda.synchronize(dev)
             entry[f"stream_ms_per_frame_pair_{in_flight}_in_flight"] = round((time.perf_counter() - t) / len(copies) * 1e3, 3)
-            entry[f"stream_{in_flight}_in_flight_identical_flow"] = bool(all(torch.equal(f, flow) for f in flows.values()))
         res[f"max_points_{mp}"] = entry
     res["cluster_dbscan"] = cluster_measurement(dev, g, gdir)
     res["cluster_hdbscan"] = hdbscan_measurement(dev, g, gdir)
