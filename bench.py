@@ -119,14 +119,14 @@ def main():
                            icp_max_iterations=a.iters, icp_stop_mode=a.stop_mode)
 
     def step():
-        T, iters = utils_match.hist_icp(args, src, dst, return_iterations=True)
-        if collective:
-            # what the sharded product exchanges: transform + the 40-byte pair row, ONE RCCL all_gather
-            # over xGMI of [B,26] float32 rows, no host sync (every rank knows all counts from shard_range)
-            ev = utils_match.match_eval(args, src, dst, T)
-            rows = pack_rows(T, first, ev[0], ev[1], ev[2], ev[3])
-            T = gather_results(rows, world, counts=counts, force_collective=True)
-        return T, iters
+        if not collective:
+            return utils_match.hist_icp(args, src, dst, return_iterations=True)
+        # what the sharded product exchanges: transform + the 40-byte pair row, ONE RCCL all_gather
+        # over xGMI of [B,26] float32 rows, no host sync (every rank knows all counts from shard_range); hist_icp +
+        # match_eval as the one call match_pairs makes (icpflow_hist_icp_eval)
+        T, ev, iters = utils_match.hist_icp_eval(args, src, dst, return_iterations=True)
+        rows = pack_rows(T, first, ev[0], ev[1], ev[2], ev[3])
+        return gather_results(rows, world, counts=counts, force_collective=True), iters
 
     def sync():
         if collective:
@@ -137,8 +137,7 @@ def main():
     gather_check = None
     if collective:
         if a.check_gather:      # the rows this rank contributed, as every rank received them
-            Tl, _ = utils_match.hist_icp(args, src, dst, return_iterations=True)
-            ev = utils_match.match_eval(args, src, dst, Tl)
+            Tl, ev, _ = utils_match.hist_icp_eval(args, src, dst, return_iterations=True)
             mine = pack_rows(Tl, first, ev[0], ev[1], ev[2], ev[3])
             gather_check = {"rows": list(T.shape), "identical_to_local_rows": bool(torch.equal(T[first:first + B], mine)),
                             "pair_index_column_ok": bool(torch.equal(T[:, 16], torch.arange(total, device=dev, dtype=torch.float32))),
@@ -286,9 +285,8 @@ def config4_single_gpu(dev, a):
         out[tag] = {"registrations_per_s": round(nb * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
                     "icp_iterations": int(iters.item()), "icp_kernel_ms_per_step": round(icp_ms / steps, 3)}
 
-        def step_eval():   # the step `--gpus N` times on every rank, less the all_gather: hist_icp + match_eval
-            T, it = utils_match.hist_icp(args, s, d, return_iterations=True)
-            utils_match.match_eval(args, s, d, T)
+        def step_eval():   # the step `--gpus N` times on every rank, less the all_gather: hist_icp + match_eval (one call)
+            T, _, it = utils_match.hist_icp_eval(args, s, d, return_iterations=True)
             return T, it
         dt, _, _, _, _ = timed_steps(step_eval, lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
         out[tag]["registrations_per_s_with_match_eval"] = round(nb * steps / dt, 1)

@@ -48,6 +48,8 @@ SIGNATURES = {
     "icpflow_hist_icp": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _sz, _p, _p]),
     "icpflow_hist_icp_many": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _p, _p, _p]),
     "icpflow_match_eval": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_hist_icp_eval": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _d, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p,
+                                   _p, _p, _sz, _p, _p]),
     "icpflow_gather_pad": (_i, [_p, _p, _i, _i, _p, _p]),
     "icpflow_gather_segments": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
     "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),

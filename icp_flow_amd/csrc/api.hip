@@ -72,6 +72,14 @@ struct Opts {
 #endif
 constexpr int kScoreSweepMinN = ICPFLOW_SCORE_SWEEP_MIN_N;
 constexpr int kMaxSortN = 16384;   // bitonic sort of (key, index) pairs in 128 KiB of LDS
+// match_eval as sorted sweeps (its own sort included) against the all-pairs scans, measured (round 3, ms per batch, scan ->
+// sweep): 1024 x 2048 0.998 -> 0.368, 1024 x 1500 0.713 -> 0.286, 256 x 1024 0.089 -> 0.067, ragged 600 x 2048 0.213 -> 0.170;
+// the scans keep the small batches, where the sort is pure latency: 256 x 512 0.037 vs 0.045, ragged 128 x 1024 0.044 vs 0.056
+inline bool eval_by_sweep(int B, int N, const Opts &o)
+{
+    if (N > kMaxSortN || !o.on(ICPFLOW_OPT_NO_EVAL_SWEEP)) return false;
+    return N > kScoreSweepMinN || (N >= 1024 && (long long)B * N >= (1LL << 18));
+}
 // ... with the branch and bound of the all-pairs scoring and the clouds sorted anyway (hist_icp sorts them for the
 // ICP on the side stream) the sweep wins from ~1000 points on (config 2: 171 -> 153 us, config 4's shard: 1.50 -> 0.94 ms)
 #ifndef ICPFLOW_SCORE_SWEEP_MIN_N_SORTED
@@ -343,14 +351,14 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
 int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_t *swap, int B,
                   int N, const float *ex, int lx, const float *ey, int ly, const float *ez, int lz,
                   float shift, float *Tout, const Opts &o, hipStream_t s, hipEvent_t joinBefore = nullptr,
-                  const PairCountFuse *countFuse = nullptr)
+                  const PairCountFuse *countFuse = nullptr, bool sideBusy = false)
 {
     const int lens[3] = {lx, ly, lz};
     // vote with X = dst role, Y = src role (utils_hist.py:69); z-sorted sweep while the sort fits LDS
     // (N <= 16384), all-pairs otherwise -- identical bins either way
     if (N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE))
         ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.zsortC,
-                                            w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s, countFuse));
+                                            w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s, countFuse, sideBusy));
     else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
     if (o.voteBins != nullptr)   // debug export of the bins the peak search is about to read
@@ -734,28 +742,12 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
                               relative_rmse_thr, stop_mode, 0, d_T_out, d_iters, o, s);
 }
 
-int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x,
-                     int len_x, const float *d_edges_y, int len_y, const float *d_edges_z, int len_z,
-                     float decode_shift, double thres_dist, int max_iterations, double relative_rmse_thr,
-                     int stop_mode, float *d_T_out, int32_t *d_iters, void *d_ws, size_t ws_bytes,
-                     icpflow_stream_t stream, const icpflow_options_t *opt)
+// icpflow_hist_icp behind its argument checks: everything it enqueues, on a workspace already carved
+static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x, int len_x,
+                         const float *d_edges_y, int len_y, const float *d_edges_z, int len_z, float decode_shift,
+                         double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
+                         float *d_T_out, int32_t *d_iters, Workspace &w, const Opts &o, hipStream_t s)
 {
-    Opts o;
-    if (int r = parse_options("icpflow_hist_icp", opt, o)) return r;
-    if (int r = check_arith("icpflow_hist_icp", o, max_iterations, stop_mode)) return r;
-    if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
-        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: null pointer");
-    if (int r = check_batch("icpflow_hist_icp", B, N)) return r;
-    if (int r = check_hist_dims("icpflow_hist_icp", len_x, len_y, len_z)) return r;
-    if (max_iterations <= 0 || max_iterations > kMaxIterCap)
-        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: max_iterations must be in 1..%d", kMaxIterCap);
-    if (stop_mode != ICPFLOW_STOP_REFERENCE && stop_mode != ICPFLOW_STOP_PER_PAIR)
-        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: unknown stop_mode %d", stop_mode);
-    const size_t L = (size_t)len_x * len_y * len_z;
-    if (L < (size_t)kTopK) return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: fewer than 5 bins");
-    Workspace w(d_ws, B, N, L);
-    if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
-    hipStream_t s = (hipStream_t)stream;
     // lengths + swap (utils_match.py:139-146) + cleared scratch: by the vote's sort itself where one workgroup sorts a
     // cloud (PairCountFuse), by count_pair otherwise
     const bool countInSort = N <= kMaxSortN && N <= kChunkSortMinN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE);
@@ -795,12 +787,38 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     const bool sweepScore = score_by_sweep(N, join != nullptr, o);
     if (int r = run_init_pose(d_src, d_dst, w, w.swap, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
                               len_z, decode_shift, w.Tinit, o, s, sweepScore ? join : nullptr,
-                              countInSort ? &fuse : nullptr))
+                              countInSort ? &fuse : nullptr, join != nullptr))
         return r;
     if (join != nullptr && !sweepScore) ICPFLOW_TRY(hipStreamWaitEvent(s, join, 0));
     guard.joined();
     return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
                               relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s);
+}
+
+int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x,
+                     int len_x, const float *d_edges_y, int len_y, const float *d_edges_z, int len_z,
+                     float decode_shift, double thres_dist, int max_iterations, double relative_rmse_thr,
+                     int stop_mode, float *d_T_out, int32_t *d_iters, void *d_ws, size_t ws_bytes,
+                     icpflow_stream_t stream, const icpflow_options_t *opt)
+{
+    Opts o;
+    if (int r = parse_options("icpflow_hist_icp", opt, o)) return r;
+    if (int r = check_arith("icpflow_hist_icp", o, max_iterations, stop_mode)) return r;
+    if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: null pointer");
+    if (int r = check_batch("icpflow_hist_icp", B, N)) return r;
+    if (int r = check_hist_dims("icpflow_hist_icp", len_x, len_y, len_z)) return r;
+    if (max_iterations <= 0 || max_iterations > kMaxIterCap)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: max_iterations must be in 1..%d", kMaxIterCap);
+    if (stop_mode != ICPFLOW_STOP_REFERENCE && stop_mode != ICPFLOW_STOP_PER_PAIR)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: unknown stop_mode %d", stop_mode);
+    const size_t L = (size_t)len_x * len_y * len_z;
+    if (L < (size_t)kTopK) return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: fewer than 5 bins");
+    Workspace w(d_ws, B, N, L);
+    if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
+    return hist_icp_core(d_src, d_dst, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z, len_z, decode_shift,
+                         thres_dist, max_iterations, relative_rmse_thr, stop_mode, d_T_out, d_iters, w, o,
+                         (hipStream_t)stream);
 }
 
 // K independent batches in flight: batch k runs on worker stream k % 4 of the calling thread, forked from and joined
@@ -859,6 +877,31 @@ int icpflow_hist_icp_many(int K, const float *const *d_src, const float *const *
     return rc;
 }
 
+// match_eval behind its argument checks.  haveLens: w.lenA / w.lenC already hold the valid-row counts of pcd1 / pcd2;
+// sortedByRole: w.grid holds both clouds sorted raw along one axis by hist_icp's sort (by ROLE: the pairs flagged in
+// w.swap have pcd1 in the fixed cloud's arrays) -- no count, no sort, the sweeps read what the registration left.
+static int match_eval_core(const float *d_pcd1, const float *d_pcd2, const float *d_T, int B, int N, double thres_dist,
+                           float *d_errors, float *d_inliers, float *d_ratios, float *d_ious, float *d_translations,
+                           float *d_rotations, Workspace &w, const Opts &o, hipStream_t s, bool haveLens,
+                           bool sortedByRole)
+{
+    if (!haveLens) launch_count_pair(d_pcd1, d_pcd2, B, N, w.lenA, w.lenC, nullptr, s);
+    const bool reuse = sortedByRole && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_EVAL_SWEEP);
+    // long clouds and large batches: both directions as sorted sweeps (eval_by_sweep)
+    if (reuse || eval_by_sweep(B, N, o)) {
+        if (!reuse) ICPFLOW_TRY(launch_sort_clouds_soa(d_pcd1, d_pcd2, w.lenA, w.lenC, nullptr, B, N, &w.grid, s));
+        ICPFLOW_TRY(launch_sweep_eval(&w.grid, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.zsortA, w.partial, s,
+                                      reuse ? w.swap : nullptr));
+        ICPFLOW_TRY(launch_eval_epilogue(w.partial, sweep_qblocks(N), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
+                                         d_ratios, d_ious, d_translations, d_rotations, s));
+        return 0;
+    }
+    ICPFLOW_TRY(launch_scan_eval(d_pcd1, d_pcd2, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.partial, s));
+    ICPFLOW_TRY(launch_eval_epilogue(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
+                                     d_ratios, d_ious, d_translations, d_rotations, s));
+    return 0;
+}
+
 int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_T, int B, int N,
                        double thres_dist, float *d_errors, float *d_inliers, float *d_ratios,
                        float *d_ious, float *d_translations, float *d_rotations, void *d_ws,
@@ -872,20 +915,42 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
     if (int r = check_batch("icpflow_match_eval", B, N)) return r;
     Workspace w(d_ws, B, N, 0);
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
+    return match_eval_core(d_pcd1, d_pcd2, d_T, B, N, thres_dist, d_errors, d_inliers, d_ratios, d_ious, d_translations,
+                           d_rotations, w, o, (hipStream_t)stream, false, false);
+}
+
+// hist_icp + match_eval of the same clouds in one call (utils_match.py:92-93 calls them back to back): the metrics are
+// taken on what the registration left in the workspace -- the valid-row counts and both clouds sorted along the fixed
+// cloud's longest axis -- instead of counting and sorting again.
+int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x, int len_x,
+                          const float *d_edges_y, int len_y, const float *d_edges_z, int len_z, float decode_shift,
+                          double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
+                          float *d_T_out, int32_t *d_iters, float *d_errors, float *d_inliers, float *d_ratios,
+                          float *d_ious, float *d_translations, float *d_rotations, void *d_ws, size_t ws_bytes,
+                          icpflow_stream_t stream, const icpflow_options_t *opt)
+{
+    Opts o;
+    if (int r = parse_options("icpflow_hist_icp_eval", opt, o)) return r;
+    if (int r = check_arith("icpflow_hist_icp_eval", o, max_iterations, stop_mode)) return r;
+    if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out || !d_errors || !d_inliers || !d_ratios ||
+        !d_ious || !d_translations || !d_rotations)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp_eval: null pointer");
+    if (int r = check_batch("icpflow_hist_icp_eval", B, N)) return r;
+    if (int r = check_hist_dims("icpflow_hist_icp_eval", len_x, len_y, len_z)) return r;
+    if (max_iterations <= 0 || max_iterations > kMaxIterCap)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp_eval: max_iterations must be in 1..%d", kMaxIterCap);
+    if (stop_mode != ICPFLOW_STOP_REFERENCE && stop_mode != ICPFLOW_STOP_PER_PAIR)
+        return fail(ICPFLOW_E_ARG, "icpflow_hist_icp_eval: unknown stop_mode %d", stop_mode);
+    const size_t L = (size_t)len_x * len_y * len_z;
+    if (L < (size_t)kTopK) return fail(ICPFLOW_E_ARG, "icpflow_hist_icp_eval: fewer than 5 bins");
+    Workspace w(d_ws, B, N, L);
+    if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
-    launch_count_pair(d_pcd1, d_pcd2, B, N, w.lenA, w.lenC, nullptr, s);
-    // long clouds: both directions as sorted sweeps (the sort pays for itself above ~2000 points)
-    if (N > kScoreSweepMinN && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_EVAL_SWEEP)) {
-        ICPFLOW_TRY(launch_sort_clouds_soa(d_pcd1, d_pcd2, w.lenA, w.lenC, nullptr, B, N, &w.grid, s));
-        ICPFLOW_TRY(launch_sweep_eval(&w.grid, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.zsortA, w.partial, s));
-        ICPFLOW_TRY(launch_eval_epilogue(w.partial, sweep_qblocks(N), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
-                                         d_ratios, d_ious, d_translations, d_rotations, s));
-        return 0;
-    }
-    ICPFLOW_TRY(launch_scan_eval(d_pcd1, d_pcd2, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.partial, s));
-    ICPFLOW_TRY(launch_eval_epilogue(w.partial, scan_qblocks(N, B), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
-                                     d_ratios, d_ious, d_translations, d_rotations, s));
-    return 0;
+    if (int r = hist_icp_core(d_src, d_dst, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z, len_z, decode_shift,
+                              thres_dist, max_iterations, relative_rmse_thr, stop_mode, d_T_out, d_iters, w, o, s))
+        return r;
+    return match_eval_core(d_src, d_dst, d_T_out, B, N, thres_dist, d_errors, d_inliers, d_ratios, d_ious, d_translations,
+                           d_rotations, w, o, s, true, w.grid.presorted != 0);
 }
 
 }  // extern "C"

@@ -361,7 +361,12 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
 // workgroups whatever their size: batches that leave workgroups waiting take 512 rows -- eight waves share the counters,
 // 32 waves per CU instead of 16 (config 4's shard: vote 1.66 -> 1.44 ms); batches that fit keep 256 (more, smaller
 // workgroups spread better over the CUs).
-template <int BLOCK>
+// SPLIT: waves per 64 rows.  A wave walks the targets of its z window one after the other (~36 dependent-ish
+// instructions per target, and a lone wave issues one instruction every ~2.4 ns): a pair's longest window paces its
+// workgroup however idle the SIMD is.  With SPLIT = 2 a workgroup of BLOCK threads holds BLOCK / 2 rows and two waves
+// share each 64 rows, half of the window each: twice the waves per CU (the LDS counters allow four workgroups per CU
+// whatever their size), half the serial chain per wave.
+template <int BLOCK, int SPLIT = 1>
 __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     const float4 *__restrict__ Xs, const float4 *__restrict__ Ys, const int32_t *__restrict__ nXv,
     const int32_t *__restrict__ nYv, int N, int len_x, int len_y, int len_z,
@@ -385,7 +390,9 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     // middle of a cloud take twice as long as those at its ends.  So the waves of a pair are dealt to its workgroups
     // round robin -- wave w of row block rb takes the 64 rows of global wave w * rowBlocks + rb -- and every workgroup
     // gets slabs from everywhere (SQ counters before: 7.5 of a CU's 16 waves resident on average).
-    const int rowBlocks = (N + BLOCK - 1) / BLOCK;
+    constexpr int kRows = BLOCK / SPLIT;            // X rows per workgroup
+    constexpr int kRowWaves = kRows / kWave;
+    const int rowBlocks = (N + kRows - 1) / kRows;
     const int rb = blockIdx.x / tsplit;
     const int jBegin = (blockIdx.x % tsplit) * span;
     if (rb * kWave >= nx || jBegin >= ny) return;  // sorted: valid rows first (rb * 64: the first row of wave 0)
@@ -398,7 +405,9 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     const int Lx = L + vote_overflow_bins(len_y, len_z);   // LDS counters: the pair's bins + the overflow row (vote_range)
     const int limit = lastPair ? L : 0x7fffffff;
     const int lane = threadIdx.x & (kWave - 1);
-    const int i = ((int)(threadIdx.x >> 6) * rowBlocks + rb) * kWave + lane;
+    const int wv = (int)(threadIdx.x >> 6);
+    const int share = SPLIT > 1 ? wv / kRowWaves : 0;           // which part of the window this wave takes
+    const int i = ((SPLIT > 1 ? wv % kRowWaves : wv) * rowBlocks + rb) * kWave + lane;
     const bool xvalid = i < nx;
     float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (xvalid) xi = xb[i];
@@ -461,6 +470,11 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
         // (r0, r1 are wave-uniform: scalar loop control)
         r0 = __builtin_amdgcn_readfirstlane(r0);
         r1 = __builtin_amdgcn_readfirstlane(r1);
+        if (SPLIT > 1) {
+            const int len = max(r1 - r0, 0);
+            r1 = r0 + (len * (share + 1)) / SPLIT;
+            r0 = r0 + (len * share) / SPLIT;
+        }
         if (allFast) {
             if (useLds) vote_range<true, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist, limit);
             else vote_range<true, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb, limit);
@@ -483,7 +497,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
                                    uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
-                                   const PairCountFuse *fuse)
+                                   const PairCountFuse *fuse, bool sideBusy)
 {
     if (fuse != nullptr && N > kChunkSortMinN) return hipErrorInvalidValue;   // only zsort_kernel counts
     const size_t L = (size_t)lens[0] * lens[1] * lens[2];
@@ -513,13 +527,13 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     const int useLds = lds_hist <= 64 * 1024;
     // Workgroup shape.  The counters in LDS limit a CU to four workgroups whatever their size: batches that leave
     // workgroups waiting take 512 rows per workgroup -- eight waves share the counters, 32 waves per CU instead of 16
-    // (config 4's shard: vote 1.66 -> 1.44 ms); batches that fit keep 256 (config 2: the same either way).  Batches too
+    // (config 4's shard: vote 1.66 -> 1.44 ms; config 2, round 3: step 0.726 -> 0.715 ms); smaller batches keep 256.  Batches too
     // small to give every SIMD two waves (a frame's candidate pairs) deal the sorted Y rows of a pair to several
     // workgroups of 1024 rows, `span` Y rows each (64 x 1024: -5 % per registration; on a batch that fills the GPU the extra window
     // searches and counter flushes cost 13 %).
     const int cus = device_cus();
     const long long wgs256 = (long long)((N + kVoteBlock - 1) / kVoteBlock) * ((N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile)) * B;
-    int block = wgs256 > 4LL * cus ? 512 : kVoteBlock;
+    int block = wgs256 >= 4LL * cus ? 512 : kVoteBlock;
     int span = kVoteSpan * kVoteTile;
     const long long waves = (long long)((N + kWave - 1) / kWave) * B;
     if (waves < 8LL * cus) {   // (1024 rows share one set of counters: the split's zeroing and flushing cost the least)
@@ -527,14 +541,23 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
         while (span > 256 && waves * ((N + span - 1) / span) < 32LL * cus) span >>= 1;
     }
     const int tsplit = (N + span - 1) / span;
+    const bool split = useLds && !sideBusy && block != 1024 && wgs256 >= 2LL * cus && wgs256 <= 4LL * cus;
     if (block == 1024) {
         dim3 grid(((N + 1023) / 1024) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<1024>, grid, dim3(1024), useLds ? lds_hist : tile_bytes, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
                            ez, swap, useLds, bins_u32, keyRec, span);
-    } else if (block == 512) {
+    } else if (block == 512 && !split) {
         dim3 grid(((N + 511) / 512) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<512>, grid, dim3(512), useLds ? lds_hist : tile_bytes, s,
+                           (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
+                           ez, swap, useLds, bins_u32, keyRec, span);
+    } else if (split) {
+        // 256 rows per workgroup, two waves per 64 rows (SPLIT): 32 waves per CU at four workgroups per CU.  Not beside the
+        // axis sort of hist_icp's side stream: its 1024-thread workgroups find no room on a CU that full and the sort,
+        // instead of hiding in the vote's gaps, ends after it (config 2: vote 0.136 -> 0.113 ms alone, step unchanged).
+        dim3 grid(((N + kVoteBlock - 1) / kVoteBlock) * tsplit, B);
+        hipLaunchKernelGGL((hist_vote_sorted_kernel<2 * kVoteBlock, 2>), grid, dim3(2 * kVoteBlock), lds_hist, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
                            ez, swap, useLds, bins_u32, keyRec, span);
     } else {

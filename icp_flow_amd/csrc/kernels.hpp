@@ -116,7 +116,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
                                    uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
-                                   const PairCountFuse *fuse = nullptr);
+                                   const PairCountFuse *fuse = nullptr, bool sideBusy = false);
 // sort.hip: several workgroups per long cloud; same outputs as zsort_kernel / sort_clouds_kernel
 constexpr int kChunkSortMinN = 4096;
 int chunk_sort_length(int N);
@@ -146,7 +146,7 @@ struct GridScratch;
 int scan_qblocks(int maxRows, int batch);
 int sweep_qblocks(int maxRows);
 hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const int32_t *len2, int B, int N,
-                             const float *pose, float thres, float *srcT, double *partial, hipStream_t s);
+                             const float *pose, float thres, float *srcT, double *partial, hipStream_t s, const uint8_t *swap = nullptr);
 struct PoseSource;   // posefuse.hpp
 // poseFinal == NULL: the final pose of every pair is composed inside the kernel from `fused`
 hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,

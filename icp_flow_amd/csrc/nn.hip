@@ -347,6 +347,11 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     const bool sw = p.swap != nullptr && p.swap[b] != 0;
     const int na = (sw ? p.lenC : p.lenA)[b], nc = (sw ? p.lenA : p.lenC)[b];
     const float *as = p.Asoa + (size_t)b * 3 * p.NP16, *cs = p.Csoa + (size_t)b * 3 * p.NP16;
+    int naE = na, ncE = nc;
+    if (MODE == SWEEP_EVAL && sw) {   // clouds sorted by ROLE (hist_icp's sort): pcd1 sits in the dst role's array
+        const float *t = as; as = cs; cs = t;
+        naE = nc; ncE = na;
+    }
     // queries come from qs; the scan reads ts; the window searches read the (exactly sorted) key row of ks
     const float *qs = backward ? cs : as, *ts = backward ? as : cs, *ks = ts;
     if (MODE == SWEEP_EVAL) {
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         if (!backward) qs = st;            // src * T against dst
         else { ts = st; ks = as; }          // dst against src * T, windows in the raw frame of src
     }
-    const int nq = backward ? nc : na, nt = backward ? na : nc;
+    const int nq = backward ? ncE : naE, nt = backward ? naE : ncE;
     double *out = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     __shared__ float boundSh;   // pruned scoring: candidate 0's forward mean
@@ -573,11 +578,12 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
 
 // pcd1 * T in pcd1's sorted order, as transform_points_batch forms it (utils_match.py:162), +inf padded
 __global__ void transform_soa_kernel(const float *__restrict__ soa, const int32_t *__restrict__ len,
-                                     const float *__restrict__ pose, int NP16, float *__restrict__ out)
+                                     const float *__restrict__ pose, int NP16, float *__restrict__ out,
+                                     const float *__restrict__ soaSwapped, const uint8_t *__restrict__ swap)
 {
     const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= NP16) return;
-    const float *in = soa + (size_t)b * 3 * NP16;
+    const float *in = ((swap != nullptr && swap[b] != 0) ? soaSwapped : soa) + (size_t)b * 3 * NP16;
     float *o = out + (size_t)b * 3 * NP16;
     float x = kInf, y = kInf, z = kInf;
     if (k < len[b]) {
@@ -631,17 +637,20 @@ hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *len
     return launch_sweep<SWEEP_SCORE>(p, s);
 }
 
-// match_eval (utils_match.py:159-213) on clouds sorted by launch_sort_clouds_soa(pcd1, pcd2, no swap);
-// srcT: scratch of B * 3 * NP16 floats (+ 64 of slack)
+// match_eval (utils_match.py:159-213) on clouds sorted by launch_sort_clouds_soa(pcd1, pcd2): without swap flags pcd1 is
+// the moving cloud of that sort; with them (the sort hist_icp made, by role) pcd1 sits in the fixed cloud's arrays for
+// the pairs flagged.  srcT: scratch of B * 3 * NP16 floats (+ 64 of slack)
 hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const int32_t *len2, int B, int N,
-                             const float *pose, float thres, float *srcT, double *partial, hipStream_t s)
+                             const float *pose, float thres, float *srcT, double *partial, hipStream_t s,
+                             const uint8_t *swap)
 {
     SweepParams p{};
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = len1; p.lenC = len2; p.axis = grid->axis;
+    p.swap = swap;
     p.poseA = pose; p.thres = thres; p.srcT = srcT; p.N = N; p.njobs = B * 2; p.partial = partial;
     const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
     hipLaunchKernelGGL(transform_soa_kernel, dim3((NP16 + 255) / 256, B), dim3(256), 0, s, grid->sortXsoa, len1, pose,
-                       NP16, srcT);
+                       NP16, srcT, grid->sortYsoa, swap);
     return launch_sweep<SWEEP_EVAL>(p, s);
 }
 

@@ -78,6 +78,33 @@ def match_eval(args, pcd1, pcd2, transformations):
     return o2[0], o2[1], o2[2], o2[3], o3[0], o3[1]
 
 
+def hist_icp_eval(args, src, dst, return_iterations=False):
+    """`hist_icp(args, src, dst)` and `match_eval(args, src, dst, T)` of its result in ONE call (icpflow_hist_icp_eval):
+    what match_pairs does for every batch of candidate pairs (utils_match.py:92-93).  Same numbers as the two calls;
+    the metrics reuse the valid-row counts and the sorted clouds the registration leaves in its workspace.
+    -> (T [B,4,4], (errors, inliers, ratios, ious [B,2], translations, rotations [B,3])[, iterations])."""
+    s = _lib.cloud(src, "src")
+    d = _lib.cloud(dst, "dst")
+    assert s.shape == d.shape, "src and dst must share [B, max_points, 4]"
+    B, N, _ = s.shape
+    dev = s.device
+    ex, ey, ez = bin_edges(args, dev)
+    lens = (len(ex), len(ey), len(ez))
+    max_it, rel, stop = _icp_options(args)
+    out = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
+    iters = torch.empty((1,), dtype=torch.int32, device=dev)
+    o2 = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(4)]
+    o3 = [torch.empty((B, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    _lib.check_vote_bins(B, lens)
+    ws = _lib.workspace(dev, _lib.workspace_bytes(B, N, lens))
+    _lib.call("icpflow_hist_icp_eval", _lib.ptr(s), _lib.ptr(d), B, N, _lib.ptr(ex), lens[0], _lib.ptr(ey),
+              lens[1], _lib.ptr(ez), lens[2], float(args.thres_dist // 2), float(args.thres_dist), max_it,
+              rel, stop, _lib.ptr(out), _lib.ptr(iters), _lib.ptr(o2[0]), _lib.ptr(o2[1]), _lib.ptr(o2[2]),
+              _lib.ptr(o2[3]), _lib.ptr(o3[0]), _lib.ptr(o3[1]), _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())
+    ev = (o2[0], o2[1], o2[2], o2[3], o3[0], o3[1])
+    return (out, ev, iters) if return_iterations else (out, ev)
+
+
 # --------------------------------------------------------------------------------------
 # the caller of the registration path: cluster association (SURVEY.md 8(f), a-15)
 #
@@ -122,8 +149,7 @@ def _launch_pairs(args, st, dt, pairs):
     si, di = st.find_host(pairs[:, 0]), dt.find_host(pairs[:, 1])
     assert (si >= 0).all() and (di >= 0).all()
     segs_src, segs_dst = _gather_pair_batches(args, st, dt, si, di)
-    T, iters = hist_icp(args, segs_src, segs_dst, return_iterations=True)
-    ev = match_eval(args, segs_src, segs_dst, T)
+    T, ev, iters = hist_icp_eval(args, segs_src, segs_dst, return_iterations=True)
     B = len(pairs)
     r = torch.cat([T.reshape(B, 16)] + [e.reshape(B, -1) for e in ev] + [iters.float().expand(B, 1)], dim=1)
     return si, di, r

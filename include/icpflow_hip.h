@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 202 /* 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 203 /* 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -308,6 +308,17 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
                        float *d_inliers, float *d_ratios, float *d_ious,
                        float *d_translations, float *d_rotations, void *d_ws,
                        size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt);
+
+/* a-11 + a-12 in one call: icpflow_hist_icp followed by icpflow_match_eval of the same clouds under the transforms it
+ * found (utils_match.py:92-93: `hist_icp(...)` then `match_eval(...)`, every candidate pair of match_pairs).  Same
+ * results as the two calls; the metrics reuse what the registration left in the workspace (valid-row counts, both clouds
+ * sorted along one axis) instead of counting and sorting again.  Arguments as in the two entry points. */
+int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x, int len_x,
+                          const float *d_edges_y, int len_y, const float *d_edges_z, int len_z, float decode_shift,
+                          double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
+                          float *d_T_out, int32_t *d_iters, float *d_errors, float *d_inliers, float *d_ratios,
+                          float *d_ious, float *d_translations, float *d_rotations, void *d_ws, size_t ws_bytes,
+                          icpflow_stream_t stream, const icpflow_options_t *opt);
 
 /* ---------------------------------------------------------------------------
  * a-15 / 8(f)  helpers of the host association around the path.

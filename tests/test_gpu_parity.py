@@ -631,6 +631,53 @@ def test_hist_icp_real_data_shape_large_padding():
     np.testing.assert_array_equal(ev2[1].cpu().numpy(), wv2[1].numpy())
 
 
+def test_match_eval_sweeps_on_large_batches_equal_the_scans_and_the_oracle():
+    """match_eval runs as sorted sweeps from 1024 points on when the batch is large (api.hip eval_by_sweep; config 2's and
+    config 4's shapes), as all-pairs scans otherwise: the nearest-neighbour minima are the same numbers either way, so
+    inlier counts are EQUAL and the means differ only in the order of an fp64 sum.  Dense and ragged batches, against the
+    scans (`no_eval_sweep`) and, on a sample, against the oracle."""
+    for B, N, ragged in ((256, 1024, False), (300, 1500, True), (160, 2048, False)):
+        S, D, _ = synthetic.make_batch(B, N, seed=21, ragged=ragged, n_min=20)
+        a = rp.default_args(max_points=N, icp_max_iterations=8)
+        T = utils_match.hist_icp(a, G(S), G(D))
+        ev = [e.cpu().numpy() for e in utils_match.match_eval(a, G(S), G(D), T)]
+        with _lib.options(no_eval_sweep=True):
+            sv = [e.cpu().numpy() for e in utils_match.match_eval(a, G(S), G(D), T)]
+        np.testing.assert_array_equal(ev[1], sv[1])                      # inlier counts
+        np.testing.assert_allclose(ev[0], sv[0], atol=1e-7, rtol=1e-6)   # mean errors
+        for k in (2, 3, 4, 5):
+            np.testing.assert_array_equal(ev[k], sv[k])                  # ratios, ious, translations, rotations
+        k = 12
+        wv = rp.match_eval(a, C(S[:k]), C(D[:k]), T[:k].cpu())
+        np.testing.assert_array_equal(ev[1][:k], wv[1].numpy())
+        np.testing.assert_allclose(ev[0][:k], wv[0].numpy(), atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(ev[3][:k], wv[3].numpy(), atol=1e-6)
+
+
+@all_icp_searches
+def test_hist_icp_eval_equals_the_two_calls():
+    """icpflow_hist_icp_eval = hist_icp followed by match_eval (utils_match.py:92-93), the metrics taken on the sorted
+    clouds the registration left behind (by role: pairs whose dst cloud is the smaller one sit swapped in those arrays).
+    Transforms and iteration count bit-identical, inlier counts / ratios / ious / translations / rotations EQUAL, mean
+    errors up to the order of an fp64 sum; ragged batches with both kinds of pairs, small and long clouds, the side
+    stream switched off (the registration then sorts inside the ICP launch and the metrics count and sort for themselves)."""
+    for B, N, kw in ((40, 256, {}), (64, 1024, {}), (24, 3000, {}), (6, 6000, {}), (30, 700, {"no_side_stream": True})):
+        S, D, _ = synthetic.make_batch(B, N, seed=31 + N, ragged=True, n_min=20)
+        S[::3], D[::3] = D[::3].copy(), S[::3].copy()          # both swap states in one batch
+        a = rp.default_args(max_points=N, icp_max_iterations=10)
+        with _lib.options(**kw):
+            T0, it0 = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+            ev0 = utils_match.match_eval(a, G(S), G(D), T0)
+            T1, ev1, it1 = utils_match.hist_icp_eval(a, G(S), G(D), return_iterations=True)
+        assert torch.equal(T0, T1) and int(it0) == int(it1)
+        ns, nd = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
+        assert (nd < ns).any() and (nd > ns).any()
+        np.testing.assert_array_equal(ev1[1].cpu().numpy(), ev0[1].cpu().numpy())
+        np.testing.assert_allclose(ev1[0].cpu().numpy(), ev0[0].cpu().numpy(), atol=1e-7, rtol=1e-6)
+        for k in (2, 3, 4, 5):
+            assert torch.equal(ev1[k], ev0[k])
+
+
 @all_icp_searches
 def test_hist_icp_beyond_the_lds_image_and_beyond_the_sorts():
     """Padded lengths above 12288 (the sorted fixed cloud no longer fits LDS: scalar-load sweep) and above
