@@ -38,6 +38,10 @@ __device__ int g_stamp_block;                  // the workgroup that stamps (icp
 // at the phase stamps (accumulated in LDS by thread 0)
 __device__ long long g_tail_clock[1024 * 3];
 __device__ long long g_wg_wall[8192 * 4];
+__device__ int g_unit_pair = -1;                       // pair whose per-(iteration, pass, wave) clocks are recorded (owner, no helpers)
+__device__ long long g_unit_clk[64 * 8 * 16];
+__device__ unsigned long long g_pair_help[1024];   // passes the pair's owner received from helpers
+__device__ unsigned long long g_pair_hclk[1024 * 4];   // per pair: helper pass clocks, helper passes, helper waits (100 MHz), owner waits (100 MHz)
 __device__ unsigned long long g_help_stats[8];   // helpers that joined a pair, passes the owners took from helpers, owner clocks spent waiting   // per pair: wall clock (100 MHz) at entry and exit of its workgroup, HW_ID, XCC_ID
 __device__ long long g_tail_split[1024 * 16];
 __shared__ long long g_tcSh[17];
@@ -744,6 +748,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 const float certMargin = ICPFLOW_CERT_MARGIN * p.sweepMargin;
                 const float gateOut = p.sweepMargin;                  // > thres with 1 % to spare (1.01 thres)
                 ICPFLOW_STAMP(1);
+#ifdef ICPFLOW_TAIL_CLOCK
+                const long long unit0 = clock64();
+#endif
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                     const int i = qBegin + g * PER + (wave * Q + q) * kWave + lane;
@@ -1026,6 +1033,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     recJ[i] = certJ[q];
                 }
                 ICPFLOW_STAMP(10);
+#ifdef ICPFLOW_TAIL_CLOCK
+                if (b == g_unit_pair && lane == 0 && it < 64 && g < 8 && wave < 16) g_unit_clk[(it * 8 + g) * 16 + wave] = clock64() - unit0;
+#endif
                 // The moments are sums over (x0, gated neighbour) only -- the pose enters through WHICH neighbour is
                 // gated.  A wave none of whose queries changed its gated neighbour since the previous iteration would
                 // add up the same numbers in the same order: its 18 sums are still in `red` (single-pass clouds).
@@ -1081,7 +1091,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         }
                         asm volatile("" ::: "memory");
 #ifdef ICPFLOW_TAIL_CLOCK
-                        if (lane == 0) { atomicAdd(&g_help_stats[1], 1ull); atomicAdd(&g_help_stats[2], (unsigned long long)(wall_clock64() - t0)); }
+                        if (lane == 0) { atomicAdd(&g_help_stats[1], 1ull); atomicAdd(&g_help_stats[2], (unsigned long long)(wall_clock64() - t0)); if (b < 1024) { atomicAdd(&g_pair_help[b], 1ull); atomicAdd(&g_pair_hclk[b * 4 + 3], (unsigned long long)(wall_clock64() - t0)); } }
 #endif
                         if (!ok) {
                             if (lane == 0) __hip_atomic_store(&ctrl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1267,6 +1277,12 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 }
                 __syncthreads();
                 if (tid == 0) {
+#ifdef ICPFLOW_TAIL_CLOCK
+                    atomicAdd(&g_help_stats[4], (unsigned long long)(clock64() - tcLoop0));   // the helper's pass, shader clocks
+                    atomicAdd(&g_help_stats[5], 1ull);
+                    if (b < 1024) { atomicAdd(&g_pair_hclk[b * 4], (unsigned long long)(clock64() - tcLoop0)); atomicAdd(&g_pair_hclk[b * 4 + 1], 1ull); }
+                    const long long tw0 = wall_clock64();
+#endif
                     __hip_atomic_store(&p.help.tag[blockIdx.x], (b << 8) | (it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // the state of a LATER iteration (the owner publishes one per iteration while a helper is signed up;
                     // it cannot get further than one iteration past a pass it is waiting for)
@@ -1279,6 +1295,10 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         if (wall_clock64() - t0 > kTeamTimeoutTicks) { e = -1; break; }
                     }
                     helpSh[4] = e;
+#ifdef ICPFLOW_TAIL_CLOCK
+                    atomicAdd(&g_help_stats[6], (unsigned long long)(wall_clock64() - tw0));       // waiting for the next state, 100 MHz ticks
+                    if (b < 1024) atomicAdd(&g_pair_hclk[b * 4 + 2], (unsigned long long)(wall_clock64() - tw0));
+#endif
                 }
                 __syncthreads();
                 const int e = __builtin_amdgcn_readfirstlane(helpSh[4]);
@@ -1290,6 +1310,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 // for this helper -- the buffer may have been rewritten: the pass is then computed from garbage and
                 // nobody reads it; the next epoch is read afresh)
                 it = e - 2;                                // ++it -> iteration e - 1
+#ifdef ICPFLOW_TAIL_CLOCK
+                tcLoop0 = clock64();
+#endif
                 continue;
             }
         }
@@ -1601,9 +1624,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     ICPFLOW_STAMP(8);
     __syncthreads();
 #ifdef ICPFLOW_TAIL_CLOCK
-    if (tid == 0 && b < 1024) { g_tail_clock[b * 3] = tcTail; g_tail_clock[b * 3 + 1] = tcSearch; g_tail_clock[b * 3 + 2] = itersDone; }
+    if (tid == 0 && b < 1024 && role == 0) { g_tail_clock[b * 3] = tcTail; g_tail_clock[b * 3 + 1] = tcSearch; g_tail_clock[b * 3 + 2] = itersDone; }
     if (tid < 16 && b < 1024) g_tail_split[b * 16 + tid] = g_tcSh[tid];
-    if (tid == 0 && b < 8192) {
+    if (tid == 0 && b < 8192 && role == 0) {   // (the pair's owner: helpers of the pair must not overwrite its record)
         g_wg_wall[b * 4] = tcWall0; g_wg_wall[b * 4 + 1] = wall_clock64();
         g_wg_wall[b * 4 + 2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
         g_wg_wall[b * 4 + 3] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11));
@@ -1685,7 +1708,13 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                     // may get the slot first).  Nothing found: this workgroup is done.
                     if (nb < 0 && p.help.pair != nullptr && p.helpOn) {
                         const int lane = threadIdx.x;
-                        for (int attempt = 0; attempt < 4 && nb < 0; ++attempt) {
+                        // (Every workgroup ranks the pairs the same way, and they run out of tickets within microseconds of
+                        // each other: with a strict ranking they all sign up for the same pair, three get in and the rest
+                        // leave after a few attempts.  So the ranking is by classes (eight iterations of head-room each) and
+                        // the choice inside a class by a hash of (pair, workgroup); a lost race for a slot just picks again.
+                        // Measured on config 4's shard: 418 -> 557 helpers joining, 5.7 k -> 8.6 k passes taken over, the
+                        // launch no shorter -- what paces a helped pair is its most expensive 64-query unit)
+                        for (int attempt = 0; attempt < 64 && nb < 0; ++attempt) {
                             int best = -1, bestKey = 0;
                             for (int w = lane; w < (int)gridDim.x; w += kWave) {
                                 const int ob = __hip_atomic_load(&p.help.owner[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
@@ -1701,7 +1730,8 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
                                 // third helper shortens an iteration as much as the first).  A pair in its last
                                 // iterations is not worth joining: two iterations pass before the first delivery.
                                 if (iter > 0 && iter + 3 < itEnd && nc < slots) {
-                                    const int key = (iter > 6 ? 1 << 20 : 0) + (itEnd - iter) * 8 + nc + 1;
+                                    const int cls = (iter > 6 ? 1 << 10 : 0) + ((itEnd - iter) >> 3) * 4 + nc + 1;
+                                    const int key = cls * 64 + ((ob * 37 + (int)blockIdx.x * 11 + attempt * 5) & 63);
                                     if (key > bestKey) { bestKey = key; best = ob; }
                                 }
                             }
@@ -1954,6 +1984,24 @@ struct LaunchProfile {
 extern "C" int icpflow_debug_tail_clock(long long *out3072)
 {
     return (int)hipMemcpyFromSymbol(out3072, HIP_SYMBOL(g_tail_clock), sizeof(long long) * 3072);
+}
+extern "C" int icpflow_debug_pair_hclk(unsigned long long *out4096, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_pair_hclk), sizeof(unsigned long long) * 4096);
+    if (reset) { static unsigned long long z[4096]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_hclk), z, sizeof(z)); }
+    return rc;
+}
+extern "C" int icpflow_debug_unit_clk(long long *out8192, int pair)
+{
+    int rc = (int)hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_unit_clk), sizeof(long long) * 8192);
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_unit_pair), &pair, sizeof(int));
+    return rc;
+}
+extern "C" int icpflow_debug_pair_help(unsigned long long *out1024, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_pair_help), sizeof(unsigned long long) * 1024);
+    if (reset) { static unsigned long long z[1024]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_help), z, sizeof(z)); }
+    return rc;
 }
 extern "C" int icpflow_debug_wg_wall(long long *out32768)
 {

@@ -19,6 +19,7 @@ for B in [int(x) for x in os.environ.get("BS", "1024,2048,8192").split(",")]:
     torch.cuda.synchronize()
     ms, n = prof.collect()
     _lib._L.icpflow_debug_help_stats(hs, 0)
+    print(f"helpers' side: {hs[5]} passes, {hs[4] / max(hs[5], 1):.0f} shader clocks per pass (state read .. sums out), {hs[6] / 100.0 / max(hs[5], 1):.2f} us waiting for the next state per pass")
     print(f"helpers: joined {hs[0]}, found the pair finished {hs[3]}, passes taken from helpers {hs[1]}, owner waves waited {hs[2] / 100.0 / max(hs[1], 1):.2f} us per pass on average")
     st = (ctypes.c_longlong * 3072)()
     _lib._L.icpflow_debug_tail_clock(st)
