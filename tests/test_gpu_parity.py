@@ -726,6 +726,22 @@ def test_hist_icp_under_stream_capture_and_on_two_streams():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+    # the one-call form with the metrics (icpflow_hist_icp_eval), captured and replayed the same way
+    want_ev = [e.clone() for e in utils_match.match_eval(a, src, dst, want)]
+    with torch.cuda.stream(side):
+        utils_match.hist_icp_eval(a, src, dst)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        out2, ev2 = utils_match.hist_icp_eval(a, src, dst)
+    out2.zero_()
+    for e in ev2:
+        e.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out2, want)
+    assert torch.equal(ev2[1], want_ev[1]) and torch.allclose(ev2[0], want_ev[0], atol=1e-7, rtol=1e-6)
     # two streams, interleaved calls, different inputs
     S2, D2, _ = synthetic.make_batch(64, 512, seed=4)
     src2, dst2 = G(S2), G(D2)
