@@ -40,6 +40,7 @@ __device__ long long g_tail_clock[1024 * 3];
 __device__ long long g_wg_wall[8192 * 4];
 __device__ int g_unit_pair = -1;                       // pair whose per-(iteration, pass, wave) clocks are recorded (owner, no helpers)
 __device__ long long g_unit_clk[64 * 8 * 16];
+__device__ int g_unit_win[64 * 8 * 16 * 2];   // per (iteration, pass, wave): targets in the scanned window, lanes that searched
 __device__ unsigned long long g_pair_help[1024];   // passes the pair's owner received from helpers
 __device__ unsigned long long g_pair_hclk[1024 * 4];   // per pair: helper pass clocks, helper passes, helper waits (100 MHz), owner waits (100 MHz)
 __device__ unsigned long long g_help_stats[8];   // helpers that joined a pair, passes the owners took from helpers, owner clocks spent waiting   // per pair: wall clock (100 MHz) at entry and exit of its workgroup, HW_ID, XCC_ID
@@ -360,6 +361,22 @@ constexpr int kProbeMax = ICPFLOW_PROBE_MAX;   // uncertified queries a wave set
 // blocks of 64 targets a probe may evaluate (measured at config 2: 2 / 3 / 4 / 6 / 8 / 12 / 16 blocks -> ICP launch
 // 0.487 / 0.512 / 0.441 / 0.401 / 0.396 / 0.396 / 0.400 ms: an inconclusive probe sends its whole wave to the scan)
 constexpr int kProbeSteps = ICPFLOW_PROBE_STEPS;
+// ... and on clouds of several passes (more than one workgroup-full of queries: 2048 points and up).  A probe proves its
+// answer by the distance, ALONG THE SORT AXIS, to the ends of the range it has evaluated; where hundreds of targets share
+// one coordinate along that axis -- the face of a box that is perpendicular to it: a third of a 2048-point cloud in the
+// slowest pairs of config 4 (profiles/r03_config4_unit_clocks.txt: windows of 650-800 targets) -- that distance stays zero
+// until the range has swallowed the whole face: ten to thirteen blocks.  With eight, every probe there ended inconclusive
+// and five or ten uncertified lanes sent their wave through a broadcast scan of the whole window, in every iteration
+// (50-70 k clocks per 64 queries against 5 k).  Measured (steps, lanes) on config 4's shard, ICP launch: (8, 20) 2.19 ms,
+// (12, 20) 1.91, (24, 20) 1.84, (24, 32) 1.84, (24, 48) 1.87, (32, 32) 1.83; all 8192 pairs 11.4 -> 10.2 ms; config 2
+// (single pass) does not move with the steps and loses 6 % with 32 lanes.
+#ifndef ICPFLOW_PROBE_MAX_LONG
+#define ICPFLOW_PROBE_MAX_LONG 32
+#endif
+#ifndef ICPFLOW_PROBE_STEPS_LONG
+#define ICPFLOW_PROBE_STEPS_LONG 24
+#endif
+constexpr int kProbeMaxLong = ICPFLOW_PROBE_MAX_LONG, kProbeStepsLong = ICPFLOW_PROBE_STEPS_LONG;
 constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
 // ---------------------------------------------------------------------------------
@@ -812,16 +829,17 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 // 16-byte LDS read per coordinate and four targets).  The targets NOT evaluated lie beyond the ends of the
                 // evaluated range along the sort axis, at least rho away: the probe is conclusive when rho exceeds the
                 // minimum found (then that is the nearest neighbour) or, for a minimum outside the gate, when rho exceeds
-                // 1.01 thres; otherwise the range grows by 64 targets on its short side, up to kProbeSteps times.
+                // 1.01 thres; otherwise the range grows by 64 targets on its short side, up to kProbeSteps (kProbeStepsLong) times.
                 // Inconclusive probes, equal minima (the first-index rule is the scan's business), queries without a
                 // previous neighbour and waves with many uncertified lanes take the window scan.
                 if (REC && recOn && it > itFirst) {
+                    const int probeSteps = ngr > 1 ? kProbeStepsLong : kProbeSteps, probeMax = ngr > 1 ? kProbeMaxLong : kProbeMax;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const bool wants = live[q] && recM[q] >= 0.f && certJ[q] >= 0;
                         const unsigned long long need = __ballot(wants);
                         const int nNeed = __popcll(need);
-                        if (nNeed > kProbeMax || nNeed == 0) continue;
+                        if (nNeed > probeMax || nNeed == 0) continue;
                         // the uncertified lanes in lane order: lane k of the wave learns who the k-th of them is (one
                         // forward permute), row r of round t then serves the (8 t + r)-th
                         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
@@ -843,7 +861,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                             int lslot = 0;
                             bool done = !rowOn, ok = false, isNN = false;
                             float rowbest = kInf, rho = 0.f;
-                            for (int step = 0; step < kProbeSteps; ++step) {
+                            for (int step = 0; step < probeSteps; ++step) {
                                 const int t0 = bs + 8 * li;
                                 if (!done && t0 < be && t0 < np16) {
                                     const float4 xa = *reinterpret_cast<const float4 *>(lx + t0), xb = *reinterpret_cast<const float4 *>(lx + t0 + 4);
@@ -870,7 +888,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                                 const bool out = !(rowbest <= p.thr2) && rho > gateOut;
                                 if (!done) {
                                     if (nn || out) { done = true; ok = true; isNN = nn; }
-                                    else if (step + 1 == kProbeSteps) done = true;
+                                    else if (step + 1 == probeSteps) done = true;
                                     else if (rL < rR) { be = a; bs = max(a - 64, 0); a = bs; }   // (a > 0: rL is finite)
                                     else { bs = bEnd; be = bEnd + 64; bEnd = be; }               // (bEnd < np16: rR is finite)
                                 }
@@ -943,6 +961,14 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 }
 #ifdef ICPFLOW_PHASE_TIMING
                 else if ((int)blockIdx.x == g_stamp_block && lane == 0) g_wave_stamps[wave * 16 + 15] = 0;
+#endif
+#ifdef ICPFLOW_TAIL_CLOCK
+                if (b == g_unit_pair && it < 64 && g < 8 && wave < 16) {
+                    int nsearch = 0;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) nsearch += __popcll(__ballot(live[q] && recM[q] >= 0.f));
+                    if (lane == 0) { g_unit_win[((it * 8 + g) * 16 + wave) * 2] = ce - cb; g_unit_win[((it * 8 + g) * 16 + wave) * 2 + 1] = nsearch; }
+                }
 #endif
 #ifdef ICPFLOW_CERT_STATS
                 if (it < 128 && (g_stats_block < 0 || g_stats_block == (int)blockIdx.x)) {
@@ -1990,6 +2016,10 @@ extern "C" int icpflow_debug_pair_hclk(unsigned long long *out4096, int reset)
     int rc = (int)hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_pair_hclk), sizeof(unsigned long long) * 4096);
     if (reset) { static unsigned long long z[4096]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_hclk), z, sizeof(z)); }
     return rc;
+}
+extern "C" int icpflow_debug_unit_win(int *out16384)
+{
+    return (int)hipMemcpyFromSymbol(out16384, HIP_SYMBOL(g_unit_win), sizeof(int) * 16384);
 }
 extern "C" int icpflow_debug_unit_clk(long long *out8192, int pair)
 {

@@ -17,8 +17,12 @@ for pair in [int(x) for x in os.environ.get("PAIRS", "751,915").split(",")]:
     torch.cuda.synchronize()
     _lib._L.icpflow_debug_unit_clk(buf, -1)
     u = np.array(buf[:], dtype=np.int64).reshape(64, 8, 16)[:, :4, :8]
+    wb = (ctypes.c_int * 16384)(); _lib._L.icpflow_debug_unit_win(wb)
+    win = np.array(wb[:], dtype=np.int64).reshape(64, 8, 16, 2)[:, :4, :8]
     print(f"pair {pair}: clocks per (pass, wave) in thousands")
     for it in (0, 2, 5, 10, 15, 20, 25, 30):
         m = u[it]
         if m.sum() == 0: continue
+        if it in (0, 10, 20):
+            print(f"   iteration {it}, targets in the window per (pass, wave):\n{win[it, :, :, 0]}\n   lanes that searched:\n{win[it, :, :, 1]}\n   clocks (k):\n{np.round(m / 1e3, 0).astype(int)}")
         print(f" iteration {it}: sum over passes per wave {np.round(m.sum(0) / 1e3, 1)}; max unit {m.max() / 1e3:.1f}; slowest wave {m.sum(0).max() / 1e3:.1f}; per pass max over waves {np.round(m.max(1) / 1e3, 1)}")
