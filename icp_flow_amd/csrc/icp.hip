@@ -833,7 +833,8 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 // Inconclusive probes, equal minima (the first-index rule is the scan's business), queries without a
                 // previous neighbour and waves with many uncertified lanes take the window scan.
                 if (REC && recOn && it > itFirst) {
-                    const int probeSteps = ngr > 1 ? kProbeStepsLong : kProbeSteps, probeMax = ngr > 1 ? kProbeMaxLong : kProbeMax;
+                    const bool longProbes = ngr > 1 || yc.n > 1024;   // (team members: one pass each, but of a long cloud)
+                    const int probeSteps = longProbes ? kProbeStepsLong : kProbeSteps, probeMax = longProbes ? kProbeMaxLong : kProbeMax;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const bool wants = live[q] && recM[q] >= 0.f && certJ[q] >= 0;
