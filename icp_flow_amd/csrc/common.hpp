@@ -239,27 +239,42 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-// Bitonic sort of NP2 (power of two) (key, index) pairs held in LDS, ascending by key, ties by
-// index (deterministic).  All threads of the block must call it.
-__device__ __forceinline__ void bitonic_exchange(float *key, int *idx, int t, int j, int k)
+// Bitonic sort of NP2 (power of two) (key, index) pairs held in LDS, ascending by key, ties by index (deterministic).
+// A pair is ONE 64-bit word: the key as an order-preserving unsigned integer in the high half (sign flip; -0.0 is stored
+// as +0.0, which compares equal to it), the non-negative index in the low half -- the lexicographic order of (key, index)
+// is the unsigned order of the words, and a compare-exchange is two 8-byte LDS reads, one 64-bit compare and two 8-byte
+// writes instead of four reads, three compares and four writes on two arrays (round 3: all 8192 pairs of config 4
+// 27.8 -> 27.1 ms per step).  All threads of the block must call bitonic_sort_lds.
+__device__ __forceinline__ unsigned long long sort_pack(float key, int index)
+{
+    unsigned u = __float_as_uint(key + 0.0f);                   // (-0.0 + 0.0 = +0.0)
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)index;
+}
+__device__ __forceinline__ float sort_key_of(unsigned long long w)
+{
+    const unsigned u = (unsigned)(w >> 32);
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ int sort_index_of(unsigned long long w) { return (int)(unsigned)w; }
+
+__device__ __forceinline__ void bitonic_exchange(unsigned long long *kv, int t, int j, int k)
 {
     const int i = (t << 1) - (t & (j - 1));   // = (t / j) * 2j + t % j for the power of two j, without the division
     const int l = i + j;
-    const float ki = key[i], kl = key[l];
-    const int ii = idx[i], il = idx[l];
+    const unsigned long long a = kv[i], b = kv[l];
     const bool up = (i & k) == 0;
-    const bool gt = ki > kl || (ki == kl && ii > il);
-    if (gt == up) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+    if ((a > b) == up) { kv[i] = b; kv[l] = a; }
 }
 
-__device__ __forceinline__ void bitonic_sort_lds(float *key, int *idx, int NP2)
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long *kv, int NP2)
 {
     const int half = NP2 >> 1;  // one compare-exchange per thread and step
     for (int k = 2; k <= NP2; k <<= 1) {
         // steps with partner distance >= 128 cross the 128-element blocks owned by single waves: barrier each
         int j = k >> 1;
         for (; j > kWave; j >>= 1) {
-            for (int t = threadIdx.x; t < half; t += blockDim.x) bitonic_exchange(key, idx, t, j, k);
+            for (int t = threadIdx.x; t < half; t += blockDim.x) bitonic_exchange(kv, t, j, k);
             __syncthreads();
         }
         // distance <= 64: the 64 exchanges of a wave stay inside one 128-element block for all remaining
@@ -267,7 +282,7 @@ __device__ __forceinline__ void bitonic_sort_lds(float *key, int *idx, int NP2)
         // order; the fences only keep the compiler from reordering them): 7 barriers per phase become 1
         for (int t = threadIdx.x; t < half; t += blockDim.x) {
             for (int jj = j; jj > 0; jj >>= 1) {
-                bitonic_exchange(key, idx, t, jj, k);
+                bitonic_exchange(kv, t, jj, k);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

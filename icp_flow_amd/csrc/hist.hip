@@ -288,8 +288,7 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
                                                            float *__restrict__ keyRec, ZsortCount cnt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
-    float *key = reinterpret_cast<float *>(dynLds);
-    int *idx = reinterpret_cast<int *>(dynLds + sizeof(float) * NP2full);
+    unsigned long long *kv = reinterpret_cast<unsigned long long *>(dynLds);   // (sort key, row) pairs, NP2full of them
     __shared__ float bbScratch[6 * (kZsortBlock / kWave)];
     __shared__ float keyShared[kVoteKeyStride];
     const int b = blockIdx.x;
@@ -343,16 +342,19 @@ __global__ __launch_bounds__(kZsortBlock) void zsort_kernel(const float4 *__rest
             const float4 q = in[j];
             if (q.w > 0.0f) k = vote_key(vk, q.x, q.y, q.z);
         }
-        key[j] = k;
-        idx[j] = j;
+        kv[j] = sort_pack(k, j);
     }
     __syncthreads();
-    bitonic_sort_lds(key, idx, NP2);
+    bitonic_sort_lds(kv, NP2);
     for (int r = threadIdx.x; r < N; r += kZsortBlock) {
         // valid rows carry their key in w (the flag of a valid row is implied by its position below the
         // count); rows beyond the valid count have +inf keys
         float4 o = make_float4(0.f, 0.f, kInf, kInf);
-        if (r < NP2 && key[r] < kInf) { o = in[idx[r]]; o.w = key[r]; }
+        if (r < NP2) {
+            const unsigned long long w = kv[r];
+            const float k = sort_key_of(w);
+            if (k < kInf) { o = in[sort_index_of(w)]; o.w = k; }
+        }
         out[r] = o;
     }
 }

@@ -230,8 +230,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     float *__restrict__ Ysoa, float *__restrict__ Xsoa, int selfCount)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
-    float *key = reinterpret_cast<float *>(dynLds);
-    int *idx = reinterpret_cast<int *>(dynLds + sizeof(float) * NP2);
+    unsigned long long *kv = reinterpret_cast<unsigned long long *>(dynLds);   // (sort key, row) pairs, NP2 of them
     __shared__ float bb[6 * (kSortBlock / kWave)];
     __shared__ int axisSh;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -309,11 +308,10 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
             xf_apply(pre, q.x, q.y, q.z, px, py, pz);
             k = axis == 0 ? px : (axis == 1 ? py : pz);
         }
-        key[j] = k;
-        idx[j] = j;
+        kv[j] = sort_pack(k, j);
     }
     __syncthreads();
-    bitonic_sort_lds(key, idx, np2);
+    bitonic_sort_lds(kv, np2);
     float4 *out = (moving ? Xs : Ys) + (size_t)b * N;
     const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
     // structure-of-arrays image (x[], y[], z[], padded with +inf to a multiple of 16): always for the
@@ -322,7 +320,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     for (int r = tid; r < (soa ? NP16 : n); r += kSortBlock) {
         float px = kInf, py = kInf, pz = kInf;
         if (r < n) {
-            const int j = idx[r];
+            const int j = sort_index_of(kv[r]);
             const float4 q = cloud[j];
             xf_apply(pre, q.x, q.y, q.z, px, py, pz);
             out[r] = make_float4(px, py, pz, __int_as_float(j));

@@ -118,8 +118,7 @@ __device__ __forceinline__ float sort_key(const ChunkSortParams &p, const Roles 
 // grid (B, 2, NPc / kCsChunk)
 __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
 {
-    __shared__ float key[kCsChunk];
-    __shared__ int idx[kCsChunk];
+    __shared__ unsigned long long kv[kCsChunk];   // (sort key, row) pairs
     __shared__ float bb[6 * (kCsBlock / kWave)];
     __shared__ int axisSh;
     __shared__ float keySh[kVoteKeyStride];
@@ -148,14 +147,13 @@ __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
     for (int j = threadIdx.x; j < kCsChunk; j += kCsBlock) {
         float k = kInf, px, py, pz;
         if (base + j < r.n) k = sort_key(p, r, b, axis, vk, base + j, px, py, pz);
-        key[j] = k;
-        idx[j] = base + j;
+        kv[j] = sort_pack(k, base + j);
     }
     __syncthreads();
-    bitonic_sort_lds(key, idx, kCsChunk);
+    bitonic_sort_lds(kv, kCsChunk);
     float *ck = p.ckey + ((size_t)b * 2 + which) * p.NPc + base;
     int *ci = p.cidx + ((size_t)b * 2 + which) * p.NPc + base;
-    for (int j = threadIdx.x; j < kCsChunk; j += kCsBlock) { ck[j] = key[j]; ci[j] = idx[j]; }
+    for (int j = threadIdx.x; j < kCsChunk; j += kCsBlock) { const unsigned long long w = kv[j]; ck[j] = sort_key_of(w); ci[j] = sort_index_of(w); }
 }
 
 // number of elements (k, i) of a sorted chunk with (k, i) < (key, id), lexicographic
