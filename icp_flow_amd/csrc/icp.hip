@@ -428,10 +428,20 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
     const double *base = t.mom + ((size_t)b * 2 + (it & 1)) * kMaxTeam * kTeamStride;
     constexpr int kLanesPerGroup = kMoments, kGroups = 3;
     const int g = lane / kLanesPerGroup, k = lane - g * kLanesPerGroup;
+    // (all loads of a lane in flight together, then added in member order: as a loop of load-add pairs every record
+    // cost its lane a full round trip -- six in a row in a team of sixteen, the larger part of the exchange)
+    constexpr int kPerLane = (kMaxTeam + kGroups - 1) / kGroups;
+    double rec[kPerLane];
+#pragma unroll
+    for (int u = 0; u < kPerLane; ++u) {
+        // (unconditional, from a clamped address: a load under a branch is waited for at the branch's end)
+        const int r = min(g + kGroups * u, G - 1), kk = g < kGroups ? k : 0;
+        rec[u] = __hip_atomic_load(&base[r * kTeamStride + kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     double part = 0.0;
-    if (g < kGroups)
-        for (int r = g; r < G; r += kGroups)
-            part += __hip_atomic_load(&base[r * kTeamStride + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int u = 0; u < kPerLane; ++u)
+        if (g < kGroups && g + kGroups * u < G) part += rec[u];
     double stop = 0.0;
     if (lane == 63) stop = __hip_atomic_load(&base[kMoments], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double p1 = __shfl(part, (lane + kLanesPerGroup) & 63, kWave), p2 = __shfl(part, (lane + 2 * kLanesPerGroup) & 63, kWave);
