@@ -1132,8 +1132,16 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                             if (lane == 0) __hip_atomic_store(&ctrl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         } else {
                             const double *out = p.help.out + (size_t)wg * kHelpOutStride;
-                            for (int k = lane; k < NWAVE * kMoments; k += kWave)
-                                redDyn[gj * NWAVE * kMoments + k] = __hip_atomic_load(&out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            // (all of a lane's loads in flight together: unconditional, from clamped addresses -- as a loop
+                            // every record cost a round trip of its own, see team_collect)
+                            constexpr int kFetch = (NWAVE * kMoments + kWave - 1) / kWave;
+                            double got[kFetch];
+#pragma unroll
+                            for (int u = 0; u < kFetch; ++u)
+                                got[u] = __hip_atomic_load(&out[min(lane + u * kWave, NWAVE * kMoments - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                            for (int u = 0; u < kFetch; ++u)
+                                if (lane + u * kWave < NWAVE * kMoments) redDyn[gj * NWAVE * kMoments + lane + u * kWave] = got[u];
                         }
                     }
                 }

@@ -126,12 +126,34 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
         // direction cannot make candidate k the winner, and if the other direction still does, the score is
         // that direction's mean alone.  The scan reports +inf instead of its sum; the pick is unchanged.
         __shared__ int leave;
+        // (the sums of the earlier launches: wave 0 reads them one query block per lane, all scans in flight at once, and
+        // adds them in block order -- as a loop on one thread they were up to 88 dependent scalar loads; see
+        // sweep_scan_kernel)
+        __shared__ double scanSum[12];
+        if (threadIdx.x < kWave && p.qblocks <= kWave) {
+            const int ln = threadIdx.x, q = min(ln, p.qblocks - 1);
+            double v[11];
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                const int sc = u == 0 ? 0 : u + 1;                                     // scans 0, 2 .. 11
+                v[u] = (u == 0 || p.prune == 2) ? p.partial[((size_t)(b * 12 + sc) * p.qblocks + q) * kPartial] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                if (u > 0 && p.prune != 2) break;
+                double t = 0.0;
+                for (int qq = 0; qq < p.qblocks; ++qq) t += __shfl(v[u], qq, kWave);   // block order, as before
+                if (ln == 0) scanSum[u == 0 ? 0 : u + 1] = t;
+            }
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
             const bool sw = p.swap != nullptr && p.swap[b] != 0;
             const float na = (float)(sw ? p.lenC : p.lenA)[b], nc = (float)(sw ? p.lenA : p.lenC)[b];
             // the forward mean of candidate 0 (complete: earlier launch) is an upper bound of its score
             double f0 = 0.0;
-            for (int q = 0; q < p.qblocks; ++q) f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
+            if (p.qblocks <= kWave) f0 = scanSum[0];
+            else for (int q = 0; q < p.qblocks; ++q) f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
             const float bound = (float)f0 / na;
             if (p.prune == 2) {
                 // third launch: the backward scan of candidate 0.  score_0 = min(forward, backward) <= bound, and
@@ -140,7 +162,8 @@ __global__ __launch_bounds__(kScanBlock) void nn_scan_kernel(ScanParams p)
                 bool othersOut = true;
                 for (int k = 1; k < 6; ++k) {
                     double fk = 0.0, bk = 0.0;
-                    for (int q = 0; q < p.qblocks; ++q) {
+                    if (p.qblocks <= kWave) { fk = scanSum[2 * k]; bk = scanSum[2 * k + 1]; }
+                    else for (int q = 0; q < p.qblocks; ++q) {
                         fk += p.partial[((size_t)(b * 12 + 2 * k) * p.qblocks + q) * kPartial];
                         bk += p.partial[((size_t)(b * 12 + 2 * k + 1) * p.qblocks + q) * kPartial];
                     }
@@ -369,16 +392,40 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         // branch and bound exactly as in nn_scan_kernel (the argument is written there): the sum of the blocks
         // before this one bounds the scan's mean from below; beyond candidate 0's forward mean it reports +inf
         __shared__ int leave;
+        // The sums of earlier launches (candidate 0's forward scan; in the third launch every other scan too) are read by
+        // wave 0, one query block per lane and all scans in flight at once, then added in block order.  (As a loop on one
+        // thread these were 8, in the third launch 88, dependent scalar loads of a few hundred nanoseconds each: the
+        // whole third launch, and the first microseconds of every block of the second.)
+        __shared__ double scanSum[12];
+        if (wave == 0 && p.qblocks <= kWave) {
+            const int q = min(lane, p.qblocks - 1);
+            double v[11];
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                const int sc = u == 0 ? 0 : u + 1;                                     // scans 0, 2 .. 11
+                v[u] = (u == 0 || p.prune == 2) ? p.partial[((size_t)(b * 12 + sc) * p.qblocks + q) * kPartial] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                if (u > 0 && p.prune != 2) break;
+                double t = 0.0;
+                for (int qq = 0; qq < p.qblocks; ++qq) t += __shfl(v[u], qq, kWave);   // block order, as before
+                if (lane == 0) scanSum[u == 0 ? 0 : u + 1] = t;
+            }
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
             double f0 = 0.0;
-            for (int q = 0; q < p.qblocks; ++q) f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
+            if (p.qblocks <= kWave) f0 = scanSum[0];
+            else for (int q = 0; q < p.qblocks; ++q) f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
             const float bound = (float)f0 / (float)na;
             boundSh = bound;
             if (p.prune == 2) {
                 bool othersOut = true;
                 for (int k = 1; k < 6; ++k) {
                     double fk = 0.0, bk = 0.0;
-                    for (int q = 0; q < p.qblocks; ++q) {
+                    if (p.qblocks <= kWave) { fk = scanSum[2 * k]; bk = scanSum[2 * k + 1]; }
+                    else for (int q = 0; q < p.qblocks; ++q) {
                         fk += p.partial[((size_t)(b * 12 + 2 * k) * p.qblocks + q) * kPartial];
                         bk += p.partial[((size_t)(b * 12 + 2 * k + 1) * p.qblocks + q) * kPartial];
                     }
