@@ -21,7 +21,6 @@ namespace icpflow {
 
 constexpr int kCsChunk = 2048;   // keys per chunk (one 1024-thread workgroup, 16 KiB of LDS)
 constexpr int kCsBlock = 1024;
-constexpr int kMergeMaxChunks = 8;   // chunks merged with their searches in lockstep (16384 rows; more: one after the other)
 
 struct ChunkSortParams {
     int mode;                 // 0: by z (vote), 1: along the fixed cloud's longest axis (sweeps)
@@ -194,40 +193,10 @@ __global__ __launch_bounds__(kCsBlock) void chunk_merge_kernel(ChunkSortParams p
     const int c = e / kCsChunk;
     int rank = e - c * kCsChunk;
     const int nchunks = (r.n + kCsChunk - 1) / kCsChunk;
-    if (nchunks <= kMergeMaxChunks) {
-        // The binary searches over the other chunks are independent: all of them advance one step at a time, their
-        // loads in flight together -- twelve round trips to L2 per element instead of twelve per chunk.
-        int lo[kMergeMaxChunks], hi[kMergeMaxChunks];
-#pragma unroll
-        for (int o = 0; o < kMergeMaxChunks; ++o) {
-            lo[o] = 0;
-            hi[o] = (o < nchunks && o != c) ? min(kCsChunk, r.n - o * kCsChunk) : 0;
-        }
-        for (int step = 0; step < 12; ++step) {      // 2^12 > kCsChunk: every search has ended
-            float k[kMergeMaxChunks];
-            int ci[kMergeMaxChunks];
-#pragma unroll
-            for (int o = 0; o < kMergeMaxChunks; ++o) {
-                const int mid = min((lo[o] + hi[o]) >> 1, kCsChunk - 1);       // (unconditional loads, inside the chunk array)
-                const size_t at = (size_t)min(o, max(nchunks - 1, 0)) * kCsChunk + mid;
-                k[o] = ckAll[at];
-                ci[o] = ciAll[at];
-            }
-#pragma unroll
-            for (int o = 0; o < kMergeMaxChunks; ++o) {
-                const int mid = (lo[o] + hi[o]) >> 1;
-                const bool less = k[o] < key || (k[o] == key && ci[o] < id);
-                if (lo[o] < hi[o]) { if (less) lo[o] = mid + 1; else hi[o] = mid; }
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < kMergeMaxChunks; ++o) rank += lo[o];
-    } else {
-        for (int o = 0; o < nchunks; ++o) {
-            if (o == c) continue;
-            const int len = min(kCsChunk, r.n - o * kCsChunk);
-            rank += count_less(ckAll + (size_t)o * kCsChunk, ciAll + (size_t)o * kCsChunk, len, key, id);
-        }
+    for (int o = 0; o < nchunks; ++o) {
+        if (o == c) continue;
+        const int len = min(kCsChunk, r.n - o * kCsChunk);
+        rank += count_less(ckAll + (size_t)o * kCsChunk, ciAll + (size_t)o * kCsChunk, len, key, id);
     }
     if (p.mode == 0) {
         // rows whose flag is not set carry +inf keys and sort behind the valid ones: emitted as invalid rows
