@@ -16,6 +16,15 @@ __device__ __forceinline__ double partial_total(const double *partial, int job, 
 {
     double s = 0.0;
     const double *base = partial + (size_t)job * qblocks * kPartial + k;
+    if (qblocks <= 4) {   // (config 2: four blocks -- no point in eight loads)
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = base[(size_t)min(u, qblocks - 1) * kPartial];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < qblocks) s += v[u];
+        return s;
+    }
     for (int q0 = 0; q0 < qblocks; q0 += 8) {
         double v[8];
 #pragma unroll
