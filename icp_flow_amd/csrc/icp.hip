@@ -1877,10 +1877,12 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     size[b] = max(n - 768, 0);   // queries beyond one pass of a (768-thread) workgroup
     for (int w = threadIdx.x; w < t.maxWG; w += blockDim.x) { t.wgPair[w] = -1; t.wgRank[w] = 0; }
     __syncthreads();
-    if (b == 0) {
+    if (b < kWave) {   // (wave 0 adds the sizes: exact integers, any order)
         long long s = 0;
-        for (int k = 0; k < B; ++k) s += size[k];
-        total = s;
+        for (int k = b; k < B; k += kWave) s += size[k];
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+        if (b == 0) total = s;
     }
     __syncthreads();
     int G = 0;
@@ -1902,12 +1904,16 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
         const int nx = (per == t.maxWG) ? 1 : 8;
         bool ok = true;
         for (int k = 0; k < B && ok; ++k) {
-            int x = 0;
-            for (int c = 1; c < nx; ++c)
-                if (used[c] < used[x]) x = c;
-            if (used[x] + size[k] > per) ok = false;
-            first[k] = x * per + used[x];
-            used[x] += size[k];
+            // (the least-used XCD, first one on ties; the counters stay in registers: no indexing by a variable)
+            int x = 0, ux = used[0];
+#pragma unroll
+            for (int c = 1; c < 8; ++c)
+                if (c < nx && used[c] < ux) { x = c; ux = used[c]; }
+            const int sz = size[k];
+            if (ux + sz > per) ok = false;
+            first[k] = x * per + ux;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) used[c] += (c == x) ? sz : 0;
         }
         if (!ok) {   // does not fit XCD by XCD: plain packing (teams may span two XCDs)
             int acc = 0;
