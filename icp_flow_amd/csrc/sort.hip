@@ -71,11 +71,7 @@ __device__ int fixed_axis(const ChunkSortParams &p, int b, float *bb, int *axisS
 {
     const Roles f = roles_of(p, b, 0);
     float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
-    for (int j = threadIdx.x; j < f.n; j += kCsBlock) {
-        const float4 q = f.cloud[j];
-        mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
-        mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
-    }
+    bbox_rows(f.cloud, f.n, false, mn, mx);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll

@@ -41,6 +41,25 @@ __device__ __forceinline__ VoteKey vote_key_load(const float *rec)
     return k;
 }
 
+// this thread's share of the bounding box of `n` rows (rows tid, tid + blockDim, ...; flagged rows only when `flagged`):
+// four rows in flight per thread -- a row at a time, the loop is one dependent chain of loads (min / max are exact in any
+// order)
+__device__ __forceinline__ void bbox_rows(const float4 *__restrict__ pts, int n, bool flagged, float (&mn)[3], float (&mx)[3])
+{
+    const int stride = (int)blockDim.x;
+    for (int j0 = (int)threadIdx.x; j0 < n; j0 += 4 * stride) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = pts[min(j0 + u * stride, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u * stride >= n || (flagged && !(q[u].w > 0.0f))) continue;
+            mn[0] = fminf(mn[0], q[u].x); mn[1] = fminf(mn[1], q[u].y); mn[2] = fminf(mn[2], q[u].z);
+            mx[0] = fmaxf(mx[0], q[u].x); mx[1] = fmaxf(mx[1], q[u].y); mx[2] = fmaxf(mx[2], q[u].z);
+        }
+    }
+}
+
 // Block-cooperative: bounding box of the valid rows of BOTH clouds -> key parameters (identical in every
 // block that calls it for the same pair).  scratch: 6 floats per wave of the block.
 __device__ inline VoteKey vote_key_params(const float4 *__restrict__ P, int nP, const float4 *__restrict__ Q,
@@ -52,12 +71,8 @@ __device__ inline VoteKey vote_key_params(const float4 *__restrict__ P, int nP, 
         return vote_key_load(result);
     }
     float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
-    for (int j = threadIdx.x; j < nP + nQ; j += blockDim.x) {
-        const float4 q = j < nP ? P[j] : Q[j - nP];
-        if (!(q.w > 0.0f)) continue;
-        mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
-        mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
-    }
+    bbox_rows(P, nP, true, mn, mx);
+    bbox_rows(Q, nQ, true, mn, mx);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
