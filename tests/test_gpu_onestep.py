@@ -192,3 +192,14 @@ def test_config4_sample_every_pair_one_step_from_the_oracle_state():
     """BASELINE config 4's shape: the first 64 pairs x 2048 points of rank 0's shard."""
     S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
     _one_step_conformance(S[:64], D[:64], 50, chunk=16)
+
+
+def test_ragged_team_batch_every_pair_one_step_from_the_oracle_state():
+    """The shape real frames present: a dozen ragged pairs, 300 ... 4000 points padded to 4000 -- few enough
+    for the ICP to run its large pairs as TEAMS of workgroups (several members per pair, partial moments exchanged every
+    iteration, long probes), with both role orders in the batch."""
+    S, D, _ = synthetic.make_batch(12, 4000, seed=11, ragged=True, n_min=300)
+    S[::4], D[::4] = D[::4].copy(), S[::4].copy()
+    ns, nd = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
+    assert (ns > nd).any() and (ns < nd).any() and max(ns.max(), nd.max()) > 2500
+    _one_step_conformance(S, D, 30, chunk=2)
