@@ -339,6 +339,49 @@ def test_certificates_on_adversarial_clouds_change_nothing():
     assert a1.converged.iterations == n0 and torch.equal(a1.RTs.R, R0)
 
 
+def _boxes_with_faces(B, N, seed):
+    """Axis-aligned boxes sampled on their surface with a THIRD of the points on the two faces perpendicular to the long
+    axis: hundreds of targets with exactly one coordinate along the ICP's sort axis (the case the long probes exist for,
+    icp.hip kProbeStepsLong).  Small yaw and translation, independently resampled destination."""
+    rng = np.random.default_rng(seed)
+    S = np.full((B, N, 4), 1e8, np.float32); D = np.full((B, N, 4), 1e8, np.float32)
+    S[:, :, 3] = D[:, :, 3] = 0.0
+    for b in range(B):
+        ext = np.array([rng.uniform(3.0, 5.0), rng.uniform(1.6, 2.2), rng.uniform(1.4, 2.0)])
+        centre = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), 0.8])
+        def sample(n):
+            p = rng.uniform(-0.5, 0.5, (n, 3)) * ext
+            face = rng.random(n) < 1.0 / 3.0
+            p[face, 0] = np.where(rng.random(face.sum()) < 0.5, -0.5, 0.5) * ext[0]        # the two end faces: exact coordinate
+            side = ~face
+            ax = rng.integers(1, 3, side.sum())
+            sgn = np.where(rng.random(side.sum()) < 0.5, -0.5, 0.5)
+            q = p[side]; q[np.arange(len(q)), ax] = sgn * ext[ax]; p[side] = q
+            return p
+        ns, nd = int(rng.integers(N // 2, N + 1)), int(rng.integers(N // 2, N + 1))
+        yaw = np.deg2rad(rng.uniform(-2, 2)); c, s_ = np.cos(yaw), np.sin(yaw)
+        R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+        t = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), 0.0])
+        S[b, :ns, :3] = sample(ns) + centre; S[b, :ns, 3] = 1.0
+        D[b, :nd, :3] = sample(nd) @ R.T + centre + t + rng.normal(0, 0.01, (nd, 3)); D[b, :nd, 3] = 1.0
+    return S, D
+
+
+@pytest.mark.parametrize("shape", ["two_per_cu_600x2048", "one_per_cu_200x3000", "teams_20x6000"])
+def test_long_probes_on_faces_perpendicular_to_the_sort_axis_change_nothing(shape):
+    """Clouds of several passes whose end faces hold hundreds of points with ONE coordinate along the sort axis: the
+    probes there need more than ten blocks to prove anything (kProbeStepsLong = 24).  Against the plain window scan
+    (`no_adaptive_windows`): transforms and iteration counts bit-identical, single workgroups, two per CU and teams."""
+    B, N = {"two_per_cu_600x2048": (600, 2048), "one_per_cu_200x3000": (200, 3000), "teams_20x6000": (20, 6000)}[shape]
+    S, D = _boxes_with_faces(B, N, seed=77)
+    a = rp.default_args(max_points=N, icp_max_iterations=40)
+    with _lib.options(no_adaptive_windows=True):
+        T0, it0 = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+    T1, it1 = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+    assert int(it0) == int(it1) and torch.equal(T0, T1)
+    assert torch.isfinite(T1).all()
+
+
 # ------------------------------------------------------------------------------------------ fused vote bins
 def _wide_pair(n, seed):
     """A wall: 24 m x 0.4 m x 2.6 m, n points -- wider than the 8 m above which the vote sorts by the composite
