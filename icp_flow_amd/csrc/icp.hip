@@ -842,7 +842,12 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 // previous neighbour and waves with many uncertified lanes take the window scan.
                 if (REC && recOn && it > itFirst) {
                     const bool longProbes = ngr > 1 || yc.n > 1024;   // (team members: one pass each, but of a long cloud)
-                    const int probeSteps = longProbes ? kProbeStepsLong : kProbeSteps, probeMax = longProbes ? kProbeMaxLong : kProbeMax;
+                    // (and every lane of the wave where the alternative is a scan of a long window of a long cloud: this wave's window
+                    // of the previous search held more than 512 targets -- a dense 10000-point cluster; on the ragged real-shape
+                    // batch the ICP launch 1.33 -> 0.94 ms; the demo frame's wall, long but thin, keeps its short windows and 32)
+                    const bool wideWindows = yc.n > 4096 && winHi - winLo > 512;
+                    const int probeSteps = longProbes ? kProbeStepsLong : kProbeSteps;
+                    const int probeMax = longProbes ? (wideWindows ? kWave : kProbeMaxLong) : kProbeMax;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const bool wants = live[q] && recM[q] >= 0.f && certJ[q] >= 0;
