@@ -412,6 +412,7 @@ def frame_pair_measurement(dev):
     G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     ps, pd = G(g["point_src"]), G(g["point_dst"])
     ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
+    ego = torch.eye(4, device=dev)                 # the ego pose: an input like the clouds (demo.py:217 passes the identity)
     res = {"data": "demo.npz frame pair of the reference, labels from the G8 fixture", "points": [len(ps), len(pd)]}
     for mp in (int(g["max_points"]), 10000):
         a = frame_pairs.default_args(max_points=mp)
@@ -419,7 +420,7 @@ def frame_pair_measurement(dev):
         def run():
             torch.manual_seed(0)
             pairs, Tm = utils_track.track(a, ps, pd, ls, ld)
-            return pairs, utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, torch.eye(4, device=dev))
+            return pairs, utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, ego)
 
         run()
         torch.cuda.synchronize(dev)

@@ -55,7 +55,10 @@ SIGNATURES = {
     "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "icpflow_cluster_table_workspace_bytes": (_sz, [_i, _i]),
     "icpflow_cluster_table": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _sz, _p]),
+    "icpflow_cluster_table_pair_workspace_bytes": (_sz, [_i, _i, _i]),
+    "icpflow_cluster_table_pair": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "icpflow_flow_rigid": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _sz, _p]),
+    "icpflow_flow_rigid_rows": (_i, [_p, _p, _i, _p, _i, _p, _i, _p, _p, _p]),
     "icpflow_dbscan_workspace_bytes": (_sz, [_i]),
     "icpflow_dbscan": (_i, [_p, _i, _p, _i, _d, _i, _p, _p, _p, _p, _sz, _p]),
     "icpflow_hdbscan_mst_workspace_bytes": (_sz, [_i]),

@@ -625,18 +625,56 @@ int icpflow_cluster_table(const float *d_points, const float *d_labels, int M, i
     return 0;
 }
 
-int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
-                       const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws, size_t ws_bytes,
-                       icpflow_stream_t stream)
+size_t icpflow_cluster_table_pair_workspace_bytes(int MA, int MB, int Lmax)
+{
+    if (MA <= 0 || MB <= 0 || Lmax <= 0 || (long long)MA + MB > 0x7fffffffll) return 0;
+    size_t bytes = 0;
+    if (cluster_table_pair_workspace_bytes(MA, MB, Lmax, &bytes) != hipSuccess) return 0;
+    return bytes;
+}
+
+int icpflow_cluster_table_pair(const float *d_points_a, const float *d_labels_a, int MA, int64_t *d_order_a, double *d_table_a,
+                               int32_t *d_num_a, const float *d_points_b, const float *d_labels_b, int MB,
+                               int64_t *d_order_b, double *d_table_b, int32_t *d_num_b, int Lmax, void *d_ws, size_t ws_bytes,
+                               icpflow_stream_t stream)
+{
+    if (!d_points_a || !d_labels_a || !d_order_a || !d_table_a || !d_num_a || !d_points_b || !d_labels_b || !d_order_b ||
+        !d_table_b || !d_num_b)
+        return fail(ICPFLOW_E_ARG, "icpflow_cluster_table_pair: null pointer");
+    if (MA <= 0 || MB <= 0) return fail(ICPFLOW_E_ARG, "icpflow_cluster_table_pair: MA, MB must be positive (got %d, %d)", MA, MB);
+    if ((long long)MA + MB > 0x7fffffffll)
+        return fail(ICPFLOW_E_LIMIT, "icpflow_cluster_table_pair: MA + MB must stay below 2^31 (got %d + %d)", MA, MB);
+    if (Lmax <= 0 || Lmax > 4096) return fail(ICPFLOW_E_LIMIT, "icpflow_cluster_table_pair: 1 <= Lmax <= 4096 (got %d)", Lmax);
+    if (!d_ws) return fail(ICPFLOW_E_WORKSPACE, "icpflow_cluster_table_pair: workspace is NULL");
+    bool tooSmall = false;
+    ICPFLOW_TRY(launch_cluster_table_pair(d_points_a, d_labels_a, MA, d_order_a, d_table_a, d_num_a, d_points_b, d_labels_b, MB,
+                                          d_order_b, d_table_b, d_num_b, Lmax, d_ws, ws_bytes, &tooSmall, (hipStream_t)stream));
+    if (tooSmall)
+        return fail(ICPFLOW_E_WORKSPACE, "icpflow_cluster_table_pair: workspace too small (%zu bytes, need %zu)", ws_bytes,
+                    icpflow_cluster_table_pair_workspace_bytes(MA, MB, Lmax));
+    return 0;
+}
+
+int icpflow_flow_rigid_rows(const float *d_points, const float *d_labels, int N, const float *d_pair_rows, int pair_stride,
+                            const float *d_T, int P, const float *d_pose, float *d_flow, icpflow_stream_t stream)
 {
     if (!d_points || !d_labels || !d_pose || !d_flow) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: null pointer");
     if (N <= 0) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: N must be positive");
     if (P < 0 || P > (1 << 24)) return fail(ICPFLOW_E_LIMIT, "icpflow_flow_rigid: 0 <= P <= 2^24 pairs (got %d)", P);
-    if (P > 0 && (!d_pair_labels || !d_T)) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: null pair arrays");
-    if (int r = check_ws(d_ws, ws_bytes, (size_t)(P + 1) * 16 * sizeof(float))) return r;
-    ICPFLOW_TRY(launch_flow_rigid(d_points, d_labels, N, d_pair_labels, d_T, P, d_pose, (float *)d_ws, d_flow,
-                                  (hipStream_t)stream));
+    if (P > 0 && (!d_pair_rows || !d_T)) return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: null pair arrays");
+    if (pair_stride < 1 || pair_stride > 1024)
+        return fail(ICPFLOW_E_ARG, "icpflow_flow_rigid: pair_stride must be in 1 ... 1024 floats (got %d)", pair_stride);
+    ICPFLOW_TRY(launch_flow_rigid(d_points, d_labels, N, d_pair_rows, pair_stride, d_T, P, d_pose, d_flow, (hipStream_t)stream));
     return 0;
+}
+
+int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
+                       const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws, size_t ws_bytes,
+                       icpflow_stream_t stream)
+{
+    (void)d_ws;        // (the products T[p] * pose are formed per point since version 204: no scratch)
+    (void)ws_bytes;
+    return icpflow_flow_rigid_rows(d_points, d_labels, N, d_pair_labels, 1, d_T, P, d_pose, d_flow, stream);
 }
 
 int icpflow_count_valid(const float *d_pts, int B, int N, int32_t *d_len, icpflow_stream_t stream)

@@ -1869,6 +1869,11 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
 // Team sizes for one launch: every pair gets one workgroup, the spare ones go to the pairs whose
 // moving cloud needs more than one pass of a workgroup (768 queries), in proportion to the excess;
 // a member keeps at least 256 queries.  One block; B <= 256.
+#ifndef ICPFLOW_TEAM_MIN_SHARE
+#define ICPFLOW_TEAM_MIN_SHARE 256
+#endif
+constexpr int kTeamMinShare = ICPFLOW_TEAM_MIN_SHARE;   // queries per member, at least
+
 __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__restrict__ lenX,
                                                             const int32_t *__restrict__ lenY,
                                                             const uint8_t *__restrict__ swap, int B, IcpTeam t)
@@ -1894,7 +1899,7 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     if (b < B) {
         const long long spare = t.maxWG - B;
         G = 1 + (total > 0 ? (int)(spare * size[b] / total) : 0);
-        G = min(G, min(kMaxTeam, max(1, (n + 255) / 256)));
+        G = min(G, min(kMaxTeam, max(1, (n + kTeamMinShare - 1) / kTeamMinShare)));
     }
     __syncthreads();
     size[b] = G;

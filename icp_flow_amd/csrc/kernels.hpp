@@ -259,14 +259,19 @@ hipError_t launch_gather_segments(const float *points, const int64_t *order, con
 hipError_t launch_cluster_stats(const float *points, const int64_t *order, const int64_t *start,
                                 const int64_t *count, const float *labels, int L, float *mean, float *extent,
                                 hipStream_t s);
-hipError_t launch_flow_rigid(const float *points, const float *labels, int N, const float *pairLabels,
-                             const float *T, int P, const float *pose, float *M, float *flow, hipStream_t s);
+hipError_t launch_flow_rigid(const float *points, const float *labels, int N, const float *pairRows, int pairStride,
+                             const float *T, int P, const float *pose, float *flow, hipStream_t s);
 hipError_t launch_transform_points(const float *xyz, const float *pose, int B, int N, float *out,
                                    hipStream_t s);
 
 
 // table.hip: the cluster table of a labelled cloud (rows sorted by label, distinct labels, per-cluster statistics)
 hipError_t cluster_table_workspace_bytes(int M, int Lmax, size_t *bytes);
+hipError_t cluster_table_pair_workspace_bytes(int MA, int MB, int Lmax, size_t *bytes);
+hipError_t launch_cluster_table_pair(const float *pointsA, const float *labelsA, int MA, int64_t *orderA, double *tableA,
+                                     int32_t *numA, const float *pointsB, const float *labelsB, int MB, int64_t *orderB,
+                                     double *tableB, int32_t *numB, int Lmax, void *ws, size_t wsBytes, bool *wsTooSmall,
+                                     hipStream_t s);
 hipError_t launch_cluster_table(const float *points, const float *labels, int M, int64_t *order, double *table, int Lmax,
                                 int32_t *num, void *ws, size_t wsBytes, bool *wsTooSmall, hipStream_t s);
 

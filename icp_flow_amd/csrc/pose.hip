@@ -372,31 +372,17 @@ hipError_t launch_cluster_stats(const float *points, const int64_t *order, const
     return hipGetLastError();
 }
 
-// M[p] = T[p] * pose for p < P, M[P] = pose (points of unmatched clusters move with the ego pose
-// only: T_per_point starts as the identity, utils_flow.py:62-65); fp32 bmm order
-__global__ void flow_compose_kernel(const float *__restrict__ T, const float *__restrict__ pose, int P,
-                                    float *__restrict__ M)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > P) return;
-    float A[16];
-    for (int k = 0; k < 16; ++k) A[k] = (p < P) ? T[(size_t)p * 16 + k] : ((k % 5 == 0) ? 1.f : 0.f);
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            float acc = A[i * 4 + 0] * pose[0 * 4 + j];
-            acc = fmaf(A[i * 4 + 1], pose[1 * 4 + j], acc);
-            acc = fmaf(A[i * 4 + 2], pose[2 * 4 + j], acc);
-            acc = fmaf(A[i * 4 + 3], pose[3 * 4 + j], acc);
-            M[(size_t)p * 16 + i * 4 + j] = acc;
-        }
-}
-
 constexpr int kFlowBlock = 256;
 constexpr int kFlowTile = 2048;   // pair labels cached in LDS, one tile at a time (any number of pairs)
 
+// Every point looks its label up among the matched source labels (pairRows[p * pairStride]: a column of the [P,10] pair
+// rows, or a plain array) and moves with M = T[p] * pose, a point of an unmatched cluster with M = I * pose (T_per_point
+// starts as the identity, utils_flow.py:62-65); the product is formed per point, in the fp32 order of the bmm -- one
+// launch, no scratch
 __global__ __launch_bounds__(kFlowBlock) void flow_rigid_kernel(
     const float *__restrict__ points, const float *__restrict__ labels, int N,
-    const float *__restrict__ pairLabels, int P, const float *__restrict__ M, float *__restrict__ flow)
+    const float *__restrict__ pairRows, int pairStride, int P, const float *__restrict__ T,
+    const float *__restrict__ pose, float *__restrict__ flow)
 {
     __shared__ float lab[kFlowTile];
     const int i = blockIdx.x * kFlowBlock + threadIdx.x;
@@ -405,13 +391,27 @@ __global__ __launch_bounds__(kFlowBlock) void flow_rigid_kernel(
     for (int k0 = 0; k0 < P; k0 += kFlowTile) {
         const int kn = min(kFlowTile, P - k0);
         if (k0 > 0) __syncthreads();
-        for (int k = threadIdx.x; k < kn; k += kFlowBlock) lab[k] = pairLabels[k0 + k];
+        for (int k = threadIdx.x; k < kn; k += kFlowBlock) lab[k] = pairRows[(size_t)(k0 + k) * pairStride];
         __syncthreads();
         for (int k = 0; k < kn; ++k)
             if (lab[k] == l) p = k0 + k;         // pairs[:,0] holds each source label at most once
     }
     if (i >= N) return;
-    const float *m = M + (size_t)p * 16;
+    float m[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = (p < P) ? T[(size_t)p * 16 + r * 4 + k] : ((k == r) ? 1.f : 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = a[0] * pose[0 * 4 + c];
+            acc = fmaf(a[1], pose[1 * 4 + c], acc);
+            acc = fmaf(a[2], pose[2 * 4 + c], acc);
+            acc = fmaf(a[3], pose[3 * 4 + c], acc);
+            m[r * 4 + c] = acc;
+        }
+    }
     const float x = points[(size_t)i * 3 + 0], y = points[(size_t)i * 3 + 1], z = points[(size_t)i * 3 + 2];
     // (T pose [x y z 1]^T)[0:3] - p, utils_flow.py:67-68
     flow[(size_t)i * 3 + 0] = fmaf(1.f, m[3], fmaf(z, m[2], fmaf(y, m[1], x * m[0]))) - x;
@@ -419,12 +419,11 @@ __global__ __launch_bounds__(kFlowBlock) void flow_rigid_kernel(
     flow[(size_t)i * 3 + 2] = fmaf(1.f, m[11], fmaf(z, m[10], fmaf(y, m[9], x * m[8]))) - z;
 }
 
-hipError_t launch_flow_rigid(const float *points, const float *labels, int N, const float *pairLabels,
-                             const float *T, int P, const float *pose, float *M, float *flow, hipStream_t s)
+hipError_t launch_flow_rigid(const float *points, const float *labels, int N, const float *pairRows, int pairStride,
+                             const float *T, int P, const float *pose, float *flow, hipStream_t s)
 {
-    hipLaunchKernelGGL(flow_compose_kernel, dim3((P + 1 + 127) / 128), dim3(128), 0, s, T, pose, P, M);
     hipLaunchKernelGGL(flow_rigid_kernel, dim3((N + kFlowBlock - 1) / kFlowBlock), dim3(kFlowBlock), 0, s, points,
-                       labels, N, pairLabels, P, M, flow);
+                       labels, N, pairRows, pairStride, P, T, pose, flow);
     return hipGetLastError();
 }
 

@@ -37,36 +37,59 @@ __device__ __forceinline__ float unsortable(uint32_t k)
     return __int_as_float((int)u);
 }
 
-__global__ __launch_bounds__(kTableBlock) void table_key_kernel(const float *__restrict__ labels, int M,
-                                                                uint32_t *__restrict__ key, uint32_t *__restrict__ val,
-                                                                int *__restrict__ counter)
+// One chain serves one labelled cloud (32-bit keys) or the TWO clouds of a frame pair at once (64-bit keys: the cloud's
+// number above the label's 32 bits, so that one sort leaves cloud 0's rows in front of cloud 1's): half as many launches
+// on the path of a frame pair, where every launch of the chain is a few microseconds of work behind a dispatch.
+struct TableSides {
+    const float *points[2];
+    const float *labels[2];
+    int M[2];              // rows of each cloud (M[1] = 0: one cloud)
+    int64_t *order[2];
+    double *table[2];
+    int32_t *num[2];
+    int *bnd[2];
+    int *counter;          // [2]
+};
+
+template <typename KeyT>
+__global__ __launch_bounds__(kTableBlock) void table_key_kernel(TableSides t, KeyT *__restrict__ key,
+                                                                uint32_t *__restrict__ val)
 {
     const int i = blockIdx.x * kTableBlock + threadIdx.x;
-    if (i == 0) *counter = 0;
-    if (i < M) { key[i] = sortable(labels[i]); val[i] = (uint32_t)i; }
+    if (i < 2) t.counter[i] = 0;
+    if (i >= t.M[0] + t.M[1]) return;
+    const int side = i >= t.M[0] ? 1 : 0, local = i - (side ? t.M[0] : 0);
+    KeyT k = (KeyT)sortable(t.labels[side][local]);
+    if constexpr (sizeof(KeyT) == 8) k |= (KeyT)side << 32;
+    key[i] = k;
+    val[i] = (uint32_t)local;
 }
 
-__global__ __launch_bounds__(kTableBlock) void table_boundary_kernel(const uint32_t *__restrict__ key,
-                                                                     const uint32_t *__restrict__ val, int M,
-                                                                     int64_t *__restrict__ order, int *__restrict__ bnd,
-                                                                     int *__restrict__ counter, int Lmax)
+template <typename KeyT>
+__global__ __launch_bounds__(kTableBlock) void table_boundary_kernel(TableSides t, const KeyT *__restrict__ key,
+                                                                     const uint32_t *__restrict__ val, int Lmax)
 {
     const int i = blockIdx.x * kTableBlock + threadIdx.x;
-    if (i >= M) return;
-    order[i] = (int64_t)val[i];
-    if (i == 0 || key[i] != key[i - 1]) {
-        const int slot = atomicAdd(counter, 1);
-        if (slot < Lmax) bnd[slot] = i;
+    if (i >= t.M[0] + t.M[1]) return;
+    const int side = i >= t.M[0] ? 1 : 0, local = i - (side ? t.M[0] : 0);
+    t.order[side][local] = (int64_t)val[i];
+    if (local == 0 || key[i] != key[i - 1]) {
+        const int slot = atomicAdd(&t.counter[side], 1);
+        if (slot < Lmax) t.bnd[side][slot] = local;
     }
 }
 
-// one workgroup: the boundaries in ascending order -> (label, count, start) of every cluster
-__global__ __launch_bounds__(kRowsBlock) void table_rows_kernel(const uint32_t *__restrict__ key, int M,
-                                                                const int *__restrict__ bnd, const int *__restrict__ counter,
-                                                                int Lmax, double *__restrict__ table, int32_t *__restrict__ num)
+// one workgroup per cloud: the boundaries in ascending order -> (label, count, start) of every cluster
+template <typename KeyT>
+__global__ __launch_bounds__(kRowsBlock) void table_rows_kernel(TableSides t, const KeyT *__restrict__ keyAll, int Lmax)
 {
     extern __shared__ int sb[];
-    const int found = *counter;
+    const int side = blockIdx.x;
+    const KeyT *key = keyAll + (side ? t.M[0] : 0);
+    const int M = t.M[side];
+    const int *bnd = t.bnd[side];
+    double *table = t.table[side];
+    const int found = t.counter[side];
     const int n = min(found, Lmax);
     int P = 1;
     while (P < n) P <<= 1;
@@ -74,8 +97,8 @@ __global__ __launch_bounds__(kRowsBlock) void table_rows_kernel(const uint32_t *
     __syncthreads();
     for (int len = 2; len <= P; len <<= 1)
         for (int stride = len >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < P / 2; t += kRowsBlock) {
-                const int lo = (t / stride) * 2 * stride + (t % stride), hi = lo + stride;
+            for (int u = threadIdx.x; u < P / 2; u += kRowsBlock) {
+                const int lo = (u / stride) * 2 * stride + (u % stride), hi = lo + stride;
                 const bool up = ((lo & len) == 0);
                 const int a = sb[lo], b = sb[hi];
                 if ((a > b) == up) { sb[lo] = b; sb[hi] = a; }
@@ -85,23 +108,24 @@ __global__ __launch_bounds__(kRowsBlock) void table_rows_kernel(const uint32_t *
     for (int c = threadIdx.x; c < n; c += kRowsBlock) {
         const int start = sb[c], end = (c + 1 < n) ? sb[c + 1] : M;
         double *row = table + (size_t)c * kTableCols;
-        row[0] = (double)unsortable(key[start]);
+        row[0] = (double)unsortable((uint32_t)key[start]);
         row[1] = (double)(end - start);
         row[2] = (double)start;
     }
-    if (threadIdx.x == 0) *num = found <= Lmax ? found : -found;   // < 0: more clusters than the table holds
+    if (threadIdx.x == 0) *t.num[side] = found <= Lmax ? found : -found;   // < 0: more clusters than the table holds
 }
 
 // one workgroup per cluster: centroid (fp64 sums) and sorted bounding-box extents; clusters with a negative label
 // (ground, noise: never candidates, utils_check.py:32 -- and by far the largest "clusters" of a frame) report zeros
-__global__ __launch_bounds__(kRowsBlock) void table_stats_kernel(const float *__restrict__ points,
-                                                                 const int64_t *__restrict__ order,
-                                                                 const int32_t *__restrict__ num, double *__restrict__ table)
+__global__ __launch_bounds__(kRowsBlock) void table_stats_kernel(TableSides t)
 {
     __shared__ double ssum[kRowsBlock / kWave][3];
     __shared__ float smin[kRowsBlock / kWave][3], smax[kRowsBlock / kWave][3];
-    const int c = blockIdx.x;
-    const int n_clusters = *num;
+    const int c = blockIdx.x, side = blockIdx.y;
+    const float *points = t.points[side];
+    const int64_t *order = t.order[side];
+    double *table = t.table[side];
+    const int n_clusters = *t.num[side];
     if (c >= n_clusters) return;   // (also when the table overflowed: num < 0)
     double *row = table + (size_t)c * kTableCols;
     const int64_t n = (int64_t)row[1], s0 = (int64_t)row[2];
@@ -154,17 +178,27 @@ __global__ __launch_bounds__(kRowsBlock) void table_stats_kernel(const float *__
 }
 
 struct TableCarve {
-    uint32_t *keyIn, *keyOut, *valIn, *valOut;
-    int *bnd, *counter;
+    void *keyIn, *keyOut;
+    uint32_t *valIn, *valOut;
+    int *bnd[2], *counter;
     void *sortTmp;
     size_t sortTmpBytes, total;
 };
 
+template <typename KeyT>
+hipError_t table_sort(void *tmp, size_t &tmpBytes, const TableCarve *c, size_t M, hipStream_t s)
+{
+    // (two clouds: 33 key bits -- the label's 32 and the cloud's number)
+    return rocprim::radix_sort_pairs(tmp, tmpBytes, c ? (KeyT *)c->keyIn : (KeyT *)nullptr, c ? (KeyT *)c->keyOut : (KeyT *)nullptr,
+                                     c ? c->valIn : (uint32_t *)nullptr, c ? c->valOut : (uint32_t *)nullptr, M, 0,
+                                     sizeof(KeyT) == 8 ? 33 : 32, s);
+}
+
+template <typename KeyT>
 hipError_t table_carve(int M, int Lmax, void *ws, TableCarve *c, hipStream_t s)
 {
     size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                             (uint32_t *)nullptr, (size_t)M, 0, 32, s);
+    hipError_t e = table_sort<KeyT>(nullptr, tmp, nullptr, (size_t)M, s);
     if (e != hipSuccess) return e;
     char *p = (char *)ws;
     size_t off = 0;
@@ -173,11 +207,12 @@ hipError_t table_carve(int M, int Lmax, void *ws, TableCarve *c, hipStream_t s)
         off += (bytes + 255) / 256 * 256;
         return q;
     };
-    c->keyIn = (uint32_t *)take((size_t)M * 4);
-    c->keyOut = (uint32_t *)take((size_t)M * 4);
+    c->keyIn = take((size_t)M * sizeof(KeyT));
+    c->keyOut = take((size_t)M * sizeof(KeyT));
     c->valIn = (uint32_t *)take((size_t)M * 4);
     c->valOut = (uint32_t *)take((size_t)M * 4);
-    c->bnd = (int *)take((size_t)Lmax * 4);
+    c->bnd[0] = (int *)take((size_t)Lmax * 4);
+    c->bnd[1] = (int *)take((size_t)Lmax * 4);
     c->counter = (int *)take(256);
     c->sortTmp = take(tmp);
     c->sortTmpBytes = tmp;
@@ -185,12 +220,44 @@ hipError_t table_carve(int M, int Lmax, void *ws, TableCarve *c, hipStream_t s)
     return hipSuccess;
 }
 
+template <typename KeyT>
+hipError_t table_chain(TableSides t, int Lmax, void *ws, size_t wsBytes, bool *wsTooSmall, hipStream_t s)
+{
+    const int M = t.M[0] + t.M[1], sides = t.M[1] > 0 ? 2 : 1;
+    TableCarve c{};
+    hipError_t e = table_carve<KeyT>(M, Lmax, ws, &c, s);
+    if (e != hipSuccess) return e;
+    *wsTooSmall = wsBytes < c.total;
+    if (*wsTooSmall) return hipSuccess;
+    t.bnd[0] = c.bnd[0];
+    t.bnd[1] = c.bnd[1];
+    t.counter = c.counter;
+    const int blocks = (M + kTableBlock - 1) / kTableBlock;
+    table_key_kernel<KeyT><<<blocks, kTableBlock, 0, s>>>(t, (KeyT *)c.keyIn, c.valIn);
+    e = table_sort<KeyT>(c.sortTmp, c.sortTmpBytes, &c, (size_t)M, s);
+    if (e != hipSuccess) return e;
+    table_boundary_kernel<KeyT><<<blocks, kTableBlock, 0, s>>>(t, (const KeyT *)c.keyOut, c.valOut, Lmax);
+    int P = 1;
+    while (P < Lmax) P <<= 1;
+    table_rows_kernel<KeyT><<<sides, kRowsBlock, (size_t)P * sizeof(int), s>>>(t, (const KeyT *)c.keyOut, Lmax);
+    table_stats_kernel<<<dim3(Lmax, sides), kRowsBlock, 0, s>>>(t);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t cluster_table_workspace_bytes(int M, int Lmax, size_t *bytes)
 {
     TableCarve c{};
-    const hipError_t e = table_carve(M, Lmax, nullptr, &c, nullptr);
+    const hipError_t e = table_carve<uint32_t>(M, Lmax, nullptr, &c, nullptr);
+    *bytes = c.total;
+    return e;
+}
+
+hipError_t cluster_table_pair_workspace_bytes(int MA, int MB, int Lmax, size_t *bytes)
+{
+    TableCarve c{};
+    const hipError_t e = table_carve<uint64_t>(MA + MB, Lmax, nullptr, &c, nullptr);
     *bytes = c.total;
     return e;
 }
@@ -198,21 +265,20 @@ hipError_t cluster_table_workspace_bytes(int M, int Lmax, size_t *bytes)
 hipError_t launch_cluster_table(const float *points, const float *labels, int M, int64_t *order, double *table, int Lmax,
                                 int32_t *num, void *ws, size_t wsBytes, bool *wsTooSmall, hipStream_t s)
 {
-    TableCarve c{};
-    hipError_t e = table_carve(M, Lmax, ws, &c, s);
-    if (e != hipSuccess) return e;
-    *wsTooSmall = wsBytes < c.total;
-    if (*wsTooSmall) return hipSuccess;
-    const int blocks = (M + kTableBlock - 1) / kTableBlock;
-    table_key_kernel<<<blocks, kTableBlock, 0, s>>>(labels, M, c.keyIn, c.valIn, c.counter);
-    e = rocprim::radix_sort_pairs(c.sortTmp, c.sortTmpBytes, c.keyIn, c.keyOut, c.valIn, c.valOut, (size_t)M, 0, 32, s);
-    if (e != hipSuccess) return e;
-    table_boundary_kernel<<<blocks, kTableBlock, 0, s>>>(c.keyOut, c.valOut, M, order, c.bnd, c.counter, Lmax);
-    int P = 1;
-    while (P < Lmax) P <<= 1;
-    table_rows_kernel<<<1, kRowsBlock, (size_t)P * sizeof(int), s>>>(c.keyOut, M, c.bnd, c.counter, Lmax, table, num);
-    table_stats_kernel<<<Lmax, kRowsBlock, 0, s>>>(points, order, num, table);
-    return hipGetLastError();
+    TableSides t{};
+    t.points[0] = points; t.labels[0] = labels; t.M[0] = M; t.order[0] = order; t.table[0] = table; t.num[0] = num;
+    return table_chain<uint32_t>(t, Lmax, ws, wsBytes, wsTooSmall, s);
+}
+
+hipError_t launch_cluster_table_pair(const float *pointsA, const float *labelsA, int MA, int64_t *orderA, double *tableA,
+                                     int32_t *numA, const float *pointsB, const float *labelsB, int MB, int64_t *orderB,
+                                     double *tableB, int32_t *numB, int Lmax, void *ws, size_t wsBytes, bool *wsTooSmall,
+                                     hipStream_t s)
+{
+    TableSides t{};
+    t.points[0] = pointsA; t.labels[0] = labelsA; t.M[0] = MA; t.order[0] = orderA; t.table[0] = tableA; t.num[0] = numA;
+    t.points[1] = pointsB; t.labels[1] = labelsB; t.M[1] = MB; t.order[1] = orderB; t.table[1] = tableB; t.num[1] = numB;
+    return table_chain<uint64_t>(t, Lmax, ws, wsBytes, wsTooSmall, s);
 }
 
 }  // namespace icpflow

@@ -30,7 +30,7 @@ class ClusterTable:
              utils_helper.py:166-170); both zero for negative labels (ground, noise: never candidates, :32)
     """
 
-    def __init__(self, points, labels, fetch=True, _buffer=None):
+    def __init__(self, points, labels, fetch=True, _buffer=None, _launch=True):
         _lib.require_gpu(points, labels)
         self.points = points[:, 0:3].contiguous().float()
         self.labels = labels
@@ -40,10 +40,11 @@ class ClusterTable:
         self.order = torch.empty((M,), dtype=torch.int64, device=dev)
         # one buffer: [0] holds the int32 number of clusters (first four bytes), [1:] the float64 table [TABLE_ROWS, 9]
         self._packed = _buffer if _buffer is not None else torch.empty((1 + TABLE_ROWS * 9,), dtype=torch.float64, device=dev)
-        ws = _lib.workspace(dev, int(_lib._L.icpflow_cluster_table_workspace_bytes(M, TABLE_ROWS)))
-        _lib.call("icpflow_cluster_table", _lib.ptr(self.points), _lib.ptr(lab), M, _lib.ptr(self.order),
-                  self._packed.data_ptr() + 8, TABLE_ROWS, _lib.ptr(self._packed), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
         self._lab = lab
+        if _launch:
+            ws = _lib.workspace(dev, int(_lib._L.icpflow_cluster_table_workspace_bytes(M, TABLE_ROWS)))
+            _lib.call("icpflow_cluster_table", _lib.ptr(self.points), _lib.ptr(lab), M, _lib.ptr(self.order),
+                      self._packed.data_ptr() + 8, TABLE_ROWS, _lib.ptr(self._packed), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
         if fetch:
             self.fetch()
 
@@ -90,10 +91,17 @@ class ClusterTable:
 
     @staticmethod
     def pair(src_points, src_labels, dst_points, dst_labels, fetch=True):
-        """Both tables of a frame pair in ONE buffer: one device -> host transfer for the two."""
+        """Both tables of a frame pair from ONE chain of launches (icpflow_cluster_table_pair) into ONE buffer: one
+        device -> host transfer for the two."""
         both = torch.empty((2, 1 + TABLE_ROWS * 9), dtype=torch.float64, device=src_labels.device)
-        st = ClusterTable(src_points, src_labels, fetch=False, _buffer=both[0])
-        dt = ClusterTable(dst_points, dst_labels, fetch=False, _buffer=both[1])
+        st = ClusterTable(src_points, src_labels, fetch=False, _buffer=both[0], _launch=False)
+        dt = ClusterTable(dst_points, dst_labels, fetch=False, _buffer=both[1], _launch=False)
+        MA, MB = int(st._lab.shape[0]), int(dt._lab.shape[0])
+        dev = src_labels.device
+        ws = _lib.workspace(dev, int(_lib._L.icpflow_cluster_table_pair_workspace_bytes(MA, MB, TABLE_ROWS)))
+        _lib.call("icpflow_cluster_table_pair", _lib.ptr(st.points), _lib.ptr(st._lab), MA, _lib.ptr(st.order),
+                  both[0].data_ptr() + 8, _lib.ptr(both[0]), _lib.ptr(dt.points), _lib.ptr(dt._lab), MB, _lib.ptr(dt.order),
+                  both[1].data_ptr() + 8, _lib.ptr(both[1]), TABLE_ROWS, _lib.ptr(ws), ws.numel(), _lib.stream(dev))
         st._both = both
         if fetch:
             host = both.cpu().numpy()

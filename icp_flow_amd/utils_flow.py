@@ -15,11 +15,16 @@ def flow_estimation_torch(args, src_points, dst_points, src_labels, dst_labels, 
     N = pts.shape[0]
     P = int(pairs.shape[0])
     lab = src_labels.contiguous().float()
-    pair_lab = pairs[:, 0].to(dev).contiguous().float() if P else None
-    T = transformations.to(dev).contiguous().float() if P else None
-    pose = pose.to(dev).contiguous().float()
     flow = torch.empty((N, 3), dtype=torch.float32, device=dev)
-    ws = _lib.workspace(dev, (P + 1) * 64)
-    _lib.call("icpflow_flow_rigid", _lib.ptr(pts), _lib.ptr(lab), N, _lib.ptr(pair_lab), _lib.ptr(T), P,
-              _lib.ptr(pose), _lib.ptr(flow), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
+    if P:
+        # the matched source labels are read in place: column 0 of the float32 pair rows (no slice kernel)
+        rows = pairs if (pairs.device == dev and pairs.dtype == torch.float32 and pairs.dim() == 2 and pairs.stride(1) == 1
+                         and 1 <= pairs.stride(0) <= 1024) else pairs[:, 0:1].to(dev).contiguous().float()
+        stride = int(rows.stride(0)) if rows.shape[1] > 1 else 1
+        T = transformations.to(dev).contiguous().float()
+    else:
+        rows, stride, T = None, 1, None
+    pose = pose.to(dev).contiguous().float()
+    _lib.call("icpflow_flow_rigid_rows", _lib.ptr(pts), _lib.ptr(lab), N, _lib.ptr(rows), stride, _lib.ptr(T), P,
+              _lib.ptr(pose), _lib.ptr(flow), _lib.stream(dev))
     return flow

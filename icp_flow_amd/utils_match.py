@@ -1,4 +1,6 @@
 """Drop-ins for the registration entry points of the reference's utils_match.py."""
+import ctypes
+
 import numpy as np
 import torch
 
@@ -34,7 +36,6 @@ def hist_icp_many(args, srcs, dsts, return_iterations=False):
     its own batch-global ICP stop and returns exactly what `hist_icp` returns for it; the library overlaps the tail of
     one batch's ICP launch with the vote and scoring of the others on internal streams forked from / joined into the
     current stream.  srcs, dsts: sequences of float32 [B_k, max_points, 4] -> list of [B_k,4,4] (and of iteration counts)."""
-    import ctypes
     K = len(srcs)
     assert K == len(dsts) and K > 0
     ss = [_lib.cloud(x, "src") for x in srcs]
@@ -78,11 +79,14 @@ def match_eval(args, pcd1, pcd2, transformations):
     return o2[0], o2[1], o2[2], o2[3], o3[0], o3[1]
 
 
-def hist_icp_eval(args, src, dst, return_iterations=False):
-    """`hist_icp(args, src, dst)` and `match_eval(args, src, dst, T)` of its result in ONE call (icpflow_hist_icp_eval):
-    what match_pairs does for every batch of candidate pairs (utils_match.py:92-93).  Same numbers as the two calls;
-    the metrics reuse the valid-row counts and the sorted clouds the registration leaves in its workspace.
-    -> (T [B,4,4], (errors, inliers, ratios, ious [B,2], translations, rotations [B,3])[, iterations])."""
+# layout of the flat result buffer of one hist_icp_eval call: float32 offsets in units of B (transforms 16, errors,
+# inliers, ratios, ious 2 each, translations, rotations 3 each), then ONE int32: the iteration count
+_EVAL_COLS = (0, 16, 18, 20, 22, 24, 27, 30)
+
+
+def _hist_icp_eval_flat(args, src, dst):
+    """icpflow_hist_icp_eval with every result in ONE float32 buffer [30 B + 1] (array after array, the iteration count
+    as the last word): one allocation, and one transfer for a caller that wants the numbers on the host."""
     s = _lib.cloud(src, "src")
     d = _lib.cloud(dst, "dst")
     assert s.shape == d.shape, "src and dst must share [B, max_points, 4]"
@@ -91,17 +95,35 @@ def hist_icp_eval(args, src, dst, return_iterations=False):
     ex, ey, ez = bin_edges(args, dev)
     lens = (len(ex), len(ey), len(ez))
     max_it, rel, stop = _icp_options(args)
-    out = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
-    iters = torch.empty((1,), dtype=torch.int32, device=dev)
-    o2 = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(4)]
-    o3 = [torch.empty((B, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    flat = torch.empty((30 * B + 1,), dtype=torch.float32, device=dev)
+    base = flat.data_ptr()
+    at = [ctypes.c_void_p(base + 4 * B * c) for c in _EVAL_COLS]
     _lib.check_vote_bins(B, lens)
     ws = _lib.workspace(dev, _lib.workspace_bytes(B, N, lens))
     _lib.call("icpflow_hist_icp_eval", _lib.ptr(s), _lib.ptr(d), B, N, _lib.ptr(ex), lens[0], _lib.ptr(ey),
               lens[1], _lib.ptr(ez), lens[2], float(args.thres_dist // 2), float(args.thres_dist), max_it,
-              rel, stop, _lib.ptr(out), _lib.ptr(iters), _lib.ptr(o2[0]), _lib.ptr(o2[1]), _lib.ptr(o2[2]),
-              _lib.ptr(o2[3]), _lib.ptr(o3[0]), _lib.ptr(o3[1]), _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())
-    ev = (o2[0], o2[1], o2[2], o2[3], o3[0], o3[1])
+              rel, stop, at[0], at[7], at[1], at[2], at[3], at[4], at[5], at[6], _lib.ptr(ws), ws.numel(),
+              _lib.stream(dev), _lib.opt())
+    return flat, B
+
+
+def _eval_views(r, B):
+    """The arrays of a flat result buffer (device tensor or host numpy array): T [B,4,4], the six metric arrays, iterations [1]."""
+    c = _EVAL_COLS
+    part = [r[B * c[k]: B * c[k + 1]] for k in range(7)]
+    shapes = [(B, 4, 4), (B, 2), (B, 2), (B, 2), (B, 2), (B, 3), (B, 3)]
+    arrs = [x.reshape(sh) for x, sh in zip(part, shapes)]
+    iters = r[30 * B:].view(torch.int32 if isinstance(r, torch.Tensor) else np.int32)
+    return arrs[0], tuple(arrs[1:]), iters
+
+
+def hist_icp_eval(args, src, dst, return_iterations=False):
+    """`hist_icp(args, src, dst)` and `match_eval(args, src, dst, T)` of its result in ONE call (icpflow_hist_icp_eval):
+    what match_pairs does for every batch of candidate pairs (utils_match.py:92-93).  Same numbers as the two calls;
+    the metrics reuse the valid-row counts and the sorted clouds the registration leaves in its workspace.
+    -> (T [B,4,4], (errors, inliers, ratios, ious [B,2], translations, rotations [B,3])[, iterations])."""
+    flat, B = _hist_icp_eval_flat(args, src, dst)
+    out, ev, iters = _eval_views(flat, B)
     return (out, ev, iters) if return_iterations else (out, ev)
 
 
@@ -112,34 +134,48 @@ def hist_icp_eval(args, src, dst, return_iterations=False):
 # hist_icp, match_eval.  Everything else -- candidate lists, sanity_check, the reject test, the S x D
 # matrices and the row arg-min -- involves a few hundred numbers and runs on the host copy of the
 # cluster tables (utils_check.ClusterTable) in numpy; a stage costs ONE device -> host transfer of the
-# [B, 29] results instead of the reference's per-pair scalar reads.
+# 30 B + 1 result words instead of the reference's per-pair scalar reads.
 # --------------------------------------------------------------------------------------
 def _gather_pair_batches(args, st, dt, si, di):
     """pad_segment (utils_helper.py:185-196) of the candidate clusters (rows si / di of the tables), one
-    kernel per cloud: -> two [B, max_points, 4] device tensors.  Over-long clusters are subsampled with
+    kernel per cloud: -> two [B, width, 4] device tensors (width: see below).  Over-long clusters are subsampled with
     torch.randperm on the host generator (or `args.generator`, a torch.Generator private to the caller, so that
     frame pairs registered concurrently do not share a stream of draws), src then dst, pair by pair -- the
     reference's stream of draws
     (utils_match.py:84-89, utils_helper.py:198-201)."""
-    N = int(args.max_points)
     dev = st.points.device
     B = len(si)
     cs, cd = st.h_count[si], dt.h_count[di]
-    seg = np.empty((2, 3, B), dtype=np.int64)
-    seg[0, 0], seg[0, 1], seg[0, 2] = st.h_start[si], np.minimum(cs, N), -1
-    seg[1, 0], seg[1, 1], seg[1, 2] = dt.h_start[di], np.minimum(cd, N), -1
-    perms = []
-    for k in np.nonzero((cs > N) | (cd > N))[0]:            # random_choice, utils_helper.py:198-201
+    # Padded to the longest cluster of THIS batch (in steps of 64 rows), max_points at most: padding rows carry flag 0 and
+    # no entry point reads them, so the registrations are those of the max_points-wide batch (the sums of a pair follow
+    # the shape of the workgroups that serve it: agreement to rounding, not to the bit) -- but every sort, vote and scan
+    # of the stage is sized by the width.  Stage 2 of a frame pair holds the small clusters stage 1 left over: 12 pairs of
+    # <= 540 points at max_points 10000 on the demo frame.
+    N = int(args.max_points)
+    cap = N                                                  # (clusters above it are subsampled to exactly max_points)
+    N = min(N, max(64, (int(max(cs.max(), cd.max())) + 63) // 64 * 64)) if getattr(args, "tight_padding", True) else N
+    over = np.nonzero((cs > cap) | (cd > cap))[0]
+    n_perm = int((cs[over] > cap).sum() + (cd[over] > cap).sum())
+    # ONE upload: the int64 segment rows [2, 3, B] (start, length, offset of the subsample or -1), then the int32 subsamples
+    host = np.empty((48 * B + 4 * cap * n_perm,), dtype=np.uint8)
+    seg = host[: 48 * B].view(np.int64).reshape(2, 3, B)
+    perm = host[48 * B:].view(np.int32)
+    seg[0, 0], seg[0, 1], seg[0, 2] = st.h_start[si], np.minimum(cs, cap), -1
+    seg[1, 0], seg[1, 1], seg[1, 2] = dt.h_start[di], np.minimum(cd, cap), -1
+    drawn = 0
+    for k in over:                                          # random_choice, utils_helper.py:198-201
         for which, c in ((0, cs), (1, cd)):
-            if c[k] > N:
-                seg[which, 2, k] = len(perms) * N
-                perms.append(torch.randperm(int(c[k]), generator=getattr(args, "generator", None))[0:N].to(torch.int32))
-    d_seg = torch.from_numpy(seg).to(dev)
-    d_perm = torch.cat(perms).to(dev) if perms else None
+            if c[k] > cap:
+                seg[which, 2, k] = drawn * cap
+                perm[drawn * cap: (drawn + 1) * cap] = torch.randperm(int(c[k]), generator=getattr(args, "generator", None))[0:cap].numpy()
+                drawn += 1
+    d_host = torch.from_numpy(host).to(dev)
+    base = d_host.data_ptr()
+    d_perm = ctypes.c_void_p(base + 48 * B) if n_perm else None
     segs = torch.empty((2, B, N, 4), dtype=torch.float32, device=dev)
     for which, table in enumerate((st, dt)):
-        _lib.call("icpflow_gather_segments", _lib.ptr(table.points), _lib.ptr(table.order), _lib.ptr(d_seg[which]),
-                  _lib.ptr(d_perm), B, N, _lib.ptr(segs[which]), _lib.stream(dev))
+        _lib.call("icpflow_gather_segments", _lib.ptr(table.points), _lib.ptr(table.order), ctypes.c_void_p(base + 24 * B * which),
+                  d_perm, B, N, _lib.ptr(segs[which]), _lib.stream(dev))
     return segs[0], segs[1]
 
 
@@ -149,9 +185,7 @@ def _launch_pairs(args, st, dt, pairs):
     si, di = st.find_host(pairs[:, 0]), dt.find_host(pairs[:, 1])
     assert (si >= 0).all() and (di >= 0).all()
     segs_src, segs_dst = _gather_pair_batches(args, st, dt, si, di)
-    T, ev, iters = hist_icp_eval(args, segs_src, segs_dst, return_iterations=True)
-    B = len(pairs)
-    r = torch.cat([T.reshape(B, 16)] + [e.reshape(B, -1) for e in ev] + [iters.float().expand(B, 1)], dim=1)
+    r, _ = _hist_icp_eval_flat(args, segs_src, segs_dst)
     return si, di, r
 
 
@@ -193,17 +227,17 @@ def _match_pairs_host(args, st, dt, pairs):
 
 
 def _finish_pairs(args, st, dt, launched):
-    """The host half, on the [B, 31] results of the stage brought to the host in ONE transfer: reject test, S x D
-    matrices, row arg-min."""
+    """The host half, on the results of the stage brought to the host in ONE transfer (the flat buffer of
+    _hist_icp_eval_flat): reject test, S x D matrices, row arg-min."""
     si, di, r = launched
     B = len(si)
-    if r[0, -1] < 0:
+    T_h, (errors, inliers, ratios, ious, translations, rotations), iters = _eval_views(r, B)
+    if iters[0] < 0:
         # a team of workgroups sharing one large pair gave up waiting for a member (include/icpflow_hip.h, a-5):
         # the transforms are NaN.  Never let that pass as "no match" -- the points would silently get ego flow only.
         raise RuntimeError("icpflow_hist_icp abandoned the batch: a workgroup team timed out (GPU shared with another "
                            "process?); retry, or register with _lib.options(no_teams=True)")
-    T_h, errors, inliers, ratios, ious = r[:, 0:16].reshape(B, 4, 4), r[:, 16:18], r[:, 18:20], r[:, 20:22], r[:, 22:24]
-    keep = check_transformation(args, r[:, 24:27], r[:, 27:30], np.minimum(ious[:, 0], ious[:, 1]))
+    keep = check_transformation(args, translations, rotations, np.minimum(ious[:, 0], ious[:, 1]))
     S, D = len(st.h_labels), len(dt.h_labels)
     if not keep.any():
         return np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32)
@@ -240,8 +274,10 @@ def setdiff1d(t1, t2):
     if isinstance(t1, torch.Tensor):
         t12, counts = torch.cat([torch.unique(t1), torch.unique(t2)]).unique(return_counts=True)
         return t12[counts == 1]
-    t12, counts = np.unique(np.concatenate([np.unique(t1), np.unique(t2)]), return_counts=True)
-    return t12[counts == 1]
+    u1 = np.unique(t1)
+    gone = np.zeros(len(u1), dtype=bool)
+    gone[np.searchsorted(u1, np.asarray(t2))] = True       # (t2 a subset of t1: the labels counted once are those of t1 alone)
+    return u1[~gone]
 
 
 def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, asynchronous=False):
@@ -293,9 +329,12 @@ def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, async
         pairs_dyn, T_dyn = _finish_pairs(args, st, dt, (launched[0], launched[1], pend.get()))
     else:
         pairs_dyn, T_dyn = empty
-    out = np.concatenate([pairs_sta, pairs_dyn], axis=0)
-    T = np.concatenate([T_sta, T_dyn], axis=0)
-    return torch.from_numpy(out).to(dev, non_blocking=asynchronous), torch.from_numpy(T).to(dev, non_blocking=asynchronous)
+    P = len(pairs_sta) + len(pairs_dyn)
+    both = np.empty((26 * P,), dtype=np.float32)             # ONE upload: the pair rows [P,10], then the transforms [P,4,4]
+    np.concatenate([pairs_sta, pairs_dyn], axis=0, out=both[: 10 * P].reshape(P, 10))
+    np.concatenate([T_sta, T_dyn], axis=0, out=both[10 * P:].reshape(P, 4, 4))
+    d_both = torch.from_numpy(both).to(dev, non_blocking=asynchronous)
+    return d_both[: 10 * P].view(P, 10), d_both[10 * P:].view(P, 4, 4)
 
 
 def drive(gen):

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 203 /* 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 204 /* 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -342,7 +342,7 @@ int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, 
  *
  * icpflow_flow_rigid replaces flow_estimation_torch (utils_flow.py:57-69): every point whose
  * float label equals d_pair_labels[p] moves with T[p]*pose, every other point with pose alone;
- * flow = moved - point.  d_ws: (P+1)*64 bytes of scratch.
+ * flow = moved - point.  d_ws: not used since version 204 (may be NULL).
  * ------------------------------------------------------------------------- */
 int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int N, float *d_out,
                        icpflow_stream_t stream);
@@ -363,9 +363,21 @@ int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const i
 size_t icpflow_cluster_table_workspace_bytes(int M, int Lmax);
 int icpflow_cluster_table(const float *d_points, const float *d_labels, int M, int64_t *d_order, double *d_table, int Lmax,
                           int32_t *d_num, void *d_ws, size_t ws_bytes, icpflow_stream_t stream);
+/* The tables of BOTH clouds of a frame pair (what match_pcds needs before anything else, utils_match.py:27-29) in one
+ * chain of launches -- half as many as two icpflow_cluster_table calls; every output exactly what those calls write. */
+size_t icpflow_cluster_table_pair_workspace_bytes(int MA, int MB, int Lmax);
+int icpflow_cluster_table_pair(const float *d_points_a, const float *d_labels_a, int MA, int64_t *d_order_a,
+                               double *d_table_a, int32_t *d_num_a, const float *d_points_b, const float *d_labels_b,
+                               int MB, int64_t *d_order_b, double *d_table_b, int32_t *d_num_b, int Lmax, void *d_ws,
+                               size_t ws_bytes, icpflow_stream_t stream);
 int icpflow_flow_rigid(const float *d_points, const float *d_labels, int N, const float *d_pair_labels,
                        const float *d_T, int P, const float *d_pose, float *d_flow, void *d_ws,
                        size_t ws_bytes, icpflow_stream_t stream);
+/* The same with the matched source labels read where match_pcds leaves them: column 0 of its pair rows (d_pair_rows
+ * float32 [P, pair_stride], pair_stride = 10 for the [P,10] rows of utils_match.py:118-127; 1 = a plain array). */
+int icpflow_flow_rigid_rows(const float *d_points, const float *d_labels, int N, const float *d_pair_rows,
+                            int pair_stride, const float *d_T, int P, const float *d_pose, float *d_flow,
+                            icpflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * 8(f) row 4  density clustering of a frame pair's points -- the `cluster_dbscan` branch of

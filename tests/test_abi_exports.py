@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_the_header():
     from icp_flow_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.VERSION == 203
+    assert _lib.VERSION == 204
     assert re.fullmatch(r"[0-9a-f]{16}", _lib.BUILD_INFO), _lib.BUILD_INFO
 
 

@@ -932,6 +932,12 @@ def test_flow_rigid_with_more_pairs_than_one_label_tile():
     got = utils_flow.flow_estimation_torch(None, G(pts), None, G(labels), None, G(pairs), G(T), G(pose)).cpu().numpy()
     want = rp.flow_estimation_torch(C(pts), C(labels), C(pairs), C(T), C(pose)).numpy()
     np.testing.assert_allclose(got, want, atol=2e-5)
+    # the matched labels read in place (column 0 of the [P,10] rows) or from a plain array / another dtype: the same flow
+    for other in (G(pairs)[:, 0:1].contiguous(), G(pairs).double(), G(np.concatenate([pairs, pairs], axis=1))[:, :10]):
+        again = utils_flow.flow_estimation_torch(None, G(pts), None, G(labels), None, other, G(T), G(pose)).cpu().numpy()
+        assert np.array_equal(again, got)
+    none = utils_flow.flow_estimation_torch(None, G(pts), None, G(labels), None, G(pairs[:0]), G(T[:0]), G(pose)).cpu().numpy()
+    np.testing.assert_allclose(none, pts @ pose[:3, :3].T + pose[:3, 3] - pts, atol=2e-5)
 
 
 def test_cluster_stats_kernel_vs_torch():
@@ -1197,3 +1203,30 @@ def test_cluster_table_chain_equals_the_torch_ops():
         assert np.array_equal(t.h_labels, np.unique(lab))
     st, dt = ClusterTable.pair(G(pts), G(cases["one"]), G(pts[:500]), G(cases["one"][:500]))
     assert list(st.h_count) == [777] and list(dt.h_count) == [500]
+
+
+def test_cluster_table_pair_chain_equals_two_single_chains():
+    """icpflow_cluster_table_pair (both clouds of a frame pair through ONE sort with the cloud's number above the label's
+    bits) against two icpflow_cluster_table calls: row order, labels, counts, starts, centroids, extents and the number of
+    clusters bit for bit -- clouds of different sizes, labels of either sign shared and not shared between the two, one
+    cloud overflowing the device table (its table falls back to the torch ops, the other one stays), single-row clouds."""
+    from icp_flow_amd.utils_check import ClusterTable, TABLE_ROWS
+    rng = np.random.default_rng(6)
+    vals = np.array([-1e8, -1.0, 0, 1, 2, 7, 19, 300, 2.5, -3.25], dtype=np.float32)
+    prob = [0.5, 0.1, 0.05, 0.05, 0.1, 0.05, 0.05, 0.04, 0.03, 0.03]
+    cases = {"frames": (rng.choice(vals, size=70000, p=prob), rng.choice(vals[1:], size=41234)),
+             "many": (rng.integers(0, TABLE_ROWS - 3, 50000).astype(np.float32), rng.integers(-5, 40, 3000).astype(np.float32)),
+             "overflow in one": (rng.integers(0, 50, 20000).astype(np.float32), rng.integers(0, TABLE_ROWS + 500, 60000).astype(np.float32)),
+             "single rows": (np.array([3.0], np.float32), np.array([-2.0], np.float32)),
+             "same label everywhere": (np.full(5000, 9.0, np.float32), np.full(64, 9.0, np.float32))}
+    for name, (la, lb) in cases.items():
+        pa = rng.normal(0, 20, size=(len(la), 3)).astype(np.float32)
+        pb = rng.normal(0, 20, size=(len(lb), 3)).astype(np.float32)
+        st, dt = ClusterTable.pair(G(pa), G(la), G(pb), G(lb))
+        for got, pts, lab in ((st, pa, la), (dt, pb, lb)):
+            want = ClusterTable(G(pts), G(lab))
+            assert torch.equal(got.order, want.order), name
+            for attr in ("h_labels", "h_count", "h_start", "h_mean", "h_extent"):
+                assert np.array_equal(getattr(got, attr), getattr(want, attr)), (name, attr)
+            assert torch.equal(got.labels_unq, want.labels_unq) and torch.equal(got.mean, want.mean) and torch.equal(got.extent, want.extent)
+            assert np.array_equal(got.h_labels, np.unique(lab)), name
