@@ -45,7 +45,10 @@ from . import utils_eval, utils_flow, utils_track
 # demo.sh:9-13 / main.sh flags of the registration stage
 DEFAULT_ARGS = dict(max_points=10000, min_cluster_size=20, translation_frame=2.0, thres_dist=0.1, thres_box=0.1,
                     thres_rot=0.1, thres_error=0.2, thres_iou=0.2, chunk_size=50, speed=None,
-                    cluster=None, epsilon=0.25, num_clusters=200, range_x=None, range_y=None)
+                    cluster=None, epsilon=0.25, num_clusters=200, range_x=None, range_y=None,
+                    # not a flag of the reference: candidate batches padded to the longest cluster of the stage instead of
+                    # max_points (utils_match._gather_pair_batches; False = the reference's width, same registrations)
+                    tight_padding=True)
 
 
 def default_args(**over):

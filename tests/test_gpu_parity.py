@@ -982,6 +982,46 @@ def test_synthetic_frame_pair_vs_oracle():
     assert np.linalg.norm(out["flow"].cpu().numpy() - fp.gt_flow, axis=1).mean() < 0.02
 
 
+@pytest.mark.parametrize("mp", [2048, 10000])
+def test_batches_padded_to_their_longest_cluster_register_like_max_points_wide_ones(mp):
+    """match_pcds pads the candidate batches of a stage to the longest cluster of the stage (utils_match.
+    _gather_pair_batches), the reference to max_points (pad_segment, utils_helper.py:185-196).  Padding rows carry flag 0:
+    the demo frame pair registered both ways (args.tight_padding False = the reference's width) -- the same matched pairs,
+    the same stage-2 draws, transforms and per-point flow within 1e-5 m of each other (the fp64 sums of a pair follow the
+    shape of the workgroups that serve it; stage 2 at max_points 10000 is 576 rows wide instead of 10000)."""
+    from icp_flow_amd import utils_flow, utils_track, utils_match
+    g0, lab = load_golden("g8_demo"), load_golden("g8_demo_labels")
+    ps, pd = G(g0["point_src"]), G(g0["point_dst"])
+    ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
+    widths = {}
+    orig = utils_match._hist_icp_eval_flat
+
+    def spy(args, s, d):
+        widths.setdefault(bool(getattr(args, "tight_padding", True)), []).append(int(s.shape[1]))
+        return orig(args, s, d)
+
+    runs = {}
+    utils_match._hist_icp_eval_flat = spy
+    try:
+        for tight in (True, False):
+            a = rp.default_args(max_points=mp, min_cluster_size=20, translation_frame=2.0, thres_box=0.1, thres_rot=0.1,
+                                thres_error=0.2, thres_iou=0.2)
+            a.tight_padding = tight
+            torch.manual_seed(0)
+            pairs, Tm = utils_track.track(a, ps, pd, ls, ld)
+            flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, torch.eye(4, device=DEV))
+            runs[tight] = (pairs.cpu().numpy(), Tm.cpu().numpy(), flow.cpu().numpy())
+    finally:
+        utils_match._hist_icp_eval_flat = orig
+    assert widths[False] == [mp, mp] and widths[True][0] == mp and widths[True][1] < mp and widths[True][1] % 64 == 0, widths
+    (p1, T1, f1), (p0, T0, f0) = runs[True], runs[False]
+    assert np.array_equal(p1[:, 0:2], p0[:, 0:2]) and len(p1) == 83
+    np.testing.assert_allclose(T1, T0, atol=1e-5)
+    np.testing.assert_allclose(p1[:, 2:4], p0[:, 2:4], atol=1e-5)          # errors
+    assert np.array_equal(p1[:, 4:6], p0[:, 4:6])                            # inlier counts
+    assert np.linalg.norm(f1 - f0, axis=1).max() < 1e-5
+
+
 @pytest.mark.parametrize("clusterer", ["dbscan", "hdbscan"])
 def test_multi_gap_sequence_vs_oracle(tmp_path, clusterer):
     """BASELINE config 3's shape without the dataset: a 4-frame sample in the reference's Waymo / nuScenes format
