@@ -553,6 +553,19 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     }
     const int tsplit = (N + span - 1) / span;
     const bool split = useLds && !sideBusy && block != 1024 && wgs256 >= 2LL * cus && wgs256 <= 4LL * cus;
+    // Wide batches of few pairs (a frame's candidate clusters padded to max_points = 10000; the ragged real-shape batch): the
+    // launch is paced by chains -- a wave walks its window target by target -- and by the LDS counters of the few CUs that
+    // hold the large pairs' workgroups.  128 rows per workgroup, FOUR waves per 64 rows: a quarter of the chain per wave, four
+    // times the CUs per pair.  Demo frame, stage 1 (93 pairs, width 10000; rows per workgroup x waves per 64 rows): 512 x 1
+    // 186 us, 256 x 1 180, 128 x 1 186, 256 x 2 135, 128 x 2 121, 64 x 2 134, 128 x 4 105, 64 x 4 103; the pair's valid rows
+    // dealt to as few 512-row workgroups as hold them: 188 (the padded width spreads a pair over more CUs: kept).
+    if (useLds && N > 4096 && B <= 2 * cus) {
+        dim3 grid(((N + 127) / 128) * tsplit, B);
+        hipLaunchKernelGGL((hist_vote_sorted_kernel<512, 4>), grid, dim3(512), lds_hist, s,
+                           (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
+                           ez, swap, useLds, bins_u32, keyRec, span);
+        return hipGetLastError();
+    }
     if (block == 1024) {
         dim3 grid(((N + 1023) / 1024) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<1024>, grid, dim3(1024), useLds ? lds_hist : tile_bytes, s,
