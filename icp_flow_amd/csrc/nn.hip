@@ -387,6 +387,14 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     __shared__ float boundSh;   // pruned scoring: candidate 0's forward mean
     __shared__ int prunedSh;    // ... a wave of this block has proven the scan out of the race
+    if (qb * kSweepBlock >= nq) {   // block beyond the cloud: its record is still summed
+        // (before the pruning prologue: on a batch padded far beyond its clusters -- a frame's candidate pairs at max_points
+        // 10000 -- nine blocks in ten are such blocks, and the prologue reads and adds the sums of up to eleven scans.  A
+        // scan that the prologue would have declared out of the race here reports its true sum instead of +inf: above the
+        // bound either way, the pick is the same.)
+        if (threadIdx.x < kPartial) out[threadIdx.x] = 0.0;
+        return;
+    }
     if (MODE == SWEEP_SCORE && threadIdx.x == 0) prunedSh = 0;
     if (MODE == SWEEP_SCORE && p.prune) {
         // branch and bound exactly as in nn_scan_kernel (the argument is written there): the sum of the blocks
@@ -445,10 +453,6 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         }
         __syncthreads();
         if (leave) return;
-    }
-    if (qb * kSweepBlock >= nq) {   // block beyond the cloud: its record is still summed
-        if (threadIdx.x < kPartial) out[threadIdx.x] = 0.0;
-        return;
     }
     __shared__ float poseSh[16];
     if (MODE == SWEEP_CHECK) {   // the pose of this job: init (sub 0) or final (sub 1; composed here when fused)
