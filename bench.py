@@ -355,13 +355,19 @@ def extra_measurements(args, src, dst, T, dev, a):
         out["ragged_real_shape"] = ragged_real_shape(dev)
     except Exception as e:
         out["ragged_real_shape"] = {"error": repr(e)}
+    try:
+        # the same distribution of cluster sizes with the two clouds of a pair alike (round 3: the independent draw pits
+        # 35-point clusters against 7000-point ones, which no candidate pair of match_pcds is after sanity_check)
+        out["ragged_real_shape_matched_sizes"] = ragged_real_shape(dev, sizes="matched")
+    except Exception as e:
+        out["ragged_real_shape_matched_sizes"] = {"error": repr(e)}
     fp = frame_pair_measurement(dev)
     if fp is not None:
         out["frame_pair"] = fp
     return out
 
 
-def ragged_real_shape(dev, B=128, N=10000, cap=100):
+def ragged_real_shape(dev, B=128, N=10000, cap=100, sizes=True):
     """SURVEY 8(d) "ragged variant": the shape the real sweeps (BASELINE configs 3 and 5) present -- clusters of
     n ~ logUniform(20, 10^4) points padded to max_points = 10000 (main.sh:10) with (1e8, 1e8, 1e8, 0), a frame's worth of
     candidate pairs per batch (B = 128), the reference's 100-iteration cap (utils_icp.py:54).  Registrations/s of
@@ -369,7 +375,7 @@ def ragged_real_shape(dev, B=128, N=10000, cap=100):
     scans), apply_icp (ICP from those poses + roll-back check), match_eval; the ICP kernel's share by HIP events."""
     from types import SimpleNamespace
     from icp_flow_amd import _lib, synthetic, utils_hist, utils_icp, utils_match
-    S, D, _ = synthetic.make_batch(B, N, seed=0, ragged=True, n_min=20)
+    S, D, _ = synthetic.make_batch(B, N, seed=0, ragged=sizes, n_min=20)
     src, dst = torch.from_numpy(S).to(dev), torch.from_numpy(D).to(dev)
     args = SimpleNamespace(thres_dist=0.1, translation_frame=2.0, chunk_size=50, max_points=N, icp_max_iterations=cap,
                            icp_stop_mode="reference")
@@ -392,7 +398,9 @@ def ragged_real_shape(dev, B=128, N=10000, cap=100):
     ms_icp, _ = timeit(lambda: utils_icp.apply_icp(args, src, dst, init))
     ms_eval, _ = timeit(lambda: utils_match.match_eval(args, src, dst, T))
     n = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
-    return {"workload": f"{B} cluster pairs, n ~ logUniform(20, {N}) padded to {N}, <= {cap} ICP iterations (reference stop)",
+    how = ("both clouds of a pair draw their sizes independently" if sizes is True else
+           "n_dst = n_src * U(0.8, 1.25): the same object from two ranges, as candidate pairs are after sanity_check")
+    return {"workload": f"{B} cluster pairs, n ~ logUniform(20, {N}) padded to {N} ({how}), <= {cap} ICP iterations (reference stop)",
             "points_per_cluster_median": int(np.median(np.concatenate(n))), "points_per_cluster_max": int(max(n[0].max(), n[1].max())),
             "registrations_per_s": round(B / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "icp_iterations": int(iters.item()),
             "icp_kernel_ms_per_batch": round(icp_ms / 6, 3),   # (6 calls: one warm-up + 5 timed)

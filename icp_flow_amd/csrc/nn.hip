@@ -349,9 +349,17 @@ constexpr int kSweepBlock = 256;
 constexpr int kSweepStage = 4096;   // sort keys staged in LDS up to this many targets
 enum SweepMode : int { SWEEP_SCORE = 0, SWEEP_CHECK = 1, SWEEP_EVAL = 2 };
 
+#ifdef ICPFLOW_SWEEP_CLOCK
+__device__ long long g_sweep_clk[4096 * 8];   // per (mode 1 job, block 0): wall start, wall end, shader clocks: entry->loop, loop, rounds, nt, nq, chunks scanned
+#endif
 template <int MODE>
 __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
 {
+#ifdef ICPFLOW_SWEEP_CLOCK
+    const long long dbgW0 = wall_clock64(), dbgC0 = clock64();
+    long long dbgC1 = 0, dbgC2 = 0;
+    int dbgRounds = 0, dbgChunks = 0;
+#endif
     __shared__ double red[(kSweepBlock / kWave) * kPartial];
     extern __shared__ __attribute__((aligned(16))) float keyLds[];   // the targets' sort keys (window searches)
     const int lin = blockIdx.x;
@@ -541,6 +549,9 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         for (int j = threadIdx.x; j < np16; j += kSweepBlock) keyLds[j] = gkey[j];
         __syncthreads();
     }
+#ifdef ICPFLOW_SWEEP_CLOCK
+    dbgC1 = clock64();
+#endif
     if (lo <= hi && nt > 0) {   // wave-uniform
         const float *key = stage ? keyLds : gkey;
         // slack: rounding of src + t / of the inverse map (ulps of the coordinates) and of the window arithmetic
@@ -564,6 +575,9 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
                 scan_range_min_uniform<false>(tkx, tky, tkz, k0, min(cb, k1), qx, qy, qz, 0.f, 0.f, 0.f, best);
                 scan_range_min_uniform<false>(tkx, tky, tkz, max(ce, k0), k1, qx, qy, qz, 0.f, 0.f, 0.f, best);
             }
+#ifdef ICPFLOW_SWEEP_CLOCK
+            ++dbgRounds; dbgChunks = ce - cb;
+#endif
             cb = min(cb, k0); ce = max(ce, k1);
             const float worst = wave_max_uniform(live ? best : 0.f);
             const float proven = r * shrink;
@@ -599,6 +613,14 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             if (MODE == SWEEP_SCORE && p.prune == 1) r = fminf(r, rPrev * 2.0f);
         }
     }
+#ifdef ICPFLOW_SWEEP_CLOCK
+    dbgC2 = clock64();
+    if (MODE == SWEEP_CHECK && threadIdx.x == 0 && qb == 0 && (int)(blockIdx.x) >= 0) {
+        const int slot = (b * 2 + sub) & 4095;
+        long long *o = g_sweep_clk + slot * 8;
+        o[0] = dbgW0; o[1] = wall_clock64(); o[2] = dbgC1 - dbgC0; o[3] = dbgC2 - dbgC1; o[4] = dbgRounds; o[5] = nt; o[6] = nq; o[7] = dbgChunks;
+    }
+#endif
     // masked sums over this block's queries: sum of Euclidean NN distances (utils_helper.py:30,
     // utils_hist.py:89-95); match_eval adds inlier counts and, forward, the centroids (utils_match.py:168-181)
     double v[kPartial];
@@ -644,6 +666,12 @@ __global__ void transform_soa_kernel(const float *__restrict__ soa, const int32_
     o[k] = x; o[NP16 + k] = y; o[2 * NP16 + k] = z;
 }
 
+#ifdef ICPFLOW_SWEEP_CLOCK
+extern "C" int icpflow_debug_sweep_clk(long long *out32768)
+{
+    return (int)hipMemcpyFromSymbol(out32768, HIP_SYMBOL(g_sweep_clk), sizeof(long long) * 32768);
+}
+#endif
 int sweep_qblocks(int maxRows) { return (maxRows + kSweepBlock - 1) / kSweepBlock; }
 
 template <int MODE>

@@ -59,7 +59,10 @@ def make_batch(num_pairs, max_points, seed=0, first=0, ragged=False, n_min=20):
     """[B,N,4] src/dst float32 + ground-truth transforms [B,4,4].
 
     ragged=False: n_src = n_dst = max_points (BASELINE configs 2 and 4).
-    ragged=True : n ~ logUniform(n_min, max_points), padded with (1e8,1e8,1e8,0).
+    ragged=True : n ~ logUniform(n_min, max_points), padded with (1e8,1e8,1e8,0); the two clouds of a pair draw their
+                  sizes independently (a 35-point cluster may face a 7000-point one).
+    ragged="matched": n_src as above, n_dst = n_src * U(0.8, 1.25) -- the same object seen from two ranges, which is what
+                  the candidate pairs of match_pcds are after sanity_check (similar extents, utils_check.py:21-49).
     """
     S = np.empty((num_pairs, max_points, 4), np.float32)
     D = np.empty((num_pairs, max_points, 4), np.float32)
@@ -70,6 +73,8 @@ def make_batch(num_pairs, max_points, seed=0, first=0, ragged=False, n_min=20):
             r = np.random.default_rng(10_000_019 + seed + k)
             ns = int(round(np.exp(r.uniform(np.log(n_min), np.log(max_points)))))
             nd = int(round(np.exp(r.uniform(np.log(n_min), np.log(max_points)))))
+            if ragged == "matched":
+                nd = int(min(max(round(ns * r.uniform(0.8, 1.25)), n_min), max_points))
         else:
             ns = nd = max_points
         S[i], D[i], T[i] = make_pair(k, ns, nd, max_points, seed)
