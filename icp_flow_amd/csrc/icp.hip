@@ -1882,9 +1882,22 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     __shared__ int first[257];
     __shared__ long long total;
     const int b = threadIdx.x;
-    int n = 0;
-    if (b < B) n = (swap != nullptr && swap[b] != 0) ? lenY[b] : lenX[b];
-    size[b] = max(n - 768, 0);   // queries beyond one pass of a (768-thread) workgroup
+    int n = 0, nf = 0;
+    if (b < B) {
+        const bool sw = swap != nullptr && swap[b] != 0;
+        n = sw ? lenY[b] : lenX[b];
+        nf = sw ? lenX[b] : lenY[b];
+    }
+    // queries beyond one pass of a (768-thread) workgroup, weighted by the length of the fixed cloud: what a query costs
+    // grows with the targets inside its window, and the pairs iterate side by side towards one batch-global stop -- a
+    // dense 10^4 x 10^4 pair with two passes per member (132 k clocks per iteration) paces a batch whose mid-sized pairs
+    // have spare time
+    {
+        // (the square root: between no weight -- ragged real-shape batch with matched sizes 2.23 ms of ICP, with independent
+        // sizes 0.93 ms -- and the full ratio, 1.75 / 1.01 ms; with the root 1.72 / 0.99 ms; the demo frame does not move)
+        const long long w = (long long)((double)max(n - 768, 0) * sqrt((double)max(nf, 1024) / 1024.0));
+        size[b] = (int)min(w, (long long)0x3fffffff);
+    }
     for (int w = threadIdx.x; w < t.maxWG; w += blockDim.x) { t.wgPair[w] = -1; t.wgRank[w] = 0; }
     __syncthreads();
     if (b < kWave) {   // (wave 0 adds the sizes: exact integers, any order)
