@@ -729,15 +729,20 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             // every case: results are bit-identical (test_adaptive_windows_change_nothing), the iterations after the
             // first few cost a distance evaluation per query instead of a window scan.
             constexpr bool REC = (GRID == 4);
-            // team member `rank` owns the sorted queries [qBegin, qEnd)
-            const int qShare = (TEAM && G > 1) ? ((xc.n + G - 1) / G + kWave - 1) / kWave * kWave : xc.n;
-            const int qBegin = min(rank * qShare, xc.n), qEnd = min(qBegin + qShare, xc.n);
-            // records of this workgroup's queries (indexed from qBegin), if its share fits the room behind the image
-            float4 *rec = reinterpret_cast<float4 *>(dyn + (size_t)NP16 * 12) - qBegin;
-            int *recJ = reinterpret_cast<int *>(dyn + (size_t)NP16 * 12 + (size_t)p.recCap * 16) - qBegin;
-            const bool recOn = REC && p.recCap > 0 && qEnd - qBegin <= p.recCap;
+            // Team member `rank` takes the units (64 consecutive sorted queries: what a wave searches at a time) rank,
+            // rank + G, rank + 2 G, ... of the pair.  (Round 3; a contiguous share per member before.  The cost of a unit
+            // follows the density of the fixed cloud around it, so a contiguous share could hold all the dense units of a
+            // pair: on the ragged real-shape batch with matched sizes member 0 of the slowest team searched for 25 k clocks per
+            // iteration and waited 53 k for the others.)  Local slot li = the li-th query this member takes, in sorted order.
+            const int unitsAll = (xc.n + kWave - 1) / kWave;
+            const bool dealt = TEAM && G > 1;
+            const int myCount = dealt ? (unitsAll > rank ? (unitsAll - rank + G - 1) / G : 0) * kWave : xc.n;
+            // records of this workgroup's queries (indexed by local slot), if its share fits the room behind the image
+            float4 *rec = reinterpret_cast<float4 *>(dyn + (size_t)NP16 * 12);
+            int *recJ = reinterpret_cast<int *>(dyn + (size_t)NP16 * 12 + (size_t)p.recCap * 16);
+            const bool recOn = REC && p.recCap > 0 && myCount <= p.recCap;
             // (and the query's own point, pre-pose applied, when there is room: read from L2 once, not once per iteration)
-            float *x0c = reinterpret_cast<float *>(dyn + (size_t)NP16 * 12 + (size_t)p.recCap * 20) - qBegin;
+            float *x0c = reinterpret_cast<float *>(dyn + (size_t)NP16 * 12 + (size_t)p.recCap * 20);
             const bool x0On = recOn && p.x0Cache != 0;
             if (GRID == 4 && it == itFirst) {
                 for (int k = tid; k < np16; k += BLOCK) { lx[k] = gx[k]; ly[k] = gy[k]; lz[k] = gz[k]; }
@@ -746,7 +751,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             const float *keyf = (GRID == 4) ? (axis == 0 ? lx : (axis == 1 ? ly : lz))
                                             : (axis == 0 ? gx : (axis == 1 ? gy : gz));
             constexpr int PER = BLOCK * Q;            // a wave owns 64 CONSECUTIVE sorted queries
-            const int ngr = (qEnd - qBegin + PER - 1) / PER;
+            const int ngr = (myCount + PER - 1) / PER;
             double fold[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
             bool reuseMoments = false;   // this wave's 18 sums are those of the previous iteration (still in `red`)
             [[maybe_unused]] int helpedPasses = 0;   // owner: passes of this iteration that helpers deliver (bit g)
@@ -778,13 +783,14 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
 #endif
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    const int i = qBegin + g * PER + (wave * Q + q) * kWave + lane;
-                    live[q] = i < qEnd;
+                    const int li = g * PER + (wave * Q + q) * kWave + lane;                   // local slot
+                    const int i = dealt ? ((li >> 6) * G + rank) * kWave + lane : li;        // sorted query
+                    live[q] = li < myCount && i < xc.n;
                     x0x[q] = x0y[q] = x0z[q] = 0.f;
                     qx[q] = qy[q] = qz[q] = 0.f;
                     if (live[q]) {
                         if (x0On && it > itFirst) {
-                            x0x[q] = x0c[i]; x0y[q] = x0c[p.recCap + i]; x0z[q] = x0c[2 * p.recCap + i];
+                            x0x[q] = x0c[li]; x0y[q] = x0c[p.recCap + li]; x0z[q] = x0c[2 * p.recCap + li];
                         } else {
                         const float4 s4 = xs[i];   // sorted; pre-pose (utils_icp.py:21) applied by the sort or here
                         x0x[q] = s4.x; x0y[q] = s4.y; x0z[q] = s4.z;
@@ -793,7 +799,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                             x0y[q] = fmaf(s4.z, preL[5], fmaf(s4.y, preL[4], s4.x * preL[3])) + preL[10];
                             x0z[q] = fmaf(s4.z, preL[8], fmaf(s4.y, preL[7], s4.x * preL[6])) + preL[11];
                         }
-                        if (x0On) { x0c[i] = x0x[q]; x0c[p.recCap + i] = x0y[q]; x0c[2 * p.recCap + i] = x0z[q]; }
+                        if (x0On) { x0c[li] = x0x[q]; x0c[p.recCap + li] = x0y[q]; x0c[2 * p.recCap + li] = x0z[q]; }
                         }
                         float rx = fmaf(x0z[q], Rf[6], fmaf(x0y[q], Rf[3], x0x[q] * Rf[0]));  // :177, :395
                         float ry = fmaf(x0z[q], Rf[7], fmaf(x0y[q], Rf[4], x0x[q] * Rf[1]));
@@ -810,8 +816,8 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         if (recOn) {
                             m = certMargin;   // first iteration: nothing known
                             if (it > itFirst) {
-                                const float4 o = rec[i];
-                                const int j1 = recJ[i];
+                                const float4 o = rec[li];
+                                const int j1 = recJ[li];
                                 const float ex = qx[q] - o.x, ey = qy[q] - o.y, ez = qz[q] - o.z;
                                 // (raw v_sqrt_f32, 1 ulp: every bound below carries a relative margin of 1e-6, 8 ulp)
                                 const float dq = __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
@@ -1068,9 +1074,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     if (!(acc.best[q] < kInf)) certJ[q] = -1;
                 }
                 if (recOn && newL[q] >= 0.f) {
-                    const int i = qBegin + g * PER + (wave * Q + q) * kWave + lane;
-                    rec[i] = make_float4(qx[q], qy[q], qz[q], newL[q]);
-                    recJ[i] = certJ[q];
+                    const int li = g * PER + (wave * Q + q) * kWave + lane;
+                    rec[li] = make_float4(qx[q], qy[q], qz[q], newL[q]);
+                    recJ[li] = certJ[q];
                 }
                 ICPFLOW_STAMP(10);
 #ifdef ICPFLOW_TAIL_CLOCK
