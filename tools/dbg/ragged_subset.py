@@ -7,7 +7,7 @@ from types import SimpleNamespace
 from icp_flow_amd import synthetic, utils_match
 dev = torch.device("cuda:0")
 B, N = 128, 10000
-S, D, _ = synthetic.make_batch(B, N, seed=0, ragged=True, n_min=20)
+S, D, _ = synthetic.make_batch(B, N, seed=0, ragged=("matched" if os.environ.get("SIZES") == "matched" else True), n_min=20)
 n = np.minimum((S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1))
 sub = os.environ.get("SUBSET", "all")
 idx = {"all": np.arange(B), "small": np.nonzero(n <= 1000)[0], "mid": np.nonzero((n > 1000) & (n <= 3000))[0],
