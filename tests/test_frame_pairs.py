@@ -193,3 +193,53 @@ def test_sequence_files_in_the_reference_waymo_format(tmp_path):
     one = os.path.join(tmp_path, "pair.npz")
     frame_pairs.save_frame_pair(one, frame_pairs.FramePair(fps[0].points_src, fps[0].points_dst))
     assert not frame_pairs.is_sequence(one) and len(frame_pairs.load_any(one)) == 1
+
+
+def test_setdiff1d_equals_the_reference_statement():
+    """utils_match.setdiff1d (utils_helper.py:172-183: labels of t1 not in t2, t2 a subset of t1, sorted) on numpy arrays
+    -- the form match_pcds uses between its two stages -- and on tensors, against the oracle's restatement."""
+    from icp_flow_amd import utils_match
+    from oracle import reference_path as rp
+    rng = np.random.default_rng(4)
+    for trial in range(50):
+        n = int(rng.integers(1, 200))
+        t1 = rng.choice(np.arange(-3, 400), size=n, replace=False).astype(np.int64)
+        if trial % 3 == 0:
+            t1 = np.concatenate([t1, t1[: n // 2]])                      # repeated labels in t1
+        t2 = rng.choice(t1, size=int(rng.integers(0, len(t1) + 1)), replace=False) if trial % 7 else t1[:0]
+        want = rp.setdiff1d(torch.from_numpy(t1), torch.from_numpy(t2)).numpy()
+        got = utils_match.setdiff1d(t1, t2)
+        assert got.dtype == t1.dtype and np.array_equal(got, want), trial
+        assert torch.equal(utils_match.setdiff1d(torch.from_numpy(t1), torch.from_numpy(t2)), torch.from_numpy(want))
+
+
+def test_flat_result_buffer_of_a_stage_maps_to_the_arrays():
+    """The one buffer a stage of match_pcds brings to the host (utils_match._hist_icp_eval_flat: transforms, errors, inliers,
+    ratios, ious [B,2], translations, rotations [B,3], one int32 iteration count) and its views, host and tensor form."""
+    from icp_flow_amd import utils_match
+    B = 7
+    rng = np.random.default_rng(1)
+    parts = [rng.normal(size=(B, 4, 4)), *[rng.normal(size=(B, 2)) for _ in range(4)], *[rng.normal(size=(B, 3)) for _ in range(2)]]
+    flat = np.concatenate([p.astype(np.float32).reshape(-1) for p in parts] + [np.array([37], np.int32).view(np.float32)])
+    assert flat.shape == (30 * B + 1,)
+    for r in (flat, torch.from_numpy(flat)):
+        T, ev, iters = utils_match._eval_views(r, B)
+        got = [T, *ev]
+        assert [tuple(g.shape) for g in got] == [p.shape for p in parts]
+        for g, p in zip(got, parts):
+            assert np.array_equal(np.asarray(g), p.astype(np.float32))
+        assert int(iters[0]) == 37 and len(iters) == 1
+
+
+def test_ragged_batches_independent_and_matched_sizes():
+    """synthetic.make_batch: the ragged generator of bench.py's real-shape lines -- independent sizes (pinned: the bench
+    line of rounds 2 and 3 must stay the same batch) and matched sizes (n_dst within 0.8 ... 1.25 of n_src)."""
+    S, D, _ = synthetic.make_batch(16, 10000, seed=0, ragged=True, n_min=20)
+    ns, nd = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
+    assert list(ns[:6]) == [478, 2462, 37, 56, 3324, 3698] and list(nd[:6]) == [147, 1177, 1875, 153, 51, 6619]
+    S, D, _ = synthetic.make_batch(16, 10000, seed=0, ragged="matched", n_min=20)
+    ms, md = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
+    assert np.array_equal(ms, ns)
+    ratio = md / ms
+    assert (md >= 20).all() and (md <= 10000).all() and ((ratio > 0.79) & (ratio < 1.26) | (md == 20)).all()
+    assert (S[:, :, 3][np.arange(16), ms - 1] == 1).all() and (S[0, ms[0]:, 0] == 1e8).all()
