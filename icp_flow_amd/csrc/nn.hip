@@ -785,11 +785,10 @@ hipError_t launch_scan_score_pruned(const float *A, const float *C, const int32_
     p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
     hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) / 8) * 8 * p.qblocks)),
                        dim3(kScanBlock), 0, s, p);
-    p.njobs = B * 10; p.subBegin = 2; p.subCount = 10; p.prune = 1;
-    hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) & ~7) * p.qblocks)),
-                       dim3(kScanBlock), 0, s, p);
-    // candidate 0's backward scan last: it only matters when some other candidate survived the bound
-    p.njobs = B; p.subBegin = 1; p.subCount = 1; p.prune = 2;
+    // the other eleven scans under the bound of candidate 0's forward mean -- candidate 0's backward scan among them (its
+    // score is min(forward, backward): pruned for exceeding the forward mean, it leaves the score where it was; a third
+    // launch of its own until round 3, see launch_sweep_score_pruned)
+    p.njobs = B * 11; p.subBegin = 1; p.subCount = 11; p.prune = 1;
     hipLaunchKernelGGL((nn_scan_kernel<1, MODE_SCORE>), dim3((unsigned)(((p.njobs + 7) & ~7) * p.qblocks)),
                        dim3(kScanBlock), 0, s, p);
     return hipGetLastError();
