@@ -17,7 +17,9 @@ check) of every pair of the workload, inputs resident in HBM before the timed re
             one GPU (`config4_on_one_gpu`) so that the scaling curve has its N = 1 point.
   --workload config2|config4 overrides the choice.
   --force-collective   world of ONE rank: initialise RCCL anyway and run the all_gather (single-GPU boxes exercise the
-            N > 1 code path); --check-gather compares the gathered rows with the local ones.
+            N > 1 code path); the gathered rows are compared with the local ones after the timed region (`gather_check`).
+  With no launcher around it (WORLD_SIZE unset) `--gpus N > 1` starts its N ranks itself (self_launch: the contract's
+  own torch.distributed.run command line on 127.0.0.1 and a free port); fewer than N devices => "needs N devices, found M".
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -54,7 +56,77 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements")
     ap.add_argument("--force-collective", action="store_true", help="one rank: init RCCL and all_gather anyway")
     ap.add_argument("--check-gather", action="store_true", help="compare the gathered rows with the local ones")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="no GPU work: the ranks run the launcher, the rendezvous, the sharding and the one all_gather of "
+                         "[B,26] rows over gloo on CPU tensors (what tests/test_bench_launcher.py drives)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here, the way the
+    contract's own command line does -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py <the same arguments>` -- and hand its exit code on.  Rank 0 of the child world
+    prints the one JSON line on the stdout this process shares with it."""
+    import subprocess
+    have = a.gpus if a.launch_selftest else torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} needs {a.gpus} devices, found {have}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_selftest(a, rank, world):
+    """The N > 1 plumbing of main() without a GPU: environment of the launcher, gloo rendezvous on 127.0.0.1, contiguous
+    shards of the config-4 pair list, `steps` exchanges of the [B,26] rows through the ONE all_gather of the path
+    (sharding.gather_results with the counts every rank knows), max over ranks of the timed region, one JSON line from
+    rank 0.  The rows are made up (a generator seeded by the pair index stands in for hist_icp_eval): this checks the
+    launcher and the exchange, it measures nothing."""
+    import torch.distributed as dist
+    from icp_flow_amd.sharding import gather_results, pack_rows, shard_range, unpack_rows
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = a.pairs or 8192
+    counts = [shard_range(r, world, total)[1] for r in range(world)]
+    first, B = shard_range(rank, world, total)
+    g = torch.Generator().manual_seed(2024)
+    allrows = torch.randn(total, 24, generator=g)
+    mine = allrows[first:first + B]
+    rows = pack_rows(mine[:, :16].reshape(B, 4, 4).contiguous(), first, mine[:, 16:18], mine[:, 18:20], mine[:, 20:22], mine[:, 22:24])
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        got = gather_results(rows, world, counts=counts, force_collective=True)
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    Tg, pr = unpack_rows(got)
+    ok = bool(torch.equal(Tg.reshape(total, 16), allrows[:, :16]) and torch.equal(pr[:, 2:], allrows[:, 16:]) and
+              torch.equal(pr[:, 0], torch.arange(total, dtype=torch.float32)))
+    if rank == 0:
+        print(json.dumps({"launch_selftest": True, "metric": "cluster-pair ICP registrations/sec", "value": None,
+                          "unit": "registrations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(float(tmax.item()) / max(a.steps, 1) * 1e3, 4), "scaling": "strong",
+                          "data": "made-up rows (no GPU work)",
+                          "config": {"pairs_total": total, "pairs_per_gpu": counts},
+                          "gather_check": {"rows": list(got.shape), "identical_to_all_ranks_rows": ok,
+                                           "backend": dist.get_backend(), "rccl_library": None}}))
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("launch selftest: the gathered rows differ from the rows the ranks contributed")
 
 
 def timed_steps(step, sync, steps, warmup, iters_cap):
@@ -80,13 +152,16 @@ def timed_steps(step, sync, steps, warmup, iters_cap):
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.force_collective or a.launch_selftest):
+        self_launch(a)                      # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+    a.gpus = world                          # under a launcher the world it made is the truth
+    if a.launch_selftest:
+        return launch_selftest(a, rank, world)
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} needs device {local}, found {torch.cuda.device_count()} device(s)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -136,7 +211,7 @@ def main():
     dt, icp_ms, icp_launches, T, iters = timed_steps(step, sync, a.steps, a.warmup, a.iters)
     gather_check = None
     if collective:
-        if a.check_gather:      # the rows this rank contributed, as every rank received them
+        if True:                # (always, outside the timed region) the rows this rank contributed, as every rank received them
             Tl, ev, _ = utils_match.hist_icp_eval(args, src, dst, return_iterations=True)
             mine = pack_rows(Tl, first, ev[0], ev[1], ev[2], ev[3])
             gather_check = {"rows": list(T.shape), "identical_to_local_rows": bool(torch.equal(T[first:first + B], mine)),

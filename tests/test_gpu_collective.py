@@ -1,4 +1,5 @@
-"""The N > 1 code path on the box it will run on: one process, `init_process_group("nccl", world_size=1)` (RCCL),
+"""The N > 1 code path on the box it will run on, entered the way a bare `python bench.py --gpus N` enters it: no launcher
+environment, bench.py starts its own rank(s) (self_launch -> torch.distributed.run), `init_process_group("nccl")` (RCCL),
 bench.py's config-4 branch on the 1024-pair shard with the all_gather FORCED (not the world == 1 early return), the
 gathered [B,26] rows (transform + 40-byte pair row) compared with the ungathered ones bit for bit.  The
 8-GPU run of the driver is then not the first execution of that code."""
@@ -28,8 +29,7 @@ def _free_port():
 
 
 def test_config4_branch_through_rccl_on_one_rank():
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--workload", "config4", "--pairs", "1024",
            "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-pairs", "0", "--force-collective", "--check-gather"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
