@@ -172,6 +172,7 @@ struct Workspace {
         team.wgPair = (int32_t *)take((size_t)team.maxWG * 4);
         team.wgRank = (int32_t *)take((size_t)team.maxWG * 4);
         team.teamSize = (int32_t *)take(b * 4);
+        team.next = (int32_t *)take(b * 4);
         team.arrived = (unsigned int *)take(b * 4);
         team.mom = (double *)take((b < 256 ? b : 256) * 2 * (size_t)kMaxTeam * kTeamStride * 8);
         bytes = off;

@@ -1731,6 +1731,14 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         if (b < 0) return;                   // spare workgroup
         rank = p.team.wgRank[blockIdx.x];
         G = p.team.teamSize[b];
+        // a chain of single-pass pairs (icp_team_plan_kernel): one after the other, like the tickets of a persistent grid
+        for (;;) {
+            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false>(p, b, rank, G, itBegin, itEnd);
+            b = __builtin_amdgcn_readfirstlane(p.team.next[b]);
+            if (b < 0) return;
+            __syncthreads();                 // the pair's last reads of the static LDS state are done
+            rank = 0; G = 1;
+        }
     }
     if constexpr (!PERSIST) {
         icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false>(p, b, rank, G, itBegin, itEnd);
@@ -1872,56 +1880,151 @@ __global__ void icp_export_kernel(const IcpState *__restrict__ st, const IcpCtrl
     }
 }
 
-// Team sizes for one launch: every pair gets one workgroup, the spare ones go to the pairs whose
-// moving cloud needs more than one pass of a workgroup (768 queries), in proportion to the excess;
-// a member keeps at least 256 queries.  One block; B <= 256.
+// Team plan for one launch (one block of 256 threads; B <= 256).  Round 4: sizes by PASS BOUNDARIES.
+//
+// A member's waves take one unit (64 consecutive sorted queries) per pass, so an iteration of a member lasts
+// passes x (its slowest unit), passes = ceil(units per member / 12) for the 768-thread team kernel: a fifth workgroup on
+// a pair of 73 units (19 -> 15 units per member) shortens nothing, the seventh (11 units: one pass) halves the iteration.
+// So team sizes move from one level of "units per member" to the next -- ..., 36, 24, 12 (passes 3, 2, 1), then 8 and 4
+// (fewer waves sharing a SIMD: the early iterations, where every unit scans its window, are VALU issue) -- and the spare
+// workgroups go, one level at a time, to the pair whose estimated iteration is the longest (levels x a weight that grows
+// with the length of the fixed cloud: what a unit costs follows the targets in its window).
+//   * A pair first gets the team that lets its members keep the per-query RECORDS (neighbour certificates: a member's
+//     share of the queries must fit `recCap`): a 2200-query pair served by ONE workgroup of a batch padded to 10000
+//     searched every window in every iteration (90 k clocks per iteration against 25 k; ragged real-shape batch).
+//   * Pairs of a single pass (<= 768 queries) are CHAINED: up to kTeamChain of them are served one after the other by one
+//     workgroup (t.next), when the large pairs can use the workgroups that frees.  They finish within a few per cent
+//     of the launch (nobody waits for anybody under the speculative batch rule; a chained pair only arrives later at
+//     the tallies), and a workgroup that has finished its one small pair would idle for the rest of the launch.
+// The sums of a team are added in member order: the plan decides the rounding of a registration's moment sums, so it
+// depends on the batch's lengths alone (never on timing).
+#ifndef ICPFLOW_TEAM_CHAIN
+#define ICPFLOW_TEAM_CHAIN 4
+#endif
+constexpr int kTeamChain = ICPFLOW_TEAM_CHAIN;
 #ifndef ICPFLOW_TEAM_MIN_SHARE
 #define ICPFLOW_TEAM_MIN_SHARE 256
 #endif
 constexpr int kTeamMinShare = ICPFLOW_TEAM_MIN_SHARE;   // queries per member, at least
+constexpr int kTeamWaves = 768 / kWave;   // units per pass of a member
+
+// units per member at the level below `u`
+__device__ __forceinline__ int team_next_level(int u)
+{
+    if (u > kTeamWaves) return (u - 1) / kTeamWaves * kTeamWaves;   // one pass fewer
+    return u > 8 ? 8 : (u > 4 ? 4 : 0);
+}
+// relative length of an iteration at u units per member
+__device__ __forceinline__ float team_level_cost(int u)
+{
+    if (u >= kTeamWaves) return (float)((u + kTeamWaves - 1) / kTeamWaves);
+    return u > 8 ? 1.0f : (u > 4 ? 0.85f : 0.7f);
+}
 
 __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__restrict__ lenX,
                                                             const int32_t *__restrict__ lenY,
-                                                            const uint8_t *__restrict__ swap, int B, IcpTeam t)
+                                                            const uint8_t *__restrict__ swap, int B, IcpTeam t, int recCap)
 {
     __shared__ int size[256];
     __shared__ int first[257];
-    __shared__ long long total;
-    const int b = threadIdx.x;
+    __shared__ float keyW[4];
+    __shared__ int keyB[4];
+    __shared__ int sh[8];        // [0] small pairs, [1] sum of minimum teams, [2] sum of wishes, [3] chain length, [4] slots left, [5] winner
+    const int b = threadIdx.x, lane = b & (kWave - 1), wv = b >> 6;
     int n = 0, nf = 0;
     if (b < B) {
         const bool sw = swap != nullptr && swap[b] != 0;
         n = sw ? lenY[b] : lenX[b];
         nf = sw ? lenX[b] : lenY[b];
     }
-    // queries beyond one pass of a (768-thread) workgroup, weighted by the length of the fixed cloud: what a query costs
-    // grows with the targets inside its window, and the pairs iterate side by side towards one batch-global stop -- a
-    // dense 10^4 x 10^4 pair with two passes per member (132 k clocks per iteration) paces a batch whose mid-sized pairs
-    // have spare time
-    {
-        // (the square root: between no weight -- ragged real-shape batch with matched sizes 2.23 ms of ICP, with independent
-        // sizes 0.93 ms -- and the full ratio, 1.75 / 1.01 ms; with the root 1.72 / 0.99 ms; the demo frame does not move)
-        const long long w = (long long)((double)max(n - 768, 0) * sqrt((double)max(nf, 1024) / 1024.0));
-        size[b] = (int)min(w, (long long)0x3fffffff);
+    const int units = (n + kWave - 1) / kWave;
+    const bool small = b < B && units <= kTeamWaves;
+    // smallest team whose members keep their records; the team of one pass
+    int gMin = 1;
+    if (b < B && !small && recCap > 0) {
+        const int capUnits = max(recCap / kWave, 1);
+        gMin = min(kMaxTeam, (units + capUnits - 1) / capUnits);
     }
+    const int gWish = small ? 1 : min(kMaxTeam, (units + kTeamWaves - 1) / kTeamWaves);
+    // (the square root: between no weight and the full ratio of the fixed clouds' lengths, measured in round 3)
+    const float weight = (b < B && !small) ? sqrtf((float)max(nf, 1024) / 1024.0f) : 0.f;
     for (int w = threadIdx.x; w < t.maxWG; w += blockDim.x) { t.wgPair[w] = -1; t.wgRank[w] = 0; }
+    if (b < 8) sh[b] = 0;
     __syncthreads();
-    if (b < kWave) {   // (wave 0 adds the sizes: exact integers, any order)
-        long long s = 0;
-        for (int k = b; k < B; k += kWave) s += size[k];
+    {
+        int c0 = small ? 1 : 0, c1 = (b < B && !small) ? gMin : 0, c2 = (b < B && !small) ? max(gWish, gMin) : 0;
 #pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
-        if (b == 0) total = s;
+        for (int o = kWave / 2; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, kWave); c1 += __shfl_xor(c1, o, kWave); c2 += __shfl_xor(c2, o, kWave); }
+        if (lane == 0) { atomicAdd(&sh[0], c0); atomicAdd(&sh[1], c1); atomicAdd(&sh[2], c2); }
     }
     __syncthreads();
-    int G = 0;
-    if (b < B) {
-        const long long spare = t.maxWG - B;
-        G = 1 + (total > 0 ? (int)(spare * size[b] / total) : 0);
-        G = min(G, min(kMaxTeam, max(1, (n + kTeamMinShare - 1) / kTeamMinShare)));
+    const int nSmall = sh[0], nBig = B - nSmall;
+    if (b == 0) {
+        // chain the single-pass pairs only as far as the large pairs can use the workgroups: chain length c frees
+        // nSmall - ceil(nSmall / c) of them
+        int c = 1;
+        while (c < kTeamChain && nBig > 0 && t.maxWG - (nSmall + c - 1) / c < sh[2]) ++c;
+        sh[3] = c;
+        const int left = t.maxWG - (nSmall + c - 1) / c - sh[1];
+        sh[4] = left;     // < 0: not even the minimum teams fit: every pair one workgroup, no chains (B <= maxWG)
     }
     __syncthreads();
-    size[b] = G;
+    const bool fits = sh[4] >= 0;
+    const int chain = fits ? sh[3] : 1;
+    int G = (b < B) ? (fits ? gMin : 1) : 0;
+    int u = (b < B && !small) ? (units + G - 1) / G : 0;     // units per member now
+    // the spare workgroups, one level at a time, to the pair with the longest estimated iteration that can still move
+    if (fits && nBig > 0) {
+        bool open = b < B && !small;
+        for (int round = 0; round < 4 * 256; ++round) {
+            int gNext = 0, uNext = 0;
+            if (open) {
+                uNext = team_next_level(u);
+                gNext = uNext > 0 ? (units + uNext - 1) / uNext : 0;
+                if (uNext <= 0 || gNext > kMaxTeam || gNext <= G || n / gNext < kTeamMinShare) open = false;
+            }
+            float key = open ? team_level_cost(u) * weight : -1.f;
+            int who = b;
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) {
+                const float k2 = __shfl_xor(key, o, kWave);
+                const int w2 = __shfl_xor(who, o, kWave);
+                if (k2 > key || (k2 == key && w2 < who)) { key = k2; who = w2; }
+            }
+            if (lane == 0) { keyW[wv] = key; keyB[wv] = who; }
+            __syncthreads();
+            if (b == 0) {
+                float kb = keyW[0];
+                int wb = keyB[0];
+                for (int q = 1; q < 4; ++q)
+                    if (keyW[q] > kb || (keyW[q] == kb && keyB[q] < wb)) { kb = keyW[q]; wb = keyB[q]; }
+                sh[5] = kb > 0.f ? wb : -1;
+            }
+            __syncthreads();
+            const int win = sh[5];
+            if (win < 0) break;
+            if (b == win) {
+                if (gNext - G <= sh[4]) { sh[4] -= gNext - G; G = gNext; u = (units + G - 1) / G; }
+                else open = false;      // does not fit any more: the others may still
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // a chain of single-pass pairs is one workgroup: its first pair carries the slot, the others hang on t.next
+    {
+        size[b] = small ? 1 : 0;
+        __syncthreads();
+        int seq = 0;                    // this small pair's number among the small pairs (in pair order)
+        if (small) for (int k = 0; k < b; ++k) seq += size[k];
+        __syncthreads();
+        if (small) first[seq] = b;      // (first[] is scratch here: small pair number -> pair)
+        __syncthreads();
+        const bool head = small && (seq % chain) == 0;
+        if (b < B) t.next[b] = (small && seq + 1 < nSmall && (seq + 1) % chain != 0) ? first[seq + 1] : -1;
+        __syncthreads();
+        size[b] = (b < B) ? (small ? (head ? 1 : 0) : G) : 0;
+    }
     __syncthreads();
     // Workgroup w is dispatched to XCD w % 8, so slot k = (w % 8) * per + w / 8 enumerates the
     // workgroups XCD by XCD (per = maxWG / 8 of them each).  A team takes consecutive slots of ONE
@@ -1953,7 +2056,7 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     if (b < B) {
         t.teamSize[b] = G;
         t.arrived[b] = 0u;
-        for (int r = 0; r < G; ++r) {
+        for (int r = 0; r < size[b]; ++r) {
             const int k = first[b] + r;
             const int w = (per == t.maxWG) ? k : (k % per) * 8 + k / per;
             t.wgPair[w] = b;
@@ -2337,7 +2440,11 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         B <= 256 && (speculative || stopMode == ICPFLOW_STOP_PER_PAIR_)) {
         p.team = *team;
         p.team.maxWG = min(cus, team->maxWG);
-        hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, p.team);
+        // (records behind the LDS image of the padded length: what a member's share of the queries has to fit, see below)
+        const size_t imgT = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
+        const int recCapT = (p.sortY != nullptr && recWanted && N <= 12288 && imgT + 64 * 20 <= 152 * 1024)
+                                ? (int)((152 * 1024 - imgT) / 20 / 64 * 64) : 0;
+        hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, p.team, recCapT);
     }
     if (p.sortY != nullptr) {
         // room for the per-query records behind the LDS image: every query of a pair when one workgroup serves it,
@@ -2386,7 +2493,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
             p.history = history;
             p.persistent = opts.persistent ? 1 : 0;   // (one launch for all iterations: the ticket counter starts at zero)
             p.help = opts.help;
-            p.helpOn = opts.helpers ? 1 : 0;
+            p.helpOn = (opts.helpers && maxIter <= kHelpMaxEpoch - 2) ? 1 : 0;   // (always: maxIter <= kHistIters here)
             launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
             if (opts.historyPending != nullptr) {
                 *opts.historyPending = true;   // the consumers read the history themselves (posefuse.hpp)
@@ -2400,7 +2507,11 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     } else {
         p.persistent = opts.persistent ? 1 : 0;
         p.help = opts.help;
-        p.helpOn = opts.helpers ? 1 : 0;
+        // The hand-off words of the helper protocol carry the iteration epoch E = it + 1 in their low 8 bits
+        // ((workgroup << 8) | E in HelpPair::from, (pair << 8) | E in IcpHelp::tag): a per-pair launch may run up to
+        // kMaxIterCap iterations in one go, and an epoch past 255 would spill into the workgroup / pair bits.  The
+        // batch-global rule never gets there (one launch covers <= kHistIters = 128 iterations).
+        p.helpOn = (opts.helpers && maxIter <= kHelpMaxEpoch - 2) ? 1 : 0;
         launch_icp_iters(p, B, 0, maxIter, opts.profile, s);
     }
     return hipGetLastError();

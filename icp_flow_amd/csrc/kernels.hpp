@@ -52,6 +52,7 @@ struct HelpPair {          // 64 bytes, cleared with the control block at the st
     int pad[8];
 };
 constexpr int kHelpSlots = 3;
+constexpr int kHelpMaxEpoch = 255;   // the epoch E = iteration + 1 travels in the low 8 bits of HelpPair::from and IcpHelp::tag
 constexpr int kHelpMaxWG = 1024;              // workgroups of a persistent grid, at most
 constexpr int kHelpOutStride = 16 * 18;       // doubles per outbox: the moment sums of one pass, <= 16 waves x 18
 struct IcpHelp {
@@ -73,6 +74,7 @@ struct IcpTeam {
     int32_t *wgPair;        // [maxWG] pair served by workgroup w, -1 = none
     int32_t *wgRank;        // [maxWG] rank inside the team
     int32_t *teamSize;      // [B]
+    int32_t *next;          // [B] single-pass pairs chained on one workgroup: the pair served after pair b, -1 = none
     unsigned int *arrived;  // [B] members that have published (monotone over the launch)
     double *mom;            // [B, 2, kMaxTeam, kTeamStride]
     int maxWG;

@@ -446,8 +446,14 @@ def main(argv=None):
     ap.add_argument("directory")
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--in-flight", type=int, default=1, help="frame pairs registered at once (streams, one host thread)")
+    def flag(text):      # (type=bool would read every non-empty string, "False" included, as True)
+        if text.lower() in ("1", "true", "yes", "on"):
+            return True
+        if text.lower() in ("0", "false", "no", "off"):
+            return False
+        raise argparse.ArgumentTypeError(f"expected true/false, got {text!r}")
     for k, v in DEFAULT_ARGS.items():
-        kind = str if k == "cluster" else float if isinstance(v, float) or v is None else type(v)
+        kind = str if k == "cluster" else flag if isinstance(v, bool) else float if isinstance(v, float) or v is None else type(v)
         ap.add_argument("--" + k.replace("_", "-"), type=kind, default=v)
     ns = ap.parse_args(argv)
     import torch.distributed as dist

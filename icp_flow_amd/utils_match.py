@@ -235,8 +235,9 @@ def _finish_pairs(args, st, dt, launched):
     if iters[0] < 0:
         # a team of workgroups sharing one large pair gave up waiting for a member (include/icpflow_hip.h, a-5):
         # the transforms are NaN.  Never let that pass as "no match" -- the points would silently get ego flow only.
-        raise RuntimeError("icpflow_hist_icp abandoned the batch: a workgroup team timed out (GPU shared with another "
-                           "process?); retry, or register with _lib.options(no_teams=True)")
+        raise RuntimeError("icpflow_hist_icp abandoned the batch: a wait between workgroups timed out -- a team sharing one "
+                           "large pair, or a helper's hand-off in a persistent launch (GPU shared with another process?); "
+                           "retry, or register with _lib.options(no_teams=True, no_helpers=True, no_persistent=True)")
     keep = check_transformation(args, translations, rotations, np.minimum(ious[:, 0], ious[:, 1]))
     S, D = len(st.h_labels), len(dt.h_labels)
     if not keep.any():
@@ -274,10 +275,10 @@ def setdiff1d(t1, t2):
     if isinstance(t1, torch.Tensor):
         t12, counts = torch.cat([torch.unique(t1), torch.unique(t2)]).unique(return_counts=True)
         return t12[counts == 1]
-    u1 = np.unique(t1)
-    gone = np.zeros(len(u1), dtype=bool)
-    gone[np.searchsorted(u1, np.asarray(t2))] = True       # (t2 a subset of t1: the labels counted once are those of t1 alone)
-    return u1[~gone]
+    # (the labels counted once in unique(t1) ++ unique(t2), like the tensor branch and the reference: with t2 a subset of
+    # t1 -- the only way match_pcds calls it -- those are the labels of t1 alone; a label of t2 alone is kept too)
+    u1, u2 = np.unique(t1), np.unique(np.asarray(t2))
+    return np.concatenate([u1[~np.isin(u1, u2)], u2[~np.isin(u2, u1)]]) if len(u2) else u1
 
 
 def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, asynchronous=False):

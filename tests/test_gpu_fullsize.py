@@ -220,6 +220,23 @@ def test_ticket_dispatch_changes_nothing(shape):
         assert torch.equal(utils_match.hist_icp(a, s, d), utils_match.hist_icp(rp.default_args(max_points=S.shape[1], icp_max_iterations=50), s, d))
 
 
+def test_per_pair_stop_with_a_long_iteration_cap_keeps_the_helper_protocol_sound():
+    """the helper hand-off words carry the iteration epoch in 8 bits; ICPFLOW_STOP_PER_PAIR runs ONE persistent
+    launch of up to 1024 iterations, so a cap beyond 253 must not be served with helpers (launch_icp switches them off:
+    kHelpMaxEpoch).  A helper-eligible shape (more pairs than workgroup slots, several passes per pair) at
+    max_iterations = 512: finite, no abandoned team, and bit-identical to ICPFLOW_OPT_NO_HELPERS; the same at a cap of
+    200, where helpers do run."""
+    S, D, _ = synthetic.make_batch(900, 2048, seed=23, ragged=True, n_min=100)
+    s, d = G(S), G(D)
+    for cap in (512, 200):
+        a = rp.default_args(max_points=S.shape[1], icp_max_iterations=cap, icp_stop_mode="per_pair")
+        T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert int(it1) > 0 and torch.isfinite(T1).all()
+        with _lib.options(no_helpers=True):
+            T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert int(it0) == int(it1) and torch.equal(T0, T1)
+
+
 @pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_90x2048"])
 def test_scoring_variants_change_nothing(shape):
     """The six candidate translations are scored by sorted sweeps with branch and bound when hist_icp has the clouds

@@ -18,5 +18,8 @@ buf = (ctypes.c_longlong * 3072)(); _lib._L.icpflow_debug_tail_clock(buf)
 v = np.array(buf[:], dtype=np.int64).reshape(1024, 3)[:B]
 its = np.maximum(v[:, 2], 1)
 print(f"stop after {int(it.item())} iterations; pairs by clocks of member 0 (serial part + search / exchange):")
-for k in np.argsort(-(v[:, 0] + v[:, 1]))[:14]:
+for k in np.argsort(-(v[:, 0] + v[:, 1]))[:int(os.environ.get('TOP', '30'))]:
     print(f"   pair {k:3d}: {ns[k]:5d} x {nd[k]:5d} points, {v[k, 2]:3d} iterations, per iteration: serial {v[k, 0] / its[k]:7.0f} clocks, search + exchange {v[k, 1] / its[k]:7.0f}")
+tot = v[:, 0] + v[:, 1]
+print("pairs by executed iterations:", np.bincount(np.minimum(v[:, 2], 100) // 10).tolist(), "(bins of 10)")
+print("total clocks per pair: median %.0f, p90 %.0f, max %.0f (%.3f ms at 2.4 GHz)" % (np.median(tot), np.percentile(tot, 90), tot.max(), tot.max() / 2.4e6))
