@@ -375,6 +375,10 @@ constexpr int kProbeSteps = ICPFLOW_PROBE_STEPS;
 #define ICPFLOW_PROBE_STEPS_LONG 24
 #endif
 constexpr int kProbeMaxLong = ICPFLOW_PROBE_MAX_LONG, kProbeStepsLong = ICPFLOW_PROBE_STEPS_LONG;
+#ifndef ICPFLOW_PROBE_CAP
+#define ICPFLOW_PROBE_CAP 128
+#endif
+constexpr int kProbeCap = ICPFLOW_PROBE_CAP;   // entries of a pass's shared probe queue (teams; 28 B of LDS each)
 constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
 // ---------------------------------------------------------------------------------
@@ -498,6 +502,10 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     static_assert(!HELP || (GRID == 4 && !TEAM && Q == 1), "helpers: sorted sweep with the LDS image, one workgroup per pair");
     __shared__ int helpSh[8];                 // [0] passes done by helpers this iteration (bit g), [1..3] their workgroups,
                                               // [4] helper: E(next iteration), [5] scratch
+    // teams: the probes of a pass, shared by the member's waves (see the search phase)
+    __shared__ float probeQ[4][TEAM && GRID == 4 ? kProbeCap : 1];   // (query position, previous neighbour)
+    __shared__ float probeR[3][TEAM && GRID == 4 ? kProbeCap : 1];   // (distance, bound on the others, neighbour)
+    __shared__ int probeCnt[2], probeNext[2]; // entries posted / handed out, by pass parity
     [[maybe_unused]] const bool helping = HELP && role != 0;
     [[maybe_unused]] HelpPair *hp = nullptr;
     if constexpr (HELP) hp = (p.helpOn && p.help.pair != nullptr) ? p.help.pair + b : nullptr;
@@ -558,6 +566,8 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
         if (tid == 0) { bcast[12] = active ? 1.f : 0.f; bcast[13] = st->rmse; bcast[14] = st->rmse; bcast[15] = st->s; }
     }
     int itersDone = (itBegin == 0) ? 0 : st->iters;
+    if (tid == 0) { probeCnt[0] = 0; probeCnt[1] = 0; probeNext[0] = 0; probeNext[1] = 0; }
+    [[maybe_unused]] int probePar = 0;   // parity of the next pass's queue counters (workgroup-uniform)
 
     // per-pair origin of the moment accumulation: the first (pre-posed) source point
     if (tid == 0) {
@@ -846,6 +856,173 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 // 1.01 thres; otherwise the range grows by 64 targets on its short side, up to kProbeSteps (kProbeStepsLong) times.
                 // Inconclusive probes, equal minima (the first-index rule is the scan's business), queries without a
                 // previous neighbour and waves with many uncertified lanes take the window scan.
+                ScanAcc<Q> acc;
+                bool tie[Q];
+                float second[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { tie[q] = false; second[q] = kInf; }
+                scan_init(acc);
+                int cb = 0, ce = 0;
+                // the window scan of this wave: the part of the sort axis in which its searching queries can find their neighbours
+                auto scan_window = [&]() {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
+                        if (live[q] && recM[q] >= 0.f) { lo = fminf(lo, qa - recM[q]); hi = fmaxf(hi, qa + recM[q]); }
+                    }
+                    ICPFLOW_STAMP(11);
+                    bool anyScan = false;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) anyScan = anyScan || __ballot(live[q] && recM[q] >= 0.f) != 0ull;
+                    if (anyScan) {
+                        lo = wave_min_uniform(lo);
+                        hi = wave_max_uniform(hi);
+                    }
+                    if (lo <= hi) {  // wave has searching queries (wave-uniform)
+                        // single pass: this wave's window of the previous iteration is the hint
+                        int jlo = winLo, jhi = winHi;
+                        if (ngr == 1 && winHi >= 0)
+                            sorted_window_hint(keyf, yc.n, lo, hi, lane, jlo, jhi);
+                        else
+                            sorted_window(keyf, yc.n, lo, hi, lane, jlo, jhi);
+                        winLo = jlo; winHi = jhi;
+                        cb = (jlo / kChunk) * kChunk;
+                        ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
+                        ICPFLOW_STAMP(12);
+#ifdef ICPFLOW_PHASE_TIMING
+                        if ((int)blockIdx.x == g_stamp_block && lane == 0) g_wave_stamps[wave * 16 + 15] = ce - cb;
+#endif
+                        if (GRID == 4) {
+                            if (REC && recOn)
+                                scan_range_tie<Q, true>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
+                                                        reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie, second);
+                            else
+                                scan_range_tie<Q>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
+                                                  reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie);
+                        } else
+                            scan_range_tie_uniform<Q>(gx, gy, gz, cb, ce, qx, qy, qz, acc, tie);
+                    }
+                };
+                bool scanNow = true;      // no shared probes in this pass: the wave scans right here (if it has searching queries)
+                if constexpr (TEAM) {
+                if (REC && recOn && it > itFirst) {
+                    const bool longProbes = ngr > 1 || yc.n > 1024;   // (team members: one pass each, but of a long cloud)
+                    // (and every lane of the wave where the alternative is a scan of a long window of a long cloud: this wave's window
+                    // of the previous search held more than 512 targets -- a dense 10000-point cluster; on the ragged real-shape
+                    // batch the ICP launch 1.33 -> 0.94 ms; the demo frame's wall, long but thin, keeps its short windows and 32)
+                    const bool wideWindows = yc.n > 4096 && winHi - winLo > 512;
+                    const int probeSteps = longProbes ? kProbeStepsLong : kProbeSteps;
+                    const int probeMax = longProbes ? (wideWindows ? kWave : kProbeMaxLong) : kProbeMax;
+                    // Round 4: the probes of a pass are SHARED by the workgroup.  The uncertified queries are few, but they
+                    // cluster: where the pair still slides along a face, one wave holds twenty of them and its neighbours
+                    // none, and the pass lasted as long as that wave's three rounds of probes while fifteen waves waited at
+                    // the barrier behind the moments.  So every wave posts its uncertified queries (position, previous
+                    // neighbour) to a queue in LDS, and after a barrier the waves serve the queue, eight entries at a time
+                    // drawn from a ticket, each entry by a row of eight lanes exactly as before; the answers go back through
+                    // LDS.  A wave that has to scan its window anyway -- more uncertified lanes than probes pay for, or a lane
+                    // without a previous neighbour -- posts nothing and scans WHILE the others probe (then takes what tickets
+                    // are left).  A probe's answer depends on its entry alone: which wave served it changes nothing.
+                    static_assert(Q == 1, "teams: one query per lane");
+                    const bool wants = live[0] && recM[0] >= 0.f && certJ[0] >= 0;
+                    const unsigned long long need = __ballot(wants);
+                    const int nNeed = __popcll(need);
+                    const bool mustScan = nNeed > probeMax || __ballot(live[0] && recM[0] >= 0.f && certJ[0] < 0) != 0ull;
+                    int myEntry = -1;
+                    if (!mustScan && nNeed > 0) {   // (wave-uniform)
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&probeCnt[probePar], nNeed);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const int e = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+                        if (wants && e < kProbeCap) {        // (a full queue leaves the query to the window scan)
+                            probeQ[0][e] = qx[0]; probeQ[1][e] = qy[0]; probeQ[2][e] = qz[0]; probeQ[3][e] = __int_as_float(certJ[0]);
+                            myEntry = e;
+                        }
+                    }
+                    barrier_lds_only();
+                    const int posted = min(__builtin_amdgcn_readfirstlane(probeCnt[probePar]), kProbeCap);
+                    if (tid == 0) { probeCnt[probePar ^ 1] = 0; probeNext[probePar ^ 1] = 0; }   // the next pass's (last read a whole pass ago)
+                    if (mustScan) scan_window();
+                    const int row = lane >> 3, li = lane & 7;
+                    for (;;) {
+                        int e0 = 0;
+                        if (lane == 0) e0 = atomicAdd(&probeNext[probePar], 8);
+                        e0 = __builtin_amdgcn_readfirstlane(e0);
+                        if (e0 >= posted) break;
+                        const int ent = e0 + row;
+                        const bool rowOn = ent < posted;
+                        const int entC = min(ent, kProbeCap - 1);
+                        const float sx = probeQ[0][entC], sy = probeQ[1][entC], sz = probeQ[2][entC];
+                        const int j1 = rowOn ? __float_as_int(probeQ[3][entC]) : 0;
+                        const float qa = axis == 0 ? sx : (axis == 1 ? sy : sz);
+                        int a = min(max((j1 & ~7) - 32, 0), max(np16 - 64, 0));   // evaluated so far: [a, bEnd)
+                        int bEnd = a + 64;
+                        int bs = a, be = bEnd;                                    // this step's block
+                        float lb = kInf, lsec = kInf;                             // this lane's minimum and runner-up
+                        int lslot = 0;
+                        bool done = !rowOn, ok = false, isNN = false;
+                        float rowbest = kInf, rho = 0.f;
+                        for (int step = 0; step < probeSteps; ++step) {
+                            const int t0 = bs + 8 * li;
+                            if (!done && t0 < be && t0 < np16) {
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {     // (four targets at a time: twelve registers of targets, not twenty-four)
+                                    const float4 xa = *reinterpret_cast<const float4 *>(lx + t0 + 4 * h);
+                                    const float4 ya = *reinterpret_cast<const float4 *>(ly + t0 + 4 * h);
+                                    const float4 za = *reinterpret_cast<const float4 *>(lz + t0 + 4 * h);
+                                    const float txs[4] = {xa.x, xa.y, xa.z, xa.w};
+                                    const float tys[4] = {ya.x, ya.y, ya.z, ya.w};
+                                    const float tzs[4] = {za.x, za.y, za.z, za.w};
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float d = sqdist(sx, sy, sz, txs[e], tys[e], tzs[e]);
+                                        const bool lt = d < lb;
+                                        lsec = lt ? lb : min_nonneg(lsec, d);
+                                        lslot = lt ? t0 + 4 * h + e : lslot;
+                                        lb = lt ? d : lb;
+                                    }
+                                }
+                            }
+                            rowbest = row8_min_nonneg(lb);
+                            const float kLo = a > 0 ? keyf[a] : -kInf;
+                            const float kHi = bEnd < np16 ? keyf[bEnd - 1] : kInf;   // (+inf padding past the last target)
+                            const float rL = qa - kLo, rR = kHi - qa;
+                            rho = fminf(rL, rR) * 0.9999f - 1e-6f;
+                            const bool nn = rho > 0.f && rho * rho > rowbest * 1.000003f;
+                            const bool out = !(rowbest <= p.thr2) && rho > gateOut;
+                            if (!done) {
+                                if (nn || out) { done = true; ok = true; isNN = nn; }
+                                else if (step + 1 == probeSteps) done = true;
+                                else if (rL < rR) { be = a; bs = max(a - 64, 0); a = bs; }   // (a > 0: rL is finite)
+                                else { bs = bEnd; be = bEnd + 64; bEnd = be; }               // (bEnd < np16: rR is finite)
+                            }
+                            if (__ballot(!done) == 0ull) break;
+                        }
+                        // the row's winner: exactly one lane may hold the minimum, and only once
+                        const bool isW = rowOn && lb == rowbest;
+                        const unsigned long long wm = __ballot(isW);
+                        const int cnt = __popc((unsigned)(wm >> (lane & ~7)) & 0xffu);
+                        const float secv = row8_min_nonneg(isW ? lsec : lb);
+                        const int slot = row8_min(isW ? lslot : 0x7fffffff);
+                        ok = ok && cnt == 1 && secv > rowbest;
+#ifdef ICPFLOW_CERT_STATS
+                        if (li == 0 && rowOn && it < 128 && (g_stats_block < 0 || g_stats_block == (int)blockIdx.x)) { atomicAdd(&g_probe_stats[it * 2], 1ull); atomicAdd(&g_probe_stats[it * 2 + 1], ok ? 1ull : 0ull); }
+#endif
+                        // the answer: (certified squared distance or inf, bound on every other target, the neighbour's slot or -1)
+                        if (rowOn && li == 0) {
+                            probeR[0][ent] = isNN ? rowbest : kInf;
+                            probeR[1][ent] = fminf(__builtin_amdgcn_sqrtf(secv), rho);
+                            probeR[2][ent] = __int_as_float(ok ? slot : -1);
+                        }
+                    }
+                    probePar ^= 1;
+                    barrier_lds_only();
+                    if (myEntry >= 0) {
+                        const int rSlot = __float_as_int(probeR[2][myEntry]);
+                        if (rSlot >= 0) { recM[0] = -1.f; certD[0] = probeR[0][myEntry]; certJ[0] = rSlot; newL[0] = probeR[1][myEntry]; }
+                    }
+                    scanNow = !mustScan;   // (an inconclusive probe, or a full queue, leaves its query to the scan)
+                }
+                } else {
                 if (REC && recOn && it > itFirst) {
                     const bool longProbes = ngr > 1 || yc.n > 1024;   // (team members: one pass each, but of a long cloud)
                     // (and every lane of the wave where the alternative is a scan of a long window of a long cloud: this wave's window
@@ -934,54 +1111,8 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         }
                     }
                 }
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
-                    if (live[q] && recM[q] >= 0.f) { lo = fminf(lo, qa - recM[q]); hi = fmaxf(hi, qa + recM[q]); }
                 }
-                ICPFLOW_STAMP(11);
-                // the part of the sort axis in which this wave's searching queries can find their neighbours
-                bool anyScan = false;
-#pragma unroll
-                for (int q = 0; q < Q; ++q) anyScan = anyScan || __ballot(live[q] && recM[q] >= 0.f) != 0ull;
-                if (anyScan) {
-                    lo = wave_min_uniform(lo);
-                    hi = wave_max_uniform(hi);
-                }
-                ScanAcc<Q> acc;
-                bool tie[Q];
-                float second[Q];
-#pragma unroll
-                for (int q = 0; q < Q; ++q) { tie[q] = false; second[q] = kInf; }
-                scan_init(acc);
-                int cb = 0, ce = 0;
-                if (lo <= hi) {  // wave has searching queries (wave-uniform)
-                    // single pass: this wave's window of the previous iteration is the hint
-                    int jlo = winLo, jhi = winHi;
-                    if (ngr == 1 && winHi >= 0)
-                        sorted_window_hint(keyf, yc.n, lo, hi, lane, jlo, jhi);
-                    else
-                        sorted_window(keyf, yc.n, lo, hi, lane, jlo, jhi);
-                    winLo = jlo; winHi = jhi;
-                    cb = (jlo / kChunk) * kChunk;
-                    ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
-                    ICPFLOW_STAMP(12);
-#ifdef ICPFLOW_PHASE_TIMING
-                    if ((int)blockIdx.x == g_stamp_block && lane == 0) g_wave_stamps[wave * 16 + 15] = ce - cb;
-#endif
-                    if (GRID == 4) {
-                        if (REC && recOn)
-                            scan_range_tie<Q, true>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
-                                                    reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie, second);
-                        else
-                            scan_range_tie<Q>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
-                                              reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie);
-                    } else
-                        scan_range_tie_uniform<Q>(gx, gy, gz, cb, ce, qx, qy, qz, acc, tie);
-                }
-#ifdef ICPFLOW_PHASE_TIMING
-                else if ((int)blockIdx.x == g_stamp_block && lane == 0) g_wave_stamps[wave * 16 + 15] = 0;
-#endif
+                if (scanNow) scan_window();
 #ifdef ICPFLOW_TAIL_CLOCK
                 if (b == g_unit_pair && it < 64 && g < 8 && wave < 16) {
                     int nsearch = 0;
@@ -1927,9 +2058,10 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
 {
     __shared__ int size[256];
     __shared__ int first[257];
-    __shared__ float keyW[4];
-    __shared__ int keyB[4];
-    __shared__ int sh[8];        // [0] small pairs, [1] sum of minimum teams, [2] sum of wishes, [3] chain length, [4] slots left, [5] winner
+    __shared__ int part[4];
+    __shared__ int sh[8];        // [0] small pairs, [1] sum of minimum teams, [2] sum of wishes, [3] chain length, [4] slots for the large pairs
+    __shared__ int teamList[256];
+    __shared__ int xcdUsed[8];
     const int b = threadIdx.x, lane = b & (kWave - 1), wv = b >> 6;
     int n = 0, nf = 0;
     if (b < B) {
@@ -1939,78 +2071,99 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     }
     const int units = (n + kWave - 1) / kWave;
     const bool small = b < B && units <= kTeamWaves;
+    const bool big = b < B && !small;
     // smallest team whose members keep their records; the team of one pass
     int gMin = 1;
-    if (b < B && !small && recCap > 0) {
+    if (big && recCap > 0) {
         const int capUnits = max(recCap / kWave, 1);
         gMin = min(kMaxTeam, (units + capUnits - 1) / capUnits);
     }
     const int gWish = small ? 1 : min(kMaxTeam, (units + kTeamWaves - 1) / kTeamWaves);
     // (the square root: between no weight and the full ratio of the fixed clouds' lengths, measured in round 3)
-    const float weight = (b < B && !small) ? sqrtf((float)max(nf, 1024) / 1024.0f) : 0.f;
+    const float weight = big ? sqrtf((float)max(nf, 1024) / 1024.0f) : 0.f;
     for (int w = threadIdx.x; w < t.maxWG; w += blockDim.x) { t.wgPair[w] = -1; t.wgRank[w] = 0; }
     if (b < 8) sh[b] = 0;
     __syncthreads();
+    // block-wide sum of one int per thread (all threads call it)
+    auto block_sum_int = [&](int v) -> int {
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+        __syncthreads();
+        if (lane == 0) part[wv] = v;
+        __syncthreads();
+        return part[0] + part[1] + part[2] + part[3];
+    };
+    const int nSmall = block_sum_int(small ? 1 : 0), nBig = B - nSmall;
+    const int sumMin = block_sum_int(big ? gMin : 0);
+    const int sumWish = block_sum_int(big ? max(gWish, gMin) : 0);
+    // chain the single-pass pairs only as far as the large pairs can use the workgroups: chain length c frees
+    // nSmall - ceil(nSmall / c) of them
+    int chain = 1;
+    while (chain < kTeamChain && nBig > 0 && t.maxWG - (nSmall + chain - 1) / chain < sumWish) ++chain;
+    int slots = t.maxWG - (nSmall + chain - 1) / chain;     // workgroups for the large pairs
+    const bool fits = slots >= sumMin;       // not even the minimum teams: every pair one workgroup, no chains (B <= maxWG)
+    if (!fits) { chain = 1; slots = t.maxWG - nSmall; }
+    // The levels this pair's team can take: (workgroups, estimated length of an iteration), from its minimum team down the
+    // levels of units per member.  The spare workgroups go where they shorten the LONGEST estimated iteration: the
+    // smallest bound tau such that every pair brought down to tau (or as far as it can go) still fits, by bisection
+    // over the levels' costs (a block-wide sum per step), then what is left over to the pairs just above, in pair order.
+    constexpr int kLevels = 8;
+    int lvG[kLevels];          // (every loop over the levels is fully unrolled: the tables stay in registers)
+    float lvC[kLevels];
+    int gLast = 0;
     {
-        int c0 = small ? 1 : 0, c1 = (b < B && !small) ? gMin : 0, c2 = (b < B && !small) ? max(gWish, gMin) : 0;
+        int G = fits ? gMin : 1;
+        int u = (units + G - 1) / G;
+        bool open = big;
 #pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, kWave); c1 += __shfl_xor(c1, o, kWave); c2 += __shfl_xor(c2, o, kWave); }
-        if (lane == 0) { atomicAdd(&sh[0], c0); atomicAdd(&sh[1], c1); atomicAdd(&sh[2], c2); }
+        for (int k = 0; k < kLevels; ++k) {
+            lvG[k] = G; lvC[k] = open ? team_level_cost(u) * weight : 3.0e38f;
+            if (open) gLast = G;
+            const int uNext = team_next_level(u);
+            const int gNext = uNext > 0 ? (units + uNext - 1) / uNext : 0;
+            open = open && uNext > 0 && gNext <= kMaxTeam && gNext > G && n / max(gNext, 1) >= kTeamMinShare;
+            if (open) { G = gNext; u = (units + G - 1) / G; }
+        }
     }
-    __syncthreads();
-    const int nSmall = sh[0], nBig = B - nSmall;
-    if (b == 0) {
-        // chain the single-pass pairs only as far as the large pairs can use the workgroups: chain length c frees
-        // nSmall - ceil(nSmall / c) of them
-        int c = 1;
-        while (c < kTeamChain && nBig > 0 && t.maxWG - (nSmall + c - 1) / c < sh[2]) ++c;
-        sh[3] = c;
-        const int left = t.maxWG - (nSmall + c - 1) / c - sh[1];
-        sh[4] = left;     // < 0: not even the minimum teams fit: every pair one workgroup, no chains (B <= maxWG)
-    }
-    __syncthreads();
-    const bool fits = sh[4] >= 0;
-    const int chain = fits ? sh[3] : 1;
-    int G = (b < B) ? (fits ? gMin : 1) : 0;
-    int u = (b < B && !small) ? (units + G - 1) / G : 0;     // units per member now
-    // the spare workgroups, one level at a time, to the pair with the longest estimated iteration that can still move
-    if (fits && nBig > 0) {
-        bool open = b < B && !small;
-        for (int round = 0; round < 4 * 256; ++round) {
-            int gNext = 0, uNext = 0;
-            if (open) {
-                uNext = team_next_level(u);
-                gNext = uNext > 0 ? (units + uNext - 1) / uNext : 0;
-                if (uNext <= 0 || gNext > kMaxTeam || gNext <= G || n / gNext < kTeamMinShare) open = false;
-            }
-            float key = open ? team_level_cost(u) * weight : -1.f;
-            int who = b;
+    auto teams_at = [&](float tau) -> int {      // this pair's team under the bound tau: the first level that meets it, or its last
+        int G = gLast;
 #pragma unroll
-            for (int o = kWave / 2; o > 0; o >>= 1) {
-                const float k2 = __shfl_xor(key, o, kWave);
-                const int w2 = __shfl_xor(who, o, kWave);
-                if (k2 > key || (k2 == key && w2 < who)) { key = k2; who = w2; }
-            }
-            if (lane == 0) { keyW[wv] = key; keyB[wv] = who; }
+        for (int k = kLevels - 1; k >= 0; --k)
+            if (lvC[k] <= tau) G = lvG[k];
+        return big ? G : 0;
+    };
+    int G = b < B ? 1 : 0;
+    if (nBig > 0) {
+        // bisection on tau between 0 (everybody at its last level) and the largest first-level cost
+        float hiC = big ? lvC[0] : 0.f;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) hiC = fmaxf(hiC, __shfl_xor(hiC, o, kWave));
+        __syncthreads();
+        if (lane == 0) part[wv] = __float_as_int(hiC);
+        __syncthreads();
+        float hi = fmaxf(fmaxf(__int_as_float(part[0]), __int_as_float(part[1])), fmaxf(__int_as_float(part[2]), __int_as_float(part[3])));
+        float lo = 0.f;
+        // (hi always fits: every pair at its first level is sumMin <= slots, or one workgroup each)
+        for (int step = 0; step < 14; ++step) {
+            const float mid = 0.5f * (lo + hi);
+            if (block_sum_int(teams_at(mid)) <= slots) hi = mid; else lo = mid;
+        }
+        G = big ? teams_at(hi) : G;
+        // left-over workgroups: one more level for the pairs that can take one, in pair order
+        int left = slots - block_sum_int(big ? G : 0);
+        if (left > 0) {
+            int want = 0;
+#pragma unroll
+            for (int k = 0; k + 1 < kLevels; ++k)
+                if (big && lvG[k] == G && lvC[k + 1] < 3.0e38f && want == 0) want = lvG[k + 1] - G;
+            size[b] = want;
             __syncthreads();
-            if (b == 0) {
-                float kb = keyW[0];
-                int wb = keyB[0];
-                for (int q = 1; q < 4; ++q)
-                    if (keyW[q] > kb || (keyW[q] == kb && keyB[q] < wb)) { kb = keyW[q]; wb = keyB[q]; }
-                sh[5] = kb > 0.f ? wb : -1;
-            }
-            __syncthreads();
-            const int win = sh[5];
-            if (win < 0) break;
-            if (b == win) {
-                if (gNext - G <= sh[4]) { sh[4] -= gNext - G; G = gNext; u = (units + G - 1) / G; }
-                else open = false;      // does not fit any more: the others may still
-            }
+            int before = 0;
+            for (int k = 0; k < b; ++k) before += size[k];
+            if (want > 0 && before + want <= left) G += want;
             __syncthreads();
         }
     }
-    __syncthreads();
     // a chain of single-pass pairs is one workgroup: its first pair carries the slot, the others hang on t.next
     {
         size[b] = small ? 1 : 0;
@@ -2029,28 +2182,53 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     // Workgroup w is dispatched to XCD w % 8, so slot k = (w % 8) * per + w / 8 enumerates the
     // workgroups XCD by XCD (per = maxWG / 8 of them each).  A team takes consecutive slots of ONE
     // XCD (its exchange stays inside one L2); teams go to the XCD with the most free slots, which
-    // spreads the launch over all eight L2s.
+    // spreads the launch over all eight L2s.  Only the teams of several members go through that (serial) loop; the
+    // single workgroups then fill what is left, XCD by XCD.
     const int per = (t.maxWG % 8 == 0) ? t.maxWG / 8 : t.maxWG;
+    const int nx = (per == t.maxWG) ? 1 : 8;
+    int teamNo = 0, singleNo = 0;       // this pair's number among the teams / the single workgroups (in pair order)
+    for (int k = 0; k < b; ++k) { teamNo += size[k] > 1 ? 1 : 0; singleNo += size[k] == 1 ? 1 : 0; }
+    if (b < B && size[b] > 1) teamList[teamNo] = b;
+    const int nTeams = block_sum_int((b < B && size[b] > 1) ? 1 : 0);
     if (b == 0) {
         int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int nx = (per == t.maxWG) ? 1 : 8;
         bool ok = true;
-        for (int k = 0; k < B && ok; ++k) {
+        for (int k = 0; k < nTeams && ok; ++k) {
             // (the least-used XCD, first one on ties; the counters stay in registers: no indexing by a variable)
             int x = 0, ux = used[0];
 #pragma unroll
             for (int c = 1; c < 8; ++c)
                 if (c < nx && used[c] < ux) { x = c; ux = used[c]; }
-            const int sz = size[k];
+            const int sz = size[teamList[k]];
             if (ux + sz > per) ok = false;
-            first[k] = x * per + ux;
+            first[teamList[k]] = x * per + ux;
 #pragma unroll
             for (int c = 0; c < 8; ++c) used[c] += (c == x) ? sz : 0;
         }
         if (!ok) {   // does not fit XCD by XCD: plain packing (teams may span two XCDs)
             int acc = 0;
-            for (int k = 0; k < B; ++k) { first[k] = acc; acc += size[k]; }
+            for (int k = 0; k < nTeams; ++k) { first[teamList[k]] = acc; acc += size[teamList[k]]; }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) used[c] = 0;
+            for (int c = 0; c < 8; ++c) { const int take = min(max(acc - c * per, 0), per); xcdUsed[c] = (c < nx) ? take : per; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xcdUsed[c] = (c < nx) ? used[c] : per;
         }
+    }
+    __syncthreads();
+    if (b < B && size[b] == 1) {
+        // the singleNo-th single workgroup: the singleNo-th free slot, XCD by XCD
+        int skip = singleNo, slot = -1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int freeC = per - xcdUsed[c];
+            if (slot < 0 && c < nx) {
+                if (skip < freeC) slot = c * per + xcdUsed[c] + skip;
+                else skip -= freeC;
+            }
+        }
+        first[b] = slot;    // (>= 0: the plan never hands out more workgroups than there are)
     }
     __syncthreads();
     if (b < B) {
@@ -2059,8 +2237,7 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
         for (int r = 0; r < size[b]; ++r) {
             const int k = first[b] + r;
             const int w = (per == t.maxWG) ? k : (k % per) * 8 + k / per;
-            t.wgPair[w] = b;
-            t.wgRank[w] = r;
+            if (first[b] >= 0 && w < t.maxWG) { t.wgPair[w] = b; t.wgRank[w] = r; }
         }
     }
 }
