@@ -125,9 +125,21 @@ def test_config2_full_batch_vs_oracle(config2):
     # the reference's own fp32 arithmetic (torch's and pairwise summation order): the north-star bound on every pair it
     # pins; a pair outside the bound must be one of the oracle's own undetermined pairs (a report on ITS rounding:
     # every pair is pinned by the line above and, step by step against the fp32 oracle, by tests/test_gpu_onestep.py)
-    assert determined.sum() >= 256 - 16, msg
+    # Measured on the MI355X box's host (32 threads): 247 determined pairs, the other nine are
+    # [47, 69, 88, 115, 127, 129, 169, 182, 215]; four of them (215, 47, 69, 129) end up more than 1e-4 m from the
+    # torch-order fp32 evaluation (5.4 mm at most), three from the pairwise-order one (0.52 mm at most) -- and the two
+    # fp32 evaluations of the oracle are as far from each other.  The bounds below are those counts + 2 and hard ceilings
+    # on what the excused pairs may hide (COVERAGE.md "named deviations"; the reference's CUDA tree reductions are a third
+    # fp32 evaluation of the same trajectory).
+    undetermined = np.nonzero(~determined)[0]
+    print("excused pairs (oracle's fp32 / fp64 evaluations disagree):",
+          [(int(k), f"{err32[k]:.2e}", f"{errtr[k]:.2e}", f"{err64[k]:.2e}") for k in undetermined])
+    assert determined.sum() >= 256 - 11, msg
     assert err32[determined].max() < TOL_M and errtr[determined].max() < TOL_M, msg
-    assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(np.nonzero(~determined)[0]), msg
+    assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(undetermined), msg
+    assert (err32 >= TOL_M).sum() <= 6 and (errtr >= TOL_M).sum() <= 5, msg
+    if len(undetermined):
+        assert err32[undetermined].max() < 1e-2 and errtr[undetermined].max() < 2e-3, msg
 
 
 def test_config2_full_batch_fp32_reference_arithmetic(config2):
@@ -510,8 +522,16 @@ def test_config4_shape_64_pair_batch_vs_oracle(config4_shard):
     assert err64.max() < 1e-5, msg               # every pair, no mask, against the exact evaluation of the oracle
     # the reference's fp32 arithmetic: every pair it pins (every pair runs into the cap of 50 here: more of them are still
     # moving, and fp32 summation order decides where those end up -- a report on the oracle's rounding, see config 2)
+    # (measured on the MI355X box's host, 32 threads: 56 determined pairs of 64, three pairs -- 45, 7, 57 -- beyond 1e-4 m of
+    # the torch-order fp32 evaluation, 0.6 mm at most: counts + 2, and a ceiling on the excused pairs)
+    undetermined = np.nonzero(~determined)[0]
+    print("excused pairs:", [(int(k), f"{err32[k]:.2e}", f"{err64[k]:.2e}") for k in undetermined])
+    assert determined.sum() >= 64 - 10, msg
     assert err32[determined].max() < TOL_M, msg
-    assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(np.nonzero(~determined)[0]), msg
+    assert set(np.nonzero(err32 >= TOL_M)[0]) <= set(undetermined), msg
+    assert (err32 >= TOL_M).sum() <= 5, msg
+    if len(undetermined):
+        assert err32[undetermined].max() < 2e-3, msg
 
 
 # ------------------------------------------------------------------------------------------ p = len (no clamp)
