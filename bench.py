@@ -39,7 +39,8 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_LANE_OPS = 78.6e12    # 256 CU x 128 fp32 lanes x 2.4 GHz; 157.3 TFLOP/s counting fma = 2
 LANE_OPS_PER_EVAL = 8           # one 3-D squared distance + compare = 8 lane-ops
-COUNTERS_FILE = os.path.join(REPO, "profiles", "r03_icp_kernel_counters.json")
+COUNTERS_FILE = os.path.join(REPO, "profiles", "r04_icp_kernel_counters.json")
+RAGGED_COUNTERS_FILE = os.path.join(REPO, "profiles", "r04_ragged_counters.json")
 
 
 def parse():
@@ -473,13 +474,61 @@ def ragged_real_shape(dev, B=128, N=10000, cap=100, sizes=True):
     ms_icp, _ = timeit(lambda: utils_icp.apply_icp(args, src, dst, init))
     ms_eval, _ = timeit(lambda: utils_match.match_eval(args, src, dst, T))
     n = (S[:, :, 3] > 0).sum(1), (D[:, :, 3] > 0).sum(1)
+    roof = ragged_roofline(n[0], n[1], int(iters.item()), icp_ms / 6, ms, "matched" if sizes == "matched" else "independent", _lib.BUILD_INFO)
     how = ("both clouds of a pair draw their sizes independently" if sizes is True else
            "n_dst = n_src * U(0.8, 1.25): the same object from two ranges, as candidate pairs are after sanity_check")
     return {"workload": f"{B} cluster pairs, n ~ logUniform(20, {N}) padded to {N} ({how}), <= {cap} ICP iterations (reference stop)",
             "points_per_cluster_median": int(np.median(np.concatenate(n))), "points_per_cluster_max": int(max(n[0].max(), n[1].max())),
             "registrations_per_s": round(B / ms * 1e3, 1), "ms_per_batch": round(ms, 3), "icp_iterations": int(iters.item()),
             "icp_kernel_ms_per_batch": round(icp_ms / 6, 3),   # (6 calls: one warm-up + 5 timed)
-            "split_ms": {"estimate_init_pose": round(ms_init, 3), "apply_icp": round(ms_icp, 3), "match_eval": round(ms_eval, 3)}}
+            "split_ms": {"estimate_init_pose": round(ms_init, 3), "apply_icp": round(ms_icp, 3), "match_eval": round(ms_eval, 3)},
+            "roofline": roof}
+
+
+def ragged_roofline(ns, nd, iters, icp_ms, batch_ms, sizes, build):
+    """Roofline of the ragged real-shape batch, in SURVEY 8(d)'s terms with the VALID lengths of every
+    pair (not the padded width): per scan P_b = (n_s + n_d) * 16 B and E_b = n_s * n_d pair-evaluations; the ICP launch
+    runs I iterations of the batch rule, a registration 15 + I scans.  HBM contract figure = algorithmic bytes of the ICP
+    launch / its duration (HIP events on its stream); the roofline that binds is VALU (the counters: SQ_INSTS_VALU x 64
+    lanes against 256 CU x 128 lanes x 2.4 GHz), from profiles/r04_ragged_counters.json when it describes this build."""
+    ns, nd = ns.astype(np.int64), nd.astype(np.int64)
+    P, E = int(((ns + nd) * 16).sum()), int((ns * nd).sum())
+    sec = icp_ms * 1e-3
+    alg_bytes_icp = P * iters
+    out = {"bound": "valu", "kernel": "icp_kernel<768, TEAM> (all ICP iterations of the batch in one launch; teams of workgroups on the long pairs)",
+           "achieved": round(alg_bytes_icp / sec / 1e9, 3) if sec > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(alg_bytes_icp / sec / 1e9 / HBM_PEAK_GBS, 6) if sec > 0 else 0.0,
+           "algorithmic_bytes_per_launch": alg_bytes_icp, "algorithmic_bytes_per_registration_batch": P * (15 + iters),
+           "algorithmic_pair_evaluations_per_launch": E * iters, "sum_valid_points": int((ns + nd).sum()),
+           "avg_launch_ms": round(icp_ms, 4), "icp_share_of_batch": round(icp_ms / batch_ms, 4) if batch_ms > 0 else None,
+           "traffic": None, "traffic_source": "no counters file", "valu": None}
+    if os.path.exists(RAGGED_COUNTERS_FILE):
+        try:
+            cj = json.load(open(RAGGED_COUNTERS_FILE))
+            if cj.get("library_build") != build:
+                out["traffic_source"] = (f"{os.path.basename(RAGGED_COUNTERS_FILE)} was collected with library build "
+                                         f"{cj.get('library_build')}, this is {build}: refused")
+            elif sizes in cj:
+                k = next((v for name, v in cj[sizes]["kernels"].items() if name.startswith("icp_kernel")), None)
+                pb = cj[sizes]["per_batch"]
+                out["traffic_source"] = "PMC passes of the same library build (profiles/, rocprofv3 --pmc, separate passes; read side x2)"
+                if k is not None:
+                    out["traffic"] = k.get("hbm_bytes_per_dispatch")
+                    insts = k.get("SQ_INSTS_VALU_per_dispatch")
+                    if insts and sec > 0:
+                        lane = insts * 64.0 / sec
+                        out["valu"] = {"peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "SQ_INSTS_VALU_per_launch": insts,
+                                       "executed_lane_ops_per_s": round(lane, 1), "executed_frac": round(lane / VALU_PEAK_LANE_OPS, 4),
+                                       "algorithmic_lane_ops_per_s": round(E * iters * LANE_OPS_PER_EVAL / sec, 1),
+                                       "algorithmic_frac": round(E * iters * LANE_OPS_PER_EVAL / sec / VALU_PEAK_LANE_OPS, 4)}
+                if batch_ms > 0 and pb.get("SQ_INSTS_VALU"):
+                    out["whole_batch"] = {"hbm_bytes_counters": pb.get("hbm_bytes"), "hbm_bytes_algorithmic": P * (15 + iters),
+                                          "SQ_INSTS_VALU": pb["SQ_INSTS_VALU"],
+                                          "executed_valu_frac": round(pb["SQ_INSTS_VALU"] * 64.0 / (batch_ms * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                                          "hbm_frac_counters": round(pb.get("hbm_bytes", 0) / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        except Exception as e:
+            out["traffic_source"] = "unreadable counters file: " + repr(e)
+    return out
 
 
 def frame_pair_measurement(dev):

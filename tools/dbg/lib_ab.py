@@ -6,7 +6,7 @@ from types import SimpleNamespace
 from icp_flow_amd import _lib, synthetic, utils_match
 dev = torch.device("cuda", 0)
 out = []
-for B, N, reps in ((1024, 2048, 8), (8192, 2048, 3), (2048, 1024, 8), (600, 2048, 8)):
+for B, N, reps in ((256, 1024, 30), (1024, 2048, 8), (8192, 2048, 3), (2048, 1024, 8), (600, 2048, 8)):
     S, D, _ = synthetic.make_batch(B, N, seed=0)
     s, d = torch.from_numpy(S).to(dev), torch.from_numpy(D).to(dev)
     a = SimpleNamespace(thres_dist=0.1, translation_frame=2.0, chunk_size=50, max_points=N, icp_max_iterations=50)
