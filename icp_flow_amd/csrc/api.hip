@@ -320,7 +320,8 @@ struct JoinGuard {
 // shared tail of apply_icp / hist_icp: ICP from Tinit, compose, check, select
 int run_icp_and_select(const float *src, const float *dst, Workspace &w, const uint8_t *swap,
                        const float *init, int B, int N, double thres, int maxIter, double relThr,
-                       int stopMode, int invertSwapped, float *Tout, int32_t *iters, const Opts &o, hipStream_t s)
+                       int stopMode, int invertSwapped, float *Tout, int32_t *iters, const Opts &o, hipStream_t s,
+                       bool teamPlanned = false)
 {
     const GridScratch *search = search_scratch(w, N, o);
     const bool sweepCheck = search != nullptr && search->mode == 3 && o.on(ICPFLOW_OPT_NO_CHECK_SWEEP);
@@ -329,6 +330,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     bool historyPending = false;
     IcpOpts io = o.icp(w.grid.sortX);
     io.help = icp_help_carve(w.ctrl, B, w.helpState, w.helpOut);
+    io.teamPlanned = teamPlanned;
     if (sweepCheck && o.arith == ICPFLOW_ARITH_FP64) io.historyPending = &historyPending;
     ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
                            w.state, w.ctrl, search, w.history, &w.team, io, s));
@@ -795,6 +797,7 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
                           (size_t)B * 12 * sizeof(double));
     // the axis sort of both clouds (scoring sweep, ICP) runs on the side stream next to the vote
     hipEvent_t join = nullptr;
+    bool teamPlanned = false;
     JoinGuard guard;   // every return below leaves the side stream joined into s
     const GridScratch *search = search_scratch(w, N, o);
     SideStream *side = nullptr;
@@ -810,6 +813,13 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
         // nothing on the side stream waits for a kernel of this call: the axis sort counts for itself (selfCount).
         const hipError_t se = launch_sort_clouds_soa(d_src, d_dst, w.lenA, w.lenC, w.swap, B, N, &w.grid, side->stream,
                                                      countInSort ? 2 : 0);
+        // the ICP's team plan reads the lengths and roles only: where count_pair has written them before the fork it runs
+        // here, beside the vote, instead of in front of the ICP launch (22-31 us of a serial chain)
+        if (se == hipSuccess && !countInSort &&
+            icp_teams_wanted(&w.team, o.icp(w.grid.sortX), search, B, N, max_iterations, stop_mode, w.history)) {
+            launch_icp_team_plan(&w.team, w.lenA, w.lenC, w.swap, B, N, o.icp(w.grid.sortX), side->stream);
+            teamPlanned = true;
+        }
         const hipError_t je = hipEventRecord(side->join, side->stream);
         if (je == hipSuccess) { guard.s = s; guard.join = side->join; }
         ICPFLOW_TRY(se);
@@ -831,7 +841,7 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
     if (join != nullptr && !sweepScore) ICPFLOW_TRY(hipStreamWaitEvent(s, join, 0));
     guard.joined();
     return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
-                              relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s);
+                              relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, teamPlanned);
 }
 
 int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x,

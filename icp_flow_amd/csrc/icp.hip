@@ -2546,6 +2546,30 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
     if (timed) (void)hipEventRecord(prof->stop[prof->used++], s);
 }
 
+// Teams: with at most half of the CUs taken by one workgroup per pair, the spare CUs join the pairs
+// whose moving cloud needs several passes (real clusters, N > 1024).  Needs every workgroup of the
+// launch resident at once (members wait for each other): single-launch modes only.
+bool icp_teams_wanted(const IcpTeam *team, const IcpOpts &opts, const GridScratch *grid, int B, int N, int maxIter,
+                      int stopMode, const float *history)
+{
+    const bool speculative = stopMode == ICPFLOW_STOP_REFERENCE_ && history != nullptr && opts.speculative &&
+                             maxIter > 1 && maxIter <= kHistIters;
+    return opts.arith != ICPFLOW_ARITH_FP32_REFERENCE && team != nullptr && opts.teams && grid != nullptr && grid->mode == 3 &&
+           N > 1024 && 2 * B <= device_cus() && B <= 256 && (speculative || stopMode == ICPFLOW_STOP_PER_PAIR_);
+}
+
+// the plan of a team launch (icp_team_plan_kernel): depends on the pairs' lengths and roles only
+void launch_icp_team_plan(const IcpTeam *team, const int32_t *lenX, const int32_t *lenY, const uint8_t *swap, int B, int N,
+                          const IcpOpts &opts, hipStream_t s)
+{
+    IcpTeam t = *team;
+    t.maxWG = min(device_cus(), team->maxWG);
+    // (records behind the LDS image of the padded length: what a member's share of the queries has to fit, see launch_icp)
+    const size_t imgT = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
+    const int recCapT = (opts.adaptiveWindows && N <= 12288 && imgT + 64 * 20 <= 152 * 1024) ? (int)((152 * 1024 - imgT) / 20 / 64 * 64) : 0;
+    hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, t, recCapT);
+}
+
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                       const uint8_t *swap, const float *prePose, int B, int N, double thres,
                       int maxIter, double relThr, int stopMode, IcpState *state, IcpCtrl *ctrl,
@@ -2610,18 +2634,11 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
     const int cus = device_cus();
     const bool speculative = stopMode == ICPFLOW_STOP_REFERENCE_ && history != nullptr && opts.speculative &&
                              maxIter > 1 && maxIter <= kHistIters;
-    // Teams: with at most half of the CUs taken by one workgroup per pair, the spare CUs join the pairs
-    // whose moving cloud needs several passes (real clusters, N > 1024).  Needs every workgroup of the
-    // launch resident at once (members wait for each other): single-launch modes only.
-    if (team != nullptr && opts.teams && grid != nullptr && grid->mode == 3 && N > 1024 && 2 * B <= cus &&
-        B <= 256 && (speculative || stopMode == ICPFLOW_STOP_PER_PAIR_)) {
+    if (icp_teams_wanted(team, opts, grid, B, N, maxIter, stopMode, history)) {
         p.team = *team;
         p.team.maxWG = min(cus, team->maxWG);
-        // (records behind the LDS image of the padded length: what a member's share of the queries has to fit, see below)
-        const size_t imgT = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
-        const int recCapT = (p.sortY != nullptr && recWanted && N <= 12288 && imgT + 64 * 20 <= 152 * 1024)
-                                ? (int)((152 * 1024 - imgT) / 20 / 64 * 64) : 0;
-        hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, p.team, recCapT);
+        // (the plan depends on the lengths alone: hist_icp launches it on its side stream, next to the vote)
+        if (!opts.teamPlanned) launch_icp_team_plan(team, lenX, lenY, swap, B, N, opts, s);
     }
     if (p.sortY != nullptr) {
         // room for the per-query records behind the LDS image: every query of a pair when one workgroup serves it,

@@ -213,7 +213,12 @@ struct IcpOpts {
     bool *historyPending = nullptr;   // non-NULL: do not launch the history epilogue; *historyPending = "the final
                                    // states are still in the per-iteration history" (the consumers resolve it)
     float *fp32Scratch = nullptr;  // ICPFLOW_ARITH_FP32_REFERENCE: [B,N,4] floats (neighbour and weight per point)
+    bool teamPlanned = false;      // the caller has launched the team plan itself (launch_icp_team_plan, ordered before the ICP)
 };
+bool icp_teams_wanted(const IcpTeam *team, const IcpOpts &opts, const GridScratch *grid, int B, int N, int maxIter,
+                      int stopMode, const float *history);
+void launch_icp_team_plan(const IcpTeam *team, const int32_t *lenX, const int32_t *lenY, const uint8_t *swap, int B, int N,
+                          const IcpOpts &opts, hipStream_t s);
 // icp_fp32.hip: the reference's fp32 operation order (study mode), batch-global stop via the history epilogue
 hipError_t launch_icp_fp32ref(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                               const uint8_t *swap, const float *prePose, int B, int N, double thres, int maxIter,

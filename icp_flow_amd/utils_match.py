@@ -277,8 +277,18 @@ def setdiff1d(t1, t2):
         return t12[counts == 1]
     # (the labels counted once in unique(t1) ++ unique(t2), like the tensor branch and the reference: with t2 a subset of
     # t1 -- the only way match_pcds calls it -- those are the labels of t1 alone; a label of t2 alone is kept too)
-    u1, u2 = np.unique(t1), np.unique(np.asarray(t2))
-    return np.concatenate([u1[~np.isin(u1, u2)], u2[~np.isin(u2, u1)]]) if len(u2) else u1
+    t1, t2 = np.asarray(t1), np.asarray(t2)
+    u1 = t1 if (t1.ndim == 1 and (len(t1) < 2 or (t1[1:] > t1[:-1]).all())) else np.unique(t1)   # (match_pcds passes sorted unique labels)
+    if len(t2) == 0:
+        return u1
+    if len(u1):
+        pos = np.minimum(np.searchsorted(u1, t2), len(u1) - 1)
+        if (u1[pos] == t2).all():                       # the subset case, the only one match_pcds produces: one scatter
+            keep = np.ones(len(u1), dtype=bool)
+            keep[pos] = False
+            return u1[keep]
+    u2 = np.unique(t2)
+    return np.concatenate([u1[~np.isin(u1, u2)], u2[~np.isin(u2, u1)]])
 
 
 def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, asynchronous=False):
