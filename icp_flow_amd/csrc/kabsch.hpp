@@ -118,8 +118,11 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
         lam -= step;
         const double as = fabs(step);
         // steps shrink monotonically above the largest root (real-rooted quartic): the first one
-        // that does not is rounding noise
-        if (as <= 1e-16 * fabs(lam) || as >= prevStep) break;
+        // that does not is rounding noise.  (Round 4) Newton converges quadratically on a simple root: after a step of
+        // relative size 1e-9 the iterate is exact to ~1e-18, the steps that used to follow it (one or two, until the
+        // step fell below 1e-16 or stopped shrinking) only moved lam by its own rounding -- a quarter of the
+        // iteration's dependent chain in the serial tail of every ICP iteration.
+        if (as <= 1e-9 * fabs(lam) || as >= prevStep) break;
         prevStep = as;
     }
     ICPFLOW_STAMP(14);
@@ -140,14 +143,19 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
     k = __builtin_amdgcn_readfirstlane(k);
     double q0 = readlane_f64(C, 4 * k + 0), q1 = readlane_f64(C, 4 * k + 1), q2 = readlane_f64(C, 4 * k + 2),
            q3 = readlane_f64(C, 4 * k + 3);
-    const double inv = rsqrt(fma(q3, q3, fma(q2, q2, fma(q1, q1, q0 * q0))));
-    q0 *= inv; q1 *= inv; q2 *= inv; q3 *= inv;
-    // column-convention rotation Rc (y = Rc x) of the quaternion; the row convention wants Rc^T
+    // column-convention rotation Rc (y = Rc x) of the quaternion q / |q|; the row convention wants Rc^T.  The products of
+    // the UNNORMALISED q are formed beside the reciprocal of |q|^2 (a refined v_rcp_f64: five dependent operations
+    // where rsqrt + four scalings took a dozen) and scaled once.
+    const double n2 = fma(q3, q3, fma(q2, q2, fma(q1, q1, q0 * q0)));
+    double inv = __builtin_amdgcn_rcp(n2);
+    inv = fma(fma(-n2, inv, 1.0), inv, inv);
+    inv = fma(fma(-n2, inv, 1.0), inv, inv);
     const double ww = q0 * q0, xx = q1 * q1, yy = q2 * q2, zz = q3 * q3;
     const double xy = q1 * q2, xz = q1 * q3, yz = q2 * q3, wx = q0 * q1, wy = q0 * q2, wz = q0 * q3;
-    R[0] = ww + xx - yy - zz; R[3] = 2.0 * (xy - wz);     R[6] = 2.0 * (xz + wy);
-    R[1] = 2.0 * (xy + wz);     R[4] = ww - xx + yy - zz; R[7] = 2.0 * (yz - wx);
-    R[2] = 2.0 * (xz - wy);     R[5] = 2.0 * (yz + wx);     R[8] = ww - xx - yy + zz;
+    const double i2 = 2.0 * inv;
+    R[0] = (ww + xx - yy - zz) * inv; R[3] = (xy - wz) * i2;            R[6] = (xz + wy) * i2;
+    R[1] = (xy + wz) * i2;            R[4] = (ww - xx + yy - zz) * inv; R[7] = (yz - wx) * i2;
+    R[2] = (xz - wy) * i2;            R[5] = (yz + wx) * i2;            R[8] = (ww - xx - yy + zz) * inv;
     return true;
 }
 

@@ -399,12 +399,13 @@ def test_gpu_hdbscan_demo_frame_against_reference_run():
     raw = _hip().hdbscan(pts, 20)                              # before the keep-largest step (all clusters survive here)
     n_bad = _assert_mismatches_sit_at_tied_merge_heights(t["a"].cpu().numpy().astype(np.int64), t["b"].cpu().numpy().astype(np.int64),
                                                          np.sqrt(t["w2"].cpu().numpy()), raw, want)
-    # the gap to the reference run (sklearn's HDBSCAN through the reference's cluster_hdbscan) is 44 points
-    # of 126 598 and one cluster (147 against 148), every one of them at a tied merge height (asserted above).  Bounded HERE
-    # at what was measured (+ a handful): a change that widens it fails.
+    # the gap to the reference run (sklearn's HDBSCAN through the reference's cluster_hdbscan) is 54 points
+    # of 126 598 by this count (raw labels, before the keep-largest step; 44 change between noise and cluster in bench.py's
+    # count) and one cluster (147 against 148), every one of them at a tied merge height (asserted above).  Bounded HERE at
+    # what was measured (+ a handful): a change that widens it fails.
     n_clusters_got, n_clusters_want = int(got.max()) + 1, int(want.max()) + 1
     print(f"HDBSCAN demo frame: {n_bad} points labelled differently, {n_clusters_got} clusters against the reference run's {n_clusters_want}")
-    assert n_bad <= 50, n_bad
+    assert n_bad <= 60, n_bad
     assert abs(n_clusters_got - n_clusters_want) <= 1, (n_clusters_got, n_clusters_want)
     with pytest.raises(RuntimeError):
         _hip().hdbscan_mst(pts, 65)                      # min_samples beyond the wave-wide selection

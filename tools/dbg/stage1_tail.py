@@ -1,0 +1,29 @@
+import ctypes, os, sys
+ROOT = "/root/repo" if os.path.isdir("/root/repo/tools") else os.environ["GRAFT_REPO_ROOT"]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch
+from conftest import load_golden
+from icp_flow_amd import _lib, utils_track, utils_match, frame_pairs
+g = load_golden("g8_demo"); lab = load_golden("g8_demo_labels")
+dev = torch.device("cuda:0")
+G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+ps, pd = G(g["point_src"]), G(g["point_dst"]); ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
+a = frame_pairs.default_args(max_points=10000)
+kept = []
+orig = utils_match._gather_pair_batches
+def stash(args, st, dt, si, di):
+    r = orig(args, st, dt, si, di)
+    kept.append((r[0].clone(), r[1].clone(), st.h_count[si].copy(), dt.h_count[di].copy()))
+    return r
+utils_match._gather_pair_batches = stash
+torch.manual_seed(0); utils_track.track(a, ps, pd, ls, ld)
+utils_match._gather_pair_batches = orig
+S, D, cs, cd = kept[0]
+for _ in range(2): utils_match.hist_icp_eval(a, S, D)
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 3072)(); _lib._L.icpflow_debug_tail_clock(buf)
+v = np.array(buf[:], dtype=np.int64).reshape(1024, 3)[:len(cs)]
+its = np.maximum(v[:, 2], 1)
+for k in np.argsort(-(v[:, 0] + v[:, 1]))[:14]:
+    print(f"pair {k:3d}: {min(cs[k],10000):5d} x {min(cd[k],10000):5d} points, {v[k, 2]:3d} iterations, per iteration: serial {v[k, 0] / its[k]:7.0f}, search+exchange {v[k, 1] / its[k]:7.0f}, total {(v[k,0]+v[k,1])/2.4e6:.3f} ms")
+print("iterations histogram:", np.bincount(np.minimum(v[:,2],100)//10).tolist())
