@@ -475,7 +475,7 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
 // HELP (persistent sorted-sweep kernels): role 0 = the pair's owner, role j + 1 = helper in slot j of pair b: it runs pass
 // `passes - 1 - j` of every iteration from the state the owner publishes and hands the pass's moment sums back (see
 // HelpPair in kernels.hpp and icp_kernel).
-template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE, bool HELP, typename P>
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE, bool HELP, bool LATE, typename P>
 __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank, const int G, const int itBegin,
                                          const int itEnd, const int role = 0)
 {
@@ -638,17 +638,32 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     int sweepAxis = 0;            // sorted sweep: the sort axis of this pair (read once: a load from L2 at the top of every
                                   // iteration is a round trip that every wave of the workgroup sits out together)
     if constexpr (GRID >= 3) sweepAxis = __builtin_amdgcn_readfirstlane(p.sortAxis[b]);
-    unsigned long long ownConvLo = 0ull, ownConvHi = 0ull;   // iterations at which this pair was converged
+    // iterations at which this pair was converged: four 32-bit words in LDS, read and written by wave 0 only (as loop-carried
+    // registers they were the first victims of every change to the loop: spilled, and reloaded in the serial tail)
+    __shared__ unsigned int ownConvSh[4];
+    if (tid < 4) ownConvSh[tid] = 0u;
 #ifdef ICPFLOW_TAIL_CLOCK
     const long long tcWall0 = wall_clock64();
     long long tcTail = 0, tcSearch = 0, tcLoop0 = clock64();
     if (threadIdx.x < 17) g_tcSh[threadIdx.x] = threadIdx.x == 16 ? clock64() : 0;
     __syncthreads();
 #endif
+    // Round 4: the bookkeeping of an iteration (history record, tally, batch-rule check, cycle detection: ~1.5 k clocks of
+    // one wave) runs BEHIND the barrier that publishes the new (R, T), under the next iteration's search phase, instead of
+    // in front of it with the other waves waiting.  Whether the pair goes on is therefore known one search phase late: the
+    // flag bcast[12] is looked at by every wave at the same point -- behind the barrier that ends a search phase -- and a
+    // pair that has finished runs one search phase for nothing (no exchange, no solve, nothing recorded).  Kernels with
+    // helpers keep the old order (the owner's hand-off words are written with the bookkeeping).
+    // (Only where it pays: launches of one workgroup per CU, whose length is their slowest pair's chain of iterations.  With
+    // two workgroups per CU or a persistent grid the bookkeeping of one pair already runs under another pair's search, and
+    // the search phase run for nothing costs throughput: config 4's shard 1.83 -> 1.98 ms; in a team every wave meets wave 0
+    // at the barriers of the shared probes, so nothing is hidden: p.lateBook, set by launch_icp_variant.)
+    // (a property of the instantiation -- as a run-time flag the two orders side by side cost the 1024-thread kernel 17 spilled
+    // registers: LATE is chosen by icp_kernel)
+    constexpr bool kLateBook = LATE && !HELP && !TEAM;
     for (int it = itFirst; it < itEnd; ++it) {
-        if (!active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
-            // speculative mode: only member 0 watches the batch tally; it tells its team to stop
-            // through the record of the iteration the others are about to exchange
+        // (only the state the launch starts from: a pair retired by an earlier launch; workgroup-uniform)
+        if (it == itFirst && !active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
             if (TEAM && G > 1 && rank == 0 && p.stopMode == ICPFLOW_STOP_REFERENCE_ && wave == 0)
                 team_publish(team, b, it, 0, 0.0, 1.0, lane);
             break;
@@ -664,10 +679,10 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             // (wave-uniform values kept scalar: left to itself the compiler vectorises this search over the lanes)
             specChk = __builtin_amdgcn_readfirstlane(specChk);
             {
-                const unsigned long long lo = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(ownConvLo >> 32)) << 32) |
-                                              (unsigned)__builtin_amdgcn_readfirstlane((int)ownConvLo);
-                const unsigned long long hi = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(ownConvHi >> 32)) << 32) |
-                                              (unsigned)__builtin_amdgcn_readfirstlane((int)ownConvHi);
+                const unsigned long long lo = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ownConvSh[1]) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)ownConvSh[0]);
+                const unsigned long long hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ownConvSh[3]) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)ownConvSh[2]);
                 // first own-converged iteration >= specChk: count trailing zeros of the remaining bits
                 unsigned long long rest = specChk < 64 ? (lo >> specChk) : 0ull;
                 if (rest != 0ull) specChk += __builtin_ctzll(rest);
@@ -1501,11 +1516,183 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 continue;
             }
         }
+        // the pair's flag, written by wave 0 with the previous iteration's bookkeeping (before the barrier above)
+        if (kLateBook && it > itFirst && bcast[12] == 0.f) {
+            active = 0;
+            // speculative mode: only member 0 watches the batch tally; it tells its team to stop
+            // through the record of the iteration the others are about to exchange
+            if (TEAM && G > 1 && rank == 0 && p.stopMode == ICPFLOW_STOP_REFERENCE_ && wave == 0)
+                team_publish(team, b, it, 0, 0.0, 1.0, lane);
+            break;
+        }
         // ------------- wave 0 solves for (R, T, rmse) ---------------------------------------
+        bool solved = false;      // (late bookkeeping) wave 0 has published a new state in this iteration
+        [[maybe_unused]] int helpWord = 0;
+        // The bookkeeping of an iteration: history record, tally, batch-rule check, cycle detection, the flag (and the
+        // helpers' hand-off words).  Called by wave 0 in front of the barrier that publishes (R, T) with the values in registers, or
+        // (kLateBook) behind it with the values read back from the published copy.
+        auto bookkeeping = [&](const float (&Rn)[9], const float (&Tn)[3], const float sn, const float rmse, const float prev) {
+            // relative rmse, :195-198 (fp32 like the reference's tensors)
+            const float rel = (it == 0) ? 1.0f : (prev - rmse) / prev;
+            const bool conv = rel <= p.relThr;  // NaN -> false, :209
+            if (p.stopMode == ICPFLOW_STOP_REFERENCE_ && p.history != nullptr) {
+                // speculative mode: record this iteration, publish (arrived, not converged) with one
+                // atomic, and leave once SOME iteration s <= it is known to satisfy the batch rule
+                // (every pair arrived at s, none unconverged).  Nobody ever waits.
+                if (conv && it < 128 && lane == 0) ownConvSh[it >> 5] |= 1u << (it & 31);
+                if (lane == 0 && rank == 0) {
+                    float *h = p.history + ((size_t)it * p.B + b) * kHistStride;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) h[k] = Rn[k];
+                    h[9] = Tn[0]; h[10] = Tn[1]; h[11] = Tn[2]; h[12] = rmse; h[13] = sn;
+                    h[14] = (float)tot[0];   // gated correspondences of this iteration (sum w, :161; exact below 2^24)
+                    __hip_atomic_fetch_add(&ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // specTally (fetched at the top of this iteration) describes iteration specChk <= it - 1
+                if (specLoaded) {
+                    if ((int)(specTally & 0xffffffffull) >= p.B) {   // everybody has been there
+                        if ((specTally >> 32) == 0ull) active = 0;   // the batch stops at specChk
+                        else ++specChk;
+                    }
+                }
+                ICPFLOW_STAMP(9);
+                // Periodic trajectory: the next state is a function of (R, T) alone, so once the new
+                // state (number it + 1) equals, bit for bit, one of the last kRing states, everything
+                // that follows repeats with that period (1 = the usual convergence by exact repetition,
+                // 2 = a pair flipping between two inlier sets, which never satisfies the stop test and
+                // would hold the whole batch at the iteration cap).  The pair then writes its history
+                // and its tallies for ALL remaining iterations from the cycle and leaves: the outcome of
+                // the batch rule is unchanged, the iterations are not executed.
+                int period = 0;
+                {
+                    const int newest = it + 1;   // number of the new state
+                    // four candidate periods per round: quarter q of the wave compares the new state
+                    // (replicated into every quarter) with state newest - (k0 + q)
+                    // cheap first: a 32-bit hash of the state (xor of its twelve words) against the hashes of
+                    // the remembered states, all eight at once; the word-by-word comparison only runs on a hit
+                    int hash = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) hash ^= state_hash_word(Rn[k], k);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) hash ^= state_hash_word(Tn[k], 9 + k);
+                    hash ^= state_hash_word(sn, 12);
+                    const int kk = lane + 1;   // lane l < kRing looks at state newest - (l + 1)
+                    const bool cand = lane < kRing && kk <= newest - itBegin &&
+                                      __float_as_int(ring[((newest - kk) % kRing) * 16 + 13]) == hash;
+                    const bool anyCand = __ballot(cand) != 0ull;
+                    float cur16 = 0.f;   // word (lane & 15) of the new state: only a hash hit needs it
+                    if (anyCand) {
+                        const int wd = lane & 15;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) cur16 = (wd == k) ? Rn[k] : cur16;
+                        cur16 = (wd == 9) ? Tn[0] : (wd == 10) ? Tn[1] : (wd == 11) ? Tn[2] : (wd == 14) ? sn : cur16;
+                    }
+                    for (int k0 = 1; anyCand && k0 <= kRing && period == 0; k0 += 4) {
+                        const int k = k0 + (lane >> 4);
+                        const bool valid = k <= kRing && k <= newest - itBegin;
+                        const float old = ring[(((newest - (valid ? k : 0)) % kRing + kRing) % kRing) * 16 + (lane & 15)];
+                        const bool same = ((lane & 15) >= 12 && (lane & 15) != 14) || __float_as_int(old) == __float_as_int(cur16);
+                        const unsigned long long m = __ballot(same);
+#pragma unroll
+                        for (int q = 3; q >= 0; --q) {
+                            const bool okq = ((m >> (16 * q)) & 0xffffull) == 0xffffull;
+                            const int kq = k0 + q;
+                            if (okq && kq <= kRing && kq <= newest - itBegin) period = kq;   // smallest period wins
+                        }
+                    }
+                    if (lane == 0) {   // (the values are wave-uniform: one lane stores the row)
+                        float *rw = ring + (newest % kRing) * 16;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) rw[k] = Rn[k];
+                        rw[9] = Tn[0]; rw[10] = Tn[1]; rw[11] = Tn[2]; rw[12] = rmse; rw[13] = __int_as_float(hash); rw[14] = sn;
+                        rw[15] = (float)tot[0];
+                    }
+                }
+                if (period > 0 && active) {
+                    if (rank == 0) {
+                        // remaining iterations k = it+1 .. itEnd-1, one per lane and round; row k repeats
+                        // row j(k) = it - period + 1 + ((k - it - 1) mod period)  (a row is stored in the
+                        // ring under the number of the state it produced, row + 1)
+                        for (int k0 = it + 1; k0 < itEnd; k0 += kWave) {
+                            const int k = k0 + lane;
+                            if (k < itEnd) {
+                                const int j = it - period + 1 + ((k - it - 1) % period);
+                                const int jp = (k - 1 == it) ? it : it - period + 1 + ((k - it - 2) % period);
+                                const float *rj = ring + ((j + 1) % kRing) * 16;
+                                const float rm = rj[12], rmPrev = ring[((jp + 1) % kRing) * 16 + 12];
+                                float *h = p.history + ((size_t)k * p.B + b) * kHistStride;
+                                for (int c = 0; c < 12; ++c) h[c] = rj[c];
+                                h[12] = rm;
+                                h[13] = rj[14];
+                                h[14] = rj[15];
+                                const float relk = (rmPrev - rm) / rmPrev;
+                                const bool convk = relk <= p.relThr;
+                                __hip_atomic_fetch_add(&ctrl->tally[k], 1ull | (convk ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+                    active = 0;
+                }
+            } else if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
+                if (lane == 0 && !conv && rank == 0) atomicAdd(&ctrl->notconv[it], 1);
+            } else {
+                // per-pair rule: retire a pair once its rmse has stopped DEcreasing by more than
+                // thr (0 <= rel <= thr).  A negative rel (rmse went up: the inlier set is still
+                // changing) satisfies the reference's batch test but is not convergence of this
+                // pair.  A constant (zero-inlier) pair has rel = NaN and is retired too.
+                if (it > 0 && ((conv && rel >= 0.0f) || rel != rel)) active = 0;
+            }
+            if (kLateBook) {
+                if (lane == 0 && !active) bcast[12] = 0.f;   // seen by every wave behind the next search phase's barrier
+            } else if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) bcast[k] = Rn[k];
+                bcast[9] = Tn[0]; bcast[10] = Tn[1]; bcast[11] = Tn[2];
+                bcast[12] = active ? 1.f : 0.f;
+                bcast[14] = rmse;  // :213 prev_rmse = rmse
+                bcast[15] = sn;
+            }
+            if constexpr (HELP) {
+                if (hp != nullptr) {
+                    // progress for workgroups looking for a pair to help; with helpers signed up: the state of iteration
+                    // it + 1 (double-buffered by parity, write-through, drained, THEN the epoch), and which of its passes
+                    // the helpers that have announced themselves in time will deliver
+                    const bool goesOn = active && it + 1 < itEnd;
+                    int mask = 0;
+                    const int nclaim = __builtin_amdgcn_readfirstlane(helpWord);
+                    if (goesOn && nclaim > 0) {
+                        const int e = it + 2;                 // E(it + 1)
+                        if (lane < 12) {
+                            float v = Tn[0];
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) v = lane == k ? Rn[k] : v;
+                            v = lane == 10 ? Tn[1] : (lane == 11 ? Tn[2] : v);
+                            __hip_atomic_store(&p.help.state[((size_t)b * 2 + (e & 1)) * 16 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(&hp->epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int passes = (xc.n + BLOCK - 1) / BLOCK;
+                        const int f = __shfl(helpWord, (lane + 1) & 63, kWave);     // lane j < 3: slot j's announcement
+                        const bool on = lane < kHelpSlots && f != 0 && (f & 0xff) <= e && passes - 1 - lane >= 1;
+                        if (on) helpSh[1 + lane] = f >> 8;
+                        const unsigned long long m = __ballot(on);
+#pragma unroll
+                        for (int j = 0; j < kHelpSlots; ++j)
+                            if ((m >> j) & 1ull) mask |= 1 << (passes - 1 - j);
+                    }
+                    if (lane == 0) {
+                        helpSh[0] = mask;
+                        __hip_atomic_store(&hp->iter, goesOn ? it + 2 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!goesOn) __hip_atomic_store(&hp->epoch, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        };
         if (wave == 0) {
             // helpers: who has signed up (lane 0: the count, lanes 1..3: the announcements), fetched HERE, a whole solve
             // before it is looked at -- an agent-scope load is a round trip across the fabric
-            [[maybe_unused]] int helpWord = 0;
             if constexpr (HELP) {
                 if (hp != nullptr && lane <= kHelpSlots)
                     helpWord = __hip_atomic_load(lane == 0 ? &hp->nclaim : &hp->from[lane - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1637,163 +1824,34 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             const float sn = SCALE ? (float)sd : 1.f;
             const float rmse = (float)sqrt(ms > 0.0 ? ms : 0.0);
             ICPFLOW_STAMP(15);
-            const float prev = bcast[14];
-            // relative rmse, :195-198 (fp32 like the reference's tensors)
-            const float rel = (it == 0) ? 1.0f : (prev - rmse) / prev;
-            const bool conv = rel <= p.relThr;  // NaN -> false, :209
-            if (p.stopMode == ICPFLOW_STOP_REFERENCE_ && p.history != nullptr) {
-                // speculative mode: record this iteration, publish (arrived, not converged) with one
-                // atomic, and leave once SOME iteration s <= it is known to satisfy the batch rule
-                // (every pair arrived at s, none unconverged).  Nobody ever waits.
-                if (conv) { if (it < 64) ownConvLo |= 1ull << it; else if (it < 128) ownConvHi |= 1ull << (it - 64); }
-                if (lane == 0 && rank == 0) {
-                    float *h = p.history + ((size_t)it * p.B + b) * kHistStride;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) h[k] = Rn[k];
-                    h[9] = Tn[0]; h[10] = Tn[1]; h[11] = Tn[2]; h[12] = rmse; h[13] = sn;
-                    h[14] = (float)tot[0];   // gated correspondences of this iteration (sum w, :161; exact below 2^24)
-                    __hip_atomic_fetch_add(&ctrl->tally[it], 1ull | (conv ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                }
-                // specTally (fetched at the top of this iteration) describes iteration specChk <= it - 1
-                if (specLoaded) {
-                    if ((int)(specTally & 0xffffffffull) >= p.B) {   // everybody has been there
-                        if ((specTally >> 32) == 0ull) active = 0;   // the batch stops at specChk
-                        else ++specChk;
-                    }
-                }
-                ICPFLOW_STAMP(9);
-                // Periodic trajectory: the next state is a function of (R, T) alone, so once the new
-                // state (number it + 1) equals, bit for bit, one of the last kRing states, everything
-                // that follows repeats with that period (1 = the usual convergence by exact repetition,
-                // 2 = a pair flipping between two inlier sets, which never satisfies the stop test and
-                // would hold the whole batch at the iteration cap).  The pair then writes its history
-                // and its tallies for ALL remaining iterations from the cycle and leaves: the outcome of
-                // the batch rule is unchanged, the iterations are not executed.
-                int period = 0;
-                {
-                    const int newest = it + 1;   // number of the new state
-                    // four candidate periods per round: quarter q of the wave compares the new state
-                    // (replicated into every quarter) with state newest - (k0 + q)
-                    // cheap first: a 32-bit hash of the state (xor of its twelve words) against the hashes of
-                    // the remembered states, all eight at once; the word-by-word comparison only runs on a hit
-                    int hash = 0;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) hash ^= state_hash_word(Rn[k], k);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) hash ^= state_hash_word(Tn[k], 9 + k);
-                    hash ^= state_hash_word(sn, 12);
-                    const int kk = lane + 1;   // lane l < kRing looks at state newest - (l + 1)
-                    const bool cand = lane < kRing && kk <= newest - itBegin &&
-                                      __float_as_int(ring[((newest - kk) % kRing) * 16 + 13]) == hash;
-                    const bool anyCand = __ballot(cand) != 0ull;
-                    float cur16 = 0.f;   // word (lane & 15) of the new state: only a hash hit needs it
-                    if (anyCand) {
-                        const int wd = lane & 15;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) cur16 = (wd == k) ? Rn[k] : cur16;
-                        cur16 = (wd == 9) ? Tn[0] : (wd == 10) ? Tn[1] : (wd == 11) ? Tn[2] : (wd == 14) ? sn : cur16;
-                    }
-                    for (int k0 = 1; anyCand && k0 <= kRing && period == 0; k0 += 4) {
-                        const int k = k0 + (lane >> 4);
-                        const bool valid = k <= kRing && k <= newest - itBegin;
-                        const float old = ring[(((newest - (valid ? k : 0)) % kRing + kRing) % kRing) * 16 + (lane & 15)];
-                        const bool same = ((lane & 15) >= 12 && (lane & 15) != 14) || __float_as_int(old) == __float_as_int(cur16);
-                        const unsigned long long m = __ballot(same);
-#pragma unroll
-                        for (int q = 3; q >= 0; --q) {
-                            const bool okq = ((m >> (16 * q)) & 0xffffull) == 0xffffull;
-                            const int kq = k0 + q;
-                            if (okq && kq <= kRing && kq <= newest - itBegin) period = kq;   // smallest period wins
-                        }
-                    }
-                    if (lane == 0) {   // (the values are wave-uniform: one lane stores the row)
-                        float *rw = ring + (newest % kRing) * 16;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) rw[k] = Rn[k];
-                        rw[9] = Tn[0]; rw[10] = Tn[1]; rw[11] = Tn[2]; rw[12] = rmse; rw[13] = __int_as_float(hash); rw[14] = sn;
-                        rw[15] = (float)tot[0];
-                    }
-                }
-                if (period > 0 && active) {
-                    if (rank == 0) {
-                        // remaining iterations k = it+1 .. itEnd-1, one per lane and round; row k repeats
-                        // row j(k) = it - period + 1 + ((k - it - 1) mod period)  (a row is stored in the
-                        // ring under the number of the state it produced, row + 1)
-                        for (int k0 = it + 1; k0 < itEnd; k0 += kWave) {
-                            const int k = k0 + lane;
-                            if (k < itEnd) {
-                                const int j = it - period + 1 + ((k - it - 1) % period);
-                                const int jp = (k - 1 == it) ? it : it - period + 1 + ((k - it - 2) % period);
-                                const float *rj = ring + ((j + 1) % kRing) * 16;
-                                const float rm = rj[12], rmPrev = ring[((jp + 1) % kRing) * 16 + 12];
-                                float *h = p.history + ((size_t)k * p.B + b) * kHistStride;
-                                for (int c = 0; c < 12; ++c) h[c] = rj[c];
-                                h[12] = rm;
-                                h[13] = rj[14];
-                                h[14] = rj[15];
-                                const float relk = (rmPrev - rm) / rmPrev;
-                                const bool convk = relk <= p.relThr;
-                                __hip_atomic_fetch_add(&ctrl->tally[k], 1ull | (convk ? 0ull : (1ull << 32)), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
-                    }
-                    active = 0;
-                }
-            } else if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
-                if (lane == 0 && !conv && rank == 0) atomicAdd(&ctrl->notconv[it], 1);
+            const float prevRmse = bcast[14];
+            if constexpr (!kLateBook) {
+                bookkeeping(Rn, Tn, sn, rmse, prevRmse);
             } else {
-                // per-pair rule: retire a pair once its rmse has stopped DEcreasing by more than
-                // thr (0 <= rel <= thr).  A negative rel (rmse went up: the inlier set is still
-                // changing) satisfies the reference's batch test but is not convergence of this
-                // pair.  A constant (zero-inlier) pair has rel = NaN and is retired too.
-                if (it > 0 && ((conv && rel >= 0.0f) || rel != rel)) active = 0;
-            }
-            if (lane == 0) {
+                solved = true;
+                if (lane == 0) {   // the new state, for every wave's next search phase (the flag stays as it is)
 #pragma unroll
-                for (int k = 0; k < 9; ++k) bcast[k] = Rn[k];
-                bcast[9] = Tn[0]; bcast[10] = Tn[1]; bcast[11] = Tn[2];
-                bcast[12] = active ? 1.f : 0.f;
-                bcast[14] = rmse;  // :213 prev_rmse = rmse
-                bcast[15] = sn;
-            }
-            if constexpr (HELP) {
-                if (hp != nullptr) {
-                    // progress for workgroups looking for a pair to help; with helpers signed up: the state of iteration
-                    // it + 1 (double-buffered by parity, write-through, drained, THEN the epoch), and which of its passes
-                    // the helpers that have announced themselves in time will deliver
-                    const bool goesOn = active && it + 1 < itEnd;
-                    int mask = 0;
-                    const int nclaim = __builtin_amdgcn_readfirstlane(helpWord);
-                    if (goesOn && nclaim > 0) {
-                        const int e = it + 2;                 // E(it + 1)
-                        if (lane < 12) {
-                            float v = Tn[0];
-#pragma unroll
-                            for (int k = 0; k < 9; ++k) v = lane == k ? Rn[k] : v;
-                            v = lane == 10 ? Tn[1] : (lane == 11 ? Tn[2] : v);
-                            __hip_atomic_store(&p.help.state[((size_t)b * 2 + (e & 1)) * 16 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0) __hip_atomic_store(&hp->epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int passes = (xc.n + BLOCK - 1) / BLOCK;
-                        const int f = __shfl(helpWord, (lane + 1) & 63, kWave);     // lane j < 3: slot j's announcement
-                        const bool on = lane < kHelpSlots && f != 0 && (f & 0xff) <= e && passes - 1 - lane >= 1;
-                        if (on) helpSh[1 + lane] = f >> 8;
-                        const unsigned long long m = __ballot(on);
-#pragma unroll
-                        for (int j = 0; j < kHelpSlots; ++j)
-                            if ((m >> j) & 1ull) mask |= 1 << (passes - 1 - j);
-                    }
-                    if (lane == 0) {
-                        helpSh[0] = mask;
-                        __hip_atomic_store(&hp->iter, goesOn ? it + 2 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!goesOn) __hip_atomic_store(&hp->epoch, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    for (int k = 0; k < 9; ++k) bcast[k] = Rn[k];
+                    bcast[9] = Tn[0]; bcast[10] = Tn[1]; bcast[11] = Tn[2];
+                    bcast[13] = prevRmse;
+                    bcast[14] = rmse;  // :213 prev_rmse = rmse
+                    bcast[15] = sn;
                 }
             }
             }  // !teamStop
+        }
+        if constexpr (kLateBook) {
+            if (it + 1 < itEnd) {
+                barrier_lds_only();                 // (R, T) are read back at the top of the loop
+                if (bcast[12] == 0.f) { active = 0; itersDone = it + 1; break; }   // the team was told to stop (workgroup-uniform)
+            }
+            if (wave == 0 && solved) {   // (read back from where wave 0 has just published them: nothing is carried across the barrier)
+                float R2[9], T2[3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R2[k] = bcast[k];
+                T2[0] = bcast[9]; T2[1] = bcast[10]; T2[2] = bcast[11];
+                bookkeeping(R2, T2, bcast[15], bcast[14], bcast[13]);
+            }
         }
         itersDone = it + 1;
         ICPFLOW_STAMP(7);
@@ -1801,9 +1859,16 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
         tcLoop0 = clock64();
         tcTail += tcLoop0 - tcTail0;
 #endif
-        if (it + 1 < itEnd) {  // more iterations inside this launch: publish (R, T) to the block
+        if (!kLateBook && it + 1 < itEnd) {  // more iterations inside this launch: publish (R, T) to the block
             barrier_lds_only();   // the history stores / tally atomic of wave 0 stay in flight
-            if (wave != 0) active = bcast[12] != 0.f;   // (R, T) are read back at the top of the loop
+            if (bcast[12] == 0.f && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {   // (workgroup-uniform)
+                active = 0;
+                // speculative mode: only member 0 watches the batch tally; it tells its team to stop
+                // through the record of the iteration the others are about to exchange
+                if (TEAM && G > 1 && rank == 0 && p.stopMode == ICPFLOW_STOP_REFERENCE_ && wave == 0)
+                    team_publish(team, b, it + 1, 0, 0.0, 1.0, lane);
+                break;
+            }
         }
     }
     ICPFLOW_STAMP(8);
@@ -1864,7 +1929,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         G = p.team.teamSize[b];
         // a chain of single-pass pairs (icp_team_plan_kernel): one after the other, like the tickets of a persistent grid
         for (;;) {
-            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false>(p, b, rank, G, itBegin, itEnd);
+            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, false>(p, b, rank, G, itBegin, itEnd);
             b = __builtin_amdgcn_readfirstlane(p.team.next[b]);
             if (b < 0) return;
             __syncthreads();                 // the pair's last reads of the static LDS state are done
@@ -1872,7 +1937,10 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         }
     }
     if constexpr (!PERSIST) {
-        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false>(p, b, rank, G, itBegin, itEnd);
+        // one workgroup per pair, at most one (1024 / 768 threads) per CU: the launch lasts as long as its slowest pair's chain
+        // of iterations -- late bookkeeping.  512-thread workgroups share their CUs (two per CU: batches of two pairs per CU
+        // and more), like the persistent grids below: one pair's bookkeeping already runs under another pair's search.
+        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, BLOCK != 512>(p, b, rank, G, itBegin, itEnd);
     } else {
         static_assert(!PERSIST || !TEAM, "teams are planned per launch");
         constexpr bool HELP = HELPK && GRID == 4 && !SCALE && Q == 1;
@@ -1885,7 +1953,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         int role = 0;
         for (;;) {
             asm volatile("" : "+s"(pp));
-            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, HELP>(*pp, b, rank, G, itBegin, itEnd, role);
+            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, HELP, false>(*pp, b, rank, G, itBegin, itEnd, role);
             __syncthreads();                     // the pair's last reads of the static LDS state are done
             if (threadIdx.x < kWave) {
                 int nb = -1, nr = 0;
