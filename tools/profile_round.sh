@@ -1,11 +1,11 @@
 #!/bin/bash
 # Everything the judge reads under profiles/ for one round, in one gpurun call:
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r04
 # kernel trace + stats of the default bench command, the PMC passes (separate runs, tools/profile_pmc.sh), the
 # condensed summaries (tools/summarize_profiles.py) and the bench line itself.  Outputs land in gpurun_out/;
 # copy gpurun_out/profiles_<tag>/* into profiles/ and commit.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p "$ROOT/gpurun_out/stats_$TAG"

@@ -53,8 +53,8 @@ if dom:
         "WRITE_SIZE_KiB_per_launch_raw": write_kb,
         "correction": "gfx950 rocprofv3 reports 1/2 of the bytes of wide (16 B/lane) coalesced reads "
                       "(FETCH_SIZE = TCC_EA0_RDREQ x 64 B with 128-B requests tallied at 64 B): read side x2; "
-                      "WRITE_SIZE taken as is (per-iteration history records plus the register-spill stores of the "
-                      "1024-thread, 128-VGPR kernel that leave the L2)",
+                      "WRITE_SIZE taken as is (the per-iteration history records and tallies; the kernel has no vector-register "
+                      "spills and no scratch -- tools/kernel_resources.py -- and spilled SGPRs live in VGPR lanes, not in memory)",
         "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024)),
         "launch_shape": "all_iterations" if e["dispatches"] <= 16 else "one_iteration",
         "dispatches_profiled": e["dispatches"],
