@@ -298,6 +298,10 @@ def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, async
     when its transfer has landed, so that the host half of one frame pair runs under the kernels of the others."""
     _lib.require_gpu(src_points, dst_points, src_labels, dst_labels)
     dev = src_points.device
+    if len(src_points) == 0 or len(dst_points) == 0:
+        # a frame whose points were all filtered out: no cluster, no candidate pair -- the reference's match_pcds returns
+        # empty pairs for it (utils_match.py:24-66 with empty label sets); the cluster-table kernels want rows (ADVICE r3)
+        return torch.zeros((0, 10), dtype=torch.float32, device=dev), torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
     st, dt = ClusterTable.pair(src_points, src_labels, dst_points, dst_labels, fetch=False)
     pend = Pending(st._both, asynchronous, 0)
     yield pend

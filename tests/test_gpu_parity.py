@@ -1270,3 +1270,17 @@ def test_cluster_table_pair_chain_equals_two_single_chains():
                 assert np.array_equal(getattr(got, attr), getattr(want, attr)), (name, attr)
             assert torch.equal(got.labels_unq, want.labels_unq) and torch.equal(got.mean, want.mean) and torch.equal(got.extent, want.extent)
             assert np.array_equal(got.h_labels, np.unique(lab)), name
+
+
+def test_match_pcds_with_an_empty_cloud_returns_no_pairs():
+    """a frame whose points were all filtered out (an empty cloud on either side) is "no pairs", like the
+    reference's match_pcds on empty label sets -- not an error from the cluster-table kernels; the flow of such a frame pair
+    is the ego flow alone."""
+    from icp_flow_amd import frame_pairs
+    a = frame_pairs.default_args(max_points=512)
+    pts = torch.randn(300, 3, device=DEV)
+    lab = torch.zeros(300, device=DEV)
+    empty_p, empty_l = torch.zeros((0, 3), device=DEV), torch.zeros((0,), device=DEV)
+    for sp, sl, dp, dl in ((empty_p, empty_l, pts, lab), (pts, lab, empty_p, empty_l), (empty_p, empty_l, empty_p, empty_l)):
+        pairs, T = utils_match.match_pcds(a, sp, dp, sl, dl)
+        assert tuple(pairs.shape) == (0, 10) and tuple(T.shape) == (0, 4, 4)
