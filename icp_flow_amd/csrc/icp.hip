@@ -660,7 +660,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     // at the barriers of the shared probes, so nothing is hidden: p.lateBook, set by launch_icp_variant.)
     // (a property of the instantiation -- as a run-time flag the two orders side by side cost the 1024-thread kernel 17 spilled
     // registers: LATE is chosen by icp_kernel)
-    constexpr bool kLateBook = LATE && !HELP && !TEAM;
+    constexpr bool kLateBook = LATE && !HELP;
     for (int it = itFirst; it < itEnd; ++it) {
         // (only the state the launch starts from: a pair retired by an earlier launch; workgroup-uniform)
         if (it == itFirst && !active && (p.stopMode == ICPFLOW_STOP_PER_PAIR_ || p.history != nullptr)) {
@@ -785,6 +785,15 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 if constexpr (HELP) {
                     if (helping ? g != ngr - role : ((helpedPasses >> g) & 1) != 0) continue;   // (workgroup-uniform)
                 }
+                // Which 64 queries of the pass a wave takes: wave w takes unit w -- except in a team member's pass of fewer
+                // units than waves (a member holds 4, 8 or 12 units, §3.5 of DESIGN.md), where the units go to the HIGH
+                // waves: wave 0, which starts every search phase a bookkeeping late (kLateBook), then has no unit and reaches
+                // the first barrier of the shared probes with the others.
+                int unitWave = wave;
+                if constexpr (TEAM) {
+                    const int unitsHere = min(NWAVE, (myCount - g * PER + kWave - 1) / kWave);
+                    unitWave = wave - (NWAVE - unitsHere);      // < 0: this wave has no unit in this pass
+                }
                 float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
                 bool live[Q];
                 float lo = kInf, hi = -kInf;
@@ -808,9 +817,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
 #endif
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    const int li = g * PER + (wave * Q + q) * kWave + lane;                   // local slot
+                    const int li = g * PER + (unitWave * Q + q) * kWave + lane;               // local slot
                     const int i = dealt ? ((li >> 6) * G + rank) * kWave + lane : li;        // sorted query
-                    live[q] = li < myCount && i < xc.n;
+                    live[q] = unitWave >= 0 && li < myCount && i < xc.n;
                     x0x[q] = x0y[q] = x0z[q] = 0.f;
                     qx[q] = qy[q] = qz[q] = 0.f;
                     if (live[q]) {
@@ -1220,7 +1229,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     if (!(acc.best[q] < kInf)) certJ[q] = -1;
                 }
                 if (recOn && newL[q] >= 0.f) {
-                    const int li = g * PER + (wave * Q + q) * kWave + lane;
+                    const int li = g * PER + (unitWave * Q + q) * kWave + lane;
                     rec[li] = make_float4(qx[q], qy[q], qz[q], newL[q]);
                     recJ[li] = certJ[q];
                 }
@@ -1929,7 +1938,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         G = p.team.teamSize[b];
         // a chain of single-pass pairs (icp_team_plan_kernel): one after the other, like the tickets of a persistent grid
         for (;;) {
-            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, false>(p, b, rank, G, itBegin, itEnd);
+            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, true>(p, b, rank, G, itBegin, itEnd);
             b = __builtin_amdgcn_readfirstlane(p.team.next[b]);
             if (b < 0) return;
             __syncthreads();                 // the pair's last reads of the static LDS state are done
