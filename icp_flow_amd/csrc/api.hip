@@ -744,10 +744,15 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
                                    "(2 <= max_iterations <= %d, fp64 arithmetic)", kHistIters);
     if (o.initR != nullptr && o.arith != ICPFLOW_ARITH_FP64)
         return fail(ICPFLOW_E_ARG, "icpflow_icp: an initial transform is not built for ICPFLOW_ARITH_FP32_REFERENCE");
-    const GridScratch *search = search_scratch(w, N, o);
+    // similarity transforms are built into the sorted-sweep kernels only: below 64 points, where the automatic choice is the
+    // all-pairs scan, a request for a scale takes the sweep (the drop-in must not raise where the
+    // reference works); beyond the sort's length (kMaxSortN) it is still refused
+    Opts os = o;
+    if ((o.estimateScale || o.initS != nullptr) && o.search == 0 && N < 64) os.search = 3;
+    const GridScratch *search = search_scratch(w, N, os);
     if ((o.estimateScale || o.initS != nullptr) && (search == nullptr || search->mode != 3))
         return fail(ICPFLOW_E_ARG, "icpflow_icp: estimate_scale / an initial transform with a scale need the sorted-sweep "
-                                   "search (the default for 64 <= N <= %d)", kMaxSortN);
+                                   "search (the default up to N = %d)", kMaxSortN);
     launch_count_pair(d_X, d_Y, B, N, w.lenA, w.lenC, nullptr, s, w.ctrl, icp_ctrl_bytes(B));
     ICPFLOW_TRY(launch_icp(d_X, d_Y, w.lenA, w.lenC, nullptr, d_pre_pose, B, N, thres, max_iterations,
                            relative_rmse_thr, stop_mode, w.state, w.ctrl, search, w.history, &w.team,

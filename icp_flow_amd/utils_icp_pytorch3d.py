@@ -42,7 +42,8 @@ def iterative_closest_point(X, Y, init_transform=None, thres=0.1, max_iterations
     flag.  `allow_reflection=True` (:354-362) returns the best orthogonal matrix instead of the best rotation.
     `estimate_scale=True` (:364-374): s = trace(E S) / Xcov -- trace(E S) is the largest eigenvalue of the closed-form
     solve -- and Xt = s X R + T.  Limit: similarity transforms (estimate_scale, or an init_transform whose scale is not
-    1) are built for the sorted-sweep correspondence search only, i.e. 64 <= N <= 16384 without a `search` override and
+    1) are built for the sorted-sweep correspondence search only, i.e. N <= 16384 (below 64 points a request for a scale
+    selects the sweep instead of the all-pairs scan, round 4) without a `search` override and
     with the default fp64 arithmetic; outside of that icpflow_icp refuses the call (RuntimeError, nothing enqueued).
     ICP-Flow itself never asks for either (utils_icp.py:51-58).
     """

@@ -361,8 +361,8 @@ def test_icp_init_transform_and_t_history_vs_oracle():
     assert len(utils_icp_pytorch3d.iterative_closest_point(src.to(DEV), dst.to(DEV), stop_mode="per_pair").t_history) == 0
 
 
-@pytest.mark.parametrize("B,N", [(8, 400), (6, 1500), (300, 1400), (520, 800)],
-                         ids=["one-pass", "teams", "several-passes", "two-workgroups-per-cu"])
+@pytest.mark.parametrize("B,N", [(8, 400), (6, 1500), (300, 1400), (520, 800), (5, 40)],
+                         ids=["one-pass", "teams", "several-passes", "two-workgroups-per-cu", "below-64-points"])
 def test_icp_estimate_scale_vs_oracle(B, N):
     """estimate_scale=True (utils_icp_pytorch3d.py:364-374): the transform is a similarity, Xt = s X R + T with
     s = trace(E S) / Xcov.  Targets = the source scaled by 0.9 .. 1.1 about its centre, turned by a few degrees and
