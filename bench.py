@@ -549,8 +549,13 @@ def frame_pair_measurement(dev):
     for mp in (int(g["max_points"]), 10000):
         a = frame_pairs.default_args(max_points=mp)
 
+        # main.py:139 seeds torch's global generator once per run; a private generator with the same seed gives the same draws
+        # (the random subsample of the over-long wall, utils_helper.py:198-201) -- torch.manual_seed() itself costs ~50 us a
+        # call here (it walks every backend's lazy-init queue and formats a stack trace), which is not the product's time
+        a.generator = torch.Generator()
+
         def run():
-            torch.manual_seed(0)
+            a.generator.manual_seed(0)
             pairs, Tm = utils_track.track(a, ps, pd, ls, ld)
             return pairs, utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, ego)
 

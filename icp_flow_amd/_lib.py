@@ -229,8 +229,23 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def stream_handle(device):
+    """The current stream of `device` as an integer handle.  torch.cuda.current_stream() builds a Stream object through
+    several Python layers (7.5 us a call, 22 calls per frame pair: a tenth of the host thread's time on a stream of frame
+    pairs, tools/dbg/stream_host_profile.py); torch's raw getter is one C call."""
+    if _raw_stream is not None:
+        idx = device.index if isinstance(device, torch.device) else None
+        if idx is None:
+            idx = torch.cuda.current_device()
+        return int(_raw_stream(idx))
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
 def stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(stream_handle(device))
 
 
 _ws_cache = {}
@@ -239,7 +254,7 @@ _ws_cache = {}
 def workspace(device, nbytes):
     """A cached, grow-only scratch buffer per (device, current stream): calls issued on different streams
     may overlap on the GPU and must not share scratch (torch caching-allocator owned)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, stream_handle(device))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -251,7 +266,7 @@ def workspaces(device, sizes):
     """Distinct cached scratch buffers for the batches of one icpflow_hist_icp_many call (slot k of the current stream)."""
     out = []
     for k, nbytes in enumerate(sizes):
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, "many", k)
+        key = (device.type, device.index, stream_handle(device), "many", k)
         buf = _ws_cache.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

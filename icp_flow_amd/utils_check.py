@@ -155,13 +155,13 @@ def sanity_grid(args, st, dt, si, di):
     ms, md = st.h_mean[si][rs], dt.h_mean[di][cs]
     dx = md[None, :, 0] - ms[:, None, 0]
     dy = md[None, :, 1] - ms[:, None, 1]
-    sub = ~(np.sqrt(dx * dx + dy * dy) > np.float32(args.translation_frame))                           # :36
-    es, ed = st.h_extent[si][rs], dt.h_extent[di][cs]
+    near = ~(np.sqrt(dx * dx + dy * dy) > np.float32(args.translation_frame))                          # :36
+    # (the distance test leaves a few hundred of the S x D combinations: the box test runs on those pairs only)
+    pr, pc = np.nonzero(near)
+    es, ed = st.h_extent[si][rs][pr], dt.h_extent[di][cs][pc]
     tb = np.float32(args.thres_box)
-    for k in range(3):                                                                                   # :41-43
-        a, b = es[:, None, k], ed[None, :, k]
-        sub &= ~(np.minimum(a, b) < tb * np.maximum(a, b))
-    ok[np.ix_(rs, cs)] = sub
+    keep = ~(np.minimum(es, ed) < tb * np.maximum(es, ed)).any(axis=1)                                  # :41-43
+    ok[rs[pr[keep]], cs[pc[keep]]] = True
     return ok
 
 

@@ -199,7 +199,7 @@ class Pending:
         if not asynchronous:
             self.host, self.ev, self._dev = None, None, t      # (copied when asked for: host work in between overlaps the GPU)
             return
-        key = (torch.cuda.current_stream(t.device).cuda_stream, slot, t.dtype)
+        key = (_lib.stream_handle(t.device), slot, t.dtype)
         buf = Pending._pinned.get(key)
         if buf is None or buf.numel() < t.numel():
             buf = torch.empty(max(t.numel(), 1 << 14), dtype=t.dtype, pin_memory=True)
@@ -239,21 +239,21 @@ def _finish_pairs(args, st, dt, launched):
                            "large pair, or a helper's hand-off in a persistent launch (GPU shared with another process?); "
                            "retry, or register with _lib.options(no_teams=True, no_helpers=True, no_persistent=True)")
     keep = check_transformation(args, translations, rotations, np.minimum(ious[:, 0], ious[:, 1]))
-    S, D = len(st.h_labels), len(dt.h_labels)
     if not keep.any():
         return np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32)
-    m_err = np.full((S, D, 2), 1e8, np.float32)
-    m_idx = np.full((S, D), -1, np.int64)
+    # The reference fills S x D matrices (1e8 where no candidate), takes the row arg-min of min(err_src, err_dst) -- the FIRST
+    # minimal column -- and keeps the rows below thres_error (utils_helper.py:108-110, utils_match.py:112).  The same choice on
+    # the list of kept candidates (a few dozen rows instead of S x D entries; the (source, destination) pairs of a stage are
+    # distinct): per source row the smallest error, ties to the smallest destination index; a row whose best error is not below
+    # thres_error (< 1e8) has no match, and rows come out in ascending source order like the matrix rows.
     ks = np.nonzero(keep)[0]
-    m_err[si[ks], di[ks]] = errors[ks]
-    m_idx[si[ks], di[ks]] = ks
-    err_min = np.minimum(m_err[:, :, 0], m_err[:, :, 1])
-    rows = np.arange(S)
-    best = np.argmin(err_min, axis=1)                                     # utils_helper.py:108-110
-    valid = err_min[rows, best] < np.float32(args.thres_error)            # utils_match.py:112
-    rows, best = rows[valid], best[valid]
-    k = m_idx[rows, best]
-    out = np.concatenate([st.h_labels[rows][:, None], dt.h_labels[best][:, None], errors[k], inliers[k], ratios[k],
+    err = np.minimum(errors[ks, 0], errors[ks, 1])
+    order = np.lexsort((di[ks], err, si[ks]))
+    ks, err = ks[order], err[order]
+    first = np.ones(len(ks), dtype=bool)
+    first[1:] = si[ks[1:]] != si[ks[:-1]]
+    k = ks[first & (err < np.float32(args.thres_error))]
+    out = np.concatenate([st.h_labels[si[k]][:, None], dt.h_labels[di[k]][:, None], errors[k], inliers[k], ratios[k],
                           ious[k]], axis=1).astype(np.float32)
     return out, T_h[k].astype(np.float32)
 
