@@ -117,6 +117,7 @@ struct IcpParams {
     int x0Cache;             // the records are followed by the queries' own points (12 B each): no L2 round trip per iteration
     int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
                              // certificates, see the search phase); a workgroup whose share of the queries fits uses them
+    int teamLanes;           // host side only: 2 = this team launch takes at most half of the CUs (chained two deep)
 };
 
 
@@ -2586,21 +2587,37 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
             // part of the GPU with members that spin for teammates the other launch keeps from starting; so the team
             // launches of one host thread are chained by an event, whatever streams they are on.  (Not under stream
             // capture, where an event from outside the graph cannot be waited for: a captured registration stands alone.)
-            struct TeamLane { hipEvent_t ev = nullptr; int device = -1; bool recorded = false; };
+            // Round 4: launches that take at most half of the CUs (ICPFLOW_OPT_TEAMS_HALF_GPU, p.teamLanes == 2) are chained two
+            // deep -- they alternate between two lanes, each lane a chain of its own, so that two of them (256 workgroups of
+            // 152 KiB of LDS at most: all resident) run side by side; a full-GPU launch waits for both lanes and leaves its
+            // event in both.
+            // (three and four lanes on a third / a quarter of the CUs were measured: 1.42 / 1.53 ms per demo frame pair with four
+            // in flight against 1.46 with two, and slower one at a time -- the teams get too small)
+            struct TeamLane { hipEvent_t ev[2] = {nullptr, nullptr}; int device = -1; bool recorded[2] = {false, false}; int next = 0; };
             static thread_local TeamLane lane;
             int dev = -1;
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            const bool chain = hipGetDevice(&dev) == hipSuccess && hipStreamIsCapturing(s, &cap) == hipSuccess &&
-                               cap == hipStreamCaptureStatusNone;
-            if (chain && (lane.ev == nullptr || lane.device != dev)) {
+            bool chain = hipGetDevice(&dev) == hipSuccess && hipStreamIsCapturing(s, &cap) == hipSuccess &&
+                         cap == hipStreamCaptureStatusNone;
+            if (chain && (lane.ev[0] == nullptr || lane.device != dev)) {
                 lane = TeamLane{};
                 lane.device = dev;
-                if (hipEventCreateWithFlags(&lane.ev, hipEventDisableTiming) != hipSuccess) lane.ev = nullptr;
+                if (hipEventCreateWithFlags(&lane.ev[0], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&lane.ev[1], hipEventDisableTiming) != hipSuccess) { lane.ev[0] = nullptr; chain = false; }
             }
-            if (chain && lane.ev != nullptr && lane.recorded) (void)hipStreamWaitEvent(s, lane.ev, 0);
+            const bool half = p.teamLanes == 2;
+            const int mine = lane.next & 1;
+            if (chain) {
+                for (int k = 0; k < 2; ++k)
+                    if ((!half || k == mine) && lane.recorded[k]) (void)hipStreamWaitEvent(s, lane.ev[k], 0);
+            }
             if (p.N <= 12288) launch_icp_variant<768, 1, 1, 4, true>(p, B, itBegin, itEnd, s);
             else launch_icp_variant<768, 1, 1, 3, true>(p, B, itBegin, itEnd, s);
-            if (chain && lane.ev != nullptr) lane.recorded = hipEventRecord(lane.ev, s) == hipSuccess;
+            if (chain) {
+                for (int k = 0; k < 2; ++k)
+                    if (!half || k == mine) lane.recorded[k] = hipEventRecord(lane.ev[k], s) == hipSuccess;
+                if (half) lane.next ^= 1;
+            }
         }
         // 1024 threads (4 waves per SIMD, 128 VGPRs: the kernel fits but for three pointers spilled once
         // outside the loop) take a 1024-point cloud in one pass; up to 768 points 12 waves (170 VGPRs) do
@@ -2635,12 +2652,19 @@ bool icp_teams_wanted(const IcpTeam *team, const IcpOpts &opts, const GridScratc
            N > 1024 && 2 * B <= device_cus() && B <= 256 && (speculative || stopMode == ICPFLOW_STOP_PER_PAIR_);
 }
 
+// workgroups of a team launch: one per CU, or one per CU of HALF the GPU (a multiple of the eight XCDs either way)
+int icp_team_workgroups(const IcpOpts &opts)
+{
+    const int cus = device_cus();
+    return opts.teamsHalfGpu ? max(8, cus / 2 / 8 * 8) : cus;
+}
+
 // the plan of a team launch (icp_team_plan_kernel): depends on the pairs' lengths and roles only
 void launch_icp_team_plan(const IcpTeam *team, const int32_t *lenX, const int32_t *lenY, const uint8_t *swap, int B, int N,
                           const IcpOpts &opts, hipStream_t s)
 {
     IcpTeam t = *team;
-    t.maxWG = min(device_cus(), team->maxWG);
+    t.maxWG = min(icp_team_workgroups(opts), team->maxWG);
     // (records behind the LDS image of the padded length: what a member's share of the queries has to fit, see launch_icp)
     const size_t imgT = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
     const int recCapT = (opts.adaptiveWindows && N <= 12288 && imgT + 64 * 20 <= 152 * 1024) ? (int)((152 * 1024 - imgT) / 20 / 64 * 64) : 0;
@@ -2713,7 +2737,8 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
                              maxIter > 1 && maxIter <= kHistIters;
     if (icp_teams_wanted(team, opts, grid, B, N, maxIter, stopMode, history)) {
         p.team = *team;
-        p.team.maxWG = min(cus, team->maxWG);
+        p.team.maxWG = min(icp_team_workgroups(opts), team->maxWG);
+        p.teamLanes = opts.teamsHalfGpu ? 2 : 1;
         // (the plan depends on the lengths alone: hist_icp launches it on its side stream, next to the vote)
         if (!opts.teamPlanned) launch_icp_team_plan(team, lenX, lenY, swap, B, N, opts, s);
     }

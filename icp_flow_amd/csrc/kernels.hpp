@@ -214,9 +214,11 @@ struct IcpOpts {
                                    // states are still in the per-iteration history" (the consumers resolve it)
     float *fp32Scratch = nullptr;  // ICPFLOW_ARITH_FP32_REFERENCE: [B,N,4] floats (neighbour and weight per point)
     bool teamPlanned = false;      // the caller has launched the team plan itself (launch_icp_team_plan, ordered before the ICP)
+    bool teamsHalfGpu = false;     // ICPFLOW_OPT_TEAMS_HALF_GPU: a team launch takes at most half of the CUs (two may run side by side)
 };
 bool icp_teams_wanted(const IcpTeam *team, const IcpOpts &opts, const GridScratch *grid, int B, int N, int maxIter,
                       int stopMode, const float *history);
+int icp_team_workgroups(const IcpOpts &opts);
 void launch_icp_team_plan(const IcpTeam *team, const int32_t *lenX, const int32_t *lenY, const uint8_t *swap, int B, int N,
                           const IcpOpts &opts, hipStream_t s);
 // icp_fp32.hip: the reference's fp32 operation order (study mode), batch-global stop via the history epilogue

@@ -185,7 +185,12 @@ def _launch_pairs(args, st, dt, pairs):
     si, di = st.find_host(pairs[:, 0]), dt.find_host(pairs[:, 1])
     assert (si >= 0).all() and (di >= 0).all()
     segs_src, segs_dst = _gather_pair_batches(args, st, dt, si, di)
-    r, _ = _hist_icp_eval_flat(args, segs_src, segs_dst)
+    # The stages of a frame pair keep their teams of workgroups on half of the GPU (ICPFLOW_OPT_TEAMS_HALF_GPU): a frame's
+    # stage needs far fewer workgroups than the GPU has CUs, and two frame pairs in flight can then run their team launches
+    # side by side instead of one after the other.  Always, in flight or not: the plan decides the order of a team's sums, and
+    # a frame pair registers to the same bits whatever else is in flight (`args.teams_full_gpu = True`: the full-GPU plan).
+    with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False)):
+        r, _ = _hist_icp_eval_flat(args, segs_src, segs_dst)
     return si, di, r
 
 

@@ -116,6 +116,11 @@ const char *icpflow_build_info(void);
 #define ICPFLOW_OPT_NO_ADAPTIVE_WINDOWS (1u << 8) /* ICP sweep: no neighbour certificates / probes: every query scans */
 #define ICPFLOW_OPT_NO_PERSISTENT (1u << 9)   /* ICP: one workgroup per pair dealt by the hardware dispatcher, whatever B */
 #define ICPFLOW_OPT_NO_HELPERS (1u << 10)     /* ICP, persistent grid: workgroups without a pair left do not take passes of others */
+/* NOT a bit-identity switch: teams of workgroups (several per large pair) take at most HALF of the CUs, so that two team
+ * launches of one host thread may run side by side (frame pairs in flight).  The plan -- hence the order of a team's sums --
+ * follows the number of workgroups: results equal those of the full-GPU plan to rounding, and are the same whatever else is
+ * in flight.  Team launches WITH the flag are chained two deep (two lanes), launches without it wait for both lanes. */
+#define ICPFLOW_OPT_TEAMS_HALF_GPU (1u << 11)
 
 typedef struct icpflow_profile icpflow_profile_t; /* opaque */
 

@@ -72,7 +72,7 @@ def test_options_are_per_call_and_per_thread():
         t.join()
     assert seen["other"] == 0
     assert _lib._current()[-1]["search"] == 0
-    assert set(_lib.OPT_FLAGS.values()) == {1 << k for k in range(11)}
+    assert set(_lib.OPT_FLAGS.values()) == {1 << k for k in range(12)}   # eleven bit-identity switches + teams_half_gpu
     assert ctypes.sizeof(_lib.Options) == 88   # size_t, int, int, unsigned, pad, five pointers, two ints, two pointers on LP64
 
 
