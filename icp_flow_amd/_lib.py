@@ -52,6 +52,8 @@ SIGNATURES = {
                                    _p, _p, _sz, _p, _p]),
     "icpflow_gather_pad": (_i, [_p, _p, _i, _i, _p, _p]),
     "icpflow_gather_segments": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
+    "icpflow_assoc_assign": (_i, [_p, _p, _p, _i, _p, _i, _i, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _p]),
+    "icpflow_assoc_collect": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "icpflow_cluster_table_workspace_bytes": (_sz, [_i, _i]),
     "icpflow_cluster_table": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _sz, _p]),
@@ -101,7 +103,7 @@ class Options(ctypes.Structure):
     _fields_ = [("struct_size", _sz), ("icp_search", _i), ("icp_arith", _i), ("flags", ctypes.c_uint),
                 ("profile", _p), ("d_vote_bins_u32", _p), ("d_icp_init_R", _p), ("d_icp_init_T", _p),
                 ("d_icp_history", _p), ("icp_allow_reflection", _i), ("icp_estimate_scale", _i),
-                ("d_icp_scale", _p), ("d_icp_init_s", _p)]
+                ("d_icp_scale", _p), ("d_icp_init_s", _p), ("d_pair_active", _p)]
 
 
 class Profile:
@@ -144,19 +146,19 @@ _DEFAULT_FLAGS = _env_default_flags()
 def _current():
     return getattr(_tls, "stack", None) or [dict(search=0, arith=0, flags=_DEFAULT_FLAGS, profile=None, vote_bins=None,
                                                  icp_init=None, icp_history=None, icp_allow_reflection=False,
-                                                 icp_scale=None)]
+                                                 icp_scale=None, pair_active=None)]
 
 
 @contextlib.contextmanager
 def options(search=None, arith=None, profile=None, vote_bins=None, icp_init=None, icp_history=None,
-            icp_allow_reflection=None, icp_scale=None, **switches):
+            icp_allow_reflection=None, icp_scale=None, pair_active=None, **switches):
     """Per-call options for every wrapper invoked inside the `with` block on this thread.
     search: 'auto' | 'scan' | 'grid' | 'sweep';  arith: 'fp64' | 'fp32_reference';  profile: a Profile;
     vote_bins: uint32 device tensor [B, Lx*Ly*Lz] receiving the fused vote's bins;  switches: no_teams=True ..."""
     cur = dict(_current()[-1])
     # device buffers belong to ONE call (their sizes follow that call's B, max_iterations, histogram): a nested block never
     # inherits them from the block around it -- it names them itself or runs without
-    cur.update(vote_bins=None, icp_init=None, icp_history=None, icp_scale=None)
+    cur.update(vote_bins=None, icp_init=None, icp_history=None, icp_scale=None, pair_active=None)
     if search is not None:
         cur["search"] = {"auto": 0, "scan": 1, "grid": 2, "sweep": 3}.get(search, search)
     if arith is not None:
@@ -173,6 +175,8 @@ def options(search=None, arith=None, profile=None, vote_bins=None, icp_init=None
         cur["icp_allow_reflection"] = bool(icp_allow_reflection)
     if icp_scale is not None:       # float32 [B] device tensor: estimate_scale of icpflow_icp, receives s
         cur["icp_scale"] = icp_scale
+    if pair_active is not None:     # uint8 [B] device tensor: pairs flagged 0 are not in the batch (hist_icp / hist_icp_eval)
+        cur["pair_active"] = pair_active
     for k, v in switches.items():
         cur["flags"] = (cur["flags"] | OPT_FLAGS[k]) if v else (cur["flags"] & ~OPT_FLAGS[k])
     stack = getattr(_tls, "stack", None)
@@ -190,7 +194,7 @@ def opt():
     cur = _current()[-1]
     if (cur["search"] == 0 and cur["arith"] == 0 and cur["flags"] == 0 and cur["profile"] is None
             and cur["vote_bins"] is None and cur["icp_init"] is None and cur["icp_history"] is None
-            and not cur["icp_allow_reflection"] and cur["icp_scale"] is None):
+            and not cur["icp_allow_reflection"] and cur["icp_scale"] is None and cur.get("pair_active") is None):
         return None
     dp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
     # (ICPFLOW_OPTIONS_SIZE: developer override for loading an older build of the ABI, whose struct was a prefix of this one)
@@ -199,7 +203,8 @@ def opt():
                 dp(cur["icp_init"][0] if cur["icp_init"] is not None else None),
                 dp(cur["icp_init"][1] if cur["icp_init"] is not None else None), dp(cur["icp_history"]),
                 1 if cur["icp_allow_reflection"] else 0, 1 if cur["icp_scale"] is not None else 0, dp(cur["icp_scale"]),
-                dp(cur["icp_init"][2] if cur["icp_init"] is not None and len(cur["icp_init"]) > 2 else None))
+                dp(cur["icp_init"][2] if cur["icp_init"] is not None and len(cur["icp_init"]) > 2 else None),
+                dp(cur.get("pair_active")))
     _tls.last = o          # keep the struct alive until this thread builds the next one
     return ctypes.cast(ctypes.pointer(o), _p)
 

@@ -48,6 +48,7 @@ struct Opts {
     bool estimateScale = false;
     float *scaleOut = nullptr;
     const float *initS = nullptr;
+    const uint8_t *pairActive = nullptr;
     bool on(unsigned offFlag) const { return (flags & offFlag) == 0u; }
     IcpOpts icp(float *scratch) const
     {
@@ -61,6 +62,7 @@ struct Opts {
         o.persistent = on(ICPFLOW_OPT_NO_PERSISTENT);
         o.helpers = on(ICPFLOW_OPT_NO_HELPERS);
         o.teamsHalfGpu = (flags & ICPFLOW_OPT_TEAMS_HALF_GPU) != 0u;
+        o.pairActive = pairActive;
         o.profile = profile;
         return o;
     }
@@ -217,8 +219,21 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
     o.estimateScale = opt->icp_estimate_scale != 0;
     o.scaleOut = opt->d_icp_scale;
     o.initS = opt->d_icp_init_s;
+    o.pairActive = opt->d_pair_active;
     if (o.initS != nullptr && o.initR == nullptr)
         return fail(ICPFLOW_E_ARG, "%s: options.d_icp_init_s comes with d_icp_init_R / d_icp_init_T", fn);
+    return 0;
+}
+
+// options.d_pair_active: only the fused registrations honour it, and only where ONE speculative launch runs the batch rule
+int check_pair_active(const char *fn, const Opts &o, bool fused, int maxIter, int stopMode)
+{
+    if (o.pairActive == nullptr) return 0;
+    if (!fused) return fail(ICPFLOW_E_ARG, "%s: options.d_pair_active is honoured by icpflow_hist_icp / icpflow_hist_icp_eval only", fn);
+    if (stopMode != ICPFLOW_STOP_REFERENCE || maxIter < 2 || maxIter > kHistIters || !o.on(ICPFLOW_OPT_NO_SPECULATIVE) ||
+        o.arith != ICPFLOW_ARITH_FP64)
+        return fail(ICPFLOW_E_ARG, "%s: options.d_pair_active needs the single-launch reference stop (2 <= max_iterations <= %d, "
+                                   "fp64 arithmetic, speculation on)", fn, kHistIters);
     return 0;
 }
 
@@ -532,6 +547,38 @@ int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const
     return 0;
 }
 
+int icpflow_assoc_assign(const float *d_result, const int32_t *d_si, const int32_t *d_di, int K, const uint8_t *d_active,
+                         int S, int D, float translation_frame, float thres_iou, float rot_limit_deg, float thres_error,
+                         int32_t *d_best, int K2, const int32_t *d_si2, const int32_t *d_di2, int64_t *d_seg2,
+                         uint8_t *d_active2, icpflow_stream_t stream)
+{
+    if (!d_result || !d_si || !d_di || !d_best) return fail(ICPFLOW_E_ARG, "icpflow_assoc_assign: null pointer");
+    if (K <= 0 || S <= 0 || D <= 0 || S > assoc_max_rows() || D > assoc_max_rows())
+        return fail(ICPFLOW_E_LIMIT, "icpflow_assoc_assign: K (%d) must be positive and S, D (%d, %d) in 1..%d", K, S, D, assoc_max_rows());
+    if (K2 < 0 || (K2 > 0 && (!d_si2 || !d_di2 || !d_seg2 || !d_active2)))
+        return fail(ICPFLOW_E_ARG, "icpflow_assoc_assign: the next stage's candidates come with d_si2, d_di2, d_seg2 and d_active2");
+    ICPFLOW_TRY(launch_assoc_assign(d_result, d_si, d_di, K, d_active, S, D, translation_frame, thres_iou, rot_limit_deg,
+                                    thres_error, d_best, K2, d_si2, d_di2, d_seg2, d_active2, (hipStream_t)stream));
+    return 0;
+}
+
+int icpflow_assoc_collect(const int32_t *d_best1, const float *d_result1, const int32_t *d_si1, const int32_t *d_di1, int K1,
+                          const int32_t *d_best2, const float *d_result2, const int32_t *d_si2, const int32_t *d_di2, int K2,
+                          const double *d_src_table, const double *d_dst_table, int label_stride, int S, int cap,
+                          float *d_rows, float *d_T, int32_t *d_count, icpflow_stream_t stream)
+{
+    if (!d_best1 || !d_result1 || !d_si1 || !d_di1 || !d_src_table || !d_dst_table || !d_rows || !d_T || !d_count)
+        return fail(ICPFLOW_E_ARG, "icpflow_assoc_collect: null pointer");
+    if (K1 <= 0 || S <= 0 || S > assoc_max_rows() || cap <= 0 || label_stride <= 0)
+        return fail(ICPFLOW_E_LIMIT, "icpflow_assoc_collect: K1 (%d), cap (%d), label_stride (%d) must be positive and S (%d) in 1..%d", K1, cap,
+                    label_stride, S, assoc_max_rows());
+    if (K2 < 0 || (K2 > 0 && (!d_best2 || !d_result2 || !d_si2 || !d_di2)))
+        return fail(ICPFLOW_E_ARG, "icpflow_assoc_collect: stage 2 comes with d_best2, d_result2, d_si2 and d_di2");
+    ICPFLOW_TRY(launch_assoc_collect(d_best1, d_result1, d_si1, d_di1, K1, K2 > 0 ? d_best2 : nullptr, d_result2, d_si2, d_di2, K2,
+                                     d_src_table, d_dst_table, label_stride, S, cap, d_rows, d_T, d_count, (hipStream_t)stream));
+    return 0;
+}
+
 size_t icpflow_dbscan_workspace_bytes(int n)
 {
     if (n <= 0) return 0;
@@ -697,6 +744,7 @@ int icpflow_estimate_init_pose(const float *d_src, const float *d_dst, int B, in
 {
     Opts o;
     if (int r = parse_options("icpflow_estimate_init_pose", opt, o)) return r;
+    if (int r = check_pair_active("icpflow_estimate_init_pose", o, false, 0, 0)) return r;
     if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
         return fail(ICPFLOW_E_ARG, "icpflow_estimate_init_pose: null pointer");
     if (int r = check_batch("icpflow_estimate_init_pose", B, N)) return r;
@@ -718,6 +766,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
 {
     Opts o;
     if (int r = parse_options("icpflow_icp", opt, o)) return r;
+    if (int r = check_pair_active("icpflow_icp", o, false, 0, 0)) return r;
     if (int r = check_arith("icpflow_icp", o, max_iterations, stop_mode)) return r;
     if (!d_X || !d_Y) return fail(ICPFLOW_E_ARG, "icpflow_icp: null pointer");
     if (int r = check_batch("icpflow_icp", B, N)) return r;
@@ -773,6 +822,7 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
     Opts o;
     if (int r = parse_options("icpflow_apply_icp", opt, o)) return r;
     if (int r = check_arith("icpflow_apply_icp", o, max_iterations, stop_mode)) return r;
+    if (int r = check_pair_active("icpflow_apply_icp", o, false, max_iterations, stop_mode)) return r;
     if (!d_src || !d_dst || !d_init || !d_T_out) return fail(ICPFLOW_E_ARG, "icpflow_apply_icp: null pointer");
     if (int r = check_batch("icpflow_apply_icp", B, N)) return r;
     if (max_iterations <= 0 || max_iterations > kMaxIterCap)
@@ -859,6 +909,7 @@ int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const
     Opts o;
     if (int r = parse_options("icpflow_hist_icp", opt, o)) return r;
     if (int r = check_arith("icpflow_hist_icp", o, max_iterations, stop_mode)) return r;
+    if (int r = check_pair_active("icpflow_hist_icp", o, true, max_iterations, stop_mode)) return r;
     if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out)
         return fail(ICPFLOW_E_ARG, "icpflow_hist_icp: null pointer");
     if (int r = check_batch("icpflow_hist_icp", B, N)) return r;
@@ -964,6 +1015,7 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
 {
     Opts o;
     if (int r = parse_options("icpflow_match_eval", opt, o)) return r;
+    if (int r = check_pair_active("icpflow_match_eval", o, false, 0, 0)) return r;
     if (!d_pcd1 || !d_pcd2 || !d_T || !d_errors || !d_inliers || !d_ratios || !d_ious || !d_translations ||
         !d_rotations)
         return fail(ICPFLOW_E_ARG, "icpflow_match_eval: null pointer");
@@ -987,6 +1039,7 @@ int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, 
     Opts o;
     if (int r = parse_options("icpflow_hist_icp_eval", opt, o)) return r;
     if (int r = check_arith("icpflow_hist_icp_eval", o, max_iterations, stop_mode)) return r;
+    if (int r = check_pair_active("icpflow_hist_icp_eval", o, true, max_iterations, stop_mode)) return r;
     if (!d_src || !d_dst || !d_edges_x || !d_edges_y || !d_edges_z || !d_T_out || !d_errors || !d_inliers || !d_ratios ||
         !d_ious || !d_translations || !d_rotations)
         return fail(ICPFLOW_E_ARG, "icpflow_hist_icp_eval: null pointer");

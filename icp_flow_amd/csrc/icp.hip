@@ -118,6 +118,7 @@ struct IcpParams {
     int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
                              // certificates, see the search phase); a workgroup whose share of the queries fits uses them
     int teamLanes;           // host side only: 2 = this team launch takes at most half of the CUs (chained two deep)
+    const uint8_t *pairActive;   // options.d_pair_active or NULL: pairs flagged 0 are not in the batch (speculative mode only)
 };
 
 
@@ -521,6 +522,22 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     const int ts = wave % TS;                // target share of this wave
     const int qg = wave / TS;                // query group of this wave
     IcpCtrl *ctrl = p.ctrl;
+    if (p.pairActive != nullptr && p.history != nullptr && p.pairActive[b] == 0) {
+        // Not in the batch (options.d_pair_active; the caller handed the pair over as two empty clouds): the batch rule is
+        // taken over the other pairs -- this one reports "arrived, converged" for every iteration of the launch, like a pair
+        // whose trajectory has become periodic does for its remaining iterations, and leaves.  Its outputs are unspecified.
+        if (rank == 0 && wave == 0)
+            for (int k = itBegin + lane; k < itEnd; k += kWave)
+                __hip_atomic_fetch_add(&ctrl->tally[k], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && rank == 0) {
+            IcpState *st0 = p.state + b;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) st0->R[k] = (k % 4 == 0) ? 1.f : 0.f;
+            st0->T[0] = st0->T[1] = st0->T[2] = 0.f;
+            st0->rmse = 0.f; st0->s = 1.f; st0->active = 0; st0->iters = 0;
+        }
+        return;
+    }
     if (p.stopMode == ICPFLOW_STOP_REFERENCE_ && itBegin > 0) {
         // previous iteration satisfied the batch-global rule (or an earlier one did)
         if (ctrl->done || ctrl->notconv[itBegin - 1] == 0) {
@@ -2787,6 +2804,7 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         // Beyond kHistIters iterations: one launch per iteration.
         if (speculative) {
             p.history = history;
+            p.pairActive = opts.pairActive;   // (api.hip has refused the mask wherever this branch is not taken)
             p.persistent = opts.persistent ? 1 : 0;   // (one launch for all iterations: the ticket counter starts at zero)
             p.help = opts.help;
             p.helpOn = (opts.helpers && maxIter <= kHelpMaxEpoch - 2) ? 1 : 0;   // (always: maxIter <= kHistIters here)

@@ -214,6 +214,7 @@ struct IcpOpts {
                                    // states are still in the per-iteration history" (the consumers resolve it)
     float *fp32Scratch = nullptr;  // ICPFLOW_ARITH_FP32_REFERENCE: [B,N,4] floats (neighbour and weight per point)
     bool teamPlanned = false;      // the caller has launched the team plan itself (launch_icp_team_plan, ordered before the ICP)
+    const uint8_t *pairActive = nullptr;   // options.d_pair_active: pairs flagged 0 are not in the batch (speculative reference stop only)
     bool teamsHalfGpu = false;     // ICPFLOW_OPT_TEAMS_HALF_GPU: a team launch takes at most half of the CUs (two may run side by side)
 };
 bool icp_teams_wanted(const IcpTeam *team, const IcpOpts &opts, const GridScratch *grid, int B, int N, int maxIter,
@@ -295,5 +296,15 @@ hipError_t hdbscan_workspace_bytes(int n, size_t *bytes);
 hipError_t launch_hdbscan_mst(const float *pts, int stride, const uint8_t *mask, int n, int minSamples, double cell,
                               double *core2, int32_t *edgeA, int32_t *edgeB, double *edgeW2, int32_t *numEdges,
                               int32_t *numLive, void *ws, size_t wsBytes, bool *wsTooSmall, hipStream_t s);
+
+// assoc.hip: the host half of an association stage as kernels (icpflow_assoc_assign / icpflow_assoc_collect)
+hipError_t launch_assoc_assign(const float *r, const int32_t *si, const int32_t *di, int K, const uint8_t *active, int S, int D,
+                               float tf, float iouMin, float rotMax, float errMax, int32_t *best, int K2, const int32_t *si2,
+                               const int32_t *di2, int64_t *seg2, uint8_t *active2, hipStream_t s);
+hipError_t launch_assoc_collect(const int32_t *best1, const float *r1, const int32_t *si1, const int32_t *di1, int K1,
+                                const int32_t *best2, const float *r2, const int32_t *si2, const int32_t *di2, int K2,
+                                const double *srcTable, const double *dstTable, int stride, int S, int cap, float *rows,
+                                float *T, int32_t *count, hipStream_t s);
+int assoc_max_rows();
 
 }  // namespace icpflow

@@ -253,6 +253,10 @@ def _finish_pairs(args, st, dt, launched):
     # thres_error (< 1e8) has no match, and rows come out in ascending source order like the matrix rows.
     ks = np.nonzero(keep)[0]
     err = np.minimum(errors[ks, 0], errors[ks, 1])
+    if np.isnan(err).any():
+        # np.argmin takes a NaN for the minimum of its row, and NaN < thres_error is False: such a row has no match
+        ok = ~np.isin(si[ks], si[ks][np.isnan(err)])
+        ks, err = ks[ok], err[ok]
     order = np.lexsort((di[ks], err, si[ks]))
     ks, err = ks[order], err[order]
     first = np.ones(len(ks), dtype=bool)
@@ -320,6 +324,13 @@ def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, async
     pairs = np.stack([labels_unq, labels_unq], axis=1)
     pairs = pairs[np.minimum(pairs[:, 0], pairs[:, 1]) >= 0].astype(np.float32)                  # :30-31
     pairs_true = pairs[_sanity_mask(args, st, dt, pairs)] if len(pairs) else pairs
+    if len(pairs_true) > 0 and _device_association_ok(args, st, dt):
+        # both stages, the step between them, the pair rows: enqueued without reading a stage's results back (below)
+        out = yield from _match_pcds_device(args, st, dt, pairs_true, asynchronous)
+        if out is not None:
+            return out
+        # (a cluster too long for max_points turned out to need a second try: its random subsample must be drawn in the
+        # reference's order, which only the path below knows -- registered again from the start, same generator state)
     launched = _launch_pairs(args, st, dt, pairs_true) if len(pairs_true) > 0 else None
     pend = Pending(launched[2], asynchronous, 1) if launched is not None else None
     # while stage 1 runs on the GPU: the sanity test of EVERY source cluster against every destination cluster (stage 2
@@ -355,6 +366,131 @@ def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, async
     np.concatenate([T_sta, T_dyn], axis=0, out=both[10 * P:].reshape(P, 4, 4))
     d_both = torch.from_numpy(both).to(dev, non_blocking=asynchronous)
     return d_both[: 10 * P].view(P, 10), d_both[10 * P:].view(P, 4, 4)
+
+
+def _device_association_ok(args, st, dt):
+    """The device-side association (icpflow_assoc_assign / _collect, options.d_pair_active) needs the ICP's single speculative
+    launch (reference stop rule, <= 128 iterations) and cluster tables that fit the kernels' LDS tables.
+    `args.device_association` (default True; False = the host path: every stage read back, numpy in between).  A frame pair
+    on its own gains the read-back between the stages, time the GPU idled (2.45 -> 2.25 ms at 2048 points, 2.6 -> 2.4 at
+    10000); with frame pairs in flight that read-back was hidden behind the other frame pairs already and the superset's
+    extra work is not, which comes out even (1.41-1.51 vs 1.42-1.59 ms with four in flight, 1.37-1.44 vs 1.36-1.46 with
+    eight).  One path in both modes: a frame pair registers to the same bits in flight or on its own."""
+    if not getattr(args, "device_association", True):
+        return False
+    max_it, _, stop = _icp_options(args)
+    cur = _lib._current()[-1]
+    return (stop == 0 and 2 <= max_it <= 128 and cur["arith"] == 0 and not (cur["flags"] & _lib.OPT_FLAGS["no_speculative"])
+            and len(st.h_labels) <= 1024 and len(dt.h_labels) <= 1024)
+
+
+def _match_pcds_device(args, st, dt, pairs_true, asynchronous):
+    """match_pcds from the cluster tables on, with ONE hand-over at the end.  Stage 1 as usual; stage 2 is
+    enqueued for a SUPERSET of its candidates -- every (source, destination) the sanity grid lets through, known from the tables
+    alone -- and a one-workgroup kernel (icpflow_assoc_assign) does on the device what _finish_pairs does on the host, then
+    switches every stage-2 candidate on or off (both clusters still without a partner, utils_match.py:45-53): the switched-off
+    ones are handed over as empty clouds and flagged in options.d_pair_active, which keeps them out of the ICP's batch-global
+    stop -- stage 2's batch IS the reference's batch.  icpflow_assoc_collect writes the pair rows of both stages.
+    -> (pairs [P,10], transforms [P,4,4]) device tensors, or None when a candidate of stage 2 that had to be left out of the
+    superset -- a cluster longer than max_points, whose random subsample must be drawn in the reference's order of draws --
+    turned out to be needed: the caller then runs the host path."""
+    dev = st.points.device
+    S, D = len(st.h_labels), len(dt.h_labels)
+    gen_state = None
+    g = getattr(args, "generator", None)
+    gen_state = g.get_state() if g is not None else torch.get_rng_state()
+    si1, di1 = st.find_host(pairs_true[:, 0]), dt.find_host(pairs_true[:, 1])
+    K1 = len(si1)
+    # stage 1 first: the host work below (grid, superset) runs while the GPU is in it
+    segs_src, segs_dst = _gather_pair_batches(args, st, dt, si1, di1)
+    with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False)):
+        r1, _ = _hist_icp_eval_flat(args, segs_src, segs_dst)
+    # Left out of the superset: pairs with a cluster longer than max_points (its random subsample must be drawn in the
+    # reference's order of draws, which depends on what stage 1 matches) -- and pairs with a cluster longer than
+    # `args.device_association_width` (1024): the superset's batch is as wide as its longest cluster, and a wide batch of two
+    # hundred mostly switched-off pairs reserves LDS for its width on every CU it touches (130 KiB at 2944 points: with frame
+    # pairs in flight its workgroups queued behind the other frames' team launches and held up everything behind them, 1.4
+    # -> 2.1 ms per frame pair).  Long clusters are the ones stage 1 matches; if one of them does need its second try, the
+    # check at the end sends the frame pair through the host path.
+    cap_pts = min(int(args.max_points), int(getattr(args, "device_association_width", 1024)))
+    grid = sanity_grid(args, st, dt, np.arange(S), np.arange(D))
+    long_s, long_d = st.h_count > cap_pts, dt.h_count > cap_pts
+    left_out = grid & (long_s[:, None] | long_d[None, :])
+    rs, rd = np.nonzero(grid & ~left_out)
+    K2 = len(rs)
+    N2 = min(cap_pts, max(64, (int(max(st.h_count[rs].max(), dt.h_count[rd].max())) + 63) // 64 * 64)) if K2 else 64
+    if not getattr(args, "tight_padding", True):
+        N2 = int(args.max_points)
+    # ONE upload: stage 2's segment rows [2,3,K2] int64, then the candidate rows of both stages as int32
+    # ... through a pinned staging buffer: a pageable host -> device copy waits for everything queued on its stream, i.e.
+    # the host would sit out stage 1 right here (frame pairs in flight stopped overlapping, 1.3 -> 1.9 ms per frame pair)
+    nbytes = 48 * K2 + 8 * (K1 + K2)
+    key = (_lib.stream_handle(dev), "assoc", torch.uint8)
+    stage = Pending._pinned.get(key)
+    if stage is None or stage.numel() < nbytes:
+        stage = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+        Pending._pinned[key] = stage
+    host = stage.numpy()[:nbytes]
+    seg2 = host[: 48 * K2].view(np.int64).reshape(2, 3, K2)
+    idx = host[48 * K2:].view(np.int32)
+    if K2:
+        seg2[0, 0], seg2[0, 1], seg2[0, 2] = st.h_start[rs], st.h_count[rs], -1
+        seg2[1, 0], seg2[1, 1], seg2[1, 2] = dt.h_start[rd], dt.h_count[rd], -1
+    idx[0:K1], idx[K1:2 * K1] = si1, di1
+    idx[2 * K1:2 * K1 + K2], idx[2 * K1 + K2:] = rs, rd
+    d_host = stage[:nbytes].to(dev, non_blocking=True)
+    base = d_host.data_ptr()
+    at = lambda off: ctypes.c_void_p(base + off)   # noqa: E731
+    p_si1, p_di1 = at(48 * K2), at(48 * K2 + 4 * K1)
+    p_si2, p_di2 = at(48 * K2 + 8 * K1), at(48 * K2 + 8 * K1 + 4 * K2)
+    small = torch.empty((2 * S + 2,), dtype=torch.int32, device=dev)      # best1 [S], best2 [S], count, -
+    best1, best2, count = small[:S], small[S:2 * S], small[2 * S:2 * S + 1]
+    active2 = torch.empty((max(K2, 1),), dtype=torch.uint8, device=dev)
+    f32 = lambda v: float(np.float32(v))   # noqa: E731
+    thr = (f32(args.translation_frame), f32(args.thres_iou), f32(args.thres_rot * 90.0), f32(args.thres_error))
+    _lib.call("icpflow_assoc_assign", _lib.ptr(r1), p_si1, p_di1, K1, None, S, D, *thr, _lib.ptr(best1), K2,
+              p_si2 if K2 else None, p_di2 if K2 else None, at(0) if K2 else None, _lib.ptr(active2) if K2 else None,
+              _lib.stream(dev))
+    r2 = None
+    if K2:
+        segs2 = torch.empty((2, K2, N2, 4), dtype=torch.float32, device=dev)
+        for which, table in enumerate((st, dt)):
+            _lib.call("icpflow_gather_segments", _lib.ptr(table.points), _lib.ptr(table.order), at(24 * K2 * which), None, K2, N2,
+                      _lib.ptr(segs2[which]), _lib.stream(dev))
+        with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False), pair_active=active2):
+            r2, _ = _hist_icp_eval_flat(args, segs2[0], segs2[1])
+        _lib.call("icpflow_assoc_assign", _lib.ptr(r2), p_si2, p_di2, K2, _lib.ptr(active2), S, D, *thr, _lib.ptr(best2), 0,
+                  None, None, None, None, _lib.stream(dev))
+    cap = 2 * S
+    rows = torch.empty((cap, 10), dtype=torch.float32, device=dev)
+    T = torch.empty((cap, 4, 4), dtype=torch.float32, device=dev)
+    _lib.call("icpflow_assoc_collect", _lib.ptr(best1), _lib.ptr(r1), p_si1, p_di1, K1, _lib.ptr(best2) if K2 else None,
+              _lib.ptr(r2) if K2 else None, p_si2 if K2 else None, p_di2 if K2 else None, K2,
+              ctypes.c_void_p(st._packed.data_ptr() + 8), ctypes.c_void_p(dt._packed.data_ptr() + 8), 9, S, cap,
+              _lib.ptr(rows), _lib.ptr(T), _lib.ptr(count), _lib.stream(dev))
+    pend = Pending(small, asynchronous, 1)
+    yield pend
+    h = pend.get()
+    P = int(h[2 * S])
+    if P < 0:
+        raise RuntimeError("icpflow_hist_icp abandoned the batch: a wait between workgroups timed out -- a team sharing one "
+                           "large pair, or a helper's hand-off in a persistent launch (GPU shared with another process?); "
+                           "retry, or register with _lib.options(no_teams=True, no_helpers=True, no_persistent=True)")
+    if left_out.any():
+        # a pair that was left out of the superset (over-long cluster) and whose clusters both found no partner in stage 1 is
+        # a stage-2 candidate of the reference: this path cannot serve it
+        b1 = h[:S]
+        m_s = b1 >= 0
+        m_d = np.zeros(D, dtype=bool)
+        m_d[di1[b1[m_s]]] = True
+        ls, ld = np.nonzero(left_out)
+        if (~m_s[ls] & ~m_d[ld]).any():
+            if g is not None:
+                g.set_state(gen_state)
+            else:
+                torch.set_rng_state(gen_state)
+            return None
+    return rows[:P], T[:P]
 
 
 def drive(gen):

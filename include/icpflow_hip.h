@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 204 /* 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 205 /* 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -138,6 +138,12 @@ typedef struct icpflow_options {
     int icp_estimate_scale;
     float *d_icp_scale;
     const float *d_icp_init_s;
+    /* icpflow_hist_icp / icpflow_hist_icp_eval: uint8 [B] or NULL.  Pairs flagged 0 are NOT IN THE BATCH: the batch-global
+     * stop of the ICP (utils_icp_pytorch3d.py:209) is taken over the flagged pairs only, their outputs are unspecified.  For
+     * callers that must size a batch before the device has decided which of its candidate pairs exist (stage 2 of match_pcds
+     * enqueued before stage 1's results are known: icpflow_assoc_assign); the caller hands such pairs over as EMPTY clouds
+     * (all flags 0), so that every other kernel of the path skips them.  Reference stop rule, max_iterations <= 128 only. */
+    const uint8_t *d_pair_active;
 } icpflow_options_t;
 
 /* Bytes of device scratch the fused entry points below need for a batch of B
@@ -351,6 +357,33 @@ int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, 
  * ------------------------------------------------------------------------- */
 int icpflow_gather_pad(const float *d_points, const int32_t *d_rows, int B, int N, float *d_out,
                        icpflow_stream_t stream);
+/* Device-side association of a frame pair (match_pairs' host half, utils_match.py:96-115, as kernels -- so that match_pcds can
+ * enqueue both of its stages and the flow without reading a stage's results back).
+ *
+ * icpflow_assoc_assign: one association stage.  d_result = the results of icpflow_hist_icp_eval for the stage's K candidate
+ * pairs, float32 array after array [T 16K | errors 2K | inliers 2K | ratios 2K | ious 2K | translations 3K | rotations 3K];
+ * candidate k pairs source cluster d_si[k] (row of the source table, < S) with destination cluster d_di[k] (< D); d_active
+ * (uint8 [K] or NULL): candidates flagged 0 do not exist.  A candidate survives check_transformation (utils_check.py:51-66)
+ * iff |translation| <= translation_frame, min(iou) >= thres_iou and max(|rot_y|, |rot_x|) <= rot_limit_deg; every source
+ * row takes the surviving candidate with the smallest min(error_src, error_dst), ties to the smallest destination row
+ * (np.argmin's first minimum, utils_helper.py:108-110), if that error is < thres_error (utils_match.py:112): d_best int32 [S]
+ * receives its index or -1.  With K2 > 0 the NEXT stage's candidates (d_si2, d_di2 [K2]) are switched on or off in the same
+ * launch (utils_match.py:45-53: only clusters that found no partner go on): d_active2 uint8 [K2], and the lengths of the
+ * inactive ones in d_seg2 (int64 [2,3,K2], the segment rows of icpflow_gather_segments for both clouds) are set to 0.
+ *
+ * icpflow_assoc_collect: the pair rows of both stages, stage 1 first, each in ascending source row: d_rows float32 [cap,10]
+ * (source label, destination label, errors, inliers, ratios, ious: utils_match.py:120-131), d_T float32 [cap,16]; rows beyond
+ * the matches carry the label -3e38 (no point has it) and the identity.  d_count int32: the number of matches, or -1 when a
+ * stage reported an abandoned batch (iteration count < 0).  Labels: float64 tables with `label_stride` doubles per row (the
+ * d_table of icpflow_cluster_table).  Stage 2 may be absent (K2 = 0). */
+int icpflow_assoc_assign(const float *d_result, const int32_t *d_si, const int32_t *d_di, int K, const uint8_t *d_active,
+                         int S, int D, float translation_frame, float thres_iou, float rot_limit_deg, float thres_error,
+                         int32_t *d_best, int K2, const int32_t *d_si2, const int32_t *d_di2, int64_t *d_seg2,
+                         uint8_t *d_active2, icpflow_stream_t stream);
+int icpflow_assoc_collect(const int32_t *d_best1, const float *d_result1, const int32_t *d_si1, const int32_t *d_di1, int K1,
+                          const int32_t *d_best2, const float *d_result2, const int32_t *d_si2, const int32_t *d_di2, int K2,
+                          const double *d_src_table, const double *d_dst_table, int label_stride, int S, int cap,
+                          float *d_rows, float *d_T, int32_t *d_count, icpflow_stream_t stream);
 int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const int64_t *d_seg,
                             const int32_t *d_perm, int B, int N, float *d_out, icpflow_stream_t stream);
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,

@@ -1284,3 +1284,78 @@ def test_match_pcds_with_an_empty_cloud_returns_no_pairs():
     for sp, sl, dp, dl in ((empty_p, empty_l, pts, lab), (pts, lab, empty_p, empty_l), (empty_p, empty_l, empty_p, empty_l)):
         pairs, T = utils_match.match_pcds(a, sp, dp, sl, dl)
         assert tuple(pairs.shape) == (0, 10) and tuple(T.shape) == (0, 4, 4)
+
+
+@pytest.mark.parametrize("seed,n_objects,n_max,max_points", [(2, 9, 400, 512), (5, 14, 300, 512), (11, 6, 700, 1024), (3, 10, 400, 128)],
+                         ids=["two-stages", "more-objects", "larger", "over-long-clusters-fall-back"])
+def test_device_association_equals_the_host_path(seed, n_objects, n_max, max_points):
+    """match_pcds with both stages enqueued from the cluster tables on (icpflow_assoc_assign / _collect, stage 2 as a superset
+    with options.d_pair_active: utils_match._match_pcds_device, the default) against the host path (args.device_association =
+    False: every stage's results read back, numpy in between).  Relabelled objects, so that stage 2 has work: the same matched
+    pairs in the same order, errors / inliers / transforms to rounding (stage 2's batch is wider and larger on the device path:
+    other workgroup shapes, same registrations), per-point flow within 1e-5 m.  With max_points below the cluster sizes the
+    relabelled clusters are over-long AND unmatched after stage 1: their random subsamples must be drawn in the reference's
+    order, the device path gives up and the host path answers -- bit for bit."""
+    from icp_flow_amd import frame_pairs, utils_flow
+    d = synthetic.make_frame_pair(seed=seed, n_objects=n_objects, n_max=n_max, n_background=1200)
+    ps, pd, ls, ld = G(d["points_src"]), G(d["points_dst"]), G(d["labels_src"]).float(), G(d["labels_dst"]).float()
+    pose = G(d["pose"])
+    out = {}
+    tried = []
+    orig = utils_match._match_pcds_device
+
+    def spy(*a, **k):
+        r = yield from orig(*a, **k)
+        tried.append(r is not None)
+        return r
+
+    utils_match._match_pcds_device = spy
+    try:
+        for device_path in (True, False):
+            a = frame_pairs.default_args(max_points=max_points)
+            a.device_association = device_path
+            a.generator = torch.Generator()
+            a.generator.manual_seed(0)
+            pairs, T = utils_match.match_pcds(a, ps, pd, ls, ld)
+            flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, T, pose)
+            out[device_path] = (pairs.cpu().numpy(), T.cpu().numpy(), flow.cpu().numpy())
+    finally:
+        utils_match._match_pcds_device = orig
+    (pd_, Td, fd), (ph, Th, fh) = out[True], out[False]
+    assert len(tried) == 1                                   # the device path was entered once (and not at all when switched off)
+    assert pd_.shape == ph.shape and np.array_equal(pd_[:, :2], ph[:, :2])
+    assert len(ph) >= 3
+    if max_points == 128:
+        assert tried == [False]                              # gave up: an over-long cluster needed its second try
+        assert np.array_equal(pd_, ph) and np.array_equal(Td, Th) and np.array_equal(fd, fh)
+        return
+    assert tried == [True]
+    assert (ph[:, 1] >= 1000).sum() >= 1                     # some objects matched by stage 2
+    np.testing.assert_allclose(pd_[:, 2:4], ph[:, 2:4], atol=2e-5)          # errors
+    assert np.array_equal(pd_[:, 4:6], ph[:, 4:6])                           # inlier counts
+    np.testing.assert_allclose(Td, Th, atol=2e-5)
+    assert np.abs(fd - fh).max() < 1e-5
+
+
+def test_pairs_outside_the_batch_do_not_touch_its_stop_rule():
+    """options.d_pair_active: pairs flagged 0 (handed over as empty clouds) are not in the batch -- the registrations and the
+    iteration count of the flagged pairs are those of the batch made of the flagged pairs alone (to rounding: the launch shape
+    differs), whatever sits in the other rows; refused outside the single speculative launch of the reference stop."""
+    S, D, _ = synthetic.make_batch(40, 512, seed=77, ragged=True, n_min=40)
+    keep = np.zeros(40, dtype=bool)
+    keep[[1, 4, 5, 9, 17, 18, 30, 39]] = True
+    S2, D2 = S.copy(), D.copy()
+    S2[~keep] = 0; S2[~keep, :, :3] = 1e8
+    D2[~keep] = 0; D2[~keep, :, :3] = 1e8
+    a = rp.default_args(max_points=512, icp_max_iterations=100)
+    T_sub, it_sub = utils_match.hist_icp(a, G(S[keep]), G(D[keep]), return_iterations=True)
+    with _lib.options(pair_active=G(keep.astype(np.uint8))):
+        T_all, it_all = utils_match.hist_icp(a, G(S2), G(D2), return_iterations=True)
+    assert int(it_all) == int(it_sub)
+    np.testing.assert_allclose(T_all.cpu().numpy()[keep], T_sub.cpu().numpy(), atol=2e-6)
+    # without the mask the empty pairs never satisfy the stop test: the batch runs to the cap
+    _, it_nomask = utils_match.hist_icp(a, G(S2), G(D2), return_iterations=True)
+    assert int(it_nomask) == 100 > int(it_sub)
+    with _lib.options(pair_active=G(keep.astype(np.uint8))):
+        with pytest.raises(RuntimeError, match="d_pair_active"):
+            utils_match.hist_icp(rp.default_args(max_points=512, icp_stop_mode="per_pair"), G(S2), G(D2))

@@ -44,6 +44,8 @@ def test_finish_pairs_equals_the_matrix_form_on_random_stages():
         si, di = cells // D, cells % D
         K = len(cells)
         errors = rng.choice([0.03, 0.05, 0.1, 0.15, 0.19, 0.2, 0.3], size=(K, 2)).astype(np.float32)     # many ties
+        if trial % 3 == 0:
+            errors[rng.random((K, 2)) < 0.1] = np.nan       # (a pair without inliers: np.argmin takes the NaN, the row has no match)
         inliers = rng.integers(0, 500, (K, 2)).astype(np.float32)
         ratios = rng.random((K, 2)).astype(np.float32)
         ious = rng.choice([0.1, 0.2, 0.5, 0.9], size=(K, 2)).astype(np.float32)

@@ -7,7 +7,7 @@ from conftest import load_golden
 from icp_flow_amd import frame_pairs
 g = load_golden("g8_demo"); lab = load_golden("g8_demo_labels")
 dev = torch.device("cuda:0")
-a = frame_pairs.default_args(max_points=10000)
+a = frame_pairs.default_args(max_points=10000); a.device_association = os.environ.get("DEVICE_ASSOC", "1") == "1"
 fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
 copies = [fp] * 24
 for _ in frame_pairs.register_in_flight(a, copies[:8], dev, 4): pass
