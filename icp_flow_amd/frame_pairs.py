@@ -284,14 +284,21 @@ def register_frame_pair_steps(args, fp, device, gap=None, asynchronous=False):
     # draws (random subsampling of over-long clusters) without touching the caller's global RNG state
     a.generator = torch.Generator()
     a.generator.manual_seed(0)
+    # multi-gap sample: flow of the RAW source points, the ego pose composed in (main.py:230-234; T registers the
+    # ego-compensated cloud, so a point moves by T * pose); frame-pair files hand over ego-compensated clouds, their `pose`
+    # (identity in demo.py:221) is composed as given
+    flow_src = ps if fp.points_src_raw is None else _upload(fp.points_src_raw, device)
+    early = []
+
+    def flow_of(rows, T):
+        return utils_flow.flow_estimation_torch(a, flow_src, pd, ls, ld, rows, T, pose)
+
+    # the device-side association hands its (padded) pair rows over before it reads anything back: the flow is enqueued
+    # right behind the association and the frame pair has ONE wait, at its end
+    a.on_association_enqueued = lambda rows, T: early.append(flow_of(rows, T))
+    a.association_path = None
     pairs, T = yield from utils_match.match_pcds_steps(a, ps, pd, ls, ld, asynchronous)      # utils_track.py:31-35
-    if fp.points_src_raw is not None:
-        # multi-gap sample: flow of the RAW source points, the ego pose composed in (main.py:230-234; T registers the
-        # ego-compensated cloud, so a point moves by T * pose)
-        flow = utils_flow.flow_estimation_torch(a, torch.from_numpy(fp.points_src_raw).to(device), pd, ls, ld, pairs, T, pose)
-    else:
-        # frame-pair files hand over ego-compensated clouds; their `pose` (identity in demo.py:221) is composed as given
-        flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, T, pose)
+    flow = early[0] if (early and a.association_path == "device") else flow_of(pairs, T)
     return dict(pairs=pairs, transformations=T, flow=flow, translation_frame=a.translation_frame)
 
 

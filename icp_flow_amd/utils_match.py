@@ -327,6 +327,7 @@ def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, async
     if len(pairs_true) > 0 and _device_association_ok(args, st, dt):
         # both stages, the step between them, the pair rows: enqueued without reading a stage's results back (below)
         out = yield from _match_pcds_device(args, st, dt, pairs_true, asynchronous)
+        args.association_path = "device" if out is not None else "host"
         if out is not None:
             return out
         # (a cluster too long for max_points turned out to need a second try: its random subsample must be drawn in the
@@ -468,6 +469,11 @@ def _match_pcds_device(args, st, dt, pairs_true, asynchronous):
               _lib.ptr(r2) if K2 else None, p_si2 if K2 else None, p_di2 if K2 else None, K2,
               ctypes.c_void_p(st._packed.data_ptr() + 8), ctypes.c_void_p(dt._packed.data_ptr() + 8), 9, S, cap,
               _lib.ptr(rows), _lib.ptr(T), _lib.ptr(count), _lib.stream(dev))
+    # What only needs the pair rows ON THE DEVICE goes in now, ahead of the read-back (frame_pairs: the flow of the frame
+    # pair): rows beyond the matches carry a label no point has and the identity, so the padded arrays serve.
+    hook = getattr(args, "on_association_enqueued", None)
+    if hook is not None:
+        hook(rows, T)
     pend = Pending(small, asynchronous, 1)
     yield pend
     h = pend.get()

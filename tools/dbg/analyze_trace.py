@@ -20,3 +20,15 @@ for r in rows:
     acc[k][0] += 1; acc[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 for k, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:12]:
     print('  %-50s calls %4d avg %8.1f us total %7.2f ms' % (k, c, t / c, t / 1e3))
+if len(sys.argv) > 2 and sys.argv[2] == "timeline":
+    # the kernels of the LAST frame pair (K=1: one at a time), in order: start offset, duration, gap since the previous kernel's end
+    per = len(rows) // max(1, int(sys.argv[3]) if len(sys.argv) > 3 else 16)
+    last_rows = rows[-per:]
+    base = int(last_rows[0]['Start_Timestamp']); prev_end = base
+    for r in last_rows:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('icpflow::', '')[:60]
+        print('  +%8.1f us  dur %7.1f  gap %7.1f  %s  grid %s wg %s' % ((s - base) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name,
+              r.get('Grid_Size', '?'), r.get('Workgroup_Size', '?')))
+        prev_end = max(prev_end, e)
+    print('  frame span %.1f us over %d kernels' % ((prev_end - base) / 1e3, len(last_rows)))
