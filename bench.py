@@ -590,11 +590,13 @@ def frame_pair_measurement(dev):
             except OSError:
                 pass
         # the same frame pair as a STREAM (BASELINE configs 3 / 5 are streams of independent frame pairs, main.py:184-215):
-        # 12 copies, 4 in flight (frame_pairs.register_in_flight: one stream each, asynchronous hand-overs, one host
-        # thread); wall time of the stream over its frame pairs -- throughput, not the latency above
+        # 12 copies with 4 in flight, 24 with 8 (frame_pairs.register_in_flight: one stream each, asynchronous hand-overs, one
+        # host thread); wall time of the stream over its frame pairs -- throughput, not the latency above.  (Round 4: with the
+        # association on the device a frame pair has two long host bursts instead of four short ones; four in flight no longer
+        # keep the GPU fed through a burst -- 1.26 -> 1.5 ms -- eight do)
         fp_obj = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
-        copies = [fp_obj] * 12
-        for in_flight in (4,):
+        for in_flight in (4, 8):
+            copies = [fp_obj] * (3 * in_flight)
             # (the untimed pass keeps every result for the comparison; the timed one consumes them as a sweep would --
             # holding twelve frames' outputs makes the caching allocator grow on every stream inside the timed region)
             flows = {i: o["flow"] for i, _, o in frame_pairs.register_in_flight(a, copies, dev, in_flight)}

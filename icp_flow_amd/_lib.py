@@ -54,6 +54,8 @@ SIGNATURES = {
     "icpflow_gather_segments": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
     "icpflow_assoc_assign": (_i, [_p, _p, _p, _i, _p, _i, _i, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _p]),
     "icpflow_assoc_collect": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "icpflow_register_stage": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_associate_frame": (_i, [_p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _sz, _p, _p]),
     "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "icpflow_cluster_table_workspace_bytes": (_sz, [_i, _i]),
     "icpflow_cluster_table": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _sz, _p]),
@@ -104,6 +106,23 @@ class Options(ctypes.Structure):
                 ("profile", _p), ("d_vote_bins_u32", _p), ("d_icp_init_R", _p), ("d_icp_init_T", _p),
                 ("d_icp_history", _p), ("icp_allow_reflection", _i), ("icp_estimate_scale", _i),
                 ("d_icp_scale", _p), ("d_icp_init_s", _p), ("d_pair_active", _p)]
+
+
+class Tables(ctypes.Structure):
+    """icpflow_tables_t: both clouds of a frame pair as icpflow_cluster_table leaves them."""
+    _fields_ = [("d_points_src", _p), ("d_order_src", _p), ("d_table_src", _p), ("d_points_dst", _p), ("d_order_dst", _p),
+                ("d_table_dst", _p), ("S", _i), ("D", _i), ("label_stride", _i)]
+
+
+class Stage(ctypes.Structure):
+    """icpflow_stage_t: the candidate pairs of one association stage."""
+    _fields_ = [("d_seg", _p), ("d_perm", _p), ("d_si", _p), ("d_di", _p), ("d_clouds", _p), ("d_result", _p), ("K", _i), ("N", _i)]
+
+
+class Registration(ctypes.Structure):
+    """icpflow_registration_t: the arguments of icpflow_hist_icp_eval that do not depend on the batch."""
+    _fields_ = [("d_edges_x", _p), ("d_edges_y", _p), ("d_edges_z", _p), ("len_x", _i), ("len_y", _i), ("len_z", _i),
+                ("decode_shift", _f), ("thres_dist", _d), ("relative_rmse_thr", _d), ("max_iterations", _i), ("stop_mode", _i)]
 
 
 class Profile:

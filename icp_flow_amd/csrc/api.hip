@@ -579,6 +579,74 @@ int icpflow_assoc_collect(const int32_t *d_best1, const float *d_result1, const 
     return 0;
 }
 
+// One association stage per call: the padded batch of both clouds, the registration, its metrics (declared below)
+int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x, int len_x,
+                          const float *d_edges_y, int len_y, const float *d_edges_z, int len_z, float decode_shift,
+                          double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
+                          float *d_T_out, int32_t *d_iters, float *d_errors, float *d_inliers, float *d_ratios,
+                          float *d_ious, float *d_translations, float *d_rotations, void *d_ws, size_t ws_bytes,
+                          icpflow_stream_t stream, const icpflow_options_t *opt);
+int icpflow_flow_rigid_rows(const float *d_points, const float *d_labels, int N, const float *d_pair_rows, int pair_stride,
+                            const float *d_T, int P, const float *d_pose, float *d_flow, icpflow_stream_t stream);
+
+int icpflow_register_stage(const icpflow_tables_t *t, const icpflow_stage_t *st, const icpflow_registration_t *reg,
+                           void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt)
+{
+    if (!t || !st || !reg) return fail(ICPFLOW_E_ARG, "icpflow_register_stage: null argument");
+    if (!t->d_points_src || !t->d_order_src || !t->d_points_dst || !t->d_order_dst || !st->d_seg || !st->d_clouds || !st->d_result)
+        return fail(ICPFLOW_E_ARG, "icpflow_register_stage: null pointer");
+    const int K = st->K, N = st->N;
+    if (int r = check_batch("icpflow_register_stage", K, N)) return r;
+    const size_t cloud = (size_t)K * N * 4;
+    if (int r = icpflow_gather_segments(t->d_points_src, t->d_order_src, st->d_seg, st->d_perm, K, N, st->d_clouds, stream)) return r;
+    if (int r = icpflow_gather_segments(t->d_points_dst, t->d_order_dst, st->d_seg + (size_t)3 * K, st->d_perm, K, N,
+                                        st->d_clouds + cloud, stream))
+        return r;
+    float *R = st->d_result;
+    const size_t k = (size_t)K;
+    return icpflow_hist_icp_eval(st->d_clouds, st->d_clouds + cloud, K, N, reg->d_edges_x, reg->len_x, reg->d_edges_y, reg->len_y,
+                                 reg->d_edges_z, reg->len_z, reg->decode_shift, reg->thres_dist, reg->max_iterations,
+                                 reg->relative_rmse_thr, reg->stop_mode, R, reinterpret_cast<int32_t *>(R + 30 * k), R + 16 * k,
+                                 R + 18 * k, R + 20 * k, R + 22 * k, R + 24 * k, R + 27 * k, d_ws, ws_bytes, stream, opt);
+}
+
+int icpflow_associate_frame(const icpflow_tables_t *t, const icpflow_stage_t *s1, const icpflow_stage_t *s2, uint8_t *d_active2,
+                            const icpflow_registration_t *reg, float translation_frame, float thres_iou, float rot_limit_deg,
+                            float thres_error, int32_t *d_best, int cap, float *d_rows, float *d_T, const float *d_flow_points,
+                            const float *d_flow_labels, int n_flow, const float *d_pose, float *d_flow, void *d_ws,
+                            size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt)
+{
+    if (!t || !s1 || !reg || !d_best || !d_rows || !d_T) return fail(ICPFLOW_E_ARG, "icpflow_associate_frame: null argument");
+    if (!t->d_table_src || !t->d_table_dst || !s1->d_result || !s1->d_si || !s1->d_di)
+        return fail(ICPFLOW_E_ARG, "icpflow_associate_frame: null pointer");
+    const int S = t->S, D = t->D, K1 = s1->K, K2 = s2 ? s2->K : 0;
+    if (K2 > 0 && (!d_active2 || !s2->d_si || !s2->d_di || !s2->d_seg || !s2->d_result))
+        return fail(ICPFLOW_E_ARG, "icpflow_associate_frame: stage 2 comes with d_active2, d_si, d_di, d_seg and d_result");
+    int32_t *best1 = d_best, *best2 = d_best + S, *count = d_best + 2 * (size_t)S;
+    // (stage 2's segment rows are written by the assignment: the lengths of the switched-off candidates become 0)
+    if (int r = icpflow_assoc_assign(s1->d_result, s1->d_si, s1->d_di, K1, nullptr, S, D, translation_frame, thres_iou, rot_limit_deg,
+                                     thres_error, best1, K2, K2 ? s2->d_si : nullptr, K2 ? s2->d_di : nullptr,
+                                     K2 ? const_cast<int64_t *>(s2->d_seg) : nullptr, K2 ? d_active2 : nullptr, stream))
+        return r;
+    if (K2 > 0) {
+        icpflow_options_t o2{};
+        o2.struct_size = sizeof(icpflow_options_t);
+        if (opt) o2 = *opt;
+        o2.d_pair_active = d_active2;
+        if (int r = icpflow_register_stage(t, s2, reg, d_ws, ws_bytes, stream, &o2)) return r;
+        if (int r = icpflow_assoc_assign(s2->d_result, s2->d_si, s2->d_di, K2, d_active2, S, D, translation_frame, thres_iou,
+                                         rot_limit_deg, thres_error, best2, 0, nullptr, nullptr, nullptr, nullptr, stream))
+            return r;
+    }
+    if (int r = icpflow_assoc_collect(best1, s1->d_result, s1->d_si, s1->d_di, K1, K2 ? best2 : nullptr, K2 ? s2->d_result : nullptr,
+                                      K2 ? s2->d_si : nullptr, K2 ? s2->d_di : nullptr, K2, t->d_table_src, t->d_table_dst,
+                                      t->label_stride, S, cap, d_rows, d_T, count, stream))
+        return r;
+    if (d_flow != nullptr)
+        return icpflow_flow_rigid_rows(d_flow_points, d_flow_labels, n_flow, d_rows, 10, d_T, cap, d_pose, d_flow, stream);
+    return 0;
+}
+
 size_t icpflow_dbscan_workspace_bytes(int n)
 {
     if (n <= 0) return 0;

@@ -377,6 +377,10 @@ constexpr int kProbeSteps = ICPFLOW_PROBE_STEPS;
 #define ICPFLOW_PROBE_STEPS_LONG 24
 #endif
 constexpr int kProbeMaxLong = ICPFLOW_PROBE_MAX_LONG, kProbeStepsLong = ICPFLOW_PROBE_STEPS_LONG;
+#ifndef ICPFLOW_WIDE_WINDOW
+#define ICPFLOW_WIDE_WINDOW 512
+#endif
+constexpr int kWideWindow = ICPFLOW_WIDE_WINDOW;   // (targets in a wave's previous window from which every lane may probe)
 #ifndef ICPFLOW_PROBE_CAP
 #define ICPFLOW_PROBE_CAP 128
 #endif
@@ -952,7 +956,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     // (and every lane of the wave where the alternative is a scan of a long window of a long cloud: this wave's window
                     // of the previous search held more than 512 targets -- a dense 10000-point cluster; on the ragged real-shape
                     // batch the ICP launch 1.33 -> 0.94 ms; the demo frame's wall, long but thin, keeps its short windows and 32)
-                    const bool wideWindows = yc.n > 4096 && winHi - winLo > 512;
+                    const bool wideWindows = yc.n > 4096 && winHi - winLo > kWideWindow;
                     const int probeSteps = longProbes ? kProbeStepsLong : kProbeSteps;
                     const int probeMax = longProbes ? (wideWindows ? kWave : kProbeMaxLong) : kProbeMax;
                     // Round 4: the probes of a pass are SHARED by the workgroup.  The uncertified queries are few, but they
@@ -1070,7 +1074,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     // (and every lane of the wave where the alternative is a scan of a long window of a long cloud: this wave's window
                     // of the previous search held more than 512 targets -- a dense 10000-point cluster; on the ragged real-shape
                     // batch the ICP launch 1.33 -> 0.94 ms; the demo frame's wall, long but thin, keeps its short windows and 32)
-                    const bool wideWindows = yc.n > 4096 && winHi - winLo > 512;
+                    const bool wideWindows = yc.n > 4096 && winHi - winLo > kWideWindow;
                     const int probeSteps = longProbes ? kProbeStepsLong : kProbeSteps;
                     const int probeMax = longProbes ? (wideWindows ? kWave : kProbeMaxLong) : kProbeMax;
 #pragma unroll

@@ -288,17 +288,16 @@ def register_frame_pair_steps(args, fp, device, gap=None, asynchronous=False):
     # ego-compensated cloud, so a point moves by T * pose); frame-pair files hand over ego-compensated clouds, their `pose`
     # (identity in demo.py:221) is composed as given
     flow_src = ps if fp.points_src_raw is None else _upload(fp.points_src_raw, device)
-    early = []
-
-    def flow_of(rows, T):
-        return utils_flow.flow_estimation_torch(a, flow_src, pd, ls, ld, rows, T, pose)
-
-    # the device-side association hands its (padded) pair rows over before it reads anything back: the flow is enqueued
-    # right behind the association and the frame pair has ONE wait, at its end
-    a.on_association_enqueued = lambda rows, T: early.append(flow_of(rows, T))
+    # the device-side association enqueues the flow right behind the pair rows, in the same call and ahead of its one
+    # read-back (utils_match._match_pcds_device): the frame pair has ONE wait, at its end
+    a.flow_request = dict(points=flow_src, labels=ls, pose=pose)
+    a.flow_result = None
     a.association_path = None
     pairs, T = yield from utils_match.match_pcds_steps(a, ps, pd, ls, ld, asynchronous)      # utils_track.py:31-35
-    flow = early[0] if (early and a.association_path == "device") else flow_of(pairs, T)
+    if a.association_path == "device" and a.flow_result is not None:
+        flow = a.flow_result
+    else:
+        flow = utils_flow.flow_estimation_torch(a, flow_src, pd, ls, ld, pairs, T, pose)
     return dict(pairs=pairs, transformations=T, flow=flow, translation_frame=a.translation_frame)
 
 

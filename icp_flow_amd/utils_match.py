@@ -136,9 +136,39 @@ def hist_icp_eval(args, src, dst, return_iterations=False):
 # cluster tables (utils_check.ClusterTable) in numpy; a stage costs ONE device -> host transfer of the
 # 30 B + 1 result words instead of the reference's per-pair scalar reads.
 # --------------------------------------------------------------------------------------
-def _gather_pair_batches(args, st, dt, si, di):
-    """pad_segment (utils_helper.py:185-196) of the candidate clusters (rows si / di of the tables), one
-    kernel per cloud: -> two [B, width, 4] device tensors (width: see below).  Over-long clusters are subsampled with
+class _Staging:
+    """Pinned host buffers that kernels read IN PLACE (per stream and slot): a stage's few KB of segment rows, subsamples and
+    candidate rows are written here by the host and never uploaded -- the gather and assignment kernels load them over PCIe
+    (tools/dbg/zero_copy_probe.py: 5 us of host time and 6 us to the end of the gather, against 26 / 26 us with a pageable
+    .to() in front and 9 / 21 us with a pinned non-blocking copy).  The host writes without regard to the stream, so a slot
+    carries an event: `done()` records it behind the launches that read the buffer, `get()` waits for it before handing the
+    buffer out again (a stage's results are normally read back long before: the wait is a query)."""
+    _slots = {}
+
+    @staticmethod
+    def get(dev, slot, nbytes):
+        """-> (key, uint8 numpy view of nbytes, address for the kernels)."""
+        key = (_lib.stream_handle(dev), slot)
+        ent = _Staging._slots.get(key)
+        if ent is None or ent[0].numel() < nbytes:
+            if ent is not None:
+                ent[1].synchronize()
+            ent = (torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, pin_memory=True), torch.cuda.Event())
+            _Staging._slots[key] = ent
+        else:
+            ent[1].synchronize()
+        return key, ent[0].numpy()[:nbytes], ent[0].data_ptr()
+
+    @staticmethod
+    def done(key):
+        _Staging._slots[key][1].record()
+
+
+def _stage_rows(args, st, dt, si, di):
+    """The segment rows of a stage's candidate clusters (rows si / di of the tables) for icpflow_gather_segments, in a
+    staging buffer the kernels read in place (_Staging; the caller calls _Staging.done(key) behind its launches):
+    -> (key, address of int64 [2,3,B] rows (start, length, offset of the subsample or -1) followed by the int32 subsamples, B,
+    width, whether there are subsamples).  Over-long clusters are subsampled with
     torch.randperm on the host generator (or `args.generator`, a torch.Generator private to the caller, so that
     frame pairs registered concurrently do not share a stream of draws), src then dst, pair by pair -- the
     reference's stream of draws
@@ -156,8 +186,8 @@ def _gather_pair_batches(args, st, dt, si, di):
     N = min(N, max(64, (int(max(cs.max(), cd.max())) + 63) // 64 * 64)) if getattr(args, "tight_padding", True) else N
     over = np.nonzero((cs > cap) | (cd > cap))[0]
     n_perm = int((cs[over] > cap).sum() + (cd[over] > cap).sum())
-    # ONE upload: the int64 segment rows [2, 3, B] (start, length, offset of the subsample or -1), then the int32 subsamples
-    host = np.empty((48 * B + 4 * cap * n_perm,), dtype=np.uint8)
+    # the int64 segment rows [2, 3, B] (start, length, offset of the subsample or -1), then the int32 subsamples
+    key, host, address = _Staging.get(dev, "rows", 48 * B + 4 * cap * n_perm)
     seg = host[: 48 * B].view(np.int64).reshape(2, 3, B)
     perm = host[48 * B:].view(np.int32)
     seg[0, 0], seg[0, 1], seg[0, 2] = st.h_start[si], np.minimum(cs, cap), -1
@@ -169,14 +199,30 @@ def _gather_pair_batches(args, st, dt, si, di):
                 seg[which, 2, k] = drawn * cap
                 perm[drawn * cap: (drawn + 1) * cap] = torch.randperm(int(c[k]), generator=getattr(args, "generator", None))[0:cap].numpy()
                 drawn += 1
-    d_host = torch.from_numpy(host).to(dev)
-    base = d_host.data_ptr()
-    d_perm = ctypes.c_void_p(base + 48 * B) if n_perm else None
+    return key, address, B, N, n_perm > 0
+
+
+def _gather_pair_batches(args, st, dt, si, di):
+    """pad_segment (utils_helper.py:185-196) of the candidate clusters (rows si / di of the tables), one
+    kernel per cloud: -> two [B, width, 4] device tensors (width: _stage_rows)."""
+    dev = st.points.device
+    key, base, B, N, has_perm = _stage_rows(args, st, dt, si, di)
+    d_perm = ctypes.c_void_p(base + 48 * B) if has_perm else None
     segs = torch.empty((2, B, N, 4), dtype=torch.float32, device=dev)
     for which, table in enumerate((st, dt)):
         _lib.call("icpflow_gather_segments", _lib.ptr(table.points), _lib.ptr(table.order), ctypes.c_void_p(base + 24 * B * which),
                   d_perm, B, N, _lib.ptr(segs[which]), _lib.stream(dev))
+    _Staging.done(key)
     return segs[0], segs[1]
+
+
+def _registration(args, dev):
+    """icpflow_registration_t of `args` (+ the tensors it points to, to be kept alive by the caller)."""
+    ex, ey, ez = bin_edges(args, dev)
+    max_it, rel, stop = _icp_options(args)
+    reg = _lib.Registration(ex.data_ptr(), ey.data_ptr(), ez.data_ptr(), len(ex), len(ey), len(ez), float(args.thres_dist // 2),
+                            float(args.thres_dist), float(rel), int(max_it), int(stop))
+    return reg, (ex, ey, ez)
 
 
 def _launch_pairs(args, st, dt, pairs):
@@ -184,14 +230,33 @@ def _launch_pairs(args, st, dt, pairs):
     asynchronous.  -> what _finish_pairs needs (host work placed between the two overlaps the kernels)."""
     si, di = st.find_host(pairs[:, 0]), dt.find_host(pairs[:, 1])
     assert (si >= 0).all() and (di >= 0).all()
-    segs_src, segs_dst = _gather_pair_batches(args, st, dt, si, di)
+    r = _register_stage(args, st, dt, si, di)[0]
+    return si, di, r
+
+
+def _register_stage(args, st, dt, si, di, d_si=None, d_di=None):
+    """One association stage in ONE call into the library (icpflow_register_stage: both padded clouds, hist_icp, match_eval).
+    -> (flat result tensor [30 K + 1], the icpflow_stage_t, what it points to)."""
+    dev = st.points.device
+    key, base, K, N, has_perm = _stage_rows(args, st, dt, si, di)
+    reg, edges = _registration(args, dev)
+    lens = (reg.len_x, reg.len_y, reg.len_z)
+    _lib.check_vote_bins(K, lens)
+    tables = _lib.Tables(st.points.data_ptr(), st.order.data_ptr(), st._packed.data_ptr() + 8, dt.points.data_ptr(),
+                         dt.order.data_ptr(), dt._packed.data_ptr() + 8, len(st.h_labels), len(dt.h_labels), 9)
+    n_clouds = 2 * K * N * 4
+    scratch = torch.empty((n_clouds + 30 * K + 1,), dtype=torch.float32, device=dev)
+    stage = _lib.Stage(base, base + 48 * K if has_perm else None, d_si, d_di, scratch.data_ptr(), scratch.data_ptr() + 4 * n_clouds, K, N)
+    ws = _lib.workspace(dev, _lib.workspace_bytes(K, N, lens))
     # The stages of a frame pair keep their teams of workgroups on half of the GPU (ICPFLOW_OPT_TEAMS_HALF_GPU): a frame's
     # stage needs far fewer workgroups than the GPU has CUs, and two frame pairs in flight can then run their team launches
     # side by side instead of one after the other.  Always, in flight or not: the plan decides the order of a team's sums, and
     # a frame pair registers to the same bits whatever else is in flight (`args.teams_full_gpu = True`: the full-GPU plan).
     with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False)):
-        r, _ = _hist_icp_eval_flat(args, segs_src, segs_dst)
-    return si, di, r
+        _lib.call("icpflow_register_stage", ctypes.byref(tables), ctypes.byref(stage), ctypes.byref(reg), _lib.ptr(ws), ws.numel(),
+                  _lib.stream(dev), _lib.opt())
+    _Staging.done(key)
+    return scratch[n_clouds:], stage, (tables, reg, lens, scratch, edges)
 
 
 class Pending:
@@ -391,7 +456,8 @@ def _match_pcds_device(args, st, dt, pairs_true, asynchronous):
     alone -- and a one-workgroup kernel (icpflow_assoc_assign) does on the device what _finish_pairs does on the host, then
     switches every stage-2 candidate on or off (both clusters still without a partner, utils_match.py:45-53): the switched-off
     ones are handed over as empty clouds and flagged in options.d_pair_active, which keeps them out of the ICP's batch-global
-    stop -- stage 2's batch IS the reference's batch.  icpflow_assoc_collect writes the pair rows of both stages.
+    stop -- stage 2's batch IS the reference's batch.  icpflow_assoc_collect writes the pair rows of both stages (two calls into the library:
+    icpflow_register_stage for stage 1, icpflow_associate_frame for everything behind it).
     -> (pairs [P,10], transforms [P,4,4]) device tensors, or None when a candidate of stage 2 that had to be left out of the
     superset -- a cluster longer than max_points, whose random subsample must be drawn in the reference's order of draws --
     turned out to be needed: the caller then runs the host path."""
@@ -402,10 +468,10 @@ def _match_pcds_device(args, st, dt, pairs_true, asynchronous):
     gen_state = g.get_state() if g is not None else torch.get_rng_state()
     si1, di1 = st.find_host(pairs_true[:, 0]), dt.find_host(pairs_true[:, 1])
     K1 = len(si1)
-    # stage 1 first: the host work below (grid, superset) runs while the GPU is in it
-    segs_src, segs_dst = _gather_pair_batches(args, st, dt, si1, di1)
-    with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False)):
-        r1, _ = _hist_icp_eval_flat(args, segs_src, segs_dst)
+    # stage 1 first (ONE call: both padded clouds, hist_icp, match_eval): the host work below (grid, superset) runs while the
+    # GPU is in it
+    _, stage1, (tables, reg, lens, *keep_alive) = _register_stage(args, st, dt, si1, di1)
+    ws_bytes1 = _lib.workspace_bytes(K1, stage1.N, lens)
     # Left out of the superset: pairs with a cluster longer than max_points (its random subsample must be drawn in the
     # reference's order of draws, which depends on what stage 1 matches) -- and pairs with a cluster longer than
     # `args.device_association_width` (1024): the superset's batch is as wide as its longest cluster, and a wide batch of two
@@ -422,16 +488,11 @@ def _match_pcds_device(args, st, dt, pairs_true, asynchronous):
     N2 = min(cap_pts, max(64, (int(max(st.h_count[rs].max(), dt.h_count[rd].max())) + 63) // 64 * 64)) if K2 else 64
     if not getattr(args, "tight_padding", True):
         N2 = int(args.max_points)
-    # ONE upload: stage 2's segment rows [2,3,K2] int64, then the candidate rows of both stages as int32
-    # ... through a pinned staging buffer: a pageable host -> device copy waits for everything queued on its stream, i.e.
-    # the host would sit out stage 1 right here (frame pairs in flight stopped overlapping, 1.3 -> 1.9 ms per frame pair)
+    # stage 2's segment rows [2,3,K2] int64, then the candidate rows of both stages as int32: read in place by the kernels
+    # (_Staging; a pageable upload here waited for everything queued on its stream -- the host sat out stage 1 and frame pairs
+    # in flight stopped overlapping, 1.3 -> 1.9 ms per frame pair)
     nbytes = 48 * K2 + 8 * (K1 + K2)
-    key = (_lib.stream_handle(dev), "assoc", torch.uint8)
-    stage = Pending._pinned.get(key)
-    if stage is None or stage.numel() < nbytes:
-        stage = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
-        Pending._pinned[key] = stage
-    host = stage.numpy()[:nbytes]
+    key2, host, base = _Staging.get(dev, "superset", nbytes)
     seg2 = host[: 48 * K2].view(np.int64).reshape(2, 3, K2)
     idx = host[48 * K2:].view(np.int32)
     if K2:
@@ -439,41 +500,41 @@ def _match_pcds_device(args, st, dt, pairs_true, asynchronous):
         seg2[1, 0], seg2[1, 1], seg2[1, 2] = dt.h_start[rd], dt.h_count[rd], -1
     idx[0:K1], idx[K1:2 * K1] = si1, di1
     idx[2 * K1:2 * K1 + K2], idx[2 * K1 + K2:] = rs, rd
-    d_host = stage[:nbytes].to(dev, non_blocking=True)
-    base = d_host.data_ptr()
-    at = lambda off: ctypes.c_void_p(base + off)   # noqa: E731
-    p_si1, p_di1 = at(48 * K2), at(48 * K2 + 4 * K1)
-    p_si2, p_di2 = at(48 * K2 + 8 * K1), at(48 * K2 + 8 * K1 + 4 * K2)
-    small = torch.empty((2 * S + 2,), dtype=torch.int32, device=dev)      # best1 [S], best2 [S], count, -
-    best1, best2, count = small[:S], small[S:2 * S], small[2 * S:2 * S + 1]
-    active2 = torch.empty((max(K2, 1),), dtype=torch.uint8, device=dev)
-    f32 = lambda v: float(np.float32(v))   # noqa: E731
-    thr = (f32(args.translation_frame), f32(args.thres_iou), f32(args.thres_rot * 90.0), f32(args.thres_error))
-    _lib.call("icpflow_assoc_assign", _lib.ptr(r1), p_si1, p_di1, K1, None, S, D, *thr, _lib.ptr(best1), K2,
-              p_si2 if K2 else None, p_di2 if K2 else None, at(0) if K2 else None, _lib.ptr(active2) if K2 else None,
-              _lib.stream(dev))
-    r2 = None
-    if K2:
-        segs2 = torch.empty((2, K2, N2, 4), dtype=torch.float32, device=dev)
-        for which, table in enumerate((st, dt)):
-            _lib.call("icpflow_gather_segments", _lib.ptr(table.points), _lib.ptr(table.order), at(24 * K2 * which), None, K2, N2,
-                      _lib.ptr(segs2[which]), _lib.stream(dev))
-        with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False), pair_active=active2):
-            r2, _ = _hist_icp_eval_flat(args, segs2[0], segs2[1])
-        _lib.call("icpflow_assoc_assign", _lib.ptr(r2), p_si2, p_di2, K2, _lib.ptr(active2), S, D, *thr, _lib.ptr(best2), 0,
-                  None, None, None, None, _lib.stream(dev))
+    stage1.d_si, stage1.d_di = base + 48 * K2, base + 48 * K2 + 4 * K1
+    # everything behind stage 1's registration in ONE call: the assignment of stage 1 (which switches stage 2's candidates on
+    # or off), stage 2, its assignment, the pair rows of both -- and the flow of the frame pair when the caller asked for it
+    # (frame_pairs: `args.flow_request`; rows beyond the matches carry a label no point has and the identity, so the padded
+    # pair rows serve and nothing has to be read back first)
     cap = 2 * S
-    rows = torch.empty((cap, 10), dtype=torch.float32, device=dev)
-    T = torch.empty((cap, 4, 4), dtype=torch.float32, device=dev)
-    _lib.call("icpflow_assoc_collect", _lib.ptr(best1), _lib.ptr(r1), p_si1, p_di1, K1, _lib.ptr(best2) if K2 else None,
-              _lib.ptr(r2) if K2 else None, p_si2 if K2 else None, p_di2 if K2 else None, K2,
-              ctypes.c_void_p(st._packed.data_ptr() + 8), ctypes.c_void_p(dt._packed.data_ptr() + 8), 9, S, cap,
-              _lib.ptr(rows), _lib.ptr(T), _lib.ptr(count), _lib.stream(dev))
-    # What only needs the pair rows ON THE DEVICE goes in now, ahead of the read-back (frame_pairs: the flow of the frame
-    # pair): rows beyond the matches carry a label no point has and the identity, so the padded arrays serve.
-    hook = getattr(args, "on_association_enqueued", None)
-    if hook is not None:
-        hook(rows, T)
+    n_clouds2, n_res2 = 2 * K2 * N2 * 4, 30 * K2 + 1
+    n_small = 2 * S + 2
+    scratch2 = torch.empty((n_clouds2 + n_res2 + n_small + 26 * cap + (K2 + 3) // 4,), dtype=torch.float32, device=dev)
+    o = scratch2.data_ptr()
+    stage2 = _lib.Stage(base, None, base + 48 * K2 + 8 * K1, base + 48 * K2 + 8 * K1 + 4 * K2, o, o + 4 * n_clouds2, K2, N2)
+    o_small = n_clouds2 + n_res2
+    small = scratch2[o_small: o_small + n_small].view(torch.int32)
+    rows = scratch2[o_small + n_small: o_small + n_small + 10 * cap].view(cap, 10)
+    T = scratch2[o_small + n_small + 10 * cap: o_small + n_small + 26 * cap].view(cap, 4, 4)
+    p_active2 = o + 4 * (o_small + n_small + 26 * cap)
+    f32 = lambda v: float(np.float32(v))   # noqa: E731
+    req = getattr(args, "flow_request", None)
+    flow = f_pts = f_lab = f_pose = None
+    if req is not None:
+        f_pts, f_lab, f_pose = (req["points"][:, 0:3].contiguous().float(), req["labels"].contiguous().float(),
+                                req["pose"].to(dev).contiguous().float())
+        assert len(f_pts) == len(f_lab)
+        flow = torch.empty((len(f_pts), 3), dtype=torch.float32, device=dev)
+    if K2:
+        _lib.check_vote_bins(K2, lens)
+    ws = _lib.workspace(dev, max(ws_bytes1, _lib.workspace_bytes(K2, N2, lens) if K2 else 0))
+    with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False)):
+        _lib.call("icpflow_associate_frame", ctypes.byref(tables), ctypes.byref(stage1), ctypes.byref(stage2) if K2 else None,
+                  ctypes.c_void_p(p_active2) if K2 else None, ctypes.byref(reg), f32(args.translation_frame), f32(args.thres_iou),
+                  f32(args.thres_rot * 90.0), f32(args.thres_error), _lib.ptr(small), cap, _lib.ptr(rows), _lib.ptr(T),
+                  _lib.ptr(f_pts), _lib.ptr(f_lab), len(f_pts) if flow is not None else 0, _lib.ptr(f_pose), _lib.ptr(flow),
+                  _lib.ptr(ws), ws.numel(), _lib.stream(dev), _lib.opt())
+    _Staging.done(key2)
+    args.flow_result = flow
     pend = Pending(small, asynchronous, 1)
     yield pend
     h = pend.get()

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 205 /* 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 206 /* 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -386,6 +386,68 @@ int icpflow_assoc_collect(const int32_t *d_best1, const float *d_result1, const 
                           float *d_rows, float *d_T, int32_t *d_count, icpflow_stream_t stream);
 int icpflow_gather_segments(const float *d_points, const int64_t *d_order, const int64_t *d_seg,
                             const int32_t *d_perm, int B, int N, float *d_out, icpflow_stream_t stream);
+
+/* The same, one call per stage instead of one per kernel (version 206) -- match_pairs (utils_match.py:69-136) and match_pcds
+ * (utils_match.py:26-66) from the cluster tables on.  A frame pair in flight costs its host thread a fixed price per call
+ * into the library; these two take what used to be ten.
+ *
+ * icpflow_tables_t: both clouds of the frame pair as icpflow_cluster_table leaves them (points float32 rows of 3, the
+ * label-sorted order, the float64 table with `label_stride` doubles per cluster, label first; S and D clusters).
+ * icpflow_stage_t: K candidate pairs of an association stage.  d_seg int64 [2,3,K] are the segment rows of
+ * icpflow_gather_segments (start, length, offset of the subsample in d_perm or -1; source cloud first), d_si / d_di int32 [K]
+ * the table rows of each candidate, N the width of the padded batch; d_clouds float32 [2,K,N,4] is scratch for the padded
+ * batch, d_result float32 [30 K + 1] receives the results of icpflow_hist_icp_eval, array after array
+ * [T 16K | errors 2K | inliers 2K | ratios 2K | ious 2K | translations 3K | rotations 3K | iteration count (int32)].
+ * icpflow_registration_t: the arguments of icpflow_hist_icp_eval that do not depend on the batch.
+ *
+ * icpflow_register_stage: pad_segment of both clouds (utils_match.py:81-91) + hist_icp + match_eval of one stage.
+ * icpflow_associate_frame: everything of match_pcds behind stage 1's registration (`stage1`, registered by
+ *   icpflow_register_stage on the same stream): icpflow_assoc_assign of stage 1 (which switches stage 2's candidates on or
+ *   off: d_active2 uint8 [stage2->K], scratch), icpflow_register_stage of stage 2 with options.d_pair_active = d_active2,
+ *   icpflow_assoc_assign of stage 2, icpflow_assoc_collect (d_best int32 [2 S + 2]: stage 1's choice per source row, stage
+ *   2's, the number of matches; d_rows [cap,10], d_T [cap,16]) and, with d_flow != NULL, icpflow_flow_rigid_rows of n_flow
+ *   points on the padded pair rows.  stage2 may be NULL or have K = 0.  d_ws / ws_bytes: icpflow_workspace_bytes of the
+ *   larger stage. */
+typedef struct icpflow_tables {
+    const float *d_points_src;
+    const int64_t *d_order_src;
+    const double *d_table_src;
+    const float *d_points_dst;
+    const int64_t *d_order_dst;
+    const double *d_table_dst;
+    int S, D, label_stride;
+} icpflow_tables_t;
+
+typedef struct icpflow_stage {
+    const int64_t *d_seg;
+    const int32_t *d_perm;
+    const int32_t *d_si;
+    const int32_t *d_di;
+    float *d_clouds;
+    float *d_result;
+    int K, N;
+} icpflow_stage_t;
+
+typedef struct icpflow_registration {
+    const float *d_edges_x;
+    const float *d_edges_y;
+    const float *d_edges_z;
+    int len_x, len_y, len_z;
+    float decode_shift;
+    double thres_dist;
+    double relative_rmse_thr;
+    int max_iterations;
+    int stop_mode;
+} icpflow_registration_t;
+
+int icpflow_register_stage(const icpflow_tables_t *tables, const icpflow_stage_t *stage, const icpflow_registration_t *reg,
+                           void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt);
+int icpflow_associate_frame(const icpflow_tables_t *tables, const icpflow_stage_t *stage1, const icpflow_stage_t *stage2,
+                            uint8_t *d_active2, const icpflow_registration_t *reg, float translation_frame, float thres_iou,
+                            float rot_limit_deg, float thres_error, int32_t *d_best, int cap, float *d_rows, float *d_T,
+                            const float *d_flow_points, const float *d_flow_labels, int n_flow, const float *d_pose,
+                            float *d_flow, void *d_ws, size_t ws_bytes, icpflow_stream_t stream,
+                            const icpflow_options_t *opt);
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
                           const int64_t *d_count, const float *d_labels, int L, float *d_mean,
                           float *d_extent, icpflow_stream_t stream);

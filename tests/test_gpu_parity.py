@@ -985,7 +985,7 @@ def test_synthetic_frame_pair_vs_oracle():
 @pytest.mark.parametrize("mp", [2048, 10000])
 def test_batches_padded_to_their_longest_cluster_register_like_max_points_wide_ones(mp):
     """match_pcds pads the candidate batches of a stage to the longest cluster of the stage (utils_match.
-    _gather_pair_batches), the reference to max_points (pad_segment, utils_helper.py:185-196).  Padding rows carry flag 0:
+    _stage_rows), the reference to max_points (pad_segment, utils_helper.py:185-196).  Padding rows carry flag 0:
     the demo frame pair registered both ways (args.tight_padding False = the reference's width) -- the same matched pairs,
     the same stage-2 draws, transforms and per-point flow within 1e-5 m of each other (the fp64 sums of a pair follow the
     shape of the workgroups that serve it; stage 2 at max_points 10000 is 576 rows wide instead of 10000)."""
@@ -994,25 +994,27 @@ def test_batches_padded_to_their_longest_cluster_register_like_max_points_wide_o
     ps, pd = G(g0["point_src"]), G(g0["point_dst"])
     ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
     widths = {}
-    orig = utils_match._hist_icp_eval_flat
+    orig = utils_match._register_stage
 
-    def spy(args, s, d):
-        widths.setdefault(bool(getattr(args, "tight_padding", True)), []).append(int(s.shape[1]))
-        return orig(args, s, d)
+    def spy(args, *rest):
+        out = orig(args, *rest)
+        widths.setdefault(bool(getattr(args, "tight_padding", True)), []).append(int(out[1].N))
+        return out
 
     runs = {}
-    utils_match._hist_icp_eval_flat = spy
+    utils_match._register_stage = spy
     try:
         for tight in (True, False):
             a = rp.default_args(max_points=mp, min_cluster_size=20, translation_frame=2.0, thres_box=0.1, thres_rot=0.1,
                                 thres_error=0.2, thres_iou=0.2)
             a.tight_padding = tight
+            a.device_association = False        # (both stages through _register_stage; the device path has its own test)
             torch.manual_seed(0)
             pairs, Tm = utils_track.track(a, ps, pd, ls, ld)
             flow = utils_flow.flow_estimation_torch(a, ps, pd, ls, ld, pairs, Tm, torch.eye(4, device=DEV))
             runs[tight] = (pairs.cpu().numpy(), Tm.cpu().numpy(), flow.cpu().numpy())
     finally:
-        utils_match._hist_icp_eval_flat = orig
+        utils_match._register_stage = orig
     assert widths[False] == [mp, mp] and widths[True][0] == mp and widths[True][1] < mp and widths[True][1] % 64 == 0, widths
     (p1, T1, f1), (p0, T0, f0) = runs[True], runs[False]
     assert np.array_equal(p1[:, 0:2], p0[:, 0:2]) and len(p1) == 83

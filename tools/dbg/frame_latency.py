@@ -10,7 +10,7 @@ g = load_golden("g8_demo"); lab = load_golden("g8_demo_labels")
 dev = torch.device("cuda:0")
 G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 ps, pd = G(g["point_src"]), G(g["point_dst"]); ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
-a = frame_pairs.default_args(max_points=int(os.environ.get("MP", "10000")))
+a = frame_pairs.default_args(max_points=int(os.environ.get("MP", "10000"))); a.device_association = os.environ.get("DEVICE_ASSOC", "0") == "1"   # (the phases below are those of the host path)
 eye = torch.eye(4, device=dev)
 def run():
     torch.manual_seed(0)
@@ -31,7 +31,7 @@ def timed(name, fn):
     return w
 utils_check.ClusterTable.pair = staticmethod(timed("ClusterTable.pair", utils_check.ClusterTable.pair))
 utils_match.ClusterTable.pair = utils_check.ClusterTable.pair
-for mod, name in ((utils_match, "_sanity_mask"), (utils_match, "_gather_pair_batches"), (utils_match, "hist_icp_eval"),
+for mod, name in ((utils_match, "_sanity_mask"), (utils_match, "_register_stage"),
                   (utils_match, "sanity_grid"), (utils_match, "_finish_pairs"), (utils_match, "setdiff1d")):
     setattr(mod, name, timed(name, getattr(mod, name)))
 utils_match.Pending.get = timed("Pending.get", utils_match.Pending.get)

@@ -11,15 +11,17 @@ G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 ps, pd = G(g["point_src"]), G(g["point_dst"]); ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
 a = frame_pairs.default_args(max_points=int(os.environ.get("MP", "10000")))
 kept = []
-orig = utils_match._gather_pair_batches
-def stash(args, st, dt, si, di):
-    r = orig(args, st, dt, si, di)
-    kept.append((r[0].clone(), r[1].clone(), st.h_count[si].copy(), dt.h_count[di].copy()))
-    return r
-utils_match._gather_pair_batches = stash
+orig = utils_match._register_stage
+def stash(args, st, dt, si, di, *rest):
+    out = orig(args, st, dt, si, di, *rest)
+    stage, scratch = out[1], out[2][3]
+    clouds = scratch[: 2 * stage.K * stage.N * 4].view(2, stage.K, stage.N, 4)
+    kept.append((clouds[0].clone(), clouds[1].clone(), st.h_count[si].copy(), dt.h_count[di].copy()))
+    return out
+utils_match._register_stage = stash
 torch.manual_seed(0)
 utils_track.track(a, ps, pd, ls, ld)
-utils_match._gather_pair_batches = orig
+utils_match._register_stage = orig
 S, D, cs, cd = kept[0]
 B = len(cs)
 big = np.minimum(cs, cd)
