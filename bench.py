@@ -570,7 +570,15 @@ def frame_pair_measurement(dev):
             pairs, flow = run()
             torch.cuda.synchronize(dev)
             runs.append(round((time.perf_counter() - t) * 1e3, 3))
+        # (one at a time the association runs on the device, in flight on the host -- utils_match._device_association_ok; the
+        # host path's result for this frame pair: what the frame pairs in flight below must reproduce bit for bit)
+        a.device_association = False
+        pairs_host, flow_host = run()
+        a.device_association = None
         entry = {"ms_per_frame_pair": sorted(runs)[len(runs) // 2], "ms_per_frame_pair_runs": runs, "matched_cluster_pairs": int(len(pairs)),
+                 "association": "on the device one at a time (one read-back per frame pair), on the host in flight",
+                 "device_vs_host_association_same_pairs": bool(torch.equal(pairs[:, :2], pairs_host[:, :2])),
+                 "device_vs_host_association_max_flow_difference_m": float((flow - flow_host).abs().max()),
                  "epe_vs_ground_truth_m": round(float(np.linalg.norm(flow.cpu().numpy() - g["gt_flow"], axis=1).mean()), 5)}
         # against the reference's own run at the same max_points: the G8 fixtures made with torch.topk's CUDA tie order
         # (tools/gen_golden.py topk_cuda_order -- the order of ATen's radix select, which is also the product's rule;
@@ -591,16 +599,14 @@ def frame_pair_measurement(dev):
                 pass
         # the same frame pair as a STREAM (BASELINE configs 3 / 5 are streams of independent frame pairs, main.py:184-215):
         # 12 copies with 4 in flight, 24 with 8 (frame_pairs.register_in_flight: one stream each, asynchronous hand-overs, one
-        # host thread); wall time of the stream over its frame pairs -- throughput, not the latency above.  (Round 4: with the
-        # association on the device a frame pair has two long host bursts instead of four short ones; four in flight no longer
-        # keep the GPU fed through a burst -- 1.26 -> 1.5 ms -- eight do)
+        # host thread); wall time of the stream over its frame pairs -- throughput, not the latency above
         fp_obj = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
         for in_flight in (4, 8):
             copies = [fp_obj] * (3 * in_flight)
             # (the untimed pass keeps every result for the comparison; the timed one consumes them as a sweep would --
             # holding twelve frames' outputs makes the caching allocator grow on every stream inside the timed region)
             flows = {i: o["flow"] for i, _, o in frame_pairs.register_in_flight(a, copies, dev, in_flight)}
-            entry[f"stream_{in_flight}_in_flight_identical_flow"] = bool(all(torch.equal(f, flow) for f in flows.values()))
+            entry[f"stream_{in_flight}_in_flight_identical_flow"] = bool(all(torch.equal(f, flow_host) for f in flows.values()))
             del flows
             # three timed passes of the 12-frame stream, the median reported and every pass listed: a single pass has been seen
             # to catch a stall of the caching allocator (4.6 ms per frame pair once, after the other extras, against 1.4-1.8)

@@ -389,7 +389,7 @@ def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, async
     pairs = np.stack([labels_unq, labels_unq], axis=1)
     pairs = pairs[np.minimum(pairs[:, 0], pairs[:, 1]) >= 0].astype(np.float32)                  # :30-31
     pairs_true = pairs[_sanity_mask(args, st, dt, pairs)] if len(pairs) else pairs
-    if len(pairs_true) > 0 and _device_association_ok(args, st, dt):
+    if len(pairs_true) > 0 and _device_association_ok(args, st, dt, asynchronous):
         # both stages, the step between them, the pair rows: enqueued without reading a stage's results back (below)
         out = yield from _match_pcds_device(args, st, dt, pairs_true, asynchronous)
         args.association_path = "device" if out is not None else "host"
@@ -434,15 +434,22 @@ def match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels, async
     return d_both[: 10 * P].view(P, 10), d_both[10 * P:].view(P, 4, 4)
 
 
-def _device_association_ok(args, st, dt):
+def _device_association_ok(args, st, dt, asynchronous=False):
     """The device-side association (icpflow_assoc_assign / _collect, options.d_pair_active) needs the ICP's single speculative
     launch (reference stop rule, <= 128 iterations) and cluster tables that fit the kernels' LDS tables.
-    `args.device_association` (default True; False = the host path: every stage read back, numpy in between).  A frame pair
-    on its own gains the read-back between the stages, time the GPU idled (2.45 -> 2.25 ms at 2048 points, 2.6 -> 2.4 at
-    10000); with frame pairs in flight that read-back was hidden behind the other frame pairs already and the superset's
-    extra work is not, which comes out even (1.41-1.51 vs 1.42-1.59 ms with four in flight, 1.37-1.44 vs 1.36-1.46 with
-    eight).  One path in both modes: a frame pair registers to the same bits in flight or on its own."""
-    if not getattr(args, "device_association", True):
+    `args.device_association`: True / False (the host path: every stage read back, numpy in between), default None = on for a
+    frame pair registered on its own (`asynchronous` False), off for frame pairs in flight.  On its own a frame pair gains the
+    read-back between the stages, time the GPU idled (2.15-2.24 -> 2.01-2.03 ms at 2048 points, 2.33 -> 2.21-2.26 at 10000);
+    a stream of frame pairs in flight is bound by its ONE host thread (tools/dbg/stream_host_busy.py: wall = host busy + 0.08
+    ms), the read-backs were hidden behind the other frame pairs already, and the device path costs that thread more (the
+    superset; calls that block longer the more is queued on the GPU: 1.25-1.64 ms busy per frame pair against 1.10-1.31).
+    The two paths agree on the matched pairs and to rounding on the numbers (stage 2's batch has another shape:
+    tests/test_gpu_parity.py::test_device_association_equals_the_host_path, 1e-5 m on the flow); with the option set either
+    way a frame pair registers to the same bits in flight and on its own."""
+    want = getattr(args, "device_association", None)
+    if want is None:
+        want = not asynchronous
+    if not want:
         return False
     max_it, _, stop = _icp_options(args)
     cur = _lib._current()[-1]

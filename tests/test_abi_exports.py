@@ -49,6 +49,22 @@ def test_argument_errors_are_status_codes_with_messages():
     assert rc == -2 and b"workspace" in L.icpflow_last_error()
     rc = L.icpflow_nn_batch(one, one, 1, 4, 4, 2, 4, None, None, 1, one, one, None)
     assert rc == -1 and b"stride" in L.icpflow_last_error()
+    # the stage entry points (version 206): structs checked before anything is launched
+    tables, stage, reg = _lib.Tables(), _lib.Stage(), _lib.Registration()
+    rc = L.icpflow_register_stage(None, ctypes.byref(stage), ctypes.byref(reg), one, 1 << 30, None, None)
+    assert rc == -1 and b"null argument" in L.icpflow_last_error()
+    rc = L.icpflow_register_stage(ctypes.byref(tables), ctypes.byref(stage), ctypes.byref(reg), one, 1 << 30, None, None)
+    assert rc == -1 and b"null pointer" in L.icpflow_last_error()
+    rc = L.icpflow_associate_frame(ctypes.byref(tables), ctypes.byref(stage), None, None, ctypes.byref(reg), 2.0, 0.2, 9.0, 0.2,
+                                   one, 4, one, one, None, None, 0, None, None, one, 1 << 30, None, None)
+    assert rc == -1 and b"null pointer" in L.icpflow_last_error()
+    tables.d_table_src = tables.d_table_dst = 16
+    stage.d_result = stage.d_si = stage.d_di = 16
+    stage2 = _lib.Stage()
+    stage2.K = 3
+    rc = L.icpflow_associate_frame(ctypes.byref(tables), ctypes.byref(stage), ctypes.byref(stage2), None, ctypes.byref(reg), 2.0, 0.2,
+                                   9.0, 0.2, one, 4, one, one, None, None, 0, None, None, one, 1 << 30, None, None)
+    assert rc == -1 and b"stage 2 comes with" in L.icpflow_last_error()
 
 
 def test_options_are_per_call_and_per_thread():

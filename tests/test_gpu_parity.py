@@ -1178,8 +1178,8 @@ def test_full_size_init_pose_pick_is_the_argmin_of_all_six_scores(config2):
 def test_frame_pairs_in_flight_equal_one_after_the_other(tmp_path):
     """frame_pairs.register_in_flight: several frame pairs at once (one HIP stream each, asynchronous device -> host
     hand-overs into pinned memory, one host thread resuming whichever has landed; team launches chained by an event).
-    Frame pairs are independent (main.py:184-215): every one comes out exactly as from register_frame_pair -- pairs,
-    transforms and per-point flow bit for bit -- whatever runs next to it; labelled synthetic pairs of different sizes,
+    Frame pairs are independent (main.py:184-215): every one comes out exactly as from register_frame_pair with the same
+    association path -- pairs, transforms and per-point flow bit for bit -- whatever runs next to it; labelled synthetic pairs of different sizes,
     the demo frame pair (teams of workgroups on its large clusters, twice, so that two team launches are in flight), and a
     multi-gap sequence whose pairs are clustered on the GPU.  Then the stream harness with in_flight = 3."""
     from icp_flow_amd import frame_pairs
@@ -1191,17 +1191,31 @@ def test_frame_pairs_in_flight_equal_one_after_the_other(tmp_path):
     demo = frame_pairs.FramePair(g0["point_src"], g0["point_dst"], lab["label_src"], lab["label_dst"], None, g0["gt_flow"])
     fps = fps[:2] + [demo] + fps[2:] + [demo]
     a = frame_pairs.default_args(max_points=4096)
-    want = [frame_pairs.register_frame_pair(a, fp, DEV) for fp in fps]
-    for in_flight in (2, 4):
-        got = {}
-        for idx, fp, out in frame_pairs.register_in_flight(a, fps, DEV, in_flight=in_flight):
-            assert fp is fps[idx]
-            got[idx] = out
-        torch.cuda.synchronize()
-        assert sorted(got) == list(range(len(fps)))
-        for k, w in enumerate(want):
-            for key in ("pairs", "transformations", "flow"):
-                assert torch.equal(got[k][key], w[key]), (in_flight, k, key)
+    # By default the association of a frame pair on its own runs on the device, that of frame pairs in flight on the host
+    # (utils_match._device_association_ok: same pairs, numbers to rounding); with the option set either way a frame pair comes
+    # out bit for bit the same in flight and on its own -- and the default in flight IS the host path.
+    wants = {}
+    for assoc in (False, True):
+        a.device_association = assoc
+        wants[assoc] = want = [frame_pairs.register_frame_pair(a, fp, DEV) for fp in fps]
+        for in_flight in ((2, 4) if not assoc else (3,)):
+            got = {}
+            for idx, fp, out in frame_pairs.register_in_flight(a, fps, DEV, in_flight=in_flight):
+                assert fp is fps[idx]
+                got[idx] = out
+            torch.cuda.synchronize()
+            assert sorted(got) == list(range(len(fps)))
+            for k, w in enumerate(want):
+                for key in ("pairs", "transformations", "flow"):
+                    assert torch.equal(got[k][key], w[key]), (assoc, in_flight, k, key)
+    a.device_association = None
+    got = {idx: out for idx, _, out in frame_pairs.register_in_flight(a, fps, DEV, in_flight=4)}
+    own = [frame_pairs.register_frame_pair(a, fp, DEV) for fp in fps]
+    for k in range(len(fps)):
+        for key in ("pairs", "transformations", "flow"):
+            assert torch.equal(got[k][key], wants[False][k][key]) and torch.equal(own[k][key], wants[True][k][key]), (k, key)
+        assert torch.equal(wants[True][k]["pairs"][:, :2], wants[False][k]["pairs"][:, :2])
+        assert (wants[True][k]["flow"] - wants[False][k]["flow"]).abs().max() < 1e-5
     # the harness: same accuracy summary as one at a time, on files (a sequence file among them: GPU clustering per gap)
     paths = []
     for k, fp in enumerate(fps[:4]):
@@ -1217,7 +1231,7 @@ def test_frame_pairs_in_flight_equal_one_after_the_other(tmp_path):
         one = frame_pairs.run_stream(a2, paths, DEV)
         many = frame_pairs.run_stream(a2, paths, DEV, in_flight=3)
     assert many["frame_pairs"] == one["frame_pairs"] == 6 and many["matched_cluster_pairs"] == one["matched_cluster_pairs"]
-    assert many["evaluated_points"] == one["evaluated_points"] and abs(many["epe"] - one["epe"]) < 1e-9
+    assert many["evaluated_points"] == one["evaluated_points"] and abs(many["epe"] - one["epe"]) < 1e-6   # (device / host association)
 
 
 def test_cluster_table_chain_equals_the_torch_ops():
