@@ -570,13 +570,29 @@ def frame_pair_measurement(dev):
             pairs, flow = run()
             torch.cuda.synchronize(dev)
             runs.append(round((time.perf_counter() - t) * 1e3, 3))
-        # (one at a time the association runs on the device, in flight on the host -- utils_match._device_association_ok; the
-        # host path's result for this frame pair: what the frame pairs in flight below must reproduce bit for bit)
+        # the same through ONE call into the library (icpflow_track_frame: the host half of match_pcds in C++ as well; the
+        # default of frame_pairs.register_frame_pair / register_in_flight): same bits
+        def run_native():
+            out = frame_pairs.track_frame_native(a, ps, pd, ls, ld, ego, ps, seed=0)
+            return out["pairs"], out["flow"]
+
+        run_native()
+        runs_native = []
+        for _ in range(7):
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            pairs_native, flow_native = run_native()
+            torch.cuda.synchronize(dev)
+            runs_native.append(round((time.perf_counter() - t) * 1e3, 3))
+        # (the host-side association of the Python host, for the record: same pairs, numbers to rounding)
         a.device_association = False
         pairs_host, flow_host = run()
         a.device_association = None
-        entry = {"ms_per_frame_pair": sorted(runs)[len(runs) // 2], "ms_per_frame_pair_runs": runs, "matched_cluster_pairs": int(len(pairs)),
-                 "association": "on the device one at a time (one read-back per frame pair), on the host in flight",
+        entry = {"ms_per_frame_pair": sorted(runs_native)[len(runs_native) // 2], "ms_per_frame_pair_runs": runs_native,
+                 "ms_per_frame_pair_python_host_runs": runs, "matched_cluster_pairs": int(len(pairs)),
+                 "ms_per_frame_pair_python_host": sorted(runs)[len(runs) // 2],
+                 "association": "on the device (one read-back per frame pair); ms_per_frame_pair: one call into the library per frame pair (icpflow_track_frame), ms_per_frame_pair_python_host: utils_track.track + flow_estimation_torch",
+                 "native_call_identical_to_python_host": bool(torch.equal(pairs_native, pairs) and torch.equal(flow_native, flow)),
                  "device_vs_host_association_same_pairs": bool(torch.equal(pairs[:, :2], pairs_host[:, :2])),
                  "device_vs_host_association_max_flow_difference_m": float((flow - flow_host).abs().max()),
                  "epe_vs_ground_truth_m": round(float(np.linalg.norm(flow.cpu().numpy() - g["gt_flow"], axis=1).mean()), 5)}
@@ -598,28 +614,33 @@ def frame_pair_measurement(dev):
             except OSError:
                 pass
         # the same frame pair as a STREAM (BASELINE configs 3 / 5 are streams of independent frame pairs, main.py:184-215):
-        # 12 copies with 4 in flight, 24 with 8 (frame_pairs.register_in_flight: one stream each, asynchronous hand-overs, one
-        # host thread); wall time of the stream over its frame pairs -- throughput, not the latency above
+        # 12 copies with 4 in flight, 24 with 8 (frame_pairs.register_in_flight: one stream and one host thread per frame pair
+        # in flight, each frame pair one blocking icpflow_track_frame call; "_python_scheduler": one host thread, generators,
+        # asynchronous hand-overs, host-side association); wall time of the stream over its frame pairs, uploads of the
+        # clouds included -- throughput, not the latency above
         fp_obj = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
         for in_flight in (4, 8):
             copies = [fp_obj] * (3 * in_flight)
-            # (the untimed pass keeps every result for the comparison; the timed one consumes them as a sweep would --
-            # holding twelve frames' outputs makes the caching allocator grow on every stream inside the timed region)
-            flows = {i: o["flow"] for i, _, o in frame_pairs.register_in_flight(a, copies, dev, in_flight)}
-            entry[f"stream_{in_flight}_in_flight_identical_flow"] = bool(all(torch.equal(f, flow_host) for f in flows.values()))
-            del flows
-            # three timed passes of the 12-frame stream, the median reported and every pass listed: a single pass has been seen
-            # to catch a stall of the caching allocator (4.6 ms per frame pair once, after the other extras, against 1.4-1.8)
-            passes = []
-            for _ in range(3):
-                torch.cuda.synchronize(dev)
-                t = time.perf_counter()
-                for _ in frame_pairs.register_in_flight(a, copies, dev, in_flight):
-                    pass
-                torch.cuda.synchronize(dev)
-                passes.append(round((time.perf_counter() - t) / len(copies) * 1e3, 3))
-            entry[f"stream_ms_per_frame_pair_{in_flight}_in_flight"] = sorted(passes)[1]
-            entry[f"stream_ms_per_frame_pair_{in_flight}_in_flight_passes"] = passes
+            for native, suffix, want_flow in ((True, "", flow), (False, "_python_scheduler", flow_host)):
+                a.native_host = native
+                # (the untimed pass keeps every result for the comparison; the timed one consumes them as a sweep would --
+                # holding twelve frames' outputs makes the caching allocator grow on every stream inside the timed region)
+                flows = {i: o["flow"] for i, _, o in frame_pairs.register_in_flight(a, copies, dev, in_flight)}
+                entry[f"stream_{in_flight}_in_flight_identical_flow{suffix}"] = bool(all(torch.equal(f, want_flow) for f in flows.values()))
+                del flows
+                # three timed passes of the stream, the median reported and every pass listed: a single pass has been seen
+                # to catch a stall of the caching allocator (4.6 ms per frame pair once, after the other extras, against 1.4-1.8)
+                passes = []
+                for _ in range(3):
+                    torch.cuda.synchronize(dev)
+                    t = time.perf_counter()
+                    for _ in frame_pairs.register_in_flight(a, copies, dev, in_flight):
+                        pass
+                    torch.cuda.synchronize(dev)
+                    passes.append(round((time.perf_counter() - t) / len(copies) * 1e3, 3))
+                entry[f"stream_ms_per_frame_pair_{in_flight}_in_flight{suffix}"] = sorted(passes)[1]
+                entry[f"stream_ms_per_frame_pair_{in_flight}_in_flight_passes{suffix}"] = passes
+            a.native_host = True
         res[f"max_points_{mp}"] = entry
     res["cluster_dbscan"] = cluster_measurement(dev, g, gdir)
     res["cluster_hdbscan"] = hdbscan_measurement(dev, g, gdir)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "icpflow_assoc_collect": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "icpflow_register_stage": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
     "icpflow_associate_frame": (_i, [_p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_track_frame": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _p]),
     "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "icpflow_cluster_table_workspace_bytes": (_sz, [_i, _i]),
     "icpflow_cluster_table": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _sz, _p]),
@@ -123,6 +124,13 @@ class Registration(ctypes.Structure):
     """icpflow_registration_t: the arguments of icpflow_hist_icp_eval that do not depend on the batch."""
     _fields_ = [("d_edges_x", _p), ("d_edges_y", _p), ("d_edges_z", _p), ("len_x", _i), ("len_y", _i), ("len_z", _i),
                 ("decode_shift", _f), ("thres_dist", _d), ("relative_rmse_thr", _d), ("max_iterations", _i), ("stop_mode", _i)]
+
+
+class FrameParams(ctypes.Structure):
+    """icpflow_frame_params_t: the flags of the reference's parser that icpflow_track_frame reads."""
+    _fields_ = [("struct_size", _sz), ("seed", ctypes.c_uint64), ("max_points", _i), ("min_cluster_size", _i),
+                ("translation_frame", _f), ("thres_box", _f), ("thres_iou", _f), ("rot_limit_deg", _f), ("thres_error", _f),
+                ("tight_padding", _i), ("superset_width", _i)]
 
 
 class Profile:

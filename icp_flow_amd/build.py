@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(HERE, "libicpflow_hip.so")
-SOURCES = ["api.hip", "hist.hip", "nn.hip", "icp.hip", "icp_fp32.hip", "pose.hip", "sort.hip", "cluster.hip", "hdbscan.hip", "table.hip", "assoc.hip",
+SOURCES = ["api.hip", "hist.hip", "nn.hip", "icp.hip", "icp_fp32.hip", "pose.hip", "sort.hip", "cluster.hip", "hdbscan.hip", "table.hip", "assoc.hip", "frame.hip",
            "hdbscan_tree.cpp"]
 HEADERS = ["common.hpp", "scan.hpp", "kernels.hpp", "kabsch.hpp", "posefuse.hpp", "votekey.hpp", "cluster_util.hpp",
            os.path.join("..", "..", "include", "icpflow_hip.h")]

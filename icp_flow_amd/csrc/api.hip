@@ -29,6 +29,19 @@ int hipfail(hipError_t e, const char *what)
     return (int)e;
 }
 
+}  // namespace
+
+namespace icpflow {
+// icpflow_last_error for the entry points that live in other files (frame.hip)
+int report_error(int code, const char *message)
+{
+    snprintf(g_err, sizeof(g_err), "%s", message);
+    return code;
+}
+}  // namespace icpflow
+
+namespace {
+
 #define ICPFLOW_TRY(expr)                                  \
     do {                                                   \
         hipError_t e__ = (expr);                           \

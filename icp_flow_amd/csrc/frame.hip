@@ -1,0 +1,346 @@
+// frame.hip -- one frame pair per call: the host half of match_pcds (utils_match.py:24-66) around the registration path, in
+// C++ (HOST code; the only device work here is what the entry points it calls enqueue).
+//
+// A stream of frame pairs is bound by the host thread that feeds the GPU (wall time per frame pair = host
+// busy time + 0.08 ms), and two thirds of that time is the Python between the calls: cluster-table bookkeeping, candidate
+// lists, sanity tests, segment rows, the superset of stage 2.  icpflow_track_frame does all of it on a few hundred numbers of
+// the cluster tables in microseconds, in ONE blocking call -- the interpreter lock is released for its whole duration, so
+// several host threads (one frame pair each, on their own streams) keep as many frame pairs in flight.
+//
+// What it follows, line by line, is icp_flow_amd/utils_match.py (match_pcds_steps + _match_pcds_device: the association on
+// the device) and utils_check.py (_sanity_mask, sanity_grid), themselves the drop-ins of the reference's
+// utils_match.py:24-66 / utils_check.py:21-49: same candidate order, same float32 comparisons (numpy's NaN rules), same
+// stream of random draws -- torch.randperm on a torch.Generator seeded with `seed` is a Fisher-Yates shuffle on MT19937
+// (ATen randperm_cpu: z = engine() % (n - i), swap(i, i + z)), restated here and pinned against torch in
+// tests/test_gpu_parity.py (test_native_frame_pair_equals_the_python_host, case "draws").  The result is bit for bit what utils_match.match_pcds returns with the device-side association.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/icpflow_hip.h"
+
+namespace icpflow {
+int report_error(int code, const char *message);   // api.hip: what icpflow_last_error returns
+}
+using icpflow::report_error;
+
+namespace {
+
+constexpr int kTableRows = 512;                    // utils_check.TABLE_ROWS
+constexpr int kTableDoubles = 1 + kTableRows * 9;  // [0]: int32 number of clusters, then [L, 9] rows
+
+struct Mt19937 {   // at::mt19937 (the engine of torch's CPU generator)
+    uint32_t s[624];
+    int idx;
+    explicit Mt19937(uint32_t seed)
+    {
+        s[0] = seed;
+        for (int j = 1; j < 624; ++j) s[j] = 1812433253u * (s[j - 1] ^ (s[j - 1] >> 30)) + (uint32_t)j;
+        idx = 624;
+    }
+    uint32_t next()
+    {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                const uint32_t y = (s[k] & 0x80000000u) | (s[(k + 1) % 624] & 0x7fffffffu);
+                s[k] = s[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = s[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+
+// torch.randperm(n, generator)[0:take] as int32 (n < 2^32 / 20: the 32-bit branch of randperm_cpu)
+void randperm_head(Mt19937 &g, int64_t n, int take, int32_t *out, std::vector<int32_t> &tmp)
+{
+    tmp.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = (int32_t)i;
+    for (int64_t i = 0; i < n - 1; ++i) {
+        const int64_t z = (int64_t)(g.next() % (uint64_t)(n - i));
+        std::swap(tmp[(size_t)i], tmp[(size_t)(i + z)]);
+    }
+    std::memcpy(out, tmp.data(), sizeof(int32_t) * (size_t)take);
+}
+
+// numpy's minimum / maximum: a NaN on either side gives NaN
+inline float np_min(float a, float b) { return (std::isnan(a) || std::isnan(b)) ? NAN : (a < b ? a : b); }
+inline float np_max(float a, float b) { return (std::isnan(a) || std::isnan(b)) ? NAN : (a > b ? a : b); }
+
+struct Table {   // host copy of one cluster table (utils_check.ClusterTable._set_host)
+    int L = 0;
+    std::vector<float> label, mean, extent;   // [L], [L,3], [L,3]
+    std::vector<int64_t> count, start;
+    void set(const double *packed)
+    {
+        int32_t n;
+        std::memcpy(&n, packed, 4);
+        L = n;
+        if (L < 0) return;
+        label.resize(L); count.resize(L); start.resize(L); mean.resize(3 * (size_t)L); extent.resize(3 * (size_t)L);
+        const double *rows = packed + 1;
+        for (int r = 0; r < L; ++r) {
+            label[r] = (float)rows[r * 9 + 0];
+            count[r] = (int64_t)rows[r * 9 + 1];
+            start[r] = (int64_t)rows[r * 9 + 2];
+            for (int k = 0; k < 3; ++k) {
+                mean[3 * r + k] = (float)rows[r * 9 + 3 + k];
+                extent[3 * r + k] = (float)rows[r * 9 + 6 + k];
+            }
+        }
+    }
+    int find(float wanted) const   // ClusterTable.find_host: rows are in ascending label order
+    {
+        if (L <= 0) return -1;
+        const int pos = std::min((int)(std::lower_bound(label.begin(), label.end(), wanted) - label.begin()), L - 1);
+        return label[pos] == wanted ? pos : -1;
+    }
+};
+
+// the pairwise part of sanity_check (utils_check.py:36, 41-43) on table rows s, d
+inline bool pair_passes(const Table &st, const Table &dt, int s, int d, float translationFrame, float thresBox)
+{
+    const float dx = dt.mean[3 * d] - st.mean[3 * s], dy = dt.mean[3 * d + 1] - st.mean[3 * s + 1];
+    const float xx = dx * dx, yy = dy * dy;
+    const float sum = xx + yy;
+    if (std::sqrt(sum) > translationFrame) return false;
+    for (int k = 0; k < 3; ++k) {
+        const float es = st.extent[3 * s + k], ed = dt.extent[3 * d + k];
+        const float rhs = thresBox * np_max(es, ed);
+        if (np_min(es, ed) < rhs) return false;
+    }
+    return true;
+}
+
+struct Host {   // per host thread: pinned staging (read in place by the kernels / target of the read-backs) and scratch
+    void *pinned = nullptr;
+    size_t pinnedBytes = 0;
+    int device = -1;
+    std::vector<int32_t> perm;
+    char *need(size_t bytes)
+    {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        if (pinned == nullptr || pinnedBytes < bytes || device != dev) {
+            if (pinned != nullptr) (void)hipHostFree(pinned);
+            pinned = nullptr;
+            pinnedBytes = std::max(bytes, (size_t)1 << 20);
+            if (hipHostMalloc(&pinned, pinnedBytes, hipHostMallocDefault) != hipSuccess) { pinned = nullptr; pinnedBytes = 0; }
+            device = dev;
+        }
+        return static_cast<char *>(pinned);
+    }
+};
+
+inline size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int round64(int64_t x) { return (int)((x + 63) / 64 * 64); }
+
+}  // namespace
+
+extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_labels_src, int n_src, const float *d_points_dst,
+                                   const float *d_labels_dst, int n_dst, const icpflow_registration_t *reg,
+                                   const icpflow_frame_params_t *par, float *d_rows, float *d_T, int32_t *h_pairs,
+                                   const float *d_flow_points, const float *d_pose, float *d_flow, void *d_scratch,
+                                   size_t scratch_bytes, size_t *scratch_needed, icpflow_stream_t stream,
+                                   const icpflow_options_t *opt)
+{
+    if (!d_points_src || !d_labels_src || !d_points_dst || !d_labels_dst || !reg || !par || !d_rows || !d_T || !h_pairs ||
+        !scratch_needed)
+        return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: null pointer");
+    if (par->struct_size != sizeof(icpflow_frame_params_t) || n_src <= 0 || n_dst <= 0 || par->max_points <= 0)
+        return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: params.struct_size, n_src, n_dst, max_points must be valid / positive");
+    if ((d_flow != nullptr) != (d_flow_points != nullptr) || (d_flow != nullptr && d_pose == nullptr))
+        return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: d_flow comes with d_flow_points and d_pose");
+    *h_pairs = ICPFLOW_FRAME_HOST_PATH;
+    hipStream_t s = (hipStream_t)stream;
+    static thread_local Host H;
+
+    // ---- device scratch, first part: the label-sorted orders, both tables, the tables' workspace
+    char *base = static_cast<char *>(d_scratch);
+    size_t off = 0;
+    const size_t oOrderS = off; off += up(sizeof(int64_t) * (size_t)n_src);
+    const size_t oOrderD = off; off += up(sizeof(int64_t) * (size_t)n_dst);
+    const size_t oTables = off; off += up(sizeof(double) * 2 * kTableDoubles);
+    const size_t tableWs = icpflow_cluster_table_pair_workspace_bytes(n_src, n_dst, kTableRows);
+    const size_t oTableWs = off; off += up(tableWs);
+    const size_t fixedBytes = off;
+    *scratch_needed = fixedBytes;
+    if (d_scratch == nullptr || scratch_bytes < fixedBytes) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: scratch too small (see *scratch_needed)");
+    int64_t *orderS = reinterpret_cast<int64_t *>(base + oOrderS), *orderD = reinterpret_cast<int64_t *>(base + oOrderD);
+    double *tabS = reinterpret_cast<double *>(base + oTables), *tabD = tabS + kTableDoubles;
+
+    // ---- both cluster tables, one read-back (ClusterTable.pair)
+    if (int r = icpflow_cluster_table_pair(d_points_src, d_labels_src, n_src, orderS, tabS + 1, reinterpret_cast<int32_t *>(tabS),
+                                           d_points_dst, d_labels_dst, n_dst, orderD, tabD + 1, reinterpret_cast<int32_t *>(tabD),
+                                           kTableRows, base + oTableWs, tableWs, stream))
+        return r;
+    const size_t tableBytes = sizeof(double) * 2 * kTableDoubles;
+    char *pin = H.need(tableBytes);
+    if (pin == nullptr) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: no pinned host memory");
+    if (hipMemcpyAsync(pin, tabS, tableBytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the cluster tables failed");
+    Table st, dt;
+    st.set(reinterpret_cast<const double *>(pin));
+    dt.set(reinterpret_cast<const double *>(pin) + kTableDoubles);
+    if (st.L < 0 || dt.L < 0) return 0;   // more distinct labels than the device table holds: the host path (torch ops)
+    const int S = st.L, D = dt.L;
+    if (S == 0 || D == 0) return 0;
+
+    const float tf = par->translation_frame, tb = par->thres_box;
+    const int minSize = par->min_cluster_size, maxPoints = par->max_points;
+
+    // ---- stage 1: the labels both clouds carry (utils_match.py:29-35), through sanity_check
+    // labels_unq = unique(int64(labels of either cloud)), >= 0; looked up as float32 in both tables
+    std::vector<int64_t> unq;
+    unq.reserve((size_t)S + D);
+    for (int r = 0; r < S; ++r) unq.push_back((int64_t)st.label[r]);
+    for (int r = 0; r < D; ++r) unq.push_back((int64_t)dt.label[r]);
+    std::sort(unq.begin(), unq.end());
+    unq.erase(std::unique(unq.begin(), unq.end()), unq.end());
+    std::vector<int32_t> si1, di1;
+    for (const int64_t v : unq) {
+        if (v < 0) continue;
+        const float f = (float)v;
+        const int a = st.find(f), b = dt.find(f);
+        if (a < 0 || b < 0) continue;
+        if (std::min(st.count[a], dt.count[b]) < minSize) continue;
+        if (!(f >= 0.f)) continue;
+        if (!pair_passes(st, dt, a, b, tf, tb)) continue;
+        si1.push_back(a);
+        di1.push_back(b);
+    }
+    const int K1 = (int)si1.size();
+    if (K1 == 0) return 0;   // (stage 2 alone: the host path)
+
+    // ---- stage 1's segment rows and subsamples (utils_match._stage_rows), in pinned memory the kernels read in place
+    int64_t longest = 0;
+    int nPerm = 0;
+    for (int k = 0; k < K1; ++k) {
+        longest = std::max(longest, std::max(st.count[si1[k]], dt.count[di1[k]]));
+        nPerm += (st.count[si1[k]] > maxPoints) + (dt.count[di1[k]] > maxPoints);
+    }
+    const int N1 = par->tight_padding ? std::min(maxPoints, std::max(64, round64(longest))) : maxPoints;
+
+    // ---- stage 2's superset (utils_match._match_pcds_device): every pair of the sanity grid, less the over-long clusters
+    const int capPts = std::min(maxPoints, par->superset_width > 0 ? par->superset_width : 1024);
+    std::vector<uint8_t> sOk(S), dOk(D);
+    for (int r = 0; r < S; ++r) sOk[r] = st.count[r] >= minSize && st.label[r] >= 0.f;
+    for (int r = 0; r < D; ++r) dOk[r] = dt.count[r] >= minSize && dt.label[r] >= 0.f;
+    std::vector<int32_t> si2, di2, leftS, leftD;
+    int64_t longest2 = 0;
+    for (int a = 0; a < S; ++a) {
+        if (!sOk[a]) continue;
+        for (int b = 0; b < D; ++b) {
+            if (!dOk[b] || !pair_passes(st, dt, a, b, tf, tb)) continue;
+            if (st.count[a] > capPts || dt.count[b] > capPts) {
+                leftS.push_back(a);
+                leftD.push_back(b);
+            } else {
+                si2.push_back(a);
+                di2.push_back(b);
+                longest2 = std::max(longest2, std::max(st.count[a], dt.count[b]));
+            }
+        }
+    }
+    const int K2 = (int)si2.size();
+    int N2 = K2 ? std::min(capPts, std::max(64, round64(longest2))) : 64;
+    if (!par->tight_padding) N2 = maxPoints;
+
+    // ---- device scratch, second part
+    const size_t ws1 = icpflow_workspace_bytes(K1, N1, reg->len_x, reg->len_y, reg->len_z);
+    const size_t ws2 = K2 ? icpflow_workspace_bytes(K2, N2, reg->len_x, reg->len_y, reg->len_z) : 0;
+    const size_t oClouds1 = off; off += up(sizeof(float) * 8 * (size_t)K1 * N1);
+    const size_t oRes1 = off; off += up(sizeof(float) * (30 * (size_t)K1 + 1));
+    const size_t oClouds2 = off; off += up(sizeof(float) * 8 * (size_t)K2 * N2);
+    const size_t oRes2 = off; off += up(sizeof(float) * (30 * (size_t)K2 + 1));
+    const size_t oActive = off; off += up((size_t)K2 + 1);
+    const size_t oBest = off; off += up(sizeof(int32_t) * (2 * (size_t)S + 2));
+    const size_t oWs = off; off += up(std::max(ws1, ws2));
+    *scratch_needed = off;
+    if (scratch_bytes < off) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: scratch too small (see *scratch_needed)");
+
+    // pinned staging: [tables (done with) | seg1 int64 [2,3,K1] | perm int32 [nPerm, maxPoints] | seg2 int64 [2,3,K2] |
+    //                  si1, di1, si2, di2 int32 | best int32 [2S+2]]
+    const size_t pSeg1 = 0, pPerm = pSeg1 + 48 * (size_t)K1, pSeg2 = up(pPerm + 4 * (size_t)nPerm * maxPoints);
+    const size_t pIdx = pSeg2 + 48 * (size_t)K2, pBest = up(pIdx + 8 * ((size_t)K1 + K2));
+    const size_t pinBytes = pBest + 4 * (2 * (size_t)S + 2);
+    pin = H.need(pinBytes);   // (the tables have been parsed: the buffer may move)
+    if (pin == nullptr) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: no pinned host memory");
+    int64_t *seg1 = reinterpret_cast<int64_t *>(pin + pSeg1);
+    int32_t *perm = reinterpret_cast<int32_t *>(pin + pPerm);
+    int64_t *seg2 = reinterpret_cast<int64_t *>(pin + pSeg2);
+    int32_t *idx = reinterpret_cast<int32_t *>(pin + pIdx);
+    int32_t *hBest = reinterpret_cast<int32_t *>(pin + pBest);
+    {
+        Mt19937 gen((uint32_t)par->seed);
+        int drawn = 0;
+        for (int k = 0; k < K1; ++k) {
+            const int64_t cs = st.count[si1[k]], cd = dt.count[di1[k]];
+            seg1[0 * K1 + k] = st.start[si1[k]]; seg1[1 * K1 + k] = std::min<int64_t>(cs, maxPoints); seg1[2 * K1 + k] = -1;
+            seg1[3 * K1 + k] = dt.start[di1[k]]; seg1[4 * K1 + k] = std::min<int64_t>(cd, maxPoints); seg1[5 * K1 + k] = -1;
+            if (cs > maxPoints) {   // random_choice, utils_helper.py:198-201: src then dst, pair by pair
+                seg1[2 * K1 + k] = (int64_t)drawn * maxPoints;
+                randperm_head(gen, cs, maxPoints, perm + (size_t)drawn * maxPoints, H.perm);
+                ++drawn;
+            }
+            if (cd > maxPoints) {
+                seg1[5 * K1 + k] = (int64_t)drawn * maxPoints;
+                randperm_head(gen, cd, maxPoints, perm + (size_t)drawn * maxPoints, H.perm);
+                ++drawn;
+            }
+        }
+    }
+    for (int k = 0; k < K2; ++k) {
+        seg2[0 * K2 + k] = st.start[si2[k]]; seg2[1 * K2 + k] = st.count[si2[k]]; seg2[2 * K2 + k] = -1;
+        seg2[3 * K2 + k] = dt.start[di2[k]]; seg2[4 * K2 + k] = dt.count[di2[k]]; seg2[5 * K2 + k] = -1;
+    }
+    std::memcpy(idx, si1.data(), 4 * (size_t)K1);
+    std::memcpy(idx + K1, di1.data(), 4 * (size_t)K1);
+    if (K2) {
+        std::memcpy(idx + 2 * K1, si2.data(), 4 * (size_t)K2);
+        std::memcpy(idx + 2 * K1 + K2, di2.data(), 4 * (size_t)K2);
+    }
+
+    // ---- everything else is enqueued: stage 1, then the assignment / stage 2 / assignment / pair rows / flow
+    icpflow_tables_t tables{d_points_src, orderS, tabS + 1, d_points_dst, orderD, tabD + 1, S, D, 9};
+    icpflow_stage_t stage1{seg1, nPerm ? perm : nullptr, idx, idx + K1, reinterpret_cast<float *>(base + oClouds1),
+                           reinterpret_cast<float *>(base + oRes1), K1, N1};
+    icpflow_stage_t stage2{seg2, nullptr, idx + 2 * K1, idx + 2 * K1 + K2, reinterpret_cast<float *>(base + oClouds2),
+                           reinterpret_cast<float *>(base + oRes2), K2, N2};
+    if (int r = icpflow_register_stage(&tables, &stage1, reg, base + oWs, std::max(ws1, ws2), stream, opt)) return r;
+    int32_t *dBest = reinterpret_cast<int32_t *>(base + oBest);
+    const int cap = 2 * S;
+    if (int r = icpflow_associate_frame(&tables, &stage1, K2 ? &stage2 : nullptr, reinterpret_cast<uint8_t *>(base + oActive), reg,
+                                        par->translation_frame, par->thres_iou, par->rot_limit_deg, par->thres_error, dBest, cap,
+                                        d_rows, d_T, d_flow_points, d_flow != nullptr ? d_labels_src : nullptr, n_src, d_pose,
+                                        d_flow, base + oWs, std::max(ws1, ws2), stream, opt))
+        return r;
+    if (hipMemcpyAsync(hBest, dBest, 4 * (2 * (size_t)S + 2), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the matches failed");
+    const int P = hBest[2 * S];
+    if (P < 0) {
+        *h_pairs = ICPFLOW_FRAME_ABANDONED;   // a team's wait timed out: the transforms are NaN (include/icpflow_hip.h, a-5)
+        return 0;
+    }
+    // a pair that had to stay out of the superset and whose clusters both found no partner in stage 1 is a candidate of the
+    // reference's stage 2: the host path serves it (with the generator as it was: nothing of it was consumed here)
+    if (!leftS.empty()) {
+        std::vector<uint8_t> mD(D, 0);
+        for (int a = 0; a < S; ++a)
+            if (hBest[a] >= 0) mD[di1[hBest[a]]] = 1;
+        for (size_t k = 0; k < leftS.size(); ++k)
+            if (hBest[leftS[k]] < 0 && !mD[leftD[k]]) return 0;   // (*h_pairs still says "host path")
+    }
+    *h_pairs = P;
+    return 0;
+}

@@ -14,6 +14,7 @@
 // it+1 returns immediately when notconv[it] == 0.  ICPFLOW_STOP_PER_PAIR loops inside one
 // launch and lets every pair stop on its own.
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "scan.hpp"
@@ -2606,7 +2607,7 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
             // The members of a team wait for each other inside the launch.  Two team launches in flight at once (the
             // same host thread registering on several streams: hist_icp_many, frame pairs in flight) could each hold
             // part of the GPU with members that spin for teammates the other launch keeps from starting; so the team
-            // launches of one host thread are chained by an event, whatever streams they are on.  (Not under stream
+            // launches on one device are chained by an event, whatever streams and host threads they come from.  (Not under stream
             // capture, where an event from outside the graph cannot be waited for: a captured registration stands alone.)
             // Round 4: launches that take at most half of the CUs (ICPFLOW_OPT_TEAMS_HALF_GPU, p.teamLanes == 2) are chained two
             // deep -- they alternate between two lanes, each lane a chain of its own, so that two of them (256 workgroups of
@@ -2614,13 +2615,20 @@ static void launch_icp_iters(const IcpParams &p, int B, int itBegin, int itEnd, 
             // event in both.
             // (three and four lanes on a third / a quarter of the CUs were measured: 1.42 / 1.53 ms per demo frame pair with four
             // in flight against 1.46 with two, and slower one at a time -- the teams get too small)
+            // The chains belong to the DEVICE, not to the host thread (until version 206 they were thread-local: two host
+            // threads registering on one GPU could have had four half-GPU team launches in flight): one table per process,
+            // the wait / launch / record of a team launch under its lock (enqueues only; nothing here waits for the GPU).
             struct TeamLane { hipEvent_t ev[2] = {nullptr, nullptr}; int device = -1; bool recorded[2] = {false, false}; int next = 0; };
-            static thread_local TeamLane lane;
+            static TeamLane lanes[64];
+            static std::mutex lanesLock;
             int dev = -1;
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            bool chain = hipGetDevice(&dev) == hipSuccess && hipStreamIsCapturing(s, &cap) == hipSuccess &&
+            bool chain = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && hipStreamIsCapturing(s, &cap) == hipSuccess &&
                          cap == hipStreamCaptureStatusNone;
-            if (chain && (lane.ev[0] == nullptr || lane.device != dev)) {
+            std::unique_lock<std::mutex> guard(lanesLock, std::defer_lock);
+            if (chain) guard.lock();
+            TeamLane &lane = lanes[chain ? dev : 0];
+            if (chain && lane.ev[0] == nullptr) {
                 lane = TeamLane{};
                 lane.device = dev;
                 if (hipEventCreateWithFlags(&lane.ev[0], hipEventDisableTiming) != hipSuccess ||

@@ -34,6 +34,7 @@ import argparse
 import glob
 import json
 import os
+import threading
 import time
 from types import SimpleNamespace
 
@@ -298,16 +299,27 @@ def register_frame_pair_steps(args, fp, device, gap=None, asynchronous=False):
         flow = a.flow_result
     else:
         flow = utils_flow.flow_estimation_torch(a, flow_src, pd, ls, ld, pairs, T, pose)
-    return dict(pairs=pairs, transformations=T, flow=flow, translation_frame=a.translation_frame)
+    return dict(pairs=pairs, transformations=T, flow=flow, translation_frame=a.translation_frame, association=a.association_path or "host")
+
+
+def _native_host(args):
+    """One call into the library per frame pair (icpflow_track_frame) unless switched off: `args.native_host = False`, or
+    `args.device_association = False` (the host-side association is the Python host's)."""
+    return getattr(args, "native_host", True) and getattr(args, "device_association", None) is not False
 
 
 def register_frame_pair(args, fp, device, gap=None):
-    """`register_frame_pair_steps` driven to its end (every hand-over blocks)."""
+    """One frame pair: through `register_frame_pair_native` (one blocking call into the library) where that serves it,
+    otherwise `register_frame_pair_steps` driven to its end (every hand-over blocks).  Same result either way."""
     from . import utils_match
+    if _native_host(args) and torch.device(device).type == "cuda":
+        out = register_frame_pair_native(args, fp, device, gap)
+        if out is not None:
+            return out
     return utils_match.drive(register_frame_pair_steps(args, fp, device, gap))
 
 
-def register_in_flight(args, fps, device, in_flight=4):
+def register_in_flight_scheduler(args, fps, device, in_flight=4):
     """Register the frame pairs `fps` (an iterable) with up to `in_flight` of them at once: each on its own HIP stream,
     its device -> host hand-overs as asynchronous copies into pinned memory, and ONE host thread that resumes whichever
     frame pair's transfer has landed -- the host half of one frame pair (candidate lists, reject test, assignment) and
@@ -317,7 +329,8 @@ def register_in_flight(args, fps, device, in_flight=4):
     device = torch.device(device)
     # (the streams live as long as the process: pinned staging buffers and workspaces are kept per stream, and pinned
     # memory is expensive to allocate)
-    pool = _stream_pool.setdefault((device.type, device.index), [])
+    # (per host thread: two threads registering on one device must not share streams)
+    pool = _stream_pool.setdefault((device.type, device.index, threading.get_ident()), [])
     while len(pool) < max(int(in_flight), 1):
         pool.append(torch.cuda.Stream(device))
     streams = pool[: max(int(in_flight), 1)]
@@ -374,14 +387,160 @@ def register_in_flight(args, fps, device, in_flight=4):
                 finished[0][3].synchronize()
 
 
+_frame_scratch = {}
+
+
+def register_frame_pair_native(args, fp, device, gap=None):
+    """One frame pair through icpflow_track_frame: the whole of match_pcds + flow -- the host half included (cluster tables,
+    candidate lists, sanity_check, padded batches and their random subsamples, both association stages on the device) -- in ONE
+    blocking call into the library, which releases the interpreter lock.  Bit for bit the result of `register_frame_pair` with
+    the device-side association (tests/test_gpu_parity.py::test_native_frame_pair_equals_the_python_host).
+    -> the result dict, or None when the call cannot serve this frame pair (options outside the single speculative launch, no
+    common label, more than 512 clusters, an over-long cluster needing its second try): the caller takes
+    `register_frame_pair_steps`."""
+    a = SimpleNamespace(**vars(args))
+    a.translation_frame = frame_translation(args, fp.pose_exact, fp.gap if gap is None else gap)
+    device = torch.device(device)
+    ps = _upload(fp.points_src, device)
+    pd = _upload(fp.points_dst, device)
+    if fp.labels_src is None:
+        ls, ld = cluster_frame_pair(args, ps, pd, fp.nonground_src, fp.nonground_dst)
+    else:
+        ls = _upload(fp.labels_src, device)
+        ld = _upload(fp.labels_dst, device)
+    pose = torch.from_numpy(fp.pose).to(device)
+    flow_src = ps if fp.points_src_raw is None else _upload(fp.points_src_raw, device)
+    return track_frame_native(a, ps, pd, ls, ld, pose, flow_src)
+
+
+def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0):
+    """icpflow_track_frame on device tensors: `track(a, ps, pd, ls, ld)` (+ `flow_estimation_torch` of `flow_points` under
+    `pose` when given) with `a.translation_frame` set; the random subsamples of over-long clusters are torch.randperm's on a
+    generator seeded with `seed`.  -> dict(pairs, transformations[, flow]) or None (see register_frame_pair_native)."""
+    from . import _lib, utils_match
+    import ctypes
+    device = ps.device
+    max_it, _, stop = utils_match._icp_options(a)
+    cur = _lib._current()[-1]
+    if not (stop == 0 and 2 <= max_it <= 128 and cur["arith"] == 0 and not (cur["flags"] & _lib.OPT_FLAGS["no_speculative"])):
+        return None
+    if len(ps) == 0 or len(pd) == 0:
+        return None
+    _lib.require_gpu(ps, pd, ls, ld)
+    ps3, pd3 = ps[:, 0:3].contiguous().float(), pd[:, 0:3].contiguous().float()
+    ls, ld = ls.contiguous().float(), ld.contiguous().float()
+    rows = torch.empty((1024, 10), dtype=torch.float32, device=device)
+    T = torch.empty((1024, 4, 4), dtype=torch.float32, device=device)
+    flow = f_pts = f_pose = None
+    if flow_points is not None:
+        f_pts = ps3 if flow_points is ps else flow_points[:, 0:3].contiguous().float()
+        assert len(f_pts) == len(ls)
+        f_pose = pose.to(device).contiguous().float()
+        flow = torch.empty((len(ps3), 3), dtype=torch.float32, device=device)
+    reg, keep_alive = utils_match._registration(a, device)
+    f32 = lambda v: float(np.float32(v))   # noqa: E731
+    par = _lib.FrameParams(ctypes.sizeof(_lib.FrameParams), int(seed), int(a.max_points), int(a.min_cluster_size),
+                           f32(a.translation_frame), f32(a.thres_box), f32(a.thres_iou), f32(a.thres_rot * 90.0), f32(a.thres_error),
+                           1 if getattr(a, "tight_padding", True) else 0, int(getattr(a, "device_association_width", 1024)))
+    key = (device.index, _lib.stream_handle(device))
+    scratch = _frame_scratch.get(key)
+    if scratch is None:
+        scratch = _frame_scratch[key] = torch.empty((64 << 20,), dtype=torch.uint8, device=device)
+    pairs, need = ctypes.c_int32(0), ctypes.c_size_t(0)
+    with _lib.options(teams_half_gpu=not getattr(a, "teams_full_gpu", False)):
+        opt = _lib.opt()
+        for _ in range(3):
+            rc = _lib._L.icpflow_track_frame(_lib.ptr(ps3), _lib.ptr(ls), len(ps3), _lib.ptr(pd3), _lib.ptr(ld), len(pd3),
+                                             ctypes.byref(reg), ctypes.byref(par), _lib.ptr(rows), _lib.ptr(T), ctypes.byref(pairs),
+                                             _lib.ptr(f_pts), _lib.ptr(f_pose), _lib.ptr(flow), _lib.ptr(scratch), scratch.numel(),
+                                             ctypes.byref(need), _lib.stream(device), opt)
+            if rc != -2:
+                break
+            # (the scratch grows to what this frame pair needs, with some room: the next ones are alike)
+            scratch = _frame_scratch[key] = torch.empty((int(need.value * 1.25),), dtype=torch.uint8, device=device)
+    if rc != 0:
+        msg = _lib._L.icpflow_last_error()
+        raise RuntimeError(f"icpflow_track_frame failed (code {rc}): {msg.decode() if msg else ''}")
+    P = int(pairs.value)
+    if P == -2:
+        return None
+    if P < 0:
+        raise RuntimeError("icpflow_hist_icp abandoned the batch: a wait between workgroups timed out -- a team sharing one "
+                           "large pair (GPU shared with another process?); retry, or register with _lib.options(no_teams=True)")
+    out = dict(pairs=rows[:P], transformations=T[:P], translation_frame=a.translation_frame, association="device")
+    if flow is not None:
+        out["flow"] = flow
+    return out
+
+
+def register_in_flight(args, fps, device, in_flight=4):
+    """Up to `in_flight` frame pairs at once: `register_in_flight_native` (a host thread per frame pair in flight, one blocking
+    call into the library each) unless `args.native_host` / `args.device_association` is False -- then the generator-based
+    scheduler on one host thread (`register_in_flight_scheduler`).  Yields (index, frame pair, result dict) in completion order."""
+    if _native_host(args) and torch.device(device).type == "cuda":
+        yield from register_in_flight_native(args, fps, device, in_flight)
+    else:
+        yield from register_in_flight_scheduler(args, fps, device, in_flight)
+
+
+def register_in_flight_native(args, fps, device, in_flight=4):
+    """`register_in_flight` with one HOST THREAD per frame pair in flight, each on its own HIP stream, each frame pair one
+    blocking `register_frame_pair_native` call (frame pairs that call cannot serve go through `register_frame_pair` on the
+    same thread).  The threads spend their time inside the library with the interpreter lock released; the library chains
+    team launches per device whatever thread they come from.  Yields (index, frame pair, result dict) in completion order,
+    results complete on the device."""
+    import queue
+    from . import utils_match
+    device = torch.device(device)
+    source = enumerate(fps)
+    lock = threading.Lock()
+    out = queue.Queue()
+
+    def worker():
+        try:
+            torch.cuda.set_device(device)
+            stream = torch.cuda.Stream(device)
+            with torch.cuda.stream(stream):
+                while True:
+                    with lock:
+                        try:
+                            idx, fp = next(source)
+                        except StopIteration:
+                            return
+                    res = register_frame_pair_native(args, fp, device)
+                    if res is None:
+                        res = utils_match.drive(register_frame_pair_steps(args, fp, device))
+                    stream.synchronize()
+                    out.put((idx, fp, res))
+        except BaseException as e:   # noqa: BLE001  (handed to the consumer)
+            out.put(e)
+        finally:
+            out.put(None)
+
+    threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, int(in_flight)))]
+    for t in threads:
+        t.start()
+    done = 0
+    while done < len(threads):
+        item = out.get()
+        if item is None:
+            done += 1
+        elif isinstance(item, BaseException):
+            raise item
+        else:
+            yield item
+    for t in threads:
+        t.join()
+
+
 def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, register_fn=None, in_flight=1):
     """Register this rank's share of `paths`; -> summary dict (identical on every rank).
     ms / frame pair is the mean wall time per pair, host -> device upload of the clouds included
     (the stream hands over host buffers); frame_pairs_per_s uses the slowest rank's total.
     `register_fn(args, fp, device) -> dict(pairs, transformations, flow)` defaults to the HIP path
     (`register_frame_pair`); the CPU tests of the sharding logic pass the oracle here.
-    in_flight > 1 (HIP path only): that many frame pairs at once (`register_in_flight`: one stream each, asynchronous
-    hand-overs, one host thread); ms / frame pair is then the wall time of the whole share over its frame pairs --
+    in_flight > 1 (HIP path only): that many frame pairs at once (`register_in_flight`: one stream and one host thread each, a
+    blocking call into the library per frame pair; or the one-thread scheduler with asynchronous hand-overs); ms / frame pair is then the wall time of the whole share over its frame pairs --
     throughput of the stream, not the latency of one pair."""
     import torch.distributed as dist
     device = torch.device(device)

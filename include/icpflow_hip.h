@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 206 /* 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 207 /* 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -117,7 +117,7 @@ const char *icpflow_build_info(void);
 #define ICPFLOW_OPT_NO_PERSISTENT (1u << 9)   /* ICP: one workgroup per pair dealt by the hardware dispatcher, whatever B */
 #define ICPFLOW_OPT_NO_HELPERS (1u << 10)     /* ICP, persistent grid: workgroups without a pair left do not take passes of others */
 /* NOT a bit-identity switch: teams of workgroups (several per large pair) take at most HALF of the CUs, so that two team
- * launches of one host thread may run side by side (frame pairs in flight).  The plan -- hence the order of a team's sums --
+ * launches may run side by side (frame pairs in flight; the chains are per device, whatever host threads launch).  The plan -- hence the order of a team's sums --
  * follows the number of workgroups: results equal those of the full-GPU plan to rounding, and are the same whatever else is
  * in flight.  Team launches WITH the flag are chained two deep (two lanes), launches without it wait for both lanes. */
 #define ICPFLOW_OPT_TEAMS_HALF_GPU (1u << 11)
@@ -448,6 +448,47 @@ int icpflow_associate_frame(const icpflow_tables_t *tables, const icpflow_stage_
                             const float *d_flow_points, const float *d_flow_labels, int n_flow, const float *d_pose,
                             float *d_flow, void *d_ws, size_t ws_bytes, icpflow_stream_t stream,
                             const icpflow_options_t *opt);
+/* ---------------------------------------------------------------------------
+ * One frame pair per call (version 207): match_pcds (utils_match.py:24-66) + flow_estimation_torch (utils_flow.py:57-69) from two
+ * labelled clouds on, the HOST half included -- cluster tables, candidate lists, sanity_check (utils_check.py:21-49), padded
+ * batches with the reference's stream of random subsamples, both association stages (device-side association: icpflow_
+ * register_stage + icpflow_associate_frame), the flow.  BLOCKING: returns when the results are complete on the device (two
+ * waits inside: the cluster tables, the end).  A host thread per frame pair in flight, each on its own stream, keeps several
+ * going: the time a Python host spends between the calls of the finer-grained entry points is what binds a stream of frame
+ * pairs.
+ *
+ * d_points_* float32 [n,3], d_labels_* float32 [n].  par: the flags of the reference's argument parser that the path reads
+ * (main.py / demo.sh) + `seed`: the over-long clusters of stage 1 are subsampled by torch.randperm's algorithm on MT19937
+ * seeded with it (= torch.Generator().manual_seed(seed), the generator frame_pairs.py gives every frame pair).
+ * Outputs: d_rows float32 [1024,10], d_T float32 [1024,16] (the first *h_pairs rows are the matches, the rest padding),
+ * d_flow float32 [n_src,3] of d_flow_points (or NULL: no flow) under d_pose [4,4].  *h_pairs: the number of matched pairs;
+ * ICPFLOW_FRAME_HOST_PATH when this call cannot serve the frame pair (no common label, more than 512 clusters, or a stage-2
+ * candidate with a cluster too long for the superset turned out to be needed: the caller runs the finer-grained path, nothing
+ * was consumed); ICPFLOW_FRAME_ABANDONED when a team's wait timed out (transforms NaN).  d_scratch / scratch_bytes: device
+ * scratch; on ICPFLOW_E_WORKSPACE *scratch_needed says how much this frame pair needs (call again with that much).
+ * ------------------------------------------------------------------------- */
+#define ICPFLOW_FRAME_HOST_PATH (-2)
+#define ICPFLOW_FRAME_ABANDONED (-1)
+typedef struct icpflow_frame_params {
+    size_t struct_size;       /* sizeof(icpflow_frame_params_t) */
+    uint64_t seed;
+    int max_points;           /* --max_points */
+    int min_cluster_size;     /* --min_cluster_size */
+    float translation_frame;  /* --translation_frame (or 2 * speed * gap, main.py:200) */
+    float thres_box;          /* --thres_box */
+    float thres_iou;          /* --thres_iou */
+    float rot_limit_deg;      /* --thres_rot * 90 */
+    float thres_error;        /* --thres_error */
+    int tight_padding;        /* 1: batches as wide as their longest cluster (icp_flow_amd's default), 0: max_points wide */
+    int superset_width;       /* clusters above it stay out of stage 2's superset (0 = 1024) */
+} icpflow_frame_params_t;
+int icpflow_track_frame(const float *d_points_src, const float *d_labels_src, int n_src, const float *d_points_dst,
+                        const float *d_labels_dst, int n_dst, const icpflow_registration_t *reg,
+                        const icpflow_frame_params_t *par, float *d_rows, float *d_T, int32_t *h_pairs,
+                        const float *d_flow_points, const float *d_pose, float *d_flow, void *d_scratch,
+                        size_t scratch_bytes, size_t *scratch_needed, icpflow_stream_t stream,
+                        const icpflow_options_t *opt);
+
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
                           const int64_t *d_count, const float *d_labels, int L, float *d_mean,
                           float *d_extent, icpflow_stream_t stream);

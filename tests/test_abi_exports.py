@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_the_header():
     from icp_flow_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.VERSION == 206
+    assert _lib.VERSION == 207
     assert re.fullmatch(r"[0-9a-f]{16}", _lib.BUILD_INFO), _lib.BUILD_INFO
 
 
@@ -65,6 +65,18 @@ def test_argument_errors_are_status_codes_with_messages():
     rc = L.icpflow_associate_frame(ctypes.byref(tables), ctypes.byref(stage), ctypes.byref(stage2), None, ctypes.byref(reg), 2.0, 0.2,
                                    9.0, 0.2, one, 4, one, one, None, None, 0, None, None, one, 1 << 30, None, None)
     assert rc == -1 and b"stage 2 comes with" in L.icpflow_last_error()
+    # one frame pair per call (version 207)
+    par, pairs, need = _lib.FrameParams(), ctypes.c_int32(0), ctypes.c_size_t(0)
+    rc = L.icpflow_track_frame(one, one, 10, one, one, 10, ctypes.byref(reg), ctypes.byref(par), one, one, ctypes.byref(pairs), None, None, None,
+                               one, 1 << 30, ctypes.byref(need), None, None)
+    assert rc == -1 and b"struct_size" in L.icpflow_last_error()
+    rc = L.icpflow_track_frame(one, one, 10, one, one, 10, ctypes.byref(reg), None, one, one, ctypes.byref(pairs), None, None, None,
+                               one, 1 << 30, ctypes.byref(need), None, None)
+    assert rc == -1 and b"null pointer" in L.icpflow_last_error()
+    par.struct_size, par.max_points = ctypes.sizeof(par), 2048
+    rc = L.icpflow_track_frame(one, one, 10, one, one, 10, ctypes.byref(reg), ctypes.byref(par), one, one, ctypes.byref(pairs), None, None, None,
+                               one, 16, ctypes.byref(need), None, None)
+    assert rc == -2 and need.value > 16 and b"scratch" in L.icpflow_last_error()
 
 
 def test_options_are_per_call_and_per_thread():
@@ -92,6 +104,7 @@ def test_options_are_per_call_and_per_thread():
     assert ctypes.sizeof(_lib.Options) == 96   # size_t, int, int, unsigned, pad, five pointers, two ints, two pointers on LP64
     # the structs of icpflow_register_stage / icpflow_associate_frame (include/icpflow_hip.h), LP64
     assert (ctypes.sizeof(_lib.Tables), ctypes.sizeof(_lib.Stage), ctypes.sizeof(_lib.Registration)) == (64, 56, 64)
+    assert ctypes.sizeof(_lib.FrameParams) == 56        # icpflow_frame_params_t
 
 
 def test_product_refuses_cpu_tensors_no_fallback():

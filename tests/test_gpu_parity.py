@@ -1191,14 +1191,15 @@ def test_frame_pairs_in_flight_equal_one_after_the_other(tmp_path):
     demo = frame_pairs.FramePair(g0["point_src"], g0["point_dst"], lab["label_src"], lab["label_dst"], None, g0["gt_flow"])
     fps = fps[:2] + [demo] + fps[2:] + [demo]
     a = frame_pairs.default_args(max_points=4096)
-    # By default the association of a frame pair on its own runs on the device, that of frame pairs in flight on the host
-    # (utils_match._device_association_ok: same pairs, numbers to rounding); with the option set either way a frame pair comes
-    # out bit for bit the same in flight and on its own -- and the default in flight IS the host path.
+    # Three hosts: the native one (icpflow_track_frame, a host thread per frame pair in flight: the default), the Python
+    # scheduler with the device-side association, the Python scheduler with the host-side association.  With any of them a
+    # frame pair comes out bit for bit the same in flight and on its own; the first two agree bit for bit with each other,
+    # the host-side association with both to rounding (same pairs).
     wants = {}
-    for assoc in (False, True):
-        a.device_association = assoc
-        wants[assoc] = want = [frame_pairs.register_frame_pair(a, fp, DEV) for fp in fps]
-        for in_flight in ((2, 4) if not assoc else (3,)):
+    for name, native, assoc, flights in (("native", True, None, (2, 4)), ("device", False, True, (3,)), ("host", False, False, (2, 4))):
+        a.native_host, a.device_association = native, assoc
+        wants[name] = want = [frame_pairs.register_frame_pair(a, fp, DEV) for fp in fps]
+        for in_flight in flights:
             got = {}
             for idx, fp, out in frame_pairs.register_in_flight(a, fps, DEV, in_flight=in_flight):
                 assert fp is fps[idx]
@@ -1207,15 +1208,13 @@ def test_frame_pairs_in_flight_equal_one_after_the_other(tmp_path):
             assert sorted(got) == list(range(len(fps)))
             for k, w in enumerate(want):
                 for key in ("pairs", "transformations", "flow"):
-                    assert torch.equal(got[k][key], w[key]), (assoc, in_flight, k, key)
-    a.device_association = None
-    got = {idx: out for idx, _, out in frame_pairs.register_in_flight(a, fps, DEV, in_flight=4)}
-    own = [frame_pairs.register_frame_pair(a, fp, DEV) for fp in fps]
+                    assert torch.equal(got[k][key], w[key]), (name, in_flight, k, key)
     for k in range(len(fps)):
         for key in ("pairs", "transformations", "flow"):
-            assert torch.equal(got[k][key], wants[False][k][key]) and torch.equal(own[k][key], wants[True][k][key]), (k, key)
-        assert torch.equal(wants[True][k]["pairs"][:, :2], wants[False][k]["pairs"][:, :2])
-        assert (wants[True][k]["flow"] - wants[False][k]["flow"]).abs().max() < 1e-5
+            assert torch.equal(wants["native"][k][key], wants["device"][k][key]), (k, key)
+        assert torch.equal(wants["device"][k]["pairs"][:, :2], wants["host"][k]["pairs"][:, :2])
+        assert (wants["device"][k]["flow"] - wants["host"][k]["flow"]).abs().max() < 1e-5
+    a.native_host, a.device_association = True, None
     # the harness: same accuracy summary as one at a time, on files (a sequence file among them: GPU clustering per gap)
     paths = []
     for k, fp in enumerate(fps[:4]):
@@ -1375,3 +1374,45 @@ def test_pairs_outside_the_batch_do_not_touch_its_stop_rule():
     with _lib.options(pair_active=G(keep.astype(np.uint8))):
         with pytest.raises(RuntimeError, match="d_pair_active"):
             utils_match.hist_icp(rp.default_args(max_points=512, icp_stop_mode="per_pair"), G(S2), G(D2))
+
+
+@pytest.mark.parametrize("case", ["synthetic", "draws", "demo-2048", "demo-10000", "fallback"])
+def test_native_frame_pair_equals_the_python_host(case):
+    """icpflow_track_frame (frame_pairs.register_frame_pair_native: the host half of match_pcds in C++ -- cluster tables,
+    candidate lists, sanity_check, padded batches with the stream of random subsamples restated on MT19937, stage 2's superset,
+    the checks at the end) against the Python host with the device-side association: pairs, transforms and per-point flow bit
+    for bit.  "draws": clusters longer than max_points in stage 1 (torch.randperm's draws).  "fallback": an over-long cluster
+    needs its second try -- the call reports that it cannot serve the frame pair and consumes nothing."""
+    from icp_flow_amd import frame_pairs
+    if case.startswith("demo"):
+        g0, lab = load_golden("g8_demo"), load_golden("g8_demo_labels")
+        fps = [frame_pairs.FramePair(g0["point_src"], g0["point_dst"], lab["label_src"], lab["label_dst"], None, g0["gt_flow"])]
+        a = frame_pairs.default_args(max_points=int(case.split("-")[1]))
+    else:
+        fps = []
+        for k, (nobj, nmax) in enumerate(((9, 400), (14, 900), (5, 2500), (11, 300))):
+            d = synthetic.make_frame_pair(seed=40 + k, n_objects=nobj, n_max=nmax, n_background=1000)
+            fps.append(frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"], d["gt_flow"]))
+        if case == "synthetic":
+            a = frame_pairs.default_args(max_points=4096)
+        else:
+            # the background cluster (1000 points) and the larger objects are over-long: subsampled in stage 1
+            a = frame_pairs.default_args(max_points=512 if case == "draws" else 128)
+    a.device_association = True
+    served = 0
+    for fp in fps:
+        want = frame_pairs.register_frame_pair(a, fp, DEV)
+        got = frame_pairs.register_frame_pair_native(a, fp, DEV)
+        torch.cuda.synchronize()
+        # the call gives up exactly where the Python host's device path gives up (an over-long cluster needs its second try)
+        assert (got is None) == (want["association"] == "host"), case
+        if got is None:
+            continue
+        served += 1
+        assert len(want["pairs"]) >= 3
+        for key in ("pairs", "transformations", "flow"):
+            assert torch.equal(got[key], want[key]), (case, key)
+    if case == "fallback":
+        assert served < len(fps)            # at least one frame pair needed the host path
+    else:
+        assert served >= len(fps) - 1 and served >= 1

@@ -11,7 +11,7 @@ for DEFS in "$@"; do
   OUT=/tmp/libicpflow_sweep_$i.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
       -Wno-unused-function $FLAGS -Iinclude -I$C -shared -o $OUT \
-      $C/api.hip $C/hist.hip $C/nn.hip $C/icp.hip $C/icp_fp32.hip $C/pose.hip $C/sort.hip $C/cluster.hip $C/hdbscan.hip $C/table.hip $C/assoc.hip $C/hdbscan_tree.cpp 2>&1 | grep -v warning | head -5 &
+      $C/api.hip $C/hist.hip $C/nn.hip $C/icp.hip $C/icp_fp32.hip $C/pose.hip $C/sort.hip $C/cluster.hip $C/hdbscan.hip $C/table.hip $C/assoc.hip $C/frame.hip $C/hdbscan_tree.cpp 2>&1 | grep -v warning | head -5 &
 done
 wait
 i=0

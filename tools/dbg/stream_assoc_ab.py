@@ -12,11 +12,11 @@ for mp in (2048, 10000):
     for mode in (False, True, False, True):
         a = frame_pairs.default_args(max_points=mp); a.device_association = mode
         def stream(k):
-            for _ in frame_pairs.register_in_flight(a, copies, dev, k): pass
+            for _ in frame_pairs.register_in_flight_scheduler(a, copies, dev, k): pass
             ts = []
             for _ in range(5):
                 torch.cuda.synchronize(); t = time.perf_counter()
-                for _ in frame_pairs.register_in_flight(a, copies, dev, k): pass
+                for _ in frame_pairs.register_in_flight_scheduler(a, copies, dev, k): pass
                 torch.cuda.synchronize(); ts.append((time.perf_counter() - t) / len(copies) * 1e3)
             return sorted(ts)[2]
         print(mp, "device" if mode else "host  ", " ".join(f"{k} in flight {stream(k):.3f}" for k in (1, 2, 4, 8)))

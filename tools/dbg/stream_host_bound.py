@@ -12,11 +12,11 @@ a = frame_pairs.default_args(max_points=10000)
 fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
 copies = [fp] * 12
 def stream(k):
-    for _ in frame_pairs.register_in_flight(a, copies, dev, k): pass
+    for _ in frame_pairs.register_in_flight_scheduler(a, copies, dev, k): pass
     ts = []
     for _ in range(5):
         torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in frame_pairs.register_in_flight(a, copies, dev, k): pass
+        for _ in frame_pairs.register_in_flight_scheduler(a, copies, dev, k): pass
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t) / len(copies) * 1e3)
     return sorted(ts)[2]
 for k in (1, 2, 4, 8):

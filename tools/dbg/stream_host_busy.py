@@ -38,10 +38,10 @@ for mp in (2048, 10000):
     for mode in (True, False):
         a = frame_pairs.default_args(max_points=mp); a.device_association = mode
         for k in (4, 8):
-            for _ in frame_pairs.register_in_flight(a, [fp] * 8, dev, k): pass
+            for _ in frame_pairs.register_in_flight_scheduler(a, [fp] * 8, dev, k): pass
             torch.cuda.synchronize(); busy[0] = 0.0; steps.clear(); t = time.perf_counter()
             n = 32
-            for _ in frame_pairs.register_in_flight(a, [fp] * n, dev, k): pass
+            for _ in frame_pairs.register_in_flight_scheduler(a, [fp] * n, dev, k): pass
             torch.cuda.synchronize(); wall = time.perf_counter() - t
             by = {}
             for s, d in steps: by.setdefault(s, []).append(d)

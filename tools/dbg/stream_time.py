@@ -16,7 +16,7 @@ for mp in (2048, 10000):
     for _ in range(n): frame_pairs.register_frame_pair(a, fp, dev)
     torch.cuda.synchronize(); print(f"max_points {mp}: one at a time (host upload included) {(time.perf_counter() - t) / n * 1e3:.3f} ms / frame pair")
     for k in (2, 3, 4, 6, 8):
-        for _ in frame_pairs.register_in_flight(a, [fp] * k, dev, k): pass
+        for _ in frame_pairs.register_in_flight_scheduler(a, [fp] * k, dev, k): pass
         torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in frame_pairs.register_in_flight(a, [fp] * n, dev, k): pass
+        for _ in frame_pairs.register_in_flight_scheduler(a, [fp] * n, dev, k): pass
         torch.cuda.synchronize(); print(f"   {k} in flight: {(time.perf_counter() - t) / n * 1e3:.3f} ms / frame pair")

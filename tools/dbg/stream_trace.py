@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
 a = frame_pairs.default_args(max_points=10000); a.device_association = os.environ.get("MODE", "device") == "device"
 k = int(os.environ.get("K", "4"))
-for _ in frame_pairs.register_in_flight(a, [fp] * 8, dev, k): pass
+for _ in frame_pairs.register_in_flight_scheduler(a, [fp] * 8, dev, k): pass
 torch.cuda.synchronize(); t = time.perf_counter()
-for _ in frame_pairs.register_in_flight(a, [fp] * 16, dev, k): pass
+for _ in frame_pairs.register_in_flight_scheduler(a, [fp] * 16, dev, k): pass
 torch.cuda.synchronize(); print("ms per frame pair", (time.perf_counter() - t) / 16 * 1e3)
