@@ -65,10 +65,14 @@ void randperm_head(Mt19937 &g, int64_t n, int take, int32_t *out, std::vector<in
 {
     tmp.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = (int32_t)i;
-    for (int64_t i = 0; i < n - 1; ++i) {
+    // step i fixes element i for good: the first `take` steps give the head; the rest of the shuffle only has to consume its
+    // draws (the next randperm continues on the same generator)
+    const int64_t steps = std::min<int64_t>(take, n - 1);
+    for (int64_t i = 0; i < steps; ++i) {
         const int64_t z = (int64_t)(g.next() % (uint64_t)(n - i));
         std::swap(tmp[(size_t)i], tmp[(size_t)(i + z)]);
     }
+    for (int64_t i = steps; i < n - 1; ++i) (void)g.next();
     std::memcpy(out, tmp.data(), sizeof(int32_t) * (size_t)take);
 }
 

@@ -12,6 +12,7 @@ fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab
 n = int(os.environ.get("FRAMES", "48"))
 for mp in (2048, 10000):
     a = frame_pairs.default_args(max_points=mp)
+    a.teams_full_gpu = os.environ.get("TEAMS_FULL_GPU") == "1"
     a.device_association = True
     ref = frame_pairs.register_frame_pair(a, fp, dev)["flow"]
     a.device_association = None

@@ -14,7 +14,8 @@ for tag in ("g8_demo", "g8_demo_mp10000"):
 bad = 0
 for mp in (2048, 10000):
     a = frame_pairs.default_args(max_points=mp)
-    a.device_association = {"1": True, "0": False}.get(os.environ.get("DEVICE_ASSOC", ""), None)   # (None: in flight = the host path)
+    a.device_association = {"1": True, "0": False}.get(os.environ.get("DEVICE_ASSOC", ""), None)
+    a.native_host = os.environ.get("NATIVE", "1") == "1"   # (0: the generator-based scheduler on one host thread)
     ref = [o["flow"] for _, _, o in frame_pairs.register_in_flight(a, fps[:1], dev, 1)][0]
     for k in (2, 3, 4, 8):
         t = time.perf_counter(); n = 0
@@ -23,5 +24,5 @@ for mp in (2048, 10000):
                 n += 1
                 if not torch.equal(o["flow"], ref): bad += 1
         torch.cuda.synchronize()
-        print(f"association {os.environ.get('DEVICE_ASSOC', 'default')}, max_points {mp}, {k} in flight: {n} frame pairs, {(time.perf_counter() - t) / n * 1e3:.3f} ms each, different flows so far {bad}")
+        print(f"native host {os.environ.get('NATIVE', '1')}, device association {os.environ.get('DEVICE_ASSOC', 'default')}, max_points {mp}, {k} in flight: {n} frame pairs, {(time.perf_counter() - t) / n * 1e3:.3f} ms each, different flows so far {bad}")
 print("different:", bad)
