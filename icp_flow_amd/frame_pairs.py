@@ -34,6 +34,7 @@ import argparse
 import glob
 import json
 import os
+import queue
 import threading
 import time
 from types import SimpleNamespace
@@ -483,54 +484,81 @@ def register_in_flight(args, fps, device, in_flight=4):
         yield from register_in_flight_scheduler(args, fps, device, in_flight)
 
 
+class _Worker(threading.Thread):
+    """A host thread that lives as long as the process, with its own HIP stream: the library keeps state per host thread (side
+    streams, pinned staging) and `track_frame_native` keeps its device scratch per stream -- a thread and a stream per CALL of
+    register_in_flight_native would allocate all of that again every time (hipMalloc and hipHostMalloc synchronise the device)."""
+
+    def __init__(self, device):
+        super().__init__(daemon=True)
+        self.device = device
+        self.jobs = queue.Queue()
+        self.start()
+
+    def run(self):
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.Stream(self.device)
+        while True:
+            job = self.jobs.get()
+            with torch.cuda.stream(stream):
+                job(stream)
+
+
+_workers = {}
+_workers_lock = threading.Lock()
+
+
 def register_in_flight_native(args, fps, device, in_flight=4):
     """`register_in_flight` with one HOST THREAD per frame pair in flight, each on its own HIP stream, each frame pair one
-    blocking `register_frame_pair_native` call (frame pairs that call cannot serve go through `register_frame_pair` on the
-    same thread).  The threads spend their time inside the library with the interpreter lock released; the library chains
+    blocking `register_frame_pair_native` call (frame pairs that call cannot serve go through `register_frame_pair_steps` on
+    the same thread).  The threads spend their time inside the library with the interpreter lock released; the library chains
     team launches per device whatever thread they come from.  Yields (index, frame pair, result dict) in completion order,
     results complete on the device."""
-    import queue
     from . import utils_match
     device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     source = enumerate(fps)
     lock = threading.Lock()
     out = queue.Queue()
 
-    def worker():
+    def job(stream):
         try:
-            torch.cuda.set_device(device)
-            stream = torch.cuda.Stream(device)
-            with torch.cuda.stream(stream):
-                while True:
-                    with lock:
-                        try:
-                            idx, fp = next(source)
-                        except StopIteration:
-                            return
-                    res = register_frame_pair_native(args, fp, device)
-                    if res is None:
-                        res = utils_match.drive(register_frame_pair_steps(args, fp, device))
-                    stream.synchronize()
-                    out.put((idx, fp, res))
+            while True:
+                with lock:
+                    try:
+                        idx, fp = next(source)
+                    except StopIteration:
+                        return
+                res = register_frame_pair_native(args, fp, device)
+                if res is None:
+                    res = utils_match.drive(register_frame_pair_steps(args, fp, device))
+                stream.synchronize()
+                out.put((idx, fp, res))
         except BaseException as e:   # noqa: BLE001  (handed to the consumer)
             out.put(e)
         finally:
             out.put(None)
 
-    threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, int(in_flight)))]
-    for t in threads:
-        t.start()
-    done = 0
-    while done < len(threads):
+    n = max(1, int(in_flight))
+    with _workers_lock:
+        pool = _workers.setdefault(device.index, [])
+        while len(pool) < n:
+            pool.append(_Worker(device))
+        mine = pool[:n]
+    for w in mine:
+        w.jobs.put(job)
+    done, error = 0, None
+    while done < n:
         item = out.get()
         if item is None:
             done += 1
         elif isinstance(item, BaseException):
-            raise item
-        else:
+            error = error or item        # (the other workers run to the end of the frame pairs: nothing is left half done)
+        elif error is None:
             yield item
-    for t in threads:
-        t.join()
+    if error is not None:
+        raise error
 
 
 def run_stream(args, paths, device, rank=0, world=1, repeat=1, group=None, register_fn=None, in_flight=1):

@@ -30,3 +30,12 @@ its = np.maximum(v[:, 2], 1)
 for k in np.argsort(-(v[:, 0] + v[:, 1]))[:14]:
     print(f"pair {k:3d}: {min(cs[k],10000):5d} x {min(cd[k],10000):5d} points, {v[k, 2]:3d} iterations, per iteration: serial {v[k, 0] / its[k]:7.0f}, search+exchange {v[k, 1] / its[k]:7.0f}, total {(v[k,0]+v[k,1])/2.4e6:.3f} ms")
 print("iterations histogram:", np.bincount(np.minimum(v[:,2],100)//10).tolist())
+if os.environ.get("SPLIT"):   # library built with -DICPFLOW_TAIL_CLOCK -DICPFLOW_TAIL_SPLIT: the phases of the pacing pairs
+    sp = (ctypes.c_longlong * 16384)(); _lib._L.icpflow_debug_tail_split(sp)
+    w = np.array(sp[:], dtype=np.int64).reshape(1024, 16)[:len(cs)]
+    names = {1: "top of loop -> queries loaded", 11: "certificates + probes", 12: "window", 2: "scan", 10: "resolve + records", 3: "moments", 4: "block barrier",
+             5: "totals + H", 13: "quartic coefficients", 14: "newton", 6: "adjugate + rotation", 15: "T, rmse", 9: "history + tally + stop check", 7: "cycle detection + publish"}
+    for b in np.argsort(-(v[:, 0] + v[:, 1]))[:3]:
+        print(f"pair {b} ({min(cs[b],10000)} x {min(cd[b],10000)}): clocks per iteration between the stamps of thread 0")
+        for k in (1, 11, 12, 2, 10, 3, 4, 5, 13, 14, 6, 15, 9, 7):
+            print(f"   {names[k]:34s} {w[b, k] / max(v[b, 2], 1):8.0f}")
