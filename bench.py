@@ -553,6 +553,7 @@ def frame_pair_measurement(dev):
         # (the random subsample of the over-long wall, utils_helper.py:198-201) -- torch.manual_seed() itself costs ~50 us a
         # call here (it walks every backend's lazy-init queue and formats a stack trace), which is not the product's time
         a.generator = torch.Generator()
+        a.native_host = False          # (`run` below times the Python host; the native call is timed on its own)
 
         def run():
             a.generator.manual_seed(0)
@@ -584,6 +585,18 @@ def frame_pair_measurement(dev):
             pairs_native, flow_native = run_native()
             torch.cuda.synchronize(dev)
             runs_native.append(round((time.perf_counter() - t) * 1e3, 3))
+        # the reference's own two calls, track() + flow_estimation_torch(), as a user of the drop-in makes them: track() goes
+        # through the same native call (utils_match.match_pcds), the flow is a launch of its own
+        a.native_host = True
+        run()
+        runs_api = []
+        for _ in range(7):
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            pairs_api, flow_api = run()
+            torch.cuda.synchronize(dev)
+            runs_api.append(round((time.perf_counter() - t) * 1e3, 3))
+        a.native_host = False
         # (the host-side association of the Python host, for the record: same pairs, numbers to rounding)
         a.device_association = False
         pairs_host, flow_host = run()
@@ -591,7 +604,9 @@ def frame_pair_measurement(dev):
         entry = {"ms_per_frame_pair": sorted(runs_native)[len(runs_native) // 2], "ms_per_frame_pair_runs": runs_native,
                  "ms_per_frame_pair_python_host_runs": runs, "matched_cluster_pairs": int(len(pairs)),
                  "ms_per_frame_pair_python_host": sorted(runs)[len(runs) // 2],
-                 "association": "on the device (one read-back per frame pair); ms_per_frame_pair: one call into the library per frame pair (icpflow_track_frame), ms_per_frame_pair_python_host: utils_track.track + flow_estimation_torch",
+                 "ms_per_frame_pair_track_then_flow": sorted(runs_api)[len(runs_api) // 2], "ms_per_frame_pair_track_then_flow_runs": runs_api,
+                 "track_then_flow_identical_to_python_host": bool(torch.equal(pairs_api, pairs) and torch.equal(flow_api, flow)),
+                 "association": "on the device (one read-back per frame pair); ms_per_frame_pair: one call into the library per frame pair (icpflow_track_frame), ms_per_frame_pair_track_then_flow: the drop-in's track() (same native call) + flow_estimation_torch(), ms_per_frame_pair_python_host: the same two with the Python host (args.native_host = False)",
                  "native_call_identical_to_python_host": bool(torch.equal(pairs_native, pairs) and torch.equal(flow_native, flow)),
                  "device_vs_host_association_same_pairs": bool(torch.equal(pairs[:, :2], pairs_host[:, :2])),
                  "device_vs_host_association_max_flow_difference_m": float((flow - flow_host).abs().max()),

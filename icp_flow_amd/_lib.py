@@ -57,6 +57,7 @@ SIGNATURES = {
     "icpflow_register_stage": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
     "icpflow_associate_frame": (_i, [_p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _sz, _p, _p]),
     "icpflow_track_frame": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _p]),
+    "icpflow_selftest_randperm": (_i, [_p, ctypes.c_int64, _i, _p]),
     "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "icpflow_cluster_table_workspace_bytes": (_sz, [_i, _i]),
     "icpflow_cluster_table": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _sz, _p]),
@@ -126,9 +127,40 @@ class Registration(ctypes.Structure):
                 ("decode_shift", _f), ("thres_dist", _d), ("relative_rmse_thr", _d), ("max_iterations", _i), ("stop_mode", _i)]
 
 
+class Mt19937(ctypes.Structure):
+    """icpflow_mt19937_t: the state of torch's CPU generator (at::mt19937)."""
+    _fields_ = [("state", ctypes.c_uint32 * 624), ("index", ctypes.c_int32)]
+
+    @staticmethod
+    def from_torch(generator=None):
+        """The engine state of a torch CPU generator (default: torch's global one) out of get_state() -- the legacy layout
+        ATen keeps (CPUGeneratorImplStateLegacy: uint64 seed, int left, int seeded, uint64 next, uint64 state[624], ...)."""
+        raw = (generator if generator is not None else torch.default_generator).get_state().numpy()
+        if raw.size < 24 + 8 * 624:
+            raise RuntimeError("unexpected layout of torch.Generator.get_state()")
+        left = int(raw[8:12].view("<i4")[0])
+        nxt = int(raw[16:24].view("<u8")[0])
+        mt = Mt19937()
+        ctypes.memmove(mt.state, raw[24:24 + 8 * 624].view("<u8").astype("<u4").tobytes(), 4 * 624)
+        # at::mt19937 regenerates its block when --left reaches 0: left == 1 <=> every word of the block is consumed
+        mt.index = 624 if left == 1 else nxt
+        return mt
+
+    def to_torch(self, generator=None):
+        """Write the (advanced) state back into the torch generator it was taken from."""
+        import numpy as np
+        g = generator if generator is not None else torch.default_generator
+        raw = g.get_state().numpy().copy()
+        raw[24:24 + 8 * 624] = np.frombuffer(bytes(self.state), dtype="<u4").astype("<u8").view(np.uint8)
+        idx = int(self.index)
+        raw[8:12] = np.array([1 if idx >= 624 else 625 - idx], "<i4").view(np.uint8)
+        raw[16:24] = np.array([idx], "<u8").view(np.uint8)
+        g.set_state(torch.from_numpy(raw))
+
+
 class FrameParams(ctypes.Structure):
     """icpflow_frame_params_t: the flags of the reference's parser that icpflow_track_frame reads."""
-    _fields_ = [("struct_size", _sz), ("seed", ctypes.c_uint64), ("max_points", _i), ("min_cluster_size", _i),
+    _fields_ = [("struct_size", _sz), ("seed", ctypes.c_uint64), ("generator", _p), ("max_points", _i), ("min_cluster_size", _i),
                 ("translation_frame", _f), ("thres_box", _f), ("thres_iou", _f), ("rot_limit_deg", _f), ("thres_error", _f),
                 ("tight_padding", _i), ("superset_width", _i)]
 

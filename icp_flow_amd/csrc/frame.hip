@@ -42,6 +42,16 @@ struct Mt19937 {   // at::mt19937 (the engine of torch's CPU generator)
         for (int j = 1; j < 624; ++j) s[j] = 1812433253u * (s[j - 1] ^ (s[j - 1] >> 30)) + (uint32_t)j;
         idx = 624;
     }
+    explicit Mt19937(const icpflow_mt19937_t &st)
+    {
+        std::memcpy(s, st.state, sizeof(s));
+        idx = std::min(std::max(st.index, 0), 624);
+    }
+    void save(icpflow_mt19937_t *st) const
+    {
+        std::memcpy(st->state, s, sizeof(s));
+        st->index = idx;
+    }
     uint32_t next()
     {
         if (idx >= 624) {
@@ -284,8 +294,9 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     int64_t *seg2 = reinterpret_cast<int64_t *>(pin + pSeg2);
     int32_t *idx = reinterpret_cast<int32_t *>(pin + pIdx);
     int32_t *hBest = reinterpret_cast<int32_t *>(pin + pBest);
+    // the frame pair's stream of draws: the caller's generator (advanced only if this call serves the frame pair) or a seed
+    Mt19937 gen = par->generator != nullptr ? Mt19937(*par->generator) : Mt19937((uint32_t)par->seed);
     {
-        Mt19937 gen((uint32_t)par->seed);
         int drawn = 0;
         for (int k = 0; k < K1; ++k) {
             const int64_t cs = st.count[si1[k]], cd = dt.count[di1[k]];
@@ -345,6 +356,18 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
         for (size_t k = 0; k < leftS.size(); ++k)
             if (hBest[leftS[k]] < 0 && !mD[leftD[k]]) return 0;   // (*h_pairs still says "host path")
     }
+    if (par->generator != nullptr) gen.save(par->generator);
     *h_pairs = P;
+    return 0;
+}
+
+// torch.randperm(n, generator)[0:take] on a generator in the state `gen` (advanced): the restatement above, for the CPU tests
+extern "C" int icpflow_selftest_randperm(icpflow_mt19937_t *gen, int64_t n, int take, int32_t *h_out)
+{
+    if (!gen || !h_out || n <= 0 || take < 0 || take > n) return report_error(ICPFLOW_E_ARG, "icpflow_selftest_randperm: bad argument");
+    Mt19937 g(*gen);
+    std::vector<int32_t> tmp;
+    randperm_head(g, n, take, h_out, tmp);
+    g.save(gen);
     return 0;
 }

@@ -414,10 +414,12 @@ def register_frame_pair_native(args, fp, device, gap=None):
     return track_frame_native(a, ps, pd, ls, ld, pose, flow_src)
 
 
-def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0):
+def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0, generator=None):
     """icpflow_track_frame on device tensors: `track(a, ps, pd, ls, ld)` (+ `flow_estimation_torch` of `flow_points` under
     `pose` when given) with `a.translation_frame` set; the random subsamples of over-long clusters are torch.randperm's on a
-    generator seeded with `seed`.  -> dict(pairs, transformations[, flow]) or None (see register_frame_pair_native)."""
+    generator seeded with `seed` -- or on `generator` (a torch CPU generator, or "global" for torch's own: its state goes in,
+    and comes back advanced when the call has served the frame pair).
+    -> dict(pairs, transformations[, flow]) or None (see register_frame_pair_native)."""
     from . import _lib, utils_match
     import ctypes
     device = ps.device
@@ -440,7 +442,11 @@ def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0):
         flow = torch.empty((len(ps3), 3), dtype=torch.float32, device=device)
     reg, keep_alive = utils_match._registration(a, device)
     f32 = lambda v: float(np.float32(v))   # noqa: E731
-    par = _lib.FrameParams(ctypes.sizeof(_lib.FrameParams), int(seed), int(a.max_points), int(a.min_cluster_size),
+    mt = None
+    if generator is not None:
+        mt = _lib.Mt19937.from_torch(None if isinstance(generator, str) else generator)
+    par = _lib.FrameParams(ctypes.sizeof(_lib.FrameParams), int(seed), ctypes.addressof(mt) if mt is not None else None,
+                           int(a.max_points), int(a.min_cluster_size),
                            f32(a.translation_frame), f32(a.thres_box), f32(a.thres_iou), f32(a.thres_rot * 90.0), f32(a.thres_error),
                            1 if getattr(a, "tight_padding", True) else 0, int(getattr(a, "device_association_width", 1024)))
     key = (device.index, _lib.stream_handle(device))
@@ -468,6 +474,8 @@ def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0):
     if P < 0:
         raise RuntimeError("icpflow_hist_icp abandoned the batch: a wait between workgroups timed out -- a team sharing one "
                            "large pair (GPU shared with another process?); retry, or register with _lib.options(no_teams=True)")
+    if mt is not None:
+        mt.to_torch(None if isinstance(generator, str) else generator)
     out = dict(pairs=rows[:P], transformations=T[:P], translation_frame=a.translation_frame, association="device")
     if flow is not None:
         out["flow"] = flow

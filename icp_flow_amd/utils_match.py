@@ -579,5 +579,15 @@ def drive(gen):
 def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
     """utils_match.py:24-66: stage 1 registers clusters that keep their label across the two
     frames (static / slow objects), stage 2 every remaining source cluster against every remaining
-    destination cluster.  -> pairs [P,10] (labels, errors, inliers, ratios, ious), transforms [P,4,4]."""
+    destination cluster.  -> pairs [P,10] (labels, errors, inliers, ratios, ious), transforms [P,4,4].
+    Where it can, through ONE call into the library (icpflow_track_frame: the host half in C++ as well, frame_pairs.
+    track_frame_native; the random subsamples continue `args.generator` or torch's global generator exactly as torch.randperm
+    would) -- same bits as the generators below; `args.native_host = False` / `args.device_association = False` keep to those."""
+    if (getattr(args, "native_host", True) and getattr(args, "device_association", None) is not False
+            and isinstance(src_points, torch.Tensor) and src_points.is_cuda):
+        from . import frame_pairs
+        out = frame_pairs.track_frame_native(args, src_points, dst_points, src_labels, dst_labels,
+                                             generator=getattr(args, "generator", None) or "global")
+        if out is not None:
+            return out["pairs"], out["transformations"]
     return drive(match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels))

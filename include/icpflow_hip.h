@@ -469,9 +469,17 @@ int icpflow_associate_frame(const icpflow_tables_t *tables, const icpflow_stage_
  * ------------------------------------------------------------------------- */
 #define ICPFLOW_FRAME_HOST_PATH (-2)
 #define ICPFLOW_FRAME_ABANDONED (-1)
+/* The state of torch's CPU generator (at::mt19937): the 624 words and how many of them have been consumed (624 = the next
+ * draw regenerates the block; a generator fresh from manual_seed).  icp_flow_amd/_lib.py converts to and from
+ * torch.Generator.get_state(). */
+typedef struct icpflow_mt19937 {
+    uint32_t state[624];
+    int32_t index;
+} icpflow_mt19937_t;
 typedef struct icpflow_frame_params {
     size_t struct_size;       /* sizeof(icpflow_frame_params_t) */
-    uint64_t seed;
+    uint64_t seed;            /* the draws start from torch.Generator().manual_seed(seed) ... */
+    icpflow_mt19937_t *generator; /* ... or, when not NULL, from this state, which is advanced (only when the call serves the frame pair) */
     int max_points;           /* --max_points */
     int min_cluster_size;     /* --min_cluster_size */
     float translation_frame;  /* --translation_frame (or 2 * speed * gap, main.py:200) */
@@ -488,6 +496,8 @@ int icpflow_track_frame(const float *d_points_src, const float *d_labels_src, in
                         const float *d_flow_points, const float *d_pose, float *d_flow, void *d_scratch,
                         size_t scratch_bytes, size_t *scratch_needed, icpflow_stream_t stream,
                         const icpflow_options_t *opt);
+/* torch.randperm(n, generator)[0:take] as this library restates it (host only; the CPU tests pin it against torch) */
+int icpflow_selftest_randperm(icpflow_mt19937_t *gen, int64_t n, int take, int32_t *h_out);
 
 int icpflow_cluster_stats(const float *d_points, const int64_t *d_order, const int64_t *d_start,
                           const int64_t *d_count, const float *d_labels, int L, float *d_mean,

@@ -104,7 +104,8 @@ def test_options_are_per_call_and_per_thread():
     assert ctypes.sizeof(_lib.Options) == 96   # size_t, int, int, unsigned, pad, five pointers, two ints, two pointers on LP64
     # the structs of icpflow_register_stage / icpflow_associate_frame (include/icpflow_hip.h), LP64
     assert (ctypes.sizeof(_lib.Tables), ctypes.sizeof(_lib.Stage), ctypes.sizeof(_lib.Registration)) == (64, 56, 64)
-    assert ctypes.sizeof(_lib.FrameParams) == 56        # icpflow_frame_params_t
+    assert ctypes.sizeof(_lib.FrameParams) == 64        # icpflow_frame_params_t
+    assert ctypes.sizeof(_lib.Mt19937) == 2500          # icpflow_mt19937_t
 
 
 def test_product_refuses_cpu_tensors_no_fallback():

@@ -1329,6 +1329,7 @@ def test_device_association_equals_the_host_path(seed, n_objects, n_max, max_poi
         for device_path in (True, False):
             a = frame_pairs.default_args(max_points=max_points)
             a.device_association = device_path
+            a.native_host = False                     # (the Python host's two paths; the native call has its own test)
             a.generator = torch.Generator()
             a.generator.manual_seed(0)
             pairs, T = utils_match.match_pcds(a, ps, pd, ls, ld)
@@ -1416,3 +1417,43 @@ def test_native_frame_pair_equals_the_python_host(case):
         assert served < len(fps)            # at least one frame pair needed the host path
     else:
         assert served >= len(fps) - 1 and served >= 1
+
+
+def test_match_pcds_native_call_continues_torchs_generators():
+    """utils_match.match_pcds goes through icpflow_track_frame with the state of the generator the Python host would draw from
+    -- `args.generator`, else torch's global one -- and hands the advanced state back: same pairs and transforms as the Python
+    host bit for bit, and the generator ends in the same state (over-long clusters, so that there are draws; two calls in a
+    row, so that the second starts mid-stream)."""
+    from icp_flow_amd import frame_pairs
+    fps = []
+    for k, (nobj, nmax) in enumerate(((9, 400), (14, 900))):
+        d = synthetic.make_frame_pair(seed=60 + k, n_objects=nobj, n_max=nmax, n_background=1000)
+        fps.append([G(d["points_src"]), G(d["points_dst"]), G(d["labels_src"]).float(), G(d["labels_dst"]).float()])
+    a = frame_pairs.default_args(max_points=384)
+    a.device_association = True
+
+    def both_calls(native, generator):
+        a.native_host = native
+        a.generator = generator
+        out = [utils_match.match_pcds(a, *fp) for fp in fps]
+        torch.cuda.synchronize()
+        return out
+
+    saved = torch.get_rng_state()
+    try:
+        results = {}
+        for native in (True, False):
+            torch.manual_seed(5)
+            results[native, "global"] = (both_calls(native, None), torch.get_rng_state().clone())
+            g = torch.Generator()
+            g.manual_seed(9)
+            results[native, "own"] = (both_calls(native, g), g.get_state().clone())
+    finally:
+        torch.set_rng_state(saved)
+    for which in ("global", "own"):
+        (out_n, state_n), (out_p, state_p) = results[True, which], results[False, which]
+        assert torch.equal(state_n, state_p), which
+        for (pn, Tn), (pp, Tp) in zip(out_n, out_p):
+            assert len(pp) >= 3 and torch.equal(pn, pp) and torch.equal(Tn, Tp), which
+    # (and the draws mattered: the two generators give different subsamples, hence different numbers somewhere)
+    assert not all(torch.equal(x[1], y[1]) for x, y in zip(results[True, "global"][0], results[True, "own"][0]))
