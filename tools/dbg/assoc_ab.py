@@ -14,7 +14,7 @@ eye = torch.eye(4, device=dev)
 for mp in (2048, 10000):
     res = {}
     for mode in (False, True, False, True):
-        a = frame_pairs.default_args(max_points=mp)
+        a = frame_pairs.default_args(max_points=mp); a.native_host = False   # (device against host association of the PYTHON host)
         a.device_association = mode
         a.generator = torch.Generator()
         def run():

@@ -10,7 +10,7 @@ g = load_golden("g8_demo"); lab = load_golden("g8_demo_labels")
 dev = torch.device("cuda:0")
 G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 ps, pd = G(g["point_src"]), G(g["point_dst"]); ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
-a = frame_pairs.default_args(max_points=int(os.environ.get("MP", "10000"))); a.device_association = os.environ.get("DEVICE_ASSOC", "0") == "1"   # (the phases below are those of the host path)
+a = frame_pairs.default_args(max_points=int(os.environ.get("MP", "10000"))); a.native_host = False; a.device_association = os.environ.get("DEVICE_ASSOC", "0") == "1"   # (the phases below are those of the host path)
 eye = torch.eye(4, device=dev)
 def run():
     torch.manual_seed(0)

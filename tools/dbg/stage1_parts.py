@@ -9,7 +9,7 @@ g = load_golden("g8_demo"); lab = load_golden("g8_demo_labels")
 dev = torch.device("cuda:0")
 G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 ps, pd = G(g["point_src"]), G(g["point_dst"]); ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
-a = frame_pairs.default_args(max_points=int(os.environ.get("MP", "10000")))
+a = frame_pairs.default_args(max_points=int(os.environ.get("MP", "10000"))); a.native_host = False   # (the hook below sits in the Python host)
 kept = []
 orig = utils_match._register_stage
 def stash(args, st, dt, si, di, *rest):
