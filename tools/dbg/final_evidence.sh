@@ -17,5 +17,5 @@ unset ICPFLOW_HIP_LIB
 C=icp_flow_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -DICPFLOW_TAIL_CLOCK -DICPFLOW_TAIL_SPLIT -Iinclude -I$C -shared -o tools/dbg/libicpflow_dbg.so $C/api.hip $C/hist.hip $C/nn.hip $C/icp.hip $C/icp_fp32.hip $C/pose.hip $C/sort.hip $C/cluster.hip $C/hdbscan.hip $C/table.hip $C/assoc.hip $C/frame.hip $C/hdbscan_tree.cpp > /dev/null 2>&1
 SPLIT=1 ICPFLOW_HIP_LIB=tools/dbg/libicpflow_dbg.so python tools/dbg/tail_clock.py > $O/tail_split.txt 2>&1
-tail -2 $O/stress_default.txt $O/stress_device.txt $O/tail_clock.txt $O/stage1_tail.txt
+for f in stress_default stress_device stress_host tail_clock stage1_tail; do tail -n 2 $O/$f.txt; done
 for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz; do tail -1 $O/$f.txt; done
