@@ -49,8 +49,11 @@ DEFAULT_ARGS = dict(max_points=10000, min_cluster_size=20, translation_frame=2.0
                     thres_rot=0.1, thres_error=0.2, thres_iou=0.2, chunk_size=50, speed=None,
                     cluster=None, epsilon=0.25, num_clusters=200, range_x=None, range_y=None,
                     # not a flag of the reference: candidate batches padded to the longest cluster of the stage instead of
-                    # max_points (utils_match._gather_pair_batches; False = the reference's width, same registrations)
-                    tight_padding=True)
+                    # max_points (utils_match._stage_rows; False = the reference's width, same registrations)
+                    tight_padding=True,
+                    # not a flag of the reference: one call into the library per frame pair (icpflow_track_frame, the host half of
+                    # match_pcds in C++, a host thread per frame pair in flight); False = the Python host (generators), same bits
+                    native_host=True)
 
 
 def default_args(**over):
@@ -646,7 +649,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("directory")
     ap.add_argument("--repeat", type=int, default=1)
-    ap.add_argument("--in-flight", type=int, default=1, help="frame pairs registered at once (streams, one host thread)")
+    ap.add_argument("--in-flight", type=int, default=1, help="frame pairs registered at once (a stream and a host thread each)")
     def flag(text):      # (type=bool would read every non-empty string, "False" included, as True)
         if text.lower() in ("1", "true", "yes", "on"):
             return True
