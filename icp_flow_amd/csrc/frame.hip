@@ -354,7 +354,10 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
         for (int a = 0; a < S; ++a)
             if (hBest[a] >= 0) mD[di1[hBest[a]]] = 1;
         for (size_t k = 0; k < leftS.size(); ++k)
-            if (hBest[leftS[k]] < 0 && !mD[leftD[k]]) return 0;   // (*h_pairs still says "host path")
+            if (hBest[leftS[k]] < 0 && !mD[leftD[k]]) {
+                *h_pairs = ICPFLOW_FRAME_HOST_ASSOCIATION;
+                return 0;
+            }
     }
     if (par->generator != nullptr) gen.save(par->generator);
     *h_pairs = P;

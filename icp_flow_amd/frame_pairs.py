@@ -318,8 +318,9 @@ def register_frame_pair(args, fp, device, gap=None):
     from . import utils_match
     if _native_host(args) and torch.device(device).type == "cuda":
         out = register_frame_pair_native(args, fp, device, gap)
-        if out is not None:
+        if _served(out):
             return out
+        return _python_host(args, fp, device, gap, out)
     return utils_match.drive(register_frame_pair_steps(args, fp, device, gap))
 
 
@@ -392,6 +393,22 @@ def register_in_flight_scheduler(args, fps, device, in_flight=4):
 
 
 _frame_scratch = {}
+# what track_frame_native returns when a stage-2 candidate that cannot be in the superset (an over-long cluster) is needed: the
+# device-side association of the Python host would give up on this frame pair as well -- go to the host-side association
+NEEDS_HOST_ASSOCIATION = "needs the host-side association"
+
+
+def _served(out):
+    return out is not None and out is not NEEDS_HOST_ASSOCIATION
+
+
+def _python_host(args, fp, device, gap, out):
+    """The generators, for a frame pair the native call did not serve (`out`: what it returned)."""
+    from . import utils_match
+    if out is NEEDS_HOST_ASSOCIATION:
+        args = SimpleNamespace(**vars(args))
+        args.device_association = False
+    return utils_match.drive(register_frame_pair_steps(args, fp, device, gap))
 
 
 def register_frame_pair_native(args, fp, device, gap=None):
@@ -422,7 +439,7 @@ def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0, g
     `pose` when given) with `a.translation_frame` set; the random subsamples of over-long clusters are torch.randperm's on a
     generator seeded with `seed` -- or on `generator` (a torch CPU generator, or "global" for torch's own: its state goes in,
     and comes back advanced when the call has served the frame pair).
-    -> dict(pairs, transformations[, flow]) or None (see register_frame_pair_native)."""
+    -> dict(pairs, transformations[, flow]), None (see register_frame_pair_native) or NEEDS_HOST_ASSOCIATION."""
     from . import _lib, utils_match
     import ctypes
     device = ps.device
@@ -472,6 +489,8 @@ def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0, g
         msg = _lib._L.icpflow_last_error()
         raise RuntimeError(f"icpflow_track_frame failed (code {rc}): {msg.decode() if msg else ''}")
     P = int(pairs.value)
+    if P == -3:
+        return NEEDS_HOST_ASSOCIATION
     if P == -2:
         return None
     if P < 0:
@@ -542,8 +561,8 @@ def register_in_flight_native(args, fps, device, in_flight=4):
                     except StopIteration:
                         return
                 res = register_frame_pair_native(args, fp, device)
-                if res is None:
-                    res = utils_match.drive(register_frame_pair_steps(args, fp, device))
+                if not _served(res):
+                    res = _python_host(args, fp, device, None, res)
                 stream.synchronize()
                 out.put((idx, fp, res))
         except BaseException as e:   # noqa: BLE001  (handed to the consumer)

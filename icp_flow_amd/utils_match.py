@@ -588,6 +588,10 @@ def match_pcds(args, src_points, dst_points, src_labels, dst_labels):
         from . import frame_pairs
         out = frame_pairs.track_frame_native(args, src_points, dst_points, src_labels, dst_labels,
                                              generator=getattr(args, "generator", None) or "global")
-        if out is not None:
+        if frame_pairs._served(out):
             return out["pairs"], out["transformations"]
+        if out is frame_pairs.NEEDS_HOST_ASSOCIATION:
+            from types import SimpleNamespace
+            args = SimpleNamespace(**vars(args))
+            args.device_association = False     # (the Python host's device path would give up on this frame pair as well)
     return drive(match_pcds_steps(args, src_points, dst_points, src_labels, dst_labels))

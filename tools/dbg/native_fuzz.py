@@ -1,0 +1,29 @@
+"""Developer check: random labelled synthetic frame pairs (ragged clusters, relabelled objects, over-long clusters that get
+subsampled, small max_points that force the fall-back) through icpflow_track_frame and through the Python host with the
+device-side association: bit for bit, and the call gives up exactly where the Python host's device path gives up."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from icp_flow_amd import frame_pairs, synthetic
+dev = torch.device("cuda", 0)
+bad = served = 0
+first, trials = int(os.environ.get("FIRST", "100")), int(os.environ.get("TRIALS", "60"))
+for seed in range(first, first + trials):
+    rng = np.random.default_rng(seed)
+    nobj = int(rng.integers(2, 16)); nmax = int(rng.choice([120, 300, 700, 1500, 3000])); mp = int(rng.choice([128, 256, 512, 2048, 10000]))
+    d = synthetic.make_frame_pair(seed=seed, n_objects=nobj, n_max=nmax, n_background=int(rng.integers(100, 4000)))
+    fp = frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"], d["gt_flow"])
+    a = frame_pairs.default_args(max_points=mp, tight_padding=bool(rng.integers(0, 2)))
+    a.native_host, a.device_association = False, True
+    want = frame_pairs.register_frame_pair(a, fp, dev)
+    got = frame_pairs.register_frame_pair_native(a, fp, dev)
+    torch.cuda.synchronize()
+    ok = (not frame_pairs._served(got)) == (want["association"] == "host")
+    if frame_pairs._served(got):
+        served += 1
+        ok = ok and all(torch.equal(got[k], want[k]) for k in ("pairs", "transformations", "flow"))
+    bad += not ok
+    print(f"seed {seed}: objects {nobj} n_max {nmax} max_points {mp} tight {a.tight_padding}: matched {len(want['pairs'])}, "
+          f"native {'served' if frame_pairs._served(got) else 'gave up'}, python host's association: {want['association']}{'' if ok else '   <-- look'}")
+print(f"frame pairs {trials}, served by the native call {served}, different: {bad}")
