@@ -135,24 +135,29 @@ inline bool pair_passes(const Table &st, const Table &dt, int s, int d, float tr
     return true;
 }
 
-struct Host {   // per host thread: pinned staging (read in place by the kernels / target of the read-backs) and scratch
-    void *pinned = nullptr;
-    size_t pinnedBytes = 0;
+struct Pinned {   // a pinned host buffer that grows (read in place by the kernels / target of the read-backs)
+    void *ptr = nullptr;
+    size_t bytes = 0;
     int device = -1;
-    std::vector<int32_t> perm;
-    char *need(size_t bytes)
+    char *need(size_t want)
     {
         int dev = -1;
         (void)hipGetDevice(&dev);
-        if (pinned == nullptr || pinnedBytes < bytes || device != dev) {
-            if (pinned != nullptr) (void)hipHostFree(pinned);
-            pinned = nullptr;
-            pinnedBytes = std::max(bytes, (size_t)1 << 20);
-            if (hipHostMalloc(&pinned, pinnedBytes, hipHostMallocDefault) != hipSuccess) { pinned = nullptr; pinnedBytes = 0; }
+        if (ptr == nullptr || bytes < want || device != dev) {
+            if (ptr != nullptr) (void)hipHostFree(ptr);
+            ptr = nullptr;
+            bytes = std::max(want, (size_t)1 << 20);
+            if (hipHostMalloc(&ptr, bytes, hipHostMallocDefault) != hipSuccess) { ptr = nullptr; bytes = 0; }
             device = dev;
         }
-        return static_cast<char *>(pinned);
+        return static_cast<char *>(ptr);
     }
+};
+
+struct Host {   // per host thread
+    Pinned main, second;   // (second: the exact stage 2 of a frame pair whose superset fell short -- the first is still in use then)
+    std::vector<int32_t> perm;
+    char *need(size_t bytes) { return main.need(bytes); }
 };
 
 inline size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -342,22 +347,101 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     if (hipMemcpyAsync(hBest, dBest, 4 * (2 * (size_t)S + 2), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
         return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the matches failed");
-    const int P = hBest[2 * S];
-    if (P < 0) {
+    const int P0 = hBest[2 * S];
+    if (P0 < 0) {
         *h_pairs = ICPFLOW_FRAME_ABANDONED;   // a team's wait timed out: the transforms are NaN (include/icpflow_hip.h, a-5)
         return 0;
     }
-    // a pair that had to stay out of the superset and whose clusters both found no partner in stage 1 is a candidate of the
-    // reference's stage 2: the host path serves it (with the generator as it was: nothing of it was consumed here)
+    // A pair that had to stay out of the superset and whose clusters both found no partner in stage 1 is a candidate of the
+    // reference's stage 2: then stage 2 is registered again the reference's way -- its exact candidates (every unmatched source
+    // against every unmatched destination through the sanity grid, utils_match.py:42-53), over-long clusters subsampled with the
+    // next draws of the same generator -- on top of stage 1's results, which stand.  Same bits as the host-side association.
+    bool exact = false;
     if (!leftS.empty()) {
         std::vector<uint8_t> mD(D, 0);
         for (int a = 0; a < S; ++a)
             if (hBest[a] >= 0) mD[di1[hBest[a]]] = 1;
-        for (size_t k = 0; k < leftS.size(); ++k)
-            if (hBest[leftS[k]] < 0 && !mD[leftD[k]]) {
-                *h_pairs = ICPFLOW_FRAME_HOST_ASSOCIATION;
-                return 0;
+        for (size_t k = 0; k < leftS.size() && !exact; ++k) exact = hBest[leftS[k]] < 0 && !mD[leftD[k]];
+    }
+    int P = P0;
+    if (exact) {
+        std::vector<uint8_t> mS(S, 0), mD(D, 0);
+        size_t matched = 0;
+        for (int a = 0; a < S; ++a)
+            if (hBest[a] >= 0) { mS[a] = 1; mD[di1[hBest[a]]] = 1; ++matched; }
+        std::vector<int32_t> si3, di3;
+        int64_t longest3 = 0;
+        int nPerm3 = 0;
+        if (matched < unq.size()) {                                                                    // :42
+            for (int a = 0; a < S; ++a) {
+                if (mS[a] || !sOk[a]) continue;
+                for (int b = 0; b < D; ++b) {
+                    if (mD[b] || !dOk[b] || !pair_passes(st, dt, a, b, tf, tb)) continue;
+                    si3.push_back(a);
+                    di3.push_back(b);
+                    longest3 = std::max(longest3, std::max(st.count[a], dt.count[b]));
+                    nPerm3 += (st.count[a] > maxPoints) + (dt.count[b] > maxPoints);
+                }
             }
+        }
+        const int K3 = (int)si3.size();
+        const int N3 = par->tight_padding ? std::min(maxPoints, std::max(64, round64(longest3))) : maxPoints;
+        const size_t ws3 = K3 ? icpflow_workspace_bytes(K3, N3, reg->len_x, reg->len_y, reg->len_z) : 0;
+        const size_t oClouds3 = off; off += up(sizeof(float) * 8 * (size_t)K3 * N3);
+        const size_t oRes3 = off; off += up(sizeof(float) * (30 * (size_t)K3 + 1));
+        const size_t oWs3 = off; off += up(ws3);
+        *scratch_needed = off;
+        if (scratch_bytes < off) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: scratch too small (see *scratch_needed)");
+        const size_t qPerm = 48 * (size_t)K3, qIdx = up(qPerm + 4 * (size_t)nPerm3 * maxPoints), qBest = up(qIdx + 8 * (size_t)K3);
+        char *pin3 = H.second.need(qBest + 4 * (2 * (size_t)S + 2));
+        if (pin3 == nullptr) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: no pinned host memory");
+        int64_t *seg3 = reinterpret_cast<int64_t *>(pin3);
+        int32_t *perm3 = reinterpret_cast<int32_t *>(pin3 + qPerm), *idx3 = reinterpret_cast<int32_t *>(pin3 + qIdx);
+        int32_t *hBest3 = reinterpret_cast<int32_t *>(pin3 + qBest);
+        int drawn = 0;
+        for (int k = 0; k < K3; ++k) {
+            const int64_t cs = st.count[si3[k]], cd = dt.count[di3[k]];
+            seg3[0 * K3 + k] = st.start[si3[k]]; seg3[1 * K3 + k] = std::min<int64_t>(cs, maxPoints); seg3[2 * K3 + k] = -1;
+            seg3[3 * K3 + k] = dt.start[di3[k]]; seg3[4 * K3 + k] = std::min<int64_t>(cd, maxPoints); seg3[5 * K3 + k] = -1;
+            if (cs > maxPoints) {
+                seg3[2 * K3 + k] = (int64_t)drawn * maxPoints;
+                randperm_head(gen, cs, maxPoints, perm3 + (size_t)drawn * maxPoints, H.perm);
+                ++drawn;
+            }
+            if (cd > maxPoints) {
+                seg3[5 * K3 + k] = (int64_t)drawn * maxPoints;
+                randperm_head(gen, cd, maxPoints, perm3 + (size_t)drawn * maxPoints, H.perm);
+                ++drawn;
+            }
+        }
+        if (K3) {
+            std::memcpy(idx3, si3.data(), 4 * (size_t)K3);
+            std::memcpy(idx3 + K3, di3.data(), 4 * (size_t)K3);
+        }
+        icpflow_stage_t stage3{seg3, nPerm3 ? perm3 : nullptr, idx3, idx3 + K3, reinterpret_cast<float *>(base + oClouds3),
+                               reinterpret_cast<float *>(base + oRes3), K3, N3};
+        if (K3) {
+            if (int r = icpflow_register_stage(&tables, &stage3, reg, base + oWs3, ws3, stream, opt)) return r;
+            if (int r = icpflow_assoc_assign(stage3.d_result, stage3.d_si, stage3.d_di, K3, nullptr, S, D, par->translation_frame,
+                                             par->thres_iou, par->rot_limit_deg, par->thres_error, dBest + S, 0, nullptr, nullptr,
+                                             nullptr, nullptr, stream))
+                return r;
+        }
+        if (int r = icpflow_assoc_collect(dBest, stage1.d_result, stage1.d_si, stage1.d_di, K1, K3 ? dBest + S : nullptr,
+                                          K3 ? stage3.d_result : nullptr, K3 ? stage3.d_si : nullptr, K3 ? stage3.d_di : nullptr, K3,
+                                          tables.d_table_src, tables.d_table_dst, tables.label_stride, S, cap, d_rows, d_T,
+                                          dBest + 2 * (size_t)S, stream))
+            return r;
+        if (d_flow != nullptr)
+            if (int r = icpflow_flow_rigid_rows(d_flow_points, d_labels_src, n_src, d_rows, 10, d_T, cap, d_pose, d_flow, stream)) return r;
+        if (hipMemcpyAsync(hBest3, dBest, 4 * (2 * (size_t)S + 2), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the matches failed");
+        P = hBest3[2 * S];
+        if (P < 0) {
+            *h_pairs = ICPFLOW_FRAME_ABANDONED;
+            return 0;
+        }
     }
     if (par->generator != nullptr) gen.save(par->generator);
     *h_pairs = P;

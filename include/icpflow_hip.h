@@ -463,12 +463,13 @@ int icpflow_associate_frame(const icpflow_tables_t *tables, const icpflow_stage_
  * Outputs: d_rows float32 [1024,10], d_T float32 [1024,16] (the first *h_pairs rows are the matches, the rest padding),
  * d_flow float32 [n_src,3] of d_flow_points (or NULL: no flow) under d_pose [4,4].  *h_pairs: the number of matched pairs;
  * ICPFLOW_FRAME_HOST_PATH when this call cannot serve the frame pair (no common label, more than 512 clusters: the caller runs
- * the finer-grained path, nothing was consumed), ICPFLOW_FRAME_HOST_ASSOCIATION when a stage-2 candidate with a cluster too long
- * for the superset turned out to be needed (the caller registers stage 2 the reference's way, reading stage 1 back); ICPFLOW_FRAME_ABANDONED when a team's wait timed out (transforms NaN).  d_scratch / scratch_bytes: device
+ * the finer-grained path, nothing was consumed).  When a stage-2 candidate with a cluster too long for the superset turns out
+ * to be needed, the call registers stage 2 once more the reference's way -- its exact candidates, read from stage 1's
+ * assignment, subsamples drawn next from the same generator -- on top of stage 1's results (one more wait); ICPFLOW_FRAME_ABANDONED when a team's wait timed out (transforms NaN).  d_scratch / scratch_bytes: device
  * scratch; on ICPFLOW_E_WORKSPACE *scratch_needed says how much this frame pair needs (call again with that much).
  * ------------------------------------------------------------------------- */
 #define ICPFLOW_FRAME_HOST_PATH (-2)
-#define ICPFLOW_FRAME_HOST_ASSOCIATION (-3) /* as HOST_PATH, and the device-side association cannot serve this frame pair either */
+#define ICPFLOW_FRAME_HOST_ASSOCIATION (-3) /* (reserved: as HOST_PATH, and the device-side association cannot serve the frame pair either) */
 #define ICPFLOW_FRAME_ABANDONED (-1)
 /* The state of torch's CPU generator (at::mt19937): the 624 words and how many of them have been consumed (624 = the next
  * draw regenerates the block; a generator fresh from manual_seed).  icp_flow_amd/_lib.py converts to and from
