@@ -5,7 +5,7 @@ python bench.py > $O/r04_bench.json 2> $O/r04_bench.err
 REPS=6 python tools/dbg/stream_stress.py > $O/stress_default.txt 2>&1
 REPS=6 NATIVE=0 DEVICE_ASSOC=1 python tools/dbg/stream_stress.py > $O/stress_device.txt 2>&1
 REPS=6 DEVICE_ASSOC=0 python tools/dbg/stream_stress.py > $O/stress_host.txt 2>&1
-for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz; do timeout 500 python tools/dbg/$f.py > $O/$f.txt 2>&1; echo "$f rc=$?"; done
+for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz; do timeout 500 python tools/dbg/$f.py > $O/$f.txt 2>&1; echo "$f rc=$?"; done
 bash tools/dbg/build_debug.sh ICPFLOW_TAIL_CLOCK tools/dbg/libicpflow_dbg.so > /dev/null 2>&1
 export ICPFLOW_HIP_LIB=tools/dbg/libicpflow_dbg.so
 python tools/dbg/tail_clock.py > $O/tail_clock.txt 2>&1

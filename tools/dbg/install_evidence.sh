@@ -22,5 +22,5 @@ grep -v amdgpu.ids $E/config2_units.txt > profiles/r04_config2_wave_units.txt
   echo "DEVICE_ASSOC=0 (the Python scheduler with the host-side association)."
   grep -v amdgpu.ids $E/stress_default.txt; grep -v amdgpu.ids $E/stress_device.txt; [ -f $E/stress_host.txt ] && grep -v amdgpu.ids $E/stress_host.txt; } > profiles/r04_stream_stress.txt
 { echo "Developer fuzzers on the final round-4 library (build $B), one MI355X; tools/dbg/*_fuzz.py"
-  for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz; do echo; echo "== tools/dbg/$f.py (last lines)"; grep -v amdgpu.ids $E/$f.txt | tail -4; done; } > profiles/r04_fuzz_final_build.txt
+  for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz; do [ -f $E/$f.txt ] || continue; echo; echo "== tools/dbg/$f.py (last lines)"; grep -v amdgpu.ids $E/$f.txt | tail -4; done; } > profiles/r04_fuzz_final_build.txt
 grep -o '"library_build": "[0-9a-f]*"' profiles/r04_bench.json profiles/r04_icp_kernel_counters.json profiles/r04_ragged_counters.json | sort | uniq -c
