@@ -52,21 +52,43 @@ struct Mt19937 {   // at::mt19937 (the engine of torch's CPU generator)
         std::memcpy(st->state, s, sizeof(s));
         st->index = idx;
     }
+    // the block of 624 words regenerated in place: three loops without index arithmetic (the first reads words the loop has not
+    // written yet, the second words written 227 steps earlier: both vectorise)
+    void twist()
+    {
+        constexpr uint32_t U = 0x80000000u, L = 0x7fffffffu, M = 0x9908b0dfu;
+        uint32_t *p = s;
+        for (int k = 0; k < 227; ++k) {
+            const uint32_t y = (p[k] & U) | (p[k + 1] & L);
+            p[k] = p[k + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & M);
+        }
+        for (int k = 227; k < 623; ++k) {
+            const uint32_t y = (p[k] & U) | (p[k + 1] & L);
+            p[k] = p[k - 227] ^ (y >> 1) ^ ((0u - (y & 1u)) & M);
+        }
+        const uint32_t y = (p[623] & U) | (p[0] & L);
+        p[623] = p[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & M);
+        idx = 0;
+    }
     uint32_t next()
     {
-        if (idx >= 624) {
-            for (int k = 0; k < 624; ++k) {
-                const uint32_t y = (s[k] & 0x80000000u) | (s[(k + 1) % 624] & 0x7fffffffu);
-                s[k] = s[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            }
-            idx = 0;
-        }
+        if (idx >= 624) twist();
         uint32_t y = s[idx++];
         y ^= y >> 11;
         y ^= (y << 7) & 0x9d2c5680u;
         y ^= (y << 15) & 0xefc60000u;
         y ^= y >> 18;
         return y;
+    }
+    // n draws whose values nobody reads: only the state moves
+    void skip(int64_t n)
+    {
+        while (n > 0) {
+            if (idx >= 624) twist();
+            const int64_t step = std::min<int64_t>(n, 624 - idx);
+            idx += (int)step;
+            n -= step;
+        }
     }
 };
 
@@ -82,7 +104,7 @@ void randperm_head(Mt19937 &g, int64_t n, int take, int32_t *out, std::vector<in
         const int64_t z = (int64_t)(g.next() % (uint64_t)(n - i));
         std::swap(tmp[(size_t)i], tmp[(size_t)(i + z)]);
     }
-    for (int64_t i = steps; i < n - 1; ++i) (void)g.next();
+    g.skip(n - 1 - steps);
     std::memcpy(out, tmp.data(), sizeof(int32_t) * (size_t)take);
 }
 
@@ -126,7 +148,11 @@ inline bool pair_passes(const Table &st, const Table &dt, int s, int d, float tr
     const float dx = dt.mean[3 * d] - st.mean[3 * s], dy = dt.mean[3 * d + 1] - st.mean[3 * s + 1];
     const float xx = dx * dx, yy = dy * dy;
     const float sum = xx + yy;
-    if (std::sqrt(sum) > translationFrame) return false;
+    // sqrt(sum) > translation_frame, decided without the root away from the threshold (the root is correctly rounded and
+    // monotone: it can only disagree with the comparison of the squares within a few ulps of equality)
+    const float t2 = translationFrame * translationFrame;
+    if (sum > t2 * 1.000001f) return false;
+    if (!(sum < t2 * 0.999999f) && std::sqrt(sum) > translationFrame) return false;
     for (int k = 0; k < 3; ++k) {
         const float es = st.extent[3 * s + k], ed = dt.extent[3 * d + k];
         const float rhs = thresBox * np_max(es, ed);
