@@ -542,6 +542,10 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     // small to give every SIMD two waves (a frame's candidate pairs) deal the sorted Y rows of a pair to several
     // workgroups of 1024 rows, `span` Y rows each (64 x 1024: -5 % per registration; on a batch that fills the GPU the extra window
     // searches and counter flushes cost 13 %).
+#ifndef ICPFLOW_VOTE_WIDE_N
+#define ICPFLOW_VOTE_WIDE_N 1023
+#endif
+    constexpr int kVoteWideN = ICPFLOW_VOTE_WIDE_N;   // widths above it take the four-waves-per-64-rows variant on small batches
     const int cus = device_cus();
     const long long wgs256 = (long long)((N + kVoteBlock - 1) / kVoteBlock) * ((N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile)) * B;
     int block = wgs256 >= 4LL * cus ? 512 : kVoteBlock;
@@ -559,7 +563,11 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     // times the CUs per pair.  Demo frame, stage 1 (93 pairs, width 10000; rows per workgroup x waves per 64 rows): 512 x 1
     // 186 us, 256 x 1 180, 128 x 1 186, 256 x 2 135, 128 x 2 121, 64 x 2 134, 128 x 4 105, 64 x 4 103; the pair's valid rows
     // dealt to as few 512-row workgroups as hold them: 188 (the padded width spreads a pair over more CUs: kept).
-    if (useLds && N > 4096 && B <= 2 * cus) {
+    // Round 4: from 1024 rows on instead of from 4097 (tools/dbg/define_sweep.sh, ICPFLOW_VOTE_WIDE_N = 4096 / 2047 / 1023 / 511 / 255):
+    // the demo frame pair through icpflow_track_frame 1.68 / 1.60 / 1.56 / 1.55 / 1.57 ms at max_points 2048 (stage 1 is 97 pairs
+    // 2048 wide: its vote 129 -> 60 us) and 1.95 / 1.90 / 1.88 / 1.86 / 1.88 at 10000 (stage 2's superset, 1024 wide); config 2
+    // (256 x 1024) 0.712 / 0.709 / 0.700 / 0.700 / 0.703 ms per step; batches above 2 x #CUs pairs are not concerned.
+    if (useLds && N > kVoteWideN && B <= 2 * cus) {
         dim3 grid(((N + 127) / 128) * tsplit, B);
         hipLaunchKernelGGL((hist_vote_sorted_kernel<512, 4>), grid, dim3(512), lds_hist, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,

@@ -19,5 +19,7 @@ for DEFS in "$@"; do
   i=$((i+1))
   echo "== [$DEFS]"
   ICPFLOW_HIP_LIB=/tmp/libicpflow_sweep_$i.so python tools/dbg/team_ab.py 2>&1 | tail -1
-  [ -z "${SWEEP_NO_SHAPES:-}" ] && ICPFLOW_HIP_LIB=/tmp/libicpflow_sweep_$i.so python tools/dbg/lib_ab.py 2>&1 | tail -1
+  ICPFLOW_HIP_LIB=/tmp/libicpflow_sweep_$i.so python tools/dbg/frame_native_ab.py 2>&1 | tail -1
+  ICPFLOW_HIP_LIB=/tmp/libicpflow_sweep_$i.so python tools/dbg/stream_native_ab.py 2>&1 | tail -1
+  [ -z "${SWEEP_NO_SHAPES:-}" ] && ICPFLOW_HIP_LIB=/tmp/libicpflow_sweep_$i.so python tools/dbg/lib_ab.py 2>&1 | grep "step" | tail -1
 done
