@@ -545,6 +545,10 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
 #ifndef ICPFLOW_VOTE_WIDE_N
 #define ICPFLOW_VOTE_WIDE_N 1023
 #endif
+#ifndef ICPFLOW_VOTE_WIDE_B
+#define ICPFLOW_VOTE_WIDE_B 2
+#endif
+    constexpr int kVoteWideB = ICPFLOW_VOTE_WIDE_B;   // ... on batches of at most that many pairs per CU
     constexpr int kVoteWideN = ICPFLOW_VOTE_WIDE_N;   // widths above it take the four-waves-per-64-rows variant on small batches
     const int cus = device_cus();
     const long long wgs256 = (long long)((N + kVoteBlock - 1) / kVoteBlock) * ((N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile)) * B;
@@ -567,7 +571,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     // the demo frame pair through icpflow_track_frame 1.68 / 1.60 / 1.56 / 1.55 / 1.57 ms at max_points 2048 (stage 1 is 97 pairs
     // 2048 wide: its vote 129 -> 60 us) and 1.95 / 1.90 / 1.88 / 1.86 / 1.88 at 10000 (stage 2's superset, 1024 wide); config 2
     // (256 x 1024) 0.712 / 0.709 / 0.700 / 0.700 / 0.703 ms per step; batches above 2 x #CUs pairs are not concerned.
-    if (useLds && N > kVoteWideN && B <= 2 * cus) {
+    if (useLds && N > kVoteWideN && B <= kVoteWideB * cus) {
         dim3 grid(((N + 127) / 128) * tsplit, B);
         hipLaunchKernelGGL((hist_vote_sorted_kernel<512, 4>), grid, dim3(512), lds_hist, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
