@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"])
 out = []
 for mp in (2048, 10000):
-    a = frame_pairs.default_args(max_points=mp)
+    a = frame_pairs.default_args(max_points=mp); a.device_association_width = int(os.environ.get("WIDTH", "1024"))
     for k in (4, 8):
         for _ in frame_pairs.register_in_flight(a, [fp] * (2 * k), dev, k): pass
         ts = []
