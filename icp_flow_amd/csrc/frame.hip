@@ -186,6 +186,20 @@ struct Host {   // per host thread
     char *need(size_t bytes) { return main.need(bytes); }
 };
 
+// Wait for the stream by POLLING it (then, should that last milliseconds, by blocking in the runtime): a frame pair has two
+// waits of a fraction of a millisecond, and waking a blocked host thread costs more than that when several threads keep frame
+// pairs in flight (tools/dbg/define_sweep.sh, blocking -> polling: the demo frame pair 1.60 -> 1.52 / 1.91 -> 1.85 ms on its own,
+// 0.86 -> 0.72 / 1.01 -> 0.91 ms per frame pair with four in flight).
+inline hipError_t wait_stream(hipStream_t s)
+{
+    for (int spin = 0; spin < 200000; ++spin) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        __builtin_ia32_pause();
+    }
+    return hipStreamSynchronize(s);
+}
+
 inline size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int round64(int64_t x) { return (int)((x + 63) / 64 * 64); }
 
@@ -231,7 +245,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     const size_t tableBytes = sizeof(double) * 2 * kTableDoubles;
     char *pin = H.need(tableBytes);
     if (pin == nullptr) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: no pinned host memory");
-    if (hipMemcpyAsync(pin, tabS, tableBytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    if (hipMemcpyAsync(pin, tabS, tableBytes, hipMemcpyDeviceToHost, s) != hipSuccess || wait_stream(s) != hipSuccess)
         return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the cluster tables failed");
     Table st, dt;
     st.set(reinterpret_cast<const double *>(pin));
@@ -371,7 +385,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
                                         d_flow, base + oWs, std::max(ws1, ws2), stream, opt))
         return r;
     if (hipMemcpyAsync(hBest, dBest, 4 * (2 * (size_t)S + 2), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
+        wait_stream(s) != hipSuccess)
         return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the matches failed");
     const int P0 = hBest[2 * S];
     if (P0 < 0) {
@@ -461,7 +475,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
         if (d_flow != nullptr)
             if (int r = icpflow_flow_rigid_rows(d_flow_points, d_labels_src, n_src, d_rows, 10, d_T, cap, d_pose, d_flow, stream)) return r;
         if (hipMemcpyAsync(hBest3, dBest, 4 * (2 * (size_t)S + 2), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess)
+            wait_stream(s) != hipSuccess)
             return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the matches failed");
         P = hBest3[2 * S];
         if (P < 0) {
