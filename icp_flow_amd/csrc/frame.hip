@@ -277,8 +277,23 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
         si1.push_back(a);
         di1.push_back(b);
     }
+    std::vector<uint8_t> sOk(S), dOk(D);   // (the per-cluster half of sanity_check, utils_check.py:31-32)
+    for (int r = 0; r < S; ++r) sOk[r] = st.count[r] >= minSize && st.label[r] >= 0.f;
+    for (int r = 0; r < D; ++r) dOk[r] = dt.count[r] >= minSize && dt.label[r] >= 0.f;
+    // No cluster keeps its label and passes: the reference goes on with stage 2 alone, every source against every destination
+    // through the sanity check (utils_match.py:42-53 with nothing matched) -- registered here as the only stage, in its order.
+    const bool stage2Only = si1.empty();
+    if (stage2Only)
+        for (int a = 0; a < S; ++a) {
+            if (!sOk[a]) continue;
+            for (int b = 0; b < D; ++b)
+                if (dOk[b] && pair_passes(st, dt, a, b, tf, tb)) {
+                    si1.push_back(a);
+                    di1.push_back(b);
+                }
+        }
     const int K1 = (int)si1.size();
-    if (K1 == 0) return 0;   // (stage 2 alone: the host path)
+    if (K1 == 0) return 0;   // (nothing to register at all: left to the caller)
 
     // ---- stage 1's segment rows and subsamples (utils_match._stage_rows), in pinned memory the kernels read in place
     int64_t longest = 0;
@@ -291,12 +306,9 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
 
     // ---- stage 2's superset (utils_match._match_pcds_device): every pair of the sanity grid, less the over-long clusters
     const int capPts = std::min(maxPoints, par->superset_width > 0 ? par->superset_width : 1024);
-    std::vector<uint8_t> sOk(S), dOk(D);
-    for (int r = 0; r < S; ++r) sOk[r] = st.count[r] >= minSize && st.label[r] >= 0.f;
-    for (int r = 0; r < D; ++r) dOk[r] = dt.count[r] >= minSize && dt.label[r] >= 0.f;
     std::vector<int32_t> si2, di2, leftS, leftD;
     int64_t longest2 = 0;
-    for (int a = 0; a < S; ++a) {
+    for (int a = 0; a < S && !stage2Only; ++a) {
         if (!sOk[a]) continue;
         for (int b = 0; b < D; ++b) {
             if (!dOk[b] || !pair_passes(st, dt, a, b, tf, tb)) continue;

@@ -417,8 +417,7 @@ def register_frame_pair_native(args, fp, device, gap=None):
     blocking call into the library, which releases the interpreter lock.  Bit for bit the result of `register_frame_pair` with
     the device-side association (tests/test_gpu_parity.py::test_native_frame_pair_equals_the_python_host).
     -> the result dict, or None when the call cannot serve this frame pair (options outside the single speculative launch, no
-    common label, more than 512 clusters, an over-long cluster needing its second try): the caller takes
-    `register_frame_pair_steps`."""
+    candidate pair at all, more than 512 clusters): the caller takes `register_frame_pair_steps`."""
     a = SimpleNamespace(**vars(args))
     a.translation_frame = frame_translation(args, fp.pose_exact, fp.gap if gap is None else gap)
     device = torch.device(device)

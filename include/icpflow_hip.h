@@ -462,7 +462,7 @@ int icpflow_associate_frame(const icpflow_tables_t *tables, const icpflow_stage_
  * seeded with it (= torch.Generator().manual_seed(seed), the generator frame_pairs.py gives every frame pair).
  * Outputs: d_rows float32 [1024,10], d_T float32 [1024,16] (the first *h_pairs rows are the matches, the rest padding),
  * d_flow float32 [n_src,3] of d_flow_points (or NULL: no flow) under d_pose [4,4].  *h_pairs: the number of matched pairs;
- * ICPFLOW_FRAME_HOST_PATH when this call cannot serve the frame pair (no common label, more than 512 clusters: the caller runs
+ * ICPFLOW_FRAME_HOST_PATH when this call cannot serve the frame pair (no candidate pair at all, more than 512 clusters: the caller runs
  * the finer-grained path, nothing was consumed).  When a stage-2 candidate with a cluster too long for the superset turns out
  * to be needed, the call registers stage 2 once more the reference's way -- its exact candidates, read from stage 1's
  * assignment, subsamples drawn next from the same generator -- on top of stage 1's results (one more wait); ICPFLOW_FRAME_ABANDONED when a team's wait timed out (transforms NaN).  d_scratch / scratch_bytes: device

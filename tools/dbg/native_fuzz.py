@@ -21,8 +21,8 @@ for seed in range(first, first + trials):
     got = frame_pairs.register_frame_pair_native(a, fp, dev)
     torch.cuda.synchronize()
     if got is None:
-        # the one case the call leaves to the finer-grained path on such data: no cluster keeps its label and passes the
-        # sanity check, i.e. stage 1 has no candidate (checked here on the Python host's tables)
+        # (until the call registered the reference's stage 2 alone itself: no cluster keeps its label and passes the sanity
+        # check, i.e. stage 1 has no candidate -- checked here on the Python host's tables; no longer expected)
         from icp_flow_amd.utils_check import ClusterTable, _sanity_mask
         G = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
         st, dt = ClusterTable.pair(G(fp.points_src), G(fp.labels_src).float(), G(fp.points_dst), G(fp.labels_dst).float())
