@@ -142,6 +142,55 @@ def test_config2_full_batch_vs_oracle(config2):
         assert err32[undetermined].max() < 1e-2 and errtr[undetermined].max() < 2e-3, msg
 
 
+def _vs_reference_import(name, S, D, o):
+    """HIP against the G12 fixture `name` (the reference's OWN Python at this size, tools/gen_golden.py g12) and, beside it,
+    the oracle run on this host.  -> (err vs fixture [B], message)."""
+    from conftest import load_golden
+    g = load_golden(name)
+    B, N = int(g["num_pairs"]), int(g["max_points"])
+    assert S.shape[:2] == (B, N)
+    a = rp.default_args(max_points=N, icp_max_iterations=int(g["icp_max_iterations"]))
+    init = utils_hist.estimate_init_pose(a, G(S), G(D)).cpu().numpy()
+    assert np.array_equal(init, g["T_init"]), "initial poses differ from the reference-import run"
+    T, iters = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
+    T = T.cpu().numpy()
+    assert int(iters) == int(g["icp_iterations"]), (int(iters), int(g["icp_iterations"]))
+    err = displacement(T, g["T_hist_icp"], S)
+    und = np.nonzero(~o["determined"])[0]
+    here = displacement(o["T32"], g["T_hist_icp"], S)
+    exact = displacement(o["T64"], g["T_hist_icp"], S)
+    out = np.nonzero(err >= TOL_M)[0]
+    msg = "\n".join([
+        f"{name}: HIP vs the reference-import run: {int((err < TOL_M).sum())}/{B} pairs within {TOL_M:g} m, max {err.max():.2e}, "
+        f"outside: {[(int(k), f'{err[k]:.2e}') for k in out]}",
+        f"  this host's fp32 oracle vs the reference-import run: {int((here == 0).sum())}/{B} pairs identical, max {here.max():.2e}",
+        f"  the oracle's exact (fp64 Kabsch) evaluation vs the reference-import run: max {exact.max():.2e}, "
+        f"outside {TOL_M:g}: {[(int(k), f'{exact[k]:.2e}') for k in np.nonzero(exact >= TOL_M)[0]]}",
+        f"  pairs this host's oracle leaves undetermined, as the reference-import run decides them (HIP - run): "
+        f"{[(int(k), f'{err[k]:.2e}') for k in und]}"])
+    print(msg)
+    # ev_* of the run on the run's own transforms, through the HIP match_eval (a sweep, no trajectory: tight)
+    ev = utils_match.match_eval(a, G(S), G(D), G(g["T_hist_icp"]))
+    for got, key in zip(ev, ("errors", "inliers", "ratios", "ious", "translations", "rotations")):
+        np.testing.assert_allclose(got.cpu().numpy(), g["ev_" + key], atol=2e-5, rtol=1e-5, err_msg=key)
+    return err, exact, msg
+
+
+def test_config2_full_batch_vs_the_reference_import_run(config2):
+    """G12: the whole config-2 batch against a run of the reference's own Python at this size (not the restatement).
+    Initial poses bit for bit, the iteration count (47) equal, match_eval of the run's transforms within 2e-5.  Transforms:
+    the HIP path's Kabsch moments are fp64, so it sits on the EXACT evaluation of each step (within 1e-5 m of the oracle's
+    fp64-Kabsch run on every pair, previous test); the reference-import run is ONE fp32 evaluation of the same trajectory.
+    Measured when the fixture was made: the run is further than 1e-4 m from the exact evaluation on 3 of 256 pairs (93: 1.4 mm,
+    129: 1.2 mm, 127: 0.11 mm; pairs still sliding at the stop) -- the HIP path inherits exactly those, no others:
+    a pair outside the bound must be one where the run itself is that far from the exact evaluation of its own formulas."""
+    c = config2
+    err, exact, msg = _vs_reference_import("g12_config2", c["S"], c["D"], c)
+    assert (err >= TOL_M).sum() <= 5 and err.max() < 3e-3, msg
+    assert set(np.nonzero(err >= TOL_M)[0]) <= set(np.nonzero(exact >= 0.5 * TOL_M)[0]), msg
+    assert np.abs(err - exact).max() < 1e-5, msg    # HIP and the exact evaluation see the run from the same place
+
+
 def test_config2_full_batch_fp32_reference_arithmetic(config2):
     """ICPFLOW_ARITH_FP32_REFERENCE (a study mode): the Kabsch step in the reference's own fp32 operation order, its
     sums as GPU tree reductions.  Same iteration count as the pairwise-order fp32 oracle and the exact evaluations
@@ -503,11 +552,17 @@ def test_config4_shard_properties(config4_shard):
     assert np.percentile(displacement(T, Tp, S), 90) < TOL_M
 
 
-def test_config4_shape_64_pair_batch_vs_oracle(config4_shard):
+@pytest.fixture(scope="module")
+def config4_sample_oracle(config4_shard):
+    S, D, _ = config4_shard
+    return _oracle_three(rp.default_args(max_points=2048, icp_max_iterations=50), S[:64], D[:64], 50)
+
+
+def test_config4_shape_64_pair_batch_vs_oracle(config4_shard, config4_sample_oracle):
     S, D, _ = config4_shard
     S, D = S[:64], D[:64]
     a = rp.default_args(max_points=2048, icp_max_iterations=50)
-    o = _oracle_three(a, S, D, 50)
+    o = config4_sample_oracle
     init = utils_hist.estimate_init_pose(a, G(S), G(D)).cpu().numpy()
     assert np.array_equal(init, o["aux32"]["init"].numpy())
     T, iters = utils_match.hist_icp(a, G(S), G(D), return_iterations=True)
@@ -532,6 +587,18 @@ def test_config4_shape_64_pair_batch_vs_oracle(config4_shard):
     assert (err32 >= TOL_M).sum() <= 5, msg
     if len(undetermined):
         assert err32[undetermined].max() < 2e-3, msg
+
+
+def test_config4_shape_64_pair_batch_vs_the_reference_import_run(config4_shard, config4_sample_oracle):
+    """G12: config 4's 64-pair sample against the reference's own Python run (50 iterations, not converged: every pair is
+    cut off at the cap while some still move).  Measured when the fixture was made: the run is > 1e-4 m from the exact
+    evaluation of its own formulas on 4 of 64 pairs (7: 0.30 mm, 61: 0.19 mm, 57: 0.15 mm, 53: 0.14 mm)."""
+    S, D, _ = config4_shard
+    S, D = S[:64], D[:64]
+    err, exact, msg = _vs_reference_import("g12_config4_sample", S, D, config4_sample_oracle)
+    assert (err >= TOL_M).sum() <= 6 and err.max() < 1e-3, msg
+    assert set(np.nonzero(err >= TOL_M)[0]) <= set(np.nonzero(exact >= 0.5 * TOL_M)[0]), msg
+    assert np.abs(err - exact).max() < 1e-5, msg
 
 
 # ------------------------------------------------------------------------------------------ p = len (no clamp)

@@ -535,7 +535,79 @@ def g8_cuda_rule():
     g8_demo(max_points=10000, name="g8_demo_mp10000_cudatopk", topk_rule="cuda")
 
 
-GENS = dict(g8cuda=g8_cuda_rule, g8mp10000=g8_demo_mp10000, g11=g11_hdbscan, g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
+def _ref_hist_icp_capped(a, src, dst, cap):
+    """The reference's own utils_match.hist_icp + match_eval with the ICP cap of BASELINE configs 2 / 4 (<= 50
+    iterations): utils_icp.pytorch3d_icp passes max_iterations=100 as a literal (utils_icp.py:54), so the imported
+    `iterative_closest_point` name inside utils_icp is wrapped for the duration of the call; everything else runs
+    unmodified.  -> T, init poses (estimate_init_pose on the swapped batch, what hist_icp computes), batch-global
+    iteration count, converged flag, match_eval's six outputs."""
+    seen = {}
+    orig = utils_icp.iterative_closest_point
+
+    def capped(*args, **kw):
+        kw["max_iterations"] = cap
+        r = orig(*args, **kw)
+        seen["iterations"] = len(r.t_history)
+        seen["converged"] = bool(r.converged)
+        return r
+
+    orig_init = utils_match.estimate_init_pose
+
+    def spy_init(args_, s_, d_):
+        r = orig_init(args_, s_, d_)
+        seen["init"] = r.clone()
+        return r
+
+    utils_icp.iterative_closest_point = capped
+    utils_match.estimate_init_pose = spy_init
+    try:
+        T = utils_match.hist_icp(a, src, dst)
+    finally:
+        utils_icp.iterative_closest_point = orig
+        utils_match.estimate_init_pose = orig_init
+    ev = utils_match.match_eval(a, src, dst, T)
+    return T, seen, ev
+
+
+def g12_headline():
+    """G12: the reference's own Python at the sizes the bench quotes -- the whole config-2 batch
+    (256 x 1024, synthetic.make_batch(256, 1024, seed=0)) and config 4's 64-pair sample (pairs 0..63 of
+    make_batch(1024, 2048, seed=0)), ICP capped at 50 iterations.  Inputs are seeds (the generator is this repo's);
+    stored: transforms, initial poses, the batch-global iteration count, match_eval's outputs.
+
+    The run is repeated with 1 and 32 torch threads (torch-CPU's long fp32 sums are split by thread count, so the
+    REFERENCE'S OWN result depends on it): the rows of T that differ from the 8-thread run are stored sparsely
+    (`alt{n}_idx`, `alt{n}_T`, `alt{n}_iterations`) -- the scatter of the reference against itself at this size."""
+    import time
+    for name, B, N, nb in (("g12_config2", 256, 1024, 256), ("g12_config4_sample", 64, 2048, 1024)):
+        S, D, Tt = synthetic.make_batch(nb, N, seed=0)
+        src, dst = t(S[:B]), t(D[:B])
+        a = args_ns(max_points=N)
+        torch.set_num_threads(8)
+        t0 = time.time()
+        T, seen, ev = _ref_hist_icp_capped(a, src, dst, 50)
+        print(f"{name}: reference hist_icp + match_eval {time.time() - t0:.0f} s, {seen['iterations']} iterations, "
+              f"converged {seen['converged']}, torch threads {torch.get_num_threads()}")
+        alt = {}
+        for n in (1, 32):
+            torch.set_num_threads(n)
+            Tn, sn, _ = _ref_hist_icp_capped(a, src, dst, 50)
+            assert torch.equal(sn["init"], seen["init"])
+            idx = np.nonzero((Tn != T).any(dim=2).any(dim=1).numpy())[0]
+            alt[f"alt{n}_idx"] = idx.astype(np.int64)
+            alt[f"alt{n}_T"] = Tn.numpy()[idx]
+            alt[f"alt{n}_iterations"] = np.array(sn["iterations"])
+            print(f"  {n} threads: {sn['iterations']} iterations, {len(idx)} of {B} transforms differ in some bit from the 8-thread run")
+        torch.set_num_threads(8)
+        save(name, seed=np.array(0), num_pairs=np.array(B), max_points=np.array(N), make_batch_pairs=np.array(nb),
+             icp_max_iterations=np.array(50), torch_threads=np.array(8),
+             T_hist_icp=T.numpy(), T_init=seen["init"].numpy(), icp_iterations=np.array(seen["iterations"]),
+             icp_converged=np.array(seen["converged"]), cut_tied=cut_is_tied(a, src, dst, True),
+             ev_errors=ev[0].numpy(), ev_inliers=ev[1].numpy(), ev_ratios=ev[2].numpy(),
+             ev_ious=ev[3].numpy(), ev_translations=ev[4].numpy(), ev_rotations=ev[5].numpy(), **alt)
+
+
+GENS = dict(g12=g12_headline, g8cuda=g8_cuda_rule, g8mp10000=g8_demo_mp10000, g11=g11_hdbscan, g10=g10_dbscan, g9=g9_epe, g1=g1_hist, g3=g3_nn, g4=g4_init_pose, g5=g5_icp, g6=g6_hist_icp, g8=g8_demo)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -543,7 +615,7 @@ if __name__ == "__main__":
     ns = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g8mp10000", "g8cuda", "g9", "g10", "g11")]   # g8: ~3 min, on request
+    want = [s for s in ns.only.split(",") if s] or [k for k in GENS if k not in ("g8", "g8mp10000", "g8cuda", "g9", "g10", "g11", "g12")]   # g8: ~3 min, on request
     for k in want:
         print(f"== {k}")
         GENS[k]()
