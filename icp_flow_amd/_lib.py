@@ -99,7 +99,7 @@ OPT_FLAGS = {"no_sorted_vote": 1 << 0, "no_side_stream": 1 << 1, "no_eval_sweep"
              "no_score_sweep": 1 << 4, "no_score_prune": 1 << 5, "no_teams": 1 << 6, "no_speculative": 1 << 7,
              "no_adaptive_windows": 1 << 8, "no_persistent": 1 << 9, "no_helpers": 1 << 10,
              # (not a bit-identity switch: teams on at most half of the CUs, two team launches side by side; icpflow_hip.h)
-             "teams_half_gpu": 1 << 11}
+             "teams_half_gpu": 1 << 11, "no_shared_scans": 1 << 12}
 
 
 class Options(ctypes.Structure):

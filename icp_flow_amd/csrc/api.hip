@@ -75,6 +75,7 @@ struct Opts {
         o.persistent = on(ICPFLOW_OPT_NO_PERSISTENT);
         o.helpers = on(ICPFLOW_OPT_NO_HELPERS);
         o.teamsHalfGpu = (flags & ICPFLOW_OPT_TEAMS_HALF_GPU) != 0u;
+        o.sharedScans = on(ICPFLOW_OPT_NO_SHARED_SCANS);
         o.pairActive = pairActive;
         o.profile = profile;
         return o;
@@ -217,7 +218,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
     if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
-    if (opt->flags >> 12) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    if (opt->flags >> 13) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
     o.search = opt->icp_search;
     o.arith = opt->icp_arith;
     o.flags = opt->flags;

@@ -118,6 +118,7 @@ struct IcpParams {
     int x0Cache;             // the records are followed by the queries' own points (12 B each): no L2 round trip per iteration
     int recCap;              // sorted sweep in LDS: room for this many per-query records behind the LDS image (neighbour
                              // certificates, see the search phase); a workgroup whose share of the queries fits uses them
+    int shareScans;          // team kernel with the LDS image: the waves of a member share their long window scans (the launch left room for the accumulators)
     int teamLanes;           // host side only: 2 = this team launch takes at most half of the CUs (chained two deep)
     const uint8_t *pairActive;   // options.d_pair_active or NULL: pairs flagged 0 are not in the batch (speculative mode only)
 };
@@ -386,6 +387,18 @@ constexpr int kWideWindow = ICPFLOW_WIDE_WINDOW;   // (targets in a wave's previ
 #define ICPFLOW_PROBE_CAP 128
 #endif
 constexpr int kProbeCap = ICPFLOW_PROBE_CAP;   // entries of a pass's shared probe queue (teams; 28 B of LDS each)
+// Shared window scans (teams, round 5): a wave whose window holds at least kShareMinW targets cuts it into up to kShareParts
+// parts of at least kSharePartMin targets; the waves that are through with their own unit take parts (see the search phase).
+#ifndef ICPFLOW_SHARE_MIN_W
+#define ICPFLOW_SHARE_MIN_W 256
+#endif
+#ifndef ICPFLOW_SHARE_PART_MIN
+#define ICPFLOW_SHARE_PART_MIN 128
+#endif
+#ifndef ICPFLOW_SHARE_MIN_N
+#define ICPFLOW_SHARE_MIN_N 3000
+#endif
+constexpr int kShareMinW = ICPFLOW_SHARE_MIN_W, kSharePartMin = ICPFLOW_SHARE_PART_MIN, kShareMinN = ICPFLOW_SHARE_MIN_N;
 constexpr int kRing = 8;   // states remembered for the detection of periodic trajectories (speculative mode)
 
 // ---------------------------------------------------------------------------------
@@ -482,7 +495,7 @@ __device__ __forceinline__ bool team_collect(const IcpTeam &t, IcpCtrl *ctrl, in
 // HELP (persistent sorted-sweep kernels): role 0 = the pair's owner, role j + 1 = helper in slot j of pair b: it runs pass
 // `passes - 1 - j` of every iteration from the state the owner publishes and hands the pass's moment sums back (see
 // HelpPair in kernels.hpp and icp_kernel).
-template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE, bool HELP, bool LATE, typename P>
+template <int BLOCK, int Q, int TS, int GRID, bool TEAM, bool SCALE, bool HELP, bool LATE, bool SHAREK, typename P>
 __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank, const int G, const int itBegin,
                                          const int itEnd, const int role = 0)
 {
@@ -513,6 +526,19 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     __shared__ float probeQ[4][TEAM && GRID == 4 ? kProbeCap : 1];   // (query position, previous neighbour)
     __shared__ float probeR[3][TEAM && GRID == 4 ? kProbeCap : 1];   // (distance, bound on the others, neighbour)
     __shared__ int probeCnt[2], probeNext[2]; // entries posted / handed out, by pass parity
+    // teams: window scans shared by the member's waves (see the search phase): per owner wave the posted window and its
+    // ticket / completion counters, the waves with an open posting, the arrivals at the help barriers
+    // (SHAREK: an instantiation of its own -- the team kernel sits at its register limit, and the code alone costs the pairs
+    // that never share 3-6 % -- chosen by the launch: padded width from kShareLaunchMinN on, ICPFLOW_OPT_NO_SHARED_SCANS off)
+#ifdef ICPFLOW_NO_SHARE
+    constexpr bool SHARE = false;
+#else
+    constexpr bool SHARE = SHAREK && TEAM && GRID == 4 && Q == 1;
+#endif
+    __shared__ int shHdr[SHARE ? NWAVE : 1][4];   // cb, ce, part length, parts | pass << 8 | unit << 16
+    __shared__ int shNext[SHARE ? NWAVE : 1], shDone[SHARE ? NWAVE : 1], shLock[SHARE ? NWAVE : 1];
+    __shared__ unsigned int shAcc[SHARE ? NWAVE : 1][3][kWave];   // per owner wave and lane: what the helpers' parts add up to (minimum, runner-up, chunk | tie)
+    __shared__ unsigned int shState;   // arrivals at the help phases so far (low 20 bits: they only grow) | open postings (bit 20 + wave)
     [[maybe_unused]] const bool helping = HELP && role != 0;
     [[maybe_unused]] HelpPair *hp = nullptr;
     if constexpr (HELP) hp = (p.helpOn && p.help.pair != nullptr) ? p.help.pair + b : nullptr;
@@ -590,6 +616,8 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     }
     int itersDone = (itBegin == 0) ? 0 : st->iters;
     if (tid == 0) { probeCnt[0] = 0; probeCnt[1] = 0; probeNext[0] = 0; probeNext[1] = 0; }
+    if (SHARE && tid == 0) shState = 0u;
+    [[maybe_unused]] int hbSeq = 0;      // help barriers passed so far (workgroup-uniform)
     [[maybe_unused]] int probePar = 0;   // parity of the next pass's queue counters (workgroup-uniform)
 
     // per-pair origin of the moment accumulation: the first (pre-posed) source point
@@ -804,6 +832,109 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             bool reuseMoments = false;   // this wave's 18 sums are those of the previous iteration (still in `red`)
             [[maybe_unused]] int helpedPasses = 0;   // owner: passes of this iteration that helpers deliver (bit g)
             if constexpr (HELP) helpedPasses = helping ? 0 : __builtin_amdgcn_readfirstlane(helpSh[0]);
+            // ---- shared window scans (teams, round 5) --------------------------------------------------------------------
+            // Where a pair still slides along a face of its cluster, a few waves of a member scan windows of 700-1000 targets
+            // (a face across the sort axis: every target of the face has the queries' key) while the others hold certificates
+            // and wait at the next barrier: 60-77 k clocks for those units against 2-5 k (ragged real-shape batch, r04 profile),
+            // and a wave that scans alone on its SIMD is bound by the latency of its own LDS reads, not by the VALU.
+            // So a wave whose window holds kShareMinW targets or more POSTS it (window, pass, unit) in LDS, cut into parts of
+            // >= kSharePartMin targets, and takes parts by ticket itself; every wave that reaches one of the search phase's
+            // barriers first looks for open postings and takes parts too (it forms the owner's 64 queries itself: same
+            // operations, same bits) and adds its (minimum, runner-up, chunk | tie) per lane to the owner's accumulator in
+            // LDS under the posting's lock.  The owner merges that accumulator with the parts it scanned itself:
+            // minimum with the first-chunk rule, tie flag and second-smallest chunk minimum combine exactly (the merge
+            // gives what ONE scan over the whole window gives, in any order), so results are bit-identical.
+            // A barrier of the search phase becomes: count the arrival, help while others have not arrived, then the barrier.
+            // An owner arrives only after its posting is merged, so "everybody has arrived" means no part is open or in flight.
+            [[maybe_unused]] bool shareOn = false;
+            if constexpr (SHARE) shareOn = recOn && p.shareScans != 0 && yc.n >= kShareMinN;
+            // the moved query of lane `lane` of unit `uw` of pass `gp` (what the unit's own wave computes below)
+            [[maybe_unused]] auto unit_query = [&](int gp, int uw, float &ux, float &uy, float &uz) {
+                const int li = gp * PER + uw * kWave + lane;
+                const int i = dealt ? ((li >> 6) * G + rank) * kWave + lane : li;
+                ux = uy = uz = 0.f;
+                if (li < myCount && i < xc.n) {
+                    float ax0, ay0, az0;
+                    if (x0On && it > itFirst) {
+                        ax0 = x0c[li]; ay0 = x0c[p.recCap + li]; az0 = x0c[2 * p.recCap + li];
+                    } else {
+                        const float4 s4 = xs[i];
+                        ax0 = s4.x; ay0 = s4.y; az0 = s4.z;
+                        if (p.sortedRaw) {
+                            ax0 = fmaf(s4.z, preL[2], fmaf(s4.y, preL[1], s4.x * preL[0])) + preL[9];
+                            ay0 = fmaf(s4.z, preL[5], fmaf(s4.y, preL[4], s4.x * preL[3])) + preL[10];
+                            az0 = fmaf(s4.z, preL[8], fmaf(s4.y, preL[7], s4.x * preL[6])) + preL[11];
+                        }
+                    }
+                    float rx = fmaf(az0, Rf[6], fmaf(ay0, Rf[3], ax0 * Rf[0]));
+                    float ry = fmaf(az0, Rf[7], fmaf(ay0, Rf[4], ax0 * Rf[1]));
+                    float rz = fmaf(az0, Rf[8], fmaf(ay0, Rf[5], ax0 * Rf[2]));
+                    if constexpr (SCALE) { rx *= sc; ry *= sc; rz *= sc; }
+                    ux = rx + Tf[0]; uy = ry + Tf[1]; uz = rz + Tf[2];
+                }
+            };
+            [[maybe_unused]] auto help_phase = [&]() {
+                if constexpr (SHARE) {
+                    if (shareOn) {
+                        ++hbSeq;
+                        // (one word holds arrivals and open postings: the last wave to arrive sees "everybody here, nothing open" in the
+                        // value its own arrival returns and goes straight on)
+                        const unsigned int target = (unsigned)hbSeq * NWAVE;
+                        unsigned int state = 0u;
+                        if (lane == 0) state = atomicAdd(&shState, 1u) + 1u;
+                        state = (unsigned)__builtin_amdgcn_readfirstlane((int)state);
+                        unsigned int exhausted = 0u;
+                        for (bool fresh = true;; fresh = false) {
+                            if (!fresh) state = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&shState, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            const unsigned int open = (state >> 20) & ~exhausted;
+                            if (open != 0u) {
+                                const int w = __builtin_ctz(open);
+                                const int hcb = __builtin_amdgcn_readfirstlane(shHdr[w][0]), hce = __builtin_amdgcn_readfirstlane(shHdr[w][1]);
+                                const int hlen = __builtin_amdgcn_readfirstlane(shHdr[w][2]), hword = __builtin_amdgcn_readfirstlane(shHdr[w][3]);
+                                int t = 0;
+                                if (lane == 0) t = atomicAdd(&shNext[w], 1);
+                                t = __builtin_amdgcn_readfirstlane(t);
+                                if (t >= (hword & 0xff)) { exhausted |= 1u << w; continue; }
+                                float hx[1], hy[1], hz[1];
+                                unit_query((hword >> 8) & 0xff, (hword >> 16) & 0xff, hx[0], hy[0], hz[0]);
+                                ScanAcc<1> ha;
+                                bool ht[1] = {false};
+                                float hs[1] = {kInf};
+                                scan_init(ha);
+                                const int c0 = hcb + t * hlen;
+                                scan_range_tie<1, true>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
+                                                        reinterpret_cast<const float4 *>(lz), c0, min(c0 + hlen, hce), hx, hy, hz, ha, ht, hs);
+                                // add this part to the owner's accumulator (any order gives the same result), under the posting's lock
+                                for (;;) {
+                                    int got = 1;
+                                    if (lane == 0) got = atomicCAS(&shLock[w], 0, 1);
+                                    if (__builtin_amdgcn_readfirstlane(got) == 0) break;
+                                    __builtin_amdgcn_s_sleep(0);
+                                }
+                                {
+                                    const float b1 = __uint_as_float(shAcc[w][0][lane]), s1 = __uint_as_float(shAcc[w][1][lane]);
+                                    const unsigned int w1 = shAcc[w][2][lane];
+                                    const float b2 = ha.best[0];
+                                    const float sec = min_nonneg(max_nonneg(b1, b2), min_nonneg(s1, hs[0]));
+                                    unsigned int wn = w1;
+                                    if (b2 < b1) wn = (unsigned)ha.chunk[0] | (ht[0] ? 0x40000000u : 0u);
+                                    else if (b2 == b1) wn = min(w1 & 0x3fffffffu, (unsigned)ha.chunk[0]) | 0x40000000u;
+                                    shAcc[w][0][lane] = __float_as_uint(fminf(b1, b2));
+                                    shAcc[w][1][lane] = __float_as_uint(sec);
+                                    shAcc[w][2][lane] = wn;
+                                }
+                                if (lane == 0) {
+                                    __hip_atomic_store(&shLock[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (behind the stores: one wave's LDS operations execute in order)
+                                    atomicAdd(&shDone[w], 1);
+                                }
+                                continue;
+                            }
+                            if ((state & 0xfffffu) >= target && (state >> 20) == 0u) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                }
+            };
             for (int g = 0; g < ngr; ++g) {
                 if constexpr (HELP) {
                     if (helping ? g != ngr - role : ((helpedPasses >> g) & 1) != 0) continue;   // (workgroup-uniform)
@@ -911,7 +1042,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 scan_init(acc);
                 int cb = 0, ce = 0;
                 // the window scan of this wave: the part of the sort axis in which its searching queries can find their neighbours
-                auto scan_window = [&]() {
+                auto scan_window = [&](const bool mayShare) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
@@ -940,10 +1071,58 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         if ((int)blockIdx.x == g_stamp_block && lane == 0) g_wave_stamps[wave * 16 + 15] = ce - cb;
 #endif
                         if (GRID == 4) {
-                            if (REC && recOn)
-                                scan_range_tie<Q, true>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
-                                                        reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie, second);
-                            else
+                            if (REC && recOn) {
+                                // (ONE call site of the scan, in a loop that runs once unless the window is shared)
+                                int c0 = cb, c1 = ce;
+                                [[maybe_unused]] bool share = false;
+                                [[maybe_unused]] int nParts = 1, partLen = 0, mine = 1;
+                                if constexpr (SHARE) {
+                                    share = mayShare && shareOn && it > itFirst && ce - cb >= kShareMinW;
+                                    if (share) {
+                                        const int W = ce - cb;
+                                        nParts = min(kShareParts, W / kSharePartMin);
+                                        partLen = ((W + nParts - 1) / nParts + kChunk - 1) / kChunk * kChunk;
+                                        nParts = (W + partLen - 1) / partLen;
+                                        shAcc[wave][0][lane] = 0x7f800000u; shAcc[wave][1][lane] = 0x7f800000u; shAcc[wave][2][lane] = 0x3fffffffu;
+                                        if (lane == 0) {
+                                            shHdr[wave][0] = cb; shHdr[wave][1] = ce; shHdr[wave][2] = partLen;
+                                            shHdr[wave][3] = nParts | (g << 8) | (unitWave << 16);
+                                            shNext[wave] = 1; shDone[wave] = 0; shLock[wave] = 0;   // (part 0 is the owner's)
+                                            atomicOr(&shState, 1u << (20 + wave));     // (LDS operations of one wave execute in order)
+                                        }
+                                        c1 = min(cb + partLen, ce);
+                                    }
+                                }
+                                for (;;) {
+                                    scan_range_tie<Q, true>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
+                                                            reinterpret_cast<const float4 *>(lz), c0, c1, qx, qy, qz, acc, tie, second);
+                                    if constexpr (!SHARE) break;
+                                    if (!share) break;
+                                    int t = 0;
+                                    if (lane == 0) t = atomicAdd(&shNext[wave], 1);
+                                    t = __builtin_amdgcn_readfirstlane(t);
+                                    if (t >= nParts) break;
+                                    ++mine;
+                                    c0 = cb + t * partLen;
+                                    c1 = min(c0 + partLen, ce);
+                                }
+                                if constexpr (SHARE) {
+                                    if (share) {
+                                        if (nParts > mine) {
+                                            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&shDone[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < nParts - mine)
+                                                __builtin_amdgcn_s_sleep(1);
+                                            asm volatile("" ::: "memory");
+                                            const float b2 = __uint_as_float(shAcc[wave][0][lane]), s2 = __uint_as_float(shAcc[wave][1][lane]);
+                                            const unsigned int w2 = shAcc[wave][2][lane];
+                                            // second-smallest chunk minimum of the union: of {best, second} of either side
+                                            second[0] = min_nonneg(max_nonneg(acc.best[0], b2), min_nonneg(second[0], s2));
+                                            if (b2 < acc.best[0]) { acc.best[0] = b2; acc.chunk[0] = (int)(w2 & 0x3fffffffu); tie[0] = (w2 & 0x40000000u) != 0u; }
+                                            else if (b2 == acc.best[0]) { tie[0] = true; acc.chunk[0] = min(acc.chunk[0], (int)(w2 & 0x3fffffffu)); }
+                                        }
+                                        if (lane == 0) atomicAnd(&shState, ~(1u << (20 + wave)));
+                                    }
+                                }
+                            } else
                                 scan_range_tie<Q>(reinterpret_cast<const float4 *>(lx), reinterpret_cast<const float4 *>(ly),
                                                   reinterpret_cast<const float4 *>(lz), cb, ce, qx, qy, qz, acc, tie);
                         } else
@@ -988,7 +1167,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     barrier_lds_only();
                     const int posted = min(__builtin_amdgcn_readfirstlane(probeCnt[probePar]), kProbeCap);
                     if (tid == 0) { probeCnt[probePar ^ 1] = 0; probeNext[probePar ^ 1] = 0; }   // the next pass's (last read a whole pass ago)
-                    if (mustScan) scan_window();
+                    if (mustScan) scan_window(false);   // (the others probe meanwhile and meet this wave at the barrier below: nobody to share with)
                     const int row = lane >> 3, li = lane & 7;
                     for (;;) {
                         int e0 = 0;
@@ -1159,7 +1338,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     }
                 }
                 }
-                if (scanNow) scan_window();
+                if (scanNow) scan_window(true);
 #ifdef ICPFLOW_TAIL_CLOCK
                 if (b == g_unit_pair && it < 64 && g < 8 && wave < 16) {
                     int nsearch = 0;
@@ -1344,6 +1523,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 const int m = (j < 4) ? 4 * j + ((row & 1) * 2 + (row >> 1)) : 16 + (row >> 1);
                 if ((lane & 15) == 15) red[wave * kMoments + m] = r;
             }
+            help_phase();   // (teams: the windows posted behind the pass's last barrier; the block barrier follows below)
         } else if constexpr (GRID != 0) {
             const float4 *gpG = p.gridPts + (size_t)b * p.N;
             const int32_t *gsG = p.gridStart + (size_t)b * (p.gridH + 1);
@@ -1961,7 +2141,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         G = p.team.teamSize[b];
         // a chain of single-pass pairs (icp_team_plan_kernel): one after the other, like the tickets of a persistent grid
         for (;;) {
-            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, true>(p, b, rank, G, itBegin, itEnd);
+            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, true, HELPK>(p, b, rank, G, itBegin, itEnd);   // (teams: HELPK marks the instantiation with shared window scans)
             b = __builtin_amdgcn_readfirstlane(p.team.next[b]);
             if (b < 0) return;
             __syncthreads();                 // the pair's last reads of the static LDS state are done
@@ -1972,7 +2152,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         // one workgroup per pair, at most one (1024 / 768 threads) per CU: the launch lasts as long as its slowest pair's chain
         // of iterations -- late bookkeeping.  512-thread workgroups share their CUs (two per CU: batches of two pairs per CU
         // and more), like the persistent grids below: one pair's bookkeeping already runs under another pair's search.
-        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, BLOCK != 512>(p, b, rank, G, itBegin, itEnd);
+        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, BLOCK != 512, false>(p, b, rank, G, itBegin, itEnd);
     } else {
         static_assert(!PERSIST || !TEAM, "teams are planned per launch");
         constexpr bool HELP = HELPK && GRID == 4 && !SCALE && Q == 1;
@@ -1985,7 +2165,7 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         int role = 0;
         for (;;) {
             asm volatile("" : "+s"(pp));
-            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, HELP, false>(*pp, b, rank, G, itBegin, itEnd, role);
+            icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, HELP, false, false>(*pp, b, rank, G, itBegin, itEnd, role);
             __syncthreads();                     // the pair's last reads of the static LDS state are done
             if (threadIdx.x < kWave) {
                 int nb = -1, nr = 0;
@@ -2426,6 +2606,16 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
         ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE>), 156 * 1024, &raised);
     }
     const int wgs = TEAM ? p.team.maxWG : B;
+    if constexpr (TEAM && GRID == 4) {
+        if (p.shareScans) {   // the instantiation with shared window scans (icp_pair: SHAREK)
+            if (dyn > 48 * 1024) {
+                static std::atomic<unsigned long long> raisedS{0ull};
+                ensure_dynamic_lds(reinterpret_cast<const void *>(&icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE, false, true>), 156 * 1024, &raisedS);
+            }
+            hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE, false, true>), dim3(wgs), dim3(BLOCK), dyn, s, q, itBegin, itEnd);
+            return;
+        }
+    }
     hipLaunchKernelGGL((icp_kernel<BLOCK, Q, TS, GRID, TEAM, SCALE>), dim3(wgs), dim3(BLOCK), dyn, s, q, itBegin, itEnd);
 }
 
@@ -2678,10 +2868,21 @@ bool icp_teams_wanted(const IcpTeam *team, const IcpOpts &opts, const GridScratc
     const bool speculative = stopMode == ICPFLOW_STOP_REFERENCE_ && history != nullptr && opts.speculative &&
                              maxIter > 1 && maxIter <= kHistIters;
     return opts.arith != ICPFLOW_ARITH_FP32_REFERENCE && team != nullptr && opts.teams && grid != nullptr && grid->mode == 3 &&
-           N > 1024 && 2 * B <= device_cus() && B <= 256 && (speculative || stopMode == ICPFLOW_STOP_PER_PAIR_);
+           N > 1024 && 2 * B <= device_cus() && B <= 256 && B <= min(icp_team_workgroups(opts), team->maxWG) &&
+           (speculative || stopMode == ICPFLOW_STOP_PER_PAIR_);
+    // (B <= the workgroups the plan really gets: with teamsHalfGpu on a part whose CUs / 2 is not a multiple of eight --
+    // 104, 110, 120 CUs -- the plan has fewer slots than CUs / 2, and a pair without a slot would never be served)
 }
 
+// dynamic LDS of a team member with the LDS image (image + records): the CU's 160 KiB less the team kernel's static LDS
+// (~16 KiB with the accumulators of the shared window scans: 143 KiB; ~6.7 KiB without: 152 KiB)
 // workgroups of a team launch: one per CU, or one per CU of HALF the GPU (a multiple of the eight XCDs either way)
+// Shared window scans (icp_pair, SHAREK): from this padded width on -- below, windows of 256 targets are rare.
+#ifndef ICPFLOW_SHARE_LAUNCH_MIN_N
+#define ICPFLOW_SHARE_LAUNCH_MIN_N 5000
+#endif
+bool icp_team_shares(const IcpOpts &opts, int N) { return opts.sharedScans && opts.adaptiveWindows && N >= ICPFLOW_SHARE_LAUNCH_MIN_N && N <= 12288; }
+size_t icp_team_room(const IcpOpts &opts, int N) { return icp_team_shares(opts, N) ? (size_t)143 * 1024 : (size_t)152 * 1024; }
 int icp_team_workgroups(const IcpOpts &opts)
 {
     const int cus = device_cus();
@@ -2696,7 +2897,8 @@ void launch_icp_team_plan(const IcpTeam *team, const int32_t *lenX, const int32_
     t.maxWG = min(icp_team_workgroups(opts), team->maxWG);
     // (records behind the LDS image of the padded length: what a member's share of the queries has to fit, see launch_icp)
     const size_t imgT = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
-    const int recCapT = (opts.adaptiveWindows && N <= 12288 && imgT + 64 * 20 <= 152 * 1024) ? (int)((152 * 1024 - imgT) / 20 / 64 * 64) : 0;
+    const size_t roomT = icp_team_room(opts, N);
+    const int recCapT = (opts.adaptiveWindows && N <= 12288 && imgT + 64 * 20 <= roomT) ? (int)((roomT - imgT) / 20 / 64 * 64) : 0;
     hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, t, recCapT);
 }
 
@@ -2775,10 +2977,11 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         // room for the per-query records behind the LDS image: every query of a pair when one workgroup serves it,
         // the member's own share of the queries in a team (the image of a 10^4-point cloud leaves room for ~1800)
         const size_t img = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
-        const size_t room = 152 * 1024;   // dynamic LDS next to the kernel's ~3 KiB of static LDS
+        const size_t room = p.team.wgPair != nullptr ? icp_team_room(opts, N) : (size_t)152 * 1024;   // dynamic LDS next to the kernel's static LDS (~3 KiB; teams: see kTeamRoom)
         int recCap = 0;
         if (p.team.wgPair != nullptr) {
             if (N <= 12288 && img + 64 * 20 <= room) recCap = (int)((room - img) / 20 / 64 * 64);
+            p.shareScans = (recWanted && recCap > 0 && icp_team_shares(opts, N)) ? 1 : 0;
         } else if (N <= kRecMaxN) {
             recCap = N;
         }

@@ -122,7 +122,12 @@ static __device__ bool horn_rotation(const double *S, double gsum, double *Nsh, 
         // relative size 1e-9 the iterate is exact to ~1e-18, the steps that used to follow it (one or two, until the
         // step fell below 1e-16 or stopped shrinking) only moved lam by its own rounding -- a quarter of the
         // iteration's dependent chain in the serial tail of every ICP iteration.
-        if (as <= 1e-9 * fabs(lam) || as >= prevStep) break;
+        // The bound holds for a root that is well separated: the error left after a step e is ~ e^2 |f''| / (2 |f'|), and
+        // near a (nearly) double top root f' -> 0 while f'' does not (near-collinear correspondences, sigma2 ~ sigma3 with
+        // a reflection), so the early exit is taken only where that estimate is below the rounding of lam; otherwise the
+        // iteration goes on to the old criterion (step below 1e-16 relative, or not shrinking any more).
+        if (as >= prevStep || as <= 1e-16 * fabs(lam)) break;
+        if (as <= 1e-9 * fabs(lam) && as * fabs(fma(6.0, x2, c2)) <= 1e-7 * fabs(den)) break;
         prevStep = as;
     }
     ICPFLOW_STAMP(14);

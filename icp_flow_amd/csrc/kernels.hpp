@@ -68,8 +68,12 @@ inline size_t icp_ctrl_bytes(int B);
 // Teams (icp.hip): several workgroups share one LARGE pair.  Every member owns a contiguous range
 // of the sorted moving cloud, the 18 moments of an iteration are exchanged through `mom`, and each
 // member solves for the same (R, T) redundantly -- one exchange per iteration, nobody broadcasts.
-constexpr int kMaxTeam = 16;      // workgroups per pair, at most
+#ifndef ICPFLOW_MAX_TEAM
+#define ICPFLOW_MAX_TEAM 16
+#endif
+constexpr int kMaxTeam = ICPFLOW_MAX_TEAM;      // workgroups per pair, at most
 constexpr int kTeamStride = 20;   // doubles per (pair, parity, member): 18 moments, stop flag
+constexpr int kShareParts = 8;    // parts of a shared window scan, at most
 struct IcpTeam {
     int32_t *wgPair;        // [maxWG] pair served by workgroup w, -1 = none
     int32_t *wgRank;        // [maxWG] rank inside the team
@@ -216,6 +220,7 @@ struct IcpOpts {
     bool teamPlanned = false;      // the caller has launched the team plan itself (launch_icp_team_plan, ordered before the ICP)
     const uint8_t *pairActive = nullptr;   // options.d_pair_active: pairs flagged 0 are not in the batch (speculative reference stop only)
     bool teamsHalfGpu = false;     // ICPFLOW_OPT_TEAMS_HALF_GPU: a team launch takes at most half of the CUs (two may run side by side)
+    bool sharedScans = true;       // teams: the waves of a member share their long window scans (ICPFLOW_OPT_NO_SHARED_SCANS)
 };
 bool icp_teams_wanted(const IcpTeam *team, const IcpOpts &opts, const GridScratch *grid, int B, int N, int maxIter,
                       int stopMode, const float *history);

@@ -433,6 +433,40 @@ def register_frame_pair_native(args, fp, device, gap=None):
     return track_frame_native(a, ps, pd, ls, ld, pose, flow_src)
 
 
+_randperm_ok = None    # None: not checked yet in this process
+
+
+def randperm_restatement_ok():
+    """icpflow_track_frame draws the subsamples of over-long clusters itself: a restatement of torch.randperm's CPU stream
+    (MT19937, the 32-bit branch of randperm_cpu; csrc/frame.hip) in place of `torch.randperm` under main.py:139's seed
+    (utils_helper.py:198-201).  A torch build that draws differently would give another -- valid, but not reference-identical --
+    subsample, silently.  So the first native frame pair of a process compares the two on two (seed, n, take) cases, one of
+    them mid-stream; on a mismatch: one warning, and every frame pair of the process goes through the Python host
+    (`torch.randperm` itself).  Costs ~0.3 ms once."""
+    global _randperm_ok
+    if _randperm_ok is None:
+        import ctypes
+        import warnings
+        from . import _lib
+        ok = True
+        for seed, n, take, skip in ((0, 30552, 2048, 0), (12345, 61849, 10000, 700)):
+            g = torch.Generator()
+            g.manual_seed(seed)
+            if skip:
+                torch.randperm(skip, generator=g)
+            mt = _lib.Mt19937.from_torch(g)
+            want = torch.randperm(n, generator=g)[:take].numpy().astype(np.int32)
+            got = np.empty(take, np.int32)
+            rc = _lib._L.icpflow_selftest_randperm(ctypes.byref(mt), n, take, got.ctypes.data_as(ctypes.c_void_p))
+            ok = ok and rc == 0 and np.array_equal(got, want)
+        if not ok:
+            warnings.warn("icp_flow_amd: this torch build's randperm does not draw like the library's restatement of it "
+                          f"(torch {torch.__version__}); frame pairs are registered through the Python host "
+                          "(args.native_host=False), which calls torch.randperm itself", RuntimeWarning, stacklevel=3)
+        _randperm_ok = ok
+    return _randperm_ok
+
+
 def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0, generator=None):
     """icpflow_track_frame on device tensors: `track(a, ps, pd, ls, ld)` (+ `flow_estimation_torch` of `flow_points` under
     `pose` when given) with `a.translation_frame` set; the random subsamples of over-long clusters are torch.randperm's on a
@@ -448,6 +482,8 @@ def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0, g
         return None
     if len(ps) == 0 or len(pd) == 0:
         return None
+    if not randperm_restatement_ok():
+        return None                     # (the caller's Python host draws with torch.randperm itself)
     _lib.require_gpu(ps, pd, ls, ld)
     ps3, pd3 = ps[:, 0:3].contiguous().float(), pd[:, 0:3].contiguous().float()
     ls, ld = ls.contiguous().float(), ld.contiguous().float()
@@ -473,9 +509,9 @@ def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0, g
     if scratch is None:
         scratch = _frame_scratch[key] = torch.empty((64 << 20,), dtype=torch.uint8, device=device)
     pairs, need = ctypes.c_int32(0), ctypes.c_size_t(0)
-    with _lib.options(teams_half_gpu=not getattr(a, "teams_full_gpu", False)):
+    with _lib.options(teams_half_gpu=not getattr(a, "teams_full_gpu", False), no_shared_scans=not getattr(a, "shared_scans", False)):
         opt = _lib.opt()
-        for _ in range(3):
+        for _ in range(5):   # (the scratch is sized in up to three parts -- fixed, stages, exact stage 2 --, each learnt from a refusal)
             rc = _lib._L.icpflow_track_frame(_lib.ptr(ps3), _lib.ptr(ls), len(ps3), _lib.ptr(pd3), _lib.ptr(ld), len(pd3),
                                              ctypes.byref(reg), ctypes.byref(par), _lib.ptr(rows), _lib.ptr(T), ctypes.byref(pairs),
                                              _lib.ptr(f_pts), _lib.ptr(f_pose), _lib.ptr(flow), _lib.ptr(scratch), scratch.numel(),

@@ -252,7 +252,7 @@ def _register_stage(args, st, dt, si, di, d_si=None, d_di=None):
     # stage needs far fewer workgroups than the GPU has CUs, and two frame pairs in flight can then run their team launches
     # side by side instead of one after the other.  Always, in flight or not: the plan decides the order of a team's sums, and
     # a frame pair registers to the same bits whatever else is in flight (`args.teams_full_gpu = True`: the full-GPU plan).
-    with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False)):
+    with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False), no_shared_scans=not getattr(args, "shared_scans", False)):
         _lib.call("icpflow_register_stage", ctypes.byref(tables), ctypes.byref(stage), ctypes.byref(reg), _lib.ptr(ws), ws.numel(),
                   _lib.stream(dev), _lib.opt())
     _Staging.done(key)
@@ -534,7 +534,7 @@ def _match_pcds_device(args, st, dt, pairs_true, asynchronous):
     if K2:
         _lib.check_vote_bins(K2, lens)
     ws = _lib.workspace(dev, max(ws_bytes1, _lib.workspace_bytes(K2, N2, lens) if K2 else 0))
-    with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False)):
+    with _lib.options(teams_half_gpu=not getattr(args, "teams_full_gpu", False), no_shared_scans=not getattr(args, "shared_scans", False)):
         _lib.call("icpflow_associate_frame", ctypes.byref(tables), ctypes.byref(stage1), ctypes.byref(stage2) if K2 else None,
                   ctypes.c_void_p(p_active2) if K2 else None, ctypes.byref(reg), f32(args.translation_frame), f32(args.thres_iou),
                   f32(args.thres_rot * 90.0), f32(args.thres_error), _lib.ptr(small), cap, _lib.ptr(rows), _lib.ptr(T),

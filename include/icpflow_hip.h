@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 207 /* 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 208 /* 0.2.8: ICPFLOW_OPT_NO_SHARED_SCANS (teams: window scans shared by a member's waves); 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -121,6 +121,8 @@ const char *icpflow_build_info(void);
  * follows the number of workgroups: results equal those of the full-GPU plan to rounding, and are the same whatever else is
  * in flight.  Team launches WITH the flag are chained two deep (two lanes), launches without it wait for both lanes. */
 #define ICPFLOW_OPT_TEAMS_HALF_GPU (1u << 11)
+/* (a bit-identity switch again) ICP, teams: a wave scans its long windows alone instead of sharing them with the member's other waves */
+#define ICPFLOW_OPT_NO_SHARED_SCANS (1u << 12)
 
 typedef struct icpflow_profile icpflow_profile_t; /* opaque */
 

@@ -243,6 +243,36 @@ def test_adaptive_windows_change_nothing(shape):
     assert torch.equal(P0, utils_match.hist_icp(ap, s, d))
 
 
+@pytest.mark.parametrize("shape", ["ragged_matched_128x10000", "ragged_independent_128x10000", "teams_ragged_20x10000", "teams_12x6000",
+                                   "ragged_matched_40x4096"])
+def test_shared_window_scans_change_nothing(shape):
+    """Teams (icp.hip, round 5): a wave whose window holds 256 targets or more posts it in LDS, cut into parts; the waves of the
+    member that are through with their own unit take parts and add their (minimum, runner-up, chunk | tie) to the owner's
+    accumulator.  The merge gives what ONE scan over the window gives, whoever scanned which part: transforms and iteration
+    counts are bit-identical to ICPFLOW_OPT_NO_SHARED_SCANS (the same kernel, every wave scanning alone), under the batch rule
+    and per pair; and run-to-run (which wave takes which part is a race: the result must not depend on it)."""
+    B, N, ragged, nmin, seed, cap = {"ragged_matched_128x10000": (128, 10000, "matched", 20, 0, 100),
+                                      "ragged_independent_128x10000": (128, 10000, True, 20, 0, 100),
+                                      "teams_ragged_20x10000": (20, 10000, True, 500, 7, 50),
+                                      "teams_12x6000": (12, 6000, False, 20, 9, 50),
+                                      "ragged_matched_40x4096": (40, 4096, "matched", 200, 3, 100)}[shape]
+    S, D, _ = synthetic.make_batch(B, N, seed=seed, ragged=ragged, n_min=nmin)
+    a = rp.default_args(max_points=N, icp_max_iterations=cap)
+    s, d = G(S), G(D)
+    with _lib.options(no_shared_scans=True):
+        T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    assert int(it0) == int(it1) and int(it1) > 0
+    assert torch.isfinite(T1).all() and torch.equal(T0, T1)
+    for _ in range(3):
+        T2, it2 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert torch.equal(T1, T2) and int(it2) == int(it1)
+    ap = rp.default_args(max_points=N, icp_max_iterations=cap, icp_stop_mode="per_pair")
+    with _lib.options(no_shared_scans=True):
+        P0 = utils_match.hist_icp(ap, s, d)
+    assert torch.equal(P0, utils_match.hist_icp(ap, s, d))
+
+
 @pytest.mark.parametrize("shape", ["config4_shard_1024x2048", "ragged_2500x700", "ragged_700x3000", "dense_1500x1024", "ragged_900x2048"])
 def test_ticket_dispatch_changes_nothing(shape):
     """Batches larger than the GPU: the ICP launch is a grid as large as the GPU whose workgroups draw their further
