@@ -48,7 +48,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4", "stream"],
+                    help="stream: frame pairs dealt round-robin to the ranks (BASELINE configs 3 / 5's shape), ms / frame pair")
+    ap.add_argument("--frames", default=None, help="stream: directory of frame-pair / sequence .npz files (default: the reference's "
+                                                   "demo frame pair from tests/golden, --frame-pairs copies of it)")
+    ap.add_argument("--frame-pairs", type=int, default=None, help="stream: frame pairs per step IN TOTAL (default 64; the first so many of --frames)")
+    ap.add_argument("--in-flight", type=int, default=4, help="stream: frame pairs in flight per GPU")
+    ap.add_argument("--max-points", type=int, default=10000, help="stream: the reference's max_points (demo.sh: 10000)")
     ap.add_argument("--pairs", type=int, default=None, help="cluster pairs per step IN TOTAL (config2: 256 per GPU)")
     ap.add_argument("--points", type=int, default=None, help="points per cluster (= padded length)")
     ap.add_argument("--iters", type=int, default=50, help="ICP iteration cap (BASELINE: 50)")
@@ -130,6 +136,137 @@ def launch_selftest(a, rank, world):
         raise SystemExit("launch selftest: the gathered rows differ from the rows the ranks contributed")
 
 
+def stream_frames(a, selftest):
+    """The stream's frame pairs (the same list on every rank): --frames DIR, else copies of the reference's demo frame pair
+    (tests/golden/g8_demo*.npz; BASELINE config 1's data, the only real frame in the tree); --launch-selftest: small synthetic
+    labelled frame pairs (no GPU work is done on them).  -> (list of paths or FramePair objects, description)"""
+    from icp_flow_amd import frame_pairs, synthetic
+    total = a.frame_pairs or 64
+    if selftest:
+        fps = []
+        for k in range(total):
+            d = synthetic.make_frame_pair(seed=k, n_objects=3, n_max=60, n_background=50)
+            fps.append(frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"], d["gt_flow"], name=f"synthetic-{k}"))
+        return fps, f"{total} small synthetic frame pairs (launch selftest, no registration)"
+    if a.frames:
+        paths = frame_pairs.list_frame_pairs(a.frames)
+        if not paths:
+            raise SystemExit(f"bench.py --workload stream: no .npz under {a.frames}")
+        if a.frame_pairs:
+            paths = paths[:a.frame_pairs]
+        return paths, f"{len(paths)} files under {a.frames}"
+    gdir = os.path.join(REPO, "tests", "golden")
+    g, lab = np.load(os.path.join(gdir, "g8_demo.npz")), np.load(os.path.join(gdir, "g8_demo_labels.npz"))
+    fp = frame_pairs.FramePair(g["point_src"], g["point_dst"], lab["label_src"], lab["label_dst"], None, g["gt_flow"], name="demo.npz")
+    return [fp] * total, f"{total} copies of the reference's demo.npz frame pair (63 k points per frame, labels of the G8 fixture)"
+
+
+def stream_main(a, rank, world, local):
+    """`--workload stream` (SURVEY 8(e) second half, BASELINE.json's "ms/frame-pair"): the frame pairs are dealt round-robin to
+    the ranks (frame_pairs.shard_round_robin: a frame pair's association stays on one GPU), every rank keeps `--in-flight` of its
+    share in flight (one icpflow_track_frame call per frame pair), and ONE all_reduce per step adds up the counts -- the only
+    collective of the path.  A step = one pass over the whole stream; inputs resident in HBM; the timed region is
+    bracketed by barrier + synchronize, the max over ranks is reported.  Accuracy (EPE against the frames' ground truth)
+    comes from an untimed pass through frame_pairs.run_stream (its own all_reduce of the weighted sums).
+    --launch-selftest: the same launcher, sharding and collectives over gloo with a stand-in for the registration."""
+    import torch.distributed as dist
+    from icp_flow_amd import frame_pairs
+    selftest = a.launch_selftest
+    collective = world > 1 or a.force_collective
+    if selftest:
+        dev = torch.device("cpu")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        collective = True
+    else:
+        if torch.cuda.device_count() <= local:
+            raise SystemExit(f"bench.py: rank {rank} needs device {local}, found {torch.cuda.device_count()} device(s)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if collective:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    items, what = stream_frames(a, selftest)
+    args = frame_pairs.default_args(max_points=a.max_points)
+    mine = frame_pairs.shard_round_robin(items, rank, world)
+    counts = [len(frame_pairs.shard_round_robin(items, r, world)) for r in range(world)]
+    if selftest:
+        def stand_in(args_, fp, device):      # (what a registration returns, made up from the frame pair alone)
+            k = int(len(fp.points_src)) % 7 + 1
+            return dict(pairs=torch.zeros((k, 10)), transformations=torch.eye(4).repeat(k, 1, 1), flow=torch.from_numpy(fp.gt_flow.copy()))
+        fps = list(mine)
+    else:
+        fps = [fp for it in mine for fp in ([it] if isinstance(it, frame_pairs.FramePair) else frame_pairs.load_any(it, args))]
+        seen = {}
+        for fp in fps:                        # inputs resident in HBM (copies of one frame pair share one upload)
+            if id(fp) not in seen:
+                seen[id(fp)] = frame_pairs.make_resident(fp, dev)
+
+    def one_pass():
+        n = matched = 0
+        if selftest:
+            for fp in fps:
+                matched += int(stand_in(args, fp, dev)["pairs"].shape[0]); n += 1
+        else:
+            for _, fp, out in frame_pairs.register_in_flight(args, fps, dev, a.in_flight):
+                matched += int(out["pairs"].shape[0]); n += 1
+        tot = torch.tensor([n, matched], dtype=torch.float64, device=dev)
+        if collective:
+            dist.all_reduce(tot)              # the one collective of a step
+        return tot
+
+    def sync():
+        if collective:
+            dist.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        one_pass()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tot = one_pass()
+    sync()
+    dt = time.perf_counter() - t0
+    if collective:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    n_total, matched_total = int(tot[0].item()), int(tot[1].item())
+    # accuracy, untimed: the stream through run_stream (EPE & co. against the frames' ground truth, its one all_reduce of the sums)
+    summary = frame_pairs.run_stream(args, items, dev, rank, world, register_fn=stand_in if selftest else None,
+                                     in_flight=1 if selftest else a.in_flight)
+    if rank == 0:
+        lib = None if selftest else next((ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln or "libnccl" in ln), None)
+        from icp_flow_amd import _lib
+        out = {"metric": "ms/frame-pair (frame-pair stream)", "value": round(dt * 1e3 / max(n_total * a.steps, 1), 4),
+               "unit": "ms/frame-pair", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 4), "higher_is_better": False, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "made-up results (no GPU work)" if selftest else ("files" if a.frames else "the reference's demo.npz frame pair, replicated"),
+               "frame_pairs_per_s": round(n_total * a.steps / dt, 2),
+               "config": {"workload": f"frame-pair stream: {what}; match_pcds + per-point flow per frame pair (icpflow_track_frame), "
+                                      f"max_points {a.max_points}, {a.in_flight} frame pairs in flight per GPU, dealt round-robin to {world} rank(s)",
+                          "frame_pairs_total": len(items), "frame_pairs_per_gpu": counts, "in_flight": a.in_flight, "max_points": a.max_points,
+                          "sharding": "round-robin over ranks; ONE all_reduce of (frame pairs, matched cluster pairs) per step inside the timed region"
+                                      if collective else "one rank, no exchange step"},
+               "matched_cluster_pairs_per_step": matched_total,
+               "accuracy": {k: summary[k] for k in ("frame_pairs", "matched_cluster_pairs", "evaluated_points", "epe", "accs", "accr", "outlier", "Routlier", "pose_sources") if k in summary},
+               "reduce_check": {"frame_pairs_counted_by_all_ranks": n_total, "equals_sum_of_shares": n_total == sum(counts) == summary["frame_pairs"],
+                                "backend": dist.get_backend() if collective else None, "rccl_library": lib},
+               "library_build": None if selftest else _lib.BUILD_INFO}
+        if selftest:
+            out["launch_selftest"] = True
+        print(json.dumps(out))
+    if collective:
+        dist.destroy_process_group()
+    if not (n_total == sum(counts) == summary["frame_pairs"]):
+        raise SystemExit("stream: the ranks' frame pairs do not add up to the stream")
+
+
 def timed_steps(step, sync, steps, warmup, iters_cap):
     """W untimed steps, then exactly K steps between two (barrier + device synchronize); the launches of the
     dominant kernel are bracketed by HIP events on the stream they run on (icpflow_profile_t)."""
@@ -159,6 +296,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     a.gpus = world                          # under a launcher the world it made is the truth
+    if a.workload == "stream":
+        return stream_main(a, rank, world, local)
     if a.launch_selftest:
         return launch_selftest(a, rank, world)
     if torch.cuda.device_count() <= local:

@@ -37,3 +37,28 @@ def test_self_launch_refuses_when_devices_are_missing():
     assert r.returncode != 0
     assert f"needs {n} devices, found {torch.cuda.device_count()}" in r.stderr, r.stderr[-2000:]
     assert "Traceback" not in r.stderr
+
+
+def test_stream_workload_eight_gloo_ranks_uneven_shares():
+    """`bench.py --gpus 8 --workload stream` -- 13 frame pairs dealt round-robin to eight self-launched
+    ranks (shares 2,2,2,2,2,1,1,1), the one all_reduce per step, run_stream's summary; gloo, a stand-in for the registration
+    (`--launch-selftest`).  One JSON line naming the stream, n_gpus and the per-rank counts."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--workload", "stream", "--frame-pairs", "13", "--steps", "2", "--warmup", "1",
+                        "--launch-selftest"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["unit"] == "ms/frame-pair" and out["higher_is_better"] is False
+    assert "frame-pair stream" in out["config"]["workload"]
+    assert out["config"]["frame_pairs_per_gpu"] == [2, 2, 2, 2, 2, 1, 1, 1] and out["config"]["frame_pairs_total"] == 13
+    assert out["reduce_check"] == {"frame_pairs_counted_by_all_ranks": 13, "equals_sum_of_shares": True, "backend": "gloo", "rccl_library": None}
+    assert out["accuracy"]["frame_pairs"] == 13 and out["accuracy"]["epe"] == 0.0
+
+
+def test_stream_workload_refuses_when_devices_are_missing():
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() >= 1 else 2
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--workload", "stream", "--steps", "1"], env=_env(), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0
+    assert f"needs {n} devices, found {torch.cuda.device_count()}" in r.stderr, r.stderr[-2000:]

@@ -137,6 +137,26 @@ def test_stream_two_ranks_equals_single_process(tmp_path):
     assert np.allclose(two, want, rtol=1e-12, atol=0)
 
 
+def test_stream_eight_ranks_uneven_equals_single_process(tmp_path):
+    """World size 8, 13 frame pairs (shares of 2 and 1): the round-robin shards and the one all_reduce
+    reproduce the single-process summary; the registration is the oracle (no GPU)."""
+    paths = _tiny_stream(str(tmp_path), 13)
+    torch.set_num_threads(2)
+    one = frame_pairs.run_stream(frame_pairs.default_args(max_points=256), paths, "cpu", register_fn=_oracle_register)
+    assert one["frame_pairs"] == 13
+    assert [len(frame_pairs.shard_round_robin(paths, r, 8)) for r in range(8)] == [2, 2, 2, 2, 2, 1, 1, 1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = os.path.join(tmp_path, "eight.npy")
+    mp.spawn(_stream_worker, args=(8, port, paths, out), nprocs=8, join=True)
+    eight = np.load(out)
+    want = np.array([one[k] for k in ("frame_pairs", "matched_cluster_pairs", "evaluated_points", "epe", "accs", "accr",
+                                      "outlier", "Routlier")], dtype=np.float64)
+    assert np.array_equal(eight[:3], want[:3])                       # frame pairs, matched cluster pairs, evaluated points
+    assert np.allclose(eight[3:], want[3:], rtol=1e-6, atol=0)       # (weighted means: the sums are added in another order)
+
+
 def test_sequence_files_in_the_reference_waymo_format(tmp_path):
     """dataset_pca.py:41-45 keys -> num_frames - 1 frame pairs (frame j -> frame 0): ego compensation
     (utils_helper.py:89-93), range crop (dataset_pca.py:61-64), per-gap translation frame (main.py:200), the estimated
