@@ -38,7 +38,9 @@ __device__ __forceinline__ bool assoc_keep(const AssignParams &p, int k, float &
     const float e0 = errors[2 * k], e1 = errors[2 * k + 1];
     err = (e0 != e0 || e1 != e1) ? __int_as_float(0x7fc00000) : fminf(e0, e1);
     const bool farOff = nrm > p.tf;                                                   // (NaN: false)
-    const bool lowIou = (i0 == i0 && i1 == i1) && fminf(i0, i1) < p.iouMin;
+    // (Python's builtin min(iou) on the two-element tensor, utils_match.py:99: iou[1] if iou[1] < iou[0] else iou[0] -- a NaN in
+    // iou[1] leaves iou[0] to be tested, a NaN in iou[0] is the result and passes the comparison)
+    const bool lowIou = ((i1 < i0) ? i1 : i0) < p.iouMin;
     const bool turned = (r1 == r1 && r2 == r2) && fmaxf(fabsf(r1), fabsf(r2)) > p.rotMax;
     return !farOff && !lowIou && !turned;
 }

@@ -14,8 +14,12 @@
 // (ATen randperm_cpu: z = engine() % (n - i), swap(i, i + z)), restated here and pinned against torch in
 // tests/test_gpu_parity.py (test_native_frame_pair_equals_the_python_host, case "draws").  The result is bit for bit what utils_match.match_pcds returns with the device-side association.
 #include <hip/hip_runtime.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -32,6 +36,11 @@ namespace {
 
 constexpr int kTableRows = 512;                    // utils_check.TABLE_ROWS
 constexpr int kTableDoubles = 1 + kTableRows * 9;  // [0]: int32 number of clusters, then [L, 9] rows
+
+// host time stamps of the last icpflow_track_frame call of this thread (icpflow_debug_frame_stamps): entry, tables enqueued,
+// generator blocks ready, tables on the host, stage 1's candidates, segments + subsamples, stage 1 enqueued, all enqueued, matches read
+thread_local double g_frameStamp[9];
+inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Mt19937 {   // at::mt19937 (the engine of torch's CPU generator)
     uint32_t s[624];
@@ -54,8 +63,41 @@ struct Mt19937 {   // at::mt19937 (the engine of torch's CPU generator)
     }
     // the block of 624 words regenerated in place: three loops without index arithmetic (the first reads words the loop has not
     // written yet, the second words written 227 steps earlier: both vectorise)
+#if defined(__x86_64__)
+    // the same three loops eight words at a time (round 5: the draws nobody reads -- the tail of the 60 000-point wall's
+    // permutation -- are ~100 regenerated blocks per frame pair, the larger part of the host's time between the cluster
+    // tables and stage 1).  Loop 1 reads p[k+1 .. k+8] and p[k+397 ..] before it writes p[k .. k+7]; loop 2 reads words
+    // written 227 steps earlier: the vector steps see exactly what the scalar steps see.
+    __attribute__((target("avx2"))) void twist_avx2()
+    {
+        const __m256i U = _mm256_set1_epi32((int)0x80000000u), L = _mm256_set1_epi32(0x7fffffff), M = _mm256_set1_epi32((int)0x9908b0dfu);
+        const __m256i one = _mm256_set1_epi32(1), zero = _mm256_setzero_si256();
+        uint32_t *p = s;
+        auto step = [&](int k, int src) __attribute__((target("avx2"))) {
+            const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + k));
+            const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + k + 1));
+            const __m256i y = _mm256_or_si256(_mm256_and_si256(a, U), _mm256_and_si256(b, L));
+            const __m256i mag = _mm256_and_si256(_mm256_sub_epi32(zero, _mm256_and_si256(y, one)), M);
+            const __m256i v = _mm256_xor_si256(_mm256_xor_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + src)), _mm256_srli_epi32(y, 1)), mag);
+            _mm256_storeu_si256(reinterpret_cast<__m256i *>(p + k), v);
+        };
+        constexpr uint32_t Us = 0x80000000u, Ls = 0x7fffffffu, Ms = 0x9908b0dfu;
+        int k = 0;
+        for (; k + 8 <= 227; k += 8) step(k, k + 397);
+        for (; k < 227; ++k) { const uint32_t y = (p[k] & Us) | (p[k + 1] & Ls); p[k] = p[k + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & Ms); }
+        for (; k + 8 <= 623; k += 8) step(k, k - 227);
+        for (; k < 623; ++k) { const uint32_t y = (p[k] & Us) | (p[k + 1] & Ls); p[k] = p[k - 227] ^ (y >> 1) ^ ((0u - (y & 1u)) & Ms); }
+        const uint32_t y = (p[623] & Us) | (p[0] & Ls);
+        p[623] = p[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & Ms);
+        idx = 0;
+    }
+#endif
     void twist()
     {
+#if defined(__x86_64__)
+        static const bool avx2 = __builtin_cpu_supports("avx2");
+        if (avx2) { twist_avx2(); return; }
+#endif
         constexpr uint32_t U = 0x80000000u, L = 0x7fffffffu, M = 0x9908b0dfu;
         uint32_t *p = s;
         for (int k = 0; k < 227; ++k) {
@@ -92,20 +134,84 @@ struct Mt19937 {   // at::mt19937 (the engine of torch's CPU generator)
     }
 };
 
-// torch.randperm(n, generator)[0:take] as int32 (n < 2^32 / 20: the 32-bit branch of randperm_cpu)
-void randperm_head(Mt19937 &g, int64_t n, int take, int32_t *out, std::vector<int32_t> &tmp)
-{
-    tmp.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = (int32_t)i;
-    // step i fixes element i for good: the first `take` steps give the head; the rest of the shuffle only has to consume its
-    // draws (the next randperm continues on the same generator)
-    const int64_t steps = std::min<int64_t>(take, n - 1);
-    for (int64_t i = 0; i < steps; ++i) {
-        const int64_t z = (int64_t)(g.next() % (uint64_t)(n - i));
-        std::swap(tmp[(size_t)i], tmp[(size_t)(i + z)]);
+// The generator's output as a STREAM that can be generated ahead of its use: the state blocks (624 words each, untempered) from the
+// generator's current one on, kept one after the other.  Draw number p of the stream is word (idx0 + p) % 624 of block
+// (idx0 + p) / 624, tempered on demand; consuming draws is moving a position.  icpflow_track_frame regenerates the blocks a
+// frame pair may need while it waits for the cluster tables (the GPU is busy with them for ~0.1 ms, the host is not): what
+// is left between the tables and stage 1 is the few thousand draws that are actually read.
+struct MtStream {
+    std::vector<uint32_t> &blocks;  // [nBlocks][624] (the caller's buffer: it keeps its capacity from frame pair to frame pair)
+    Mt19937 tail;                   // the generator at the last block generated
+    int idx0;                       // position inside block 0 at which the stream starts (624: block 0 is used up)
+    int64_t pos = 0;                // draws consumed
+    MtStream(const Mt19937 &g, std::vector<uint32_t> &buffer) : blocks(buffer), tail(g), idx0(g.idx)
+    {
+        blocks.clear();
+        if (blocks.capacity() < ((size_t)1 << 18) + 3 * 624) blocks.reserve(((size_t)1 << 18) + 3 * 624);
+        blocks.insert(blocks.end(), g.s, g.s + 624);
     }
-    g.skip(n - 1 - steps);
-    std::memcpy(out, tmp.data(), sizeof(int32_t) * (size_t)take);
+    int64_t covered() const { return (int64_t)(blocks.size() / 624) * 624 - idx0; }   // draws the blocks hold
+    void ensure(int64_t draws)      // blocks for the first `draws` draws of the stream
+    {
+        while (covered() < draws) {
+            tail.twist();
+            blocks.insert(blocks.end(), tail.s, tail.s + 624);
+        }
+    }
+    static uint32_t temper(uint32_t y)
+    {
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    uint32_t draw(int64_t p) const { return temper(blocks[(size_t)(idx0 + p)]); }   // (p < covered())
+    // the generator after `pos` draws, in the form the draw-by-draw engine leaves it (a block used up stays, with idx = 624)
+    Mt19937 state() const
+    {
+        const int64_t q = idx0 + pos;
+        int64_t b = q / 624;
+        int i = (int)(q % 624);
+        if (i == 0 && b > 0) { --b; i = 624; }
+        Mt19937 g(0u);
+        std::memcpy(g.s, blocks.data() + (size_t)b * 624, sizeof(g.s));
+        g.idx = i;
+        return g;
+    }
+};
+
+// torch.randperm(n, generator)[0:take] as int32 (n < 2^32 / 20: the 32-bit branch of randperm_cpu)
+// `tmp` is kept as the IDENTITY between calls (entries are set when it grows; the places a call writes are put back at its
+// end): writing 60 000 indices per draw cost as much as the draw itself.
+void randperm_head(MtStream &g, int64_t n, int take, int32_t *out, std::vector<int32_t> &tmp)
+{
+    static thread_local std::vector<int32_t> places;
+    if ((int64_t)tmp.size() < n) {
+        const size_t old = tmp.size();
+        tmp.resize((size_t)n);
+        for (size_t i = old; i < (size_t)n; ++i) tmp[i] = (int32_t)i;
+    }
+    // step i of the shuffle swaps places i and i + z and fixes place i for good: the first `take` steps give the head; the
+    // rest of the shuffle only consumes its draws (the next randperm continues on the same stream).  Place i is never read
+    // again, so only the other half of the swap is carried out.
+    const int64_t steps = std::min<int64_t>(take, n - 1);
+    if ((int64_t)places.size() < steps) places.resize((size_t)steps);
+    g.ensure(g.pos + steps);
+    const uint32_t n32 = (uint32_t)n;
+    int32_t *t = tmp.data(), *pl = places.data();
+    const int64_t p0 = g.pos;
+    for (int64_t i = 0; i < steps; ++i) {
+        // (on 32-bit operands: the draw is a 32-bit word and n - i < 2^32 -- the value of the reference's 64-bit remainder)
+        const uint32_t z = g.draw(p0 + i) % (n32 - (uint32_t)i);
+        const int32_t place = (int32_t)((uint32_t)i + z);
+        out[i] = t[place];
+        t[place] = t[i];
+        pl[i] = place;
+    }
+    if (steps < take) out[steps] = t[steps];   // (take == n: the last element stays where the shuffle left it)
+    g.pos += n - 1;                            // (the draws of the steps nobody reads are passed over)
+    for (int64_t i = 0; i < steps; ++i) t[pl[i]] = pl[i];   // back to the identity
 }
 
 // numpy's minimum / maximum: a NaN on either side gives NaN
@@ -151,8 +257,12 @@ inline bool pair_passes(const Table &st, const Table &dt, int s, int d, float tr
     // sqrt(sum) > translation_frame, decided without the root away from the threshold (the root is correctly rounded and
     // monotone: it can only disagree with the comparison of the squares within a few ulps of equality)
     const float t2 = translationFrame * translationFrame;
-    if (sum > t2 * 1.000001f) return false;
-    if (!(sum < t2 * 0.999999f) && std::sqrt(sum) > translationFrame) return false;
+    if (!(translationFrame >= 0.f)) {          // (a negative threshold rejects every pair, a NaN none: the comparison as written)
+        if (std::sqrt(sum) > translationFrame) return false;
+    } else {
+        if (sum > t2 * 1.000001f) return false;
+        if (!(sum < t2 * 0.999999f) && std::sqrt(sum) > translationFrame) return false;
+    }
     for (int k = 0; k < 3; ++k) {
         const float es = st.extent[3 * s + k], ed = dt.extent[3 * d + k];
         const float rhs = thresBox * np_max(es, ed);
@@ -161,10 +271,46 @@ inline bool pair_passes(const Table &st, const Table &dt, int s, int d, float tr
     return true;
 }
 
+// the destination rows that pass the pairwise sanity test with source row s (and are usable themselves: dOk), in ascending
+// order -- what the loop "for b: if (dOk[b] && pair_passes(s, b))" visits.  A frame has ~150 x 150 cluster pairs of which a
+// few hundred pass: the distance test runs first over contiguous arrays (a loop the compiler vectorises), the exact test
+// (the root near the threshold, the extents) only on its survivors.
+struct PassRows {
+    std::vector<float> mx, my;      // destination means
+    std::vector<uint8_t> near;
+    void init(const Table &dt)
+    {
+        mx.resize(dt.L); my.resize(dt.L); near.resize(dt.L);
+        for (int d = 0; d < dt.L; ++d) { mx[d] = dt.mean[3 * d]; my[d] = dt.mean[3 * d + 1]; }
+    }
+    template <typename F>
+    void for_each(const Table &st, const Table &dt, const std::vector<uint8_t> &dOk, int s, float tf, float tb, F &&visit)
+    {
+        const int D = dt.L;
+        const float sx = st.mean[3 * s], sy = st.mean[3 * s + 1];
+        const float lim = tf * tf * 1.000001f;
+        const bool filter = tf >= 0.f;      // (a negative or NaN threshold: the comparison as written decides, see pair_passes)
+        const float *px = mx.data(), *py = my.data();
+        const uint8_t *ok = dOk.data();
+        uint8_t *nr = near.data();
+        for (int d = 0; d < D; ++d) {
+            const float dx = px[d] - sx, dy = py[d] - sy;
+            const float sum = dx * dx + dy * dy;
+            nr[d] = (uint8_t)(ok[d] & (uint8_t)(!filter | !(sum > lim)));   // (a NaN is not rejected here, like in pair_passes)
+        }
+        for (int d = 0; d < D; ++d)
+            if (nr[d] && pair_passes(st, dt, s, d, tf, tb)) visit(d);
+    }
+};
+
 struct Pinned {   // a pinned host buffer that grows (read in place by the kernels / target of the read-backs)
     void *ptr = nullptr;
     size_t bytes = 0;
     int device = -1;
+    Pinned() = default;
+    Pinned(const Pinned &) = delete;
+    Pinned &operator=(const Pinned &) = delete;
+    ~Pinned() { if (ptr != nullptr) (void)hipHostFree(ptr); }   // (thread_local: freed when the host thread ends)
     char *need(size_t want)
     {
         int dev = -1;
@@ -183,6 +329,7 @@ struct Pinned {   // a pinned host buffer that grows (read in place by the kerne
 struct Host {   // per host thread
     Pinned main, second;   // (second: the exact stage 2 of a frame pair whose superset fell short -- the first is still in use then)
     std::vector<int32_t> perm;
+    std::vector<uint32_t> draws;   // the generator's blocks of the frame pair at hand (MtStream)
     char *need(size_t bytes) { return main.need(bytes); }
 };
 
@@ -192,10 +339,15 @@ struct Host {   // per host thread
 // 0.86 -> 0.72 / 1.01 -> 0.91 ms per frame pair with four in flight).
 inline hipError_t wait_stream(hipStream_t s)
 {
-    for (int spin = 0; spin < 200000; ++spin) {
+    // (bounded by TIME: ~2 ms of polling -- a frame pair's own waits are fractions of a millisecond --, then the runtime blocks)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; ++spin) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
+        if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
     return hipStreamSynchronize(s);
 }
@@ -222,6 +374,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     *h_pairs = ICPFLOW_FRAME_HOST_PATH;
     hipStream_t s = (hipStream_t)stream;
     static thread_local Host H;
+    g_frameStamp[0] = now_us();
 
     // ---- device scratch, first part: the label-sorted orders, both tables, the tables' workspace
     char *base = static_cast<char *>(d_scratch);
@@ -244,9 +397,19 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
         return r;
     const size_t tableBytes = sizeof(double) * 2 * kTableDoubles;
     char *pin = H.need(tableBytes);
-    if (pin == nullptr) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: no pinned host memory");
-    if (hipMemcpyAsync(pin, tabS, tableBytes, hipMemcpyDeviceToHost, s) != hipSuccess || wait_stream(s) != hipSuccess)
+    if (pin == nullptr) return report_error(ICPFLOW_E_HOSTMEM, "icpflow_track_frame: no pinned host memory");
+    if (hipMemcpyAsync(pin, tabS, tableBytes, hipMemcpyDeviceToHost, s) != hipSuccess)
         return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the cluster tables failed");
+    // the frame pair's stream of draws: the caller's generator (advanced only if this call serves the frame pair) or a seed.
+    // While the GPU forms the tables: the blocks of the generator that the subsamples of over-long clusters can consume -- a
+    // randperm of every point of both clouds at most (frames without such a cluster: ~60 us of a host thread that waits anyway)
+    g_frameStamp[1] = now_us();   // tables enqueued
+    MtStream gen(par->generator != nullptr ? Mt19937(*par->generator) : Mt19937((uint32_t)par->seed), H.draws);
+    gen.ensure(std::min<int64_t>((int64_t)n_src + n_dst, (int64_t)1 << 18));
+    g_frameStamp[2] = now_us();   // blocks of the generator ready
+    if (wait_stream(s) != hipSuccess)
+        return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the cluster tables failed");
+    g_frameStamp[3] = now_us();   // tables on the host
     Table st, dt;
     st.set(reinterpret_cast<const double *>(pin));
     dt.set(reinterpret_cast<const double *>(pin) + kTableDoubles);
@@ -283,16 +446,15 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     // No cluster keeps its label and passes: the reference goes on with stage 2 alone, every source against every destination
     // through the sanity check (utils_match.py:42-53 with nothing matched) -- registered here as the only stage, in its order.
     const bool stage2Only = si1.empty();
+    PassRows rowsOf;
+    rowsOf.init(dt);
     if (stage2Only)
         for (int a = 0; a < S; ++a) {
             if (!sOk[a]) continue;
-            for (int b = 0; b < D; ++b)
-                if (dOk[b] && pair_passes(st, dt, a, b, tf, tb)) {
-                    si1.push_back(a);
-                    di1.push_back(b);
-                }
+            rowsOf.for_each(st, dt, dOk, a, tf, tb, [&](int b) { si1.push_back(a); di1.push_back(b); });
         }
     const int K1 = (int)si1.size();
+    g_frameStamp[4] = now_us();   // stage 1's candidates
     if (K1 == 0) return 0;   // (nothing to register at all: left to the caller)
 
     // ---- stage 1's segment rows and subsamples (utils_match._stage_rows), in pinned memory the kernels read in place
@@ -310,8 +472,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     int64_t longest2 = 0;
     for (int a = 0; a < S && !stage2Only; ++a) {
         if (!sOk[a]) continue;
-        for (int b = 0; b < D; ++b) {
-            if (!dOk[b] || !pair_passes(st, dt, a, b, tf, tb)) continue;
+        rowsOf.for_each(st, dt, dOk, a, tf, tb, [&](int b) {
             if (st.count[a] > capPts || dt.count[b] > capPts) {
                 leftS.push_back(a);
                 leftD.push_back(b);
@@ -320,7 +481,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
                 di2.push_back(b);
                 longest2 = std::max(longest2, std::max(st.count[a], dt.count[b]));
             }
-        }
+        });
     }
     const int K2 = (int)si2.size();
     int N2 = K2 ? std::min(capPts, std::max(64, round64(longest2))) : 64;
@@ -345,14 +506,13 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     const size_t pIdx = pSeg2 + 48 * (size_t)K2, pBest = up(pIdx + 8 * ((size_t)K1 + K2));
     const size_t pinBytes = pBest + 4 * (2 * (size_t)S + 2);
     pin = H.need(pinBytes);   // (the tables have been parsed: the buffer may move)
-    if (pin == nullptr) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: no pinned host memory");
+    if (pin == nullptr) return report_error(ICPFLOW_E_HOSTMEM, "icpflow_track_frame: no pinned host memory");
     int64_t *seg1 = reinterpret_cast<int64_t *>(pin + pSeg1);
     int32_t *perm = reinterpret_cast<int32_t *>(pin + pPerm);
     int64_t *seg2 = reinterpret_cast<int64_t *>(pin + pSeg2);
     int32_t *idx = reinterpret_cast<int32_t *>(pin + pIdx);
     int32_t *hBest = reinterpret_cast<int32_t *>(pin + pBest);
     // the frame pair's stream of draws: the caller's generator (advanced only if this call serves the frame pair) or a seed
-    Mt19937 gen = par->generator != nullptr ? Mt19937(*par->generator) : Mt19937((uint32_t)par->seed);
     {
         int drawn = 0;
         for (int k = 0; k < K1; ++k) {
@@ -382,6 +542,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
         std::memcpy(idx + 2 * K1 + K2, di2.data(), 4 * (size_t)K2);
     }
 
+    g_frameStamp[5] = now_us();   // segments, subsamples, stage 2's superset
     // ---- everything else is enqueued: stage 1, then the assignment / stage 2 / assignment / pair rows / flow
     icpflow_tables_t tables{d_points_src, orderS, tabS + 1, d_points_dst, orderD, tabD + 1, S, D, 9};
     icpflow_stage_t stage1{seg1, nPerm ? perm : nullptr, idx, idx + K1, reinterpret_cast<float *>(base + oClouds1),
@@ -389,6 +550,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     icpflow_stage_t stage2{seg2, nullptr, idx + 2 * K1, idx + 2 * K1 + K2, reinterpret_cast<float *>(base + oClouds2),
                            reinterpret_cast<float *>(base + oRes2), K2, N2};
     if (int r = icpflow_register_stage(&tables, &stage1, reg, base + oWs, std::max(ws1, ws2), stream, opt)) return r;
+    g_frameStamp[6] = now_us();   // stage 1 enqueued
     int32_t *dBest = reinterpret_cast<int32_t *>(base + oBest);
     const int cap = 2 * S;
     if (int r = icpflow_associate_frame(&tables, &stage1, K2 ? &stage2 : nullptr, reinterpret_cast<uint8_t *>(base + oActive), reg,
@@ -396,9 +558,11 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
                                         d_rows, d_T, d_flow_points, d_flow != nullptr ? d_labels_src : nullptr, n_src, d_pose,
                                         d_flow, base + oWs, std::max(ws1, ws2), stream, opt))
         return r;
+    g_frameStamp[7] = now_us();   // everything enqueued
     if (hipMemcpyAsync(hBest, dBest, 4 * (2 * (size_t)S + 2), hipMemcpyDeviceToHost, s) != hipSuccess ||
         wait_stream(s) != hipSuccess)
         return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: the read-back of the matches failed");
+    g_frameStamp[8] = now_us();   // matches on the host
     const int P0 = hBest[2 * S];
     if (P0 < 0) {
         *h_pairs = ICPFLOW_FRAME_ABANDONED;   // a team's wait timed out: the transforms are NaN (include/icpflow_hip.h, a-5)
@@ -427,13 +591,13 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
         if (matched < unq.size()) {                                                                    // :42
             for (int a = 0; a < S; ++a) {
                 if (mS[a] || !sOk[a]) continue;
-                for (int b = 0; b < D; ++b) {
-                    if (mD[b] || !dOk[b] || !pair_passes(st, dt, a, b, tf, tb)) continue;
+                rowsOf.for_each(st, dt, dOk, a, tf, tb, [&](int b) {
+                    if (mD[b]) return;
                     si3.push_back(a);
                     di3.push_back(b);
                     longest3 = std::max(longest3, std::max(st.count[a], dt.count[b]));
                     nPerm3 += (st.count[a] > maxPoints) + (dt.count[b] > maxPoints);
-                }
+                });
             }
         }
         const int K3 = (int)si3.size();
@@ -446,7 +610,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
         if (scratch_bytes < off) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: scratch too small (see *scratch_needed)");
         const size_t qPerm = 48 * (size_t)K3, qIdx = up(qPerm + 4 * (size_t)nPerm3 * maxPoints), qBest = up(qIdx + 8 * (size_t)K3);
         char *pin3 = H.second.need(qBest + 4 * (2 * (size_t)S + 2));
-        if (pin3 == nullptr) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: no pinned host memory");
+        if (pin3 == nullptr) return report_error(ICPFLOW_E_HOSTMEM, "icpflow_track_frame: no pinned host memory");
         int64_t *seg3 = reinterpret_cast<int64_t *>(pin3);
         int32_t *perm3 = reinterpret_cast<int32_t *>(pin3 + qPerm), *idx3 = reinterpret_cast<int32_t *>(pin3 + qIdx);
         int32_t *hBest3 = reinterpret_cast<int32_t *>(pin3 + qBest);
@@ -495,7 +659,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
             return 0;
         }
     }
-    if (par->generator != nullptr) gen.save(par->generator);
+    if (par->generator != nullptr) { gen.ensure(gen.pos); gen.state().save(par->generator); }
     *h_pairs = P;
     return 0;
 }
@@ -504,9 +668,19 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
 extern "C" int icpflow_selftest_randperm(icpflow_mt19937_t *gen, int64_t n, int take, int32_t *h_out)
 {
     if (!gen || !h_out || n <= 0 || take < 0 || take > n) return report_error(ICPFLOW_E_ARG, "icpflow_selftest_randperm: bad argument");
-    Mt19937 g(*gen);
-    std::vector<int32_t> tmp;
+    static thread_local std::vector<uint32_t> buffer;
+    MtStream g(Mt19937(*gen), buffer);
+    static thread_local std::vector<int32_t> tmp;
     randperm_head(g, n, take, h_out, tmp);
-    g.save(gen);
+    g.ensure(g.pos);
+    g.state().save(gen);
+    return 0;
+}
+
+// developer tool: the host's time stamps (microseconds, steady clock) inside the calling thread's last icpflow_track_frame
+extern "C" int icpflow_debug_frame_stamps(double *out9)
+{
+    if (!out9) return ICPFLOW_E_ARG;
+    for (int k = 0; k < 9; ++k) out9[k] = g_frameStamp[k];
     return 0;
 }

@@ -6,12 +6,10 @@
 // through device scalars).  Here: rows sorted by label (stable: the rows of a cluster keep their order, which the
 // reference's random subsample of over-long clusters indexes into, utils_helper.py:198-201), the distinct labels with
 // their row ranges, and per cluster the centroid and sorted bounding-box extents (utils_check.py:34-43,
-// get_bbox_tensor utils_helper.py:166-170) -- key kernel, one radix sort, boundary kernel, row kernel, statistics
-// kernel, back to back on the caller's stream, where a chain of ~25 small ATen kernels (argsort, unique_consecutive,
-// cumsum, casts, cat) ran before.
+// get_bbox_tensor utils_helper.py:166-170) -- a stable counting sort by label (dictionary, counts, scan, scatter) and the
+// statistics kernel, five launches back to back on the caller's stream, where a chain of ~25 small ATen kernels (argsort,
+// unique_consecutive, cumsum, casts, cat) ran before.
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -19,7 +17,6 @@
 namespace icpflow {
 namespace {
 
-constexpr int kTableBlock = 256;
 constexpr int kRowsBlock = 1024;
 constexpr int kTableCols = 9;   // label, count, start, mean (3), sorted bbox extents (3)
 
@@ -37,9 +34,21 @@ __device__ __forceinline__ float unsortable(uint32_t k)
     return __int_as_float((int)u);
 }
 
-// One chain serves one labelled cloud (32-bit keys) or the TWO clouds of a frame pair at once (64-bit keys: the cloud's
-// number above the label's 32 bits, so that one sort leaves cloud 0's rows in front of cloud 1's): half as many launches
-// on the path of a frame pair, where every launch of the chain is a few microseconds of work behind a dispatch.
+// One chain serves one labelled cloud or the TWO clouds of a frame pair at once (the kernels take the cloud from the block
+// index): half as many launches on the path of a frame pair, where every launch is a few microseconds of work behind a dispatch.
+//
+// Round 5: a stable COUNTING sort by label in four launches instead of a radix sort of (label, row) pairs in thirteen
+// (rocprim::radix_sort_pairs: ~70 us of GPU time and ~40 us of host enqueue per frame pair, two thirds of the chain).  A
+// frame has at most a few hundred distinct labels (Lmax <= 4096 rows in the table; more: the table reports overflow, as
+// before), so:
+//   1. table_dict_kernel    one workgroup per cloud: the distinct labels through a hash set in LDS, sorted -> dict, number
+//   2. table_count_kernel   one workgroup per chunk of kChunkRows rows: row -> index of its label in dict (binary search in
+//                           LDS), counts per (chunk, label)
+//   3. table_scan_kernel    one workgroup per cloud: per label the running offsets over the chunks, the exclusive scan over
+//                           the labels -> (label, count, start) rows of the table, first position of every (chunk, label)
+//   4. table_scatter_kernel one WAVE per chunk: rows to their places in chunk order and, inside a chunk, in row order
+//                           (ranks among the lanes of equal label by ballots: stable, deterministic)
+// then the statistics kernel as before.
 struct TableSides {
     const float *points[2];
     const float *labels[2];
@@ -47,72 +56,224 @@ struct TableSides {
     int64_t *order[2];
     double *table[2];
     int32_t *num[2];
-    int *bnd[2];
-    int *counter;          // [2]
+    uint32_t *dict[2];     // [Lmax] distinct labels (sortable bits), ascending
+    int *start[2];         // [Lmax] first position of every label
+    uint16_t *rowOf;       // [M0 + M1] index of the row's label in dict
+    int *counts;           // [chunks of both clouds][Lmax]
+    int chunks0;           // chunks of cloud 0 (the chunks of cloud 1 follow)
 };
 
-template <typename KeyT>
-__global__ __launch_bounds__(kTableBlock) void table_key_kernel(TableSides t, KeyT *__restrict__ key,
-                                                                uint32_t *__restrict__ val)
+constexpr int kChunkRows = 512;
+constexpr int kDictSlots = 8192, kDictMax = 4096;
+constexpr uint32_t kEmpty = 0xffffffffu;
+
+__device__ __forceinline__ uint32_t label_key(float f)
 {
-    const int i = blockIdx.x * kTableBlock + threadIdx.x;
-    if (i < 2) t.counter[i] = 0;
-    if (i >= t.M[0] + t.M[1]) return;
-    const int side = i >= t.M[0] ? 1 : 0, local = i - (side ? t.M[0] : 0);
-    KeyT k = (KeyT)sortable(t.labels[side][local]);
-    if constexpr (sizeof(KeyT) == 8) k |= (KeyT)side << 32;
-    key[i] = k;
-    val[i] = (uint32_t)local;
+    const uint32_t k = sortable(f);
+    return k == kEmpty ? kEmpty - 1u : k;    // (one NaN payload shares the empty mark's pattern)
 }
 
-template <typename KeyT>
-__global__ __launch_bounds__(kTableBlock) void table_boundary_kernel(TableSides t, const KeyT *__restrict__ key,
-                                                                     const uint32_t *__restrict__ val, int Lmax)
+__global__ __launch_bounds__(1024) void table_dict_kernel(TableSides t, int Lmax)
 {
-    const int i = blockIdx.x * kTableBlock + threadIdx.x;
-    if (i >= t.M[0] + t.M[1]) return;
-    const int side = i >= t.M[0] ? 1 : 0, local = i - (side ? t.M[0] : 0);
-    t.order[side][local] = (int64_t)val[i];
-    if (local == 0 || key[i] != key[i - 1]) {
-        const int slot = atomicAdd(&t.counter[side], 1);
-        if (slot < Lmax) t.bnd[side][slot] = local;
+    __shared__ uint32_t slot[kDictSlots];
+    __shared__ uint32_t list[kDictMax];
+    __shared__ int nFound, nListed;
+    const int side = blockIdx.x, tid = threadIdx.x, M = t.M[side];
+    const float *labels = t.labels[side];
+    for (int k = tid; k < kDictSlots; k += 1024) slot[k] = kEmpty;
+    if (tid == 0) { nFound = 0; nListed = 0; }
+    __syncthreads();
+    uint32_t last = kEmpty;
+    constexpr int kPer = 8;                       // rows per thread and round: the loads of a round are in flight together
+    for (int i0 = 0; i0 < M; i0 += 1024 * kPer) {
+        float v[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int i = i0 + u * 1024 + tid;
+            v[u] = labels[min(i, M - 1)];         // (clamped: the last row once more)
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t k = label_key(v[u]);
+            if (k == last) continue;              // (rows 1024 apart often share their label: ground, noise)
+            last = k;
+            uint32_t h = (k * 2654435761u) >> 19; // 13 bits
+            for (int probe = 0; probe < kDictSlots; ++probe) {
+                const uint32_t seen = slot[h];    // (a plain read first: most rows find their label already there)
+                if (seen == k) break;
+                if (seen == kEmpty) {
+                    const uint32_t old = atomicCAS(&slot[h], kEmpty, k);
+                    if (old == k) break;
+                    if (old == kEmpty) { atomicAdd(&nFound, 1); break; }
+                }
+                h = (h + 1) & (kDictSlots - 1);
+                if (nFound > kDictMax) break;     // (more labels than any table holds: the count is all that is reported)
+            }
+        }
     }
-}
-
-// one workgroup per cloud: the boundaries in ascending order -> (label, count, start) of every cluster
-template <typename KeyT>
-__global__ __launch_bounds__(kRowsBlock) void table_rows_kernel(TableSides t, const KeyT *__restrict__ keyAll, int Lmax)
-{
-    extern __shared__ int sb[];
-    const int side = blockIdx.x;
-    const KeyT *key = keyAll + (side ? t.M[0] : 0);
-    const int M = t.M[side];
-    const int *bnd = t.bnd[side];
-    double *table = t.table[side];
-    const int found = t.counter[side];
-    const int n = min(found, Lmax);
+    __syncthreads();
+    const int found = nFound;
+    if (found > Lmax) {
+        if (tid == 0) *t.num[side] = -found;      // < 0: more clusters than the table holds (a lower bound beyond kDictMax)
+        return;
+    }
+    for (int k = tid; k < kDictSlots; k += 1024)
+        if (slot[k] != kEmpty) list[atomicAdd(&nListed, 1)] = slot[k];
+    __syncthreads();
+    if (found <= 1024) {
+        // few labels (a frame has a few hundred): every label counts the smaller ones -- its place in the sorted order -- with
+        // all threads reading the same word per step (a broadcast), instead of ~40 barrier-separated stages of a sorting network
+        const uint32_t mine = tid < found ? list[tid] : kEmpty;
+        int rank = 0;
+        for (int j = 0; j < found; ++j) rank += list[j] < mine ? 1 : 0;
+        if (tid < found) t.dict[side][rank] = mine;
+        if (tid == 0) *t.num[side] = found;
+        return;
+    }
     int P = 1;
-    while (P < n) P <<= 1;
-    for (int k = threadIdx.x; k < P; k += kRowsBlock) sb[k] = k < n ? bnd[k] : 0x7fffffff;
+    while (P < found) P <<= 1;
+    for (int k = found + tid; k < P; k += 1024) list[k] = kEmpty;
     __syncthreads();
     for (int len = 2; len <= P; len <<= 1)
         for (int stride = len >> 1; stride > 0; stride >>= 1) {
-            for (int u = threadIdx.x; u < P / 2; u += kRowsBlock) {
+            for (int u = tid; u < P / 2; u += 1024) {
                 const int lo = (u / stride) * 2 * stride + (u % stride), hi = lo + stride;
                 const bool up = ((lo & len) == 0);
-                const int a = sb[lo], b = sb[hi];
-                if ((a > b) == up) { sb[lo] = b; sb[hi] = a; }
+                const uint32_t a = list[lo], b = list[hi];
+                if ((a > b) == up) { list[lo] = b; list[hi] = a; }
             }
             __syncthreads();
         }
-    for (int c = threadIdx.x; c < n; c += kRowsBlock) {
-        const int start = sb[c], end = (c + 1 < n) ? sb[c + 1] : M;
-        double *row = table + (size_t)c * kTableCols;
-        row[0] = (double)unsortable((uint32_t)key[start]);
-        row[1] = (double)(end - start);
-        row[2] = (double)start;
+    for (int k = tid; k < found; k += 1024) t.dict[side][k] = list[k];
+    if (tid == 0) *t.num[side] = found;
+}
+
+__global__ __launch_bounds__(256) void table_count_kernel(TableSides t, int Lmax)
+{
+    __shared__ uint32_t dict[kDictMax];
+    __shared__ int cnt[kDictMax];
+    const int side = (int)blockIdx.x >= t.chunks0 ? 1 : 0, chunk = blockIdx.x - (side ? t.chunks0 : 0);
+    const int n = *t.num[side];
+    if (n <= 0) return;
+    const int tid = threadIdx.x, M = t.M[side], base = side ? t.M[0] : 0;
+    for (int k = tid; k < n; k += 256) { dict[k] = t.dict[side][k]; cnt[k] = 0; }
+    __syncthreads();
+    uint32_t lastK = kEmpty;
+    int lastR = 0;
+    for (int j = tid; j < kChunkRows; j += 256) {
+        const int i = chunk * kChunkRows + j;
+        if (i >= M) break;
+        const uint32_t k = label_key(t.labels[side][i]);
+        int r = lastR;
+        if (k != lastK) {
+            int lo = 0, hi = n - 1;               // (the key is in the dictionary)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (dict[mid] < k) lo = mid + 1; else hi = mid;
+            }
+            r = lo; lastK = k; lastR = r;
+        }
+        atomicAdd(&cnt[r], 1);
+        t.rowOf[base + i] = (uint16_t)r;
     }
-    if (threadIdx.x == 0) *t.num[side] = found <= Lmax ? found : -found;   // < 0: more clusters than the table holds
+    __syncthreads();
+    int *out = t.counts + (size_t)blockIdx.x * Lmax;
+    for (int k = tid; k < n; k += 256) out[k] = cnt[k];
+}
+
+__global__ __launch_bounds__(1024) void table_scan_kernel(TableSides t, int Lmax)
+{
+    __shared__ int part[1024 / kWave];
+    __shared__ int carrySh;
+    const int side = blockIdx.x, tid = threadIdx.x;
+    const int n = *t.num[side];
+    if (n <= 0) return;
+    const int chunks = side ? ((t.M[1] + kChunkRows - 1) / kChunkRows) : t.chunks0;
+    int *counts = t.counts + (size_t)(side ? t.chunks0 : 0) * Lmax;
+    double *table = t.table[side];
+    if (tid == 0) carrySh = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < n; r0 += 1024) {        // labels in rounds of 1024 (one round for the tables of a frame)
+        const int r = r0 + tid;
+        int total = 0;
+        if (r < n)
+            for (int c0 = 0; c0 < chunks; c0 += 16) {   // the label's rows before chunk c (sixteen loads in flight at a time)
+                int v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = counts[(size_t)min(c0 + u, chunks - 1) * Lmax + r];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (c0 + u < chunks) {
+                        counts[(size_t)(c0 + u) * Lmax + r] = total;
+                        total += v[u];
+                    }
+            }
+        // exclusive scan of the totals over the labels (ascending): where the label's rows start
+        int incl = total;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const int up = __shfl_up(incl, o, kWave);
+            if ((tid & (kWave - 1)) >= o) incl += up;
+        }
+        if ((tid & (kWave - 1)) == kWave - 1) part[tid >> 6] = incl;
+        __syncthreads();
+        int before = carrySh;
+        for (int w = 0; w < (tid >> 6); ++w) before += part[w];
+        const int start = before + incl - total;
+        if (r < n) {
+            t.start[side][r] = start;
+            double *row = table + (size_t)r * kTableCols;
+            row[0] = (double)unsortable(t.dict[side][r]);
+            row[1] = (double)total;
+            row[2] = (double)start;
+        }
+        __syncthreads();
+        if (tid == 1023) carrySh = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kWave) void table_scatter_kernel(TableSides t, int Lmax)
+{
+    __shared__ int cur[kDictMax];
+    const int side = (int)blockIdx.x >= t.chunks0 ? 1 : 0, chunk = blockIdx.x - (side ? t.chunks0 : 0);
+    const int n = *t.num[side];
+    if (n <= 0) return;
+    const int lane = threadIdx.x, M = t.M[side], base = side ? t.M[0] : 0;
+    const int *mine = t.counts + (size_t)blockIdx.x * Lmax;
+    for (int k = lane; k < n; k += kWave) cur[k] = mine[k] + t.start[side][k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int64_t *order = t.order[side];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rr[kChunkRows / kWave];
+#pragma unroll
+    for (int u = 0; u < kChunkRows / kWave; ++u) {
+        const int i = chunk * kChunkRows + u * kWave + lane;
+        rr[u] = i < M ? (int)t.rowOf[base + i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kChunkRows / kWave; ++u) {
+        const int i = chunk * kChunkRows + u * kWave + lane;
+        const bool valid = i < M;
+        const int r = rr[u];
+        unsigned long long todo = __ballot(valid);
+        while (todo != 0ull) {                    // one label of the round at a time, in lane order inside it
+            const int leader = __builtin_ctzll(todo);
+            const int rl = __builtin_amdgcn_readlane(r, leader);
+            const unsigned long long m = __ballot(valid && r == rl);
+            const int first = cur[rl];
+            if (valid && r == rl) order[first + __popcll(m & below)] = (int64_t)i;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) cur[rl] = first + __popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            todo &= ~m;
+        }
+    }
 }
 
 // one workgroup per cluster: centroid (fp64 sums) and sorted bounding-box extents; clusters with a negative label
@@ -135,15 +296,26 @@ __global__ __launch_bounds__(kRowsBlock) void table_stats_kernel(TableSides t)
     }
     double sum[3] = {0.0, 0.0, 0.0};
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = threadIdx.x; i < n; i += kRowsBlock) {
-        const int64_t r = order[s0 + i];
+    // (four rows of a thread at a time: their loads -- the position, then the point it names -- are in flight together; the sums
+    // are added in the rows' order, as a loop over single rows adds them)
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4 * kRowsBlock) {
+        int64_t r[4];
+        float v[4][3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float v = points[r * 3 + k];
-            sum[k] += (double)v;
-            mn[k] = fminf(mn[k], v);
-            mx[k] = fmaxf(mx[k], v);
-        }
+        for (int u = 0; u < 4; ++u) r[u] = order[s0 + min(i0 + (int64_t)u * kRowsBlock, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[u][k] = points[r[u] * 3 + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + (int64_t)u * kRowsBlock < n)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    sum[k] += (double)v[u][k];
+                    mn[k] = fminf(mn[k], v[u][k]);
+                    mx[k] = fmaxf(mx[k], v[u][k]);
+                }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -178,28 +350,17 @@ __global__ __launch_bounds__(kRowsBlock) void table_stats_kernel(TableSides t)
 }
 
 struct TableCarve {
-    void *keyIn, *keyOut;
-    uint32_t *valIn, *valOut;
-    int *bnd[2], *counter;
-    void *sortTmp;
-    size_t sortTmpBytes, total;
+    uint32_t *dict[2];
+    int *start[2];
+    uint16_t *rowOf;
+    int *counts;
+    size_t total;
 };
 
-template <typename KeyT>
-hipError_t table_sort(void *tmp, size_t &tmpBytes, const TableCarve *c, size_t M, hipStream_t s)
-{
-    // (two clouds: 33 key bits -- the label's 32 and the cloud's number)
-    return rocprim::radix_sort_pairs(tmp, tmpBytes, c ? (KeyT *)c->keyIn : (KeyT *)nullptr, c ? (KeyT *)c->keyOut : (KeyT *)nullptr,
-                                     c ? c->valIn : (uint32_t *)nullptr, c ? c->valOut : (uint32_t *)nullptr, M, 0,
-                                     sizeof(KeyT) == 8 ? 33 : 32, s);
-}
+inline int table_chunks(int M) { return (M + kChunkRows - 1) / kChunkRows; }
 
-template <typename KeyT>
-hipError_t table_carve(int M, int Lmax, void *ws, TableCarve *c, hipStream_t s)
+void table_carve(int MA, int MB, int Lmax, void *ws, TableCarve *c)
 {
-    size_t tmp = 0;
-    hipError_t e = table_sort<KeyT>(nullptr, tmp, nullptr, (size_t)M, s);
-    if (e != hipSuccess) return e;
     char *p = (char *)ws;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -207,39 +368,32 @@ hipError_t table_carve(int M, int Lmax, void *ws, TableCarve *c, hipStream_t s)
         off += (bytes + 255) / 256 * 256;
         return q;
     };
-    c->keyIn = take((size_t)M * sizeof(KeyT));
-    c->keyOut = take((size_t)M * sizeof(KeyT));
-    c->valIn = (uint32_t *)take((size_t)M * 4);
-    c->valOut = (uint32_t *)take((size_t)M * 4);
-    c->bnd[0] = (int *)take((size_t)Lmax * 4);
-    c->bnd[1] = (int *)take((size_t)Lmax * 4);
-    c->counter = (int *)take(256);
-    c->sortTmp = take(tmp);
-    c->sortTmpBytes = tmp;
+    for (int k = 0; k < 2; ++k) {
+        c->dict[k] = (uint32_t *)take((size_t)Lmax * 4);
+        c->start[k] = (int *)take((size_t)Lmax * 4);
+    }
+    c->rowOf = (uint16_t *)take(((size_t)MA + MB) * 2);
+    c->counts = (int *)take((size_t)(table_chunks(MA) + table_chunks(MB)) * Lmax * 4);
     c->total = off;
-    return hipSuccess;
 }
 
-template <typename KeyT>
 hipError_t table_chain(TableSides t, int Lmax, void *ws, size_t wsBytes, bool *wsTooSmall, hipStream_t s)
 {
-    const int M = t.M[0] + t.M[1], sides = t.M[1] > 0 ? 2 : 1;
+    const int sides = t.M[1] > 0 ? 2 : 1;
+    if (Lmax > kDictMax) return hipErrorInvalidValue;      // (api.hip refuses it before: Lmax <= 4096)
     TableCarve c{};
-    hipError_t e = table_carve<KeyT>(M, Lmax, ws, &c, s);
-    if (e != hipSuccess) return e;
+    table_carve(t.M[0], t.M[1], Lmax, ws, &c);
     *wsTooSmall = wsBytes < c.total;
     if (*wsTooSmall) return hipSuccess;
-    t.bnd[0] = c.bnd[0];
-    t.bnd[1] = c.bnd[1];
-    t.counter = c.counter;
-    const int blocks = (M + kTableBlock - 1) / kTableBlock;
-    table_key_kernel<KeyT><<<blocks, kTableBlock, 0, s>>>(t, (KeyT *)c.keyIn, c.valIn);
-    e = table_sort<KeyT>(c.sortTmp, c.sortTmpBytes, &c, (size_t)M, s);
-    if (e != hipSuccess) return e;
-    table_boundary_kernel<KeyT><<<blocks, kTableBlock, 0, s>>>(t, (const KeyT *)c.keyOut, c.valOut, Lmax);
-    int P = 1;
-    while (P < Lmax) P <<= 1;
-    table_rows_kernel<KeyT><<<sides, kRowsBlock, (size_t)P * sizeof(int), s>>>(t, (const KeyT *)c.keyOut, Lmax);
+    for (int k = 0; k < 2; ++k) { t.dict[k] = c.dict[k]; t.start[k] = c.start[k]; }
+    t.rowOf = c.rowOf;
+    t.counts = c.counts;
+    t.chunks0 = table_chunks(t.M[0]);
+    const int chunks = t.chunks0 + (sides == 2 ? table_chunks(t.M[1]) : 0);
+    table_dict_kernel<<<sides, 1024, 0, s>>>(t, Lmax);
+    table_count_kernel<<<chunks, 256, 0, s>>>(t, Lmax);
+    table_scan_kernel<<<sides, 1024, 0, s>>>(t, Lmax);
+    table_scatter_kernel<<<chunks, kWave, 0, s>>>(t, Lmax);
     table_stats_kernel<<<dim3(Lmax, sides), kRowsBlock, 0, s>>>(t);
     return hipGetLastError();
 }
@@ -249,17 +403,17 @@ hipError_t table_chain(TableSides t, int Lmax, void *ws, size_t wsBytes, bool *w
 hipError_t cluster_table_workspace_bytes(int M, int Lmax, size_t *bytes)
 {
     TableCarve c{};
-    const hipError_t e = table_carve<uint32_t>(M, Lmax, nullptr, &c, nullptr);
+    table_carve(M, 0, Lmax, nullptr, &c);
     *bytes = c.total;
-    return e;
+    return hipSuccess;
 }
 
 hipError_t cluster_table_pair_workspace_bytes(int MA, int MB, int Lmax, size_t *bytes)
 {
     TableCarve c{};
-    const hipError_t e = table_carve<uint64_t>(MA + MB, Lmax, nullptr, &c, nullptr);
+    table_carve(MA, MB, Lmax, nullptr, &c);
     *bytes = c.total;
-    return e;
+    return hipSuccess;
 }
 
 hipError_t launch_cluster_table(const float *points, const float *labels, int M, int64_t *order, double *table, int Lmax,
@@ -267,7 +421,7 @@ hipError_t launch_cluster_table(const float *points, const float *labels, int M,
 {
     TableSides t{};
     t.points[0] = points; t.labels[0] = labels; t.M[0] = M; t.order[0] = order; t.table[0] = table; t.num[0] = num;
-    return table_chain<uint32_t>(t, Lmax, ws, wsBytes, wsTooSmall, s);
+    return table_chain(t, Lmax, ws, wsBytes, wsTooSmall, s);
 }
 
 hipError_t launch_cluster_table_pair(const float *pointsA, const float *labelsA, int MA, int64_t *orderA, double *tableA,
@@ -278,7 +432,7 @@ hipError_t launch_cluster_table_pair(const float *pointsA, const float *labelsA,
     TableSides t{};
     t.points[0] = pointsA; t.labels[0] = labelsA; t.M[0] = MA; t.order[0] = orderA; t.table[0] = tableA; t.num[0] = numA;
     t.points[1] = pointsB; t.labels[1] = labelsB; t.M[1] = MB; t.order[1] = orderB; t.table[1] = tableB; t.num[1] = numB;
-    return table_chain<uint64_t>(t, Lmax, ws, wsBytes, wsTooSmall, s);
+    return table_chain(t, Lmax, ws, wsBytes, wsTooSmall, s);
 }
 
 }  // namespace icpflow

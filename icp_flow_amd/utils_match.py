@@ -308,7 +308,8 @@ def _finish_pairs(args, st, dt, launched):
         raise RuntimeError("icpflow_hist_icp abandoned the batch: a wait between workgroups timed out -- a team sharing one "
                            "large pair, or a helper's hand-off in a persistent launch (GPU shared with another process?); "
                            "retry, or register with _lib.options(no_teams=True, no_helpers=True, no_persistent=True)")
-    keep = check_transformation(args, translations, rotations, np.minimum(ious[:, 0], ious[:, 1]))
+    # (Python's builtin min(iou), utils_match.py:99: iou[1] if iou[1] < iou[0] else iou[0]; differs from np.minimum only on NaNs)
+    keep = check_transformation(args, translations, rotations, np.where(ious[:, 1] < ious[:, 0], ious[:, 1], ious[:, 0]))
     if not keep.any():
         return np.zeros((0, 10), np.float32), np.zeros((0, 4, 4), np.float32)
     # The reference fills S x D matrices (1e8 where no candidate), takes the row arg-min of min(err_src, err_dst) -- the FIRST

@@ -45,6 +45,7 @@ extern "C" {
 #define ICPFLOW_E_ARG (-1)       /* bad pointer / size / enum                      */
 #define ICPFLOW_E_WORKSPACE (-2) /* workspace pointer NULL or too small            */
 #define ICPFLOW_E_LIMIT (-3)     /* size beyond what the kernels index (see docs)  */
+#define ICPFLOW_E_HOSTMEM (-4)   /* pinned host memory could not be allocated (icpflow_track_frame) */
 
 /* ICP stopping rule */
 #define ICPFLOW_STOP_REFERENCE 0 /* batch-global: stop when EVERY pair has rel<=thr
