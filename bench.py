@@ -39,8 +39,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_LANE_OPS = 78.6e12    # 256 CU x 128 fp32 lanes x 2.4 GHz; 157.3 TFLOP/s counting fma = 2
 LANE_OPS_PER_EVAL = 8           # one 3-D squared distance + compare = 8 lane-ops
-COUNTERS_FILE = os.path.join(REPO, "profiles", "r04_icp_kernel_counters.json")
-RAGGED_COUNTERS_FILE = os.path.join(REPO, "profiles", "r04_ragged_counters.json")
+COUNTERS_FILE = os.path.join(REPO, "profiles", "r05_icp_kernel_counters.json")
+RAGGED_COUNTERS_FILE = os.path.join(REPO, "profiles", "r05_ragged_counters.json")
+CONFIG4_COUNTERS_FILE = os.path.join(REPO, "profiles", "r05_config4_shard_counters.json")
 
 
 def parse():
@@ -503,8 +504,66 @@ def config4_single_gpu(dev, a):
         def step_eval():   # the step `--gpus N` times on every rank, less the all_gather: hist_icp + match_eval (one call)
             T, _, it = utils_match.hist_icp_eval(args, s, d, return_iterations=True)
             return T, it
-        dt, _, _, _, _ = timed_steps(step_eval, lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
-        out[tag]["registrations_per_s_with_match_eval"] = round(nb * steps / dt, 1)
+        dt_eval, _, _, _, _ = timed_steps(step_eval, lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
+        out[tag]["registrations_per_s_with_match_eval"] = round(nb * steps / dt_eval, 1)
+        if nb == 1024:
+            out[tag]["roofline"] = config4_roofline(nb, N, int(iters.item()), dt / steps * 1e3, icp_ms / steps)
+    return out
+
+
+def config4_roofline(B, N, iters, step_ms, icp_ms):
+    """Roofline of config 4's per-GPU shard, kernel by kernel.  Top level: the contract's figures for the
+    dominant kernel (icp_kernel: algorithmic bytes I*B*P / its launch duration, live HIP events).  `kernels`: per kernel of
+    the step the duration, the algorithmic HBM bytes (inputs once + outputs once), the HBM bytes the PMC passes count
+    (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) and the executed VALU fraction (SQ_INSTS_VALU x 64 / duration / 78.6 T
+    lane-op/s) -- from profiles/r05_config4_shard_counters.json (tools/profile_workload.sh + summarize_workload.py), refused when
+    it was collected with another build of the library."""
+    from icp_flow_amd import _lib
+    P = 2 * N * 16                                        # both clouds of a pair, 16 B a point
+    L = 41 * 41 * 3 * 4                                   # a pair's vote bins, uint32
+    alg = {"icp_kernel": ("all ICP iterations (I x B x P, SURVEY 8(d))", iters * B * P),
+           "hist_vote_sorted_kernel": ("both z-sorted clouds in, the bins out", B * (P + L)),
+           "sort_clouds_kernel": ("both clouds in, sorted float4 + SoA images out", B * (P + P + P * 3 // 4)),
+           "zsort_kernel": ("both clouds in, z-sorted out", B * 2 * P),
+           "sweep_scan_kernel<0>": ("six of the twelve scoring scans: both SoA images in per scan", 6 * B * P * 3 // 4),
+           "sweep_scan_kernel<1>": ("roll-back check: two scans", 2 * B * P),
+           "hist_peaks_kernel": ("the bins in, five peaks out", B * L)}
+    gbs = iters * B * P / (icp_ms * 1e-3) / 1e9 if icp_ms > 0 else 0.0
+    out = {"bound": "valu", "kernel": "icp_kernel<512, PERSIST, HELP> (all ICP iterations of the shard in one launch)",
+           "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
+           "algorithmic_bytes_per_launch": iters * B * P, "avg_launch_ms": round(icp_ms, 4), "icp_share_of_step": round(icp_ms / step_ms, 4),
+           "traffic": None, "traffic_source": "no counters file", "kernels": None}
+    if os.path.exists(CONFIG4_COUNTERS_FILE):
+        try:
+            cj = json.load(open(CONFIG4_COUNTERS_FILE))
+            if cj.get("library_build") != _lib.BUILD_INFO:
+                out["traffic_source"] = (f"{os.path.basename(CONFIG4_COUNTERS_FILE)} was collected with library build "
+                                         f"{cj.get('library_build')}, this is {_lib.BUILD_INFO}: refused")
+            else:
+                out["traffic_source"] = "PMC passes of the same library build (profiles/, rocprofv3 --pmc, separate passes; read side x2)"
+                ks = []
+                for name, e in sorted(cj["kernels"].items(), key=lambda kv: -kv[1].get("us_per_step", 0.0)):
+                    key = next((k for k in alg if name.startswith(k)), None)
+                    us = e.get("avg_us")
+                    row = {"kernel": name, "launches_per_step": e.get("launches_per_step"), "avg_us": round(us, 1) if us else None,
+                           "us_per_step": round(e.get("us_per_step", 0.0), 1), "hbm_bytes_counters": e.get("hbm_bytes_per_dispatch"),
+                           "executed_valu_frac": e.get("executed_valu_frac"), "wait_frac": e.get("wait_frac"),
+                           "lds_bank_conflict_frac": e.get("lds_bank_conflict_frac")}
+                    if key is not None and us:
+                        row["algorithmic_bytes"] = alg[key][1]
+                        row["algorithmic_bytes_are"] = alg[key][0]
+                        row["hbm_frac_algorithmic"] = round(alg[key][1] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+                    if e.get("hbm_bytes_per_dispatch") and us:
+                        row["hbm_frac_counters"] = round(e["hbm_bytes_per_dispatch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+                    ks.append(row)
+                    if name.startswith("icp_kernel"):
+                        out["traffic"] = e.get("hbm_bytes_per_dispatch")
+                        out["valu"] = {"peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "SQ_INSTS_VALU_per_launch": e.get("SQ_INSTS_VALU_per_dispatch"),
+                                       "executed_frac": e.get("executed_valu_frac")}
+                out["kernels"] = ks
+                out["kernel_us_per_step_under_the_profiler"] = cj.get("kernel_us_per_step")
+        except Exception as e:
+            out["traffic_source"] = "unreadable counters file: " + repr(e)
     return out
 
 

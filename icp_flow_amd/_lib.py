@@ -56,6 +56,9 @@ SIGNATURES = {
     "icpflow_assoc_collect": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "icpflow_register_stage": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
     "icpflow_associate_frame": (_i, [_p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _sz, _p, _p]),
+    "icpflow_register_stage_begin": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p]),
+    "icpflow_register_stage_finish": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p]),
+    "icpflow_associate_frame_begun": (_i, [_p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _sz, _p, _p, _p]),
     "icpflow_track_frame": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _p]),
     "icpflow_selftest_randperm": (_i, [_p, ctypes.c_int64, _i, _p]),
     "icpflow_cluster_stats": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
@@ -99,7 +102,9 @@ OPT_FLAGS = {"no_sorted_vote": 1 << 0, "no_side_stream": 1 << 1, "no_eval_sweep"
              "no_score_sweep": 1 << 4, "no_score_prune": 1 << 5, "no_teams": 1 << 6, "no_speculative": 1 << 7,
              "no_adaptive_windows": 1 << 8, "no_persistent": 1 << 9, "no_helpers": 1 << 10,
              # (not a bit-identity switch: teams on at most half of the CUs, two team launches side by side; icpflow_hip.h)
-             "teams_half_gpu": 1 << 11, "no_shared_scans": 1 << 12}
+             "teams_half_gpu": 1 << 11, "no_shared_scans": 1 << 12,
+             # icpflow_track_frame: stage 2's initial poses behind stage 1 instead of beside its ICP (same results; see icpflow_hip.h)
+             "no_stage_overlap": 1 << 13}
 
 
 class Options(ctypes.Structure):

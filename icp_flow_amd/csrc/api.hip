@@ -218,7 +218,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
     if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
-    if (opt->flags >> 13) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    if (opt->flags >> 14) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
     o.search = opt->icp_search;
     o.arith = opt->icp_arith;
     o.flags = opt->flags;
@@ -366,7 +366,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
                            w.state, w.ctrl, search, w.history, &w.team, io, s));
     if (sweepCheck) {
         PoseSource ps{w.state, w.ctrl, historyPending ? w.history : nullptr, init, B, maxIter};
-        ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, nullptr, w.partial, s, &ps));
+        ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, nullptr, w.partial, s, &ps, o.pairActive));
         ICPFLOW_TRY(launch_select(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, init, nullptr, B, invertSwapped,
                                   Tout, s, &ps, iters));
         return 0;
@@ -624,11 +624,11 @@ int icpflow_register_stage(const icpflow_tables_t *t, const icpflow_stage_t *st,
                                  R + 18 * k, R + 20 * k, R + 22 * k, R + 24 * k, R + 27 * k, d_ws, ws_bytes, stream, opt);
 }
 
-int icpflow_associate_frame(const icpflow_tables_t *t, const icpflow_stage_t *s1, const icpflow_stage_t *s2, uint8_t *d_active2,
+static int associate_frame_impl(const icpflow_tables_t *t, const icpflow_stage_t *s1, const icpflow_stage_t *s2, uint8_t *d_active2,
                             const icpflow_registration_t *reg, float translation_frame, float thres_iou, float rot_limit_deg,
                             float thres_error, int32_t *d_best, int cap, float *d_rows, float *d_T, const float *d_flow_points,
                             const float *d_flow_labels, int n_flow, const float *d_pose, float *d_flow, void *d_ws,
-                            size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt)
+                            size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt, const int32_t *h_carry2)
 {
     if (!t || !s1 || !reg || !d_best || !d_rows || !d_T) return fail(ICPFLOW_E_ARG, "icpflow_associate_frame: null argument");
     if (!t->d_table_src || !t->d_table_dst || !s1->d_result || !s1->d_si || !s1->d_di)
@@ -647,7 +647,11 @@ int icpflow_associate_frame(const icpflow_tables_t *t, const icpflow_stage_t *s1
         o2.struct_size = sizeof(icpflow_options_t);
         if (opt) o2 = *opt;
         o2.d_pair_active = d_active2;
-        if (int r = icpflow_register_stage(t, s2, reg, d_ws, ws_bytes, stream, &o2)) return r;
+        // (h_carry2: stage 2's first half has run already -- icpflow_register_stage_begin on the WHOLE superset, in d_ws --; the
+        // switched-off candidates then carry their clouds, and every kernel of the second half passes them over by the mask)
+        if (h_carry2 != nullptr) {
+            if (int r = icpflow_register_stage_finish(t, s2, reg, d_ws, ws_bytes, stream, &o2, h_carry2)) return r;
+        } else if (int r = icpflow_register_stage(t, s2, reg, d_ws, ws_bytes, stream, &o2)) return r;
         if (int r = icpflow_assoc_assign(s2->d_result, s2->d_si, s2->d_di, K2, d_active2, S, D, translation_frame, thres_iou,
                                          rot_limit_deg, thres_error, best2, 0, nullptr, nullptr, nullptr, nullptr, stream))
             return r;
@@ -659,6 +663,27 @@ int icpflow_associate_frame(const icpflow_tables_t *t, const icpflow_stage_t *s1
     if (d_flow != nullptr)
         return icpflow_flow_rigid_rows(d_flow_points, d_flow_labels, n_flow, d_rows, 10, d_T, cap, d_pose, d_flow, stream);
     return 0;
+}
+
+int icpflow_associate_frame(const icpflow_tables_t *t, const icpflow_stage_t *s1, const icpflow_stage_t *s2, uint8_t *d_active2,
+                            const icpflow_registration_t *reg, float translation_frame, float thres_iou, float rot_limit_deg,
+                            float thres_error, int32_t *d_best, int cap, float *d_rows, float *d_T, const float *d_flow_points,
+                            const float *d_flow_labels, int n_flow, const float *d_pose, float *d_flow, void *d_ws,
+                            size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt)
+{
+    return associate_frame_impl(t, s1, s2, d_active2, reg, translation_frame, thres_iou, rot_limit_deg, thres_error, d_best, cap, d_rows, d_T,
+                                d_flow_points, d_flow_labels, n_flow, d_pose, d_flow, d_ws, ws_bytes, stream, opt, nullptr);
+}
+
+int icpflow_associate_frame_begun(const icpflow_tables_t *t, const icpflow_stage_t *s1, const icpflow_stage_t *s2, uint8_t *d_active2,
+                                  const icpflow_registration_t *reg, float translation_frame, float thres_iou, float rot_limit_deg,
+                                  float thres_error, int32_t *d_best, int cap, float *d_rows, float *d_T, const float *d_flow_points,
+                                  const float *d_flow_labels, int n_flow, const float *d_pose, float *d_flow, void *d_ws2,
+                                  size_t ws2_bytes, icpflow_stream_t stream, const icpflow_options_t *opt, const int32_t *h_carry2)
+{
+    if (!h_carry2) return fail(ICPFLOW_E_ARG, "icpflow_associate_frame_begun: null argument");
+    return associate_frame_impl(t, s1, s2, d_active2, reg, translation_frame, thres_iou, rot_limit_deg, thres_error, d_best, cap, d_rows, d_T,
+                                d_flow_points, d_flow_labels, n_flow, d_pose, d_flow, d_ws2, ws2_bytes, stream, opt, h_carry2);
 }
 
 size_t icpflow_dbscan_workspace_bytes(int n)
@@ -925,8 +950,18 @@ int icpflow_apply_icp(const float *d_src, const float *d_dst, const float *d_ini
 static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x, int len_x,
                          const float *d_edges_y, int len_y, const float *d_edges_z, int len_z, float decode_shift,
                          double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
-                         float *d_T_out, int32_t *d_iters, Workspace &w, const Opts &o, hipStream_t s)
+                         float *d_T_out, int32_t *d_iters, Workspace &w, const Opts &o, hipStream_t s,
+                         int phase = 0, int32_t *carry = nullptr)
 {
+    // phase 0: the whole registration.  phase 1: its first half -- lengths, sorts, vote, peaks, scoring: the initial poses --,
+    // leaving in carry[0..1] what the second half has to know about the workspace (clouds sorted by role, team plan made);
+    // phase 2: the second half (ICP, roll-back check, select) from a workspace phase 1 has filled.  (icpflow_register_stage_begin
+    // / _finish: a frame pair's stage 2 estimates its initial poses beside stage 1's ICP, on another stream.)
+    if (phase == 2) {
+        w.grid.presorted = carry[0];
+        return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
+                                  relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, carry[1] != 0);
+    }
     // lengths + swap (utils_match.py:139-146) + cleared scratch: by the vote's sort itself where one workgroup sorts a
     // cloud (PairCountFuse), by count_pair otherwise
     const bool countInSort = N <= kMaxSortN && N <= kChunkSortMinN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE);
@@ -978,6 +1013,11 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
         return r;
     if (join != nullptr && !sweepScore) ICPFLOW_TRY(hipStreamWaitEvent(s, join, 0));
     guard.joined();
+    if (phase == 1) {
+        carry[0] = w.grid.presorted;
+        carry[1] = teamPlanned ? 1 : 0;
+        return 0;
+    }
     return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
                               relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, teamPlanned);
 }
@@ -1079,7 +1119,7 @@ static int match_eval_core(const float *d_pcd1, const float *d_pcd2, const float
     if (reuse || eval_by_sweep(B, N, o)) {
         if (!reuse) ICPFLOW_TRY(launch_sort_clouds_soa(d_pcd1, d_pcd2, w.lenA, w.lenC, nullptr, B, N, &w.grid, s));
         ICPFLOW_TRY(launch_sweep_eval(&w.grid, w.lenA, w.lenC, B, N, d_T, (float)thres_dist, w.zsortA, w.partial, s,
-                                      reuse ? w.swap : nullptr));
+                                      reuse ? w.swap : nullptr, o.pairActive));
         ICPFLOW_TRY(launch_eval_epilogue(w.partial, sweep_qblocks(N), w.lenA, w.lenC, d_T, B, d_errors, d_inliers,
                                          d_ratios, d_ious, d_translations, d_rotations, s));
         return 0;
@@ -1111,7 +1151,7 @@ int icpflow_match_eval(const float *d_pcd1, const float *d_pcd2, const float *d_
 // hist_icp + match_eval of the same clouds in one call (utils_match.py:92-93 calls them back to back): the metrics are
 // taken on what the registration left in the workspace -- the valid-row counts and both clouds sorted along the fixed
 // cloud's longest axis -- instead of counting and sorting again.
-int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x, int len_x,
+static int hist_icp_eval_phase(int phase, int32_t *carry, const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x, int len_x,
                           const float *d_edges_y, int len_y, const float *d_edges_z, int len_z, float decode_shift,
                           double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
                           float *d_T_out, int32_t *d_iters, float *d_errors, float *d_inliers, float *d_ratios,
@@ -1137,10 +1177,63 @@ int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, 
     if (int r = check_ws(d_ws, ws_bytes, w.bytes)) return r;
     hipStream_t s = (hipStream_t)stream;
     if (int r = hist_icp_core(d_src, d_dst, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z, len_z, decode_shift,
-                              thres_dist, max_iterations, relative_rmse_thr, stop_mode, d_T_out, d_iters, w, o, s))
+                              thres_dist, max_iterations, relative_rmse_thr, stop_mode, d_T_out, d_iters, w, o, s, phase, carry))
         return r;
+    if (phase == 1) return 0;
     return match_eval_core(d_src, d_dst, d_T_out, B, N, thres_dist, d_errors, d_inliers, d_ratios, d_ious, d_translations,
                            d_rotations, w, o, s, true, w.grid.presorted != 0);
+}
+
+int icpflow_hist_icp_eval(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x, int len_x,
+                          const float *d_edges_y, int len_y, const float *d_edges_z, int len_z, float decode_shift,
+                          double thres_dist, int max_iterations, double relative_rmse_thr, int stop_mode,
+                          float *d_T_out, int32_t *d_iters, float *d_errors, float *d_inliers, float *d_ratios,
+                          float *d_ious, float *d_translations, float *d_rotations, void *d_ws, size_t ws_bytes,
+                          icpflow_stream_t stream, const icpflow_options_t *opt)
+{
+    return hist_icp_eval_phase(0, nullptr, d_src, d_dst, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z, len_z, decode_shift, thres_dist,
+                               max_iterations, relative_rmse_thr, stop_mode, d_T_out, d_iters, d_errors, d_inliers, d_ratios, d_ious,
+                               d_translations, d_rotations, d_ws, ws_bytes, stream, opt);
+}
+
+// icpflow_register_stage in two halves (phase 1: gather + initial poses; phase 2: ICP, roll-back check, metrics)
+static int register_stage_phase(int phase, int32_t *carry, const icpflow_tables_t *t, const icpflow_stage_t *st,
+                                const icpflow_registration_t *reg, void *d_ws, size_t ws_bytes, icpflow_stream_t stream,
+                                const icpflow_options_t *opt)
+{
+    const char *fn = phase == 1 ? "icpflow_register_stage_begin" : "icpflow_register_stage_finish";
+    if (!t || !st || !reg || !carry) return fail(ICPFLOW_E_ARG, "%s: null argument", fn);
+    if (!t->d_points_src || !t->d_order_src || !t->d_points_dst || !t->d_order_dst || !st->d_seg || !st->d_clouds || !st->d_result)
+        return fail(ICPFLOW_E_ARG, "%s: null pointer", fn);
+    const int K = st->K, N = st->N;
+    if (int r = check_batch(fn, K, N)) return r;
+    const size_t cloud = (size_t)K * N * 4;
+    if (phase == 1) {
+        if (int r = icpflow_gather_segments(t->d_points_src, t->d_order_src, st->d_seg, st->d_perm, K, N, st->d_clouds, stream)) return r;
+        if (int r = icpflow_gather_segments(t->d_points_dst, t->d_order_dst, st->d_seg + (size_t)3 * K, st->d_perm, K, N,
+                                            st->d_clouds + cloud, stream))
+            return r;
+    }
+    float *R = st->d_result;
+    const size_t k = (size_t)K;
+    return hist_icp_eval_phase(phase, carry, st->d_clouds, st->d_clouds + cloud, K, N, reg->d_edges_x, reg->len_x, reg->d_edges_y, reg->len_y,
+                               reg->d_edges_z, reg->len_z, reg->decode_shift, reg->thres_dist, reg->max_iterations,
+                               reg->relative_rmse_thr, reg->stop_mode, R, reinterpret_cast<int32_t *>(R + 30 * k), R + 16 * k,
+                               R + 18 * k, R + 20 * k, R + 22 * k, R + 24 * k, R + 27 * k, d_ws, ws_bytes, stream, opt);
+}
+
+int icpflow_register_stage_begin(const icpflow_tables_t *t, const icpflow_stage_t *st, const icpflow_registration_t *reg,
+                                 void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt, int32_t *h_carry)
+{
+    return register_stage_phase(1, h_carry, t, st, reg, d_ws, ws_bytes, stream, opt);
+}
+
+int icpflow_register_stage_finish(const icpflow_tables_t *t, const icpflow_stage_t *st, const icpflow_registration_t *reg,
+                                  void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt, const int32_t *h_carry)
+{
+    int32_t carry[2] = {h_carry ? h_carry[0] : 0, h_carry ? h_carry[1] : 0};
+    if (!h_carry) return fail(ICPFLOW_E_ARG, "icpflow_register_stage_finish: null argument");
+    return register_stage_phase(2, carry, t, st, reg, d_ws, ws_bytes, stream, opt);
 }
 
 }  // extern "C"

@@ -352,6 +352,38 @@ inline hipError_t wait_stream(hipStream_t s)
     return hipStreamSynchronize(s);
 }
 
+// the stream stage 2's first half runs on (one per host thread and device; never destroyed: the thread's frame pairs reuse it)
+struct SecondStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t join = nullptr;
+    int device = -1;
+    bool ok = false;
+};
+inline SecondStream &second_stream()
+{
+    static thread_local SecondStream st[8];
+    static thread_local SecondStream none;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return none;
+    SecondStream &e = st[dev & 7];
+    if (e.device != dev) {
+        e = SecondStream{};
+        e.device = dev;
+        // (a stream of another PRIORITY: streams of one priority share a few hardware queues, and a second stream that lands in
+        // the caller's queue runs behind the caller's kernels, not beside them -- measured: no gain from a plain second stream
+        // when the caller's stream is a created one.  ICPFLOW_SECOND_STREAM_PRIORITY: 0 = the lowest, 1 = the highest)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+#ifndef ICPFLOW_SECOND_STREAM_PRIORITY
+#define ICPFLOW_SECOND_STREAM_PRIORITY 0
+#endif
+        const int prio = ICPFLOW_SECOND_STREAM_PRIORITY ? greatest : least;
+        e.ok = hipStreamCreateWithPriority(&e.stream, hipStreamNonBlocking, prio) == hipSuccess &&
+               hipEventCreateWithFlags(&e.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return e;
+}
+
 inline size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int round64(int64_t x) { return (int)((x + 63) / 64 * 64); }
 
@@ -496,7 +528,8 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     const size_t oRes2 = off; off += up(sizeof(float) * (30 * (size_t)K2 + 1));
     const size_t oActive = off; off += up((size_t)K2 + 1);
     const size_t oBest = off; off += up(sizeof(int32_t) * (2 * (size_t)S + 2));
-    const size_t oWs = off; off += up(std::max(ws1, ws2));
+    const size_t oWs = off; off += up(ws1);
+    const size_t oWs2 = off; off += up(ws2);     // (a workspace of its own: stage 2 estimates its initial poses beside stage 1's ICP)
     *scratch_needed = off;
     if (scratch_bytes < off) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: scratch too small (see *scratch_needed)");
 
@@ -549,14 +582,36 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
                            reinterpret_cast<float *>(base + oRes1), K1, N1};
     icpflow_stage_t stage2{seg2, nullptr, idx + 2 * K1, idx + 2 * K1 + K2, reinterpret_cast<float *>(base + oClouds2),
                            reinterpret_cast<float *>(base + oRes2), K2, N2};
-    if (int r = icpflow_register_stage(&tables, &stage1, reg, base + oWs, std::max(ws1, ws2), stream, opt)) return r;
+    if (int r = icpflow_register_stage(&tables, &stage1, reg, base + oWs, ws1, stream, opt)) return r;
+    // Stage 2's first half -- clouds of the whole superset, vote, peaks, scoring: ~0.12 ms of kernels -- on a second stream, where
+    // it runs beside stage 1's ICP (100 dependent iterations on a few long pairs: most of the GPU is idle meanwhile) instead of
+    // behind it.  Everything it reads is complete (the tables were waited for; the segment rows are host memory written above).
+    // The caller's stream waits for it BEFORE the assignment, which rewrites stage 2's segment rows.
+    int32_t carry2[2] = {0, 0};
+    bool begun = false;
+    if (K2 > 0 && !(opt != nullptr && (opt->flags & ICPFLOW_OPT_NO_STAGE_OVERLAP) != 0u)) {
+        SecondStream &b2 = second_stream();
+        if (b2.ok) {
+            if (int r = icpflow_register_stage_begin(&tables, &stage2, reg, base + oWs2, ws2, (icpflow_stream_t)b2.stream, opt, carry2)) return r;
+            if (hipEventRecord(b2.join, b2.stream) != hipSuccess || hipStreamWaitEvent(s, b2.join, 0) != hipSuccess)
+                return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: joining the second stream failed");
+            begun = true;
+        }
+    }
     g_frameStamp[6] = now_us();   // stage 1 enqueued
     int32_t *dBest = reinterpret_cast<int32_t *>(base + oBest);
     const int cap = 2 * S;
+    if (begun) {
+        if (int r = icpflow_associate_frame_begun(&tables, &stage1, &stage2, reinterpret_cast<uint8_t *>(base + oActive), reg,
+                                                  par->translation_frame, par->thres_iou, par->rot_limit_deg, par->thres_error, dBest, cap,
+                                                  d_rows, d_T, d_flow_points, d_flow != nullptr ? d_labels_src : nullptr, n_src, d_pose,
+                                                  d_flow, base + oWs2, ws2, stream, opt, carry2))
+            return r;
+    } else
     if (int r = icpflow_associate_frame(&tables, &stage1, K2 ? &stage2 : nullptr, reinterpret_cast<uint8_t *>(base + oActive), reg,
                                         par->translation_frame, par->thres_iou, par->rot_limit_deg, par->thres_error, dBest, cap,
                                         d_rows, d_T, d_flow_points, d_flow != nullptr ? d_labels_src : nullptr, n_src, d_pose,
-                                        d_flow, base + oWs, std::max(ws1, ws2), stream, opt))
+                                        d_flow, base + oWs2, ws2, stream, opt))
         return r;
     g_frameStamp[7] = now_us();   // everything enqueued
     if (hipMemcpyAsync(hBest, dBest, 4 * (2 * (size_t)S + 2), hipMemcpyDeviceToHost, s) != hipSuccess ||

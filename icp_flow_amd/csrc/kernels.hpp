@@ -152,12 +152,14 @@ struct GridScratch;
 int scan_qblocks(int maxRows, int batch);
 int sweep_qblocks(int maxRows);
 hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const int32_t *len2, int B, int N,
-                             const float *pose, float thres, float *srcT, double *partial, hipStream_t s, const uint8_t *swap = nullptr);
+                             const float *pose, float thres, float *srcT, double *partial, hipStream_t s, const uint8_t *swap = nullptr,
+                             const uint8_t *active = nullptr);
 struct PoseSource;   // posefuse.hpp
 // poseFinal == NULL: the final pose of every pair is composed inside the kernel from `fused`
 hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
                               const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
-                              const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused = nullptr);
+                              const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused = nullptr,
+                              const uint8_t *active = nullptr);
 hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
                               int B, int N, const float *cand, double *partial, hipStream_t s);
 hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC,

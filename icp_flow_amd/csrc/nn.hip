@@ -343,6 +343,7 @@ struct SweepParams {
     // this one have summed more than candidate 0's forward mean allows, prune 2: candidate 0's backward scan
     int subBegin, subCount, prune;
     double *accum;          // [B,12] running sums of the scans (cleared by the caller)
+    const uint8_t *active;  // SWEEP_CHECK / SWEEP_EVAL: optional [B], 0 = the pair is not in the batch (options.d_pair_active): its records are zeros
 };
 
 constexpr int kSweepBlock = 256;
@@ -395,7 +396,8 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     __shared__ float boundSh;   // pruned scoring: candidate 0's forward mean
     __shared__ int prunedSh;    // ... a wave of this block has proven the scan out of the race
-    if (qb * kSweepBlock >= nq) {   // block beyond the cloud: its record is still summed
+    const bool off = MODE != SWEEP_SCORE && p.active != nullptr && p.active[b] == 0;
+    if (off || qb * kSweepBlock >= nq) {   // block beyond the cloud (or a pair that is not in the batch): its record is still summed
         // (before the pruning prologue: on a batch padded far beyond its clusters -- a frame's candidate pairs at max_points
         // 10000 -- nine blocks in ten are such blocks, and the prologue reads and adds the sums of up to eleven scans.  A
         // scan that the prologue would have declared out of the race here reports its true sum instead of +inf: above the
@@ -722,9 +724,10 @@ hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *len
 // the pairs flagged.  srcT: scratch of B * 3 * NP16 floats (+ 64 of slack)
 hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const int32_t *len2, int B, int N,
                              const float *pose, float thres, float *srcT, double *partial, hipStream_t s,
-                             const uint8_t *swap)
+                             const uint8_t *swap, const uint8_t *active)
 {
     SweepParams p{};
+    p.active = active;
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = len1; p.lenC = len2; p.axis = grid->axis;
     p.swap = swap;
     p.poseA = pose; p.thres = thres; p.srcT = srcT; p.N = N; p.njobs = B * 2; p.partial = partial;
@@ -738,9 +741,11 @@ hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const
 // the composed final pose, as sweeps over the sorted clouds the ICP left in `grid`
 hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
                               const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
-                              const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused)
+                              const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused,
+                              const uint8_t *active)
 {
     SweepParams p{};
+    p.active = active;
     if (poseFinal == nullptr) {
         if (fused == nullptr) return hipErrorInvalidValue;
         p.fused = *fused;

@@ -529,7 +529,8 @@ def track_frame_native(a, ps, pd, ls, ld, pose=None, flow_points=None, seed=0, g
     if scratch is None:
         scratch = _frame_scratch[key] = torch.empty((64 << 20,), dtype=torch.uint8, device=device)
     pairs, need = ctypes.c_int32(0), ctypes.c_size_t(0)
-    with _lib.options(teams_half_gpu=not getattr(a, "teams_full_gpu", False), no_shared_scans=not getattr(a, "shared_scans", False)):
+    with _lib.options(teams_half_gpu=not getattr(a, "teams_full_gpu", False), no_shared_scans=not getattr(a, "shared_scans", False),
+                      no_stage_overlap=getattr(a, "stage_overlap", None) is False):
         opt = _lib.opt()
         for _ in range(5):   # (the scratch is sized in up to three parts -- fixed, stages, exact stage 2 --, each learnt from a refusal)
             rc = _lib._L.icpflow_track_frame(_lib.ptr(ps3), _lib.ptr(ls), len(ps3), _lib.ptr(pd3), _lib.ptr(ld), len(pd3),
@@ -606,6 +607,13 @@ def register_in_flight_native(args, fps, device, in_flight=4):
     source = enumerate(fps)
     lock = threading.Lock()
     n = max(1, int(in_flight))
+    # several frame pairs at once keep the GPU busy by themselves: stage 2's initial poses stay behind stage 1 (the overlap of
+    # icpflow_track_frame registers stage 2's whole candidate superset -- extra work that shortens one frame pair on an idle GPU
+    # and costs throughput on a busy one: 0.74 -> 0.88 ms per demo frame pair with four in flight when tried); same results
+    flight_args = args
+    if n > 1 and getattr(args, "stage_overlap", None) is None:
+        flight_args = SimpleNamespace(**vars(args))
+        flight_args.stage_overlap = False
     out = queue.Queue(maxsize=2 * n + n)     # back-pressure: a slow consumer holds at most ~2 results per worker (+ the end marks)
     stop = threading.Event()                 # the consumer has gone (generator closed, or an error): take no further frame pair
 
@@ -619,7 +627,7 @@ def register_in_flight_native(args, fps, device, in_flight=4):
                         idx, fp = next(source)
                     except StopIteration:
                         return
-                res = register_frame_pair_native(args, fp, device)
+                res = register_frame_pair_native(flight_args, fp, device)
                 if not _served(res):
                     res = _python_host(args, fp, device, None, res)
                 stream.synchronize()

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 208 /* 0.2.8: ICPFLOW_OPT_NO_SHARED_SCANS (teams: window scans shared by a member's waves); 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 209 /* 0.2.9: icpflow_register_stage_begin / _finish, icpflow_associate_frame_begun (stage 2's initial poses beside stage 1's ICP), ICPFLOW_E_HOSTMEM; 0.2.8: ICPFLOW_OPT_NO_SHARED_SCANS (teams: window scans shared by a member's waves); 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -124,6 +124,10 @@ const char *icpflow_build_info(void);
 #define ICPFLOW_OPT_TEAMS_HALF_GPU (1u << 11)
 /* (a bit-identity switch again) ICP, teams: a wave scans its long windows alone instead of sharing them with the member's other waves */
 #define ICPFLOW_OPT_NO_SHARED_SCANS (1u << 12)
+/* icpflow_track_frame: stage 2's first half runs behind stage 1 on the caller's stream instead of beside stage 1's ICP on a second
+ * one (identical results; the overlap shortens ONE frame pair by ~0.1 ms but registers the whole candidate superset of stage 2 --
+ * with several frame pairs in flight on a busy GPU that extra work costs throughput: frame_pairs.register_in_flight sets the flag) */
+#define ICPFLOW_OPT_NO_STAGE_OVERLAP (1u << 13)
 
 typedef struct icpflow_profile icpflow_profile_t; /* opaque */
 
@@ -451,6 +455,27 @@ int icpflow_associate_frame(const icpflow_tables_t *tables, const icpflow_stage_
                             const float *d_flow_points, const float *d_flow_labels, int n_flow, const float *d_pose,
                             float *d_flow, void *d_ws, size_t ws_bytes, icpflow_stream_t stream,
                             const icpflow_options_t *opt);
+/* (version 209) icpflow_register_stage in two halves, so that a frame pair's stage 2 can estimate its initial poses on another
+ * stream BESIDE stage 1's ICP (a chain of dependent iterations on a few long pairs that leaves most of the GPU idle):
+ * _begin gathers the clouds of the WHOLE candidate list and enqueues lengths, sorts, vote, peaks and scoring (utils_hist.py:82-124)
+ * on `stream`, leaving the initial poses in d_ws and two host words in h_carry; _finish enqueues the rest (ICP, roll-back check,
+ * metrics; utils_icp.py:20-35, utils_match.py:159-213) from that workspace -- options.d_pair_active of the second call says which
+ * candidates are in the batch after all: the others keep their clouds and are passed over by every kernel (their result rows are
+ * unspecified).  The pairs in the batch get bit for bit what icpflow_register_stage gives them with the others handed over as
+ * empty clouds.  The caller orders the two calls (an event from _begin's stream to _finish's); d_ws must not be used in between.
+ * icpflow_associate_frame_begun: icpflow_associate_frame for a stage 2 that has been begun (d_ws2 / h_carry2: its workspace). */
+int icpflow_register_stage_begin(const icpflow_tables_t *tables, const icpflow_stage_t *stage, const icpflow_registration_t *reg,
+                                 void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt,
+                                 int32_t *h_carry /* [2] */);
+int icpflow_register_stage_finish(const icpflow_tables_t *tables, const icpflow_stage_t *stage, const icpflow_registration_t *reg,
+                                  void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt,
+                                  const int32_t *h_carry /* [2] */);
+int icpflow_associate_frame_begun(const icpflow_tables_t *tables, const icpflow_stage_t *stage1, const icpflow_stage_t *stage2,
+                                  uint8_t *d_active2, const icpflow_registration_t *reg, float translation_frame, float thres_iou,
+                                  float rot_limit_deg, float thres_error, int32_t *d_best, int cap, float *d_rows, float *d_T,
+                                  const float *d_flow_points, const float *d_flow_labels, int n_flow, const float *d_pose,
+                                  float *d_flow, void *d_ws2, size_t ws2_bytes, icpflow_stream_t stream,
+                                  const icpflow_options_t *opt, const int32_t *h_carry2 /* [2] */);
 /* ---------------------------------------------------------------------------
  * One frame pair per call (version 207): match_pcds (utils_match.py:24-66) + flow_estimation_torch (utils_flow.py:57-69) from two
  * labelled clouds on, the HOST half included -- cluster tables, candidate lists, sanity_check (utils_check.py:21-49), padded
