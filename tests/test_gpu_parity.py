@@ -1415,6 +1415,14 @@ def test_native_frame_pair_equals_the_python_host(case):
         assert len(want["pairs"]) >= 3
         for key in ("pairs", "transformations", "flow"):
             assert torch.equal(got[key], want[key]), (case, key, want["association"])
+        # stage 2's initial poses behind stage 1 on the caller's stream (ICPFLOW_OPT_NO_STAGE_OVERLAP) instead of beside stage 1's ICP
+        # on a second one (the default above): the same bits
+        a.stage_overlap = False
+        serial = frame_pairs.register_frame_pair_native(a, fp, DEV)
+        a.stage_overlap = None
+        torch.cuda.synchronize()
+        for key in ("pairs", "transformations", "flow"):
+            assert torch.equal(serial[key], want[key]), (case, key, "stage_overlap=False")
     if case == "fallback":
         assert served < len(fps)            # at least one frame pair needed the exact stage 2
     elif not case.startswith("demo"):
