@@ -583,6 +583,12 @@ def extra_measurements(args, src, dst, T, dev, a):
 
     from icp_flow_amd import _lib
     B = src.shape[0]
+    # the frame pair FIRST: its latency (one frame pair at a time, stage 2's initial poses on a second stream beside stage 1's ICP)
+    # is the one measurement here that depends on which hardware queues the process's streams share (HIP multiplexes streams
+    # onto four queues by default; measured: 1.40 / 1.75 ms in a process that has created no other streams -- or anywhere with
+    # GPU_MAX_HW_QUEUES=16 -- against 1.6 / 1.95 ms after hist_icp_many's and the in-flight workers' streams exist), and a
+    # frame-pair pipeline is a process of its own
+    fp_first = frame_pair_measurement(dev)
     out = {"match_eval_ms_per_batch": round(timeit(lambda: utils_match.match_eval(args, src, dst, T)), 4)}
     # the same registration with the ICP loop's correspondence search forced to the all-pairs LDS scan
     # (the north star's brute-force formulation; identical results)
@@ -635,9 +641,8 @@ def extra_measurements(args, src, dst, T, dev, a):
         out["ragged_real_shape_matched_sizes"] = ragged_real_shape(dev, sizes="matched")
     except Exception as e:
         out["ragged_real_shape_matched_sizes"] = {"error": repr(e)}
-    fp = frame_pair_measurement(dev)
-    if fp is not None:
-        out["frame_pair"] = fp
+    if fp_first is not None:
+        out["frame_pair"] = fp_first
     return out
 
 
@@ -744,6 +749,7 @@ def frame_pair_measurement(dev):
     ls, ld = G(lab["label_src"]).float(), G(lab["label_dst"]).float()
     ego = torch.eye(4, device=dev)                 # the ego pose: an input like the clouds (demo.py:217 passes the identity)
     res = {"data": "demo.npz frame pair of the reference, labels from the G8 fixture", "points": [len(ps), len(pd)]}
+    kept = {}
     for mp in (int(g["max_points"]), 10000):
         a = frame_pairs.default_args(max_points=mp)
 
@@ -826,6 +832,13 @@ def frame_pair_measurement(dev):
                 entry["reference_runs_differ_between_tie_orders_by_m"] = float(np.abs(cpu["flow"] - ref["flow"]).max())
             except OSError:
                 pass
+        res[f"max_points_{mp}"] = entry
+        kept[mp] = (a, flow, flow_host)
+    # (the latencies of BOTH settings before any frame pair is put in flight: the workers' streams, once they exist, share the
+    # process's few hardware queues with the streams of a single frame pair)
+    for mp in (int(g["max_points"]), 10000):
+        a, flow, flow_host = kept[mp]
+        entry = res[f"max_points_{mp}"]
         # the same frame pair as a STREAM (BASELINE configs 3 / 5 are streams of independent frame pairs, main.py:184-215):
         # 12 copies with 4 in flight, 24 with 8 (frame_pairs.register_in_flight: one stream and one host thread per frame pair
         # in flight, each frame pair one blocking icpflow_track_frame call; "_python_scheduler": one host thread, generators,

@@ -369,16 +369,20 @@ inline SecondStream &second_stream()
     if (e.device != dev) {
         e = SecondStream{};
         e.device = dev;
-        // (a stream of another PRIORITY: streams of one priority share a few hardware queues, and a second stream that lands in
-        // the caller's queue runs behind the caller's kernels, not beside them -- measured: no gain from a plain second stream
-        // when the caller's stream is a created one.  ICPFLOW_SECOND_STREAM_PRIORITY: 0 = the lowest, 1 = the highest)
+        // (a plain second stream.  HIP multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, four by
+        // default): where the second stream lands in the caller's queue it runs behind stage 1, not beside it -- the overlap then
+        // buys nothing and costs nothing (measured: -0.09 ms per demo frame pair from the default stream of a fresh process or
+        // with GPU_MAX_HW_QUEUES=16, +-0 from a stream that shares its queue).  A stream of another PRIORITY always gets a queue
+        // of its own -- and takes it from the pool every other stream of the process shares: frame pairs in flight 0.60 -> 0.82 ms,
+        // four batches in one call 500 -> 466 k registrations/s when tried (ICPFLOW_SECOND_STREAM_PRIORITY 0 / 1: lowest / highest))
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
 #ifndef ICPFLOW_SECOND_STREAM_PRIORITY
-#define ICPFLOW_SECOND_STREAM_PRIORITY 0
+#define ICPFLOW_SECOND_STREAM_PRIORITY 2
 #endif
         const int prio = ICPFLOW_SECOND_STREAM_PRIORITY ? greatest : least;
-        e.ok = hipStreamCreateWithPriority(&e.stream, hipStreamNonBlocking, prio) == hipSuccess &&
+        e.ok = (ICPFLOW_SECOND_STREAM_PRIORITY == 2 ? hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking)
+                                                    : hipStreamCreateWithPriority(&e.stream, hipStreamNonBlocking, prio)) == hipSuccess &&
                hipEventCreateWithFlags(&e.join, hipEventDisableTiming) == hipSuccess;
     }
     return e;
