@@ -351,8 +351,12 @@ struct JoinGuard {
 int run_icp_and_select(const float *src, const float *dst, Workspace &w, const uint8_t *swap,
                        const float *init, int B, int N, double thres, int maxIter, double relThr,
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, const Opts &o, hipStream_t s,
-                       bool teamPlanned = false)
+                       bool teamPlanned = false, int part = 0, int32_t *pending = nullptr)
 {
+    // part 0: everything.  part 1: the ICP launch only, with the whole batch iterating (no pair mask); *pending = 1 when the launch
+    // left every pair's trajectory in the history (the single speculative launch with the fused finish), 0 when it could not be
+    // split off (then part 2 runs everything).  part 2 with *pending: the batch rule over o.pairActive from that history
+    // (launch_icp_retally), then roll-back check and select.
     const GridScratch *search = search_scratch(w, N, o);
     const bool sweepCheck = search != nullptr && search->mode == 3 && o.on(ICPFLOW_OPT_NO_CHECK_SWEEP);
     // fused finish: the roll-back check and the select kernel take the final pose of every pair straight from the
@@ -362,8 +366,25 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     io.help = icp_help_carve(w.ctrl, B, w.helpState, w.helpOut);
     io.teamPlanned = teamPlanned;
     if (sweepCheck && o.arith == ICPFLOW_ARITH_FP64) io.historyPending = &historyPending;
-    ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
-                           w.state, w.ctrl, search, w.history, &w.team, io, s));
+    const bool splittable = sweepCheck && o.arith == ICPFLOW_ARITH_FP64 && stopMode == ICPFLOW_STOP_REFERENCE && w.history != nullptr &&
+                            o.on(ICPFLOW_OPT_NO_SPECULATIVE) && maxIter > 1 && maxIter <= kHistIters;
+    if (part == 1) {
+        *pending = 0;
+        if (!splittable) return 0;
+        io.pairActive = nullptr;
+    }
+    if (part == 2 && pending != nullptr && *pending != 0) {
+        historyPending = true;
+        if (o.pairActive != nullptr) ICPFLOW_TRY(launch_icp_retally(w.ctrl, w.history, o.pairActive, B, maxIter, relThr, s));
+    } else {
+        ICPFLOW_TRY(launch_icp(src, dst, w.lenA, w.lenC, swap, init, B, N, thres, maxIter, relThr, stopMode,
+                               w.state, w.ctrl, search, w.history, &w.team, io, s));
+        if (part == 1) {
+            if (!historyPending) return fail(ICPFLOW_E_ARG, "icpflow_register_stage_begin: the ICP launch kept no history");
+            *pending = 1;
+            return 0;
+        }
+    }
     if (sweepCheck) {
         PoseSource ps{w.state, w.ctrl, historyPending ? w.history : nullptr, init, B, maxIter};
         ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, nullptr, w.partial, s, &ps, o.pairActive));
@@ -959,8 +980,9 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
     // / _finish: a frame pair's stage 2 estimates its initial poses beside stage 1's ICP, on another stream.)
     if (phase == 2) {
         w.grid.presorted = carry[0];
+        int32_t pending = carry[2];
         return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
-                                  relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, carry[1] != 0);
+                                  relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, carry[1] != 0, 2, &pending);
     }
     // lengths + swap (utils_match.py:139-146) + cleared scratch: by the vote's sort itself where one workgroup sorts a
     // cloud (PairCountFuse), by count_pair otherwise
@@ -1016,7 +1038,10 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
     if (phase == 1) {
         carry[0] = w.grid.presorted;
         carry[1] = teamPlanned ? 1 : 0;
-        return 0;
+        // ... and, where ONE speculative launch runs the batch rule, the ICP of the whole batch as well (carry[2] = 1): the second
+        // half then only has to find where the rule over ITS pairs stops
+        return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations, relative_rmse_thr,
+                                  stop_mode, 1, d_T_out, d_iters, o, s, teamPlanned, 1, &carry[2]);
     }
     return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
                               relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, teamPlanned);
@@ -1231,7 +1256,7 @@ int icpflow_register_stage_begin(const icpflow_tables_t *t, const icpflow_stage_
 int icpflow_register_stage_finish(const icpflow_tables_t *t, const icpflow_stage_t *st, const icpflow_registration_t *reg,
                                   void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt, const int32_t *h_carry)
 {
-    int32_t carry[2] = {h_carry ? h_carry[0] : 0, h_carry ? h_carry[1] : 0};
+    int32_t carry[3] = {h_carry ? h_carry[0] : 0, h_carry ? h_carry[1] : 0, h_carry ? h_carry[2] : 0};
     if (!h_carry) return fail(ICPFLOW_E_ARG, "icpflow_register_stage_finish: null argument");
     return register_stage_phase(2, carry, t, st, reg, d_ws, ws_bytes, stream, opt);
 }

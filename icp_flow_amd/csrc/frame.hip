@@ -591,7 +591,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     // it runs beside stage 1's ICP (100 dependent iterations on a few long pairs: most of the GPU is idle meanwhile) instead of
     // behind it.  Everything it reads is complete (the tables were waited for; the segment rows are host memory written above).
     // The caller's stream waits for it BEFORE the assignment, which rewrites stage 2's segment rows.
-    int32_t carry2[2] = {0, 0};
+    int32_t carry2[4] = {0, 0, 0, 0};
     bool begun = false;
     if (K2 > 0 && !(opt != nullptr && (opt->flags & ICPFLOW_OPT_NO_STAGE_OVERLAP) != 0u)) {
         SecondStream &b2 = second_stream();

@@ -3067,6 +3067,61 @@ hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t 
     return hipGetLastError();
 }
 
+// The batch rule over a SUBSET of the pairs, after the fact (round 5: a frame pair's stage 2 iterates all the candidates of its
+// superset beside stage 1, before it is known which of them are in the batch).  The speculative launch has left every pair's
+// (R, T, rmse) of every iteration in the history and the tallies of the rule over ALL pairs; every pair has rows up to the first
+// iteration s_all at which that rule held (a pair leaves only when it has seen such an iteration, when its trajectory is
+// periodic -- it then writes all remaining rows -- or at the cap), and the rule over a subset holds no later.  This kernel
+// recomputes, per iteration s <= s_all, "every ACTIVE pair converged" from the history's rmse values with the loop's own test
+// (:195-198, :209: rel = (prev - rmse) / prev <= thr, false at iteration 0 and on a NaN) and REWRITES the tallies so that their
+// readers (posefuse.hpp) find the subset's stopping iteration: exactly what a launch with options.d_pair_active would have left.
+__global__ __launch_bounds__(256) void icp_retally_kernel(IcpCtrl *__restrict__ ctrl, const float *__restrict__ history,
+                                                          const uint8_t *__restrict__ active, int B, int maxIter, float relThr)
+{
+    __shared__ unsigned int bad[4];       // bit s: some active pair is not converged at iteration s
+    __shared__ int limitSh;
+    const int tid = threadIdx.x;
+    if (tid < 4) bad[tid] = 0u;
+    if (tid == 0) {
+        int lim = maxIter - 1;
+        for (int s = 0; s < maxIter; ++s) {
+            const unsigned long long t = ctrl->tally[s];
+            if ((int)(t & 0xffffffffull) == B && (t >> 32) == 0ull) { lim = s; break; }
+        }
+        limitSh = lim;
+    }
+    __syncthreads();
+    const int lim = limitSh;
+    for (int b = tid; b < B; b += 256) {
+        if (active[b] == 0) continue;
+        unsigned int mine[4] = {1u, 0u, 0u, 0u};      // (iteration 0: rel = 1, never converged)
+        float prev = history[((size_t)0 * B + b) * kHistStride + 12];
+        for (int s = 1; s <= lim; ++s) {
+            const float rm = history[((size_t)s * B + b) * kHistStride + 12];
+            const float rel = (prev - rm) / prev;
+            if (!(rel <= relThr)) mine[s >> 5] |= 1u << (s & 31);
+            prev = rm;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (mine[k] != 0u) atomicOr(&bad[k], mine[k]);
+    }
+    __syncthreads();
+    for (int s = tid; s < maxIter; s += 256) {
+        unsigned long long t = 0ull;                              // beyond s_all: "not everybody has arrived"
+        if (s <= lim) t = (unsigned long long)(unsigned)B | (((bad[s >> 5] >> (s & 31)) & 1u) ? (1ull << 32) : 0ull);
+        ctrl->tally[s] = t;
+    }
+}
+
+hipError_t launch_icp_retally(IcpCtrl *ctrl, const float *history, const uint8_t *active, int B, int maxIter, double relThr,
+                              hipStream_t s)
+{
+    if (maxIter > kHistIters) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(icp_retally_kernel, dim3(1), dim3(256), 0, s, ctrl, history, active, B, maxIter, (float)relThr);
+    return hipGetLastError();
+}
+
 hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,
                              float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s, float *scale)
 {

@@ -251,6 +251,9 @@ void ensure_dynamic_lds(const void *func, int bytes, std::atomic<unsigned long l
 hipError_t launch_icp_export(IcpState *state, IcpCtrl *ctrl, int B, int stopMode, float *R,
                              float *T, float *rmse, int32_t *iters, int32_t *converged, hipStream_t s,
                              float *scale = nullptr);
+// the batch rule over the pairs flagged in `active`, from the history of a launch that iterated all of them: rewrites the tallies
+hipError_t launch_icp_retally(IcpCtrl *ctrl, const float *history, const uint8_t *active, int B, int maxIter, double relThr,
+                              hipStream_t s);
 hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const float *history, int B, int maxIter,
                                       hipStream_t s);
 

@@ -458,24 +458,26 @@ int icpflow_associate_frame(const icpflow_tables_t *tables, const icpflow_stage_
 /* (version 209) icpflow_register_stage in two halves, so that a frame pair's stage 2 can estimate its initial poses on another
  * stream BESIDE stage 1's ICP (a chain of dependent iterations on a few long pairs that leaves most of the GPU idle):
  * _begin gathers the clouds of the WHOLE candidate list and enqueues lengths, sorts, vote, peaks and scoring (utils_hist.py:82-124)
- * on `stream`, leaving the initial poses in d_ws and two host words in h_carry; _finish enqueues the rest (ICP, roll-back check,
- * metrics; utils_icp.py:20-35, utils_match.py:159-213) from that workspace -- options.d_pair_active of the second call says which
+ * -- and, where one speculative launch runs the batch rule (reference stop, 2 <= max_iterations <= 128, fp64 arithmetic), the ICP of
+ * ALL candidates (h_carry[2] = 1) -- on `stream`, leaving initial poses (and trajectories) in d_ws and a few host words in h_carry;
+ * _finish enqueues the rest (the batch rule over the pairs that are in the batch after all, found from the trajectories; else the ICP
+ * itself; roll-back check, metrics; utils_icp.py:20-35, utils_match.py:159-213) from that workspace -- options.d_pair_active of the second call says which
  * candidates are in the batch after all: the others keep their clouds and are passed over by every kernel (their result rows are
  * unspecified).  The pairs in the batch get bit for bit what icpflow_register_stage gives them with the others handed over as
  * empty clouds.  The caller orders the two calls (an event from _begin's stream to _finish's); d_ws must not be used in between.
  * icpflow_associate_frame_begun: icpflow_associate_frame for a stage 2 that has been begun (d_ws2 / h_carry2: its workspace). */
 int icpflow_register_stage_begin(const icpflow_tables_t *tables, const icpflow_stage_t *stage, const icpflow_registration_t *reg,
                                  void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt,
-                                 int32_t *h_carry /* [2] */);
+                                 int32_t *h_carry /* [4] */);
 int icpflow_register_stage_finish(const icpflow_tables_t *tables, const icpflow_stage_t *stage, const icpflow_registration_t *reg,
                                   void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt,
-                                  const int32_t *h_carry /* [2] */);
+                                  const int32_t *h_carry /* [4] */);
 int icpflow_associate_frame_begun(const icpflow_tables_t *tables, const icpflow_stage_t *stage1, const icpflow_stage_t *stage2,
                                   uint8_t *d_active2, const icpflow_registration_t *reg, float translation_frame, float thres_iou,
                                   float rot_limit_deg, float thres_error, int32_t *d_best, int cap, float *d_rows, float *d_T,
                                   const float *d_flow_points, const float *d_flow_labels, int n_flow, const float *d_pose,
                                   float *d_flow, void *d_ws2, size_t ws2_bytes, icpflow_stream_t stream,
-                                  const icpflow_options_t *opt, const int32_t *h_carry2 /* [2] */);
+                                  const icpflow_options_t *opt, const int32_t *h_carry2 /* [4] */);
 /* ---------------------------------------------------------------------------
  * One frame pair per call (version 207): match_pcds (utils_match.py:24-66) + flow_estimation_torch (utils_flow.py:57-69) from two
  * labelled clouds on, the HOST half included -- cluster tables, candidate lists, sanity_check (utils_check.py:21-49), padded
