@@ -339,7 +339,9 @@ struct Host {   // per host thread
 // 0.86 -> 0.72 / 1.01 -> 0.91 ms per frame pair with four in flight).
 inline hipError_t wait_stream(hipStream_t s)
 {
-    // (bounded by TIME: ~2 ms of polling -- a frame pair's own waits are fractions of a millisecond --, then the runtime blocks)
+    // (bounded by TIME: 20 ms of polling, then the runtime blocks.  A frame pair's own waits are fractions of a millisecond, with
+    // several frame pairs in flight a few milliseconds: a bound of 2 ms sent those waits into the blocking call and cost a stream
+    // of frame pairs 0.75 -> 1.5 ms per frame pair -- round 5)
     const auto t0 = std::chrono::steady_clock::now();
     for (int spin = 0;; ++spin) {
         const hipError_t e = hipStreamQuery(s);
@@ -347,7 +349,7 @@ inline hipError_t wait_stream(hipStream_t s)
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
 #endif
-        if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
     }
     return hipStreamSynchronize(s);
 }
