@@ -39,7 +39,7 @@ constexpr int kTableDoubles = 1 + kTableRows * 9;  // [0]: int32 number of clust
 
 // host time stamps of the last icpflow_track_frame call of this thread (icpflow_debug_frame_stamps): entry, tables enqueued,
 // generator blocks ready, tables on the host, stage 1's candidates, segments + subsamples, stage 1 enqueued, all enqueued, matches read
-thread_local double g_frameStamp[9];
+thread_local double g_frameStamp[16];
 inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Mt19937 {   // at::mt19937 (the engine of torch's CPU generator)
@@ -525,6 +525,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     int N2 = K2 ? std::min(capPts, std::max(64, round64(longest2))) : 64;
     if (!par->tight_padding) N2 = maxPoints;
 
+    g_frameStamp[9] = now_us();    // (sub-stamps of "segments + draws": the superset)
     // ---- device scratch, second part
     const size_t ws1 = icpflow_workspace_bytes(K1, N1, reg->len_x, reg->len_y, reg->len_z);
     const size_t ws2 = K2 ? icpflow_workspace_bytes(K2, N2, reg->len_x, reg->len_y, reg->len_z) : 0;
@@ -539,6 +540,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     *scratch_needed = off;
     if (scratch_bytes < off) return report_error(ICPFLOW_E_WORKSPACE, "icpflow_track_frame: scratch too small (see *scratch_needed)");
 
+    g_frameStamp[10] = now_us();   // (workspace sizes)
     // pinned staging: [tables (done with) | seg1 int64 [2,3,K1] | perm int32 [nPerm, maxPoints] | seg2 int64 [2,3,K2] |
     //                  si1, di1, si2, di2 int32 | best int32 [2S+2]]
     const size_t pSeg1 = 0, pPerm = pSeg1 + 48 * (size_t)K1, pSeg2 = up(pPerm + 4 * (size_t)nPerm * maxPoints);
@@ -570,6 +572,7 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
             }
         }
     }
+    g_frameStamp[11] = now_us();   // (stage 1's segments and draws)
     for (int k = 0; k < K2; ++k) {
         seg2[0 * K2 + k] = st.start[si2[k]]; seg2[1 * K2 + k] = st.count[si2[k]]; seg2[2 * K2 + k] = -1;
         seg2[3 * K2 + k] = dt.start[di2[k]]; seg2[4 * K2 + k] = dt.count[di2[k]]; seg2[5 * K2 + k] = -1;
@@ -743,5 +746,12 @@ extern "C" int icpflow_debug_frame_stamps(double *out9)
 {
     if (!out9) return ICPFLOW_E_ARG;
     for (int k = 0; k < 9; ++k) out9[k] = g_frameStamp[k];
+    return 0;
+}
+// ... and the stamps inside "segments + draws": [0] its start, [1] superset done, [2] workspace sizes done, [3] stage 1's segments and draws done, [4] its end
+extern "C" int icpflow_debug_frame_substamps(double *out5)
+{
+    if (!out5) return ICPFLOW_E_ARG;
+    out5[0] = g_frameStamp[4]; out5[1] = g_frameStamp[9]; out5[2] = g_frameStamp[10]; out5[3] = g_frameStamp[11]; out5[4] = g_frameStamp[5];
     return 0;
 }

@@ -3075,39 +3075,41 @@ hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t 
 // recomputes, per iteration s <= s_all, "every ACTIVE pair converged" from the history's rmse values with the loop's own test
 // (:195-198, :209: rel = (prev - rmse) / prev <= thr, false at iteration 0 and on a NaN) and REWRITES the tallies so that their
 // readers (posefuse.hpp) find the subset's stopping iteration: exactly what a launch with options.d_pair_active would have left.
-__global__ __launch_bounds__(256) void icp_retally_kernel(IcpCtrl *__restrict__ ctrl, const float *__restrict__ history,
-                                                          const uint8_t *__restrict__ active, int B, int maxIter, float relThr)
+__global__ __launch_bounds__(1024) void icp_retally_kernel(IcpCtrl *__restrict__ ctrl, const float *__restrict__ history,
+                                                           const uint8_t *__restrict__ active, int B, int maxIter, float relThr)
 {
     __shared__ unsigned int bad[4];       // bit s: some active pair is not converged at iteration s
     __shared__ int limitSh;
     const int tid = threadIdx.x;
-    if (tid < 4) bad[tid] = 0u;
-    if (tid == 0) {
+    if (tid < 4) bad[tid] = tid == 0 ? 1u : 0u;      // (iteration 0: rel = 1, nobody is converged)
+    if (tid < kWave) {                               // the first iteration at which the rule over ALL pairs held (wave 0, 64 tallies a round)
         int lim = maxIter - 1;
-        for (int s = 0; s < maxIter; ++s) {
-            const unsigned long long t = ctrl->tally[s];
-            if ((int)(t & 0xffffffffull) == B && (t >> 32) == 0ull) { lim = s; break; }
+        for (int s0 = 0; s0 < maxIter; s0 += kWave) {
+            const int s = s0 + tid;
+            bool hit = false;
+            if (s < maxIter) {
+                const unsigned long long t = ctrl->tally[s];
+                hit = (int)(t & 0xffffffffull) == B && (t >> 32) == 0ull;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m != 0ull) { lim = s0 + __builtin_ctzll(m); break; }
         }
-        limitSh = lim;
+        if (tid == 0) limitSh = lim;
     }
     __syncthreads();
     const int lim = limitSh;
-    for (int b = tid; b < B; b += 256) {
+    // one (pair, iteration) per thread and round, pairs fastest (neighbouring threads read neighbouring rows): every test reads
+    // the two rmse values it compares -- no chain through the iterations
+    for (int i = tid; i < B * lim; i += 1024) {
+        const int b = i % B, s = i / B + 1;
         if (active[b] == 0) continue;
-        unsigned int mine[4] = {1u, 0u, 0u, 0u};      // (iteration 0: rel = 1, never converged)
-        float prev = history[((size_t)0 * B + b) * kHistStride + 12];
-        for (int s = 1; s <= lim; ++s) {
-            const float rm = history[((size_t)s * B + b) * kHistStride + 12];
-            const float rel = (prev - rm) / prev;
-            if (!(rel <= relThr)) mine[s >> 5] |= 1u << (s & 31);
-            prev = rm;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (mine[k] != 0u) atomicOr(&bad[k], mine[k]);
+        const float prev = history[((size_t)(s - 1) * B + b) * kHistStride + 12];
+        const float rm = history[((size_t)s * B + b) * kHistStride + 12];
+        const float rel = (prev - rm) / prev;
+        if (!(rel <= relThr)) atomicOr(&bad[s >> 5], 1u << (s & 31));
     }
     __syncthreads();
-    for (int s = tid; s < maxIter; s += 256) {
+    for (int s = tid; s < maxIter; s += 1024) {
         unsigned long long t = 0ull;                              // beyond s_all: "not everybody has arrived"
         if (s <= lim) t = (unsigned long long)(unsigned)B | (((bad[s >> 5] >> (s & 31)) & 1u) ? (1ull << 32) : 0ull);
         ctrl->tally[s] = t;
@@ -3118,7 +3120,7 @@ hipError_t launch_icp_retally(IcpCtrl *ctrl, const float *history, const uint8_t
                               hipStream_t s)
 {
     if (maxIter > kHistIters) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(icp_retally_kernel, dim3(1), dim3(256), 0, s, ctrl, history, active, B, maxIter, (float)relThr);
+    hipLaunchKernelGGL(icp_retally_kernel, dim3(1), dim3(1024), 0, s, ctrl, history, active, B, maxIter, (float)relThr);
     return hipGetLastError();
 }
 

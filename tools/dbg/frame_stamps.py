@@ -13,15 +13,19 @@ ps, pd = G(g["point_src"]), G(g["point_dst"]); ls, ld = G(lab["label_src"]).floa
 ego = torch.eye(4, device=dev)
 names = ["enqueue tables", "generator blocks", "wait for tables", "candidates", "segments + draws", "enqueue stage 1", "enqueue the rest", "wait for matches"]
 buf = (ctypes.c_double * 9)()
+sub = (ctypes.c_double * 5)()
 for mp in (2048, 10000):
     a = frame_pairs.default_args(max_points=mp)
     for _ in range(3): frame_pairs.track_frame_native(a, ps, pd, ls, ld, ego, ps)
-    rows, tot = [], []
+    rows, tot, subs = [], [], []
     for _ in range(21):
         torch.cuda.synchronize(); t = time.perf_counter()
         frame_pairs.track_frame_native(a, ps, pd, ls, ld, ego, ps)
         torch.cuda.synchronize(); tot.append((time.perf_counter() - t) * 1e3)
         _lib._L.icpflow_debug_frame_stamps(buf)
         v = np.array(buf[:]); rows.append(np.diff(v))
+        _lib._L.icpflow_debug_frame_substamps(sub); subs.append(np.diff(np.array(sub[:])))
     med = np.median(np.array(rows), axis=0)
     print(f"max_points {mp}: {np.median(tot):.3f} ms per frame pair; inside the call {med.sum():.0f} us: " + ", ".join(f"{n} {m:.0f}" for n, m in zip(names, med)))
+    sm = np.median(np.array(subs), axis=0)
+    print(f"   segments + draws = stage 2's superset {sm[0]:.0f}, workspace sizes {sm[1]:.0f}, stage 1's segments and draws {sm[2]:.0f}, stage 2's segments and index lists {sm[3]:.0f}")
