@@ -9,7 +9,7 @@ P=gpurun_out/profiles_$TAG
 B=$(python -c "from icp_flow_amd import _lib; print(_lib.BUILD_INFO)")
 cp $P/${TAG}_* profiles/
 cp $E/${TAG}_bench.json profiles/${TAG}_bench.json; grep -v amdgpu.ids $E/${TAG}_bench.err > profiles/${TAG}_bench.err || true
-cp $E/${TAG}_bench_stream.json profiles/${TAG}_bench_stream.json; cp $E/${TAG}_bench_stream_rccl.json profiles/${TAG}_bench_stream_rccl.json
+grep '^{' $E/${TAG}_bench_stream.json > profiles/${TAG}_bench_stream.json; grep '^{' $E/${TAG}_bench_stream_rccl.json > profiles/${TAG}_bench_stream_rccl.json   # (RCCL prints its version banner on stdout first)
 grep -v amdgpu.ids $E/tail_clock.txt > profiles/${TAG}_icp_tail_clock.txt
 grep -v amdgpu.ids $E/stage1_tail.txt > profiles/${TAG}_frame_stage1_tail.txt
 { grep -v amdgpu.ids $E/ragged_tail_matched.txt; grep -v amdgpu.ids $E/ragged_tail_independent.txt; grep -v amdgpu.ids $E/ragged_units.txt; } > profiles/${TAG}_ragged_tail_clocks.txt

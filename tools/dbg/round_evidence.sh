@@ -15,7 +15,7 @@ python tools/summarize_workload.py $TAG config4_shard > $O/summarize_config4.log
 mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python bench.py --workload stream --steps 20 --warmup 3 > $O/${TAG}_bench_stream.json 2>> $O/${TAG}_bench.err
-for try in 1 2 3; do python bench.py --workload stream --steps 20 --warmup 3 --force-collective > $O/${TAG}_bench_stream_rccl.json 2>> $O/${TAG}_bench.err; [ -s $O/${TAG}_bench_stream_rccl.json ] && break; sleep 5; done
+python bench.py --workload stream --steps 20 --warmup 3 --force-collective > $O/${TAG}_bench_stream_rccl.json 2>> $O/${TAG}_bench.err
 REPS=6 python tools/dbg/stream_stress.py > $O/stress_default.txt 2>&1
 for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz; do timeout 500 python tools/dbg/$f.py > $O/$f.txt 2>&1; echo "$f rc=$?"; done
 python tools/dbg/frame_stamps.py > $O/frame_stamps.txt 2>&1
