@@ -184,6 +184,35 @@ struct MtStream {
 // torch.randperm(n, generator)[0:take] as int32 (n < 2^32 / 20: the 32-bit branch of randperm_cpu)
 // `tmp` is kept as the IDENTITY between calls (entries are set when it grows; the places a call writes are put back at its
 // end): writing 60 000 indices per draw cost as much as the draw itself.
+#if defined(__x86_64__)
+// z[k] = temper(raw[k]) % (n - (i0 + k)) for k < count (count a multiple of 8), eight at a time: the tempering on 32-bit lanes, the
+// remainder through a double division -- exact: the quotient r / m of two integers below 2^32 is at least 1 / m below the next
+// integer and q m <= r < 2^32, so the correctly rounded quotient (53 bits) truncates to floor(r / m); r - q m is exact in double.
+__attribute__((target("avx2"))) void draws_avx2(const uint32_t *raw, uint32_t n32, uint32_t i0, int count, uint32_t *z)
+{
+    const __m256i c7 = _mm256_set1_epi32((int)0x9d2c5680u), c15 = _mm256_set1_epi32((int)0xefc60000u), sign = _mm256_set1_epi32((int)0x80000000u);
+    const __m256d two31 = _mm256_set1_pd(2147483648.0);
+    const __m128i ramp = _mm_setr_epi32(0, 1, 2, 3);
+    for (int k = 0; k < count; k += 8) {
+        __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(raw + k));
+        y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 11));
+        y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 7), c7));
+        y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 15), c15));
+        y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 18));
+        const __m256i ys = _mm256_xor_si256(y, sign);                       // (unsigned -> signed + 2^31)
+        for (int h = 0; h < 2; ++h) {
+            const __m128i part = h ? _mm256_extracti128_si256(ys, 1) : _mm256_castsi256_si128(ys);
+            const __m256d r = _mm256_add_pd(_mm256_cvtepi32_pd(part), two31);
+            const uint32_t m0 = n32 - (i0 + (uint32_t)k + 4u * (uint32_t)h);
+            const __m256d m = _mm256_sub_pd(_mm256_set1_pd((double)m0), _mm256_cvtepi32_pd(ramp));
+            const __m256d q = _mm256_round_pd(_mm256_div_pd(r, m), _MM_FROUND_TO_ZERO | _MM_FROUND_NO_EXC);
+            const __m256d rem = _mm256_sub_pd(r, _mm256_mul_pd(q, m));
+            _mm_storeu_si128(reinterpret_cast<__m128i *>(z + k + 4 * h), _mm256_cvttpd_epi32(rem));
+        }
+    }
+}
+#endif
+
 void randperm_head(MtStream &g, int64_t n, int take, int32_t *out, std::vector<int32_t> &tmp)
 {
     static thread_local std::vector<int32_t> places;
@@ -201,7 +230,24 @@ void randperm_head(MtStream &g, int64_t n, int take, int32_t *out, std::vector<i
     const uint32_t n32 = (uint32_t)n;
     int32_t *t = tmp.data(), *pl = places.data();
     const int64_t p0 = g.pos;
-    for (int64_t i = 0; i < steps; ++i) {
+    int64_t i = 0;
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && n32 < (1u << 28)) {
+        // the remainders of the steps eight at a time (tempering and division vectorise; the swaps stay a chain through `t`)
+        static thread_local std::vector<uint32_t> zs;
+        const int64_t vec = steps / 8 * 8;
+        if ((int64_t)zs.size() < vec) zs.resize((size_t)vec);
+        draws_avx2(g.blocks.data() + (size_t)(g.idx0 + p0), n32, 0u, (int)vec, zs.data());
+        for (; i < vec; ++i) {
+            const int32_t place = (int32_t)((uint32_t)i + zs[(size_t)i]);
+            out[i] = t[place];
+            t[place] = t[i];
+            pl[i] = place;
+        }
+    }
+#endif
+    for (; i < steps; ++i) {
         // (on 32-bit operands: the draw is a 32-bit word and n - i < 2^32 -- the value of the reference's 64-bit remainder)
         const uint32_t z = g.draw(p0 + i) % (n32 - (uint32_t)i);
         const int32_t place = (int32_t)((uint32_t)i + z);
@@ -211,7 +257,7 @@ void randperm_head(MtStream &g, int64_t n, int take, int32_t *out, std::vector<i
     }
     if (steps < take) out[steps] = t[steps];   // (take == n: the last element stays where the shuffle left it)
     g.pos += n - 1;                            // (the draws of the steps nobody reads are passed over)
-    for (int64_t i = 0; i < steps; ++i) t[pl[i]] = pl[i];   // back to the identity
+    for (int64_t k = 0; k < steps; ++k) t[pl[k]] = pl[k];   // back to the identity
 }
 
 // numpy's minimum / maximum: a NaN on either side gives NaN
@@ -601,9 +647,15 @@ extern "C" int icpflow_track_frame(const float *d_points_src, const float *d_lab
     if (K2 > 0 && !(opt != nullptr && (opt->flags & ICPFLOW_OPT_NO_STAGE_OVERLAP) != 0u)) {
         SecondStream &b2 = second_stream();
         if (b2.ok) {
-            if (int r = icpflow_register_stage_begin(&tables, &stage2, reg, base + oWs2, ws2, (icpflow_stream_t)b2.stream, opt, carry2)) return r;
-            if (hipEventRecord(b2.join, b2.stream) != hipSuccess || hipStreamWaitEvent(s, b2.join, 0) != hipSuccess)
+            // (whatever goes wrong from here on, the second stream is drained before the call returns: its kernels write the scratch)
+            if (int r = icpflow_register_stage_begin(&tables, &stage2, reg, base + oWs2, ws2, (icpflow_stream_t)b2.stream, opt, carry2)) {
+                (void)hipStreamSynchronize(b2.stream);
+                return r;
+            }
+            if (hipEventRecord(b2.join, b2.stream) != hipSuccess || hipStreamWaitEvent(s, b2.join, 0) != hipSuccess) {
+                (void)hipStreamSynchronize(b2.stream);
                 return report_error(ICPFLOW_E_ARG, "icpflow_track_frame: joining the second stream failed");
+            }
             begun = true;
         }
     }
