@@ -525,8 +525,8 @@ def config4_roofline(B, N, iters, step_ms, icp_ms):
            "hist_vote_sorted_kernel": ("both z-sorted clouds in, the bins out", B * (P + L)),
            "sort_clouds_kernel": ("both clouds in, sorted float4 + SoA images out", B * (P + P + P * 3 // 4)),
            "zsort_kernel": ("both clouds in, z-sorted out", B * 2 * P),
-           "sweep_scan_kernel<0>": ("six of the twelve scoring scans: both SoA images in per scan", 6 * B * P * 3 // 4),
-           "sweep_scan_kernel<1>": ("roll-back check: two scans", 2 * B * P),
+           "sweep_scan_kernel<0": ("six of the twelve scoring scans: both SoA images in per scan", 6 * B * P * 3 // 4),
+           "sweep_scan_kernel<1": ("roll-back check: two scans", 2 * B * P),
            "hist_peaks_kernel": ("the bins in, five peaks out", B * L)}
     gbs = iters * B * P / (icp_ms * 1e-3) / 1e9 if icp_ms > 0 else 0.0
     out = {"bound": "valu", "kernel": "icp_kernel<512, PERSIST, HELP> (all ICP iterations of the shard in one launch)",

@@ -195,6 +195,8 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     int32_t *axis;     // sweep: [B]
     float *ckey;       // long clouds (N > kChunkSortMinN): chunk-sorted keys / rows of the multi-workgroup sort
     int *cidx;         //   [B,2,chunk_sort_length(N)] each (sort.hip), else NULL
+    float *shareBest;  // sweeps (nn.hip): [B*12, 8, 256] partial minima of small-against-long jobs shared by several blocks, or NULL
+    int *shareCount;   //   [B*12] blocks delivered (cleared by every sweep launch)
     int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose
                        // (scoring sweep ran on this batch): the ICP applies the pre-pose when it loads
 };

@@ -343,17 +343,31 @@ struct SweepParams {
     // this one have summed more than candidate 0's forward mean allows, prune 2: candidate 0's backward scan
     int subBegin, subCount, prune;
     double *accum;          // [B,12] running sums of the scans (cleared by the caller)
+    float *shareBest;       // [jobs, kSweepShares, kSweepBlock] partial minima of jobs whose ONE query block is scanned by several blocks, or NULL
+    int *shareCount;        // [jobs] blocks that have delivered (zero before the launch; the last one resets it)
+    int shareWindows;       // 1: blocks of at most 64 queries against a long cloud split every range over their four waves (sweep_scan_kernel)
     const uint8_t *active;  // SWEEP_CHECK / SWEEP_EVAL: optional [B], 0 = the pair is not in the batch (options.d_pair_active): its records are zeros
 };
 
 constexpr int kSweepBlock = 256;
+#ifndef ICPFLOW_SWEEP_SHARE_MIN_TARGETS
+#define ICPFLOW_SWEEP_SHARE_MIN_TARGETS 512
+#endif
+constexpr int kSweepShareMinTargets = ICPFLOW_SWEEP_SHARE_MIN_TARGETS;
+#ifndef ICPFLOW_SWEEP_FULLSCAN_MIN_TARGETS
+#define ICPFLOW_SWEEP_FULLSCAN_MIN_TARGETS 2048
+#endif
+constexpr int kSweepFullScanMinTargets = ICPFLOW_SWEEP_FULLSCAN_MIN_TARGETS;
+constexpr int kSweepShares = 8;   // blocks that share the ONE query block of a small cloud against a long one   // a one-wave block shares its window with the other waves from here on
 constexpr int kSweepStage = 4096;   // sort keys staged in LDS up to this many targets
 enum SweepMode : int { SWEEP_SCORE = 0, SWEEP_CHECK = 1, SWEEP_EVAL = 2 };
 
 #ifdef ICPFLOW_SWEEP_CLOCK
 __device__ long long g_sweep_clk[4096 * 8];   // per (mode 1 job, block 0): wall start, wall end, shader clocks: entry->loop, loop, rounds, nt, nq, chunks scanned
 #endif
-template <int MODE>
+// SHARE: the instantiation whose blocks may share a window (one-wave blocks: over their four waves; one-block clouds against a long
+// one: over several blocks) -- batches of a few hundred pairs; batches that fill the GPU many times over keep the plain loop
+template <int MODE, bool SHARE = false>
 __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
 {
 #ifdef ICPFLOW_SWEEP_CLOCK
@@ -397,6 +411,17 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     __shared__ float boundSh;   // pruned scoring: candidate 0's forward mean
     __shared__ int prunedSh;    // ... a wave of this block has proven the scan out of the race
     const bool off = MODE != SWEEP_SCORE && p.active != nullptr && p.active[b] == 0;
+    // A small cloud (ONE query block) against a long one: every wave would walk thousands of targets while the job's other
+    // blocks -- launched for the padded width -- return at once (round 5: 0.12-0.2 ms for such a block, the length of the launch).
+    // The first kSweepShares blocks of the job take the SAME queries and one share of ALL targets each (no window: a handful of
+    // queries spans the other cloud anyway); partial minima go to global memory, the last block to deliver combines them and
+    // writes block 0's record.  Minima are exact: the sums are bit for bit those of the windowed scan.
+    const bool fullScan = SHARE && !off && p.shareCount != nullptr && nq > 0 && nq <= kSweepBlock && nt >= kSweepFullScanMinTargets && p.qblocks >= 2;
+    const int shares = fullScan ? min(p.qblocks, kSweepShares) : 1;
+    if (fullScan && qb >= 1 && qb < shares) {
+        if (threadIdx.x < kPartial) out[threadIdx.x] = 0.0;    // (this block's own record: a block beyond the cloud)
+        out = p.partial + ((size_t)job * p.qblocks + 0) * kPartial;
+    } else
     if (off || qb * kSweepBlock >= nq) {   // block beyond the cloud (or a pair that is not in the batch): its record is still summed
         // (before the pruning prologue: on a batch padded far beyond its clusters -- a frame's candidate pairs at max_points
         // 10000 -- nine blocks in ten are such blocks, and the prologue reads and adds the sums of up to eleven scans.  A
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         return;
     }
     if (MODE == SWEEP_SCORE && threadIdx.x == 0) prunedSh = 0;
-    if (MODE == SWEEP_SCORE && p.prune) {
+    if (MODE == SWEEP_SCORE && p.prune && !fullScan) {   // (a job shared by several blocks is scanned to the end: its blocks must agree)
         // branch and bound exactly as in nn_scan_kernel (the argument is written there): the sum of the blocks
         // before this one bounds the scan's mean from below; beyond candidate 0's forward mean it reports +inf
         __shared__ int leave;
@@ -488,7 +513,15 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     }
     const int axis = p.axis[b];
     const float tu = axis == 0 ? tx : (axis == 1 ? ty : tz);
-    const int i = qb * kSweepBlock + wave * kWave + lane;
+    // A block whose queries fit ONE wave while the other cloud is long (a 40-point cluster against a 7000-point one: real
+    // candidate pairs of very unequal size) used to leave three of its four waves without rows while the one wave walked
+    // thousands of targets -- 0.2 ms for one such block, the length of the whole launch (round 5: tools/dbg/sweep_clocks.py).
+    // There all four waves take the SAME 64 queries and a quarter of every range each; the minima meet in LDS after every
+    // round.  A minimum does not depend on who found it: the sums are bit for bit those of one wave scanning alone.
+    __shared__ float shareBest[kSweepBlock / kWave][kWave];
+    __shared__ int shareLeave;
+    const bool sharedWindow = SHARE && !fullScan && p.shareWindows != 0 && nq - qb * kSweepBlock <= kWave && nt >= kSweepShareMinTargets;   // (block-uniform)
+    const int i = (fullScan ? 0 : qb) * kSweepBlock + (sharedWindow ? 0 : wave * kWave) + lane;
     const bool live = i < nq;
     float qx = 0.f, qy = 0.f, qz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
     float r = p.r0, shrink = 1.0f;   // shrink: the proof radius along u relative to the search radius
@@ -554,6 +587,29 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
 #ifdef ICPFLOW_SWEEP_CLOCK
     dbgC1 = clock64();
 #endif
+    if (fullScan) {
+        __shared__ int lastSh;
+        const int nchunks = np16 / kChunk, per = (nchunks + shares - 1) / shares * kChunk;
+        const int c0 = min(qb * per, np16), c1 = min(c0 + per, np16);
+        if (lo <= hi) {   // (a wave with queries)
+            if (MODE == SWEEP_SCORE && backward) scan_range_min_uniform<true>(tkx, tky, tkz, c0, c1, qx, qy, qz, tx, ty, tz, best);
+            else scan_range_min_uniform<false>(tkx, tky, tkz, c0, c1, qx, qy, qz, 0.f, 0.f, 0.f, best);
+        }
+        float *mine = p.shareBest + ((size_t)job * kSweepShares + qb) * kSweepBlock;
+        __hip_atomic_store(&mine[threadIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (write-through)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int before = __hip_atomic_fetch_add(&p.shareCount[job], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lastSh = before == shares - 1 ? 1 : 0;
+            if (lastSh) __hip_atomic_store(&p.shareCount[job], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
+        }
+        __syncthreads();
+        if (!lastSh) return;
+        const float *all = p.shareBest + (size_t)job * kSweepShares * kSweepBlock;
+        for (int sh = 0; sh < shares; ++sh)
+            best = fminf(best, __hip_atomic_load(&all[(size_t)sh * kSweepBlock + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else
     if (lo <= hi && nt > 0) {   // wave-uniform
         const float *key = stage ? keyLds : gkey;
         // slack: rounding of src + t / of the inverse map (ulps of the coordinates) and of the window arithmetic
@@ -570,12 +626,29 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             sorted_window(key, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
             const int k0 = (j0 / kChunk) * kChunk, k1 = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
             if (ce <= cb) { cb = k0; ce = k0; }   // nothing scanned yet
+            // the two ranges not scanned yet; in a shared window this wave's quarter of each (whole chunks)
+            int a0 = k0, a1 = min(cb, k1), b0 = max(ce, k0), b1 = k1;
+            if (sharedWindow) {
+                constexpr int W4 = kSweepBlock / kWave;
+                const int la = max(a1 - a0, 0), lb = max(b1 - b0, 0);
+                const int pa = (la / kChunk + W4 - 1) / W4 * kChunk, pb = (lb / kChunk + W4 - 1) / W4 * kChunk;
+                const int ea = a1, eb = b1;
+                a0 = a0 + wave * pa; a1 = min(a0 + pa, ea);
+                b0 = b0 + wave * pb; b1 = min(b0 + pb, eb);
+            }
             if (MODE == SWEEP_SCORE && backward) {
-                scan_range_min_uniform<true>(tkx, tky, tkz, k0, min(cb, k1), qx, qy, qz, tx, ty, tz, best);
-                scan_range_min_uniform<true>(tkx, tky, tkz, max(ce, k0), k1, qx, qy, qz, tx, ty, tz, best);
+                scan_range_min_uniform<true>(tkx, tky, tkz, a0, a1, qx, qy, qz, tx, ty, tz, best);
+                scan_range_min_uniform<true>(tkx, tky, tkz, b0, b1, qx, qy, qz, tx, ty, tz, best);
             } else {
-                scan_range_min_uniform<false>(tkx, tky, tkz, k0, min(cb, k1), qx, qy, qz, 0.f, 0.f, 0.f, best);
-                scan_range_min_uniform<false>(tkx, tky, tkz, max(ce, k0), k1, qx, qy, qz, 0.f, 0.f, 0.f, best);
+                scan_range_min_uniform<false>(tkx, tky, tkz, a0, a1, qx, qy, qz, 0.f, 0.f, 0.f, best);
+                scan_range_min_uniform<false>(tkx, tky, tkz, b0, b1, qx, qy, qz, 0.f, 0.f, 0.f, best);
+            }
+            if (sharedWindow) {   // every wave ends the round with the minimum over all four quarters
+                shareBest[wave][lane] = best;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < kSweepBlock / kWave; ++w) best = fminf(best, shareBest[w][lane]);
+                __syncthreads();
             }
 #ifdef ICPFLOW_SWEEP_CLOCK
             ++dbgRounds; dbgChunks = ce - cb;
@@ -592,7 +665,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
                 const float sb = sqrtf(best), pr = proven * 0.99999f;
                 const float lbLane = !live ? 0.f : (sb < pr ? sb : (sb != sb ? sb : pr));   // NaN stays NaN: never prunes
                 const float L = wave_sum(lbLane) * 0.99999f;
-                if (lane == 0 && L > lbAdded) atomicAdd(p.accum + job, (double)(L - lbAdded));
+                if (lane == 0 && L > lbAdded && (!sharedWindow || wave == 0)) atomicAdd(p.accum + job, (double)(L - lbAdded));
                 if (L > lbAdded) lbAdded = L;
                 const bool done = worst <= proven * proven || (cb == 0 && ce == np16);
                 if (!done) {   // before another (wider) round: is the scan still in the race?
@@ -600,7 +673,14 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
                     if (lane == 0) seen = __hip_atomic_load(p.accum + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const float low = __int_as_float(__builtin_amdgcn_readfirstlane(
                         __float_as_int((float)(seen / (double)(float)(backward ? nc : na)))));
-                    if (low > boundSh * 1.0001f) {
+                    bool leaveNow = low > boundSh * 1.0001f;
+                    if (sharedWindow) {   // (the waves read the running sum at different times: wave 0's reading decides for all)
+                        if (threadIdx.x == 0) shareLeave = leaveNow ? 1 : 0;
+                        __syncthreads();
+                        leaveNow = shareLeave != 0;
+                        __syncthreads();
+                    }
+                    if (leaveNow) {
                         if (lane == 0) prunedSh = 1;
                         break;
                     }
@@ -628,7 +708,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     double v[kPartial];
 #pragma unroll
     for (int k = 0; k < kPartial; ++k) v[k] = 0.0;
-    if (live && nt > 0) {
+    if (live && nt > 0 && (!sharedWindow || wave == 0)) {
         const float d = sqrtf(best);
         v[0] = (double)d;
         if (MODE == SWEEP_EVAL) {
@@ -682,9 +762,25 @@ static hipError_t launch_sweep(SweepParams p, hipStream_t s)
     p.NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
     p.qblocks = sweep_qblocks(p.N);
     p.r0 = 0.15f;
+#ifndef ICPFLOW_NO_SWEEP_SHARE
+    p.shareWindows = 1;
+#endif
+#ifdef ICPFLOW_NO_SWEEP_SHARE
+    p.shareCount = nullptr;
+#endif
+    if (p.N < kSweepFullScanMinTargets || p.shareBest == nullptr) p.shareCount = nullptr;
+    if (p.shareCount != nullptr) {
+        // (the jobs of this launch index the counters by their place in the partial records: b * 12 + scan, or b * 2 + direction)
+        const hipError_t me = hipMemsetAsync(p.shareCount, 0, (size_t)(MODE == SWEEP_SCORE ? (p.njobs / p.subCount) * 12 : p.njobs) * sizeof(int), s);
+        if (me != hipSuccess) return me;
+    }
     const int groups = (p.njobs + 7) / 8;
     const size_t lds = (size_t)(p.NP16 < kSweepStage ? p.NP16 : kSweepStage) * sizeof(float);
-    hipLaunchKernelGGL(sweep_scan_kernel<MODE>, dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
+    // (njobs <= 12 * 700: the batches whose workspace holds the shared minima; larger ones fill the GPU with whole pairs)
+    if (p.shareWindows != 0 && p.N >= kSweepFullScanMinTargets && p.njobs <= 12 * 700)
+        hipLaunchKernelGGL((sweep_scan_kernel<MODE, true>), dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
+    else
+        hipLaunchKernelGGL((sweep_scan_kernel<MODE, false>), dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
     return hipGetLastError();
 }
 
@@ -695,6 +791,7 @@ hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, cons
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.njobs = B * 12; p.partial = partial;
     p.subBegin = 0; p.subCount = 12;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount;
     return launch_sweep<SWEEP_SCORE>(p, s);
 }
 
@@ -707,6 +804,7 @@ hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *len
     SweepParams p{};
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.partial = partial; p.accum = accum;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount;
     p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
     hipError_t e = launch_sweep<SWEEP_SCORE>(p, s);
     if (e != hipSuccess) return e;
@@ -731,6 +829,7 @@ hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = len1; p.lenC = len2; p.axis = grid->axis;
     p.swap = swap;
     p.poseA = pose; p.thres = thres; p.srcT = srcT; p.N = N; p.njobs = B * 2; p.partial = partial;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount;
     const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
     hipLaunchKernelGGL(transform_soa_kernel, dim3((NP16 + 255) / 256, B), dim3(256), 0, s, grid->sortXsoa, len1, pose,
                        NP16, srcT, grid->sortYsoa, swap);
@@ -754,6 +853,7 @@ hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const flo
     p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.axis = grid->axis;
     p.sortX = (const float4 *)grid->sortX; p.X = X; p.Y = Y; p.poseA = poseInit; p.poseB = poseFinal;
     p.rawSorted = grid->presorted; p.N = N; p.njobs = B * 2; p.partial = partial;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount;
     return launch_sweep<SWEEP_CHECK>(p, s);
 }
 

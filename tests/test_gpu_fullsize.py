@@ -328,7 +328,7 @@ def test_per_pair_stop_with_a_long_iteration_cap_keeps_the_helper_protocol_sound
         assert int(it0) == int(it1) and torch.equal(T0, T1)
 
 
-@pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_90x2048"])
+@pytest.mark.parametrize("shape", ["config2_256x1024", "config4_shard_1024x2048", "ragged_600x1024", "ragged_90x2048", "small_against_long_48x10000"])
 def test_scoring_variants_change_nothing(shape):
     """The six candidate translations are scored by sorted sweeps with branch and bound when hist_icp has the clouds
     sorted anyway (nn.hip launch_sweep_score_pruned: blocks and waves leave a scan once its running LOWER bound rules
@@ -341,11 +341,27 @@ def test_scoring_variants_change_nothing(shape):
         S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
     elif shape == "ragged_600x1024":
         S, D, _ = synthetic.make_batch(600, 1024, seed=31, ragged=True, n_min=60)
+    elif shape == "small_against_long_48x10000":
+        # (round 5) clusters of 20 ... 10^4 points, the two clouds of a pair independent: a 40-point cloud against a 7000-point one --
+        # sweep blocks of ONE wave share their window over the block's four waves (512 <= targets < 2048), one-block clouds are
+        # scanned by eight blocks that leave partial minima in global memory (targets >= 2048): the same sums bit for bit, hence the
+        # same picks, poses and metrics as the all-pairs scans
+        S, D, _ = synthetic.make_batch(48, 10000, seed=0, ragged=True, n_min=20)
     else:
         S, D, _ = synthetic.make_batch(90, 2048, seed=5, ragged=True, n_min=40)
     a = rp.default_args(max_points=S.shape[1], icp_max_iterations=50)
     s, d = G(S), G(D)
     T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    if shape == "small_against_long_48x10000":
+        # ... and the roll-back check and match_eval sweeps against their all-pairs scans
+        with _lib.options(no_check_sweep=True):
+            Tc = utils_match.hist_icp(a, s, d)
+        assert torch.equal(Tc, T1)
+        ev1 = utils_match.match_eval(a, s, d, T1)
+        with _lib.options(no_eval_sweep=True):
+            ev0 = utils_match.match_eval(a, s, d, T1)
+        for x, y in zip(ev1, ev0):
+            assert torch.equal(x, y)
     with _lib.options(no_score_sweep=True):
         T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
     with _lib.options(no_score_prune=True):
