@@ -130,6 +130,7 @@ struct Workspace {
     float *history = nullptr;
     float *zsortA = nullptr, *zsortC = nullptr;   // z-sorted copies of both clouds (vote)
     float *zckey = nullptr;
+    float *pairBox = nullptr;   // long clouds: boxes by count_pair (grid.pairBox points here once they are written)
     float *voteKey = nullptr;   // per-pair sort-key parameters of the vote (votekey.hpp)
     int *zcidx = nullptr;
     IcpTeam team{};
@@ -182,6 +183,7 @@ struct Workspace {
             grid.cidx = (int *)take(cs);
             zckey = (float *)take(cs);
             zcidx = (int *)take(cs);
+            pairBox = (float *)take(b * kPairBoxStride * 4);
         }
         grid.axis = (int32_t *)take(b * 4);
         // (sweeps of a small cloud against a long one, shared by several blocks: nn.hip; only where the partial minima stay small)
@@ -417,7 +419,8 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
     // (N <= 16384), all-pairs otherwise -- identical bins either way
     if (N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE))
         ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.zsortC,
-                                            w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s, countFuse, sideBusy));
+                                            w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s, countFuse, sideBusy,
+                                            w.grid.pairBox));
     else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
     if (o.voteBins != nullptr)   // debug export of the bins the peak search is about to read
@@ -992,9 +995,11 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
     // lengths + swap (utils_match.py:139-146) + cleared scratch: by the vote's sort itself where one workgroup sorts a
     // cloud (PairCountFuse), by count_pair otherwise
     const bool countInSort = N <= kMaxSortN && N <= kChunkSortMinN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE);
-    if (!countInSort)
+    if (!countInSort) {
         launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s, w.ctrl, icp_ctrl_bytes(B), w.scoreAccum,
-                          (size_t)B * 12 * sizeof(double));
+                          (size_t)B * 12 * sizeof(double), w.pairBox);
+        w.grid.pairBox = w.pairBox;   // (for the sorts of exactly these clouds, lengths and roles: this call's)
+    }
     // the axis sort of both clouds (scoring sweep, ICP) runs on the side stream next to the vote
     hipEvent_t join = nullptr;
     bool teamPlanned = false;

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(1024) void count_pair_kernel(const float4 *__restri
                                                          int N, int32_t *__restrict__ lenA,
                                                          int32_t *__restrict__ lenC, uint8_t *__restrict__ swap,
                                                          uint32_t *__restrict__ zero0, unsigned words0,
-                                                         uint32_t *__restrict__ zero1, unsigned words1)
+                                                         uint32_t *__restrict__ zero1, unsigned words1,
+                                                         float *__restrict__ boxes)
 {
     __shared__ int scratch[2 * 16];
     const int b = blockIdx.x;
@@ -61,13 +62,62 @@ __global__ __launch_bounds__(1024) void count_pair_kernel(const float4 *__restri
         lenC[b] = c[1];
         if (swap != nullptr) swap[b] = c[0] > c[1] ? 1 : 0;
     }
+    if (boxes == nullptr) return;
+    // Bounding boxes for the sorts of LONG clouds (sort.hip: every chunk's workgroup would read the whole pair for them -- 11-13 us
+    // of each on a ragged batch of 128 pairs, measured with tools/dbg/sort_clocks.py): per cloud, the flagged rows and all rows below the count
+    // (min / max are exact in any order: the same numbers the sorts would find).  The rows were fetched by the count just now.
+    __shared__ float boxSh[16][kPairBoxStride];
+    float bx[kPairBoxStride];
+#pragma unroll
+    for (int k = 0; k < kPairBoxStride; ++k) bx[k] = ((k % 6) < 3) ? kInf : -kInf;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const float4 *pts = side == 0 ? pa : pc;
+        const int n = c[side];
+        for (int j0 = threadIdx.x; j0 < n; j0 += 4 * blockDim.x) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = pts[min(j0 + u * (int)blockDim.x, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u * (int)blockDim.x >= n) continue;
+                const float v[3] = {q[u].x, q[u].y, q[u].z};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    bx[side * 12 + 6 + k] = fminf(bx[side * 12 + 6 + k], v[k]);
+                    bx[side * 12 + 9 + k] = fmaxf(bx[side * 12 + 9 + k], v[k]);
+                    if (q[u].w > 0.0f) {
+                        bx[side * 12 + k] = fminf(bx[side * 12 + k], v[k]);
+                        bx[side * 12 + 3 + k] = fmaxf(bx[side * 12 + 3 + k], v[k]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPairBoxStride; ++k)
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const float other = __shfl_xor(bx[k], o, kWave);
+            bx[k] = ((k % 6) < 3) ? fminf(bx[k], other) : fmaxf(bx[k], other);
+        }
+    if ((threadIdx.x & (kWave - 1)) == 0)
+#pragma unroll
+        for (int k = 0; k < kPairBoxStride; ++k) boxSh[threadIdx.x >> 6][k] = bx[k];
+    __syncthreads();
+    if (threadIdx.x < kPairBoxStride) {
+        const int k = threadIdx.x;
+        float v = boxSh[0][k];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = ((k % 6) < 3) ? fminf(v, boxSh[w][k]) : fmaxf(v, boxSh[w][k]);
+        boxes[(size_t)b * kPairBoxStride + k] = v;
+    }
 }
 
 void launch_count_pair(const float *A, const float *C, int B, int N, int32_t *lenA, int32_t *lenC, uint8_t *swap,
-                       hipStream_t s, void *zero0, size_t bytes0, void *zero1, size_t bytes1)
+                       hipStream_t s, void *zero0, size_t bytes0, void *zero1, size_t bytes1, float *boxes)
 {
     hipLaunchKernelGGL(count_pair_kernel, dim3(B), dim3(1024), 0, s, (const float4 *)A, (const float4 *)C, N, lenA,
-                       lenC, swap, (uint32_t *)zero0, (unsigned)(bytes0 / 4), (uint32_t *)zero1, (unsigned)(bytes1 / 4));
+                       lenC, swap, (uint32_t *)zero0, (unsigned)(bytes0 / 4), (uint32_t *)zero1, (unsigned)(bytes1 / 4), boxes);
 }
 
 void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s)
@@ -508,7 +558,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
                                    uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
-                                   const PairCountFuse *fuse, bool sideBusy)
+                                   const PairCountFuse *fuse, bool sideBusy, const float *boxes)
 {
     if (fuse != nullptr && N > kChunkSortMinN) return hipErrorInvalidValue;   // only zsort_kernel counts
     const size_t L = (size_t)lens[0] * lens[1] * lens[2];
@@ -520,7 +570,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     }
     if (N > kChunkSortMinN && ckey != nullptr) {   // long clouds: several workgroups per sort (sort.hip)
         hipError_t e = launch_zsort_chunked(X, Y, nX, nY, B, N, sortX, sortY, bins_u32, (int)L, ckey, cidx, ez, lens[2],
-                                            keyRec, s);
+                                            keyRec, s, boxes);
         if (e != hipSuccess) return e;
     } else {
         ZsortCount zc{};

@@ -2373,6 +2373,22 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
         __syncthreads();
         return part[0] + part[1] + part[2] + part[3];
     };
+    // block-wide exclusive prefix sum of one int per thread, in thread order (all threads call it)
+    auto block_prefix_int = [&](int v) -> int {
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const int up = __shfl_up(inc, o, kWave);
+            if (lane >= o) inc += up;
+        }
+        __syncthreads();
+        if (lane == kWave - 1) part[wv] = inc;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) base += (k < wv) ? part[k] : 0;
+        return base + inc - v;
+    };
     const int nSmall = block_sum_int(small ? 1 : 0), nBig = B - nSmall;
     const int sumMin = block_sum_int(big ? gMin : 0);
     const int sumWish = block_sum_int(big ? max(gWish, gMin) : 0);
@@ -2436,21 +2452,13 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
 #pragma unroll
             for (int k = 0; k + 1 < kLevels; ++k)
                 if (big && lvG[k] == G && lvC[k + 1] < 3.0e38f && want == 0) want = lvG[k + 1] - G;
-            size[b] = want;
-            __syncthreads();
-            int before = 0;
-            for (int k = 0; k < b; ++k) before += size[k];
+            const int before = block_prefix_int(want);
             if (want > 0 && before + want <= left) G += want;
-            __syncthreads();
         }
     }
     // a chain of single-pass pairs is one workgroup: its first pair carries the slot, the others hang on t.next
     {
-        size[b] = small ? 1 : 0;
-        __syncthreads();
-        int seq = 0;                    // this small pair's number among the small pairs (in pair order)
-        if (small) for (int k = 0; k < b; ++k) seq += size[k];
-        __syncthreads();
+        const int seq = block_prefix_int(small ? 1 : 0);   // this small pair's number among the small pairs (in pair order)
         if (small) first[seq] = b;      // (first[] is scratch here: small pair number -> pair)
         __syncthreads();
         const bool head = small && (seq % chain) == 0;
@@ -2466,8 +2474,9 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     // single workgroups then fill what is left, XCD by XCD.
     const int per = (t.maxWG % 8 == 0) ? t.maxWG / 8 : t.maxWG;
     const int nx = (per == t.maxWG) ? 1 : 8;
-    int teamNo = 0, singleNo = 0;       // this pair's number among the teams / the single workgroups (in pair order)
-    for (int k = 0; k < b; ++k) { teamNo += size[k] > 1 ? 1 : 0; singleNo += size[k] == 1 ? 1 : 0; }
+    // this pair's number among the teams / the single workgroups (in pair order; both counts in one word)
+    const int numbers = block_prefix_int((b < B && size[b] > 1 ? 1 << 16 : 0) + (b < B && size[b] == 1 ? 1 : 0));
+    const int teamNo = numbers >> 16, singleNo = numbers & 0xffff;
     if (b < B && size[b] > 1) teamList[teamNo] = b;
     const int nTeams = block_sum_int((b < B && size[b] > 1) ? 1 : 0);
     if (b == 0) {
@@ -3060,7 +3069,7 @@ hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t 
         ensure_dynamic_lds(reinterpret_cast<const void *>(&sort_clouds_kernel), 128 * 1024, &g_sortAttr);
     if (N > kChunkSortMinN && grid->ckey != nullptr)   // long clouds: several workgroups per sort (sort.hip)
         return launch_sort_clouds_chunked(X, Y, lenX, lenY, swap, nullptr, B, N, grid->axis, grid->sortX, grid->pts,
-                                          grid->sortYsoa, grid->sortXsoa, grid->ckey, grid->cidx, s);
+                                          grid->sortYsoa, grid->sortXsoa, grid->ckey, grid->cidx, s, grid->pairBox);
     hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY, swap,
                        (const float *)nullptr, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts,
                        grid->sortYsoa, grid->sortXsoa, selfCount);

@@ -106,7 +106,8 @@ constexpr int kHistStride = 16;   // floats per (iteration, pair): R (9), T (3),
 void launch_count_valid(const float *pts, int B, int N, int32_t *len, hipStream_t s);
 // (also zeroes up to two scratch buffers the later kernels of the call want cleared: saves their memsets)
 void launch_count_pair(const float *A, const float *C, int B, int N, int32_t *lenA, int32_t *lenC, uint8_t *swap,
-                       hipStream_t s, void *zero0 = nullptr, size_t bytes0 = 0, void *zero1 = nullptr, size_t bytes1 = 0);
+                       hipStream_t s, void *zero0 = nullptr, size_t bytes0 = 0, void *zero1 = nullptr, size_t bytes1 = 0,
+                       float *boxes = nullptr);   // boxes: [B, 24] bounding boxes for the sorts of long clouds (votekey.hpp), or NULL
 hipError_t launch_hist_vote(const float *X, const float *Y, int B, int NX, int NY,
                             const float mins[3], const float maxs[3], const int lens[3],
                             const float *ex, const float *ey, const float *ez,
@@ -122,17 +123,18 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
                                    uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
-                                   const PairCountFuse *fuse = nullptr, bool sideBusy = false);
+                                   const PairCountFuse *fuse = nullptr, bool sideBusy = false, const float *boxes = nullptr);
 // sort.hip: several workgroups per long cloud; same outputs as zsort_kernel / sort_clouds_kernel
 constexpr int kChunkSortMinN = 4096;
+constexpr int kPairBoxStride = 24;   // floats per pair of count_pair's boxes (votekey.hpp)
 int chunk_sort_length(int N);
 hipError_t launch_zsort_chunked(const float *P, const float *Q, const int32_t *nP, const int32_t *nQ, int B, int N,
                                 float *outP, float *outQ, uint32_t *bins, int L, float *ckey, int *cidx,
-                                const float *ez, int len_z, float *keyRec, hipStream_t s);
+                                const float *ez, int len_z, float *keyRec, hipStream_t s, const float *boxes = nullptr);
 hipError_t launch_sort_clouds_chunked(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                                       const uint8_t *swap, const float *prePose, int B, int N, int32_t *axisOut,
                                       float *Xs, float *Ys, float *Ysoa, float *Xsoa, float *ckey, int *cidx,
-                                      hipStream_t s);
+                                      hipStream_t s, const float *boxes = nullptr);
 hipError_t launch_u32_to_f32(const uint32_t *in, float *out, size_t n, hipStream_t s);
 hipError_t launch_hist_peaks_f32(const float *bins, int B, int Lx, int Ly, int Lz, int k,
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
@@ -195,6 +197,7 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     int32_t *axis;     // sweep: [B]
     float *ckey;       // long clouds (N > kChunkSortMinN): chunk-sorted keys / rows of the multi-workgroup sort
     int *cidx;         //   [B,2,chunk_sort_length(N)] each (sort.hip), else NULL
+    const float *pairBox;  // long clouds: [B, 24] boxes left by count_pair for THESE clouds, lengths and roles (NULL: the sorts look)
     float *shareBest;  // sweeps (nn.hip): [B*12, 8, 256] partial minima of small-against-long jobs shared by several blocks, or NULL
     int *shareCount;   //   [B*12] blocks delivered (cleared by every sweep launch)
     int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose

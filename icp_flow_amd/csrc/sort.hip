@@ -20,7 +20,11 @@
 namespace icpflow {
 
 constexpr int kCsChunk = 2048;   // keys per chunk (one 1024-thread workgroup, 16 KiB of LDS)
-constexpr int kCsBlock = 1024;
+#ifndef ICPFLOW_CS_BLOCK
+#define ICPFLOW_CS_BLOCK 1024
+#endif
+constexpr int kCsBlock = ICPFLOW_CS_BLOCK;   // threads of a chunk's sort
+constexpr int kCmBlock = 1024;               // threads of the merge (one element each)
 
 struct ChunkSortParams {
     int mode;                 // 0: by z (vote), 1: along the fixed cloud's longest axis (sweeps)
@@ -40,6 +44,7 @@ struct ChunkSortParams {
     const float *ez;          // mode 0: z edges of the vote box (slab thickness of the composite key)
     int len_z;
     float *keyRec;            // mode 0: [B, kVoteKeyStride] key parameters, written here, read by the vote
+    const float *boxes;       // [B, kPairBoxStride] bounding boxes by count_pair_kernel, or NULL (every workgroup reads its pair)
 };
 
 // cloud roles of mode 1 exactly as sort_clouds_kernel resolves them
@@ -111,6 +116,13 @@ __device__ __forceinline__ float sort_key(const ChunkSortParams &p, const Roles 
     return axis == 0 ? px : (axis == 1 ? py : pz);
 }
 
+#ifdef ICPFLOW_SORT_CLOCK
+__device__ unsigned long long g_sortClock[2][4096][6];
+#define SORT_STAMP(k) do { if (threadIdx.x == 0 && slotId < 4096) g_sortClock[p.mode][slotId][k] = wall_clock64(); } while (0)
+#else
+#define SORT_STAMP(k) do { } while (0)
+#endif
+
 // grid (B, 2, NPc / kCsChunk)
 __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
 {
@@ -121,6 +133,11 @@ __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
     const int b = blockIdx.x, which = blockIdx.y, c = blockIdx.z;
     const Roles r = roles_of(p, b, which);
     const int base = c * kCsChunk;
+#ifdef ICPFLOW_SORT_CLOCK
+    const int slotId = (c * 2 + which) * gridDim.x + b;
+    if (threadIdx.x == 0 && slotId < 4096) { for (int k = 1; k < 5; ++k) g_sortClock[p.mode][slotId][k] = 0ull; g_sortClock[p.mode][slotId][5] = (unsigned long long)r.n; }
+#endif
+    SORT_STAMP(0);
     if (p.mode == 0 && c == 0) {   // clear this pair's counters (each of its two clouds takes one half)
         const int half = (p.L + 1) / 2;
         uint32_t *h = p.bins + (size_t)b * p.L + (size_t)which * half;
@@ -130,7 +147,19 @@ __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
     if (base >= r.n && c != 0) return;   // (chunk 0 still publishes the pair's axis / key parameters)
     int axis = 0;
     VoteKey vk{};
-    if (p.mode == 1) {
+    if (p.mode == 1 && p.boxes != nullptr) {
+        // (fixed role = swap ? X : Y = cloud A / C of count_pair; its rows below the count, flagged or not)
+        const float *bx = p.boxes + (size_t)b * kPairBoxStride + ((p.swap != nullptr && p.swap[b] != 0) ? 0 : 12) + 6;
+        const float e0 = bx[3] - bx[0], e1 = bx[4] - bx[1], e2 = bx[5] - bx[2];
+        axis = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2);
+        if (c == 0 && which == 0 && threadIdx.x == 0) p.axisOut[b] = axis;
+        if (base >= r.n) return;
+    } else if (p.mode == 0 && p.boxes != nullptr) {
+        vk = vote_key_params_boxed(p.boxes + (size_t)b * kPairBoxStride, min(p.nP[b], p.N), min(p.nQ[b], p.N),
+                                   p.ez[p.len_z - 1] - p.ez[0], keySh);
+        if (c == 0 && which == 0 && threadIdx.x < kVoteKeyStride) p.keyRec[(size_t)b * kVoteKeyStride + threadIdx.x] = keySh[threadIdx.x];
+        if (base >= r.n) return;
+    } else if (p.mode == 1) {
         axis = fixed_axis(p, b, bb, &axisSh);
         if (c == 0 && which == 0 && threadIdx.x == 0) p.axisOut[b] = axis;
         if (base >= r.n) return;
@@ -140,16 +169,24 @@ __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
         if (c == 0 && which == 0 && threadIdx.x < kVoteKeyStride) p.keyRec[(size_t)b * kVoteKeyStride + threadIdx.x] = keySh[threadIdx.x];
         if (base >= r.n) return;
     }
-    for (int j = threadIdx.x; j < kCsChunk; j += kCsBlock) {
+    SORT_STAMP(1);
+    // the network only has to hold THIS chunk's rows: the next power of two >= their number (a batch padded to its
+    // longest cloud is mostly short clouds; the merge reads the first r.n entries of a cloud and nothing behind them)
+    int np2 = kWave;
+    while (np2 < min(kCsChunk, r.n - base)) np2 <<= 1;
+    for (int j = threadIdx.x; j < np2; j += kCsBlock) {
         float k = kInf, px, py, pz;
         if (base + j < r.n) k = sort_key(p, r, b, axis, vk, base + j, px, py, pz);
         kv[j] = sort_pack(k, base + j);
     }
     __syncthreads();
-    bitonic_sort_lds(kv, kCsChunk);
+    SORT_STAMP(2);
+    bitonic_sort_lds(kv, np2);
+    SORT_STAMP(3);
     float *ck = p.ckey + ((size_t)b * 2 + which) * p.NPc + base;
     int *ci = p.cidx + ((size_t)b * 2 + which) * p.NPc + base;
-    for (int j = threadIdx.x; j < kCsChunk; j += kCsBlock) { const unsigned long long w = kv[j]; ck[j] = sort_key_of(w); ci[j] = sort_index_of(w); }
+    for (int j = threadIdx.x; j < np2; j += kCsBlock) { const unsigned long long w = kv[j]; ck[j] = sort_key_of(w); ci[j] = sort_index_of(w); }
+    SORT_STAMP(4);
 }
 
 // number of elements (k, i) of a sorted chunk with (k, i) < (key, id), lexicographic
@@ -166,11 +203,11 @@ __device__ __forceinline__ int count_less(const float *__restrict__ ck, const in
     return lo;
 }
 
-// grid (B, 2, ceil(NPc / kCsBlock)): one element per thread
-__global__ __launch_bounds__(kCsBlock) void chunk_merge_kernel(ChunkSortParams p)
+// grid (B, 2, ceil(NPc / kCmBlock)): one element per thread
+__global__ __launch_bounds__(kCmBlock) void chunk_merge_kernel(ChunkSortParams p)
 {
     const int b = blockIdx.x, which = blockIdx.y;
-    const int e = blockIdx.z * kCsBlock + threadIdx.x;
+    const int e = blockIdx.z * kCmBlock + threadIdx.x;
     const Roles r = roles_of(p, b, which);
     const int NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
     float4 *out = (p.mode == 0) ? ((which == 0 ? p.outP : p.outQ) + (size_t)b * p.N)
@@ -213,7 +250,7 @@ static hipError_t run_chunk_sort(ChunkSortParams p, int B, hipStream_t s)
     const int NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
     const int span = NP16 > p.NPc ? NP16 : p.NPc;
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(B, 2, p.NPc / kCsChunk), dim3(kCsBlock), 0, s, p);
-    hipLaunchKernelGGL(chunk_merge_kernel, dim3(B, 2, (span + kCsBlock - 1) / kCsBlock), dim3(kCsBlock), 0, s, p);
+    hipLaunchKernelGGL(chunk_merge_kernel, dim3(B, 2, (span + kCmBlock - 1) / kCmBlock), dim3(kCmBlock), 0, s, p);
     return hipGetLastError();
 }
 
@@ -221,25 +258,33 @@ int chunk_sort_length(int N) { return (N + kCsChunk - 1) / kCsChunk * kCsChunk; 
 
 hipError_t launch_zsort_chunked(const float *P, const float *Q, const int32_t *nP, const int32_t *nQ, int B, int N,
                                 float *outP, float *outQ, uint32_t *bins, int L, float *ckey, int *cidx,
-                                const float *ez, int len_z, float *keyRec, hipStream_t s)
+                                const float *ez, int len_z, float *keyRec, hipStream_t s, const float *boxes)
 {
     ChunkSortParams p{};
     p.mode = 0; p.P = (const float4 *)P; p.Q = (const float4 *)Q; p.nP = nP; p.nQ = nQ; p.N = N;
     p.NPc = chunk_sort_length(N); p.ckey = ckey; p.cidx = cidx; p.outP = (float4 *)outP; p.outQ = (float4 *)outQ;
-    p.bins = bins; p.L = L; p.ez = ez; p.len_z = len_z; p.keyRec = keyRec;
+    p.bins = bins; p.L = L; p.ez = ez; p.len_z = len_z; p.keyRec = keyRec; p.boxes = boxes;
     return run_chunk_sort(p, B, s);
 }
 
 hipError_t launch_sort_clouds_chunked(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                                       const uint8_t *swap, const float *prePose, int B, int N, int32_t *axisOut,
                                       float *Xs, float *Ys, float *Ysoa, float *Xsoa, float *ckey, int *cidx,
-                                      hipStream_t s)
+                                      hipStream_t s, const float *boxes)
 {
     ChunkSortParams p{};
     p.mode = 1; p.P = (const float4 *)X; p.Q = (const float4 *)Y; p.nP = lenX; p.nQ = lenY; p.swap = swap;
     p.prePose = prePose; p.N = N; p.NPc = chunk_sort_length(N); p.ckey = ckey; p.cidx = cidx;
-    p.outP = (float4 *)Xs; p.outQ = (float4 *)Ys; p.Ysoa = Ysoa; p.Xsoa = Xsoa; p.axisOut = axisOut;
+    p.outP = (float4 *)Xs; p.outQ = (float4 *)Ys; p.Ysoa = Ysoa; p.Xsoa = Xsoa; p.axisOut = axisOut; p.boxes = boxes;
     return run_chunk_sort(p, B, s);
 }
 
 }  // namespace icpflow
+
+#ifdef ICPFLOW_SORT_CLOCK
+extern "C" int icpflow_debug_sort_clock(unsigned long long *out)
+{
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(icpflow::g_sortClock), sizeof(icpflow::g_sortClock));
+}
+#endif

@@ -60,6 +60,33 @@ __device__ __forceinline__ void bbox_rows(const float4 *__restrict__ pts, int n,
     }
 }
 
+// key parameters from the bounding box of the valid rows of both clouds (one thread)
+__device__ __forceinline__ void vote_key_from_box(const float (&lo)[3], const float (&hi)[3], float hBox, float *result)
+{
+    const int ua = (hi[0] - lo[0]) >= (hi[1] - lo[1]) ? 0 : 1;
+    const float eu = hi[ua] - lo[ua], ez = hi[2] - lo[2];
+    const float h = fmaxf(hBox, 1e-3f);
+    const bool wide = eu > kWideMinExtent && eu < 1000.f && ez < 250.f * h;
+    result[0] = wide ? 1.f : 0.f; result[1] = (float)ua; result[2] = lo[ua]; result[3] = lo[2]; result[4] = h;
+}
+
+// the same from the boxes count_pair_kernel leaves per pair (kPairBoxStride floats: cloud A / C x flagged rows / all rows
+// below the count x (min xyz, max xyz)): the flagged boxes of both clouds, merged
+__device__ inline VoteKey vote_key_params_boxed(const float *__restrict__ box, int nP, int nQ, float hBox, float *result)
+{
+    if (threadIdx.x == 0) {
+        if (nP + nQ <= kWideMinPoints) {
+            result[0] = 0.f; result[1] = 0.f; result[2] = 0.f; result[3] = 0.f; result[4] = fmaxf(hBox, 1e-3f);
+        } else {
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(box[k], box[12 + k]); hi[k] = fmaxf(box[3 + k], box[15 + k]); }
+            vote_key_from_box(lo, hi, hBox, result);
+        }
+    }
+    __syncthreads();
+    return vote_key_load(result);
+}
+
 // Block-cooperative: bounding box of the valid rows of BOTH clouds -> key parameters (identical in every
 // block that calls it for the same pair).  scratch: 6 floats per wave of the block.
 __device__ inline VoteKey vote_key_params(const float4 *__restrict__ P, int nP, const float4 *__restrict__ Q,
@@ -91,11 +118,7 @@ __device__ inline VoteKey vote_key_params(const float4 *__restrict__ P, int nP, 
             lo[k] = scratch[k]; hi[k] = scratch[3 + k];
             for (int w = 1; w < nwave; ++w) { lo[k] = fminf(lo[k], scratch[w * 6 + k]); hi[k] = fmaxf(hi[k], scratch[w * 6 + 3 + k]); }
         }
-        const int ua = (hi[0] - lo[0]) >= (hi[1] - lo[1]) ? 0 : 1;
-        const float eu = hi[ua] - lo[ua], ez = hi[2] - lo[2];
-        const float h = fmaxf(hBox, 1e-3f);
-        const bool wide = eu > kWideMinExtent && eu < 1000.f && ez < 250.f * h;
-        result[0] = wide ? 1.f : 0.f; result[1] = (float)ua; result[2] = lo[ua]; result[3] = lo[2]; result[4] = h;
+        vote_key_from_box(lo, hi, hBox, result);
     }
     __syncthreads();
     return vote_key_load(result);
