@@ -130,6 +130,8 @@ struct Workspace {
     float *history = nullptr;
     float *zsortA = nullptr, *zsortC = nullptr;   // z-sorted copies of both clouds (vote)
     float *zckey = nullptr;
+    int32_t *voteWork = nullptr;   // work list of the sorted vote on wide ragged batches (hist.hip: vote_plan_kernel)
+    size_t voteWorkCap = 0;
     float *pairBox = nullptr;   // long clouds: boxes by count_pair (grid.pairBox points here once they are written)
     float *voteKey = nullptr;   // per-pair sort-key parameters of the vote (votekey.hpp)
     int *zcidx = nullptr;
@@ -177,6 +179,8 @@ struct Workspace {
         zsortA = (float *)take(b * (size_t)N * 16);
         zsortC = (float *)take(b * (size_t)N * 16);
         voteKey = (float *)take(b * 8 * 4);
+        voteWorkCap = vote_work_capacity(B, N);
+        if (voteWorkCap != 0) voteWork = (int32_t *)take(voteWorkCap * 4);
         if (N > kChunkSortMinN) {   // scratch of the multi-workgroup sorts (one set per concurrent sort)
             const size_t cs = b * 2 * (size_t)chunk_sort_length(N) * 4;
             grid.ckey = (float *)take(cs);
@@ -225,7 +229,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
     if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
-    if (opt->flags >> 14) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    if (opt->flags >> 15) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
     o.search = opt->icp_search;
     o.arith = opt->icp_arith;
     o.flags = opt->flags;
@@ -420,7 +424,7 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
     if (N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE))
         ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.zsortC,
                                             w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s, countFuse, sideBusy,
-                                            w.grid.pairBox));
+                                            w.grid.pairBox, o.on(ICPFLOW_OPT_NO_VOTE_LIST) ? w.voteWork : nullptr, w.voteWorkCap));
     else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
     if (o.voteBins != nullptr)   // debug export of the bins the peak search is about to read

@@ -433,12 +433,19 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     const int32_t *__restrict__ nYv, int N, int len_x, int len_y, int len_z,
     const float *__restrict__ ex, const float *__restrict__ ey, const float *__restrict__ ez,
     const uint8_t *__restrict__ swap, int useLds, uint32_t *__restrict__ bins_u32,
-    const float *__restrict__ keyRec, int span)
+    const float *__restrict__ keyRec, int span, const int32_t *__restrict__ work, int nPairs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + sizeof(float4) * kVoteTile);
-    const int b = blockIdx.y;
+    // work list (vote_plan_kernel; a 1-D grid): this workgroup's (pair, row block, share of the Y rows), the workgroups
+    // WITH rows first and the largest pairs first -- or nothing at all
+    int item = 0;
+    if (work != nullptr) {
+        item = work[blockIdx.x];
+        if (item < 0) return;
+    }
+    const int b = work != nullptr ? (item & 1023) : (int)blockIdx.y;
     const VoteKey vk = vote_key_load(keyRec + (size_t)b * kVoteKeyStride);
     const bool sw = swap != nullptr && swap[b] != 0;
     const float4 *xb = (sw ? Ys : Xs) + (size_t)b * N;
@@ -453,16 +460,17 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     // gets slabs from everywhere (SQ counters before: 7.5 of a CU's 16 waves resident on average).
     constexpr int kRows = BLOCK / SPLIT;            // X rows per workgroup
     constexpr int kRowWaves = kRows / kWave;
-    const int rowBlocks = (N + kRows - 1) / kRows;
-    const int rb = blockIdx.x / tsplit;
-    const int jBegin = (blockIdx.x % tsplit) * span;
+    // (with a work list the waves are dealt over the row blocks the pair HAS, not over those of the padded width)
+    const int rowBlocks = work != nullptr ? (nx + kRows - 1) / kRows : (N + kRows - 1) / kRows;
+    const int rb = work != nullptr ? ((item >> 10) & 255) : (int)blockIdx.x / tsplit;
+    const int jBegin = (work != nullptr ? (item >> 18) : (int)blockIdx.x % tsplit) * span;
     if (rb * kWave >= nx || jBegin >= ny) return;  // sorted: valid rows first (rb * 64: the first row of wave 0)
     const float min_x = ex[0], max_x = ex[len_x - 1];
     const float min_y = ey[0], max_y = ey[len_y - 1];
     const float min_z = ez[0], max_z = ez[len_z - 1];
     const int L = len_x * len_y * len_z;
     uint32_t *gb = bins_u32 + (size_t)b * L;
-    const bool lastPair = b + 1 == (int)gridDim.y;
+    const bool lastPair = b + 1 == nPairs;
     const int Lx = L + vote_overflow_bins(len_y, len_z);   // LDS counters: the pair's bins + the overflow row (vote_range)
     const int limit = lastPair ? L : 0x7fffffff;
     const int lane = threadIdx.x & (kWave - 1);
@@ -554,11 +562,73 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
     }
 }
 
+// Work list of the sorted vote on batches of few, wide, RAGGED pairs (a frame's clusters padded to their longest, the ragged
+// real-shape batch): the grid (row blocks of the padded width) x (shares of the padded Y rows) x pairs is 87 % workgroups
+// without rows there -- 50 560 workgroups for 6 000 with work, each holding 36 KiB of LDS and eight waves while it finds that
+// out, in front of the ones with work in dispatch order (a CU held 0.5 working workgroups on average: SQ_WAVE_CYCLES) -- and
+// the largest pair starts wherever the batch put it.  Entry e of the list is the e-th workgroup WITH rows, the pairs taken
+// by decreasing number of workgroups (ties by pair number), inside a pair row block by row block; entries behind the last
+// one are -1 and their workgroups leave at once, after everybody else has been dispatched.  The counters are integers:
+// neither the order nor the dealing of a pair's waves changes a bin.
+// grid: ceil(U / 1024) blocks of 1024 threads, U = capacity of the list; nPairs <= 1024
+__global__ __launch_bounds__(1024) void vote_plan_kernel(const int32_t *__restrict__ nXv, const int32_t *__restrict__ nYv,
+                                                         const uint8_t *__restrict__ swap, int nPairs, int rows, int span,
+                                                         int U, int32_t *__restrict__ work)
+{
+    __shared__ int wk[1024], by_[1024], order[1024], start[1025], part[16];
+    const int t = threadIdx.x, lane = t & (kWave - 1), wv = t >> 6;
+    int mine = 0, byMine = 0;
+    if (t < nPairs) {
+        const bool sw = swap != nullptr && swap[t] != 0;
+        const int nx = (sw ? nYv : nXv)[t], ny = (sw ? nXv : nYv)[t];
+        byMine = (ny + span - 1) / span;
+        mine = ((nx + rows - 1) / rows) * byMine;
+    }
+    wk[t] = mine;
+    __syncthreads();
+    int rank = 0;
+    if (t < nPairs)
+        for (int u = 0; u < nPairs; ++u) { const int o = wk[u]; rank += (o > mine || (o == mine && u < t)) ? 1 : 0; }
+    __syncthreads();
+    if (t < nPairs) { order[rank] = t; by_[rank] = byMine; }
+    __syncthreads();
+    // exclusive prefix over the sorted counts
+    const int v = t < nPairs ? wk[order[t]] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(inc, o, kWave); if (lane >= o) inc += up; }
+    if (lane == kWave - 1) part[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; ++k) base += part[k];
+    start[t] = base + inc - v;
+    if (t == 1023) start[1024] = base + inc;
+    __syncthreads();
+    const int total = start[1024];
+    const int e = blockIdx.x * 1024 + t;
+    if (e >= U) return;
+    int item = -1;
+    if (e < total) {
+        int lo = 0, hi = nPairs;                 // last r with start[r] <= e
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (start[mid] <= e) lo = mid; else hi = mid; }
+        const int q = e - start[lo], by = by_[lo];
+        item = order[lo] | ((q / by) << 10) | ((q % by) << 18);
+    }
+    work[e] = item;
+}
+
+size_t vote_work_capacity(int B, int N)
+{
+    if (N <= 1023 || B > 1024) return 0;   // (the work list serves the four-waves-per-64-rows variant: ICPFLOW_VOTE_WIDE_N)
+    const size_t full = (size_t)B * ((N + 127) / 128) * ((N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile));
+    return full > 32768 ? full : 32768;    // (small batches shorten the span: never above 16384 workgroups)
+}
+
 hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, int32_t *nY,
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
                                    uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
-                                   const PairCountFuse *fuse, bool sideBusy, const float *boxes)
+                                   const PairCountFuse *fuse, bool sideBusy, const float *boxes, int32_t *work, size_t workCap)
 {
     if (fuse != nullptr && N > kChunkSortMinN) return hipErrorInvalidValue;   // only zsort_kernel counts
     const size_t L = (size_t)lens[0] * lens[1] * lens[2];
@@ -595,6 +665,9 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
 #ifndef ICPFLOW_VOTE_WIDE_N
 #define ICPFLOW_VOTE_WIDE_N 1023
 #endif
+#ifndef ICPFLOW_VOTE_LIST_MIN_N
+#define ICPFLOW_VOTE_LIST_MIN_N 4097
+#endif
 #ifndef ICPFLOW_VOTE_WIDE_B
 #define ICPFLOW_VOTE_WIDE_B 2
 #endif
@@ -623,21 +696,31 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     // (256 x 1024) 0.712 / 0.709 / 0.700 / 0.700 / 0.703 ms per step; batches above 2 x #CUs pairs are not concerned.
     if (useLds && N > kVoteWideN && B <= kVoteWideB * cus) {
         dim3 grid(((N + 127) / 128) * tsplit, B);
+        const size_t U = (size_t)grid.x * B;
+        // (from the width on at which count_pair, not the sort, counts the rows: a full batch like config 2's 256 x 1024 gains nothing
+        // and pays the plan's launch, 0.705 -> 0.72 ms per step)
+        const bool listed = work != nullptr && U <= workCap && B <= 1024 && grid.x / tsplit <= 256 && tsplit <= 128 &&
+                            N >= ICPFLOW_VOTE_LIST_MIN_N;
+        if (listed) {
+            hipLaunchKernelGGL(vote_plan_kernel, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, s, nX, nY, swap, B, 128, span,
+                               (int)U, work);
+            grid = dim3((unsigned)U, 1);
+        }
         hipLaunchKernelGGL((hist_vote_sorted_kernel<512, 4>), grid, dim3(512), lds_hist, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                           ez, swap, useLds, bins_u32, keyRec, span);
+                           ez, swap, useLds, bins_u32, keyRec, span, listed ? work : (const int32_t *)nullptr, B);
         return hipGetLastError();
     }
     if (block == 1024) {
         dim3 grid(((N + 1023) / 1024) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<1024>, grid, dim3(1024), useLds ? lds_hist : tile_bytes, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                           ez, swap, useLds, bins_u32, keyRec, span);
+                           ez, swap, useLds, bins_u32, keyRec, span, (const int32_t *)nullptr, B);
     } else if (block == 512 && !split) {
         dim3 grid(((N + 511) / 512) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<512>, grid, dim3(512), useLds ? lds_hist : tile_bytes, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                           ez, swap, useLds, bins_u32, keyRec, span);
+                           ez, swap, useLds, bins_u32, keyRec, span, (const int32_t *)nullptr, B);
     } else if (split) {
         // 256 rows per workgroup, two waves per 64 rows (SPLIT): 32 waves per CU at four workgroups per CU.  Not beside the
         // axis sort of hist_icp's side stream: its 1024-thread workgroups find no room on a CU that full and the sort,
@@ -645,12 +728,12 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
         dim3 grid(((N + kVoteBlock - 1) / kVoteBlock) * tsplit, B);
         hipLaunchKernelGGL((hist_vote_sorted_kernel<2 * kVoteBlock, 2>), grid, dim3(2 * kVoteBlock), lds_hist, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                           ez, swap, useLds, bins_u32, keyRec, span);
+                           ez, swap, useLds, bins_u32, keyRec, span, (const int32_t *)nullptr, B);
     } else {
         dim3 grid(((N + kVoteBlock - 1) / kVoteBlock) * tsplit, B);
         hipLaunchKernelGGL(hist_vote_sorted_kernel<kVoteBlock>, grid, dim3(kVoteBlock), useLds ? lds_hist : tile_bytes, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                           ez, swap, useLds, bins_u32, keyRec, span);
+                           ez, swap, useLds, bins_u32, keyRec, span, (const int32_t *)nullptr, B);
     }
     return hipGetLastError();
 }

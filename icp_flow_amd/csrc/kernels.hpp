@@ -123,7 +123,9 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
                                    uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
-                                   const PairCountFuse *fuse = nullptr, bool sideBusy = false, const float *boxes = nullptr);
+                                   const PairCountFuse *fuse = nullptr, bool sideBusy = false, const float *boxes = nullptr,
+                                   int32_t *work = nullptr, size_t workCap = 0);   // work: scratch of the vote's work list (ints), or NULL
+size_t vote_work_capacity(int B, int N);   // ints the work list of a batch can take (0: such batches never use one)
 // sort.hip: several workgroups per long cloud; same outputs as zsort_kernel / sort_clouds_kernel
 constexpr int kChunkSortMinN = 4096;
 constexpr int kPairBoxStride = 24;   // floats per pair of count_pair's boxes (votekey.hpp)

@@ -530,13 +530,17 @@ def _fused_cases():
     Sc, Dc, _ = synthetic.make_batch(3, 6000, seed=5)
     Sc[1, 4000:] = (1e8, 1e8, 1e8, 0.0)                      # one shorter cloud in the chunk-sorted batch
     Sg, Dg, _ = synthetic.make_batch(6, 900, seed=21, ragged=True)
-    return {"config2_256x1024_tf2": (S2, D2, 2.0), "ragged_24x700_tf2": (Sr, Dr, 2.0),
+    Sv, Dv, _ = synthetic.make_batch(12, 5000, seed=31, ragged=True, n_min=20)   # the vote's work list: very unequal pairs,
+    Sv[3, :, 3] = 0.0                                                            # one without a single src row
+    Sv[3, :, :3] = 1e8
+    return {"ragged_wide_12x5000_work_list_tf2": (Sv, Dv, 2.0), "config2_256x1024_tf2": (S2, D2, 2.0), "ragged_24x700_tf2": (Sr, Dr, 2.0),
             "wide_cluster_composite_key_tf3p34": (Sw, Dw, 3.34), "chunked_sort_N6000_tf2": (Sc, Dc, 2.0),
             "global_atomics_269_bins_tf13p36": (Sg, Dg, 13.36)}
 
 
 @pytest.mark.parametrize("case", ["config2_256x1024_tf2", "ragged_24x700_tf2", "wide_cluster_composite_key_tf3p34",
-                                  "chunked_sort_N6000_tf2", "global_atomics_269_bins_tf13p36"])
+                                  "chunked_sort_N6000_tf2", "global_atomics_269_bins_tf13p36",
+                                  "ragged_wide_12x5000_work_list_tf2"])
 @pytest.mark.parametrize("entry", ["estimate_init_pose", "hist_icp"])
 def test_fused_vote_bins_bit_exact(case, entry):
     """The vote that the registration path actually runs (zsort_kernel + hist_vote_sorted_kernel, composite key for
@@ -564,6 +568,11 @@ def test_fused_vote_bins_bit_exact(case, entry):
     want = want.numpy().reshape(len(S), L).astype(np.int64)
     assert want.sum() > 0
     assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} bins differ"
+    # ... and the same bins from the grid over the padded widths (ICPFLOW_OPT_NO_VOTE_LIST: no work list where one is used)
+    plain = torch.full((len(S), L), -1, dtype=torch.int32, device=DEV)
+    with _lib.options(vote_bins=plain, no_vote_list=True):
+        (utils_hist.estimate_init_pose if entry == "estimate_init_pose" else utils_match.hist_icp)(a, G(S), G(D))
+    assert torch.equal(plain, bins)
 
 
 # ------------------------------------------------------------------------------------------ config 4 (per-GPU shape)
