@@ -132,6 +132,7 @@ struct Workspace {
     float *zckey = nullptr;
     int32_t *voteWork = nullptr;   // work list of the sorted vote on wide ragged batches (hist.hip: vote_plan_kernel)
     size_t voteWorkCap = 0;
+    int32_t *pairOrder = nullptr;  // ... and the pairs by decreasing size (grid.pairOrder points here once the plan has run)
     float *pairBox = nullptr;   // long clouds: boxes by count_pair (grid.pairBox points here once they are written)
     float *voteKey = nullptr;   // per-pair sort-key parameters of the vote (votekey.hpp)
     int *zcidx = nullptr;
@@ -180,7 +181,7 @@ struct Workspace {
         zsortC = (float *)take(b * (size_t)N * 16);
         voteKey = (float *)take(b * 8 * 4);
         voteWorkCap = vote_work_capacity(B, N);
-        if (voteWorkCap != 0) voteWork = (int32_t *)take(voteWorkCap * 4);
+        if (voteWorkCap != 0) { voteWork = (int32_t *)take(voteWorkCap * 4); pairOrder = (int32_t *)take(b * 4); }
         if (N > kChunkSortMinN) {   // scratch of the multi-workgroup sorts (one set per concurrent sort)
             const size_t cs = b * 2 * (size_t)chunk_sort_length(N) * 4;
             grid.ckey = (float *)take(cs);
@@ -421,11 +422,14 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
     const int lens[3] = {lx, ly, lz};
     // vote with X = dst role, Y = src role (utils_hist.py:69); z-sorted sweep while the sort fits LDS
     // (N <= 16384), all-pairs otherwise -- identical bins either way
-    if (N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE))
+    if (N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE)) {
+        bool planned = false;
         ICPFLOW_TRY(launch_hist_vote_sorted(dst, src, w.lenC, w.lenA, B, N, lens, ex, ey, ez, swap, w.zsortC,
                                             w.zsortA, w.bins, w.zckey, w.zcidx, w.voteKey, s, countFuse, sideBusy,
-                                            w.grid.pairBox, o.on(ICPFLOW_OPT_NO_VOTE_LIST) ? w.voteWork : nullptr, w.voteWorkCap));
-    else
+                                            w.grid.pairBox, o.on(ICPFLOW_OPT_NO_VOTE_LIST) ? w.voteWork : nullptr, w.voteWorkCap,
+                                            w.pairOrder, &planned));
+        if (planned) w.grid.pairOrder = w.pairOrder;   // (the sweeps of this call take the pairs largest first)
+    } else
         ICPFLOW_TRY(launch_hist_vote(dst, src, B, N, N, nullptr, nullptr, lens, ex, ey, ez, swap, w.bins, s));
     if (o.voteBins != nullptr)   // debug export of the bins the peak search is about to read
         ICPFLOW_TRY(hipMemcpyAsync(o.voteBins, w.bins, (size_t)B * lx * ly * lz * sizeof(uint32_t),

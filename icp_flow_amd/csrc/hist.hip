@@ -573,7 +573,7 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
 // grid: ceil(U / 1024) blocks of 1024 threads, U = capacity of the list; nPairs <= 1024
 __global__ __launch_bounds__(1024) void vote_plan_kernel(const int32_t *__restrict__ nXv, const int32_t *__restrict__ nYv,
                                                          const uint8_t *__restrict__ swap, int nPairs, int rows, int span,
-                                                         int U, int32_t *__restrict__ work)
+                                                         int U, int32_t *__restrict__ work, int32_t *__restrict__ orderOut)
 {
     __shared__ int wk[1024], by_[1024], order[1024], start[1025], part[16];
     const int t = threadIdx.x, lane = t & (kWave - 1), wv = t >> 6;
@@ -591,6 +591,7 @@ __global__ __launch_bounds__(1024) void vote_plan_kernel(const int32_t *__restri
         for (int u = 0; u < nPairs; ++u) { const int o = wk[u]; rank += (o > mine || (o == mine && u < t)) ? 1 : 0; }
     __syncthreads();
     if (t < nPairs) { order[rank] = t; by_[rank] = byMine; }
+    if (blockIdx.x == 0 && t < nPairs && orderOut != nullptr) orderOut[rank] = t;   // (for the sweeps that follow: nn.hip)
     __syncthreads();
     // exclusive prefix over the sorted counts
     const int v = t < nPairs ? wk[order[t]] : 0;
@@ -628,8 +629,10 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                                    int B, int N, const int lens[3], const float *ex, const float *ey,
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
                                    uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
-                                   const PairCountFuse *fuse, bool sideBusy, const float *boxes, int32_t *work, size_t workCap)
+                                   const PairCountFuse *fuse, bool sideBusy, const float *boxes, int32_t *work, size_t workCap,
+                                   int32_t *orderOut, bool *planned)
 {
+    if (planned != nullptr) *planned = false;
     if (fuse != nullptr && N > kChunkSortMinN) return hipErrorInvalidValue;   // only zsort_kernel counts
     const size_t L = (size_t)lens[0] * lens[1] * lens[2];
     int NP2 = 64;
@@ -703,7 +706,8 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                             N >= ICPFLOW_VOTE_LIST_MIN_N;
         if (listed) {
             hipLaunchKernelGGL(vote_plan_kernel, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, s, nX, nY, swap, B, 128, span,
-                               (int)U, work);
+                               (int)U, work, orderOut);
+            if (planned != nullptr) *planned = orderOut != nullptr;
             grid = dim3((unsigned)U, 1);
         }
         hipLaunchKernelGGL((hist_vote_sorted_kernel<512, 4>), grid, dim3(512), lds_hist, s,

@@ -124,7 +124,7 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
                                    const float *ez, const uint8_t *swap, float *sortX, float *sortY,
                                    uint32_t *bins_u32, float *ckey, int *cidx, float *keyRec, hipStream_t s,
                                    const PairCountFuse *fuse = nullptr, bool sideBusy = false, const float *boxes = nullptr,
-                                   int32_t *work = nullptr, size_t workCap = 0);   // work: scratch of the vote's work list (ints), or NULL
+                                   int32_t *work = nullptr, size_t workCap = 0, int32_t *orderOut = nullptr, bool *planned = nullptr);   // work: scratch of the vote's work list (ints), or NULL
 size_t vote_work_capacity(int B, int N);   // ints the work list of a batch can take (0: such batches never use one)
 // sort.hip: several workgroups per long cloud; same outputs as zsort_kernel / sort_clouds_kernel
 constexpr int kChunkSortMinN = 4096;
@@ -200,6 +200,7 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     float *ckey;       // long clouds (N > kChunkSortMinN): chunk-sorted keys / rows of the multi-workgroup sort
     int *cidx;         //   [B,2,chunk_sort_length(N)] each (sort.hip), else NULL
     const float *pairBox;  // long clouds: [B, 24] boxes left by count_pair for THESE clouds, lengths and roles (NULL: the sorts look)
+    const int32_t *pairOrder;  // [B] pairs by decreasing size (vote_plan_kernel ran for THIS batch), or NULL: the sweeps take the pairs as they come
     float *shareBest;  // sweeps (nn.hip): [B*12, 8, 256] partial minima of small-against-long jobs shared by several blocks, or NULL
     int *shareCount;   //   [B*12] blocks delivered (cleared by every sweep launch)
     int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose

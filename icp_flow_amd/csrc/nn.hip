@@ -346,6 +346,7 @@ struct SweepParams {
     float *shareBest;       // [jobs, kSweepShares, kSweepBlock] partial minima of jobs whose ONE query block is scanned by several blocks, or NULL
     int *shareCount;        // [jobs] blocks that have delivered (zero before the launch; the last one resets it)
     int shareWindows;       // 1: blocks of at most 64 queries against a long cloud split every range over their four waves (sweep_scan_kernel)
+    const int32_t *pairOrder;   // optional [B]: the pair the k-th group of jobs works on (largest pairs first: vote_plan_kernel), or NULL
     const uint8_t *active;  // SWEEP_CHECK / SWEEP_EVAL: optional [B], 0 = the pair is not in the batch (options.d_pair_active): its records are zeros
 };
 
@@ -386,9 +387,12 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         job = lin % padded;
     }
     if (job >= p.njobs) return;
-    const int b = (MODE == SWEEP_SCORE) ? job / p.subCount : job >> 1;
+    int b = (MODE == SWEEP_SCORE) ? job / p.subCount : job >> 1;
     const int sub = (MODE == SWEEP_SCORE) ? p.subBegin + job % p.subCount : (job & 1);
-    if (MODE == SWEEP_SCORE) job = b * 12 + sub;   // the scan's place in the partial records
+    // (dispatch order is job order: with the pairs taken largest first the long jobs of a ragged batch start at once instead of
+    // wherever the batch put them; records, counters and sums keep the pair's own place)
+    if (p.pairOrder != nullptr) b = p.pairOrder[b];
+    job = (MODE == SWEEP_SCORE) ? b * 12 + sub : b * 2 + sub;   // the scan's place in the partial records
     const bool backward = (MODE == SWEEP_SCORE) ? (sub & 1) : (MODE == SWEEP_EVAL ? sub == 1 : false);
     const bool sw = p.swap != nullptr && p.swap[b] != 0;
     const int na = (sw ? p.lenC : p.lenA)[b], nc = (sw ? p.lenA : p.lenC)[b];
@@ -791,7 +795,7 @@ hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, cons
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.njobs = B * 12; p.partial = partial;
     p.subBegin = 0; p.subCount = 12;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder;
     return launch_sweep<SWEEP_SCORE>(p, s);
 }
 
@@ -804,7 +808,7 @@ hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *len
     SweepParams p{};
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.partial = partial; p.accum = accum;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder;
     p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
     hipError_t e = launch_sweep<SWEEP_SCORE>(p, s);
     if (e != hipSuccess) return e;
@@ -829,7 +833,7 @@ hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = len1; p.lenC = len2; p.axis = grid->axis;
     p.swap = swap;
     p.poseA = pose; p.thres = thres; p.srcT = srcT; p.N = N; p.njobs = B * 2; p.partial = partial;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder;
     const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
     hipLaunchKernelGGL(transform_soa_kernel, dim3((NP16 + 255) / 256, B), dim3(256), 0, s, grid->sortXsoa, len1, pose,
                        NP16, srcT, grid->sortYsoa, swap);
@@ -853,7 +857,7 @@ hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const flo
     p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.axis = grid->axis;
     p.sortX = (const float4 *)grid->sortX; p.X = X; p.Y = Y; p.poseA = poseInit; p.poseB = poseFinal;
     p.rawSorted = grid->presorted; p.N = N; p.njobs = B * 2; p.partial = partial;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder;
     return launch_sweep<SWEEP_CHECK>(p, s);
 }
 
