@@ -215,7 +215,14 @@ __global__ __launch_bounds__(kCmBlock) void chunk_merge_kernel(ChunkSortParams p
     float *soa = nullptr;
     if (p.mode == 1) soa = r.moving ? (p.Xsoa ? p.Xsoa + (size_t)b * 3 * NP16 : nullptr) : p.Ysoa + (size_t)b * 3 * NP16;
     if (e >= r.n) {   // beyond the valid rows: padding of the consumer's layout
-        if (p.mode == 0) { if (e < p.N) out[e] = make_float4(0.f, 0.f, kInf, kInf); }
+        // (mode 0: the vote reads the first n rows of a z-sorted cloud and nothing behind them -- rows x[i], i < nx, tiles y[j0 + k],
+        // k < tn <= ny - j0: hist_vote_sorted_kernel -- so the 41 MB of invalid rows a ragged batch of 128 pairs padded to 10^4 used
+        // to receive per sort stay unwritten; -DICPFLOW_POISON_ZSORT_PADDING fills them with NaN for the tests' proof of that)
+#ifdef ICPFLOW_POISON_ZSORT_PADDING
+        if (p.mode == 0) { if (e < p.N) out[e] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")); }
+#else
+        if (p.mode == 0) { }
+#endif
         else if (soa != nullptr && e < NP16) { soa[e] = kInf; soa[NP16 + e] = kInf; soa[2 * NP16 + e] = kInf; }
         return;
     }
