@@ -621,7 +621,7 @@ __global__ __launch_bounds__(1024) void vote_plan_kernel(const int32_t *__restri
 size_t vote_work_capacity(int B, int N)
 {
     if (N <= 1023 || B > 1024) return 0;   // (the work list serves the four-waves-per-64-rows variant: ICPFLOW_VOTE_WIDE_N)
-    const size_t full = (size_t)B * ((N + 127) / 128) * ((N + kVoteSpan * kVoteTile - 1) / (kVoteSpan * kVoteTile));
+    const size_t full = (size_t)B * ((N + 127) / 128) * ((N + 511) / 512);   // (shares of 512 Y rows at the finest)
     return full > 32768 ? full : 32768;    // (small batches shorten the span: never above 16384 workgroups)
 }
 
@@ -671,6 +671,10 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
 #ifndef ICPFLOW_VOTE_LIST_MIN_N
 #define ICPFLOW_VOTE_LIST_MIN_N 4097
 #endif
+#ifndef ICPFLOW_VOTE_LIST_SPAN
+#define ICPFLOW_VOTE_LIST_SPAN 2048
+#endif
+    constexpr int kVoteListSpan = ICPFLOW_VOTE_LIST_SPAN;
 #ifndef ICPFLOW_VOTE_WIDE_B
 #define ICPFLOW_VOTE_WIDE_B 2
 #endif
@@ -699,20 +703,25 @@ hipError_t launch_hist_vote_sorted(const float *X, const float *Y, int32_t *nX, 
     // (256 x 1024) 0.712 / 0.709 / 0.700 / 0.700 / 0.703 ms per step; batches above 2 x #CUs pairs are not concerned.
     if (useLds && N > kVoteWideN && B <= kVoteWideB * cus) {
         dim3 grid(((N + 127) / 128) * tsplit, B);
-        const size_t U = (size_t)grid.x * B;
+        // the list's shares of a pair's Y rows (ICPFLOW_VOTE_LIST_SPAN each, at most).  Measured on the ragged real-shape batch
+        // (vote, independent / matched sizes): 512 rows 236 / 421 us, 1024 184 / 352, 2048 171 / 305-313, 4096 186 / 285, one share
+        // per pair 253 / 324 -- the launch is not paced by its last workgroups; a share costs a window search and a flush
+        const int lspan = (work != nullptr && N >= ICPFLOW_VOTE_LIST_MIN_N) ? min(span, kVoteListSpan) : span;
+        const int ltsplit = (N + lspan - 1) / lspan;
+        const size_t U = (size_t)((N + 127) / 128) * ltsplit * B;
         // (from the width on at which count_pair, not the sort, counts the rows: a full batch like config 2's 256 x 1024 gains nothing
         // and pays the plan's launch, 0.705 -> 0.72 ms per step)
-        const bool listed = work != nullptr && U <= workCap && B <= 1024 && grid.x / tsplit <= 256 && tsplit <= 128 &&
+        const bool listed = work != nullptr && U <= workCap && B <= 1024 && (N + 127) / 128 <= 256 && ltsplit <= 128 &&
                             N >= ICPFLOW_VOTE_LIST_MIN_N;
         if (listed) {
-            hipLaunchKernelGGL(vote_plan_kernel, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, s, nX, nY, swap, B, 128, span,
+            hipLaunchKernelGGL(vote_plan_kernel, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, s, nX, nY, swap, B, 128, lspan,
                                (int)U, work, orderOut);
             if (planned != nullptr) *planned = orderOut != nullptr;
             grid = dim3((unsigned)U, 1);
         }
         hipLaunchKernelGGL((hist_vote_sorted_kernel<512, 4>), grid, dim3(512), lds_hist, s,
                            (const float4 *)sortX, (const float4 *)sortY, nX, nY, N, lens[0], lens[1], lens[2], ex, ey,
-                           ez, swap, useLds, bins_u32, keyRec, span, listed ? work : (const int32_t *)nullptr, B);
+                           ez, swap, useLds, bins_u32, keyRec, listed ? lspan : span, listed ? work : (const int32_t *)nullptr, B);
         return hipGetLastError();
     }
     if (block == 1024) {

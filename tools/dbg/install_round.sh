@@ -41,5 +41,5 @@ cp /tmp/tl.txt profiles/${TAG}_frame_pair_native_timeline.txt
   echo "frame pair); every flow compared by torch.equal with the flow of the same host one frame pair at a time; a team that times out raises."
   grep -v amdgpu.ids $E/stress_default.txt; } > profiles/${TAG}_stream_stress.txt
 { echo "Developer fuzzers on the round's library (build $B), one MI355X; tools/dbg/*_fuzz.py"
-  for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz; do [ -f $E/$f.txt ] || continue; echo; echo "== tools/dbg/$f.py (last lines)"; grep -v amdgpu.ids $E/$f.txt | tail -4; done; } > profiles/${TAG}_fuzz_final_build.txt
+  for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz vote_list_fuzz; do [ -f $E/$f.txt ] || continue; echo; echo "== tools/dbg/$f.py (last lines)"; grep -v amdgpu.ids $E/$f.txt | tail -4; done; } > profiles/${TAG}_fuzz_final_build.txt
 grep -o '"library_build": "[0-9a-f]*"' profiles/${TAG}_bench.json profiles/${TAG}_icp_kernel_counters.json profiles/${TAG}_ragged_counters.json profiles/${TAG}_config4_shard_counters.json | sort | uniq -c

@@ -17,7 +17,7 @@ python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python bench.py --workload stream --steps 20 --warmup 3 > $O/${TAG}_bench_stream.json 2>> $O/${TAG}_bench.err
 python bench.py --workload stream --steps 20 --warmup 3 --force-collective > $O/${TAG}_bench_stream_rccl.json 2>> $O/${TAG}_bench.err
 REPS=6 python tools/dbg/stream_stress.py > $O/stress_default.txt 2>&1
-for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz; do timeout 500 python tools/dbg/$f.py > $O/$f.txt 2>&1; echo "$f rc=$?"; done
+for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz vote_list_fuzz; do timeout 500 python tools/dbg/$f.py > $O/$f.txt 2>&1; echo "$f rc=$?"; done
 python tools/dbg/frame_stamps.py > $O/frame_stamps.txt 2>&1
 python tools/dbg/overlap_direct_ab.py > $O/overlap_ab.txt 2>&1
 python tools/dbg/share_ab.py > $O/share_ab.txt 2>&1
@@ -32,4 +32,4 @@ PAIRS=126,9 SHOW=3,15 python tools/dbg/ragged_units.py > $O/ragged_units.txt 2>&
 unset ICPFLOW_HIP_LIB
 tail -3 $O/profile_round.log; tail -3 $O/summarize_ragged.log; tail -4 $O/summarize_config4.log; head -c 400 $O/${TAG}_bench.json; echo; head -c 300 $O/${TAG}_bench_stream.json; echo
 for f in stress_default tail_clock stage1_tail frame_stamps; do tail -n 2 $O/$f.txt; done
-for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz; do tail -1 $O/$f.txt; done
+for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz vote_list_fuzz; do tail -1 $O/$f.txt; done
