@@ -800,6 +800,29 @@ hipError_t launch_u32_to_f32(const uint32_t *in, float *out, size_t n, hipStream
 constexpr int kPeakBlock = 1024;
 constexpr int kPeakMaxK = 8;
 
+// max of V over the window |q - c| <= R along one axis (extent n, `stride` words per step), around flat position f.  With the
+// radius known at compile time the 2R + 1 reads are independent and in flight together -- positions beyond the volume are
+// clamped onto its edge, which repeats a value and leaves a maximum alone; as a loop with run-time bounds every read waited
+// for the one before it (the reference's kernel_size = 11: 11 + 11 + 3 dependent LDS reads per bin, 25 k of the kernel's
+// 45 k clocks).
+template <int R>
+__device__ __forceinline__ uint32_t peak_window_max(const uint32_t *__restrict__ V, int f, int c, int n, int stride)
+{
+    uint32_t v[2 * R + 1];
+#pragma unroll
+    for (int dq = -R; dq <= R; ++dq) v[dq + R] = V[f + (min(max(c + dq, 0), n - 1) - c) * stride];
+    uint32_t m = v[0];
+#pragma unroll
+    for (int u = 1; u < 2 * R + 1; ++u) m = max(m, v[u]);
+    return m;
+}
+
+#ifdef ICPFLOW_PEAK_CLOCK
+__device__ unsigned long long g_peakClock[1024][8];
+#define PEAK_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_peakClock[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define PEAK_STAMP(k) do { } while (0)
+#endif
 // MEM = 0: scratch volumes in global memory (any size); MEM = 1: three volumes in dynamic LDS
 // (3 * L * 4 bytes <= 150 KiB, i.e. up to 113 x 113 x 3 bins)
 template <typename BinT, int MEM>
@@ -818,10 +841,12 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
     uint32_t *A = MEM ? H0 + L : wsA + (size_t)b * L;
     uint32_t *Bv = MEM ? H0 + 2 * (size_t)L : wsB + (size_t)b * L;
     const int tid = threadIdx.x;
+    PEAK_STAMP(0);
     if (MEM) {
         for (int f = tid; f < L; f += kPeakBlock) H0[f] = (uint32_t)h[f];
         __syncthreads();
     }
+    PEAK_STAMP(1);
     // (x, y, z) of this thread's bins f = tid, tid + kPeakBlock, ...: two divisions once, increments afterwards (the
     // three passes used to spend most of their instructions on % and / by run-time extents)
     const int LyLz = Ly * Lz;
@@ -838,40 +863,52 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
         int x = x0, y = y0, z = z0;
         for (int f = tid; f < L; f += kPeakBlock) {
             (void)x;
-            const int lo = max(0, z - radius), hi = min(Lz - 1, z + radius);
             uint32_t m = 0;
-            for (int q = lo; q <= hi; ++q) m = max(m, MEM ? H0[f + (q - z)] : (uint32_t)h[f + (q - z)]);
+            if (MEM && radius >= 2 && Lz == 3) m = max(max(H0[f - z], H0[f - z + 1]), H0[f - z + 2]);   // (the whole z column)
+            else {
+                const int lo = max(0, z - radius), hi = min(Lz - 1, z + radius);
+                for (int q = lo; q <= hi; ++q) m = max(m, MEM ? H0[f + (q - z)] : (uint32_t)h[f + (q - z)]);
+            }
             A[f] = m;
             ICPFLOW_PEAK_ADVANCE();
         }
     }
     __syncthreads();
+    PEAK_STAMP(2);
     // pass y: B = max over |dy| <= r of A
     {
         int x = x0, y = y0, z = z0;
         for (int f = tid; f < L; f += kPeakBlock) {
             (void)x;
-            const int lo = max(0, y - radius), hi = min(Ly - 1, y + radius);
             uint32_t m = 0;
-            for (int q = lo; q <= hi; ++q) m = max(m, A[f + (q - y) * Lz]);
+            if (radius == 5) m = peak_window_max<5>(A, f, y, Ly, Lz);
+            else {
+                const int lo = max(0, y - radius), hi = min(Ly - 1, y + radius);
+                for (int q = lo; q <= hi; ++q) m = max(m, A[f + (q - y) * Lz]);
+            }
             Bv[f] = m;
             ICPFLOW_PEAK_ADVANCE();
         }
     }
     __syncthreads();
+    PEAK_STAMP(3);
     // pass x: A = max over |dx| <= r of B  -> full 3-D window maximum
     {
         int x = x0, y = y0, z = z0;
         for (int f = tid; f < L; f += kPeakBlock) {
-            const int lo = max(0, x - radius), hi = min(Lx - 1, x + radius);
             uint32_t m = 0;
-            for (int q = lo; q <= hi; ++q) m = max(m, Bv[f + (q - x) * LyLz]);
+            if (radius == 5) m = peak_window_max<5>(Bv, f, x, Lx, LyLz);
+            else {
+                const int lo = max(0, x - radius), hi = min(Lx - 1, x + radius);
+                for (int q = lo; q <= hi; ++q) m = max(m, Bv[f + (q - x) * LyLz]);
+            }
             A[f] = m;
             ICPFLOW_PEAK_ADVANCE();
         }
     }
 #undef ICPFLOW_PEAK_ADVANCE
     __syncthreads();
+    PEAK_STAMP(4);
     // surviving vote = h where h == window max, else 0 (utils_hist.py:25-26); selection order (vote desc, flat index
     // asc) on the key (vote << 32 | ~index).  Every wave first finds ITS k largest keys with wave reductions only (the
     // global top k is a subset of the union of the waves' top k); one barrier; wave 0 then picks the k largest of those
@@ -900,6 +937,7 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
         }
     }
     __syncthreads();
+    PEAK_STAMP(5);
     if (wave == 0) {
         constexpr int kWaves = kPeakBlock / kWave;
         // candidate c = lane, lane + 64, ... of the kWaves * k keys (at most two per lane)
@@ -917,6 +955,7 @@ __global__ __launch_bounds__(kPeakBlock) void hist_peaks_kernel(
         }
     }
     __syncthreads();
+    PEAK_STAMP(6);
     // outputs: thread r writes peak r (and its candidate translation on the fused path)
     if (tid < k) {
         const int r = tid;
@@ -968,3 +1007,11 @@ hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, in
 }
 
 }  // namespace icpflow
+
+#ifdef ICPFLOW_PEAK_CLOCK
+extern "C" int icpflow_debug_peak_clock(unsigned long long *out)
+{
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(icpflow::g_peakClock), sizeof(icpflow::g_peakClock));
+}
+#endif
