@@ -192,9 +192,9 @@ struct Workspace {
         }
         grid.axis = (int32_t *)take(b * 4);
         // (sweeps of a small cloud against a long one, shared by several blocks: nn.hip; only where the partial minima stay small)
-        if (N >= 2048 && b * 12 * 8 * 256 * 4 <= ((size_t)64 << 20)) {
-            grid.shareBest = (float *)take(b * 12 * 8 * 256 * 4);
-            grid.shareCount = (int *)take(b * 12 * 4);
+        if (N >= 2048 && b * 12 * kSweepShareSlots * 256 * 4 <= ((size_t)64 << 20)) {
+            grid.shareBest = (float *)take(b * 12 * kSweepShareSlots * 256 * 4);
+            grid.shareCount = (int *)take(b * 12 * kSweepShareSlots * 4);
         }
         history = (float *)take(b * (size_t)kHistIters * kHistStride * 4);
         team.maxWG = 1024;

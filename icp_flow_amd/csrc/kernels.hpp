@@ -186,6 +186,7 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
                           int64_t *idx, float *dist, hipStream_t s);
 
 // icp.hip
+constexpr int kSweepShareSlots = 16;   // (query blocks x shares) of a job whose blocks split ALL targets between them (nn.hip)
 struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop (see icp.hip)
     int mode;          // 2 = hashed grid, 3 = sorted sweep
     int H;             // grid: buckets per pair, power of two >= 2N
@@ -201,8 +202,8 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     int *cidx;         //   [B,2,chunk_sort_length(N)] each (sort.hip), else NULL
     const float *pairBox;  // long clouds: [B, 24] boxes left by count_pair for THESE clouds, lengths and roles (NULL: the sorts look)
     const int32_t *pairOrder;  // [B] pairs by decreasing size (vote_plan_kernel ran for THIS batch), or NULL: the sweeps take the pairs as they come
-    float *shareBest;  // sweeps (nn.hip): [B*12, 8, 256] partial minima of small-against-long jobs shared by several blocks, or NULL
-    int *shareCount;   //   [B*12] blocks delivered (cleared by every sweep launch)
+    float *shareBest;  // sweeps (nn.hip): [B*12, kSweepShareSlots, 256] partial minima of small-against-long jobs shared by several blocks, or NULL
+    int *shareCount;   //   [B*12, <= kSweepShareSlots] blocks delivered (cleared by every sweep launch)
     int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose
                        // (scoring sweep ran on this batch): the ICP applies the pre-pose when it loads
 };

@@ -343,8 +343,8 @@ struct SweepParams {
     // this one have summed more than candidate 0's forward mean allows, prune 2: candidate 0's backward scan
     int subBegin, subCount, prune;
     double *accum;          // [B,12] running sums of the scans (cleared by the caller)
-    float *shareBest;       // [jobs, kSweepShares, kSweepBlock] partial minima of jobs whose ONE query block is scanned by several blocks, or NULL
-    int *shareCount;        // [jobs] blocks that have delivered (zero before the launch; the last one resets it)
+    float *shareBest;       // [jobs, kSweepFullQb, kSweepShares, kSweepBlock] partial minima of query blocks scanned by several blocks, or NULL
+    int *shareCount;        // [jobs, kSweepFullQb] blocks that have delivered (zero before the launch; the last one resets it)
     int shareWindows;       // 1: blocks of at most 64 queries against a long cloud split every range over their four waves (sweep_scan_kernel)
     const int32_t *pairOrder;   // optional [B]: the pair the k-th group of jobs works on (largest pairs first: vote_plan_kernel), or NULL
     const uint8_t *active;  // SWEEP_CHECK / SWEEP_EVAL: optional [B], 0 = the pair is not in the batch (options.d_pair_active): its records are zeros
@@ -359,7 +359,16 @@ constexpr int kSweepShareMinTargets = ICPFLOW_SWEEP_SHARE_MIN_TARGETS;
 #define ICPFLOW_SWEEP_FULLSCAN_MIN_TARGETS 2048
 #endif
 constexpr int kSweepFullScanMinTargets = ICPFLOW_SWEEP_FULLSCAN_MIN_TARGETS;
-constexpr int kSweepShares = 8;   // blocks that share the ONE query block of a small cloud against a long one   // a one-wave block shares its window with the other waves from here on
+constexpr int kSweepShares = 8;   // blocks that share ONE query block of a small cloud against a long one
+#ifndef ICPFLOW_SWEEP_FULLSCAN_QBLOCKS
+#define ICPFLOW_SWEEP_FULLSCAN_QBLOCKS 2
+#endif
+constexpr int kSweepFullQb = ICPFLOW_SWEEP_FULLSCAN_QBLOCKS;   // ... of clouds of up to that many query blocks
+#ifndef ICPFLOW_SWEEP_FULLSCAN_MIN_NT
+#define ICPFLOW_SWEEP_FULLSCAN_MIN_NT 512
+#endif
+constexpr int kSweepFullScanMinNt = ICPFLOW_SWEEP_FULLSCAN_MIN_NT;   // ... against at least that many targets
+static_assert(kSweepFullQb * kSweepShares <= kSweepShareSlots, "GridScratch.shareBest holds kSweepShareSlots records of 256 minima per job");
 constexpr int kSweepStage = 4096;   // sort keys staged in LDS up to this many targets
 enum SweepMode : int { SWEEP_SCORE = 0, SWEEP_CHECK = 1, SWEEP_EVAL = 2 };
 
@@ -420,11 +429,17 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     // The first kSweepShares blocks of the job take the SAME queries and one share of ALL targets each (no window: a handful of
     // queries spans the other cloud anyway); partial minima go to global memory, the last block to deliver combines them and
     // writes block 0's record.  Minima are exact: the sums are bit for bit those of the windowed scan.
-    const bool fullScan = SHARE && !off && p.shareCount != nullptr && nq > 0 && nq <= kSweepBlock && nt >= kSweepFullScanMinTargets && p.qblocks >= 2;
-    const int shares = fullScan ? min(p.qblocks, kSweepShares) : 1;
-    if (fullScan && qb >= 1 && qb < shares) {
+    // (Second half of round 5: also clouds of TWO query blocks -- a sparse query cloud spreads a wave's 64 sorted queries over
+    // a sixth of the other cloud's length, and the window of such a wave is most of it anyway: the jobs with 300-400 queries
+    // against 7-9 k targets paced the check sweep of the ragged batch at 60-70 us a block.  Block qb of the job takes query
+    // block qb % nqb and share qb / nqb of the targets.)
+    const int nqb = (nq + kSweepBlock - 1) / kSweepBlock;
+    const bool fullScan = SHARE && !off && p.shareCount != nullptr && nq > 0 && nqb <= kSweepFullQb && nt >= kSweepFullScanMinNt && p.qblocks >= 2 * nqb;
+    const int shares = fullScan ? min(p.qblocks / nqb, kSweepShares) : 1;
+    const int qi = fullScan ? qb % nqb : qb, si = fullScan ? qb / nqb : 0;   // query block, share of the targets
+    if (fullScan && qb >= nqb && qb < shares * nqb) {
         if (threadIdx.x < kPartial) out[threadIdx.x] = 0.0;    // (this block's own record: a block beyond the cloud)
-        out = p.partial + ((size_t)job * p.qblocks + 0) * kPartial;
+        out = p.partial + ((size_t)job * p.qblocks + qi) * kPartial;
     } else
     if (off || qb * kSweepBlock >= nq) {   // block beyond the cloud (or a pair that is not in the batch): its record is still summed
         // (before the pruning prologue: on a batch padded far beyond its clusters -- a frame's candidate pairs at max_points
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     __shared__ float shareBest[kSweepBlock / kWave][kWave];
     __shared__ int shareLeave;
     const bool sharedWindow = SHARE && !fullScan && p.shareWindows != 0 && nq - qb * kSweepBlock <= kWave && nt >= kSweepShareMinTargets;   // (block-uniform)
-    const int i = (fullScan ? 0 : qb) * kSweepBlock + (sharedWindow ? 0 : wave * kWave) + lane;
+    const int i = qi * kSweepBlock + (sharedWindow ? 0 : wave * kWave) + lane;
     const bool live = i < nq;
     float qx = 0.f, qy = 0.f, qz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
     float r = p.r0, shrink = 1.0f;   // shrink: the proof radius along u relative to the search radius
@@ -594,23 +609,25 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     if (fullScan) {
         __shared__ int lastSh;
         const int nchunks = np16 / kChunk, per = (nchunks + shares - 1) / shares * kChunk;
-        const int c0 = min(qb * per, np16), c1 = min(c0 + per, np16);
+        const int c0 = min(si * per, np16), c1 = min(c0 + per, np16);
         if (lo <= hi) {   // (a wave with queries)
             if (MODE == SWEEP_SCORE && backward) scan_range_min_uniform<true>(tkx, tky, tkz, c0, c1, qx, qy, qz, tx, ty, tz, best);
             else scan_range_min_uniform<false>(tkx, tky, tkz, c0, c1, qx, qy, qz, 0.f, 0.f, 0.f, best);
         }
-        float *mine = p.shareBest + ((size_t)job * kSweepShares + qb) * kSweepBlock;
+        const size_t slot0 = ((size_t)job * kSweepFullQb + qi) * kSweepShares;   // this query block's shares
+        float *mine = p.shareBest + (slot0 + si) * kSweepBlock;
         __hip_atomic_store(&mine[threadIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (write-through)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int before = __hip_atomic_fetch_add(&p.shareCount[job], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int *counter = p.shareCount + (size_t)job * kSweepFullQb + qi;
+            const int before = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lastSh = before == shares - 1 ? 1 : 0;
-            if (lastSh) __hip_atomic_store(&p.shareCount[job], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
+            if (lastSh) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
         }
         __syncthreads();
         if (!lastSh) return;
-        const float *all = p.shareBest + (size_t)job * kSweepShares * kSweepBlock;
+        const float *all = p.shareBest + slot0 * kSweepBlock;
         for (int sh = 0; sh < shares; ++sh)
             best = fminf(best, __hip_atomic_load(&all[(size_t)sh * kSweepBlock + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     } else
@@ -775,7 +792,7 @@ static hipError_t launch_sweep(SweepParams p, hipStream_t s)
     if (p.N < kSweepFullScanMinTargets || p.shareBest == nullptr) p.shareCount = nullptr;
     if (p.shareCount != nullptr) {
         // (the jobs of this launch index the counters by their place in the partial records: b * 12 + scan, or b * 2 + direction)
-        const hipError_t me = hipMemsetAsync(p.shareCount, 0, (size_t)(MODE == SWEEP_SCORE ? (p.njobs / p.subCount) * 12 : p.njobs) * sizeof(int), s);
+        const hipError_t me = hipMemsetAsync(p.shareCount, 0, (size_t)(MODE == SWEEP_SCORE ? (p.njobs / p.subCount) * 12 : p.njobs) * kSweepFullQb * sizeof(int), s);
         if (me != hipSuccess) return me;
     }
     const int groups = (p.njobs + 7) / 8;
