@@ -132,6 +132,7 @@ struct Workspace {
     float *zckey = nullptr;
     int32_t *voteWork = nullptr;   // work list of the sorted vote on wide ragged batches (hist.hip: vote_plan_kernel)
     size_t voteWorkCap = 0;
+    int32_t *pairTab = nullptr;    // sweeps: the pair table of workgroups without rows (grid.pairTab points here once it is written)
     int32_t *pairOrder = nullptr;  // ... and the pairs by decreasing size (grid.pairOrder points here once the plan has run)
     float *pairBox = nullptr;   // long clouds: boxes by count_pair (grid.pairBox points here once they are written)
     float *voteKey = nullptr;   // per-pair sort-key parameters of the vote (votekey.hpp)
@@ -195,6 +196,7 @@ struct Workspace {
         if (N >= 2048 && b * 12 * kSweepShareSlots * 256 * 4 <= ((size_t)64 << 20)) {
             grid.shareBest = (float *)take(b * 12 * kSweepShareSlots * 256 * 4);
             grid.shareCount = (int *)take(b * 12 * kSweepShareSlots * 4);
+            if (B <= 32767 && N <= 255 * 256) pairTab = (int32_t *)take(b * 4 * 4);
         }
         history = (float *)take(b * (size_t)kHistIters * kHistStride * 4);
         team.maxWG = 1024;
@@ -434,6 +436,12 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
     if (o.voteBins != nullptr)   // debug export of the bins the peak search is about to read
         ICPFLOW_TRY(hipMemcpyAsync(o.voteBins, w.bins, (size_t)B * lx * ly * lz * sizeof(uint32_t),
                                    hipMemcpyDeviceToDevice, s));
+    // the sweeps' pair table (nn.hip): for the lengths, roles and pair order the vote has just fixed; batches whose sweeps take the
+    // sharing instantiation (<= 700 pairs of width >= 2048)
+    if (w.pairTab != nullptr && B <= 700 && N <= kMaxSortN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE)) {
+        ICPFLOW_TRY(launch_sweep_pair_table(w.lenA, w.lenC, swap, w.grid.pairOrder, B, N, w.pairTab, s));
+        w.grid.pairTab = w.pairTab;
+    }
     PeakDecode dec;
     dec.ex = ex; dec.ey = ey; dec.ez = ez; dec.shift = shift; dec.cand = w.cand;   // peaks -> 6 candidate translations
     ICPFLOW_TRY(launch_hist_peaks_u32(w.bins, B, lx, ly, lz, kTopK, kNmsKernel, w.volA, w.volB,

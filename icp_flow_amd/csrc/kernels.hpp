@@ -153,6 +153,8 @@ hipError_t launch_hist_peaks_u32(const uint32_t *bins, int B, int Lx, int Ly, in
 
 // nn.hip
 struct GridScratch;
+hipError_t launch_sweep_pair_table(const int32_t *lenA, const int32_t *lenC, const uint8_t *swap, const int32_t *pairOrder,
+                                   int B, int N, int32_t *tab, hipStream_t s);
 int scan_qblocks(int maxRows, int batch);
 int sweep_qblocks(int maxRows);
 hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const int32_t *len2, int B, int N,
@@ -201,6 +203,7 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     float *ckey;       // long clouds (N > kChunkSortMinN): chunk-sorted keys / rows of the multi-workgroup sort
     int *cidx;         //   [B,2,chunk_sort_length(N)] each (sort.hip), else NULL
     const float *pairBox;  // long clouds: [B, 24] boxes left by count_pair for THESE clouds, lengths and roles (NULL: the sorts look)
+    const int32_t *pairTab;    // [B, 4] (nn.hip: sweep_pair_table_kernel) for THESE lengths, roles and pair order, or NULL
     const int32_t *pairOrder;  // [B] pairs by decreasing size (vote_plan_kernel ran for THIS batch), or NULL: the sweeps take the pairs as they come
     float *shareBest;  // sweeps (nn.hip): [B*12, kSweepShareSlots, 256] partial minima of small-against-long jobs shared by several blocks, or NULL
     int *shareCount;   //   [B*12, <= kSweepShareSlots] blocks delivered (cleared by every sweep launch)

@@ -346,6 +346,7 @@ struct SweepParams {
     float *shareBest;       // [jobs, kSweepFullQb, kSweepShares, kSweepBlock] partial minima of query blocks scanned by several blocks, or NULL
     int *shareCount;        // [jobs, kSweepFullQb] blocks that have delivered (zero before the launch; the last one resets it)
     int shareWindows;       // 1: blocks of at most 64 queries against a long cloud split every range over their four waves (sweep_scan_kernel)
+    const int32_t *pairTab;     // optional [B, 4]: what a workgroup needs to know to find out that it has no rows (sweep_pair_table_kernel), or NULL
     const int32_t *pairOrder;   // optional [B]: the pair the k-th group of jobs works on (largest pairs first: vote_plan_kernel), or NULL
     const uint8_t *active;  // SWEEP_CHECK / SWEEP_EVAL: optional [B], 0 = the pair is not in the batch (options.d_pair_active): its records are zeros
 };
@@ -398,6 +399,22 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     if (job >= p.njobs) return;
     int b = (MODE == SWEEP_SCORE) ? job / p.subCount : job >> 1;
     const int sub = (MODE == SWEEP_SCORE) ? p.subBegin + job % p.subCount : (job & 1);
+    // Nine workgroups in ten of a ragged batch are launched for rows their cloud does not have (the grid covers the padded
+    // width) and used to find that out behind THREE dependent loads (pair order -> swap flag -> lengths): ~3 us each, 58 000 of
+    // them per launch, in front of the working ones in dispatch order -- the shares of a job scanned by several workgroups
+    // started 60 us into a 113 us launch (tools/dbg/sweep_clocks.py).  One load from the pair table tells such a workgroup the
+    // pair and that it has nothing to do.
+    if (SHARE && p.pairTab != nullptr && (MODE == SWEEP_SCORE || p.active == nullptr)) {
+        const bool bw = (MODE == SWEEP_SCORE) ? (sub & 1) : (MODE == SWEEP_EVAL ? sub == 1 : false);
+        const int e = p.pairTab[b * 4 + (MODE == SWEEP_EVAL ? 2 : 0) + (bw ? 1 : 0)];
+        const int blocks = (p.shareCount != nullptr) ? ((e >> 8) & 255) : (e & 255);   // with / without jobs scanned by several workgroups
+        if (qb >= blocks) {
+            const int bb = e >> 16;
+            double *rec = p.partial + ((size_t)((MODE == SWEEP_SCORE) ? bb * 12 + sub : bb * 2 + sub) * p.qblocks + qb) * kPartial;
+            if (threadIdx.x < kPartial) rec[threadIdx.x] = 0.0;
+            return;
+        }
+    }
     // (dispatch order is job order: with the pairs taken largest first the long jobs of a ragged batch start at once instead of
     // wherever the batch put them; records, counters and sums keep the pair's own place)
     if (p.pairOrder != nullptr) b = p.pairOrder[b];
@@ -718,10 +735,15 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     }
 #ifdef ICPFLOW_SWEEP_CLOCK
     dbgC2 = clock64();
-    if (MODE == SWEEP_CHECK && threadIdx.x == 0 && qb == 0 && (int)(blockIdx.x) >= 0) {
-        const int slot = (b * 2 + sub) & 4095;
+#ifndef ICPFLOW_SWEEP_CLOCK_MODE
+#define ICPFLOW_SWEEP_CLOCK_MODE 1   // SWEEP_CHECK; 0: the scoring sweeps (the LAST launch of a call overwrites: slot = b * 12 + scan)
+#endif
+    // (the block of the job that ENDS last; racy between blocks, good enough for a debug build)
+    if (MODE == ICPFLOW_SWEEP_CLOCK_MODE && threadIdx.x == 0) {
+        const int slot = (MODE == SWEEP_SCORE ? job : b * 2 + sub) & 4095;
         long long *o = g_sweep_clk + slot * 8;
-        o[0] = dbgW0; o[1] = wall_clock64(); o[2] = dbgC1 - dbgC0; o[3] = dbgC2 - dbgC1; o[4] = dbgRounds; o[5] = nt; o[6] = nq; o[7] = dbgChunks;
+        const long long now = wall_clock64();
+        if (now > o[1]) { o[0] = dbgW0; o[1] = now; o[2] = dbgC1 - dbgC0; o[3] = dbgC2 - dbgC1; o[4] = dbgRounds; o[5] = nt; o[6] = nq; o[7] = qb; }
     }
 #endif
     // masked sums over this block's queries: sum of Euclidean NN distances (utils_helper.py:30,
@@ -777,6 +799,38 @@ extern "C" int icpflow_debug_sweep_clk(long long *out32768)
 #endif
 int sweep_qblocks(int maxRows) { return (maxRows + kSweepBlock - 1) / kSweepBlock; }
 
+// Per pair in DISPATCH order (pairOrder, or as they come) and per direction -- [0] / [1]: the roles of scoring and check (queries =
+// src role / dst role), [2] / [3]: match_eval's (pcd1 / pcd2) --: pair << 16 | workgroups that have work when small-against-long
+// jobs are scanned by several workgroups << 8 | query blocks with rows.  The conditions are sweep_scan_kernel's own.
+__global__ void sweep_pair_table_kernel(const int32_t *__restrict__ lenA, const int32_t *__restrict__ lenC,
+                                        const uint8_t *__restrict__ swap, const int32_t *__restrict__ pairOrder, int B,
+                                        int qblocks, int32_t *__restrict__ tab)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const int b = pairOrder != nullptr ? pairOrder[k] : k;
+    const bool sw = swap != nullptr && swap[b] != 0;
+    const int na = (sw ? lenC : lenA)[b], nc = (sw ? lenA : lenC)[b];
+    const int nqs[4] = {na, nc, lenA[b], lenC[b]}, nts[4] = {nc, na, lenC[b], lenA[b]};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int nq = nqs[d], nt = nts[d];
+        const int nqb = (nq + kSweepBlock - 1) / kSweepBlock;
+        const bool fullScan = nq > 0 && nqb <= kSweepFullQb && nt >= kSweepFullScanMinNt && qblocks >= 2 * nqb;
+        const int shares = fullScan ? min(qblocks / nqb, kSweepShares) : 1;
+        tab[k * 4 + d] = (b << 16) | (min(shares * nqb, 255) << 8) | min(nqb, 255);
+    }
+}
+
+hipError_t launch_sweep_pair_table(const int32_t *lenA, const int32_t *lenC, const uint8_t *swap, const int32_t *pairOrder,
+                                   int B, int N, int32_t *tab, hipStream_t s)
+{
+    if (B > 32767 || sweep_qblocks(N) > 255) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sweep_pair_table_kernel, dim3((B + 255) / 256), dim3(256), 0, s, lenA, lenC, swap, pairOrder, B,
+                       sweep_qblocks(N), tab);
+    return hipGetLastError();
+}
+
 template <int MODE>
 static hipError_t launch_sweep(SweepParams p, hipStream_t s)
 {
@@ -812,7 +866,7 @@ hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, cons
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.njobs = B * 12; p.partial = partial;
     p.subBegin = 0; p.subCount = 12;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
     return launch_sweep<SWEEP_SCORE>(p, s);
 }
 
@@ -825,7 +879,7 @@ hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *len
     SweepParams p{};
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.partial = partial; p.accum = accum;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
     p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
     hipError_t e = launch_sweep<SWEEP_SCORE>(p, s);
     if (e != hipSuccess) return e;
@@ -850,7 +904,7 @@ hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = len1; p.lenC = len2; p.axis = grid->axis;
     p.swap = swap;
     p.poseA = pose; p.thres = thres; p.srcT = srcT; p.N = N; p.njobs = B * 2; p.partial = partial;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
     const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
     hipLaunchKernelGGL(transform_soa_kernel, dim3((NP16 + 255) / 256, B), dim3(256), 0, s, grid->sortXsoa, len1, pose,
                        NP16, srcT, grid->sortYsoa, swap);
@@ -874,7 +928,7 @@ hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const flo
     p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.axis = grid->axis;
     p.sortX = (const float4 *)grid->sortX; p.X = X; p.Y = Y; p.poseA = poseInit; p.poseB = poseFinal;
     p.rawSorted = grid->presorted; p.N = N; p.njobs = B * 2; p.partial = partial;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
     return launch_sweep<SWEEP_CHECK>(p, s);
 }
 

@@ -16,10 +16,14 @@ a = SimpleNamespace(thres_dist=0.1, translation_frame=2.0, chunk_size=50, max_po
 for _ in range(3): utils_match.hist_icp_eval(a, src, dst)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 32768)(); _lib._L.icpflow_debug_sweep_clk(buf)
-v = np.array(buf[:], dtype=np.int64).reshape(4096, 8)[: 2 * len(idx)]
+PER = int(os.environ.get("JOBS_PER_PAIR", 2))      # 2: the check sweep; 12: the scoring sweeps (-DICPFLOW_SWEEP_CLOCK_MODE=0)
+v = np.array(buf[:], dtype=np.int64).reshape(4096, 8)[: PER * len(idx)]
+v = v[v[:, 1] > 0]
+last = v[:, 1].max()
+v = v[v[:, 0] > last - 100000]                   # (the last call's records: within a millisecond of the end)
 t0 = v[:, 0].min()
 print(f"{len(idx)} pairs, width {W}: check sweep spans {(v[:, 1].max() - t0) / 100:.1f} us of wall clock")
-print("job: start us, end us | clocks before the loop, in the loop | rounds, targets, queries, chunk span")
+print("job: of its block that ended last -- start us, end us | clocks before the loop, in the loop | rounds, targets, queries, block")
 order = np.argsort(v[:, 1])
 for k in list(order[:6]) + list(order[-10:]):
     r = v[k]
