@@ -138,6 +138,9 @@ struct Workspace {
     float *voteKey = nullptr;   // per-pair sort-key parameters of the vote (votekey.hpp)
     int *zcidx = nullptr;
     IcpTeam team{};
+    // host-side note of THIS call: score_pick_kernel has left the forward totals of the picked candidates in scoreAccum[0 .. B)
+    // (the scoring ran as sweeps over the sort the check sweep will use): the roll-back check scans under the final pose only
+    bool initSumValid = false;
     size_t bytes = 0;
 
     Workspace(void *base, int B, int N, size_t L)
@@ -232,7 +235,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
     if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
-    if (opt->flags >> 15) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    if (opt->flags >> 16) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
     o.search = opt->icp_search;
     o.arith = opt->icp_arith;
     o.flags = opt->flags;
@@ -365,7 +368,7 @@ struct JoinGuard {
 int run_icp_and_select(const float *src, const float *dst, Workspace &w, const uint8_t *swap,
                        const float *init, int B, int N, double thres, int maxIter, double relThr,
                        int stopMode, int invertSwapped, float *Tout, int32_t *iters, const Opts &o, hipStream_t s,
-                       bool teamPlanned = false, int part = 0, int32_t *pending = nullptr)
+                       bool teamPlanned = false, int part = 0, int32_t *pending = nullptr, bool initSumValid = false)
 {
     // part 0: everything.  part 1: the ICP launch only, with the whole batch iterating (no pair mask); *pending = 1 when the launch
     // left every pair's trajectory in the history (the single speculative launch with the fused finish), 0 when it could not be
@@ -401,9 +404,13 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     }
     if (sweepCheck) {
         PoseSource ps{w.state, w.ctrl, historyPending ? w.history : nullptr, init, B, maxIter};
-        ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, nullptr, w.partial, s, &ps, o.pairActive));
+        // (hist_icp: the scan under the initial pose is the scoring's forward scan of the picked candidate -- score_pick_kernel,
+        // sweep_scan_kernel -- as long as the clouds the check reads are the raw ones of that very sort)
+        const double *initSum = (initSumValid && search->presorted && o.on(ICPFLOW_OPT_NO_CHECK_REUSE)) ? w.scoreAccum : nullptr;
+        ICPFLOW_TRY(launch_sweep_check(search, src, dst, w.lenA, w.lenC, swap, B, N, init, nullptr, w.partial, s, &ps, o.pairActive,
+                                       initSum));
         ICPFLOW_TRY(launch_select(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, init, nullptr, B, invertSwapped,
-                                  Tout, s, &ps, iters));
+                                  Tout, s, &ps, iters, initSum, o.pairActive));
         return 0;
     }
     ICPFLOW_TRY(launch_compose(w.state, init, B, w.M, s, w.ctrl, iters));   // also reports the iteration count
@@ -458,7 +465,8 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
             ICPFLOW_TRY(launch_sweep_score_pruned(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s));
         else
             ICPFLOW_TRY(launch_sweep_score(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, s));
-        ICPFLOW_TRY(launch_score_pick(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
+        ICPFLOW_TRY(launch_score_pick(w.partial, sweep_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s, w.scoreAccum));
+        w.initSumValid = true;   // (scoreAccum is free once the scans are over; the next call clears it)
     } else if (o.on(ICPFLOW_OPT_NO_SCORE_PRUNE)) {
         ICPFLOW_TRY(launch_scan_score_pruned(src, dst, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s, true));
         ICPFLOW_TRY(launch_score_pick(w.partial, score_qblocks(N), w.lenA, w.lenC, swap, w.cand, B, Tout, s));
@@ -1006,7 +1014,7 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
         w.grid.presorted = carry[0];
         int32_t pending = carry[2];
         return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
-                                  relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, carry[1] != 0, 2, &pending);
+                                  relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, carry[1] != 0, 2, &pending, carry[3] != 0);
     }
     // lengths + swap (utils_match.py:139-146) + cleared scratch: by the vote's sort itself where one workgroup sorts a
     // cloud (PairCountFuse), by count_pair otherwise
@@ -1064,13 +1072,14 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
     if (phase == 1) {
         carry[0] = w.grid.presorted;
         carry[1] = teamPlanned ? 1 : 0;
+        carry[3] = w.initSumValid ? 1 : 0;
         // ... and, where ONE speculative launch runs the batch rule, the ICP of the whole batch as well (carry[2] = 1): the second
         // half then only has to find where the rule over ITS pairs stops
         return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations, relative_rmse_thr,
                                   stop_mode, 1, d_T_out, d_iters, o, s, teamPlanned, 1, &carry[2]);
     }
     return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
-                              relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, teamPlanned);
+                              relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, teamPlanned, 0, nullptr, w.initSumValid);
 }
 
 int icpflow_hist_icp(const float *d_src, const float *d_dst, int B, int N, const float *d_edges_x,
@@ -1282,7 +1291,7 @@ int icpflow_register_stage_begin(const icpflow_tables_t *t, const icpflow_stage_
 int icpflow_register_stage_finish(const icpflow_tables_t *t, const icpflow_stage_t *st, const icpflow_registration_t *reg,
                                   void *d_ws, size_t ws_bytes, icpflow_stream_t stream, const icpflow_options_t *opt, const int32_t *h_carry)
 {
-    int32_t carry[3] = {h_carry ? h_carry[0] : 0, h_carry ? h_carry[1] : 0, h_carry ? h_carry[2] : 0};
+    int32_t carry[4] = {h_carry ? h_carry[0] : 0, h_carry ? h_carry[1] : 0, h_carry ? h_carry[2] : 0, h_carry ? h_carry[3] : 0};
     if (!h_carry) return fail(ICPFLOW_E_ARG, "icpflow_register_stage_finish: null argument");
     return register_stage_phase(2, carry, t, st, reg, d_ws, ws_bytes, stream, opt);
 }

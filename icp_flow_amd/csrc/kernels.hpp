@@ -165,7 +165,7 @@ struct PoseSource;   // posefuse.hpp
 hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
                               const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
                               const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused = nullptr,
-                              const uint8_t *active = nullptr);
+                              const uint8_t *active = nullptr, const double *initSum = nullptr);
 hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
                               int B, int N, const float *cand, double *partial, hipStream_t s);
 hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC,
@@ -272,13 +272,14 @@ hipError_t launch_icp_resolve_history(IcpState *state, IcpCtrl *ctrl, const floa
 // pose.hip
 hipError_t launch_score_pick(const double *partial, int qblocks, const int32_t *lenA,
                              const int32_t *lenC, const uint8_t *swap, const float *cand, int B,
-                             float *Tinit, hipStream_t s);
+                             float *Tinit, hipStream_t s, double *initSum = nullptr);
 hipError_t launch_compose(const IcpState *state, const float *init, int B, float *M, hipStream_t s,
                           const IcpCtrl *ctrl = nullptr, int32_t *iters = nullptr);
 // M == NULL: the composed pose comes from `fused` (and the iteration count is written to *iters)
 hipError_t launch_select(const double *partial, int qblocks, const int32_t *lenA, const int32_t *lenC,
                          const uint8_t *swap, const float *init, const float *M, int B, int invertSwapped,
-                         float *out, hipStream_t s, const PoseSource *fused = nullptr, int32_t *iters = nullptr);
+                         float *out, hipStream_t s, const PoseSource *fused = nullptr, int32_t *iters = nullptr,
+                         const double *initSum = nullptr, const uint8_t *active = nullptr);
 hipError_t launch_eval_epilogue(const double *partial, int qblocks, const int32_t *len1,
                                 const int32_t *len2, const float *T, int B, float *errors,
                                 float *inliers, float *ratios, float *ious, float *translations,

@@ -349,6 +349,10 @@ struct SweepParams {
     const int32_t *pairTab;     // optional [B, 4]: what a workgroup needs to know to find out that it has no rows (sweep_pair_table_kernel), or NULL
     const int32_t *pairOrder;   // optional [B]: the pair the k-th group of jobs works on (largest pairs first: vote_plan_kernel), or NULL
     const uint8_t *active;  // SWEEP_CHECK / SWEEP_EVAL: optional [B], 0 = the pair is not in the batch (options.d_pair_active): its records are zeros
+    // SWEEP_CHECK in hist_icp: optional [B], the scoring's forward total of the candidate score_pick_kernel picked -- the very sum
+    // the scan under the initial pose (sub 0) would form: where it is finite that scan is left out and select_kernel reads
+    // the total instead (+inf: the scan was pruned, the check scans for itself)
+    const double *initSum;
 };
 
 constexpr int kSweepBlock = 256;
@@ -396,6 +400,18 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         qb = lin / padded;
         job = lin % padded;
     }
+    if (MODE == SWEEP_CHECK && p.initSum != nullptr) {
+        // Two halves, each dealt like the whole (eight pairs to the eight XCDs): the scans under the final pose first, then
+        // those under the initial pose, most of which leave at once (below).  With the two scans of a pair side by side in
+        // the grid the working ones would all sit on the odd XCDs.
+        const int pairs = p.njobs >> 1;
+        const int half = ((pairs + 7) / 8) * 8 * p.qblocks;
+        const int l = lin < half ? lin : lin - half;
+        const int k = (l / (8 * p.qblocks)) * 8 + (l & 7);
+        qb = (l >> 3) % p.qblocks;
+        if (k >= pairs) return;
+        job = k * 2 + (lin < half ? 1 : 0);
+    }
     if (job >= p.njobs) return;
     int b = (MODE == SWEEP_SCORE) ? job / p.subCount : job >> 1;
     const int sub = (MODE == SWEEP_SCORE) ? p.subBegin + job % p.subCount : (job & 1);
@@ -419,6 +435,10 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     // wherever the batch put them; records, counters and sums keep the pair's own place)
     if (p.pairOrder != nullptr) b = p.pairOrder[b];
     job = (MODE == SWEEP_SCORE) ? b * 12 + sub : b * 2 + sub;   // the scan's place in the partial records
+    if (MODE == SWEEP_CHECK && sub == 0 && p.initSum != nullptr) {   // (every block of the job decides alike; nobody reads its records)
+        const double t = p.initSum[b];
+        if (t - t == 0.0 && (p.active == nullptr || p.active[b] != 0)) return;
+    }
     const bool backward = (MODE == SWEEP_SCORE) ? (sub & 1) : (MODE == SWEEP_EVAL ? sub == 1 : false);
     const bool sw = p.swap != nullptr && p.swap[b] != 0;
     const int na = (sw ? p.lenC : p.lenA)[b], nc = (sw ? p.lenA : p.lenC)[b];
@@ -849,7 +869,8 @@ static hipError_t launch_sweep(SweepParams p, hipStream_t s)
         const hipError_t me = hipMemsetAsync(p.shareCount, 0, (size_t)(MODE == SWEEP_SCORE ? (p.njobs / p.subCount) * 12 : p.njobs) * kSweepFullQb * sizeof(int), s);
         if (me != hipSuccess) return me;
     }
-    const int groups = (p.njobs + 7) / 8;
+    // (the check sweep beside the scoring's totals: two halves of whole groups of eight pairs, see the kernel)
+    const int groups = (MODE == SWEEP_CHECK && p.initSum != nullptr) ? 2 * ((p.njobs / 2 + 7) / 8) : (p.njobs + 7) / 8;
     const size_t lds = (size_t)(p.NP16 < kSweepStage ? p.NP16 : kSweepStage) * sizeof(float);
     // (njobs <= 12 * 700: the batches whose workspace holds the shared minima; larger ones fill the GPU with whole pairs)
     if (p.shareWindows != 0 && p.N >= kSweepFullScanMinTargets && p.njobs <= 12 * 700)
@@ -916,10 +937,11 @@ hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const
 hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const float *Y, const int32_t *lenA,
                               const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
                               const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused,
-                              const uint8_t *active)
+                              const uint8_t *active, const double *initSum)
 {
     SweepParams p{};
     p.active = active;
+    p.initSum = initSum;
     if (poseFinal == nullptr) {
         if (fused == nullptr) return hipErrorInvalidValue;
         p.fused = *fused;

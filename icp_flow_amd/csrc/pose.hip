@@ -44,20 +44,29 @@ __global__ __launch_bounds__(kWave) void score_pick_kernel(const double *__restr
                                                            const int32_t *__restrict__ lenC,
                                                            const uint8_t *__restrict__ swap,
                                                            const float *__restrict__ cand, int B,
-                                                           float *__restrict__ Tinit)
+                                                           float *__restrict__ Tinit, double *__restrict__ initSum)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const bool sw = swap != nullptr && swap[b] != 0;
     const float na = (float)(sw ? lenC[b] : lenA[b]);
     const float nc = (float)(sw ? lenA[b] : lenC[b]);
     float mean = 0.f;
-    if (lane < 2 * kCand) mean = (float)partial_total(partial, b * 12 + lane, qblocks, 0) / ((lane & 1) ? nc : na);
+    double total = 0.0;
+    if (lane < 2 * kCand) {
+        total = partial_total(partial, b * 12 + lane, qblocks, 0);
+        mean = (float)total / ((lane & 1) ? nc : na);
+    }
     int pick = 0;
     float best = 0.f;
     for (int k = 0; k < kCand; ++k) {
         const float sc = fminf(__shfl(mean, 2 * k, kWave), __shfl(mean, 2 * k + 1, kWave));
         if (k == 0 || sc < best) { best = sc; pick = k; }
     }
+    // The forward total of the picked candidate IS the roll-back check's sum under the initial pose (utils_icp.py:28-29 on
+    // src + t, the points utils_hist.py:86-89 has just scored: same queries in the same sorted order, same targets, same
+    // block records) -- kept for the check sweep of the same call, which then scans under the final pose only.  A scan
+    // that was pruned reports +inf (the pick can still fall on it through its backward mean): the check scans for itself.
+    if (initSum != nullptr && lane == 2 * pick) initSum[b] = total;
     if (lane < 16) {
         const float *t = cand + ((size_t)b * kCand + pick) * 3;
         float v = (lane % 5 == 0) ? 1.f : 0.f;
@@ -70,10 +79,10 @@ __global__ __launch_bounds__(kWave) void score_pick_kernel(const double *__restr
 
 hipError_t launch_score_pick(const double *partial, int qblocks, const int32_t *lenA,
                              const int32_t *lenC, const uint8_t *swap, const float *cand, int B,
-                             float *Tinit, hipStream_t s)
+                             float *Tinit, hipStream_t s, double *initSum)
 {
     hipLaunchKernelGGL(score_pick_kernel, dim3(B), dim3(kWave), 0, s, partial, qblocks, lenA, lenC, swap, cand, B,
-                       Tinit);
+                       Tinit, initSum);
     return hipGetLastError();
 }
 
@@ -117,7 +126,8 @@ __global__ void select_kernel(const double *__restrict__ partial, int qblocks,
                               const int32_t *__restrict__ lenA, const int32_t *__restrict__ lenC,
                               const uint8_t *__restrict__ swap, const float *__restrict__ init,
                               const float *__restrict__ M, int B, int invertSwapped, float *__restrict__ out,
-                              PoseSource fused, int32_t *__restrict__ iters)
+                              PoseSource fused, int32_t *__restrict__ iters, const double *__restrict__ initSum,
+                              const uint8_t *__restrict__ active)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     // fused finish (M == NULL): the composed pose comes straight from the ICP's history / state
@@ -132,7 +142,16 @@ __global__ void select_kernel(const double *__restrict__ partial, int qblocks,
     if (M == nullptr) final_pose(fused, b, n, Mf);
     const bool sw = swap != nullptr && swap[b] != 0;
     const float na = (float)(sw ? lenC[b] : lenA[b]);
-    const float e0 = (float)partial_total(partial, b * 2 + 0, qblocks, 0) / na;
+    // (initSum: the scoring's forward total of the picked candidate, where the check sweep has left the scan under the initial
+    // pose to it -- the same condition as in sweep_scan_kernel: finite, and the pair in the batch)
+    double s0 = 0.0;
+    bool reuse = false;
+    if (initSum != nullptr && (active == nullptr || active[b] != 0)) {
+        s0 = initSum[b];
+        reuse = s0 - s0 == 0.0;   // finite
+    }
+    if (!reuse) s0 = partial_total(partial, b * 2 + 0, qblocks, 0);
+    const float e0 = (float)s0 / na;
     const float e1 = (float)partial_total(partial, b * 2 + 1, qblocks, 0) / na;
     const float *src = (e1 >= e0) ? init + (size_t)b * 16 : (M != nullptr ? M + (size_t)b * 16 : Mf);  // NaN keeps ICP
     float P[16];
@@ -163,11 +182,12 @@ __global__ void select_kernel(const double *__restrict__ partial, int qblocks,
 
 hipError_t launch_select(const double *partial, int qblocks, const int32_t *lenA, const int32_t *lenC,
                          const uint8_t *swap, const float *init, const float *M, int B, int invertSwapped,
-                         float *out, hipStream_t s, const PoseSource *fused, int32_t *iters)
+                         float *out, hipStream_t s, const PoseSource *fused, int32_t *iters, const double *initSum,
+                         const uint8_t *active)
 {
     if (M == nullptr && fused == nullptr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, qblocks, lenA, lenC,
-                       swap, init, M, B, invertSwapped, out, fused ? *fused : PoseSource{}, iters);
+                       swap, init, M, B, invertSwapped, out, fused ? *fused : PoseSource{}, iters, initSum, active);
     return hipGetLastError();
 }
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 210 /* 0.2.10: ICPFLOW_OPT_NO_VOTE_LIST (the vote's work list on ragged batches); 0.2.9: icpflow_register_stage_begin / _finish, icpflow_associate_frame_begun (stage 2's initial poses beside stage 1's ICP), ICPFLOW_E_HOSTMEM; 0.2.8: ICPFLOW_OPT_NO_SHARED_SCANS (teams: window scans shared by a member's waves); 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 211 /* 0.2.11: ICPFLOW_OPT_NO_CHECK_REUSE (hist_icp: the roll-back check takes its sum under the initial pose from the scoring); 0.2.10: ICPFLOW_OPT_NO_VOTE_LIST (the vote's work list on ragged batches); 0.2.9: icpflow_register_stage_begin / _finish, icpflow_associate_frame_begun (stage 2's initial poses beside stage 1's ICP), ICPFLOW_E_HOSTMEM; 0.2.8: ICPFLOW_OPT_NO_SHARED_SCANS (teams: window scans shared by a member's waves); 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -131,6 +131,10 @@ const char *icpflow_build_info(void);
 /* (a bit-identity switch) vote on batches of few wide pairs: the grid covers the padded width of every pair instead of following
  * a work list of the workgroups that have rows, largest pairs first */
 #define ICPFLOW_OPT_NO_VOTE_LIST (1u << 14)
+/* (a bit-identity switch) icpflow_hist_icp and the entry points built on it: the roll-back check (utils_icp.py:27-35) scans under the
+ * initial pose as well, instead of taking that sum from the candidate scoring, whose forward scan of the picked candidate
+ * (utils_hist.py:86-101) is the same scan of the same points */
+#define ICPFLOW_OPT_NO_CHECK_REUSE (1u << 15)
 
 typedef struct icpflow_profile icpflow_profile_t; /* opaque */
 

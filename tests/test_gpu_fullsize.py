@@ -368,6 +368,14 @@ def test_scoring_variants_change_nothing(shape):
         T2, it2 = utils_match.hist_icp(a, s, d, return_iterations=True)
     assert int(it0) == int(it1) == int(it2) and int(it1) > 0
     assert torch.equal(T0, T1) and torch.equal(T2, T1)
+    # (header 0.2.11) the roll-back check takes its sum under the initial pose from the scoring's forward scan of the picked
+    # candidate -- the same scan of the same points (pose.hip score_pick_kernel, nn.hip sweep_scan_kernel) -- unless that scan
+    # was pruned; with ICPFLOW_OPT_NO_CHECK_REUSE the check scans under both poses as before: same poses bit for bit
+    with _lib.options(no_check_reuse=True):
+        T3, it3 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    assert int(it3) == int(it1) and torch.equal(T3, T1)
+    with _lib.options(no_check_reuse=True, no_score_prune=True):
+        assert torch.equal(utils_match.hist_icp(a, s, d), T1)
     for _ in range(3):
         assert torch.equal(utils_match.hist_icp(a, s, d), T1)
 
