@@ -141,7 +141,9 @@ struct Workspace {
     // host-side note of THIS call: score_pick_kernel has left the forward totals of the picked candidates in scoreAccum[0 .. B)
     // (the scoring ran as sweeps over the sort the check sweep will use): the roll-back check scans under the final pose only
     bool initSumValid = false;
+    size_t accumBytes = 0;   // scoreAccum and, where the sweeps share jobs between blocks, grid.shareCount behind it: cleared together
     size_t bytes = 0;
+    static bool shareScratch(int B, int N) { return N >= 2048 && (size_t)B * 12 * kSweepShareSlots * 256 * 4 <= ((size_t)64 << 20); }
 
     Workspace(void *base, int B, int N, size_t L)
     {
@@ -166,6 +168,10 @@ struct Workspace {
             if ((size_t)score_qblocks(N) > qb) qb = (size_t)score_qblocks(N);
             partial = (double *)take(b * 12 * qb * kPartial * 8);
             scoreAccum = (double *)take(b * 12 * 8);
+            // (the sweeps' delivery counters right behind it: the clear at the start of a registration covers both -- accumBytes --,
+            // and every sweep launch leaves its counters at zero again, so that none of them needs a memset of its own)
+            if (shareScratch(B, N)) grid.shareCount = (int *)take(b * 12 * kSweepShareSlots * 4);
+            accumBytes = up(b * 12 * 8) + (shareScratch(B, N) ? up(b * 12 * kSweepShareSlots * 4) : 0);
         }
         Tinit = (float *)take(b * 16 * 4);
         M = (float *)take(b * 16 * 4);
@@ -196,9 +202,8 @@ struct Workspace {
         }
         grid.axis = (int32_t *)take(b * 4);
         // (sweeps of a small cloud against a long one, shared by several blocks: nn.hip; only where the partial minima stay small)
-        if (N >= 2048 && b * 12 * kSweepShareSlots * 256 * 4 <= ((size_t)64 << 20)) {
+        if (shareScratch(B, N)) {
             grid.shareBest = (float *)take(b * 12 * kSweepShareSlots * 256 * 4);
-            grid.shareCount = (int *)take(b * 12 * kSweepShareSlots * 4);
             if (B <= 32767 && N <= 255 * 256) pairTab = (int32_t *)take(b * 4 * 4);
         }
         history = (float *)take(b * (size_t)kHistIters * kHistStride * 4);
@@ -1012,6 +1017,7 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
     // / _finish: a frame pair's stage 2 estimates its initial poses beside stage 1's ICP, on another stream.)
     if (phase == 2) {
         w.grid.presorted = carry[0];
+        w.grid.shareCountClean = 1;   // (phase 1 cleared the counters, and every launch since has left them at zero)
         int32_t pending = carry[2];
         return run_icp_and_select(d_src, d_dst, w, w.swap, w.Tinit, B, N, thres_dist, max_iterations,
                                   relative_rmse_thr, stop_mode, 1, d_T_out, d_iters, o, s, carry[1] != 0, 2, &pending, carry[3] != 0);
@@ -1021,7 +1027,7 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
     const bool countInSort = N <= kMaxSortN && N <= kChunkSortMinN && o.on(ICPFLOW_OPT_NO_SORTED_VOTE);
     if (!countInSort) {
         launch_count_pair(d_src, d_dst, B, N, w.lenA, w.lenC, w.swap, s, w.ctrl, icp_ctrl_bytes(B), w.scoreAccum,
-                          (size_t)B * 12 * sizeof(double), w.pairBox);
+                          w.accumBytes, w.pairBox);
         w.grid.pairBox = w.pairBox;   // (for the sorts of exactly these clouds, lengths and roles: this call's)
     }
     // the axis sort of both clouds (scoring sweep, ICP) runs on the side stream next to the vote
@@ -1060,8 +1066,9 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
     if (countInSort) {
         fuse.swapOut = w.swap;
         fuse.zero0 = w.ctrl; fuse.bytes0 = icp_ctrl_bytes(B);
-        fuse.zero1 = w.scoreAccum; fuse.bytes1 = (size_t)B * 12 * sizeof(double);
+        fuse.zero1 = w.scoreAccum; fuse.bytes1 = w.accumBytes;
     }
+    w.grid.shareCountClean = 1;   // (cleared with scoreAccum either way; the sweep launches of this call skip their memsets)
     const bool sweepScore = score_by_sweep(N, join != nullptr, o);
     if (int r = run_init_pose(d_src, d_dst, w, w.swap, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
                               len_z, decode_shift, w.Tinit, o, s, sweepScore ? join : nullptr,

@@ -206,7 +206,8 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     const int32_t *pairTab;    // [B, 4] (nn.hip: sweep_pair_table_kernel) for THESE lengths, roles and pair order, or NULL
     const int32_t *pairOrder;  // [B] pairs by decreasing size (vote_plan_kernel ran for THIS batch), or NULL: the sweeps take the pairs as they come
     float *shareBest;  // sweeps (nn.hip): [B*12, kSweepShareSlots, 256] partial minima of small-against-long jobs shared by several blocks, or NULL
-    int *shareCount;   //   [B*12, <= kSweepShareSlots] blocks delivered (cleared by every sweep launch)
+    int *shareCount;   //   [B*12, <= kSweepShareSlots] blocks delivered (zero between launches: the last block to deliver resets its counter)
+    int shareCountClean;   //   host-side: this call has cleared shareCount already (api.hip: with scoreAccum) -- no memset per launch
     int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose
                        // (scoring sweep ran on this batch): the ICP applies the pre-pose when it loads
 };

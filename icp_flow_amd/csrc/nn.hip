@@ -345,6 +345,7 @@ struct SweepParams {
     double *accum;          // [B,12] running sums of the scans (cleared by the caller)
     float *shareBest;       // [jobs, kSweepFullQb, kSweepShares, kSweepBlock] partial minima of query blocks scanned by several blocks, or NULL
     int *shareCount;        // [jobs, kSweepFullQb] blocks that have delivered (zero before the launch; the last one resets it)
+    int shareClean;         // 1: shareCount is known to be zero (GridScratch.shareCountClean): no memset in front of the launch
     int shareWindows;       // 1: blocks of at most 64 queries against a long cloud split every range over their four waves (sweep_scan_kernel)
     const int32_t *pairTab;     // optional [B, 4]: what a workgroup needs to know to find out that it has no rows (sweep_pair_table_kernel), or NULL
     const int32_t *pairOrder;   // optional [B]: the pair the k-th group of jobs works on (largest pairs first: vote_plan_kernel), or NULL
@@ -864,7 +865,7 @@ static hipError_t launch_sweep(SweepParams p, hipStream_t s)
     p.shareCount = nullptr;
 #endif
     if (p.N < kSweepFullScanMinTargets || p.shareBest == nullptr) p.shareCount = nullptr;
-    if (p.shareCount != nullptr) {
+    if (p.shareCount != nullptr && !p.shareClean) {
         // (the jobs of this launch index the counters by their place in the partial records: b * 12 + scan, or b * 2 + direction)
         const hipError_t me = hipMemsetAsync(p.shareCount, 0, (size_t)(MODE == SWEEP_SCORE ? (p.njobs / p.subCount) * 12 : p.njobs) * kSweepFullQb * sizeof(int), s);
         if (me != hipSuccess) return me;
@@ -887,7 +888,7 @@ hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, cons
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.njobs = B * 12; p.partial = partial;
     p.subBegin = 0; p.subCount = 12;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.shareClean = grid->shareCountClean; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
     return launch_sweep<SWEEP_SCORE>(p, s);
 }
 
@@ -900,7 +901,7 @@ hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *len
     SweepParams p{};
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.partial = partial; p.accum = accum;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.shareClean = grid->shareCountClean; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
     p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
     hipError_t e = launch_sweep<SWEEP_SCORE>(p, s);
     if (e != hipSuccess) return e;
@@ -925,7 +926,7 @@ hipError_t launch_sweep_eval(const GridScratch *grid, const int32_t *len1, const
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = len1; p.lenC = len2; p.axis = grid->axis;
     p.swap = swap;
     p.poseA = pose; p.thres = thres; p.srcT = srcT; p.N = N; p.njobs = B * 2; p.partial = partial;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.shareClean = grid->shareCountClean; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
     const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
     hipLaunchKernelGGL(transform_soa_kernel, dim3((NP16 + 255) / 256, B), dim3(256), 0, s, grid->sortXsoa, len1, pose,
                        NP16, srcT, grid->sortYsoa, swap);
@@ -950,7 +951,7 @@ hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const flo
     p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap; p.axis = grid->axis;
     p.sortX = (const float4 *)grid->sortX; p.X = X; p.Y = Y; p.poseA = poseInit; p.poseB = poseFinal;
     p.rawSorted = grid->presorted; p.N = N; p.njobs = B * 2; p.partial = partial;
-    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
+    p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.shareClean = grid->shareCountClean; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
     return launch_sweep<SWEEP_CHECK>(p, s);
 }
 
