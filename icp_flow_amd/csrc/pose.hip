@@ -120,6 +120,9 @@ hipError_t launch_compose(const IcpState *state, const float *init, int B, float
     return hipGetLastError();
 }
 
+#ifdef ICPFLOW_REUSE_STATS
+__device__ unsigned long long g_reuseStats[4];
+#endif
 // roll back where the ICP pose did not lower the mean NN error (utils_icp.py:27-35), then
 // invert the pose of swapped pairs (utils_match.py:152-154; exact affine inverse in fp64)
 __global__ void select_kernel(const double *__restrict__ partial, int qblocks,
@@ -151,9 +154,17 @@ __global__ void select_kernel(const double *__restrict__ partial, int qblocks,
         reuse = s0 - s0 == 0.0;   // finite
     }
     if (!reuse) s0 = partial_total(partial, b * 2 + 0, qblocks, 0);
+#ifdef ICPFLOW_REUSE_STATS
+    // [0] pairs whose sum came from the scoring, [1] pairs the check scanned although a total was offered (pruned scan / masked
+    // pair), [2] pairs of calls without an offer, [3] roll-backs (tools/dbg/check_reuse_stats.py)
+    atomicAdd(&g_reuseStats[reuse ? 0 : (initSum != nullptr ? 1 : 2)], 1ull);
+#endif
     const float e0 = (float)s0 / na;
     const float e1 = (float)partial_total(partial, b * 2 + 1, qblocks, 0) / na;
     const float *src = (e1 >= e0) ? init + (size_t)b * 16 : (M != nullptr ? M + (size_t)b * 16 : Mf);  // NaN keeps ICP
+#ifdef ICPFLOW_REUSE_STATS
+    if (e1 >= e0) atomicAdd(&g_reuseStats[3], 1ull);
+#endif
     float P[16];
     for (int k = 0; k < 16; ++k) P[k] = src[k];
     if (sw && invertSwapped) {
@@ -448,3 +459,16 @@ hipError_t launch_flow_rigid(const float *points, const float *labels, int N, co
 }
 
 }  // namespace icpflow
+
+#ifdef ICPFLOW_REUSE_STATS
+extern "C" int icpflow_debug_reuse_stats(unsigned long long *out4, int reset)
+{
+    (void)hipDeviceSynchronize();
+    const int rc = (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(icpflow::g_reuseStats), sizeof(icpflow::g_reuseStats));
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(icpflow::g_reuseStats), z, sizeof(z));
+    }
+    return rc;
+}
+#endif

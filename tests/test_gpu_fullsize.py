@@ -380,6 +380,55 @@ def test_scoring_variants_change_nothing(shape):
         assert torch.equal(utils_match.hist_icp(a, s, d), T1)
 
 
+def _backward_winner_pair(N, seed):
+    """src role: a 100-point patch P and a tight 300-point clump K three metres above it (out of the vote's z range of each other);
+    dst role: ten jittered copies of P moved by t1 = (-0.3, 0.4, 0) and 20 points of K moved by t0 = (0.4, 0.4, 0).  The vote's
+    highest peak is t0 (300 x 20 votes in one bin), seven bins from t1 (outside the 11-bin suppression window of
+    utils_hist.py:21-24).  t0's forward mean is moderate (the clump on its copies, the patch 0.7 m beside its own); t1 has the
+    LARGER forward mean (the clump 0.7 m off: 0.52 against 0.08) and by far the smallest backward mean (1000 of the 1020 dst
+    points sit on the patch: 0.018): t1 wins through its backward scan while its forward scan is cut off by candidate 0's bound."""
+    rng = np.random.default_rng(seed)
+    P = np.stack([rng.uniform(0, 1, 100), rng.uniform(0, 1, 100), rng.uniform(-0.01, 0.01, 100)], 1)
+    K = np.array([0.5, 0.5, 3.0]) + rng.uniform(-0.01, 0.01, (300, 3))
+    t0, t1 = np.array([0.4, 0.4, 0.0]), np.array([-0.3, 0.4, 0.0])
+    A = np.concatenate([P, K])
+    Cc = np.concatenate([np.repeat(P, 10, 0) + t1 + rng.normal(0, 0.003, (1000, 3)), K[:20] + t0])
+    S = np.full((N, 4), 1e8, np.float32); S[:, 3] = 0
+    D = S.copy()
+    S[:len(A), :3] = A + 10.0; S[:len(A), 3] = 1
+    D[:len(Cc), :3] = Cc + 10.0; D[:len(Cc), 3] = 1
+    return S, D
+
+
+def test_check_scans_for_itself_where_the_picked_candidates_forward_scan_was_pruned():
+    """(header 0.2.11) The roll-back check takes its sum under the initial pose from the scoring -- the forward total of the picked
+    candidate -- unless that scan was pruned: a candidate can win through its BACKWARD mean while its forward scan exceeded
+    candidate 0's bound and reports +inf.  Two such pairs (built for it; tools/dbg/check_reuse_stats.py counts them in a
+    -DICPFLOW_REUSE_STATS build) among ordinary ones: the pick is the backward winner, as in the oracle, and the registrations are
+    bit for bit those of the check that scans under both poses (ICPFLOW_OPT_NO_CHECK_REUSE), of every scoring scan run to its end
+    (where the total is finite and IS taken over) and of the all-pairs check."""
+    N = 1100
+    S, D, _ = synthetic.make_batch(8, N, seed=41, ragged=True, n_min=300)
+    for b, seed in ((2, 0), (5, 1)):
+        S[b], D[b] = _backward_winner_pair(N, seed)
+    a = rp.default_args(max_points=N, icp_max_iterations=50)
+    s, d = G(S), G(D)
+    init = utils_hist.estimate_init_pose(a, s, d).cpu().numpy()
+    want_init = rp.estimate_init_pose(a, C(S), C(D)).numpy()
+    assert np.array_equal(init, want_init)
+    for b in (2, 5):
+        assert np.allclose(init[b, :3, 3], [-0.3, 0.4, 0.0], atol=1e-6)
+    T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    for opts in ({"no_check_reuse": True}, {"no_score_prune": True}, {"no_check_sweep": True}, {"no_check_reuse": True, "no_score_prune": True}):
+        with _lib.options(**opts):
+            T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert int(it0) == int(it1) and torch.equal(T0, T1), opts
+    want = rp.hist_icp(a, C(S[[2, 5]]), C(D[[2, 5]]), max_iterations=int(it1), kabsch_dtype=torch.float64).numpy()
+    err = displacement(T1.cpu().numpy()[[2, 5]], want, S[[2, 5]])
+    print("backward winners against the oracle (same iteration count): %.2e m" % err.max())
+    assert err.max() < 1e-4
+
+
 @pytest.mark.parametrize("shape", ["config2_256x1024", "ragged_90x2048", "long_clouds_6x6000"])
 def test_launch_plumbing_variants_change_nothing(shape):
     """hist_icp's launch plumbing: where one workgroup sorts a cloud (N <= 4096) the vote's sort counts the valid rows,
