@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=50, help="ICP iteration cap (BASELINE: 50)")
     ap.add_argument("--stop-mode", default="reference", choices=["reference", "per_pair"])
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--time-every", type=int, default=5, help="HIP events around the ICP launch in every n-th step of the timed region (1 = every step)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements")
     ap.add_argument("--force-collective", action="store_true", help="one rank: init RCCL and all_gather anyway")
     ap.add_argument("--check-gather", action="store_true", help="compare the gathered rows with the local ones")
@@ -268,25 +269,33 @@ def stream_main(a, rank, world, local):
         raise SystemExit("stream: the ranks' frame pairs do not add up to the stream")
 
 
-def timed_steps(step, sync, steps, warmup, iters_cap):
+def timed_steps(step, sync, steps, warmup, iters_cap, every=1):
     """W untimed steps, then exactly K steps between two (barrier + device synchronize); the launches of the
-    dominant kernel are bracketed by HIP events on the stream they run on (icpflow_profile_t)."""
+    dominant kernel are bracketed by HIP events on the stream they run on (icpflow_profile_t) -- in every `every`-th
+    step of the timed region: an event pair costs the step ~7 us of a 0.68 ms chain of dependent launches
+    (tools/dbg/profile_cost_ab.py), so the headline times one step in five.  -> ..., steps whose launches were timed"""
     from icp_flow_amd import _lib
     for _ in range(warmup):
         step()
     # one event pair per ICP launch: one launch per step up to 128 iterations (speculative single launch), one per
     # iteration beyond
     prof = _lib.Profile(steps * (iters_cap if iters_cap > 128 else 1) + 8)
+    every = max(1, int(every))
+    timed = 0
     sync()
     t0 = time.perf_counter()
-    with _lib.options(profile=prof):
-        for _ in range(steps):
+    for k in range(steps):
+        if k % every == 0:
+            with _lib.options(profile=prof):
+                T, iters = step()
+            timed += 1
+        else:
             T, iters = step()
     sync()
     dt = time.perf_counter() - t0
     icp_ms, icp_launches = prof.collect()
     prof.close()
-    return dt, icp_ms, icp_launches, T, iters
+    return dt, icp_ms, icp_launches, T, iters, timed
 
 
 def main():
@@ -349,7 +358,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    dt, icp_ms, icp_launches, T, iters = timed_steps(step, sync, a.steps, a.warmup, a.iters)
+    dt, icp_ms, icp_launches, T, iters, steps_timed = timed_steps(step, sync, a.steps, a.warmup, a.iters, every=(a.time_every if a.iters <= 128 else 1))
     gather_check = None
     if collective:
         if True:                # (always, outside the timed region) the rows this rank contributed, as every rank received them
@@ -374,7 +383,7 @@ def main():
         return
 
     value = total * a.steps / dt
-    roofline = roofline_block(B, N, a.steps, iters_done, icp_ms, icp_launches, dt, _lib.BUILD_INFO)
+    roofline = roofline_block(B, N, a.steps, iters_done, icp_ms, icp_launches, dt, _lib.BUILD_INFO, steps_timed)
 
     extras = {}
     if not a.no_extras and world == 1 and workload == "config2":   # N > 1 runs measure scaling, nothing else
@@ -421,13 +430,14 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_block(B, N, steps, iters_done, icp_ms, icp_launches, dt, build):
+def roofline_block(B, N, steps, iters_done, icp_ms, icp_launches, dt, build, steps_timed=None):
     """Roofline of the dominant kernel, icp_kernel.  One launch runs ALL ICP iterations of the batch (speculative
     execution of the batch-global stop), or one launch per iteration beyond 128 iterations.
     Algorithmic work per executed iteration: P = (n_s + n_d) * 16 B and E = n_s * n_d pair-evaluations
     (8 lane-ops each) per pair.  Top-level achieved/peak/frac follow the bench contract (algorithmic HBM bytes /
     launch duration); `bound` names what actually binds the kernel and `valu` carries that roofline."""
     P, E = (N + N) * 16, N * N
+    steps_all, steps = steps, (steps_timed or steps)    # the steps whose launches carried events (timed_steps: one in `every`)
     executed = iters_done * steps                       # iterations of the batch rule (same every step)
     alg_bytes = B * P * executed
     alg_evals = B * E * executed
@@ -477,8 +487,9 @@ def roofline_block(B, N, steps, iters_done, icp_ms, icp_launches, dt, build):
         "algorithmic_bytes_per_launch": int(alg_bytes / launches),
         "algorithmic_bytes_per_iteration": B * P,
         "avg_launch_ms": round(icp_ms / launches, 5), "launches_timed": icp_launches,
+        "steps_with_timed_launches": steps, "steps_of_the_timed_region": steps_all,
         "icp_iterations_executed_per_step": iters_done,
-        "icp_share_of_step": round(icp_ms / (dt * 1e3), 4),
+        "icp_share_of_step": round((icp_ms / steps) / (dt * 1e3 / steps_all), 4),
         "valu": valu,
     }
 
@@ -496,7 +507,7 @@ def config4_single_gpu(dev, a):
     out = {"workload": "BASELINE config 4 (8192 cluster pairs x 2048 pts, <= %d iters), same timing protocol" % a.iters}
     for tag, nb, steps in (("all_8192_pairs", 8192, 5), ("shard_of_8_gpus_1024_pairs", 1024, 10)):
         s, d = src[:nb].contiguous(), dst[:nb].contiguous()
-        dt, icp_ms, launches, _, iters = timed_steps(lambda: utils_match.hist_icp(args, s, d, return_iterations=True),
+        dt, icp_ms, launches, _, iters, _ = timed_steps(lambda: utils_match.hist_icp(args, s, d, return_iterations=True),
                                                      lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
         out[tag] = {"registrations_per_s": round(nb * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
                     "icp_iterations": int(iters.item()), "icp_kernel_ms_per_step": round(icp_ms / steps, 3)}
@@ -504,7 +515,7 @@ def config4_single_gpu(dev, a):
         def step_eval():   # the step `--gpus N` times on every rank, less the all_gather: hist_icp + match_eval (one call)
             T, _, it = utils_match.hist_icp_eval(args, s, d, return_iterations=True)
             return T, it
-        dt_eval, _, _, _, _ = timed_steps(step_eval, lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
+        dt_eval, _, _, _, _, _ = timed_steps(step_eval, lambda: torch.cuda.synchronize(dev), steps, 1, a.iters)
         out[tag]["registrations_per_s_with_match_eval"] = round(nb * steps / dt_eval, 1)
         if nb == 1024:
             out[tag]["roofline"] = config4_roofline(nb, N, int(iters.item()), dt / steps * 1e3, icp_ms / steps)
