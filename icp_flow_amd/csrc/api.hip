@@ -201,6 +201,11 @@ struct Workspace {
             pairBox = (float *)take(b * kPairBoxStride * 4);
         }
         grid.axis = (int32_t *)take(b * 4);
+        // (occupancy grids of both sorted clouds for the pre-bound of the scoring sweeps, nn.hip: 8.2 KiB per pair)
+        if (N <= kMaxSortN) {
+            grid.occHdr = (float *)take(b * 2 * 8 * 4);
+            grid.occBits = (uint32_t *)take(b * 2 * (size_t)kOccWords * 4);
+        }
         // (sweeps of a small cloud against a long one, shared by several blocks: nn.hip; only where the partial minima stay small)
         if (shareScratch(B, N)) {
             grid.shareBest = (float *)take(b * 12 * kSweepShareSlots * 256 * 4);
@@ -240,7 +245,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
     if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
-    if (opt->flags >> 16) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    if (opt->flags >> 17) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
     o.search = opt->icp_search;
     o.arith = opt->icp_arith;
     o.flags = opt->flags;
@@ -465,6 +470,10 @@ int run_init_pose(const float *src, const float *dst, Workspace &w, const uint8_
         } else if (!w.grid.presorted) {
             ICPFLOW_TRY(launch_sort_clouds_soa(src, dst, w.lenA, w.lenC, swap, B, N, &w.grid, s));
             w.grid.presorted = 1;
+            if (o.on(ICPFLOW_OPT_NO_SCORE_PRUNE) && o.on(ICPFLOW_OPT_NO_SCORE_PREBOUND)) {
+                ICPFLOW_TRY(launch_occupancy(&w.grid, B, N, s));
+                w.grid.occReady = 1;
+            }
         }
         if (o.on(ICPFLOW_OPT_NO_SCORE_PRUNE))
             ICPFLOW_TRY(launch_sweep_score_pruned(&w.grid, w.lenA, w.lenC, swap, B, N, w.cand, w.partial, w.scoreAccum, s));
@@ -1046,8 +1055,13 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
         // from here on the side stream belongs to the caller's stream order (and capture): a failed
         // launch still records the join so that the fork never dangles.  With the counting folded into the sorts
         // nothing on the side stream waits for a kernel of this call: the axis sort counts for itself (selfCount).
-        const hipError_t se = launch_sort_clouds_soa(d_src, d_dst, w.lenA, w.lenC, w.swap, B, N, &w.grid, side->stream,
-                                                     countInSort ? 2 : 0);
+        hipError_t se = launch_sort_clouds_soa(d_src, d_dst, w.lenA, w.lenC, w.swap, B, N, &w.grid, side->stream,
+                                               countInSort ? 2 : 0);
+        // ... and, behind it, the occupancy grids of the two sorted clouds for the scoring's pre-bound (nn.hip)
+        if (se == hipSuccess && score_by_sweep(N, true, o) && o.on(ICPFLOW_OPT_NO_SCORE_PRUNE) && o.on(ICPFLOW_OPT_NO_SCORE_PREBOUND)) {
+            se = launch_occupancy(&w.grid, B, N, side->stream);
+            if (se == hipSuccess) w.grid.occReady = 1;
+        }
         // the ICP's team plan reads the lengths and roles only: where count_pair has written them before the fork it runs
         // here, beside the vote, instead of in front of the ICP launch (22-31 us of a serial chain)
         if (se == hipSuccess && !countInSort &&

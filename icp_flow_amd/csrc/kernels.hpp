@@ -166,6 +166,8 @@ hipError_t launch_sweep_check(const GridScratch *grid, const float *X, const flo
                               const int32_t *lenC, const uint8_t *swap, int B, int N, const float *poseInit,
                               const float *poseFinal, double *partial, hipStream_t s, const PoseSource *fused = nullptr,
                               const uint8_t *active = nullptr, const double *initSum = nullptr);
+// after launch_sort_clouds_soa on the same stream: the occupancy grids of both sorted clouds (GridScratch.occHdr / occBits)
+hipError_t launch_occupancy(const GridScratch *grid, int B, int N, hipStream_t s);
 hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
                               int B, int N, const float *cand, double *partial, hipStream_t s);
 hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC,
@@ -188,6 +190,7 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
                           int64_t *idx, float *dist, hipStream_t s);
 
 // icp.hip
+constexpr int kOccWords = 1024;   // 32 768 cells per (pair, role) occupancy grid (nn.hip)
 constexpr int kSweepShareSlots = 16;   // (query blocks x shares) of a job whose blocks split ALL targets between them (nn.hip)
 struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop (see icp.hip)
     int mode;          // 2 = hashed grid, 3 = sorted sweep
@@ -208,6 +211,13 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     float *shareBest;  // sweeps (nn.hip): [B*12, kSweepShareSlots, 256] partial minima of small-against-long jobs shared by several blocks, or NULL
     int *shareCount;   //   [B*12, <= kSweepShareSlots] blocks delivered (zero between launches: the last block to deliver resets its counter)
     int shareCountClean;   //   host-side: this call has cleared shareCount already (api.hip: with scoreAccum) -- no memset per launch
+    // scoring sweeps with branch and bound (nn.hip occ_build_kernel): per (pair, role) a DILATED occupancy grid of the sorted cloud --
+    // bit set: some point of the cloud lies in the cell or in one of its 26 neighbours -- from which a scan gets a lower bound of its
+    // whole sum before it has evaluated a single target.  occHdr [B,2,8]: origin x y z, 1 / h, 0.98 h, nx, ny, nz (ints as bits);
+    // occBits [B,2,kOccWords]; occReady: host-side, built for THIS call's sort (launch_occupancy)
+    float *occHdr;
+    uint32_t *occBits;
+    int occReady;
     int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose
                        // (scoring sweep ran on this batch): the ICP applies the pre-pose when it loads
 };

@@ -354,8 +354,16 @@ struct SweepParams {
     // the scan under the initial pose (sub 0) would form: where it is finite that scan is left out and select_kernel reads
     // the total instead (+inf: the scan was pruned, the check scans for itself)
     const double *initSum;
+    // SWEEP_SCORE with prune == 1: optional occupancy grids of both sorted clouds (GridScratch.occHdr / occBits): a scan first bounds
+    // its WHOLE sum from below by (queries in cells without a target in the 27-neighbourhood) x 0.98 h and leaves if that rules it out
+    const float *occHdr;
+    const uint32_t *occBits;
+    int boundBoth;          // SWEEP_SCORE, prune == 1: candidate 0's BACKWARD scan is complete as well (the first launch ran both): the bound is its score, min(forward, backward)
 };
 
+#ifdef ICPFLOW_OCC_STATS
+__device__ unsigned long long g_occStats[12];   // tools/dbg/prebound_stats.py
+#endif
 constexpr int kSweepBlock = 256;
 #ifndef ICPFLOW_SWEEP_SHARE_MIN_TARGETS
 #define ICPFLOW_SWEEP_SHARE_MIN_TARGETS 512
@@ -436,6 +444,15 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     // wherever the batch put them; records, counters and sums keep the pair's own place)
     if (p.pairOrder != nullptr) b = p.pairOrder[b];
     job = (MODE == SWEEP_SCORE) ? b * 12 + sub : b * 2 + sub;   // the scan's place in the partial records
+    if (MODE == SWEEP_SCORE && p.prune == 1 && p.occBits != nullptr && qb > 0) {
+        // a scan that its block 0 has ended by the occupancy pre-bound (below): +inf in its running sum -- one load and out
+        const double seen = __hip_atomic_load(p.accum + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == __builtin_huge_val()) {
+            double *rec = p.partial + ((size_t)job * p.qblocks + qb) * kPartial;
+            if (threadIdx.x < kPartial) rec[threadIdx.x] = threadIdx.x == 0 ? __builtin_huge_val() : 0.0;
+            return;
+        }
+    }
     if (MODE == SWEEP_CHECK && sub == 0 && p.initSum != nullptr) {   // (every block of the job decides alike; nobody reads its records)
         const double t = p.initSum[b];
         if (t - t == 0.0 && (p.active == nullptr || p.active[b] != 0)) return;
@@ -505,6 +522,12 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
                 const int sc = u == 0 ? 0 : u + 1;                                     // scans 0, 2 .. 11
                 v[u] = (u == 0 || p.prune == 2) ? p.partial[((size_t)(b * 12 + sc) * p.qblocks + q) * kPartial] : 0.0;
             }
+            if (p.boundBoth) {   // candidate 0's backward scan, complete since the first launch
+                const double v1 = p.partial[((size_t)(b * 12 + 1) * p.qblocks + q) * kPartial];
+                double t = 0.0;
+                for (int qq = 0; qq < p.qblocks; ++qq) t += __shfl(v1, qq, kWave);
+                if (lane == 0) scanSum[1] = t;
+            }
 #pragma unroll
             for (int u = 0; u < 11; ++u) {
                 if (u > 0 && p.prune != 2) break;
@@ -518,7 +541,13 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             double f0 = 0.0;
             if (p.qblocks <= kWave) f0 = scanSum[0];
             else for (int q = 0; q < p.qblocks; ++q) f0 += p.partial[((size_t)(b * 12 + 0) * p.qblocks + q) * kPartial];
-            const float bound = (float)f0 / (float)na;
+            float bound = (float)f0 / (float)na;
+            if (p.boundBoth) {   // candidate 0's score as score_pick_kernel forms it: fminf(forward mean, backward mean)
+                double b0 = 0.0;
+                if (p.qblocks <= kWave) b0 = scanSum[1];
+                else for (int q = 0; q < p.qblocks; ++q) b0 += p.partial[((size_t)(b * 12 + 1) * p.qblocks + q) * kPartial];
+                bound = fminf(bound, (float)b0 / (float)nc);
+            }
             boundSh = bound;
             if (p.prune == 2) {
                 bool othersOut = true;
@@ -545,6 +574,68 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         }
         __syncthreads();
         if (leave) return;
+        // The occupancy pre-bound (round 5, end): candidates other than the vote's winner are other peaks of the histogram, six bins
+        // (0.6 m) or more away, or the zero translation -- the moved cloud mostly lies where the other cloud has nothing.  88 % of the
+        // scanning waves of this launch used to be pruned only after ~2 rounds and ~160 evaluated targets each: here every
+        // block first counts, over ALL queries of its scan, those whose cell of the other cloud's dilated occupancy grid is empty: such a
+        // query has no target within 0.98 h (cells differ by two or more along some axis; the cell arithmetic's rounding, < 0.5 % of a cell,
+        // is inside the 2 % margin), so count x 0.98 h bounds the scan's sum from below before a single target has been evaluated.
+        // A bound only ever ends a scan whose mean provably exceeds
+        // candidate 0's forward mean: picks and sums are unchanged (ICPFLOW_OPT_NO_SCORE_PREBOUND; test_scoring_variants_change_nothing).
+        // ONE block per scan does it -- query block 0, dispatched before the others (query-block-major grid) -- and, where the bound ends
+        // the scan, leaves +inf in the scan's running sum: the prologue above then ends every later block of the scan at once.  (A block
+        // that starts before block 0 has got that far simply scans as it always did.)
+        if (p.prune == 1 && p.occBits != nullptr && sub != 1 && qb == 0) {
+            __shared__ int occCount[kSweepBlock / kWave];
+            __shared__ int occLeave;
+            const float *t3 = p.cand + ((size_t)b * 6 + (sub >> 1)) * 3;
+            const float ptx = t3[0], pty = t3[1], ptz = t3[2];
+            const int role = backward ? 0 : 1;   // the targets' cloud: src role for a backward scan, dst role for a forward one
+            const float *hdr = p.occHdr + ((size_t)b * 2 + role) * 8;
+            const uint32_t *bits = p.occBits + ((size_t)b * 2 + role) * kOccWords;
+            const float gox = hdr[0], goy = hdr[1], goz = hdr[2], ginv = hdr[3], hlb = hdr[4];
+            const int gnx = __float_as_int(hdr[5]), gny = __float_as_int(hdr[6]), gnz = __float_as_int(hdr[7]);
+            int cnt = 0;
+            if (gnx > 0) {
+                for (int i = threadIdx.x; i < nq; i += kSweepBlock) {
+                    float x = qs[i], y = qs[p.NP16 + i], z = qs[2 * p.NP16 + i];
+                    if (!backward) { x += ptx; y += pty; z += ptz; }   // the moved source cloud against dst
+                    else { x -= ptx; y -= pty; z -= ptz; }             // dst against the moved source cloud: |c - (a + t)| = |(c - t) - a| to rounding
+                    const float ux = floorf((x - gox) * ginv), uy = floorf((y - goy) * ginv), uz = floorf((z - goz) * ginv);
+                    // (NaN coordinates fail the range test below and count as "occupied": no bound from them)
+                    const bool inside = ux >= 0.f && ux < (float)gnx && uy >= 0.f && uy < (float)gny && uz >= 0.f && uz < (float)gnz;
+                    const bool finite = fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f;
+                    bool empty = finite && !inside;   // beyond the grid: two cells or more from every target's cell
+                    if (inside) {
+                        const int c = ((int)ux * gny + (int)uy) * gnz + (int)uz;
+                        empty = ((bits[c >> 5] >> (c & 31)) & 1u) == 0u;
+                    }
+                    cnt += empty ? 1 : 0;
+                }
+            }
+            cnt = wave_sum(cnt);
+            if (lane == 0) occCount[wave] = cnt;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int tot = 0;
+                for (int w = 0; w < kSweepBlock / kWave; ++w) tot += occCount[w];
+                const float low = ((float)tot * hlb * 0.999f) / (float)(backward ? nc : na);
+                occLeave = low > boundSh * 1.0001f ? 1 : 0;   // NaN / inf bounds never prune
+#ifdef ICPFLOW_OCC_STATS
+                atomicAdd(&g_occStats[0], 1ull); if (occLeave) atomicAdd(&g_occStats[1], 1ull);
+                atomicAdd(&g_occStats[2], (unsigned long long)tot); atomicAdd(&g_occStats[3], (unsigned long long)nq);
+                const float ratio = low / boundSh;   // histogram of (pre-bound / bound) in steps of 0.25, [4 .. 11]
+                atomicAdd(&g_occStats[4 + min(7, max(0, (int)(ratio * 4.0f)))], 1ull);
+#endif
+                if (occLeave) {
+                    out[0] = __builtin_huge_val();
+                    for (int k = 1; k < kPartial; ++k) out[k] = 0.0;
+                    atomicAdd(p.accum + job, __builtin_huge_val());   // (the running LOWER bound of the scan's sum: +inf ends the scan)
+                }
+            }
+            __syncthreads();
+            if (occLeave) return;
+        }
     }
     __shared__ float poseSh[16];
     if (MODE == SWEEP_CHECK) {   // the pose of this job: init (sub 0) or final (sub 1; composed here when fused)
@@ -751,7 +842,10 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             // a scan that may still be pruned widens its window by doublings: the lower bound grows with the proven
             // radius, and a wave whose worst lane is a metre from everything must not pay for a metre of targets
             // before the scan's running sum has had the chance to end it (config 2: -5 % per step)
-            if (MODE == SWEEP_SCORE && p.prune == 1) r = fminf(r, rPrev * 2.0f);
+#ifndef ICPFLOW_SWEEP_GROWTH
+#define ICPFLOW_SWEEP_GROWTH 2.0f
+#endif
+            if (MODE == SWEEP_SCORE && p.prune == 1) r = fminf(r, rPrev * ICPFLOW_SWEEP_GROWTH);
         }
     }
 #ifdef ICPFLOW_SWEEP_CLOCK
@@ -881,6 +975,123 @@ static hipError_t launch_sweep(SweepParams p, hipStream_t s)
     return hipGetLastError();
 }
 
+// Dilated occupancy grid of one sorted cloud (SoA image of launch_sort_clouds_soa: valid rows first, +inf behind them), grid (B, 2):
+// y = 0 the src role's cloud, 1 the dst role's.  Cell edge h = 0.125 m, grown by a quarter at a time until the box of the cloud --
+// plus one cell of margin all round -- fits kOccWords * 32 cells.  A point sets the bits of its cell and of the 26 around it.
+constexpr int kOccBlock = 256;
+// The whole bit array moved by `sh` bits towards higher (up) or lower cell numbers; bits moved in from outside are zero.
+__device__ __forceinline__ uint32_t occ_shifted(const uint32_t *in, int w, int sh, bool up)
+{
+    const int q = sh >> 5, r = sh & 31;
+    if (up) {
+        const int a = w - q;
+        const uint32_t lo = a >= 0 ? in[a] : 0u, lo1 = a - 1 >= 0 ? in[a - 1] : 0u;
+        return r == 0 ? lo : ((lo << r) | (lo1 >> (32 - r)));
+    }
+    const int a = w + q;
+    const uint32_t hi = a < kOccWords ? in[a] : 0u, hi1 = a + 1 < kOccWords ? in[a + 1] : 0u;
+    return r == 0 ? hi : ((hi >> r) | (hi1 << (32 - r)));
+}
+
+__global__ __launch_bounds__(kOccBlock) void occ_build_kernel(const float *__restrict__ Xsoa, const float *__restrict__ Ysoa,
+                                                            int NP16, float *__restrict__ hdrOut, uint32_t *__restrict__ bitsOut)
+{
+    __shared__ uint32_t bitsA[kOccWords], bitsB[kOccWords];
+    __shared__ float red[6 * (kOccBlock / kWave)];
+    __shared__ float hd[8];
+    const int b = blockIdx.x, which = blockIdx.y, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const float *px = (which == 0 ? Xsoa : Ysoa) + (size_t)b * 3 * NP16, *py = px + NP16, *pz = py + NP16;
+    for (int k = tid; k < kOccWords; k += kOccBlock) bitsA[k] = 0u;
+    float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
+    for (int i = tid; i < NP16; i += kOccBlock) {
+        const float x = px[i], y = py[i], z = pz[i];
+        if (fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f) {   // (pads are +inf; NaN rows fail too: they are no target anybody is near)
+            mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+            mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, kWave));
+        }
+        if (lane == 0) { red[wave * 6 + a] = mn[a]; red[wave * 6 + 3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = kInf; hi[a] = -kInf;
+            for (int w = 0; w < kOccBlock / kWave; ++w) { lo[a] = fminf(lo[a], red[w * 6 + a]); hi[a] = fmaxf(hi[a], red[w * 6 + 3 + a]); }
+        }
+        int n[3] = {0, 0, 0};
+        float h = 0.125f;
+        if (lo[0] <= hi[0]) {   // a cloud with points
+            for (int grow = 0; grow < 64; ++grow) {
+                bool fits = true;
+                long long cells = 1;
+                for (int a = 0; a < 3; ++a) {
+                    const float e = (hi[a] - lo[a]) / h;
+                    if (!(e < 30000.f)) { fits = false; break; }
+                    n[a] = (int)e + 4;   // one cell of margin below the lowest point, the points' cells, one above, one of slack
+                    cells *= n[a];
+                }
+                if (fits && cells <= (long long)kOccWords * 32) break;
+                h *= 1.25f; n[0] = 0;
+            }
+        }
+        if (n[0] <= 0) n[0] = n[1] = n[2] = 0;   // empty cloud (or one no grid holds): no bound
+        hd[0] = lo[0] - h; hd[1] = lo[1] - h; hd[2] = lo[2] - h;   // the lowest point falls into cell 1
+        // rounding of the cell arithmetic: two ulps of the largest coordinate, in cells -- below 0.5 % of a cell or no grid at all
+        // (coordinates of kilometres against a 12.5 cm cell); the bound itself keeps 2 % in hand (0.98 h)
+        float big = 0.f;
+        for (int a = 0; a < 3; ++a) big = fmaxf(big, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+        if (!(big * 2.4e-7f / h < 0.005f)) n[0] = n[1] = n[2] = 0;
+        hd[3] = 1.0f / h; hd[4] = 0.98f * h;
+        hd[5] = __int_as_float(n[0]); hd[6] = __int_as_float(n[1]); hd[7] = __int_as_float(n[2]);
+    }
+    __syncthreads();
+    const float gox = hd[0], goy = hd[1], goz = hd[2], ginv = hd[3];
+    const int gnx = __float_as_int(hd[5]), gny = __float_as_int(hd[6]), gnz = __float_as_int(hd[7]);
+    if (gnx > 0) {
+        for (int i = tid; i < NP16; i += kOccBlock) {
+            const float x = px[i], y = py[i], z = pz[i];
+            if (!(fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f)) continue;
+            // the cell, kept one cell inside the grid (rounding at the box's faces): its 27-neighbourhood stays inside, and a
+            // shift of the bit array by one cell along any axis never carries a bit across a face
+            const int cx = min(max((int)floorf((x - gox) * ginv), 1), gnx - 2);
+            const int cy = min(max((int)floorf((y - goy) * ginv), 1), gny - 2);
+            const int cz = min(max((int)floorf((z - goz) * ginv), 1), gnz - 2);
+            const int c = (cx * gny + cy) * gnz + cz;
+            atomicOr(&bitsA[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+    // dilation by one cell along z, y, x in turn (separable: the 27-neighbourhood), each a shift of the whole bit array by 1, nz,
+    // ny * nz bits up and down
+    const int strides[3] = {1, gnz, gny * gnz};
+    uint32_t *in = bitsA, *outb = bitsB;
+    for (int a = 0; a < 3; ++a) {
+        if (gnx > 0)
+            for (int w = tid; w < kOccWords; w += kOccBlock) outb[w] = in[w] | occ_shifted(in, w, strides[a], true) | occ_shifted(in, w, strides[a], false);
+        __syncthreads();
+        uint32_t *t = in; in = outb; outb = t;
+    }
+    uint32_t *bo = bitsOut + ((size_t)b * 2 + which) * kOccWords;
+    for (int k = tid; k < kOccWords; k += kOccBlock) bo[k] = gnx > 0 ? in[k] : 0u;
+    if (tid < 8) hdrOut[((size_t)b * 2 + which) * 8 + tid] = hd[tid];
+}
+
+hipError_t launch_occupancy(const GridScratch *grid, int B, int N, hipStream_t s)
+{
+    if (grid->occHdr == nullptr || grid->occBits == nullptr || grid->sortXsoa == nullptr || grid->sortYsoa == nullptr) return hipSuccess;
+    const int NP16 = (N + kChunk - 1) / kChunk * kChunk;
+    hipLaunchKernelGGL(occ_build_kernel, dim3(B, 2), dim3(kOccBlock), 0, s, grid->sortXsoa, grid->sortYsoa, NP16, grid->occHdr, grid->occBits);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep_score(const GridScratch *grid, const int32_t *lenA, const int32_t *lenC, const uint8_t *swap,
                               int B, int N, const float *cand, double *partial, hipStream_t s)
 {
@@ -901,7 +1112,19 @@ hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *len
     SweepParams p{};
     p.Asoa = grid->sortXsoa; p.Csoa = grid->sortYsoa; p.lenA = lenA; p.lenC = lenC; p.swap = swap;
     p.axis = grid->axis; p.cand = cand; p.N = N; p.partial = partial; p.accum = accum;
+    if (grid->occReady) { p.occHdr = grid->occHdr; p.occBits = grid->occBits; }
     p.shareBest = grid->shareBest; p.shareCount = grid->shareCount; p.shareClean = grid->shareCountClean; p.pairOrder = grid->pairOrder; p.pairTab = grid->pairTab;
+    if (grid->occReady) {
+        // With the occupancy pre-bound (sweep_scan_kernel) nearly every scan of the other five candidates ends before it has evaluated a
+        // target: what is left of the second launch is candidate 0's backward scan, which nothing ends before its last block.  It
+        // runs to the end beside the forward scan instead (the first launch filled half of the GPU at config 2), and the others are
+        // pruned against candidate 0's SCORE, min(forward, backward), instead of its forward mean alone.
+        p.njobs = B * 2; p.subBegin = 0; p.subCount = 2; p.prune = 0;
+        hipError_t e2 = launch_sweep<SWEEP_SCORE>(p, s);
+        if (e2 != hipSuccess) return e2;
+        p.njobs = B * 10; p.subBegin = 2; p.subCount = 10; p.prune = 1; p.boundBoth = 1;
+        return launch_sweep<SWEEP_SCORE>(p, s);
+    }
     p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
     hipError_t e = launch_sweep<SWEEP_SCORE>(p, s);
     if (e != hipSuccess) return e;
@@ -1028,3 +1251,16 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
 }
 
 }  // namespace icpflow
+
+#ifdef ICPFLOW_OCC_STATS
+extern "C" int icpflow_debug_occ_stats(unsigned long long *out12, int reset)
+{
+    (void)hipDeviceSynchronize();
+    const int rc = (int)hipMemcpyFromSymbol(out12, HIP_SYMBOL(icpflow::g_occStats), sizeof(icpflow::g_occStats));
+    if (reset) {
+        const unsigned long long z[12] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(icpflow::g_occStats), z, sizeof(z));
+    }
+    return rc;
+}
+#endif

@@ -376,8 +376,50 @@ def test_scoring_variants_change_nothing(shape):
     assert int(it3) == int(it1) and torch.equal(T3, T1)
     with _lib.options(no_check_reuse=True, no_score_prune=True):
         assert torch.equal(utils_match.hist_icp(a, s, d), T1)
+    # (header 0.2.12) the pruned sweeps first bound a scan's WHOLE sum from below by the other cloud's dilated occupancy grid (queries
+    # in cells with no target in the 27-neighbourhood x 0.98 h: nn.hip occ_build_kernel) and leave before evaluating a target where that
+    # already rules the candidate out; without the grids (ICPFLOW_OPT_NO_SCORE_PREBOUND) the same picks, hence the same poses
+    with _lib.options(no_score_prebound=True):
+        T4, it4 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    assert int(it4) == int(it1) and torch.equal(T4, T1)
+    init1 = utils_hist.estimate_init_pose(a, s, d)
+    with _lib.options(no_score_prebound=True):
+        assert torch.equal(utils_hist.estimate_init_pose(a, s, d), init1)
     for _ in range(3):
         assert torch.equal(utils_match.hist_icp(a, s, d), T1)
+
+
+@pytest.mark.parametrize("offset,scale", [(0.0, 1.0), (150.0, 1.0), (900.0, 1.0), (6000.0, 1.0), (40.0, 12.0), (0.0, 0.02)])
+def test_occupancy_prebound_never_changes_a_pick(offset, scale):
+    """(header 0.2.12) The pre-bound of the pruned scoring sweeps counts the queries whose cell of the other cloud's dilated occupancy
+    grid is empty: such a query has no target within 0.98 h, whatever the rounding of the cell arithmetic.  Clouds far from the origin
+    (cell arithmetic on coordinates of hundreds of metres; beyond ~2.6 km the build refuses the grid), clusters tens of metres across
+    (the cell edge grows until the grid fits) and clusters of centimetres (a handful of cells): the initial poses equal the oracle's
+    and those of the sweeps without the grids; the registrations are the same bit for bit."""
+    N = 1100
+    S, D, _ = synthetic.make_batch(48, N, seed=77, ragged=True, n_min=3)
+    for b, sd in ((7, 2), (19, 3)):
+        S[b], D[b] = _backward_winner_pair(N, sd)
+    for A in (S, D):
+        v = A[:, :, 3] > 0
+        A[:, :, :3][v] = A[:, :, :3][v] * np.float32(scale) + np.float32(offset)
+    a = rp.default_args(max_points=N, icp_max_iterations=30)
+    s, d = G(S), G(D)
+    init = utils_hist.estimate_init_pose(a, s, d)
+    with _lib.options(no_score_prebound=True):
+        init0 = utils_hist.estimate_init_pose(a, s, d)
+    assert torch.equal(init, init0)
+    want = rp.estimate_init_pose(a, C(S), C(D)).numpy()
+    if scale >= 1.0:
+        assert np.array_equal(init.cpu().numpy(), want)
+    else:   # centimetre clusters: the whole vote sits in a bin or two and the other "peaks" are ties among empty bins, whose order is
+        # torch.topk's (COVERAGE.md, named deviations) -- reported, not asserted; the variants below still agree bit for bit
+        print("pairs whose pick differs from the oracle's (tied peaks):", int((np.abs(init.cpu().numpy() - want).max((1, 2)) > 0).sum()))
+    T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    for opts in ({"no_score_prebound": True}, {"no_score_prune": True}, {"no_score_prebound": True, "no_check_reuse": True}):
+        with _lib.options(**opts):
+            T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert int(it0) == int(it1) and torch.equal(T0, T1), opts
 
 
 def _backward_winner_pair(N, seed):
@@ -419,7 +461,8 @@ def test_check_scans_for_itself_where_the_picked_candidates_forward_scan_was_pru
     for b in (2, 5):
         assert np.allclose(init[b, :3, 3], [-0.3, 0.4, 0.0], atol=1e-6)
     T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
-    for opts in ({"no_check_reuse": True}, {"no_score_prune": True}, {"no_check_sweep": True}, {"no_check_reuse": True, "no_score_prune": True}):
+    for opts in ({"no_check_reuse": True}, {"no_score_prune": True}, {"no_check_sweep": True}, {"no_check_reuse": True, "no_score_prune": True},
+                 {"no_score_prebound": True}):
         with _lib.options(**opts):
             T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
         assert int(it0) == int(it1) and torch.equal(T0, T1), opts
