@@ -201,10 +201,10 @@ struct Workspace {
             pairBox = (float *)take(b * kPairBoxStride * 4);
         }
         grid.axis = (int32_t *)take(b * 4);
-        // (occupancy grids of both sorted clouds for the pre-bound of the scoring sweeps, nn.hip: 8.2 KiB per pair)
+        // (occupancy grids of both sorted clouds for the pre-bound of the scoring sweeps, nn.hip: 24 KiB per pair)
         if (N <= kMaxSortN) {
             grid.occHdr = (float *)take(b * 2 * 8 * 4);
-            grid.occBits = (uint32_t *)take(b * 2 * (size_t)kOccWords * 4);
+            grid.occBits = (uint32_t *)take(b * 2 * (size_t)kOccRings * kOccWords * 4);
         }
         // (sweeps of a small cloud against a long one, shared by several blocks: nn.hip; only where the partial minima stay small)
         if (shareScratch(B, N)) {

@@ -191,6 +191,10 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
 
 // icp.hip
 constexpr int kOccWords = 1024;   // 32 768 cells per (pair, role) occupancy grid (nn.hip)
+#ifndef ICPFLOW_OCC_RINGS
+#define ICPFLOW_OCC_RINGS 3
+#endif
+constexpr int kOccRings = ICPFLOW_OCC_RINGS;   // ... in that many planes: the cloud dilated once, twice, ...
 constexpr int kSweepShareSlots = 16;   // (query blocks x shares) of a job whose blocks split ALL targets between them (nn.hip)
 struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop (see icp.hip)
     int mode;          // 2 = hashed grid, 3 = sorted sweep
@@ -214,7 +218,7 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     // scoring sweeps with branch and bound (nn.hip occ_build_kernel): per (pair, role) a DILATED occupancy grid of the sorted cloud --
     // bit set: some point of the cloud lies in the cell or in one of its 26 neighbours -- from which a scan gets a lower bound of its
     // whole sum before it has evaluated a single target.  occHdr [B,2,8]: origin x y z, 1 / h, 0.98 h, nx, ny, nz (ints as bits);
-    // occBits [B,2,kOccWords]; occReady: host-side, built for THIS call's sort (launch_occupancy)
+    // occBits [B,2,kOccRings,kOccWords]; occReady: host-side, built for THIS call's sort (launch_occupancy)
     float *occHdr;
     uint32_t *occBits;
     int occReady;

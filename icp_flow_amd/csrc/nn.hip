@@ -592,10 +592,10 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             const float ptx = t3[0], pty = t3[1], ptz = t3[2];
             const int role = backward ? 0 : 1;   // the targets' cloud: src role for a backward scan, dst role for a forward one
             const float *hdr = p.occHdr + ((size_t)b * 2 + role) * 8;
-            const uint32_t *bits = p.occBits + ((size_t)b * 2 + role) * kOccWords;
+            const uint32_t *bits = p.occBits + ((size_t)b * 2 + role) * kOccRings * kOccWords;
             const float gox = hdr[0], goy = hdr[1], goz = hdr[2], ginv = hdr[3], hlb = hdr[4];
             const int gnx = __float_as_int(hdr[5]), gny = __float_as_int(hdr[6]), gnz = __float_as_int(hdr[7]);
-            int cnt = 0;
+            int cnt = 0;   // sum over the queries of their ring level (0 .. kOccRings): level L = no target within L cells
             if (gnx > 0) {
                 for (int i = threadIdx.x; i < nq; i += kSweepBlock) {
                     float x = qs[i], y = qs[p.NP16 + i], z = qs[2 * p.NP16 + i];
@@ -605,12 +605,14 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
                     // (NaN coordinates fail the range test below and count as "occupied": no bound from them)
                     const bool inside = ux >= 0.f && ux < (float)gnx && uy >= 0.f && uy < (float)gny && uz >= 0.f && uz < (float)gnz;
                     const bool finite = fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f;
-                    bool empty = finite && !inside;   // beyond the grid: two cells or more from every target's cell
+                    int level = (finite && !inside) ? kOccRings : 0;   // beyond the grid: kOccRings + 1 cells or more from every target's cell
                     if (inside) {
                         const int c = ((int)ux * gny + (int)uy) * gnz + (int)uz;
-                        empty = ((bits[c >> 5] >> (c & 31)) & 1u) == 0u;
+#pragma unroll
+                        for (int ring = 0; ring < kOccRings; ++ring)   // (the planes are nested: empty in plane k implies empty in the planes below)
+                            level += ((bits[ring * kOccWords + (c >> 5)] >> (c & 31)) & 1u) == 0u ? 1 : 0;
                     }
-                    cnt += empty ? 1 : 0;
+                    cnt += level;
                 }
             }
             cnt = wave_sum(cnt);
@@ -1035,7 +1037,7 @@ __global__ __launch_bounds__(kOccBlock) void occ_build_kernel(const float *__res
                 for (int a = 0; a < 3; ++a) {
                     const float e = (hi[a] - lo[a]) / h;
                     if (!(e < 30000.f)) { fits = false; break; }
-                    n[a] = (int)e + 4;   // one cell of margin below the lowest point, the points' cells, one above, one of slack
+                    n[a] = (int)e + 2 + 2 * kOccRings;   // kOccRings cells of margin below the lowest point, the points' cells, as many above, one of slack
                     cells *= n[a];
                 }
                 if (fits && cells <= (long long)kOccWords * 32) break;
@@ -1043,7 +1045,7 @@ __global__ __launch_bounds__(kOccBlock) void occ_build_kernel(const float *__res
             }
         }
         if (n[0] <= 0) n[0] = n[1] = n[2] = 0;   // empty cloud (or one no grid holds): no bound
-        hd[0] = lo[0] - h; hd[1] = lo[1] - h; hd[2] = lo[2] - h;   // the lowest point falls into cell 1
+        hd[0] = lo[0] - kOccRings * h; hd[1] = lo[1] - kOccRings * h; hd[2] = lo[2] - kOccRings * h;   // the lowest point falls into cell kOccRings
         // rounding of the cell arithmetic: two ulps of the largest coordinate, in cells -- below 0.5 % of a cell or no grid at all
         // (coordinates of kilometres against a 12.5 cm cell); the bound itself keeps 2 % in hand (0.98 h)
         float big = 0.f;
@@ -1059,11 +1061,11 @@ __global__ __launch_bounds__(kOccBlock) void occ_build_kernel(const float *__res
         for (int i = tid; i < NP16; i += kOccBlock) {
             const float x = px[i], y = py[i], z = pz[i];
             if (!(fabsf(x) < 1e30f && fabsf(y) < 1e30f && fabsf(z) < 1e30f)) continue;
-            // the cell, kept one cell inside the grid (rounding at the box's faces): its 27-neighbourhood stays inside, and a
+            // the cell, kept kOccRings cells inside the grid (rounding at the box's faces): every dilation stays inside, and a
             // shift of the bit array by one cell along any axis never carries a bit across a face
-            const int cx = min(max((int)floorf((x - gox) * ginv), 1), gnx - 2);
-            const int cy = min(max((int)floorf((y - goy) * ginv), 1), gny - 2);
-            const int cz = min(max((int)floorf((z - goz) * ginv), 1), gnz - 2);
+            const int cx = min(max((int)floorf((x - gox) * ginv), kOccRings), gnx - 1 - kOccRings);
+            const int cy = min(max((int)floorf((y - goy) * ginv), kOccRings), gny - 1 - kOccRings);
+            const int cz = min(max((int)floorf((z - goz) * ginv), kOccRings), gnz - 1 - kOccRings);
             const int c = (cx * gny + cy) * gnz + cz;
             atomicOr(&bitsA[c >> 5], 1u << (c & 31));
         }
@@ -1071,16 +1073,19 @@ __global__ __launch_bounds__(kOccBlock) void occ_build_kernel(const float *__res
     __syncthreads();
     // dilation by one cell along z, y, x in turn (separable: the 27-neighbourhood), each a shift of the whole bit array by 1, nz,
     // ny * nz bits up and down
+    // Plane k (k = 0 .. kOccRings - 1) is the cloud dilated k + 1 times: a cell that is empty there has no point within k + 1 cells.
     const int strides[3] = {1, gnz, gny * gnz};
     uint32_t *in = bitsA, *outb = bitsB;
-    for (int a = 0; a < 3; ++a) {
-        if (gnx > 0)
-            for (int w = tid; w < kOccWords; w += kOccBlock) outb[w] = in[w] | occ_shifted(in, w, strides[a], true) | occ_shifted(in, w, strides[a], false);
-        __syncthreads();
-        uint32_t *t = in; in = outb; outb = t;
+    uint32_t *bo = bitsOut + ((size_t)b * 2 + which) * kOccRings * kOccWords;
+    for (int ring = 0; ring < kOccRings; ++ring) {
+        for (int a = 0; a < 3; ++a) {
+            if (gnx > 0)
+                for (int w = tid; w < kOccWords; w += kOccBlock) outb[w] = in[w] | occ_shifted(in, w, strides[a], true) | occ_shifted(in, w, strides[a], false);
+            __syncthreads();
+            uint32_t *t = in; in = outb; outb = t;
+        }
+        for (int k = tid; k < kOccWords; k += kOccBlock) bo[ring * kOccWords + k] = gnx > 0 ? in[k] : 0u;
     }
-    uint32_t *bo = bitsOut + ((size_t)b * 2 + which) * kOccWords;
-    for (int k = tid; k < kOccWords; k += kOccBlock) bo[k] = gnx > 0 ? in[k] : 0u;
     if (tid < 8) hdrOut[((size_t)b * 2 + which) * 8 + tid] = hd[tid];
 }
 

@@ -1,6 +1,6 @@
 """Developer tool: what the occupancy pre-bound of the scoring sweeps sees (-DICPFLOW_OCC_STATS build of nn.hip):
   SWEEP_SRC=nn.hip bash tools/dbg/icp_define_build.sh ICPFLOW_OCC_STATS ; ICPFLOW_HIP_LIB=tools/dbg/sweep_1.so python tools/dbg/prebound_stats.py
-blocks that evaluated it, blocks it ended, share of queries in empty cells, histogram of (pre-bound / candidate 0's forward mean)."""
+scans that evaluated it (their block 0), scans it ended, mean ring level of their queries, histogram of (pre-bound / candidate 0's forward mean)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -20,4 +20,4 @@ for name, B, N, seed, ragged in (("config 2", 256, 1024, 0, False), ("config 4 s
     stats()
     utils_match.hist_icp(a, s, d)
     st = stats()
-    print(f"{name}: blocks with a pre-bound {st[0]}, ended by it {st[1]}; queries in empty cells {100.0 * st[2] / max(1, st[3]):.1f} %; pre-bound / bound in quarters (last: >= 1.75): {st[4:12]}", flush=True)
+    print(f"{name}: blocks with a pre-bound {st[0]}, ended by it {st[1]}; mean ring level of the queries {st[2] / max(1, st[3]):.2f} (of 3: no target within that many cells); pre-bound / bound in quarters (last: >= 1.75): {st[4:12]}", flush=True)
