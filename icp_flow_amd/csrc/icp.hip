@@ -63,6 +63,7 @@ __device__ int g_dbg_pair = 0;
 // queries that searched, targets scanned (per wave)
 __device__ unsigned long long g_cert_stats[128 * 4];
 __device__ unsigned long long g_probe_stats[128 * 2];   // probes, conclusive probes
+__device__ unsigned long long g_occ_cert[128 * 4];      // per iteration: queries without a certificate; of those, queries whose cell of the fixed cloud's grid is empty (plane 1: nothing within 0.98 h > gate); queries with certificate (B); outliers among ALL live queries by the grid
 __device__ int g_stats_block = -1;                       // >= 0: only this workgroup counts
 #endif
 
@@ -72,6 +73,10 @@ namespace icpflow {
 
 // ---------------------------------------------------------------------------------
 struct IcpParams {
+#ifdef ICPFLOW_CERT_STATS
+    const float *occHdr;   // (statistics only: the fixed cloud's occupancy grids of nn.hip, or NULL)
+    const uint32_t *occBits;
+#endif
     const float *X;        // [B,N,4] moving cloud
     const float *Y;        // [B,N,4] fixed cloud
     const int32_t *lenX;
@@ -1024,6 +1029,22 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                             }
                         }
                         recM[q] = m;
+#ifdef ICPFLOW_CERT_STATS
+                        if (recOn && it > itFirst && it < 128 && p.occBits != nullptr && (g_stats_block < 0 || g_stats_block == (int)blockIdx.x)) {
+                            const float *hdr = p.occHdr + ((size_t)b * 2 + 1) * 8;
+                            const uint32_t *bits = p.occBits + ((size_t)b * 2 + 1) * kOccRings * kOccWords;
+                            const int gnx = __float_as_int(hdr[5]), gny = __float_as_int(hdr[6]), gnz = __float_as_int(hdr[7]);
+                            bool empty = false;
+                            if (gnx > 0) {
+                                const float ux = floorf((qx[q] - hdr[0]) * hdr[3]), uy = floorf((qy[q] - hdr[1]) * hdr[3]), uz = floorf((qz[q] - hdr[2]) * hdr[3]);
+                                const bool inside = ux >= 0.f && ux < (float)gnx && uy >= 0.f && uy < (float)gny && uz >= 0.f && uz < (float)gnz;
+                                empty = !inside;
+                                if (inside) { const int c = ((int)ux * gny + (int)uy) * gnz + (int)uz; empty = ((bits[c >> 5] >> (c & 31)) & 1u) == 0u; }
+                            }
+                            if (m >= 0.f) { atomicAdd(&g_occ_cert[it * 4 + 0], 1ull); if (empty) atomicAdd(&g_occ_cert[it * 4 + 1], 1ull); }
+                            if (empty) atomicAdd(&g_occ_cert[it * 4 + 3], 1ull);
+                        }
+#endif
                     }
                 }
                 // Probes.  The few queries of a wave that hold no certificate are settled eight at a time, each by a row
@@ -2700,11 +2721,19 @@ extern "C" int icpflow_debug_cert_stats(unsigned long long *out512, int reset)
     int rc = (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_cert_stats), sizeof(unsigned long long) * 512);
     rc |= (int)hipMemcpyFromSymbol(out512 + 512, HIP_SYMBOL(g_probe_stats), sizeof(unsigned long long) * 256);
     if (reset) {
+        static unsigned long long zeros4[512];
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_occ_cert), zeros4, sizeof(zeros4));
         static unsigned long long zeros[512];
         rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cert_stats), zeros, sizeof(zeros));
         rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_stats), zeros, sizeof(unsigned long long) * 256);
     }
     return rc;
+}
+#endif
+#ifdef ICPFLOW_CERT_STATS
+extern "C" int icpflow_debug_occ_cert(unsigned long long *out512)
+{
+    return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_occ_cert), sizeof(unsigned long long) * 512);
 }
 #endif
 #ifdef ICPFLOW_PHASE_TIMING
@@ -2945,6 +2974,9 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
+#ifdef ICPFLOW_CERT_STATS
+        if (grid->occReady) { p.occHdr = grid->occHdr; p.occBits = grid->occBits; }
+#endif
         p.sortedRaw = 1;
         recWanted = opts.adaptiveWindows;
     } else if (grid != nullptr && grid->mode == 3) {
