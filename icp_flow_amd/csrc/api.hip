@@ -141,6 +141,7 @@ struct Workspace {
     // host-side note of THIS call: score_pick_kernel has left the forward totals of the picked candidates in scoreAccum[0 .. B)
     // (the scoring ran as sweeps over the sort the check sweep will use): the roll-back check scans under the final pose only
     bool initSumValid = false;
+    int *ticketScratch = nullptr;
     size_t accumBytes = 0;   // scoreAccum and, where the sweeps share jobs between blocks, grid.shareCount behind it: cleared together
     size_t bytes = 0;
     static bool shareScratch(int B, int N) { return N >= 2048 && (size_t)B * 12 * kSweepShareSlots * 256 * 4 <= ((size_t)64 << 20); }
@@ -170,8 +171,9 @@ struct Workspace {
             scoreAccum = (double *)take(b * 12 * 8);
             // (the sweeps' delivery counters right behind it: the clear at the start of a registration covers both -- accumBytes --,
             // and every sweep launch leaves its counters at zero again, so that none of them needs a memset of its own)
+            ticketScratch = (int *)take(256);   // (the count of the scoring's listed scans: grid.sweepTicket once a call has cleared it)
             if (shareScratch(B, N)) grid.shareCount = (int *)take(b * 12 * kSweepShareSlots * 4);
-            accumBytes = up(b * 12 * 8) + (shareScratch(B, N) ? up(b * 12 * kSweepShareSlots * 4) : 0);
+            accumBytes = up(b * 12 * 8) + up(256) + (shareScratch(B, N) ? up(b * 12 * kSweepShareSlots * 4) : 0);
         }
         Tinit = (float *)take(b * 16 * 4);
         M = (float *)take(b * 16 * 4);
@@ -201,6 +203,7 @@ struct Workspace {
             pairBox = (float *)take(b * kPairBoxStride * 4);
         }
         grid.axis = (int32_t *)take(b * 4);
+        grid.scoreList = (int *)take(b * 12 * 4);
         // (occupancy grids of both sorted clouds for the pre-bound of the scoring sweeps, nn.hip: 24 KiB per pair)
         if (N <= kMaxSortN) {
             grid.occHdr = (float *)take(b * 2 * 8 * 4);
@@ -1083,6 +1086,7 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
         fuse.zero1 = w.scoreAccum; fuse.bytes1 = w.accumBytes;
     }
     w.grid.shareCountClean = 1;   // (cleared with scoreAccum either way; the sweep launches of this call skip their memsets)
+    w.grid.sweepTicket = w.ticketScratch;   // (cleared with it as well: the pruned scoring's count of listed scans)
     const bool sweepScore = score_by_sweep(N, join != nullptr, o);
     if (int r = run_init_pose(d_src, d_dst, w, w.swap, B, N, d_edges_x, len_x, d_edges_y, len_y, d_edges_z,
                               len_z, decode_shift, w.Tinit, o, s, sweepScore ? join : nullptr,

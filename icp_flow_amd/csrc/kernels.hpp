@@ -222,6 +222,8 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     float *occHdr;
     uint32_t *occBits;
     int occReady;
+    int *sweepTicket;   // pruned scoring in two launches (nn.hip): the number of listed scans, cleared with the scoring scratch (api.hip), or NULL: one plain grid
+    int *scoreList;     //   [B * 10] the scans that go on behind the deciding launch
     int presorted;     // sortX / pts / sortYsoa / axis already hold both clouds sorted WITHOUT the pre-pose
                        // (scoring sweep ran on this batch): the ICP applies the pre-pose when it loads
 };

@@ -358,6 +358,11 @@ struct SweepParams {
     // its WHOLE sum from below by (queries in cells without a target in the 27-neighbourhood) x 0.98 h and leaves if that rules it out
     const float *occHdr;
     const uint32_t *occBits;
+    // The pruned scoring launch in two (launch_sweep_score_pruned): listMode 1 = the DECIDING launch, one block per scan (query block
+    // 0): prologue and occupancy pre-bound, then either the scan's records (+inf) or its number appended to `list`; listMode 2 = the
+    // launch of the LISTED scans: job lin = (query block lin / count, listed scan lin % count), drawn by sweep_list_kernel.
+    int listMode;
+    int *list, *listCount;
     int boundBoth;          // SWEEP_SCORE, prune == 1: candidate 0's BACKWARD scan is complete as well (the first launch ran both): the bound is its score, min(forward, backward)
 };
 
@@ -391,8 +396,10 @@ __device__ long long g_sweep_clk[4096 * 8];   // per (mode 1 job, block 0): wall
 #endif
 // SHARE: the instantiation whose blocks may share a window (one-wave blocks: over their four waves; one-block clouds against a long
 // one: over several blocks) -- batches of a few hundred pairs; batches that fill the GPU many times over keep the plain loop
-template <int MODE, bool SHARE = false>
-__global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
+// One block's job (the kernel's body since round 5's end: sweep_scan_kernel runs it for lin = blockIdx.x, sweep_list_kernel for the
+// jobs of the listed scans).  Every `return` below is taken by the whole block alike.
+template <int MODE, bool SHARE>
+__device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
 {
 #ifdef ICPFLOW_SWEEP_CLOCK
     const long long dbgW0 = wall_clock64(), dbgC0 = clock64();
@@ -401,13 +408,17 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
 #endif
     __shared__ double red[(kSweepBlock / kWave) * kPartial];
     extern __shared__ __attribute__((aligned(16))) float keyLds[];   // the targets' sort keys (window searches)
-    const int lin = blockIdx.x;
     int job = (lin / (8 * p.qblocks)) * 8 + (lin & 7);   // XCD-aware: the 8 XCDs take 8 jobs
     int qb = (lin >> 3) % p.qblocks;
     if (MODE == SWEEP_SCORE && p.prune) {   // query block major (see nn_scan_kernel): later blocks find earlier sums
         const int padded = (p.njobs + 7) & ~7;
         qb = lin / padded;
         job = lin % padded;
+        if (p.listMode == 2) {   // (the caller has checked lin < count * qblocks)
+            const int cnt = *p.listCount;
+            qb = lin / cnt;
+            job = p.list[lin % cnt];
+        }
     }
     if (MODE == SWEEP_CHECK && p.initSum != nullptr) {
         // Two halves, each dealt like the whole (eight pairs to the eight XCDs): the scans under the final pose first, then
@@ -422,6 +433,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         job = k * 2 + (lin < half ? 1 : 0);
     }
     if (job >= p.njobs) return;
+    const int listedAs = job;   // (the scan's number in this launch's own numbering: what the list holds)
     int b = (MODE == SWEEP_SCORE) ? job / p.subCount : job >> 1;
     const int sub = (MODE == SWEEP_SCORE) ? p.subBegin + job % p.subCount : (job & 1);
     // Nine workgroups in ten of a ragged batch are launched for rows their cloud does not have (the grid covers the padded
@@ -437,6 +449,8 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             const int bb = e >> 16;
             double *rec = p.partial + ((size_t)((MODE == SWEEP_SCORE) ? bb * 12 + sub : bb * 2 + sub) * p.qblocks + qb) * kPartial;
             if (threadIdx.x < kPartial) rec[threadIdx.x] = 0.0;
+            if (MODE == SWEEP_SCORE && p.listMode == 1)   // (deciding launch: all of the scan's records)
+                for (int k = kPartial + threadIdx.x; k < p.qblocks * kPartial; k += kSweepBlock) rec[k] = 0.0;
             return;
         }
     }
@@ -444,6 +458,12 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     // wherever the batch put them; records, counters and sums keep the pair's own place)
     if (p.pairOrder != nullptr) b = p.pairOrder[b];
     job = (MODE == SWEEP_SCORE) ? b * 12 + sub : b * 2 + sub;   // the scan's place in the partial records
+    if (MODE == SWEEP_SCORE && p.listMode == 1) {
+        // deciding launch: nobody else writes this scan's records unless it gets listed -- the later query blocks' first (zeros: a
+        // scan that ends here reports through block 0's record alone)
+        double *rec = p.partial + ((size_t)job * p.qblocks + 1) * kPartial;
+        for (int k = threadIdx.x; k < (p.qblocks - 1) * kPartial; k += kSweepBlock) rec[k] = 0.0;
+    }
     if (MODE == SWEEP_SCORE && p.prune == 1 && p.occBits != nullptr && qb > 0) {
         // a scan that its block 0 has ended by the occupancy pre-bound (below): +inf in its running sum -- one load and out
         const double seen = __hip_atomic_load(p.accum + job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
         // ONE block per scan does it -- query block 0, dispatched before the others (query-block-major grid) -- and, where the bound ends
         // the scan, leaves +inf in the scan's running sum: the prologue above then ends every later block of the scan at once.  (A block
         // that starts before block 0 has got that far simply scans as it always did.)
-        if (p.prune == 1 && p.occBits != nullptr && sub != 1 && qb == 0) {
+        if (p.prune == 1 && p.occBits != nullptr && sub != 1 && qb == 0 && p.listMode != 2) {
             __shared__ int occCount[kSweepBlock / kWave];
             __shared__ int occLeave;
             const float *t3 = p.cand + ((size_t)b * 6 + (sub >> 1)) * 3;
@@ -638,6 +658,10 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
             __syncthreads();
             if (occLeave) return;
         }
+    }
+    if (MODE == SWEEP_SCORE && p.listMode == 1) {   // deciding launch: the scan goes on -- in the launch of the listed scans
+        if (threadIdx.x == 0) p.list[atomicAdd(p.listCount, 1)] = listedAs;
+        return;
     }
     __shared__ float poseSh[16];
     if (MODE == SWEEP_CHECK) {   // the pose of this job: init (sub 0) or final (sub 1; composed here when fused)
@@ -891,6 +915,28 @@ __global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
     }
 }
 
+template <int MODE, bool SHARE = false>
+__global__ __launch_bounds__(kSweepBlock) void sweep_scan_kernel(SweepParams p)
+{
+    sweep_job<MODE, SHARE>(p, (int)blockIdx.x);
+}
+
+// The pruned scoring launch behind the occupancy pre-bound: 98 % of its (scan, query block) jobs ended at their first load, and a
+// workgroup launched only to leave still costs the dispatcher ~2 ns -- 82 000 of them on config 4's shard: the whole 168 us of that
+// launch.  (Drawing the jobs by tickets was worse: a global atomic per job, 4.6 ms per shard step.)  So the launch comes in two: a
+// DECIDING launch of one block per scan (listMode 1: prologue, pre-bound, +inf records or an entry in the list) and this one, whose
+// blocks walk the (query block, listed scan) jobs of the scans that go on -- a count the host never learns: the grid is a few
+// workgroups per CU, striding.
+template <int MODE, bool SHARE = false>
+__global__ __launch_bounds__(kSweepBlock) void sweep_list_kernel(SweepParams p)
+{
+    const int entries = *p.listCount * p.qblocks;
+    for (int e = (int)blockIdx.x; e < entries; e += (int)gridDim.x) {
+        sweep_job<MODE, SHARE>(p, e);
+        __syncthreads();   // (the job's LDS -- records, flags, staged keys -- is this block's again)
+    }
+}
+
 // pcd1 * T in pcd1's sorted order, as transform_points_batch forms it (utils_match.py:162), +inf padded
 __global__ void transform_soa_kernel(const float *__restrict__ soa, const int32_t *__restrict__ len,
                                      const float *__restrict__ pose, int NP16, float *__restrict__ out,
@@ -970,10 +1016,27 @@ static hipError_t launch_sweep(SweepParams p, hipStream_t s)
     const int groups = (MODE == SWEEP_CHECK && p.initSum != nullptr) ? 2 * ((p.njobs / 2 + 7) / 8) : (p.njobs + 7) / 8;
     const size_t lds = (size_t)(p.NP16 < kSweepStage ? p.NP16 : kSweepStage) * sizeof(float);
     // (njobs <= 12 * 700: the batches whose workspace holds the shared minima; larger ones fill the GPU with whole pairs)
+    const int total = groups * 8 * p.qblocks;
+    if (MODE == SWEEP_SCORE && p.listMode == 1) {   // the deciding launch: query block 0 of every scan
+        const int first = groups * 8;
+        if (p.shareWindows != 0 && p.N >= kSweepFullScanMinTargets && p.njobs <= 12 * 700)
+            hipLaunchKernelGGL((sweep_scan_kernel<MODE, true>), dim3((unsigned)first), dim3(kSweepBlock), lds, s, p);
+        else
+            hipLaunchKernelGGL((sweep_scan_kernel<MODE, false>), dim3((unsigned)first), dim3(kSweepBlock), lds, s, p);
+        return hipGetLastError();
+    }
+    if (MODE == SWEEP_SCORE && p.listMode == 2) {   // the listed scans: eight workgroups per CU at most, striding over what the list holds
+        const int wgs = total < 8 * 256 ? total : 8 * 256;
+        if (p.shareWindows != 0 && p.N >= kSweepFullScanMinTargets && p.njobs <= 12 * 700)
+            hipLaunchKernelGGL((sweep_list_kernel<MODE, true>), dim3((unsigned)wgs), dim3(kSweepBlock), lds, s, p);
+        else
+            hipLaunchKernelGGL((sweep_list_kernel<MODE, false>), dim3((unsigned)wgs), dim3(kSweepBlock), lds, s, p);
+        return hipGetLastError();
+    }
     if (p.shareWindows != 0 && p.N >= kSweepFullScanMinTargets && p.njobs <= 12 * 700)
-        hipLaunchKernelGGL((sweep_scan_kernel<MODE, true>), dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
+        hipLaunchKernelGGL((sweep_scan_kernel<MODE, true>), dim3((unsigned)total), dim3(kSweepBlock), lds, s, p);
     else
-        hipLaunchKernelGGL((sweep_scan_kernel<MODE, false>), dim3((unsigned)(groups * 8 * p.qblocks)), dim3(kSweepBlock), lds, s, p);
+        hipLaunchKernelGGL((sweep_scan_kernel<MODE, false>), dim3((unsigned)total), dim3(kSweepBlock), lds, s, p);
     return hipGetLastError();
 }
 
@@ -1128,6 +1191,20 @@ hipError_t launch_sweep_score_pruned(const GridScratch *grid, const int32_t *len
         hipError_t e2 = launch_sweep<SWEEP_SCORE>(p, s);
         if (e2 != hipSuccess) return e2;
         p.njobs = B * 10; p.subBegin = 2; p.subCount = 10; p.prune = 1; p.boundBoth = 1;
+        // In two launches (sweep_list_kernel) where the dead jobs' dispatch is what the launch lasts: batches several times the GPU
+        // (config 4's shard: 81 920 jobs, 168 -> 66 + 43 us).  Smaller batches keep the one launch -- there the scans that go on
+        // start at once instead of behind the last deciding block (ragged 600 x 1024: 0.818 against 0.825 ms per step).
+#ifndef ICPFLOW_SCORE_LIST_MIN_JOBS
+#define ICPFLOW_SCORE_LIST_MIN_JOBS 65536
+#endif
+        if (grid->sweepTicket != nullptr && grid->scoreList != nullptr &&   // (the call has cleared the counter)
+            (long long)B * 10 * sweep_qblocks(N) >= ICPFLOW_SCORE_LIST_MIN_JOBS) {
+            p.list = grid->scoreList; p.listCount = grid->sweepTicket;
+            p.listMode = 1;
+            const hipError_t e3 = launch_sweep<SWEEP_SCORE>(p, s);
+            if (e3 != hipSuccess) return e3;
+            p.listMode = 2;
+        }
         return launch_sweep<SWEEP_SCORE>(p, s);
     }
     p.njobs = B; p.subBegin = 0; p.subCount = 1; p.prune = 0;
