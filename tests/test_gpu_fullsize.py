@@ -422,6 +422,28 @@ def test_occupancy_prebound_never_changes_a_pick(offset, scale):
         assert int(it0) == int(it1) and torch.equal(T0, T1), opts
 
 
+@pytest.mark.parametrize("offset", [0.0, 6000.0])
+def test_pruned_scoring_in_two_launches_changes_nothing(offset):
+    """(header 0.2.12) From 65 536 (scan, query block) jobs on, the pruned scoring launch comes in two: a deciding launch of one block
+    per scan and sweep_list_kernel, whose eight workgroups per CU stride over the jobs of the scans that go on.  A ragged batch of
+    config 4's size: with the occupancy grids (a hundred-odd scans go on) and 6 km from the origin, where the build refuses the grids
+    and EVERY scan goes on -- ten thousand listed scans, forty jobs per workgroup of the second launch: the registrations are those
+    of the one plain launch (ICPFLOW_OPT_NO_SCORE_PREBOUND) and of every scan run to its end."""
+    B, N = 1024, 2048
+    S, D, _ = synthetic.make_batch(B, N, seed=91, ragged=True, n_min=30)
+    for A in (S, D):
+        v = A[:, :, 3] > 0
+        A[:, :, :3][v] = A[:, :, :3][v] + np.float32(offset)
+    a = rp.default_args(max_points=N, icp_max_iterations=20)
+    s, d = G(S), G(D)
+    T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    for opts in ({"no_score_prebound": True}, {"no_score_prune": True}):
+        with _lib.options(**opts):
+            T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+        assert int(it0) == int(it1) and torch.equal(T0, T1), opts
+    assert torch.equal(utils_match.hist_icp(a, s, d), T1)
+
+
 def _backward_winner_pair(N, seed):
     """src role: a 100-point patch P and a tight 300-point clump K three metres above it (out of the vote's z range of each other);
     dst role: ten jittered copies of P moved by t1 = (-0.3, 0.4, 0) and 20 points of K moved by t0 = (0.4, 0.4, 0).  The vote's
