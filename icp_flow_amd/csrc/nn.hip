@@ -368,6 +368,7 @@ struct SweepParams {
 
 #ifdef ICPFLOW_OCC_STATS
 __device__ unsigned long long g_occStats[12];   // tools/dbg/prebound_stats.py
+__device__ unsigned int g_occPair[1024];
 #endif
 constexpr int kSweepBlock = 256;
 #ifndef ICPFLOW_SWEEP_SHARE_MIN_TARGETS
@@ -645,6 +646,7 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
                 occLeave = low > boundSh * 1.0001f ? 1 : 0;   // NaN / inf bounds never prune
 #ifdef ICPFLOW_OCC_STATS
                 atomicAdd(&g_occStats[0], 1ull); if (occLeave) atomicAdd(&g_occStats[1], 1ull);
+                if (!occLeave && b < 1024) atomicAdd(&g_occPair[b], 1u);   // scans of the pair that go on (tools/dbg/order_predictor.py)
                 atomicAdd(&g_occStats[2], (unsigned long long)tot); atomicAdd(&g_occStats[3], (unsigned long long)nq);
                 const float ratio = low / boundSh;   // histogram of (pre-bound / bound) in steps of 0.25, [4 .. 11]
                 atomicAdd(&g_occStats[4 + min(7, max(0, (int)(ratio * 4.0f)))], 1ull);
@@ -1335,6 +1337,16 @@ hipError_t launch_scan_nn(const float *Qp, const float *Tp, int B, int NQ, int N
 }  // namespace icpflow
 
 #ifdef ICPFLOW_OCC_STATS
+extern "C" int icpflow_debug_occ_pairs(unsigned int *out1024, int reset)
+{
+    (void)hipDeviceSynchronize();
+    const int rc = (int)hipMemcpyFromSymbol(out1024, HIP_SYMBOL(icpflow::g_occPair), sizeof(icpflow::g_occPair));
+    if (reset) {
+        static unsigned int z[1024];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(icpflow::g_occPair), z, sizeof(z));
+    }
+    return rc;
+}
 extern "C" int icpflow_debug_occ_stats(unsigned long long *out12, int reset)
 {
     (void)hipDeviceSynchronize();
