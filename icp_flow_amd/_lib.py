@@ -104,7 +104,9 @@ OPT_FLAGS = {"no_sorted_vote": 1 << 0, "no_side_stream": 1 << 1, "no_eval_sweep"
              # (not a bit-identity switch: teams on at most half of the CUs, two team launches side by side; icpflow_hip.h)
              "teams_half_gpu": 1 << 11, "no_shared_scans": 1 << 12,
              # icpflow_track_frame: stage 2's initial poses behind stage 1 instead of beside its ICP (same results; see icpflow_hip.h)
-             "no_stage_overlap": 1 << 13, "no_vote_list": 1 << 14, "no_check_reuse": 1 << 15, "no_score_prebound": 1 << 16}
+             "no_stage_overlap": 1 << 13, "no_vote_list": 1 << 14, "no_check_reuse": 1 << 15, "no_score_prebound": 1 << 16,
+             # (opt-IN, bit-identical) ICP of a batch of a few rounds: the persistent grid drained for a second launch of whole-CU workgroups
+             "two_launch": 1 << 17}
 
 
 class Options(ctypes.Structure):

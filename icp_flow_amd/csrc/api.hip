@@ -76,6 +76,7 @@ struct Opts {
         o.helpers = on(ICPFLOW_OPT_NO_HELPERS);
         o.teamsHalfGpu = (flags & ICPFLOW_OPT_TEAMS_HALF_GPU) != 0u;
         o.sharedScans = on(ICPFLOW_OPT_NO_SHARED_SCANS);
+        o.twoLaunch = (flags & ICPFLOW_OPT_TWO_LAUNCH) != 0u;
         o.pairActive = pairActive;
         o.profile = profile;
         return o;
@@ -138,6 +139,7 @@ struct Workspace {
     float *voteKey = nullptr;   // per-pair sort-key parameters of the vote (votekey.hpp)
     int *zcidx = nullptr;
     IcpTeam team{};
+    int32_t *icpSplit = nullptr;   // [B + 64] the pair list (and its count) of the second of two ICP launches (icp.hip: icp_split_kernel)
     // host-side note of THIS call: score_pick_kernel has left the forward totals of the picked candidates in scoreAccum[0 .. B)
     // (the scoring ran as sweeps over the sort the check sweep will use): the roll-back check scans under the final pose only
     bool initSumValid = false;
@@ -222,6 +224,7 @@ struct Workspace {
         team.next = (int32_t *)take(b * 4);
         team.arrived = (unsigned int *)take(b * 4);
         team.mom = (double *)take((b < 256 ? b : 256) * 2 * (size_t)kMaxTeam * kTeamStride * 8);
+        icpSplit = (int32_t *)take((b + 64) * 4);
         bytes = off;
     }
 };
@@ -248,7 +251,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
     if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
-    if (opt->flags >> 17) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    if (opt->flags >> 18) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
     o.search = opt->icp_search;
     o.arith = opt->icp_arith;
     o.flags = opt->flags;
@@ -394,6 +397,7 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     bool historyPending = false;
     IcpOpts io = o.icp(w.grid.sortX);
     io.help = icp_help_carve(w.ctrl, B, w.helpState, w.helpOut);
+    io.splitScratch = w.icpSplit;
     io.teamPlanned = teamPlanned;
     if (sweepCheck && o.arith == ICPFLOW_ARITH_FP64) io.historyPending = &historyPending;
     const bool splittable = sweepCheck && o.arith == ICPFLOW_ARITH_FP64 && stopMode == ICPFLOW_STOP_REFERENCE && w.history != nullptr &&
@@ -956,6 +960,7 @@ int icpflow_icp(const float *d_X, const float *d_Y, const float *d_pre_pose, int
     hipStream_t s = (hipStream_t)stream;
     IcpOpts io = o.icp(w.grid.sortX);
     io.help = icp_help_carve(w.ctrl, B, w.helpState, w.helpOut);
+    io.splitScratch = w.icpSplit;
     io.initR = o.initR;
     io.initT = o.initT;
     io.allowReflection = o.allowReflection;

@@ -126,6 +126,15 @@ struct IcpParams {
     int shareScans;          // team kernel with the LDS image: the waves of a member share their long window scans (the launch left room for the accumulators)
     int teamLanes;           // host side only: 2 = this team launch takes at most half of the CUs (chained two deep)
     const uint8_t *pairActive;   // options.d_pair_active or NULL: pairs flagged 0 are not in the batch (speculative mode only)
+    // two launches (see icp_split_kernel): the FIRST (persistent grid with helpers) is drained once at most `drainAt` pairs are
+    // unfinished -- they leave at their next iteration, still moving --; the SECOND serves those pairs, pairList[0 .. pairMeta[0]),
+    // one 1024-thread workgroup per CU, each resumed from IcpState at ITS iteration; pairMeta[1]: every iteration below it is
+    // known to be complete and not to satisfy the batch rule
+    int drainAt;                 // 0: the launch is not drained
+    const int32_t *pairList;     // NULL: workgroup w serves pair w
+    const int32_t *pairMeta;
+    int twoLaunch;               // host side only: two launches wanted where they apply (launch_icp_variant)
+    int32_t *splitScratch;       // host side only: [B + 64] ints (the list, then count and floor)
 };
 
 
@@ -563,7 +572,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
         // taken over the other pairs -- this one reports "arrived, converged" for every iteration of the launch, like a pair
         // whose trajectory has become periodic does for its remaining iterations, and leaves.  Its outputs are unspecified.
         if (rank == 0 && wave == 0)
-            for (int k = itBegin + lane; k < itEnd; k += kWave)
+            for (int k = itBegin + lane; k < p.maxIter; k += kWave)   // (to the cap, whatever this launch's itEnd: the first of two launches)
                 __hip_atomic_fetch_add(&ctrl->tally[k], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0 && rank == 0) {
             IcpState *st0 = p.state + b;
@@ -571,11 +580,14 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             for (int k = 0; k < 9; ++k) st0->R[k] = (k % 4 == 0) ? 1.f : 0.f;
             st0->T[0] = st0->T[1] = st0->T[2] = 0.f;
             st0->rmse = 0.f; st0->s = 1.f; st0->active = 0; st0->iters = 0;
+            if constexpr (HELP) {
+                if (p.drainAt > 0) __hip_atomic_fetch_add(&ctrl->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         return;
     }
-    if (p.stopMode == ICPFLOW_STOP_REFERENCE_ && itBegin > 0) {
-        // previous iteration satisfied the batch-global rule (or an earlier one did)
+    if (p.stopMode == ICPFLOW_STOP_REFERENCE_ && itBegin > 0 && p.history == nullptr) {
+        // (one launch per iteration) previous iteration satisfied the batch-global rule (or an earlier one did)
         if (ctrl->done || ctrl->notconv[itBegin - 1] == 0) {
             if (tid == 0 && b == 0) ctrl->done = 1;
             return;
@@ -598,13 +610,20 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     // (the 1024-thread kernel has 128 VGPRs; spilled values came back one dependent scratch load
     // at a time in the serial tail of every iteration).
     int active = 1;
-    if (itBegin == 0) {
+    // RESUME: the instantiation that serves the SECOND of two speculative launches (icp_split_kernel) -- a pair resumed at its own
+    // iteration finds the states of the cycle detection and its own-convergence bits in its history rows.  (Only there: the code
+    // costs the other instantiations registers they do not have.)
+    constexpr bool RESUME = BLOCK == 1024 && GRID == 4 && !TEAM && !SCALE && !HELP && LATE && Q == 1;
+    const bool resumed = RESUME && itBegin > 0 && p.history != nullptr;
+    if (itBegin == 0 || (resumed && itBegin < kRing)) {
         // state 0: identity (:140) or the caller's init_transform (:118-138)
         float s0 = (tid < 9 && tid % 4 == 0) ? 1.f : 0.f;
         if (p.initR != nullptr && tid < 12) s0 = tid < 9 ? p.initR[(size_t)b * 9 + tid] : p.initT[(size_t)b * 3 + tid - 9];
-        if (tid < 12) bcast[tid] = s0;
         const float scale0 = p.initS != nullptr ? p.initS[b] : 1.f;
-        if (tid == 0) { bcast[12] = 1.f; bcast[13] = 0.f; bcast[14] = 0.f; bcast[15] = scale0; }
+        if (itBegin == 0) {
+            if (tid < 12) bcast[tid] = s0;
+            if (tid == 0) { bcast[12] = 1.f; bcast[13] = 0.f; bcast[14] = 0.f; bcast[15] = scale0; }
+        }
         if (tid < 16) ring[tid] = tid < 12 ? s0 : (tid == 14 ? scale0 : 0.f);
         if (tid < kWave) {   // and its hash (same formula as in the loop), every lane of wave 0 the same value
             int hash = 0;
@@ -613,11 +632,29 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             hash ^= state_hash_word(scale0, 12);
             if (tid == 13) ring[13] = __int_as_float(hash);
         }
-    } else {
+    }
+    if (itBegin > 0) {
         if (tid < 9) bcast[tid] = st->R[tid];
         if (tid < 3) bcast[9 + tid] = st->T[tid];
         active = st->active;
         if (tid == 0) { bcast[12] = active ? 1.f : 0.f; bcast[13] = st->rmse; bcast[14] = st->rmse; bcast[15] = st->s; }
+        if constexpr (RESUME) {
+            if (resumed && tid < kWave) {
+                // The remembered states of the cycle detection are the pair's last history rows (row n - 1 holds state n: R, T, rmse,
+                // scale, count; hash as in the loop), so a period is found at the very iteration ONE launch would have found it.
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int n = itBegin - (r * 4 + (lane >> 4)), w = lane & 15;   // state n, word w of its ring row
+                    const bool on = n >= 1;
+                    const float *h = p.history + ((size_t)(on ? n - 1 : 0) * p.B + b) * kHistStride;
+                    const float hv = h[w < 13 ? w : (w == 15 ? 14 : 13)];
+                    int hw = w < 12 ? state_hash_word(hv, w) : (w == 13 ? state_hash_word(hv, 12) : 0);
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) hw ^= __shfl_xor(hw, o, kWave);
+                    if (on) ring[(n % kRing) * 16 + w] = w == 13 ? __int_as_float(hw) : hv;
+                }
+            }
+        }
     }
     int itersDone = (itBegin == 0) ? 0 : st->iters;
     if (tid == 0) { probeCnt[0] = 0; probeCnt[1] = 0; probeNext[0] = 0; probeNext[1] = 0; }
@@ -689,6 +726,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
         }
     }
     int specChk = 0;  // speculative mode: first iteration not yet known to be complete-and-unconverged
+    if constexpr (RESUME) {
+        if (resumed) specChk = p.pairList != nullptr ? p.pairMeta[1] : itBegin;   // (a second launch: icp_split_kernel has looked below that)
+    }
     int winLo = -1, winHi = -1;   // sorted sweep: this wave's target window of the previous iteration
     int prevNN = -2;              // certificates, single pass: this lane's gated neighbour of the previous iteration
     int sweepAxis = 0;            // sorted sweep: the sort axis of this pair (read once: a load from L2 at the top of every
@@ -697,7 +737,28 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     // iterations at which this pair was converged: four 32-bit words in LDS, read and written by wave 0 only (as loop-carried
     // registers they were the first victims of every change to the loop: spilled, and reloaded in the serial tail)
     __shared__ unsigned int ownConvSh[4];
+    __shared__ int drainSh;      // this pair leaves the launch still moving (the launch is being drained, see the bookkeeping)
+    if (tid == 0) drainSh = 0;
     if (tid < 4) ownConvSh[tid] = 0u;
+    if constexpr (RESUME) {
+        if (resumed && tid < kWave) {
+            // (its own-convergence bits of the iterations it has behind it, from the rmse column of its history rows with the loop's test)
+            unsigned long long m[2] = {0ull, 0ull};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int q = r * kWave + lane;
+                bool conv = false;
+                if (q < itBegin && q < 128) {
+                    const float rm = p.history[((size_t)q * p.B + b) * kHistStride + 12];
+                    const float prev = q > 0 ? p.history[((size_t)(q - 1) * p.B + b) * kHistStride + 12] : 0.f;
+                    const float rel = q == 0 ? 1.0f : (prev - rm) / prev;
+                    conv = rel <= p.relThr;
+                }
+                m[r] = __ballot(conv);
+            }
+            if (tid < 4) ownConvSh[tid] = (unsigned int)(m[tid >> 1] >> (32 * (tid & 1)));
+        }
+    }
 #ifdef ICPFLOW_TAIL_CLOCK
     const long long tcWall0 = wall_clock64();
     long long tcTail = 0, tcSearch = 0, tcLoop0 = clock64();
@@ -753,6 +814,13 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 specTally = __hip_atomic_load(&ctrl->tally[specChk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 specLoaded = true;
             }
+        }
+        // a launch that is drained for a second one (p.drainAt, persistent grids with helpers): the pairs finished so far, fetched
+        // here like the tally and looked at with the bookkeeping
+        [[maybe_unused]] int finishedSeen = 0;
+        if constexpr (HELP) {
+            if (wave == 0 && p.drainAt > 0 && !helping)
+                finishedSeen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctrl->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
         // this iteration's (R, T) and the origin of the moments, from LDS (dead after the search phase)
         float Rf[9], Tf[3];
@@ -1800,6 +1868,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 int period = 0;
                 {
                     const int newest = it + 1;   // number of the new state
+                    // oldest state that may be compared with: everything since the launch's first state, or (a resumed pair, RESUME
+                    // above) the kRing states restored from the history
+                    const int ringOldest = (RESUME && p.history != nullptr && itBegin > 0) ? (itBegin < kRing ? 0 : itBegin - (kRing - 1)) : itBegin;
                     // four candidate periods per round: quarter q of the wave compares the new state
                     // (replicated into every quarter) with state newest - (k0 + q)
                     // cheap first: a 32-bit hash of the state (xor of its twelve words) against the hashes of
@@ -1811,7 +1882,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     for (int k = 0; k < 3; ++k) hash ^= state_hash_word(Tn[k], 9 + k);
                     hash ^= state_hash_word(sn, 12);
                     const int kk = lane + 1;   // lane l < kRing looks at state newest - (l + 1)
-                    const bool cand = lane < kRing && kk <= newest - itBegin &&
+                    const bool cand = lane < kRing && kk <= newest - ringOldest &&
                                       __float_as_int(ring[((newest - kk) % kRing) * 16 + 13]) == hash;
                     const bool anyCand = __ballot(cand) != 0ull;
                     float cur16 = 0.f;   // word (lane & 15) of the new state: only a hash hit needs it
@@ -1823,7 +1894,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     }
                     for (int k0 = 1; anyCand && k0 <= kRing && period == 0; k0 += 4) {
                         const int k = k0 + (lane >> 4);
-                        const bool valid = k <= kRing && k <= newest - itBegin;
+                        const bool valid = k <= kRing && k <= newest - ringOldest;
                         const float old = ring[(((newest - (valid ? k : 0)) % kRing + kRing) % kRing) * 16 + (lane & 15)];
                         const bool same = ((lane & 15) >= 12 && (lane & 15) != 14) || __float_as_int(old) == __float_as_int(cur16);
                         const unsigned long long m = __ballot(same);
@@ -1831,7 +1902,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         for (int q = 3; q >= 0; --q) {
                             const bool okq = ((m >> (16 * q)) & 0xffffull) == 0xffffull;
                             const int kq = k0 + q;
-                            if (okq && kq <= kRing && kq <= newest - itBegin) period = kq;   // smallest period wins
+                            if (okq && kq <= kRing && kq <= newest - ringOldest) period = kq;   // smallest period wins
                         }
                     }
                     if (lane == 0) {   // (the values are wave-uniform: one lane stores the row)
@@ -1844,12 +1915,13 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 }
                 if (period > 0 && active) {
                     if (rank == 0) {
-                        // remaining iterations k = it+1 .. itEnd-1, one per lane and round; row k repeats
+                        // remaining iterations k = it+1 .. cap-1, one per lane and round; row k repeats
                         // row j(k) = it - period + 1 + ((k - it - 1) mod period)  (a row is stored in the
                         // ring under the number of the state it produced, row + 1)
-                        for (int k0 = it + 1; k0 < itEnd; k0 += kWave) {
+                        // (to the iteration CAP, not to this launch's itEnd: a pair that turns periodic in the first of two launches is done)
+                        for (int k0 = it + 1; k0 < p.maxIter; k0 += kWave) {
                             const int k = k0 + lane;
-                            if (k < itEnd) {
+                            if (k < p.maxIter) {
                                 const int j = it - period + 1 + ((k - it - 1) % period);
                                 const int jp = (k - 1 == it) ? it : it - period + 1 + ((k - it - 2) % period);
                                 const float *rj = ring + ((j + 1) % kRing) * 16;
@@ -1877,13 +1949,21 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 // pair.  A constant (zero-inlier) pair has rel = NaN and is retired too.
                 if (it > 0 && ((conv && rel >= 0.0f) || rel != rel)) active = 0;
             }
+            // Draining (see icp_split_kernel): at most p.drainAt pairs of the batch are unfinished, a second launch with a whole CU
+            // per pair will serve them faster than this one -- the pair leaves behind this iteration, STILL MOVING (IcpState.active
+            // stays set, its rows and tallies up to here are in place), and its helpers are told that it is finished.
+            bool drain = false;
+            if constexpr (HELP) {
+                drain = p.drainAt > 0 && active && it > itFirst && it + 1 < itEnd && p.B - finishedSeen <= p.drainAt;
+                if (drain && lane == 0) drainSh = 1;
+            }
             if (kLateBook) {
                 if (lane == 0 && !active) bcast[12] = 0.f;   // seen by every wave behind the next search phase's barrier
             } else if (lane == 0) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) bcast[k] = Rn[k];
                 bcast[9] = Tn[0]; bcast[10] = Tn[1]; bcast[11] = Tn[2];
-                bcast[12] = active ? 1.f : 0.f;
+                bcast[12] = (active && !drain) ? 1.f : 0.f;
                 bcast[14] = rmse;  // :213 prev_rmse = rmse
                 bcast[15] = sn;
             }
@@ -1892,7 +1972,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     // progress for workgroups looking for a pair to help; with helpers signed up: the state of iteration
                     // it + 1 (double-buffered by parity, write-through, drained, THEN the epoch), and which of its passes
                     // the helpers that have announced themselves in time will deliver
-                    const bool goesOn = active && it + 1 < itEnd;
+                    const bool goesOn = active && !drain && it + 1 < itEnd;
                     int mask = 0;
                     const int nclaim = __builtin_amdgcn_readfirstlane(helpWord);
                     if (goesOn && nclaim > 0) {
@@ -2130,8 +2210,11 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
         for (int k = 0; k < 3; ++k) st->T[k] = bcast[9 + k];
         st->rmse = bcast[14];
         st->s = bcast[15];
-        st->active = active;
+        st->active = active | drainSh;
         st->iters = itersDone;
+        if constexpr (HELP) {   // (a drained launch counts the pairs that are through; a pair that leaves still moving is not)
+            if (p.drainAt > 0 && drainSh == 0) __hip_atomic_fetch_add(&ctrl->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (p.stopMode == ICPFLOW_STOP_REFERENCE_) {
             if (b == 0) ctrl->iters = itersDone;
         } else {
@@ -2173,7 +2256,16 @@ void icp_kernel(IcpParams p, int itBegin, int itEnd)
         // one workgroup per pair, at most one (1024 / 768 threads) per CU: the launch lasts as long as its slowest pair's chain
         // of iterations -- late bookkeeping.  512-thread workgroups share their CUs (two per CU: batches of two pairs per CU
         // and more), like the persistent grids below: one pair's bookkeeping already runs under another pair's search.
-        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, BLOCK != 512, false>(p, b, rank, G, itBegin, itEnd);
+        int itB = itBegin;
+        if constexpr (BLOCK == 1024 && GRID == 4 && !TEAM && !SCALE && Q == 1) {
+            // the second of two launches (icp_split_kernel): workgroup w serves pair pairList[w] from the iteration IT had reached
+            if (p.pairList != nullptr) {
+                if ((int)blockIdx.x >= p.pairMeta[0]) return;
+                b = __builtin_amdgcn_readfirstlane(p.pairList[blockIdx.x]);
+                itB = __builtin_amdgcn_readfirstlane(p.state[b].iters);
+            }
+        }
+        icp_pair<BLOCK, Q, TS, GRID, TEAM, SCALE, false, BLOCK != 512, false>(p, b, rank, G, itB, itEnd);
     } else {
         static_assert(!PERSIST || !TEAM, "teams are planned per launch");
         constexpr bool HELP = HELPK && GRID == 4 && !SCALE && Q == 1;
@@ -2552,6 +2644,58 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
     }
 }
 
+// Two launches for batches of a few rounds (round 6).  A persistent grid deals its pairs in index order, and which pairs
+// are the long ones is not known beforehand (tools/dbg/order_predictor.py): config 4's shard (1024 pairs x 2048 points, two
+// 512-thread workgroups per CU) keeps its 512 slots full for the first half of the launch and spends the second half on a
+// thinning set of long pairs, each on HALF a CU (tools/dbg/help_timeline.py: 498 owners at 50 % of the span, 227 at 70 %, 55 at
+// 85 %; 30-40 us per iteration while the CU is shared, ~20 us with helpers once it is not).  So the launch is DRAINED as soon as
+// at most `drainAt` (the number of CUs) pairs are unfinished: every pair still iterating leaves behind its current iteration,
+// still moving (IcpState: state, rmse, iterations; its history rows and tallies are in place).  This kernel, between the two
+// launches, looks for the batch rule among the tallies (found: nobody goes on), finds the first iteration some pair has not
+// reached yet (the floor of the second launch's search for the rule) and lists the pairs that left still moving; the SECOND launch
+// gives each of them a whole CU -- one 1024-thread workgroup, two passes instead of four -- and resumes it at ITS iteration.
+// What makes that bit-identical (ICPFLOW_OPT_TWO_LAUNCH against the default; tests/test_gpu_fullsize.py): the first launch keeps its moment sums
+// per (pass, wave) and adds them in that order (redPasses, the helpers' bookkeeping) -- i.e. in the order of the UNITS of 64
+// consecutive sorted queries, which is the same order whether 8 waves take 4 passes or 16 waves take 2; everything else of an
+// iteration is a function of (R, T).  The neighbour certificates are rebuilt in a pair's first iteration of the second launch,
+// the cycle detection and the own-convergence bits are restored from the pair's history rows (icp_pair).
+#ifndef ICPFLOW_DRAIN_AT
+#define ICPFLOW_DRAIN_AT 0   // 0: the number of CUs
+#endif
+__global__ __launch_bounds__(1024) void icp_split_kernel(const IcpCtrl *__restrict__ ctrl, const IcpState *__restrict__ st, int B, int maxIter,
+                                                         int32_t *__restrict__ list, int32_t *__restrict__ meta)
+{
+    __shared__ int foundSh, floorSh, waveCnt[16];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    if (tid == 0) { foundSh = 0; floorSh = maxIter; }
+    __syncthreads();
+    for (int s0 = tid; s0 < maxIter; s0 += 1024) {
+        const unsigned long long t = ctrl->tally[s0];
+        if ((int)(t & 0xffffffffull) >= B) { if ((t >> 32) == 0ull) foundSh = 1; }
+        else atomicMin(&floorSh, s0);
+    }
+    __syncthreads();
+    if (foundSh) {   // the batch rule holds at an iteration every pair has reached: nobody goes on
+        if (tid == 0) { meta[0] = 0; meta[1] = 0; }
+        return;
+    }
+    int total = 0;   // (workgroup-uniform)
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int b = b0 + tid;
+        const bool on = b < B && st[b].active != 0 && st[b].iters < maxIter;
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) waveCnt[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = waveCnt[w]; before += w < wave ? c : 0; all += c; }
+        if (on) list[total + before + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = b;
+        total += all;
+        __syncthreads();
+    }
+    if (tid == 0) { meta[0] = total; meta[1] = floorSh; }
+}
+
 template <int BLOCK, int Q, int TS, int GRID, bool TEAM = false, bool SCALE = false>
 static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd, hipStream_t s)
 {
@@ -2610,6 +2754,34 @@ static void launch_icp_variant(const IcpParams &p, int B, int itBegin, int itEnd
                 const size_t dyn = dynBytes(passes);
                 q.persistent = 1;
                 q.helpOn = (p.helpOn && p.help.pair != nullptr) ? 1 : 0;
+                if constexpr (BLOCK == 512) {
+                    // Two launches (icp_split_kernel): the grid of half-CU workgroups is drained once the unfinished pairs fit one
+                    // whole CU each; the second launch is the 1024-thread kernel of batches that fit the GPU, its sums per (pass, wave)
+                    // too.  Speculative single launch only (the pairs resume from their history rows).
+                    const int cus = device_cus();
+                    const int drainAt = ICPFLOW_DRAIN_AT > 0 ? min(ICPFLOW_DRAIN_AT, cus) : cus;
+                    if (p.twoLaunch && q.history != nullptr && q.splitScratch != nullptr && itBegin == 0 && itEnd == q.maxIter && itEnd > 2 &&
+                        q.stopMode == ICPFLOW_STOP_REFERENCE_ && q.helpOn && B > drainAt) {
+                        constexpr auto kern2 = &icp_kernel<1024, 1, 1, 4, false, false>;
+                        q.drainAt = drainAt;
+                        hipLaunchKernelGGL(kernH, dim3((int)capH), dim3(BLOCK), dyn, s, q, itBegin, itEnd);
+                        hipLaunchKernelGGL(icp_split_kernel, dim3(1), dim3(1024), 0, s, q.ctrl, q.state, B, q.maxIter, q.splitScratch, q.splitScratch + B);
+                        IcpParams q2 = q;
+                        q2.persistent = 0; q2.helpOn = 0; q2.drainAt = 0; q2.halfCu = 0;
+                        q2.pairList = q.splitScratch;
+                        q2.pairMeta = q.splitScratch + B;
+                        q2.redPasses = (p.N + 1023) / 1024;
+                        const size_t red2 = (size_t)q2.redPasses * 16 * kMoments * sizeof(double), img = (size_t)((p.N + kChunk - 1) / kChunk * kChunk) * 12;
+                        q2.x0Cache = (p.recCap > 0 && red2 + img + (size_t)p.recCap * 32 <= (size_t)152 * 1024) ? 1 : 0;
+                        const size_t dyn2 = red2 + img + (size_t)p.recCap * (q2.x0Cache ? 32 : 20);
+                        if (dyn2 > 48 * 1024) {
+                            static std::atomic<unsigned long long> raised2{0ull};
+                            ensure_dynamic_lds(reinterpret_cast<const void *>(kern2), 156 * 1024, &raised2);
+                        }
+                        hipLaunchKernelGGL(kern2, dim3(drainAt), dim3(1024), dyn2, s, q2, 0, itEnd);
+                        return;
+                    }
+                }
                 hipLaunchKernelGGL(kernH, dim3((int)capH), dim3(BLOCK), dyn, s, q, itBegin, itEnd);
                 return;
             }
@@ -3062,6 +3234,8 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
             p.history = history;
             p.pairActive = opts.pairActive;   // (api.hip has refused the mask wherever this branch is not taken)
             p.persistent = opts.persistent ? 1 : 0;   // (one launch for all iterations: the ticket counter starts at zero)
+            p.twoLaunch = (opts.twoLaunch && opts.splitScratch != nullptr) ? 1 : 0;   // (where it applies: launch_icp_variant)
+            p.splitScratch = opts.splitScratch;
             p.help = opts.help;
             p.helpOn = (opts.helpers && maxIter <= kHelpMaxEpoch - 2) ? 1 : 0;   // (always: maxIter <= kHistIters here)
             launch_icp_iters(p, B, 0, maxIter, opts.profile, s);

@@ -33,6 +33,8 @@ struct IcpCtrl {
     int iters;
     int error;     // a team member waited too long for its peers (results are poisoned with NaN)
     int ticket;    // persistent launches: pairs handed out beyond the first gridDim.x (icp_kernel)
+    int finished;  // a launch that is drained for a second one (icp_split_kernel): pairs that are through
+    int pad[3];
     int notconv[kMaxIterCap];
     // speculative single-launch mode: per iteration, pairs arrived (low 32 bits) and pairs not
     // converged (high 32 bits), updated by ONE 64-bit atomic per pair so both are read consistently
@@ -252,6 +254,8 @@ struct IcpOpts {
     const uint8_t *pairActive = nullptr;   // options.d_pair_active: pairs flagged 0 are not in the batch (speculative reference stop only)
     bool teamsHalfGpu = false;     // ICPFLOW_OPT_TEAMS_HALF_GPU: a team launch takes at most half of the CUs (two may run side by side)
     bool sharedScans = true;       // teams: the waves of a member share their long window scans (ICPFLOW_OPT_NO_SHARED_SCANS)
+    bool twoLaunch = false;        // persistent grids with helpers: drained for a second launch of whole-CU workgroups (ICPFLOW_OPT_TWO_LAUNCH)
+    int32_t *splitScratch = nullptr;   // [B + 64] ints: the second launch's pair list, its count and the floor of its rule search (NULL: one launch)
 };
 bool icp_teams_wanted(const IcpTeam *team, const IcpOpts &opts, const GridScratch *grid, int B, int N, int maxIter,
                       int stopMode, const float *history);

@@ -311,6 +311,67 @@ def test_ticket_dispatch_changes_nothing(shape):
         assert torch.equal(utils_match.hist_icp(a, s, d), utils_match.hist_icp(rp.default_args(max_points=S.shape[1], icp_max_iterations=50), s, d))
 
 
+@pytest.mark.parametrize("shape", ["config4_shard_1024x2048", "ragged_900x2048", "dense_600x2048", "dense_1500x1500", "ragged_2000x1300", "cap_8_1024x2048",
+                                   "masked_1024x1100"])
+def test_two_icp_launches_change_nothing(shape):
+    """Batches of a few rounds under the reference's batch-global stop (utils_icp_pytorch3d.py:153-213): the persistent grid of
+    half-CU workgroups is DRAINED once the unfinished pairs fit one CU each -- they leave behind their current iteration, still
+    moving -- and a second launch (icp.hip icp_split_kernel: the batch rule among the tallies, the list of those pairs) gives each
+    a 1024-thread workgroup and resumes it at its own iteration from IcpState and its history rows.  Which iteration a pair is cut
+    at depends on timing; nothing else does: the moment sums are added in the order of the 64-query units in either kernel, so
+    transforms and iteration count are bit-identical to ONE launch (the default; ICPFLOW_OPT_TWO_LAUNCH switches the two launches on -- it is off because it does not pay), with and without helpers, and
+    from run to run."""
+    cap, mask = 50, None
+    if shape == "config4_shard_1024x2048":
+        S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
+    elif shape == "ragged_900x2048":                          # (the batch rule holds before the cap: 45 iterations)
+        S, D, _ = synthetic.make_batch(900, 2048, seed=23, ragged=True, n_min=100)
+    elif shape == "dense_600x2048":
+        S, D, _ = synthetic.make_batch(600, 2048, seed=31)
+    elif shape == "dense_1500x1500":
+        S, D, _ = synthetic.make_batch(1500, 1500, seed=19)
+    elif shape == "ragged_2000x1300":
+        S, D, _ = synthetic.make_batch(2000, 1300, seed=13, ragged=True, n_min=30)
+    elif shape == "cap_8_1024x2048":                          # a cap so low that pairs are cut in their first iterations
+        S, D, _ = synthetic.make_batch(1024, 2048, seed=41)
+        cap = 8
+    else:                                                     # options.d_pair_active: a third of the pairs are not in the batch
+        S, D, _ = synthetic.make_batch(1024, 1100, seed=37)
+        mask = (np.arange(1024) % 3 != 1).astype(np.uint8)
+        S[mask == 0] = np.array([1e8, 1e8, 1e8, 0], np.float32)
+        D[mask == 0] = np.array([1e8, 1e8, 1e8, 0], np.float32)
+    s, d = G(S), G(D)
+    a = rp.default_args(max_points=S.shape[1], icp_max_iterations=cap)
+    kw = dict(pair_active=G(mask)) if mask is not None else {}
+    with _lib.options(**kw):                               # (the default: one launch)
+        T0, it0 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    kw["two_launch"] = True
+    with _lib.options(**kw):
+        T1, it1 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    keep = slice(None) if mask is None else torch.from_numpy(mask.astype(bool)).to(DEV)
+    assert int(it0) == int(it1) and int(it1) > 0, (int(it0), int(it1))
+    assert torch.equal(T0[keep], T1[keep])
+    with _lib.options(no_helpers=True, **kw):             # (no helpers: one launch, the sums per (pass, wave) all the same)
+        T2, it2 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    assert int(it2) == int(it1) and torch.equal(T2[keep], T1[keep])
+    with _lib.options(no_persistent=True, **kw):
+        T3, it3 = utils_match.hist_icp(a, s, d, return_iterations=True)
+    assert int(it3) == int(it1) and torch.equal(T3[keep], T1[keep])
+    for _ in range(4):
+        with _lib.options(**kw):
+            assert torch.equal(utils_match.hist_icp(a, s, d)[keep], T1[keep])
+    # the ICP on its own (icpflow_icp) with its per-iteration records (t_history, :187): every iteration up to the stop, bit for bit
+    if mask is None and shape in ("config4_shard_1024x2048", "ragged_900x2048"):
+        from icp_flow_amd import utils_icp_pytorch3d as p3d
+        one = p3d.iterative_closest_point(s, d, max_iterations=cap)
+        with _lib.options(two_launch=True):
+            two = p3d.iterative_closest_point(s, d, max_iterations=cap)
+        assert torch.equal(one.RTs.R, two.RTs.R) and torch.equal(one.RTs.T, two.RTs.T) and torch.equal(one.rmse, two.rmse)
+        assert len(one.t_history) == len(two.t_history) > 0
+        for h1, h2 in zip(one.t_history, two.t_history):
+            assert torch.equal(h1.R, h2.R) and torch.equal(h1.T, h2.T)
+
+
 def test_per_pair_stop_with_a_long_iteration_cap_keeps_the_helper_protocol_sound():
     """the helper hand-off words carry the iteration epoch in 8 bits; ICPFLOW_STOP_PER_PAIR runs ONE persistent
     launch of up to 1024 iterations, so a cap beyond 253 must not be served with helpers (launch_icp switches them off:
