@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--time-every", type=int, default=5, help="HIP events around the ICP launch in every n-th step of the timed region (1 = every step)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements")
     ap.add_argument("--force-collective", action="store_true", help="one rank: init RCCL and all_gather anyway")
+    ap.add_argument("--no-n1", action="store_true", help="N > 1: skip the single-GPU run of the same workload on rank 0 (n1_same_workload)")
     ap.add_argument("--check-gather", action="store_true", help="compare the gathered rows with the local ones")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="no GPU work: the ranks run the launcher, the rendezvous, the sharding and the one all_gather of "
@@ -132,7 +133,10 @@ def launch_selftest(a, rank, world):
                           "data": "made-up rows (no GPU work)",
                           "config": {"pairs_total": total, "pairs_per_gpu": counts},
                           "gather_check": {"rows": list(got.shape), "identical_to_all_ranks_rows": ok,
-                                           "backend": dist.get_backend(), "rccl_library": None}}))
+                                           "backend": dist.get_backend(), "rccl_library": None},
+                          # (the fields every N > 1 line carries: main() fills them from a run of the same step on rank 0's GPU alone)
+                          "n1_same_workload": {"value": None, "unit": "registrations/s", "pairs": total, "what": "no GPU work in the launch selftest"},
+                          "scaling_efficiency": None}))
     dist.destroy_process_group()
     if not ok:
         raise SystemExit("launch selftest: the gathered rows differ from the rows the ranks contributed")
@@ -239,6 +243,29 @@ def stream_main(a, rank, world, local):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     n_total, matched_total = int(tot[0].item()), int(tot[1].item())
+    # the N = 1 point of this line: rank 0 runs the WHOLE stream alone (same in-flight depth, no collective), two passes after a warm-up
+    n1 = None
+    if world > 1 and rank == 0 and not a.no_n1:
+        try:
+            if selftest:
+                t1 = time.perf_counter(); k1 = sum(1 for _ in items); d1 = max(time.perf_counter() - t1, 1e-9); reps = 1
+            else:
+                everything = [fp for it in items for fp in ([it] if isinstance(it, frame_pairs.FramePair) else frame_pairs.load_any(it, args))]
+                for fp in everything:
+                    if id(fp) not in seen:
+                        seen[id(fp)] = frame_pairs.make_resident(fp, dev)
+                run_all = lambda: sum(1 for _ in frame_pairs.register_in_flight(args, everything, dev, a.in_flight))   # noqa: E731
+                run_all(); torch.cuda.synchronize(dev)
+                reps = 2
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    k1 = run_all()
+                torch.cuda.synchronize(dev)
+                d1 = time.perf_counter() - t1
+            n1 = {"value": round(d1 * 1e3 / max(k1 * reps, 1), 4), "unit": "ms/frame-pair", "frame_pairs": k1, "passes": reps,
+                  "what": "the whole stream on rank 0's GPU alone, after the timed region; scaling_efficiency = n1 / (n_gpus * value)"}
+        except Exception as e:
+            n1 = {"error": repr(e)}
     # accuracy, untimed: the stream through run_stream (EPE & co. against the frames' ground truth, its one all_reduce of the sums)
     summary = frame_pairs.run_stream(args, items, dev, rank, world, register_fn=stand_in if selftest else None,
                                      in_flight=1 if selftest else a.in_flight)
@@ -262,6 +289,9 @@ def stream_main(a, rank, world, local):
                "library_build": None if selftest else _lib.BUILD_INFO}
         if selftest:
             out["launch_selftest"] = True
+        if world > 1:
+            out["n1_same_workload"] = n1
+            out["scaling_efficiency"] = (round(n1["value"] / (world * out["value"]), 4) if n1 and n1.get("value") and out["value"] else None)
         print(json.dumps(out))
     if collective:
         dist.destroy_process_group()
@@ -383,6 +413,16 @@ def main():
         return
 
     value = total * a.steps / dt
+    # The N = 1 point of THIS line's curve: with more than one rank, rank 0 times the SAME step -- hist_icp +
+    # match_eval over all `total` pairs as one batch on one GPU, less the all_gather -- after the timed region, with the same
+    # protocol (the other ranks have left; nothing here is part of `value`).  A driver that divides this line's value by the
+    # `--gpus 1` line's would divide config 4 by config 2: `scaling_efficiency` is the figure that means something.
+    n1 = None
+    if collective and workload == "config4" and not a.no_n1:   # (--force-collective: a world of one exercises it too)
+        try:
+            n1 = same_workload_on_one_gpu(args, total, N, dev, a, utils_match, synthetic)
+        except Exception as e:               # the line must survive (e.g. 8192 x 2048 pairs not fitting beside the shard)
+            n1 = {"error": repr(e)}
     roofline = roofline_block(B, N, a.steps, iters_done, icp_ms, icp_launches, dt, _lib.BUILD_INFO, steps_timed)
 
     extras = {}
@@ -407,7 +447,12 @@ def main():
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{name}, <= {a.iters} ICP iters ({a.stop_mode} stop), thres_dist 0.1, "
-                               f"translation_frame 2.0 (41x41x3 bins)",
+                               f"translation_frame 2.0 (41x41x3 bins)" +
+                               ("; NOTE: `--gpus 1` runs config 2 (the headline) and is NOT the N = 1 point of the config-4 curve that "
+                                "`--gpus N > 1` runs -- that point is `config4_on_one_gpu` here and `n1_same_workload` on every N > 1 line"
+                                if workload == "config2" and world == 1 and a.workload == "auto" else
+                                "; strong scaling of ONE workload: its single-GPU point is this line's `n1_same_workload` (not the `--gpus 1` "
+                                "line, which is config 2)" if workload == "config4" and world > 1 else ""),
                    "pairs_total": total, "pairs_per_gpu": counts, "points": N, "icp_iteration_cap": a.iters,
                    "stop_mode": a.stop_mode,
                    "sharding": (f"contiguous blocks of pairs over {world} rank(s); every step = hist_icp + match_eval + ONE "
@@ -425,9 +470,30 @@ def main():
             out["config4_on_one_gpu"] = {"error": repr(e)}
     if gather_check is not None:
         out["gather_check"] = gather_check
+    if collective and workload == "config4":
+        out["n1_same_workload"] = n1
+        out["scaling_efficiency"] = (round(value / (world * n1["value"]), 4) if n1 and n1.get("value") else None)
     print(json.dumps(out))
     if collective:
         dist.destroy_process_group()
+
+
+def same_workload_on_one_gpu(args, total, N, dev, a, utils_match, synthetic, steps=5):
+    """The config-4 step of `--gpus N` on ONE GPU: all `total` pairs as one batch through hist_icp_eval (registration + the
+    40-byte pair rows; no all_gather: one rank has nobody to gather from), `steps` steps after one warm-up, synchronised on both
+    sides.  -> {value (registrations/s), ms_per_step, steps, pairs, what}"""
+    S, D, _ = synthetic.make_batch(total, N, seed=0)
+    s, d = torch.from_numpy(S).to(dev), torch.from_numpy(D).to(dev)
+    utils_match.hist_icp_eval(args, s, d, return_iterations=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        utils_match.hist_icp_eval(args, s, d, return_iterations=True)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"value": round(total * steps / dt, 2), "unit": "registrations/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "pairs": total, "what": "the same step (hist_icp + match_eval over all pairs, one batch) on rank 0's GPU alone, after the "
+                                    "timed region; scaling_efficiency = value / (n_gpus * n1_same_workload.value)"}
 
 
 def roofline_block(B, N, steps, iters_done, icp_ms, icp_launches, dt, build, steps_timed=None):

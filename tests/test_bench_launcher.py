@@ -28,6 +28,8 @@ def test_self_launch_two_gloo_ranks_print_one_json_line():
     assert out["n_gpus"] == 2 and out["steps"] == 2
     assert out["config"]["pairs_per_gpu"] == [51, 50] and out["config"]["pairs_total"] == 101
     assert out["gather_check"] == {"rows": [101, 26], "identical_to_all_ranks_rows": True, "backend": "gloo", "rccl_library": None}
+    # every N > 1 line names its own single-GPU point (the same workload on one GPU) and the efficiency against it
+    assert "n1_same_workload" in out and out["n1_same_workload"]["pairs"] == 101 and "scaling_efficiency" in out
 
 
 def test_self_launch_refuses_when_devices_are_missing():
@@ -54,6 +56,7 @@ def test_stream_workload_eight_gloo_ranks_uneven_shares():
     assert out["config"]["frame_pairs_per_gpu"] == [2, 2, 2, 2, 2, 1, 1, 1] and out["config"]["frame_pairs_total"] == 13
     assert out["reduce_check"] == {"frame_pairs_counted_by_all_ranks": 13, "equals_sum_of_shares": True, "backend": "gloo", "rccl_library": None}
     assert out["accuracy"]["frame_pairs"] == 13 and out["accuracy"]["epe"] == 0.0
+    assert out["n1_same_workload"]["frame_pairs"] == 13 and out["n1_same_workload"]["unit"] == "ms/frame-pair" and out["scaling_efficiency"] is not None
 
 
 def test_stream_workload_refuses_when_devices_are_missing():
