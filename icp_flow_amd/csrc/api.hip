@@ -405,6 +405,10 @@ int run_icp_and_select(const float *src, const float *dst, Workspace &w, const u
     if (part == 1) {
         *pending = 0;
         if (!splittable) return 0;
+        // Where the launch takes TEAMS the plan -- the order of a team's sums -- follows the pairs that are in the batch
+        // (icp_team_plan_kernel counts a masked pair as empty), and the mask is not known yet: the ICP waits for part 2,
+        // whose masked launch plans exactly as the serial path's does (the two modes could differ in rounding).
+        if (icp_teams_wanted(&w.team, io, search, B, N, maxIter, stopMode, w.history)) return 0;
         io.pairActive = nullptr;
     }
     if (part == 2 && pending != nullptr && *pending != 0) {
@@ -1072,7 +1076,8 @@ static int hist_icp_core(const float *d_src, const float *d_dst, int B, int N, c
         }
         // the ICP's team plan reads the lengths and roles only: where count_pair has written them before the fork it runs
         // here, beside the vote, instead of in front of the ICP launch (22-31 us of a serial chain)
-        if (se == hipSuccess && !countInSort &&
+        // (not in a first half, phase 1: the plan follows the pair mask, which the second half brings)
+        if (se == hipSuccess && !countInSort && phase != 1 &&
             icp_teams_wanted(&w.team, o.icp(w.grid.sortX), search, B, N, max_iterations, stop_mode, w.history)) {
             launch_icp_team_plan(&w.team, w.lenA, w.lenC, w.swap, B, N, o.icp(w.grid.sortX), side->stream);
             teamPlanned = true;

@@ -144,16 +144,31 @@ struct MtStream {
     Mt19937 tail;                   // the generator at the last block generated
     int idx0;                       // position inside block 0 at which the stream starts (624: block 0 is used up)
     int64_t pos = 0;                // draws consumed
+    int64_t firstWord = 0;          // words of the stream (block 0 = words 0 .. 623) in front of blocks[0]: blocks behind the position are let go
     MtStream(const Mt19937 &g, std::vector<uint32_t> &buffer) : blocks(buffer), tail(g), idx0(g.idx)
     {
         blocks.clear();
         if (blocks.capacity() < ((size_t)1 << 18) + 3 * 624) blocks.reserve(((size_t)1 << 18) + 3 * 624);
         blocks.insert(blocks.end(), g.s, g.s + 624);
     }
-    int64_t covered() const { return (int64_t)(blocks.size() / 624) * 624 - idx0; }   // draws the blocks hold
-    void ensure(int64_t draws)      // blocks for the first `draws` draws of the stream
+    int64_t covered() const { return firstWord + (int64_t)(blocks.size() / 624) * 624 - idx0; }   // draws the blocks reach
+    void ensure(int64_t draws)      // blocks for the draws pos .. `draws` - 1 of the stream (and the one state() reads)
     {
-        while (covered() < draws) {
+        //  Draws are consumed in order, and randperm_head passes over most of a long permutation's draws unread (n - 1
+        // per draw of a 60 000-point cluster): the blocks that end in front of the position are never read again.  They are
+        // dropped -- and those not generated yet are passed over without being stored --, so the buffer holds what lies between the
+        // position and the furthest draw asked for (plus the block in front of the position's, which state() may hand back),
+        // not every block of the frame pair.
+        const int64_t keep = std::max<int64_t>(((idx0 + pos) / 624 - 1) * 624, 0);   // first word that may still be read
+        if (keep >= firstWord + (int64_t)blocks.size()) {             // everything held is behind the position
+            firstWord += (int64_t)blocks.size();
+            blocks.clear();
+            while (firstWord + 624 <= keep) { tail.twist(); firstWord += 624; }   // (generated, not stored)
+        } else if (keep - firstWord >= 64 * 624) {                    // a long dead prefix: let it go
+            blocks.erase(blocks.begin(), blocks.begin() + (size_t)(keep - firstWord));
+            firstWord = keep;
+        }
+        while (covered() < draws || blocks.empty()) {
             tail.twist();
             blocks.insert(blocks.end(), tail.s, tail.s + 624);
         }
@@ -166,7 +181,7 @@ struct MtStream {
         y ^= y >> 18;
         return y;
     }
-    uint32_t draw(int64_t p) const { return temper(blocks[(size_t)(idx0 + p)]); }   // (p < covered())
+    uint32_t draw(int64_t p) const { return temper(blocks[(size_t)(idx0 + p - firstWord)]); }   // (pos <= p < covered(), after ensure)
     // the generator after `pos` draws, in the form the draw-by-draw engine leaves it (a block used up stays, with idx = 624)
     Mt19937 state() const
     {
@@ -175,7 +190,7 @@ struct MtStream {
         int i = (int)(q % 624);
         if (i == 0 && b > 0) { --b; i = 624; }
         Mt19937 g(0u);
-        std::memcpy(g.s, blocks.data() + (size_t)b * 624, sizeof(g.s));
+        std::memcpy(g.s, blocks.data() + (size_t)(b * 624 - firstWord), sizeof(g.s));
         g.idx = i;
         return g;
     }
@@ -238,7 +253,7 @@ void randperm_head(MtStream &g, int64_t n, int take, int32_t *out, std::vector<i
         static thread_local std::vector<uint32_t> zs;
         const int64_t vec = steps / 8 * 8;
         if ((int64_t)zs.size() < vec) zs.resize((size_t)vec);
-        draws_avx2(g.blocks.data() + (size_t)(g.idx0 + p0), n32, 0u, (int)vec, zs.data());
+        draws_avx2(g.blocks.data() + (size_t)(g.idx0 + p0 - g.firstWord), n32, 0u, (int)vec, zs.data());
         for (; i < vec; ++i) {
             const int32_t place = (int32_t)((uint32_t)i + zs[(size_t)i]);
             out[i] = t[place];

@@ -2447,7 +2447,8 @@ __device__ __forceinline__ float team_level_cost(int u)
 
 __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__restrict__ lenX,
                                                             const int32_t *__restrict__ lenY,
-                                                            const uint8_t *__restrict__ swap, int B, IcpTeam t, int recCap)
+                                                            const uint8_t *__restrict__ swap, int B, IcpTeam t, int recCap,
+                                                            const uint8_t *__restrict__ active)
 {
     __shared__ int size[256];
     __shared__ int first[257];
@@ -2461,6 +2462,10 @@ __global__ __launch_bounds__(256) void icp_team_plan_kernel(const int32_t *__res
         const bool sw = swap != nullptr && swap[b] != 0;
         n = sw ? lenY[b] : lenX[b];
         nf = sw ? lenX[b] : lenY[b];
+        // a pair that is not in the batch (options.d_pair_active) counts as the two EMPTY clouds a caller who knew the mask
+        // beforehand hands over: the plan -- hence the order of every team's sums -- is the same whether the pair's clouds are
+        // there or not (a frame pair's stage 2 on the whole superset, api.hip, against the serial path's empty clouds)
+        if (active != nullptr && active[b] == 0) { n = 0; nf = 0; }
     }
     const int units = (n + kWave - 1) / kWave;
     const bool small = b < B && units <= kTeamWaves;
@@ -3109,7 +3114,7 @@ void launch_icp_team_plan(const IcpTeam *team, const int32_t *lenX, const int32_
     const size_t imgT = (size_t)((N + kChunk - 1) / kChunk * kChunk) * 12;
     const size_t roomT = icp_team_room(opts, N);
     const int recCapT = (opts.adaptiveWindows && N <= 12288 && imgT + 64 * 20 <= roomT) ? (int)((roomT - imgT) / 20 / 64 * 64) : 0;
-    hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, t, recCapT);
+    hipLaunchKernelGGL(icp_team_plan_kernel, dim3(1), dim3(256), 0, s, lenX, lenY, swap, B, t, recCapT, opts.pairActive);
 }
 
 hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,

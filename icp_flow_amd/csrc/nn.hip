@@ -774,11 +774,13 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
         const size_t slot0 = ((size_t)job * kSweepFullQb + qi) * kSweepShares;   // this query block's shares
         float *mine = p.shareBest + (slot0 + si) * kSweepBlock;
         __hip_atomic_store(&mine[threadIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (write-through)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
+            // (release / acquire at agent scope around the delivery counter -- the barrier in front carries the other
+            // threads' stores into the release, the one behind carries the acquire to their loads: the hand-over between blocks on
+            // different XCDs rests on the memory model, not on the write-through behaviour of the stores.  One thread per block.)
             int *counter = p.shareCount + (size_t)job * kSweepFullQb + qi;
-            const int before = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int before = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             lastSh = before == shares - 1 ? 1 : 0;
             if (lastSh) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
         }

@@ -592,6 +592,7 @@ class _Worker(threading.Thread):
 
 _workers = {}
 _workers_lock = threading.Lock()
+_ABANDON_S = 120.0     # a consumer that takes no result for this long has gone (register_in_flight_native)
 
 
 def register_in_flight_native(args, fps, device, in_flight=4):
@@ -617,6 +618,22 @@ def register_in_flight_native(args, fps, device, in_flight=4):
     out = queue.Queue(maxsize=2 * n + n)     # back-pressure: a slow consumer holds at most ~2 results per worker (+ the end marks)
     stop = threading.Event()                 # the consumer has gone (generator closed, or an error): take no further frame pair
 
+    def deliver(item):
+        #  the queue is bounded and the workers outlive the call: a consumer that has gone -- the generator closed, or
+        # kept somewhere half-consumed -- must not leave a pooled thread blocked in put() for ever (every later call on this
+        # device would queue behind it).  Once `stop` is set the item is dropped; a consumer that takes nothing for
+        # _ABANDON_S seconds counts as gone.
+        waited = 0.0
+        while True:
+            try:
+                out.put(item, timeout=0.2)
+                return
+            except queue.Full:
+                waited += 0.2
+                if stop.is_set() or waited >= _ABANDON_S:
+                    stop.set()
+                    return
+
     def job(stream):
         try:
             while True:
@@ -631,11 +648,11 @@ def register_in_flight_native(args, fps, device, in_flight=4):
                 if not _served(res):
                     res = _python_host(args, fp, device, None, res)
                 stream.synchronize()
-                out.put((idx, fp, res))
+                deliver((idx, fp, res))
         except BaseException as e:   # noqa: BLE001  (handed to the consumer)
-            out.put(e)
+            deliver(e)
         finally:
-            out.put(None)
+            deliver(None)
 
     with _workers_lock:
         pool = _workers.setdefault(device.index, [])
@@ -663,9 +680,13 @@ def register_in_flight_native(args, fps, device, in_flight=4):
                 yield item
     finally:
         stop.set()                       # (closed early: the workers finish the frame pair they hold and leave)
-        while done < n:
-            if out.get() is None:
-                done += 1
+        waited = 0.0
+        while done < n and waited < _ABANDON_S:      # (bounded: a worker stuck inside the library must not hang the consumer too)
+            try:
+                if out.get(timeout=0.2) is None:
+                    done += 1
+            except queue.Empty:
+                waited += 0.2
     if error is not None:
         raise error
 

@@ -1377,7 +1377,7 @@ def test_pairs_outside_the_batch_do_not_touch_its_stop_rule():
             utils_match.hist_icp(rp.default_args(max_points=512, icp_stop_mode="per_pair"), G(S2), G(D2))
 
 
-@pytest.mark.parametrize("case", ["synthetic", "draws", "demo-2048", "demo-10000", "fallback"])
+@pytest.mark.parametrize("case", ["synthetic", "draws", "demo-2048", "demo-10000", "fallback", "stage2-teams"])
 def test_native_frame_pair_equals_the_python_host(case):
     """icpflow_track_frame (frame_pairs.register_frame_pair_native: the host half of match_pcds in C++ -- cluster tables,
     candidate lists, sanity_check, padded batches with the stream of random subsamples restated on MT19937, stage 2's superset,
@@ -1390,6 +1390,15 @@ def test_native_frame_pair_equals_the_python_host(case):
         g0, lab = load_golden("g8_demo"), load_golden("g8_demo_labels")
         fps = [frame_pairs.FramePair(g0["point_src"], g0["point_dst"], lab["label_src"], lab["label_dst"], None, g0["gt_flow"])]
         a = frame_pairs.default_args(max_points=int(case.split("-")[1]))
+    elif case == "stage2-teams":
+        # a few LARGE clusters most of which change their label -- stage 2 is a batch of a handful of pairs wider than
+        # 1024 points, i.e. its ICP takes teams, whose plan (the order of a team's sums) follows the pairs that are in the batch:
+        # the overlapped mode (the whole superset, the mask known only afterwards) must plan as the serial one does
+        fps = []
+        for k, (nobj, nmin, nmax) in enumerate(((6, 1400, 3200), (8, 1100, 2600), (5, 2000, 3900))):
+            d = synthetic.make_frame_pair(seed=90 + k, n_objects=nobj, n_min=nmin, n_max=nmax, relabel=0.7, n_background=800)
+            fps.append(frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"], d["gt_flow"]))
+        a = frame_pairs.default_args(max_points=4096)
     else:
         fps = []
         for k, (nobj, nmax) in enumerate(((9, 400), (14, 900), (5, 2500), (11, 300))):
