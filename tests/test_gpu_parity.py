@@ -1395,7 +1395,7 @@ def test_native_frame_pair_equals_the_python_host(case):
         # 1024 points, i.e. its ICP takes teams, whose plan (the order of a team's sums) follows the pairs that are in the batch:
         # the overlapped mode (the whole superset, the mask known only afterwards) must plan as the serial one does
         fps = []
-        for k, (nobj, nmin, nmax) in enumerate(((6, 1400, 3200), (8, 1100, 2600), (5, 2000, 3900))):
+        for k, (nobj, nmin, nmax) in enumerate(((6, 1400, 3200), (8, 1100, 2600), (5, 2000, 3200))):
             d = synthetic.make_frame_pair(seed=90 + k, n_objects=nobj, n_min=nmin, n_max=nmax, relabel=0.7, n_background=800)
             fps.append(frame_pairs.FramePair(d["points_src"], d["points_dst"], d["labels_src"], d["labels_dst"], d["pose"], d["gt_flow"]))
         a = frame_pairs.default_args(max_points=4096)
@@ -1434,7 +1434,7 @@ def test_native_frame_pair_equals_the_python_host(case):
             assert torch.equal(serial[key], want[key]), (case, key, "stage_overlap=False")
     if case == "fallback":
         assert served < len(fps)            # at least one frame pair needed the exact stage 2
-    elif not case.startswith("demo"):
+    elif not case.startswith("demo") and case != "stage2-teams":   # (stage2-teams: whichever association the Python host took, the three runs agree)
         assert served >= 1
 
 
