@@ -33,6 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+import icp_flow_amd  # noqa: E402,F401  (first: the package asks for sixteen hardware queues before the HIP runtime initialises, icp_flow_amd/__init__.py)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -315,7 +315,9 @@ __device__ __forceinline__ int sorted_count_below(const float *__restrict__ key,
 // Window [count(keys < vlo), count(keys <= vhi)) over n ascending keys by 64-way ballot steps
 // (one step per factor of 64 in n: two for n <= 4096, three up to 262144).  The first level shares
 // its sample load between both bounds.  Wave-uniform results.
-template <bool INCLUSIVE>
+// PAD: the keys sit in LDS with one word of padding behind every 32 (key i at i + (i >> 5)): the first level reads 64 samples
+// `step` apart, and a step of 32 (2048 keys) puts all of them into one bank.
+template <bool INCLUSIVE, bool PAD = false>
 __device__ __forceinline__ int sorted_refine(const float *__restrict__ key, int n, float v, int lane, int base,
                                              int span)
 {
@@ -324,7 +326,7 @@ __device__ __forceinline__ int sorted_refine(const float *__restrict__ key, int 
         const int step = (span + kWave - 1) / kWave;
         const int ls = __mul24(lane, step);   // (24-bit multiply: full rate)
         const int s = base + ls;
-        const float k = (ls < span && s < n) ? key[s] : kInf;
+        const float k = (ls < span && s < n) ? key[PAD ? s + (s >> 5) : s] : kInf;
         const int cnt = __popcll(__ballot(INCLUSIVE ? (k <= v) : (k < v)));
         if (cnt == 0) return base;
         if (step == 1) return base + cnt;
@@ -359,11 +361,12 @@ __device__ __forceinline__ void sorted_window_hint(const float *__restrict__ key
     jhi = sorted_refine_hint<true>(key, n, vhi, lane, jhi);
 }
 
+template <bool PAD = false>
 __device__ __forceinline__ void sorted_window(const float *__restrict__ key, int n, float vlo, float vhi, int lane,
                                               int &jlo, int &jhi)
 {
-    jlo = sorted_refine<false>(key, n, vlo, lane, 0, n);
-    jhi = sorted_refine<true>(key, n, vhi, lane, 0, n);
+    jlo = sorted_refine<false, PAD>(key, n, vlo, lane, 0, n);
+    jhi = sorted_refine<true, PAD>(key, n, vhi, lane, 0, n);
 }
 
 // Sum K values per thread over the whole block.  `scratch` holds at least

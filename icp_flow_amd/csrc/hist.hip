@@ -203,6 +203,18 @@ constexpr int kVoteSpan = 2;     // sorted vote: Y tiles per workgroup (at most)
 // behind the L bins (flushed into the next pair's bins), the global path drops what falls beyond `limit`.
 __host__ __device__ inline int vote_overflow_bins(int len_y, int len_z) { return len_y * len_z + len_z + 1; }
 
+#ifdef ICPFLOW_VOTE_STATS
+// developer build (tools/dbg/vote_stats.py): [0] (row, target) evaluations the windows let through (valid rows x targets visited),
+// [1] of those, evaluations inside the box (votes), [2] targets visited by waves (wave steps), [3] waves x windows with rows
+__device__ unsigned long long g_vote_stats[4];
+extern "C" int icpflow_debug_vote_stats(unsigned long long *out4, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_vote_stats), sizeof(unsigned long long) * 4);
+    if (reset) { static unsigned long long z[4]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_vote_stats), z, sizeof(z)); }
+    return rc;
+}
+#endif
+
 template <bool FAST, bool LDS_HIST>
 __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int r0, int r1, const float4 &xi,
                                            const VoteBox &box, const AxisQuot &dqx, const AxisQuot &dqy,
@@ -227,6 +239,14 @@ __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int 
             const float vx = xi.x - t.x, vy = xi.y - t.y, vz = xi.z - t.z;
             // min <= v < max  <=>  the median of (v, min, pred(max)) is v: one v_med3 + one compare per axis
             // instead of two compares and a scalar AND (NaN fails both forms)
+#ifdef ICPFLOW_VOTE_STATS
+            {
+                const bool in = __builtin_amdgcn_fmed3f(vx, box.min_x, hx) == vx && __builtin_amdgcn_fmed3f(vy, box.min_y, hy) == vy &&
+                                __builtin_amdgcn_fmed3f(vz, box.min_z, hz) == vz;
+                const unsigned long long m = __ballot(in);
+                if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) atomicAdd(&g_vote_stats[1], (unsigned long long)__popcll(m));
+            }
+#endif
             if (__builtin_amdgcn_fmed3f(vx, box.min_x, hx) == vx && __builtin_amdgcn_fmed3f(vy, box.min_y, hy) == vy &&
                 __builtin_amdgcn_fmed3f(vz, box.min_z, hz) == vz) {
                 const int px = (int)(axis_quot<FAST>(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor
@@ -544,6 +564,16 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
             r1 = r0 + (len * (share + 1)) / SPLIT;
             r0 = r0 + (len * share) / SPLIT;
         }
+#ifdef ICPFLOW_VOTE_STATS
+        if (r1 > r0) {
+            const unsigned long long rows = __ballot(true);      // (the valid rows: the others left at `continue` above)
+            if (lane == __builtin_ctzll(rows)) {
+                atomicAdd(&g_vote_stats[0], (unsigned long long)(r1 - r0) * __popcll(rows));
+                atomicAdd(&g_vote_stats[2], (unsigned long long)(r1 - r0));
+                atomicAdd(&g_vote_stats[3], 1ull);
+            }
+        }
+#endif
         if (allFast) {
             if (useLds) vote_range<true, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist, limit);
             else vote_range<true, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb, limit);

@@ -757,7 +757,7 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
     const float *gkey = ks + (size_t)axis * p.NP16;
     const bool stage = np16 <= kSweepStage;
     if (stage) {
-        for (int j = threadIdx.x; j < np16; j += kSweepBlock) keyLds[j] = gkey[j];
+        for (int j = threadIdx.x; j < np16; j += kSweepBlock) keyLds[j + (j >> 5)] = gkey[j];   // (padded: sorted_refine<.., PAD>)
         __syncthreads();
     }
 #ifdef ICPFLOW_SWEEP_CLOCK
@@ -791,7 +791,7 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
             best = fminf(best, __hip_atomic_load(&all[(size_t)sh * kSweepBlock + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     } else
     if (lo <= hi && nt > 0) {   // wave-uniform
-        const float *key = stage ? keyLds : gkey;
+
         // slack: rounding of src + t / of the inverse map (ulps of the coordinates) and of the window arithmetic
         const float slack = (MODE == SWEEP_EVAL ? 2e-3f : 1e-4f) + (MODE == SWEEP_EVAL ? 2e-5f : 2e-6f) * (fabsf(lo) + fabsf(hi) + fabsf(tu));
         // Grow the window until it provably holds every lane's nearest neighbour: scan the targets within
@@ -803,7 +803,10 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
         float lbAdded = 0.f;         // pruned scoring: what this wave has added to the scan's running lower bound
         for (int round = 0; round < 24; ++round) {
             int j0, j1;
-            sorted_window(key, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
+            // (staged keys are padded against the bank conflicts of the strided first level: at 2048 keys its 64 samples are 32 words
+            // apart -- r05 counters: 51-61 % of these kernels' LDS cycles were conflicts; 1 % of their wave cycles, profiles/README)
+            if (stage) sorted_window<true>(keyLds, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
+            else sorted_window<false>(gkey, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
             const int k0 = (j0 / kChunk) * kChunk, k1 = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
             if (ce <= cb) { cb = k0; ce = k0; }   // nothing scanned yet
             // the two ranges not scanned yet; in a shared window this wave's quarter of each (whole chunks)
@@ -1018,7 +1021,7 @@ static hipError_t launch_sweep(SweepParams p, hipStream_t s)
     }
     // (the check sweep beside the scoring's totals: two halves of whole groups of eight pairs, see the kernel)
     const int groups = (MODE == SWEEP_CHECK && p.initSum != nullptr) ? 2 * ((p.njobs / 2 + 7) / 8) : (p.njobs + 7) / 8;
-    const size_t lds = (size_t)(p.NP16 < kSweepStage ? p.NP16 : kSweepStage) * sizeof(float);
+    const size_t lds = (size_t)((p.NP16 < kSweepStage ? p.NP16 : kSweepStage) * 33 / 32 + 1) * sizeof(float);   // (one word of padding per 32 keys)
     // (njobs <= 12 * 700: the batches whose workspace holds the shared minima; larger ones fill the GPU with whole pairs)
     const int total = groups * 8 * p.qblocks;
     if (MODE == SWEEP_SCORE && p.listMode == 1) {   // the deciding launch: query block 0 of every scan
