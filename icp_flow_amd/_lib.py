@@ -106,7 +106,9 @@ OPT_FLAGS = {"no_sorted_vote": 1 << 0, "no_side_stream": 1 << 1, "no_eval_sweep"
              # icpflow_track_frame: stage 2's initial poses behind stage 1 instead of beside its ICP (same results; see icpflow_hip.h)
              "no_stage_overlap": 1 << 13, "no_vote_list": 1 << 14, "no_check_reuse": 1 << 15, "no_score_prebound": 1 << 16,
              # (opt-IN, bit-identical) ICP of a batch of a few rounds: the persistent grid drained for a second launch of whole-CU workgroups
-             "two_launch": 1 << 17}
+             "two_launch": 1 << 17,
+             # the sweeps' clouds sorted along the fixed cloud's longest axis only (no direction keys: csrc/sortdir.hpp)
+             "no_dir_keys": 1 << 18}
 
 
 class Options(ctypes.Structure):

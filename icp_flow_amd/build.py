@@ -23,7 +23,7 @@ OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(HERE, "libicpflow_hip.so")
 SOURCES = ["api.hip", "hist.hip", "nn.hip", "icp.hip", "icp_fp32.hip", "pose.hip", "sort.hip", "cluster.hip", "hdbscan.hip", "table.hip", "assoc.hip", "frame.hip",
            "hdbscan_tree.cpp"]
-HEADERS = ["common.hpp", "scan.hpp", "kernels.hpp", "kabsch.hpp", "posefuse.hpp", "votekey.hpp", "cluster_util.hpp",
+HEADERS = ["common.hpp", "scan.hpp", "kernels.hpp", "kabsch.hpp", "posefuse.hpp", "votekey.hpp", "cluster_util.hpp", "sortdir.hpp",
            os.path.join("..", "..", "include", "icpflow_hip.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]

@@ -237,6 +237,7 @@ const GridScratch *search_scratch(Workspace &w, int N, const Opts &o)
     if (mode == 3 && N > kMaxSortN) mode = 1;   // the bitonic sort holds (key, index) pairs in LDS
     if (mode == 1) return nullptr;
     w.grid.mode = mode;
+    w.grid.dirKeys = o.on(ICPFLOW_OPT_NO_DIR_KEYS) ? 1 : 0;   // (the sorts of this call may pick a direction key: sortdir.hpp)
     return &w.grid;
 }
 
@@ -251,7 +252,7 @@ int parse_options(const char *fn, const icpflow_options_t *opt, Opts &o)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_search must be 0..3 (got %d)", fn, opt->icp_search);
     if (opt->icp_arith != ICPFLOW_ARITH_FP64 && opt->icp_arith != ICPFLOW_ARITH_FP32_REFERENCE)
         return fail(ICPFLOW_E_ARG, "%s: options.icp_arith must be 0 or 1 (got %d)", fn, opt->icp_arith);
-    if (opt->flags >> 18) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
+    if (opt->flags >> 19) return fail(ICPFLOW_E_ARG, "%s: unknown option flags 0x%x", fn, opt->flags);
     o.search = opt->icp_search;
     o.arith = opt->icp_arith;
     o.flags = opt->flags;

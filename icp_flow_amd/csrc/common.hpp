@@ -317,6 +317,54 @@ __device__ __forceinline__ int sorted_count_below(const float *__restrict__ key,
 // its sample load between both bounds.  Wave-uniform results.
 // PAD: the keys sit in LDS with one word of padding behind every 32 (key i at i + (i >> 5)): the first level reads 64 samples
 // `step` apart, and a step of 32 (2048 keys) puts all of them into one bank.
+// the keys as an array in memory (PAD: see sorted_refine) -- or any callable int -> float (a key computed from coordinates)
+template <bool PAD>
+struct KeyArray {
+    const float *p;
+    __device__ __forceinline__ float operator()(int s) const { return p[PAD ? s + (s >> 5) : s]; }
+};
+
+template <bool INCLUSIVE, typename KEY>
+__device__ __forceinline__ int sorted_refine_fn(const KEY &key, int n, float v, int lane, int base, int span)
+{
+    while (span > 0) {
+        const int step = (span + kWave - 1) / kWave;
+        const int ls = __mul24(lane, step);
+        const int s = base + ls;
+        const float k = (ls < span && s < n) ? key(s) : kInf;
+        const int cnt = __popcll(__ballot(INCLUSIVE ? (k <= v) : (k < v)));
+        if (cnt == 0) return base;
+        if (step == 1) return base + cnt;
+        base += __mul24(cnt - 1, step);
+        span = min(step, n - base);
+        base += 1; span -= 1;
+        if (span <= 0) return base;
+    }
+    return base;
+}
+template <bool INCLUSIVE, typename KEY>
+__device__ __forceinline__ int sorted_refine_hint_fn(const KEY &key, int n, float v, int lane, int hint)
+{
+    const int base = max(0, min(hint, n) - kWave / 2);
+    const int s = base + lane;
+    const float k = s < n ? key(s) : kInf;
+    const int cnt = __popcll(__ballot(INCLUSIVE ? (k <= v) : (k < v)));
+    if ((cnt > 0 || base == 0) && cnt < kWave) return base + cnt;
+    return sorted_refine_fn<INCLUSIVE>(key, n, v, lane, 0, n);
+}
+template <typename KEY>
+__device__ __forceinline__ void sorted_window_fn(const KEY &key, int n, float vlo, float vhi, int lane, int &jlo, int &jhi)
+{
+    jlo = sorted_refine_fn<false>(key, n, vlo, lane, 0, n);
+    jhi = sorted_refine_fn<true>(key, n, vhi, lane, 0, n);
+}
+template <typename KEY>
+__device__ __forceinline__ void sorted_window_hint_fn(const KEY &key, int n, float vlo, float vhi, int lane, int &jlo, int &jhi)
+{
+    jlo = sorted_refine_hint_fn<false>(key, n, vlo, lane, jlo);
+    jhi = sorted_refine_hint_fn<true>(key, n, vhi, lane, jhi);
+}
+
 template <bool INCLUSIVE, bool PAD = false>
 __device__ __forceinline__ int sorted_refine(const float *__restrict__ key, int n, float v, int lane, int base,
                                              int span)

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "scan.hpp"
+#include "sortdir.hpp"
 #include "kernels.hpp"
 
 namespace icpflow {
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const int32_t *__restrict__ lenX,
     const int32_t *__restrict__ lenY, const uint8_t *__restrict__ swap, const float *__restrict__ prePose,
     int N, int NP2, int32_t *__restrict__ axisOut, float4 *__restrict__ Xs, float4 *__restrict__ Ys,
-    float *__restrict__ Ysoa, float *__restrict__ Xsoa, int selfCount)
+    float *__restrict__ Ysoa, float *__restrict__ Xsoa, int selfCount, int dirKeys)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
     unsigned long long *kv = reinterpret_cast<unsigned long long *>(dynLds);   // (sort key, row) pairs, NP2 of them
@@ -295,19 +296,32 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
         for (int k = 0; k < 3; ++k) { bb[(tid >> 6) * 6 + k] = mn[k]; bb[(tid >> 6) * 6 + 3 + k] = mx[k]; }
     }
     __syncthreads();
+    __shared__ float boxSh[6];
     if (tid == 0) {
         float e[3];
         for (int k = 0; k < 3; ++k) {
             float lo = bb[k], hi = bb[3 + k];
             for (int w = 1; w < kSortBlock / kWave; ++w) { lo = fminf(lo, bb[w * 6 + k]); hi = fmaxf(hi, bb[w * 6 + 3 + k]); }
             e[k] = hi - lo;
+            boxSh[k] = lo; boxSh[3 + k] = hi;
         }
         const int a = (e[0] >= e[1] && e[0] >= e[2]) ? 0 : (e[1] >= e[2] ? 1 : 2);
         axisSh = a;
-        if (!moving) axisOut[b] = a;
     }
     __syncthreads();
+    // The key that spreads the fixed cloud best (sortdir.hpp): among the three axes and kSortDirs horizontal directions, the one
+    // with the smallest sum of squared populations of 0.1 m key bins -- the longest axis, as before, unless another key is at
+    // least a tenth better (clouds of a thousand points and more: below that every window is short anyway).  Integer counts,
+    // the same on both blocks of the pair.
+    if (dirKeys && ny >= kSortDirMinN) {
+        __shared__ unsigned int scoreSh[kSortCodes];
+        // (the sort has not started: its key array -- NP2 >= 2048 entries of 8 bytes here -- holds the counters)
+        (void)choose_sort_code<kSortBlock>(yb, ny, boxSh, axisSh, reinterpret_cast<unsigned int *>(dynLds), scoreSh, &axisSh);
+    }
+    if (tid == 0 && !moving) axisOut[b] = axisSh;
     const int axis = axisSh;
+    float dirX = 0.f, dirY = 0.f;
+    if (axis >= 3) sort_dir(axis, dirX, dirY);
     const int n = moving ? nx : ny;
     const float4 *cloud = moving ? xb : yb;
     PointXf pre;
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
             const float4 q = cloud[j];
             float px, py, pz;
             xf_apply(pre, q.x, q.y, q.z, px, py, pz);
-            k = axis == 0 ? px : (axis == 1 ? py : pz);
+            k = sort_key_of(axis, dirX, dirY, px, py, pz);
         }
         kv[j] = sort_pack(k, j);
     }
@@ -855,7 +869,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             const float *gz = gy + NP16;
             const float4 *ys = p.sortY + (size_t)b * p.N;
             const float4 *xs = p.sortX + (size_t)b * p.N;
-            const int axis = sweepAxis;
+            const int axis = sweepAxis;   // the pair's sort key (sortdir.hpp): a coordinate (0 .. 2) or a horizontal direction (3 ..)
+            float dirX = 0.f, dirY = 0.f;
+            if (axis >= 3) sort_dir(axis, dirX, dirY);
             // GRID == 4: the sorted fixed cloud is staged into LDS once per launch and every
             // per-iteration access (window search, scan, resolve) stays on chip
             // dynamic LDS: [moment sums per (pass, wave): redPasses x NWAVE x 18 doubles][image][records][own points]
@@ -899,6 +915,11 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
             }
             const float *keyf = (GRID == 4) ? (axis == 0 ? lx : (axis == 1 ? ly : lz))
                                             : (axis == 0 ? gx : (axis == 1 ? gy : gz));
+            // the key of sorted target j (j < yc.n) and of a point: the coordinate, or the direction's two instructions (sortdir.hpp)
+            auto tkey = [&](int j) -> float {
+                return axis >= 3 ? sort_key_dir(dirX, dirY, (GRID == 4 ? lx : gx)[j], (GRID == 4 ? ly : gy)[j]) : keyf[j];
+            };
+            auto pkey = [&](float x, float y, float z) -> float { return sort_key_of(axis, dirX, dirY, x, y, z); };
             constexpr int PER = BLOCK * Q;            // a wave owns 64 CONSECUTIVE sorted queries
             const int ngr = (myCount + PER - 1) / PER;
             double fold[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1134,8 +1155,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 auto scan_window = [&](const bool mayShare) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
-                        const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
-                        if (live[q] && recM[q] >= 0.f) { lo = fminf(lo, qa - recM[q]); hi = fmaxf(hi, qa + recM[q]); }
+                        const float qa = pkey(qx[q], qy[q], qz[q]);
+                        const float qm = recM[q] + sort_key_slack(axis, qx[q], qy[q], recM[q]);   // (a computed key: the window gives its rounding away)
+                        if (live[q] && recM[q] >= 0.f) { lo = fminf(lo, qa - qm); hi = fmaxf(hi, qa + qm); }
                     }
                     ICPFLOW_STAMP(11);
                     bool anyScan = false;
@@ -1149,9 +1171,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         // single pass: this wave's window of the previous iteration is the hint
                         int jlo = winLo, jhi = winHi;
                         if (ngr == 1 && winHi >= 0)
-                            sorted_window_hint(keyf, yc.n, lo, hi, lane, jlo, jhi);
+                            sorted_window_hint_fn(tkey, yc.n, lo, hi, lane, jlo, jhi);
                         else
-                            sorted_window(keyf, yc.n, lo, hi, lane, jlo, jhi);
+                            sorted_window_fn(tkey, yc.n, lo, hi, lane, jlo, jhi);
                         winLo = jlo; winHi = jhi;
                         cb = (jlo / kChunk) * kChunk;
                         ce = min((jhi + kChunk - 1) / kChunk * kChunk, np16);
@@ -1268,7 +1290,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         const int entC = min(ent, kProbeCap - 1);
                         const float sx = probeQ[0][entC], sy = probeQ[1][entC], sz = probeQ[2][entC];
                         const int j1 = rowOn ? __float_as_int(probeQ[3][entC]) : 0;
-                        const float qa = axis == 0 ? sx : (axis == 1 ? sy : sz);
+                        const float qa = pkey(sx, sy, sz);
                         int a = min(max((j1 & ~7) - 32, 0), max(np16 - 64, 0));   // evaluated so far: [a, bEnd)
                         int bEnd = a + 64;
                         int bs = a, be = bEnd;                                    // this step's block
@@ -1298,10 +1320,11 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                                 }
                             }
                             rowbest = row8_min_nonneg(lb);
-                            const float kLo = a > 0 ? keyf[a] : -kInf;
-                            const float kHi = bEnd < np16 ? keyf[bEnd - 1] : kInf;   // (+inf padding past the last target)
+                            const float kLo = a > 0 ? tkey(a) : -kInf;
+                            const float kHi = (bEnd < np16 && bEnd <= yc.n) ? tkey(bEnd - 1) : kInf;   // (beyond the last target: nothing is left on that side)
                             const float rL = qa - kLo, rR = kHi - qa;
-                            rho = fminf(rL, rR) * 0.9999f - 1e-6f;
+                            rho = fminf(rL, rR);
+                            rho = (rho - sort_key_slack(axis, sx, sy, rho)) * 0.9999f - 1e-6f;
                             const bool nn = rho > 0.f && rho * rho > rowbest * 1.000003f;
                             const bool out = !(rowbest <= p.thr2) && rho > gateOut;
                             if (!done) {
@@ -1365,7 +1388,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                             const float sx = __shfl(qx[q], srcl, kWave), sy = __shfl(qy[q], srcl, kWave),
                                         sz = __shfl(qz[q], srcl, kWave);
                             const int j1 = __shfl(certJ[q], srcl, kWave);
-                            const float qa = axis == 0 ? sx : (axis == 1 ? sy : sz);
+                            const float qa = pkey(sx, sy, sz);
                             int a = min(max((j1 & ~7) - 32, 0), max(np16 - 64, 0));   // evaluated so far: [a, bEnd)
                             int bEnd = a + 64;
                             int bs = a, be = bEnd;                                    // this step's block
@@ -1392,10 +1415,11 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                                     }
                                 }
                                 rowbest = row8_min_nonneg(lb);
-                                const float kLo = a > 0 ? keyf[a] : -kInf;
-                                const float kHi = bEnd < np16 ? keyf[bEnd - 1] : kInf;   // (+inf padding past the last target)
+                                const float kLo = a > 0 ? tkey(a) : -kInf;
+                                const float kHi = (bEnd < np16 && bEnd <= yc.n) ? tkey(bEnd - 1) : kInf;   // (beyond the last target: nothing is left on that side)
                                 const float rL = qa - kLo, rR = kHi - qa;
-                                rho = fminf(rL, rR) * 0.9999f - 1e-6f;
+                                rho = fminf(rL, rR);
+                                rho = (rho - sort_key_slack(axis, sx, sy, rho)) * 0.9999f - 1e-6f;
                                 const bool nn = rho > 0.f && rho * rho > rowbest * 1.000003f;
                                 const bool out = !(rowbest <= p.thr2) && rho > gateOut;
                                 if (!done) {
@@ -1514,8 +1538,8 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     // every target other than the neighbour: at least the runner-up of the window away, and targets
                     // outside the window differ by more than this query's half-window along the sort axis (the window
                     // bounds qa -+ m are rounded: 4 ulp of head-room, and 0.1 % on the half-width)
-                    const float qa = axis == 0 ? qx[q] : (axis == 1 ? qy[q] : qz[q]);
-                    const float cap = recM[q] * 0.999f - fabsf(qa) * 2.4e-7f;
+                    const float qa = pkey(qx[q], qy[q], qz[q]);
+                    const float cap = recM[q] * 0.999f - fabsf(qa) * 2.4e-7f - sort_key_slack(axis, qx[q], qy[q], recM[q]);
                     newL[q] = fmaxf(fminf(__builtin_amdgcn_sqrtf(second[q]), cap), 0.f);
                     if (!(acc.best[q] < kInf)) certJ[q] = -1;
                 }
@@ -3163,12 +3187,12 @@ hipError_t launch_icp(const float *X, const float *Y, const int32_t *lenX, const
             ensure_dynamic_lds(reinterpret_cast<const void *>(&sort_clouds_kernel), 128 * 1024, &g_sortAttr);
         if (N > kChunkSortMinN && grid->ckey != nullptr) {   // long clouds: several workgroups per sort
             e = launch_sort_clouds_chunked(X, Y, lenX, lenY, swap, prePose, B, N, grid->axis, grid->sortX, grid->pts,
-                                           grid->sortYsoa, nullptr, grid->ckey, grid->cidx, s);
+                                           grid->sortYsoa, nullptr, grid->ckey, grid->cidx, s, nullptr, grid->dirKeys);
             if (e != hipSuccess) return e;
         } else
         hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY,
                            swap, prePose, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts, grid->sortYsoa,
-                           (float *)nullptr, 0);
+                           (float *)nullptr, 0, grid->dirKeys);
         p.sortX = (const float4 *)grid->sortX; p.sortY = (const float4 *)grid->pts; p.sortAxis = grid->axis;
         p.sortYsoa = grid->sortYsoa;
         p.sweepMargin = (float)(1.01 * thres);
@@ -3280,10 +3304,10 @@ hipError_t launch_sort_clouds_soa(const float *X, const float *Y, const int32_t 
         ensure_dynamic_lds(reinterpret_cast<const void *>(&sort_clouds_kernel), 128 * 1024, &g_sortAttr);
     if (N > kChunkSortMinN && grid->ckey != nullptr)   // long clouds: several workgroups per sort (sort.hip)
         return launch_sort_clouds_chunked(X, Y, lenX, lenY, swap, nullptr, B, N, grid->axis, grid->sortX, grid->pts,
-                                          grid->sortYsoa, grid->sortXsoa, grid->ckey, grid->cidx, s, grid->pairBox);
+                                          grid->sortYsoa, grid->sortXsoa, grid->ckey, grid->cidx, s, grid->pairBox, grid->dirKeys);
     hipLaunchKernelGGL(sort_clouds_kernel, dim3(B, 2), dim3(kSortBlock), (size_t)NP2 * 8, s, X, Y, lenX, lenY, swap,
                        (const float *)nullptr, N, NP2, grid->axis, (float4 *)grid->sortX, (float4 *)grid->pts,
-                       grid->sortYsoa, grid->sortXsoa, selfCount);
+                       grid->sortYsoa, grid->sortXsoa, selfCount, grid->dirKeys);
     return hipGetLastError();
 }
 

@@ -138,7 +138,7 @@ hipError_t launch_zsort_chunked(const float *P, const float *Q, const int32_t *n
 hipError_t launch_sort_clouds_chunked(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                                       const uint8_t *swap, const float *prePose, int B, int N, int32_t *axisOut,
                                       float *Xs, float *Ys, float *Ysoa, float *Xsoa, float *ckey, int *cidx,
-                                      hipStream_t s, const float *boxes = nullptr);
+                                      hipStream_t s, const float *boxes = nullptr, int dirKeys = 0);
 hipError_t launch_u32_to_f32(const uint32_t *in, float *out, size_t n, hipStream_t s);
 hipError_t launch_hist_peaks_f32(const float *bins, int B, int Lx, int Ly, int Lz, int k,
                                  int kernel_size, uint32_t *wsA, uint32_t *wsB, float *votes,
@@ -208,7 +208,8 @@ struct GridScratch {   // scratch of the exact gated NN searches of the ICP loop
     float *sortX;      // sweep: moving cloud sorted by axis, pre-pose applied [B,N,4]
     float *sortYsoa;   // sweep: fixed cloud sorted, x[] y[] z[] padded with +inf [B,3,NP16]
     float *sortXsoa;   // scoring sweep: moving cloud sorted (no pre-pose), same layout
-    int32_t *axis;     // sweep: [B]
+    int32_t *axis;     // sweep: [B] the pair's sort key (sortdir.hpp): 0 .. 2 a coordinate, 3 .. a horizontal direction
+    int dirKeys;       // the sorts of this call may choose direction keys (ICPFLOW_OPT_NO_DIR_KEYS: coordinates only, as before round 6)
     float *ckey;       // long clouds (N > kChunkSortMinN): chunk-sorted keys / rows of the multi-workgroup sort
     int *cidx;         //   [B,2,chunk_sort_length(N)] each (sort.hip), else NULL
     const float *pairBox;  // long clouds: [B, 24] boxes left by count_pair for THESE clouds, lengths and roles (NULL: the sorts look)

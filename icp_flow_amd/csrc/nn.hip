@@ -14,6 +14,7 @@
 // ids are laid out as [group][qblock][job-in-group(8)]: all query blocks of one job share
 // an XCD and therefore the L2 copy of that job's target cloud.
 #include "scan.hpp"
+#include "sortdir.hpp"
 #include "kernels.hpp"
 #include "posefuse.hpp"
 
@@ -687,8 +688,10 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
         const float *t3 = p.cand + ((size_t)b * 6 + (sub >> 1)) * 3;
         tx = t3[0]; ty = t3[1]; tz = t3[2];
     }
-    const int axis = p.axis[b];
-    const float tu = axis == 0 ? tx : (axis == 1 ? ty : tz);
+    const int axis = p.axis[b];   // the pair's sort key (sortdir.hpp): a coordinate or a horizontal direction
+    float dirX = 0.f, dirY = 0.f;
+    if (axis >= 3) sort_dir(axis, dirX, dirY);
+    const float tu = sort_key_of(axis, dirX, dirY, tx, ty, tz);
     // A block whose queries fit ONE wave while the other cloud is long (a 40-point cluster against a 7000-point one: real
     // candidate pairs of very unequal size) used to leave three of its four waves without rows while the one wave walked
     // thousands of targets -- 0.2 ms for one such block, the length of the whole launch (round 5: tools/dbg/sweep_clocks.py).
@@ -707,7 +710,7 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
             qx = qs[i]; qy = qs[p.NP16 + i]; qz = qs[2 * p.NP16 + i];
             if (!backward) { qx += tx; qy += ty; qz += tz; }     // the moved source cloud, as the reference forms it
         }
-        cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
+        cu = sort_key_of(axis, dirX, dirY, qx, qy, qz);
         if (backward) cu -= tu;
     } else if (MODE == SWEEP_CHECK) {
         if (live) {
@@ -722,13 +725,13 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
             const Affine pose = affine_from_pose(poseSh);
             affine_apply(pose, rx, ry, rz, qx, qy, qz);
         }
-        cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
+        cu = sort_key_of(axis, dirX, dirY, qx, qy, qz);
     } else {   // SWEEP_EVAL
         if (live) {
             qx = qs[i]; qy = qs[p.NP16 + i]; qz = qs[2 * p.NP16 + i];
             if (!backward) { ox = as[i]; oy = as[p.NP16 + i]; oz = as[2 * p.NP16 + i]; }   // the untransformed src point
         }
-        cu = axis == 0 ? qx : (axis == 1 ? qy : qz);
+        cu = sort_key_of(axis, dirX, dirY, qx, qy, qz);
         if (backward) {
             // the targets src * T are ordered by their RAW coordinate along u: look for the query where it
             // sits in that frame, c' = R^T (c - t) (T rigid: distances are the same in both frames up to the
@@ -744,7 +747,11 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
                 }
             if (!(dev <= 1e-4f)) r = 3e37f;
             shrink = 0.9995f;
-            cu = M[0 * 4 + axis] * (qx - M[3]) + M[1 * 4 + axis] * (qy - M[7]) + M[2 * 4 + axis] * (qz - M[11]);
+            {   // u . R^T (c - t): the raw frame's coordinates of the query, then the key
+                const float dx = qx - M[3], dy = qy - M[7], dz = qz - M[11];
+                const float rx = M[0] * dx + M[4] * dy + M[8] * dz, ry = M[1] * dx + M[5] * dy + M[9] * dz, rz = M[2] * dx + M[6] * dy + M[10] * dz;
+                cu = axis >= 3 ? sort_key_dir(dirX, dirY, rx, ry) : (axis == 0 ? rx : (axis == 1 ? ry : rz));
+            }
         }
     }
     const float lo = wave_min_uniform(live ? cu : kInf), hi = wave_max_uniform(live ? cu : -kInf);
@@ -754,10 +761,12 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
     // window searches: keys staged in LDS while that is cheap (<= 16 KiB per workgroup), read from
     // global memory (L2) on long clouds, where staging the whole key array would cost more than the
     // two or three dependent probes of a search
-    const float *gkey = ks + (size_t)axis * p.NP16;
+    const float *gkey = ks + (size_t)min(axis, 2) * p.NP16;   // (a coordinate key's row; a direction key is formed from the x and y rows)
     const bool stage = np16 <= kSweepStage;
     if (stage) {
-        for (int j = threadIdx.x; j < np16; j += kSweepBlock) keyLds[j + (j >> 5)] = gkey[j];   // (padded: sorted_refine<.., PAD>)
+        // (padded: sorted_refine<.., PAD>; the +inf rows behind the cloud keep +inf)
+        for (int j = threadIdx.x; j < np16; j += kSweepBlock)
+            keyLds[j + (j >> 5)] = (axis >= 3 && j < nt) ? sort_key_dir(dirX, dirY, ks[j], ks[p.NP16 + j]) : (axis >= 3 ? kInf : gkey[j]);
         __syncthreads();
     }
 #ifdef ICPFLOW_SWEEP_CLOCK
@@ -793,7 +802,9 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
     if (lo <= hi && nt > 0) {   // wave-uniform
 
         // slack: rounding of src + t / of the inverse map (ulps of the coordinates) and of the window arithmetic
-        const float slack = (MODE == SWEEP_EVAL ? 2e-3f : 1e-4f) + (MODE == SWEEP_EVAL ? 2e-5f : 2e-6f) * (fabsf(lo) + fabsf(hi) + fabsf(tu));
+        // (a direction key is computed: 2^-23 of |x| + |y| on either side, sortdir.hpp -- the wave's largest, and the translation's)
+        const float dirSlack = axis >= 3 ? 4.8e-7f * (wave_max_uniform(live ? fabsf(qx) + fabsf(qy) : 0.f) + fabsf(tx) + fabsf(ty) + 4.0f * r) : 0.f;
+        const float slack = (MODE == SWEEP_EVAL ? 2e-3f : 1e-4f) + (MODE == SWEEP_EVAL ? 2e-5f : 2e-6f) * (fabsf(lo) + fabsf(hi) + fabsf(tu)) + dirSlack;
         // Grow the window until it provably holds every lane's nearest neighbour: scan the targets within
         // r of the wave's queries along u (only the parts not scanned yet); if every lane's minimum is
         // within r, done.  Otherwise the largest minimum R bounds every NN distance -- one more round with
@@ -806,7 +817,8 @@ __device__ __forceinline__ void sweep_job(const SweepParams &p, const int lin)
             // (staged keys are padded against the bank conflicts of the strided first level: at 2048 keys its 64 samples are 32 words
             // apart -- r05 counters: 51-61 % of these kernels' LDS cycles were conflicts; 1 % of their wave cycles, profiles/README)
             if (stage) sorted_window<true>(keyLds, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
-            else sorted_window<false>(gkey, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
+            else if (axis < 3) sorted_window<false>(gkey, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
+            else sorted_window_fn([&](int j) { return sort_key_dir(dirX, dirY, ks[j], ks[p.NP16 + j]); }, nt, lo - r - slack, hi + r + slack, lane, j0, j1);
             const int k0 = (j0 / kChunk) * kChunk, k1 = min((j1 + kChunk - 1) / kChunk * kChunk, np16);
             if (ce <= cb) { cb = k0; ce = k0; }   // nothing scanned yet
             // the two ranges not scanned yet; in a shared window this wave's quarter of each (whole chunks)

@@ -14,6 +14,7 @@
 
 #include "common.hpp"
 #include "scan.hpp"
+#include "sortdir.hpp"
 #include "kernels.hpp"
 #include "votekey.hpp"
 
@@ -45,6 +46,7 @@ struct ChunkSortParams {
     int len_z;
     float *keyRec;            // mode 0: [B, kVoteKeyStride] key parameters, written here, read by the vote
     const float *boxes;       // [B, kPairBoxStride] bounding boxes by count_pair_kernel, or NULL (every workgroup reads its pair)
+    int codeChosen;           // mode 1: axisOut[b] already holds the pair's key code (sort_code_kernel, sortdir.hpp)
 };
 
 // cloud roles of mode 1 exactly as sort_clouds_kernel resolves them
@@ -113,7 +115,47 @@ __device__ __forceinline__ float sort_key(const ChunkSortParams &p, const Roles 
     pre.kind = (r.moving && p.prePose) ? XF_AFFINE : XF_NONE;
     pre.a = (r.moving && p.prePose) ? affine_from_pose(p.prePose + (size_t)b * 16) : affine_identity();
     xf_apply(pre, q.x, q.y, q.z, px, py, pz);
-    return axis == 0 ? px : (axis == 1 ? py : pz);
+    float ux = 0.f, uy = 0.f;
+    if (axis >= 3) sort_dir(axis, ux, uy);
+    return sort_key_of(axis, ux, uy, px, py, pz);
+}
+
+// mode 1 on long clouds: the pair's key code (sortdir.hpp) -- the longest axis of the fixed cloud or a key that spreads it at least
+// a tenth better --, one workgroup per pair in front of the chunk sorts (every chunk of either cloud has to use the same key)
+__global__ __launch_bounds__(kCsBlock) void sort_code_kernel(ChunkSortParams p)
+{
+    __shared__ float bb[6 * (kCsBlock / kWave)];
+    __shared__ float boxSh[6];
+    __shared__ int axisSh;
+    __shared__ unsigned int hist[3 * kSortDirBins], scoreSh[kSortCodes];
+    const int b = blockIdx.x;
+    const Roles f = roles_of(p, b, 0);
+    float mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
+    bbox_rows(f.cloud, f.n, false, mn, mx);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], o, kWave));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o, kWave));
+        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        for (int k = 0; k < 3; ++k) { bb[wave * 6 + k] = mn[k]; bb[wave * 6 + 3 + k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float e[3];
+        for (int k = 0; k < 3; ++k) {
+            float lo = bb[k], hi = bb[3 + k];
+            for (int w = 1; w < kCsBlock / kWave; ++w) { lo = fminf(lo, bb[w * 6 + k]); hi = fmaxf(hi, bb[w * 6 + 3 + k]); }
+            e[k] = hi - lo; boxSh[k] = lo; boxSh[3 + k] = hi;
+        }
+        axisSh = (e[0] >= e[1] && e[0] >= e[2]) ? 0 : (e[1] >= e[2] ? 1 : 2);   // same rule as sort_clouds_kernel
+    }
+    __syncthreads();
+    int code = axisSh;
+    if (f.n >= kSortDirMinN) code = choose_sort_code<kCsBlock>(f.cloud, f.n, boxSh, code, hist, scoreSh, &axisSh);
+    if (threadIdx.x == 0) p.axisOut[b] = code;
 }
 
 #ifdef ICPFLOW_SORT_CLOCK
@@ -147,7 +189,10 @@ __global__ __launch_bounds__(kCsBlock) void chunk_sort_kernel(ChunkSortParams p)
     if (base >= r.n && c != 0) return;   // (chunk 0 still publishes the pair's axis / key parameters)
     int axis = 0;
     VoteKey vk{};
-    if (p.mode == 1 && p.boxes != nullptr) {
+    if (p.mode == 1 && p.codeChosen) {
+        axis = p.axisOut[b];
+        if (base >= r.n) return;
+    } else if (p.mode == 1 && p.boxes != nullptr) {
         // (fixed role = swap ? X : Y = cloud A / C of count_pair; its rows below the count, flagged or not)
         const float *bx = p.boxes + (size_t)b * kPairBoxStride + ((p.swap != nullptr && p.swap[b] != 0) ? 0 : 12) + 6;
         const float e0 = bx[3] - bx[0], e1 = bx[4] - bx[1], e2 = bx[5] - bx[2];
@@ -256,6 +301,7 @@ static hipError_t run_chunk_sort(ChunkSortParams p, int B, hipStream_t s)
 {
     const int NP16 = (p.N + kChunk - 1) / kChunk * kChunk;
     const int span = NP16 > p.NPc ? NP16 : p.NPc;
+    if (p.mode == 1 && p.codeChosen) hipLaunchKernelGGL(sort_code_kernel, dim3(B), dim3(kCsBlock), 0, s, p);
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(B, 2, p.NPc / kCsChunk), dim3(kCsBlock), 0, s, p);
     hipLaunchKernelGGL(chunk_merge_kernel, dim3(B, 2, (span + kCmBlock - 1) / kCmBlock), dim3(kCmBlock), 0, s, p);
     return hipGetLastError();
@@ -277,12 +323,13 @@ hipError_t launch_zsort_chunked(const float *P, const float *Q, const int32_t *n
 hipError_t launch_sort_clouds_chunked(const float *X, const float *Y, const int32_t *lenX, const int32_t *lenY,
                                       const uint8_t *swap, const float *prePose, int B, int N, int32_t *axisOut,
                                       float *Xs, float *Ys, float *Ysoa, float *Xsoa, float *ckey, int *cidx,
-                                      hipStream_t s, const float *boxes)
+                                      hipStream_t s, const float *boxes, int dirKeys)
 {
     ChunkSortParams p{};
     p.mode = 1; p.P = (const float4 *)X; p.Q = (const float4 *)Y; p.nP = lenX; p.nQ = lenY; p.swap = swap;
     p.prePose = prePose; p.N = N; p.NPc = chunk_sort_length(N); p.ckey = ckey; p.cidx = cidx;
     p.outP = (float4 *)Xs; p.outQ = (float4 *)Ys; p.Ysoa = Ysoa; p.Xsoa = Xsoa; p.axisOut = axisOut; p.boxes = boxes;
+    p.codeChosen = dirKeys ? 1 : 0;
     return run_chunk_sort(p, B, s);
 }
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICPFLOW_VERSION 213 /* 0.2.13: ICPFLOW_OPT_TWO_LAUNCH (ICP of batches of a few rounds: the persistent grid drained for a second launch of whole-CU workgroups; off by default); 0.2.12: ICPFLOW_OPT_NO_SCORE_PREBOUND (scoring sweeps: a scan's whole sum bounded from below by the other cloud's occupancy grid before any target is evaluated); 0.2.11: ICPFLOW_OPT_NO_CHECK_REUSE (hist_icp: the roll-back check takes its sum under the initial pose from the scoring); 0.2.10: ICPFLOW_OPT_NO_VOTE_LIST (the vote's work list on ragged batches); 0.2.9: icpflow_register_stage_begin / _finish, icpflow_associate_frame_begun (stage 2's initial poses beside stage 1's ICP), ICPFLOW_E_HOSTMEM; 0.2.8: ICPFLOW_OPT_NO_SHARED_SCANS (teams: window scans shared by a member's waves); 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
+#define ICPFLOW_VERSION 214 /* 0.2.14: ICPFLOW_OPT_NO_DIR_KEYS (sort keys of the sweeps: horizontal directions next to the axes); 0.2.13: ICPFLOW_OPT_TWO_LAUNCH (ICP of batches of a few rounds: the persistent grid drained for a second launch of whole-CU workgroups; off by default); 0.2.12: ICPFLOW_OPT_NO_SCORE_PREBOUND (scoring sweeps: a scan's whole sum bounded from below by the other cloud's occupancy grid before any target is evaluated); 0.2.11: ICPFLOW_OPT_NO_CHECK_REUSE (hist_icp: the roll-back check takes its sum under the initial pose from the scoring); 0.2.10: ICPFLOW_OPT_NO_VOTE_LIST (the vote's work list on ragged batches); 0.2.9: icpflow_register_stage_begin / _finish, icpflow_associate_frame_begun (stage 2's initial poses beside stage 1's ICP), ICPFLOW_E_HOSTMEM; 0.2.8: ICPFLOW_OPT_NO_SHARED_SCANS (teams: window scans shared by a member's waves); 0.2.7: icpflow_track_frame (one frame pair per call, host half in C++); team-launch chains per device instead of per host thread; 0.2.6: icpflow_register_stage, icpflow_associate_frame (a stage / the rest of match_pcds per call); 0.2.5: options.d_pair_active, icpflow_assoc_assign / _collect (device-side association of a frame pair), ICPFLOW_OPT_TEAMS_HALF_GPU; 0.2.3: icpflow_hist_icp_eval; 0.2.2: icpflow_hist_icp_many; 0.2.1: per-call options replace the process-global switches of 0.1;
                                icpflow_icp takes an initial transform and returns its per-iteration history */
 
 #define ICPFLOW_OK 0
@@ -144,6 +144,11 @@ const char *icpflow_build_info(void);
  * workgroup and resumes it at its own iteration from its history rows (icp.hip: icp_split_kernel).  Same sums (added in the order of
  * the 64-query units in either kernel), same history: transforms and iteration counts are those of one launch, bit for bit. */
 #define ICPFLOW_OPT_TWO_LAUNCH (1u << 17)
+/* (a bit-identity switch) the sorted sweeps (ICP search, candidate scoring, roll-back check, match_eval): both clouds of every pair are
+ * sorted along the fixed cloud's longest AXIS, as before round 6, instead of by the key -- an axis or one of six horizontal
+ * directions -- that spreads the fixed cloud best (a vehicle heading along an axis shows a face across it: a third of its points on
+ * one key).  The searches are exact under any such key: same neighbours, same sums (utils_icp_pytorch3d.py:153-168, utils_hist.py:86-101) */
+#define ICPFLOW_OPT_NO_DIR_KEYS (1u << 18)
 
 typedef struct icpflow_profile icpflow_profile_t; /* opaque */
 

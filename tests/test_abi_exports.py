@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_the_header():
     from icp_flow_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.VERSION == 213
+    assert _lib.VERSION == 214
     assert re.fullmatch(r"[0-9a-f]{16}", _lib.BUILD_INFO), _lib.BUILD_INFO
 
 
@@ -100,7 +100,7 @@ def test_options_are_per_call_and_per_thread():
         t.join()
     assert seen["other"] == 0
     assert _lib._current()[-1]["search"] == 0
-    assert set(_lib.OPT_FLAGS.values()) == {1 << k for k in range(18)}   # sixteen bit-identity switches off + teams_half_gpu (bit 11) + two_launch (bit 17, opt-in)
+    assert set(_lib.OPT_FLAGS.values()) == {1 << k for k in range(19)}   # seventeen bit-identity switches off + teams_half_gpu (bit 11) + two_launch (bit 17, opt-in)
     assert ctypes.sizeof(_lib.Options) == 96   # size_t, int, int, unsigned, pad, five pointers, two ints, two pointers on LP64
     # the structs of icpflow_register_stage / icpflow_associate_frame (include/icpflow_hip.h), LP64
     assert (ctypes.sizeof(_lib.Tables), ctypes.sizeof(_lib.Stage), ctypes.sizeof(_lib.Registration)) == (64, 56, 64)

@@ -372,6 +372,59 @@ def test_two_icp_launches_change_nothing(shape):
             assert torch.equal(h1.R, h2.R) and torch.equal(h1.T, h2.T)
 
 
+@pytest.mark.parametrize("shape", ["config4_shard_1024x2048", "dense_600x2048", "matched_128x4000", "matched_teams_48x10000", "independent_64x10000",
+                                   "ragged_900x2048", "headings_along_the_axes_256x2048"])
+def test_direction_sort_keys_change_only_the_order_of_the_sums(shape):
+    """Round 6 (csrc/sortdir.hpp): the clouds of a pair are sorted by the key that spreads the fixed cloud best -- an axis or one of six
+    horizontal directions -- instead of always along its longest axis (ICPFLOW_OPT_NO_DIR_KEYS).  Every search stays exact
+    (|u . (q - t)| <= |q - t| for any unit u; a computed key gives its rounding away first): same neighbours, same gate decisions,
+    same iteration count.  What changes is the ORDER in which a pair's queries are visited, i.e. the order of the fp64 moment sums:
+    a transform may differ in its last bit (measured: 1 pair in 8192, 1.5e-13 m).  So: iteration counts equal, every point within
+    1e-9 m, nearly all transforms bit-identical -- and the scoring's picks (integer bins, exact minima) equal bit for bit."""
+    if shape == "config4_shard_1024x2048":
+        S, D, _ = synthetic.make_batch(1024, 2048, seed=0)
+    elif shape == "dense_600x2048":
+        S, D, _ = synthetic.make_batch(600, 2048, seed=31)
+    elif shape == "matched_128x4000":
+        S, D, _ = synthetic.make_batch(128, 4000, seed=3, ragged="matched", n_min=200)
+    elif shape == "matched_teams_48x10000":                  # long clouds: the chunked sorts (sort.hip), teams with shared scans
+        S, D, _ = synthetic.make_batch(48, 10000, seed=5, ragged="matched", n_min=400)
+    elif shape == "independent_64x10000":
+        S, D, _ = synthetic.make_batch(64, 10000, seed=7, ragged=True, n_min=50)
+    elif shape == "ragged_900x2048":
+        S, D, _ = synthetic.make_batch(900, 2048, seed=23, ragged=True, n_min=100)
+    else:
+        # boxes whose heading is exactly along x or y: a face across either axis -- the case the direction keys exist for
+        S, D, _ = synthetic.make_batch(256, 2048, seed=11)
+        for k in range(256):
+            r = np.random.default_rng(900 + k)
+            ext = np.array([r.uniform(2.5, 5.0), r.uniform(1.2, 2.2), r.uniform(1.0, 2.0)])
+            pts = synthetic._shell_points(r, ext, 2048)
+            if k % 2:
+                pts = pts[:, [1, 0, 2]]
+            c = np.array([r.uniform(-30, 30), r.uniform(-30, 30), 0.8])
+            t = np.array([r.uniform(-1, 1), r.uniform(-1, 1), 0.0])
+            S[k, :, :3] = (pts + c).astype(np.float32); S[k, :, 3] = 1.0
+            D[k, :, :3] = (pts + c + t + r.normal(0, 0.01, pts.shape)).astype(np.float32); D[k, :, 3] = 1.0
+    s, d = G(S), G(D)
+    a = rp.default_args(max_points=S.shape[1], icp_max_iterations=50)
+    with _lib.options(no_dir_keys=True):
+        T0, ev0, it0 = utils_match.hist_icp_eval(a, s, d, return_iterations=True)
+        P0 = utils_hist.estimate_init_pose(a, s, d)
+    T1, ev1, it1 = utils_match.hist_icp_eval(a, s, d, return_iterations=True)
+    P1 = utils_hist.estimate_init_pose(a, s, d)
+    assert torch.equal(P0, P1)                                   # the initial poses: exact minima, integer bins
+    assert int(it0) == int(it1) and int(it1) > 0
+    dis = displacement(T0.cpu().numpy(), T1.cpu().numpy(), S)
+    same = (T0 == T1).flatten(1).all(1).float().mean().item()
+    assert dis.max() < 1e-9, (shape, float(dis.max()))
+    assert same >= 0.99, (shape, same)
+    for e0, e1 in zip(ev0, ev1):
+        assert torch.allclose(e0, e1, rtol=1e-6, atol=1e-7)
+    for _ in range(2):                                          # and from run to run the same bits
+        assert torch.equal(utils_match.hist_icp(a, s, d), T1)
+
+
 def test_per_pair_stop_with_a_long_iteration_cap_keeps_the_helper_protocol_sound():
     """the helper hand-off words carry the iteration epoch in 8 bits; ICPFLOW_STOP_PER_PAIR runs ONE persistent
     launch of up to 1024 iterations, so a cap beyond 253 must not be served with helpers (launch_icp switches them off:
