@@ -40,9 +40,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_LANE_OPS = 78.6e12    # 256 CU x 128 fp32 lanes x 2.4 GHz; 157.3 TFLOP/s counting fma = 2
 LANE_OPS_PER_EVAL = 8           # one 3-D squared distance + compare = 8 lane-ops
-COUNTERS_FILE = os.path.join(REPO, "profiles", "r05_icp_kernel_counters.json")
-RAGGED_COUNTERS_FILE = os.path.join(REPO, "profiles", "r05_ragged_counters.json")
-CONFIG4_COUNTERS_FILE = os.path.join(REPO, "profiles", "r05_config4_shard_counters.json")
+COUNTERS_FILE = os.path.join(REPO, "profiles", "r06_icp_kernel_counters.json")
+RAGGED_COUNTERS_FILE = os.path.join(REPO, "profiles", "r06_ragged_counters.json")
+CONFIG4_COUNTERS_FILE = os.path.join(REPO, "profiles", "r06_config4_shard_counters.json")
 
 
 def parse():
@@ -594,7 +594,7 @@ def config4_roofline(B, N, iters, step_ms, icp_ms):
     dominant kernel (icp_kernel: algorithmic bytes I*B*P / its launch duration, live HIP events).  `kernels`: per kernel of
     the step the duration, the algorithmic HBM bytes (inputs once + outputs once), the HBM bytes the PMC passes count
     (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) and the executed VALU fraction (SQ_INSTS_VALU x 64 / duration / 78.6 T
-    lane-op/s) -- from profiles/r05_config4_shard_counters.json (tools/profile_workload.sh + summarize_workload.py), refused when
+    lane-op/s) -- from profiles/r06_config4_shard_counters.json (tools/profile_workload.sh + summarize_workload.py), refused when
     it was collected with another build of the library."""
     from icp_flow_amd import _lib
     P = 2 * N * 16                                        # both clouds of a pair, 16 B a point

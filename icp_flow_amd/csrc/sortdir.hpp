@@ -63,6 +63,12 @@ __device__ __forceinline__ float sort_key_slack(int code, float x, float y, floa
 // longest axis, unless another key is at least a tenth better.  Integer counts: every workgroup of a pair finds the same code.
 // hist: 3 * kSortDirBins counters of LDS, scoreSh: kSortCodes, codeSh: one int; box = (min x y z, max x y z) of the rows.
 constexpr int kSortDirBins = 512;
+#ifndef ICPFLOW_SORT_DIR_BIN
+#define ICPFLOW_SORT_DIR_BIN 0.1f
+#endif
+#ifndef ICPFLOW_SORT_DIR_KEEP
+#define ICPFLOW_SORT_DIR_KEEP 9   // the longest axis stays unless another key's sum is at most this many tenths of its own
+#endif
 template <int BLOCK>
 __device__ __forceinline__ int choose_sort_code(const float4 *__restrict__ rows, int n, const float *box, int legacy,
                                                 unsigned int *hist, unsigned int *scoreSh, int *codeSh)
@@ -72,7 +78,7 @@ __device__ __forceinline__ int choose_sort_code(const float4 *__restrict__ rows,
     const float cx = 0.5f * (box[0] + box[3]), cy = 0.5f * (box[1] + box[4]), cz = 0.5f * (box[2] + box[5]);
     const float ex = box[3] - box[0], ey = box[4] - box[1], ez = box[5] - box[2];
     const float R = 0.5f * sqrtf(ex * ex + ey * ey + ez * ez) + 0.05f;
-    const float inv = 1.0f / fmaxf(0.1f, 2.0f * R / (float)kSortDirBins);
+    const float inv = 1.0f / fmaxf(ICPFLOW_SORT_DIR_BIN, 2.0f * R / (float)kSortDirBins);
     if (tid < kSortCodes) scoreSh[tid] = 0u;
     for (int c0 = 0; c0 < kSortCodes; c0 += kPerRound) {
         for (int k = tid; k < kPerRound * kSortDirBins; k += BLOCK) hist[k] = 0u;
@@ -102,7 +108,7 @@ __device__ __forceinline__ int choose_sort_code(const float4 *__restrict__ rows,
         for (int c = 0; c < kSortCodes; ++c)
             if (scoreSh[c] < sb) { sb = scoreSh[c]; best = c; }
         // (a tenth better at least, in integers: 10 s_best <= 9 s_legacy)
-        *codeSh = (best != legacy && (unsigned long long)sb * 10ull <= (unsigned long long)scoreSh[legacy] * 9ull) ? best : legacy;
+        *codeSh = (best != legacy && (unsigned long long)sb * 10ull <= (unsigned long long)scoreSh[legacy] * (unsigned long long)ICPFLOW_SORT_DIR_KEEP) ? best : legacy;
     }
     __syncthreads();
     return *codeSh;

@@ -2,7 +2,7 @@
 # Developer tool: copy what tools/dbg/round_evidence.sh <tag> left under gpurun_out/ into profiles/ (run in the build container
 # after the gpurun call):  bash tools/dbg/install_round.sh r05
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/../.."
 E=gpurun_out/evidence_$TAG
 P=gpurun_out/profiles_$TAG
@@ -41,5 +41,20 @@ cp /tmp/tl.txt profiles/${TAG}_frame_pair_native_timeline.txt
   echo "frame pair); every flow compared by torch.equal with the flow of the same host one frame pair at a time; a team that times out raises."
   grep -v amdgpu.ids $E/stress_default.txt; } > profiles/${TAG}_stream_stress.txt
 { echo "Developer fuzzers on the round's library (build $B), one MI355X; tools/dbg/*_fuzz.py"
-  for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz vote_list_fuzz; do [ -f $E/$f.txt ] || continue; echo; echo "== tools/dbg/$f.py (last lines)"; grep -v amdgpu.ids $E/$f.txt | tail -4; done; } > profiles/${TAG}_fuzz_final_build.txt
+  for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz vote_list_fuzz dir_keys_fuzz; do [ -f $E/$f.txt ] || continue; echo; echo "== tools/dbg/$f.py (last lines)"; grep -v amdgpu.ids $E/$f.txt | tail -4; done; } > profiles/${TAG}_fuzz_final_build.txt
+{ echo "bench.py --workload stream, five consecutive runs per setting of GPU_MAX_HW_QUEUES (tools/dbg/stream_repro.sh: three timed steps of 64 demo frame"
+  echo "pairs each; then tools/dbg/stream_repro2.sh: ten timed steps, 16 and 32 queues), and four config-2 batches in one hist_icp_many call per process;"
+  echo "one MI355X, build $B.  The package sets GPU_MAX_HW_QUEUES=16 at import (icp_flow_amd/__init__.py); 'unset' = ICPFLOW_KEEP_HW_QUEUES=1."
+  cat $E/stream_repro.txt; cat $E/stream_repro2.txt; } > profiles/${TAG}_stream_repro.txt
+{ echo "The sweeps' sort keys: the fixed cloud's longest axis (ICPFLOW_OPT_NO_DIR_KEYS) against the best of three axes and six horizontal directions"
+  echo "(csrc/sortdir.hpp); tools/dbg/dir_keys_ab.py (step / ICP launch in ms, r = ragged independent sizes, m = matched sizes), dir_keys_diff.py and"
+  echo "dir_keys_fuzz.py (what differs: the order of the fp64 moment sums); one MI355X, build $B"
+  grep -v amdgpu.ids $E/dir_keys_ab.txt; grep -v amdgpu.ids $E/dir_keys_diff.txt; grep -v amdgpu.ids $E/dir_keys_fuzz.txt | tail -3; } > profiles/${TAG}_direction_keys.txt
+{ echo "The ICP of batches of a few rounds in ONE launch (default) against two (ICPFLOW_OPT_TWO_LAUNCH: the grid of half-CU workgroups drained once the"
+  echo "unfinished pairs fit one CU each, the rest resumed on whole CUs; icp.hip icp_split_kernel): tools/dbg/two_launch_ab.py, then -- library built with"
+  echo "-DICPFLOW_TAIL_CLOCK -- tools/dbg/help_timeline.py (the one launch: resident owners over its span, the pairs that end it) and"
+  echo "tools/dbg/two_launch_stats.py (when the drain happens, what the second launch's pairs take); config 4's shard, one MI355X, build $B"
+  grep -v amdgpu.ids $E/two_launch_ab.txt; grep -v amdgpu.ids $E/help_timeline.txt; grep -v amdgpu.ids $E/two_launch_stats.txt; } > profiles/${TAG}_two_launch.txt
+{ echo "What the sorted vote evaluates (library built with -DICPFLOW_VOTE_STATS, tools/dbg/vote_stats.py), one MI355X, build $B; VERDICT r5 item 6"
+  grep -v amdgpu.ids $E/vote_stats.txt; } > profiles/${TAG}_vote_stats.txt
 grep -o '"library_build": "[0-9a-f]*"' profiles/${TAG}_bench.json profiles/${TAG}_icp_kernel_counters.json profiles/${TAG}_ragged_counters.json profiles/${TAG}_config4_shard_counters.json | sort | uniq -c
