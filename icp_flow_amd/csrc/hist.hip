@@ -143,6 +143,7 @@ struct VoteBox {
 struct AxisQuot {
     float r, y1;
     bool fast;
+    bool pow2;   // r is a power of two (and `fast`): y1 = 1 / r exactly and the IEEE quotient a / r is the one product a * y1
 };
 
 __device__ __forceinline__ AxisQuot axis_quot_make(float mn, float mx)
@@ -154,6 +155,10 @@ __device__ __forceinline__ AxisQuot axis_quot_make(float mn, float mx)
     d.y1 = fmaf(e0, y0, y0);
     // a nonzero numerator v - mn is at least half an ulp of mn: normal range guaranteed by |mn|
     d.fast = d.r > 1e-18f && d.r < 1e18f && fabsf(mn) > 1e-18f && fabsf(mn) < 1e18f;
+    // A box whose extent is a power of two -- translation_frame 2.0: x and y run from -2 to 2, utils_hist.py:63-64 -- divides exactly:
+    // y0 = rcp(2^k) = 2^-k, e0 = 0, y1 = y0; in axis_quot q0 = a * 2^-k is exact (normal range: `fast`), so e1 = e2 = 0 and the
+    // five operations return q0.  The vote then skips the four that change nothing (vote_range<.., P2>).
+    d.pow2 = d.fast && (__float_as_uint(d.r) & 0x007fffffu) == 0u;
     return d;
 }
 
@@ -175,7 +180,7 @@ __global__ void vote_quotient_probe_kernel(const float *__restrict__ a, int n, f
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const AxisQuot d = axis_quot_make(mn, mx);
-    fast[i] = axis_quot(a[i], d);
+    fast[i] = d.pow2 ? a[i] * d.y1 : axis_quot(a[i], d);   // (what vote_range computes: the one product where the extent is a power of two)
     ieee[i] = a[i] / (mx - mn);
 }
 
@@ -215,7 +220,7 @@ extern "C" int icpflow_debug_vote_stats(unsigned long long *out4, int reset)
 }
 #endif
 
-template <bool FAST, bool LDS_HIST>
+template <bool FAST, bool LDS_HIST, bool P2 = false>
 __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int r0, int r1, const float4 &xi,
                                            const VoteBox &box, const AxisQuot &dqx, const AxisQuot &dqy,
                                            const AxisQuot &dqz, uint32_t *__restrict__ counters, int limit)
@@ -249,8 +254,9 @@ __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int 
 #endif
             if (__builtin_amdgcn_fmed3f(vx, box.min_x, hx) == vx && __builtin_amdgcn_fmed3f(vy, box.min_y, hy) == vy &&
                 __builtin_amdgcn_fmed3f(vz, box.min_z, hz) == vz) {
-                const int px = (int)(axis_quot<FAST>(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor
-                const int py = (int)(axis_quot<FAST>(vy - box.min_y, dqy) * fly);
+                // (P2: the x and y extents of the box are powers of two -- the quotient is one exact product, see axis_quot_make)
+                const int px = (int)((P2 ? (vx - box.min_x) * dqx.y1 : axis_quot<FAST>(vx - box.min_x, dqx)) * flx);   // >= 0: truncation == floor
+                const int py = (int)((P2 ? (vy - box.min_y) * dqy.y1 : axis_quot<FAST>(vy - box.min_y, dqy)) * fly);
                 const int pz = (int)(axis_quot<FAST>(vz - box.min_z, dqz) * flz);
                 // FAST also promises len_x * len_y and len_z below 2^23: 24-bit multiplies (full rate) are exact
                 int bin;
@@ -327,7 +333,8 @@ __global__ __launch_bounds__(kVoteBlock) void hist_vote_kernel(
         }
         if (!__syncthreads_or(any)) continue;  // a tile of pads
         if (!xvalid) continue;
-        if (allFast) vote_range<true, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb, limit);
+        if (allFast && dqx.pow2 && dqy.pow2) vote_range<true, LDS_HIST, true>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb, limit);
+        else if (allFast) vote_range<true, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb, limit);
         else vote_range<false, LDS_HIST>(tile, 0, tn, xi, box, dqx, dqy, dqz, LDS_HIST ? lhist : gb, limit);
     }
     if (LDS_HIST) {
@@ -574,7 +581,10 @@ __global__ __launch_bounds__(BLOCK) void hist_vote_sorted_kernel(
             }
         }
 #endif
-        if (allFast) {
+        if (allFast && dqx.pow2 && dqy.pow2) {
+            if (useLds) vote_range<true, true, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist, limit);
+            else vote_range<true, false, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb, limit);
+        } else if (allFast) {
             if (useLds) vote_range<true, true>(tile, r0, r1, xi, box, dqx, dqy, dqz, lhist, limit);
             else vote_range<true, false>(tile, r0, r1, xi, box, dqx, dqy, dqz, gb, limit);
         } else {
