@@ -233,6 +233,7 @@ __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int 
     if (empty) return;
     const float hx = nextafterf(box.max_x, -INFINITY), hy = nextafterf(box.max_y, -INFINITY),
                 hz = nextafterf(box.max_z, -INFINITY);
+    [[maybe_unused]] const float p2x = dqx.y1 * flx, p2y = dqy.y1 * fly;   // (P2: exact products of a power of two and an integer below 2^23)
     for (int k = r0; k < r1; k += 4) {
         float4 t4[4];
 #pragma unroll
@@ -255,8 +256,10 @@ __device__ __forceinline__ void vote_range(const float4 *__restrict__ tile, int 
             if (__builtin_amdgcn_fmed3f(vx, box.min_x, hx) == vx && __builtin_amdgcn_fmed3f(vy, box.min_y, hy) == vy &&
                 __builtin_amdgcn_fmed3f(vz, box.min_z, hz) == vz) {
                 // (P2: the x and y extents of the box are powers of two -- the quotient is one exact product, see axis_quot_make)
-                const int px = (int)((P2 ? (vx - box.min_x) * dqx.y1 : axis_quot<FAST>(vx - box.min_x, dqx)) * flx);   // >= 0: truncation == floor
-                const int py = (int)((P2 ? (vy - box.min_y) * dqy.y1 : axis_quot<FAST>(vy - box.min_y, dqy)) * fly);
+                // ... and with it the quotient's product with float(len): (a 2^-k) len rounds once, like a (2^-k len) -- 2^-k len is exact
+                // for any length the 24-bit fast path admits
+                const int px = P2 ? (int)((vx - box.min_x) * p2x) : (int)(axis_quot<FAST>(vx - box.min_x, dqx) * flx);   // >= 0: truncation == floor
+                const int py = P2 ? (int)((vy - box.min_y) * p2y) : (int)(axis_quot<FAST>(vy - box.min_y, dqy) * fly);
                 const int pz = (int)(axis_quot<FAST>(vz - box.min_z, dqz) * flz);
                 // FAST also promises len_x * len_y and len_z below 2^23: 24-bit multiplies (full rate) are exact
                 int bin;
