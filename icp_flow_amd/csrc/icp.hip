@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kSortBlock) void sort_clouds_kernel(
     // with the smallest sum of squared populations of 0.1 m key bins -- the longest axis, as before, unless another key is at
     // least a tenth better (clouds of a thousand points and more: below that every window is short anyway).  Integer counts,
     // the same on both blocks of the pair.
-    if (dirKeys && ny >= kSortDirMinN) {
+    if (dirKeys && ny >= kSortDirMinN && nx >= kSortDirMinMoving) {
         __shared__ unsigned int scoreSh[kSortCodes];
         // (the sort has not started: its key array -- NP2 >= 2048 entries of 8 bytes here -- holds the counters)
         (void)choose_sort_code<kSortBlock>(yb, ny, boxSh, axisSh, reinterpret_cast<unsigned int *>(dynLds), scoreSh, &axisSh);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kCsBlock) void sort_code_kernel(ChunkSortParams p)
     }
     __syncthreads();
     int code = axisSh;
-    if (f.n >= kSortDirMinN) code = choose_sort_code<kCsBlock>(f.cloud, f.n, boxSh, code, hist, scoreSh, &axisSh);
+    if (f.n >= kSortDirMinN && roles_of(p, b, 1).n >= kSortDirMinMoving) code = choose_sort_code<kCsBlock>(f.cloud, f.n, boxSh, code, hist, scoreSh, &axisSh);
     if (threadIdx.x == 0) p.axisOut[b] = code;
 }
 
