@@ -45,7 +45,12 @@ cp /tmp/tl.txt profiles/${TAG}_frame_pair_native_timeline.txt
 { echo "bench.py --workload stream, five consecutive runs per setting of GPU_MAX_HW_QUEUES (tools/dbg/stream_repro.sh: three timed steps of 64 demo frame"
   echo "pairs each; then tools/dbg/stream_repro2.sh: ten timed steps, 16 and 32 queues), and four config-2 batches in one hist_icp_many call per process;"
   echo "one MI355X, build $B.  The package sets GPU_MAX_HW_QUEUES=16 at import (icp_flow_amd/__init__.py); 'unset' = ICPFLOW_KEEP_HW_QUEUES=1."
-  cat $E/stream_repro.txt; cat $E/stream_repro2.txt; } > profiles/${TAG}_stream_repro.txt
+  cat $E/stream_repro.txt; cat $E/stream_repro2.txt
+  echo; echo "tools/dbg/stream_repro3.sh: the same at the evidence's own length (20 timed steps, 3 warm-up), five runs per setting, twice, alternating"
+  [ -f $E/stream_repro3.txt ] && cat $E/stream_repro3.txt
+  echo; echo "tools/dbg/four_queues.sh: the default bench.py line five times per setting -- its extras that use several streams INSIDE one busy process"
+  echo "(stream4 = four demo frame pairs in flight at max_points 2048 / 10000, four = four config-2 batches in one hist_icp_many call)"
+  [ -f $E/four_queues.txt ] && cat $E/four_queues.txt; } > profiles/${TAG}_stream_repro.txt
 { echo "The sweeps' sort keys: the fixed cloud's longest axis (ICPFLOW_OPT_NO_DIR_KEYS) against the best of three axes and six horizontal directions"
   echo "(csrc/sortdir.hpp); tools/dbg/dir_keys_ab.py (step / ICP launch in ms, r = ragged independent sizes, m = matched sizes), dir_keys_diff.py and"
   echo "dir_keys_fuzz.py (what differs: the order of the fp64 moment sums); one MI355X, build $B"

@@ -21,6 +21,8 @@ for f in cert_fuzz frame_fuzz score_fuzz registration_fuzz native_fuzz vote_list
 # round 6: the stream's spread per setting of GPU_MAX_HW_QUEUES, the A/Bs of the round's switches, the direction keys' fuzz
 bash tools/dbg/stream_repro.sh $O/stream_repro.txt > /dev/null 2>&1
 bash tools/dbg/stream_repro2.sh > /dev/null 2>&1; cp gpurun_out/r6_stream_repro2.txt $O/stream_repro2.txt
+bash tools/dbg/stream_repro3.sh > $O/stream_repro3.txt 2>&1
+bash tools/dbg/four_queues.sh > $O/four_queues.txt 2>&1
 SHAPES=256x1024,1024x2048,600x2048,1500x1500,m128x4000,m128x10000,r128x10000,8192x2048 python tools/dbg/dir_keys_ab.py > $O/dir_keys_ab.txt 2>&1
 python tools/dbg/dir_keys_diff.py > $O/dir_keys_diff.txt 2>&1
 timeout 900 python tools/dbg/dir_keys_fuzz.py > $O/dir_keys_fuzz.txt 2>&1
