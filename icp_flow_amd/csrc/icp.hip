@@ -745,6 +745,7 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
     }
     int winLo = -1, winHi = -1;   // sorted sweep: this wave's target window of the previous iteration
     int prevNN = -2;              // certificates, single pass: this lane's gated neighbour of the previous iteration
+    [[maybe_unused]] int ownedPrev = 0;   // several passes: bit g = THIS workgroup computed pass g in the previous iteration (workgroup-uniform)
     int sweepAxis = 0;            // sorted sweep: the sort axis of this pair (read once: a load from L2 at the top of every
                                   // iteration is a round trip that every wave of the workgroup sits out together)
     if constexpr (GRID >= 3) sweepAxis = __builtin_amdgcn_readfirstlane(p.sortAxis[b]);
@@ -1045,6 +1046,9 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                 float x0x[Q], x0y[Q], x0z[Q], qx[Q], qy[Q], qz[Q];
                 bool live[Q];
                 float lo = kInf, hi = -kInf;
+                int prevWord[Q];   // the neighbour word of this query's record as it was found (-2: none read: first iteration of the launch)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) prevWord[q] = -2;
                 float recM[Q];   // this query's half-window; < 0: certified, takes no part in the search
                 int certJ[Q];    // certificate (A): the neighbour (slot of the sorted image)
                 float certD[Q];  // certified squared distance (inf: outside the gate)
@@ -1099,7 +1103,10 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                             m = certMargin;   // first iteration: nothing known
                             if (it > itFirst) {
                                 const float4 o = rec[li];
-                                const int j1 = recJ[li];
+                                // (the record's neighbour word: slot | "was gated when the unit's moments were last formed" << 30, or -1)
+                                const int word = recJ[li];
+                                const int j1 = word < 0 ? word : (word & 0x3fffffff);
+                                prevWord[q] = word;
                                 const float ex = qx[q] - o.x, ey = qy[q] - o.y, ez = qz[q] - o.z;
                                 // (raw v_sqrt_f32, 1 ulp: every bound below carries a relative margin of 1e-6, 8 ulp)
                                 const float dq = __builtin_amdgcn_sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
@@ -1543,10 +1550,12 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     newL[q] = fmaxf(fminf(__builtin_amdgcn_sqrtf(second[q]), cap), 0.f);
                     if (!(acc.best[q] < kInf)) certJ[q] = -1;
                 }
-                if (recOn && newL[q] >= 0.f) {
+                if (recOn && live[q]) {
                     const int li = g * PER + (unitWave * Q + q) * kWave + lane;
-                    rec[li] = make_float4(qx[q], qy[q], qz[q], newL[q]);
-                    recJ[li] = certJ[q];
+                    if (newL[q] >= 0.f) rec[li] = make_float4(qx[q], qy[q], qz[q], newL[q]);
+                    // the neighbour word follows the neighbour AND the gate decision of this iteration (see the unit's reuse below)
+                    const int newWord = certJ[q] < 0 ? -1 : (certJ[q] | (nnSlot >= 0 ? 0x40000000 : 0));
+                    if (newL[q] >= 0.f || newWord != prevWord[q]) recJ[li] = newWord;
                 }
                 ICPFLOW_STAMP(10);
 #ifdef ICPFLOW_TAIL_CLOCK
@@ -1560,6 +1569,17 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                         reuseMoments = it > itFirst && __ballot(nnSlot != prevNN) == 0ull;
                         prevNN = nnSlot;
                     }
+#ifndef ICPFLOW_NO_UNIT_REUSE
+                    else if (recOn && perPass) {
+                        // (round 6) clouds of several passes whose sums are kept per (pass, wave) -- i.e. per UNIT, in dynamic LDS,
+                        // from iteration to iteration: the same reuse, unit by unit.  What a query's gated neighbour was when
+                        // the unit's sums were last formed rides in its record's neighbour word (slot | gated << 30; recJ above);
+                        // a pass that a helper computed in the previous iteration holds the HELPER's sums: no reuse there.
+                        const int nnPrev = (prevWord[0] >= 0 && (prevWord[0] & 0x40000000) != 0) ? (prevWord[0] & 0x3fffffff) : -1;
+                        const bool differs = live[0] && (prevWord[0] == -2 || nnSlot != nnPrev);
+                        reuseMoments = it > itFirst && ((ownedPrev >> g) & 1) != 0 && __ballot(differs) == 0ull;
+                    }
+#endif
                 }
                 // 18 moments -> 5 registers by two folding levels (see common.hpp): fold[j] holds, per
                 // row of 16 lanes, partial sums of moments (4j, 4j+2, 4j+1, 4j+3); fold[4]: 16,16,17,17
@@ -1627,6 +1647,8 @@ __device__ __forceinline__ void icp_pair(const P &p, const int b, const int rank
                     }
                 }
             }
+            if constexpr (HELP) ownedPrev = helping ? (1 << (ngr - role)) : ~helpedPasses;
+            else ownedPrev = -1;
             // rows of 16 lanes -> lane 15 of each row holds the wave total of "its" moment
             if (!perPass && !reuseMoments)
 #pragma unroll
